@@ -1,0 +1,389 @@
+"""
+oracle/augment.py -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Restatement of the online depth-crop augmentation:
+
+  augment_crop         NetTrainer.augmentCrop        /root/reference/src/trainer/nettrainer.py:919-997
+  move_com             HandDetector.moveCoM          /root/reference/src/util/handdetector.py:678-710
+  rotate_hand          HandDetector.rotateHand       handdetector.py:712-747
+  scale_hand           HandDetector.scaleHand        handdetector.py:750-780
+  recrop_hand          HandDetector.recropHand       handdetector.py:782-803
+  com_to_bounds / com_to_transform                   handdetector.py:204-258
+  Camera.*             DepthImporter / NYU / MSRA projections, /root/reference/src/data/importers.py:80-119,
+                       756-793, 1187-1224
+  rotate_point_2d      /root/reference/src/data/transformations.py:71-88
+  pca_transform        sklearn PCA.transform as used at /root/reference/src/trainer/poseregnettrainer.py:262
+
+PARITY UNPINNED for the two OpenCV calls (cv2 2.4.x is absent here; the reference holds no
+vectors).  `warp_affine_nn` / `warp_perspective_nn` restate OpenCV 2.4's imgwarp.cpp:
+  * warpAffine inverts the 2x3 matrix in double, then addresses with 10-bit fixed point:
+      X = (cvRound((M01*y + M02)*1024) + 512 + cvRound(M00*x*1024)) >> 10   (same for Y)
+  * warpPerspective inverts the 3x3 matrix in double (cofactor formula), walks the destination in
+    64x16 blocks and rounds (X0 + M0*x1) / W with cvRound (round half to even)
+  * BORDER_CONSTANT value 0, INTER_NEAREST.
+Bit-exactness versus real cv2 is claimed only for pixels whose source coordinate is at least
+2^-9 away from a rounding boundary.
+
+Python-2 integer division in com_to_transform (handdetector.py:246,249) is kept with `//`.
+NumPy-1.x scalar semantics are kept: float32 scalar (op) python float evaluates in float64 and
+is rounded to float32 only when stored into the float32 result array.
+"""
+import numpy as np
+
+
+def cv_round(v):
+    """cvRound: round half to even (lrint)."""
+    return np.rint(v).astype(np.int64)
+
+
+# --------------------------------------------------------------------------- camera models
+class Camera(object):
+    """Pinhole (un)projection of the importers.  flip_y: NYU and MSRA negate the y axis."""
+
+    def __init__(self, fx, fy, ux, uy, flip_y):
+        self.fx, self.fy, self.ux, self.uy, self.flip_y = float(fx), float(fy), float(ux), float(uy), bool(flip_y)
+
+    @staticmethod
+    def icvl():      # importers.py:199
+        return Camera(241.42, 241.42, 160., 120., False)
+
+    @staticmethod
+    def msra():      # importers.py:547
+        return Camera(241.42, 241.42, 160., 120., True)
+
+    @staticmethod
+    def nyu():       # importers.py:891
+        return Camera(588.03, 587.07, 320., 240., True)
+
+    def jointImgTo3D(self, s):
+        s = [float(v) for v in s]
+        ret = np.zeros((3,), np.float32)
+        ret[0] = (s[0] - self.ux) * s[2] / self.fx
+        ret[1] = ((self.uy - s[1]) if self.flip_y else (s[1] - self.uy)) * s[2] / self.fy
+        ret[2] = s[2]
+        return ret
+
+    def joint3DToImg(self, s):
+        f32in = isinstance(s, np.ndarray) and s.dtype == np.float32
+        s = [float(v) for v in s]
+        ret = np.zeros((3,), np.float32)
+        if s[2] == 0.:
+            ret[0] = self.ux
+            ret[1] = self.uy
+            return ret
+        q0, q1 = s[0] / s[2], s[1] / s[2]
+        if f32in:       # float32 scalar / float32 scalar stays float32 (sample[0]/sample[2], importers.py:115)
+            q0, q1 = float(np.float32(q0)), float(np.float32(q1))
+        ret[0] = q0 * self.fx + self.ux
+        ret[1] = (self.uy - q1 * self.fy) if self.flip_y else (q1 * self.fy + self.uy)
+        ret[2] = s[2]
+        return ret
+
+    def jointsImgTo3D(self, pts):
+        return np.stack([self.jointImgTo3D(p) for p in pts]).astype(np.float32)
+
+    def joints3DToImg(self, pts):
+        return np.stack([self.joint3DToImg(p) for p in pts]).astype(np.float32)
+
+
+def rotate_point_2d(p1, center, angle):
+    """rotatePoint2D, transformations.py:71-88 (angle in degrees, keeps the dtype of p1)."""
+    alpha = angle * np.pi / 180.
+    pp = p1.copy()
+    pp[0:2] -= center[0:2]
+    pr = np.zeros_like(pp)
+    pr[0] = pp[0] * np.cos(alpha) - pp[1] * np.sin(alpha)
+    pr[1] = pp[0] * np.sin(alpha) + pp[1] * np.cos(alpha)
+    pr[2] = pp[2]
+    pr[0:2] += center[0:2]
+    return pr
+
+
+# --------------------------------------------------------------------------- crop geometry
+def com_to_bounds(com, size, fx, fy):
+    """comToBounds, handdetector.py:204-226 (the ill-defined-CoM branch is not on the augment path:
+    moveCoM/scaleHand guard against z == 0 before calling)."""
+    c0, c1, c2 = float(com[0]), float(com[1]), float(com[2])
+    zstart = c2 - size[2] / 2.
+    zend = c2 + size[2] / 2.
+    xstart = int(np.floor((c0 * c2 / fx - size[0] / 2.) / c2 * fx + 0.5))
+    xend = int(np.floor((c0 * c2 / fx + size[0] / 2.) / c2 * fx + 0.5))
+    ystart = int(np.floor((c1 * c2 / fy - size[1] / 2.) / c2 * fy + 0.5))
+    yend = int(np.floor((c1 * c2 / fy + size[1] / 2.) / c2 * fy + 0.5))
+    return xstart, xend, ystart, yend, zstart, zend
+
+
+def com_to_transform(com, size, fx, fy, dsize=(128, 128)):
+    """comToTransform, handdetector.py:228-258: off . scale . trans (3x3 float64)."""
+    xstart, xend, ystart, yend, _, _ = com_to_bounds(com, size, fx, fy)
+    trans = np.eye(3)
+    trans[0, 2] = -xstart
+    trans[1, 2] = -ystart
+    wb = (xend - xstart)
+    hb = (yend - ystart)
+    if wb > hb:
+        scale = np.eye(3) * dsize[0] / float(wb)
+        sz = (dsize[0], hb * dsize[0] // wb)          # py2 int division, handdetector.py:246
+    else:
+        scale = np.eye(3) * dsize[1] / float(hb)
+        sz = (wb * dsize[1] // hb, dsize[1])          # handdetector.py:249
+    scale[2, 2] = 1
+    xs = int(np.floor(dsize[0] / 2. - sz[1] / 2.))    # the x/y swap of handdetector.py:252-253 is kept
+    ys = int(np.floor(dsize[1] / 2. - sz[0] / 2.))
+    off = np.eye(3)
+    off[0, 2] = xs
+    off[1, 2] = ys
+    return np.dot(off, np.dot(scale, trans))
+
+
+# --------------------------------------------------------------------------- cv2 restatements
+def rotation_matrix_2d(center, angle_deg, scale=1.0):
+    """cv2.getRotationMatrix2D (center is a Point2f)."""
+    a = angle_deg * np.pi / 180.
+    alpha = np.cos(a) * scale
+    beta = np.sin(a) * scale
+    cx, cy = float(np.float32(center[0])), float(np.float32(center[1]))
+    return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy],
+                     [-beta, alpha, beta * cx + (1 - alpha) * cy]], dtype=np.float64)
+
+
+def invert_affine(M):
+    """The in-place inversion at the top of cv::warpAffine (imgwarp.cpp)."""
+    M = np.array(M, dtype=np.float64).reshape(2, 3).copy()
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1. / D if D != 0 else 0.
+    A11 = M[1, 1] * D
+    A22 = M[0, 0] * D
+    m = np.empty(6)
+    m[0] = A11
+    m[1] = M[0, 1] * (-D)
+    m[3] = M[1, 0] * (-D)
+    m[4] = A22
+    m[2] = -m[0] * M[0, 2] - m[1] * M[1, 2]
+    m[5] = -m[3] * M[0, 2] - m[4] * M[1, 2]
+    return m
+
+
+def warp_affine_coords(Minv6, w, h):
+    """Source pixel (X, Y) for every destination pixel, warpAffine INTER_NEAREST fixed point."""
+    m = Minv6
+    xs = np.arange(w, dtype=np.float64)
+    ys = np.arange(h, dtype=np.float64)
+    adelta = cv_round(m[0] * xs * 1024.)
+    bdelta = cv_round(m[3] * xs * 1024.)
+    X0 = cv_round((m[1] * ys + m[2]) * 1024.) + 512
+    Y0 = cv_round((m[4] * ys + m[5]) * 1024.) + 512
+    X = (X0[:, None] + adelta[None, :]) >> 10
+    Y = (Y0[:, None] + bdelta[None, :]) >> 10
+    return X, Y
+
+
+def _gather(src, X, Y, border=0.):
+    h, w = src.shape
+    ok = (X >= 0) & (X < w) & (Y >= 0) & (Y < h)
+    out = np.full(X.shape, border, dtype=src.dtype)
+    out[ok] = src[Y[ok], X[ok]]
+    return out
+
+
+def warp_affine_nn(src, M23, border=0.):
+    h, w = src.shape
+    X, Y = warp_affine_coords(invert_affine(M23), w, h)
+    return _gather(src, X, Y, border)
+
+
+def invert_3x3(M):
+    """cv::invert for a 3x3 double matrix: determinant + cofactors (matrix.cpp, n == 3 branch)."""
+    S = np.array(M, dtype=np.float64).reshape(3, 3)
+    d = (S[0, 0] * (S[1, 1] * S[2, 2] - S[1, 2] * S[2, 1]) -
+         S[0, 1] * (S[1, 0] * S[2, 2] - S[1, 2] * S[2, 0]) +
+         S[0, 2] * (S[1, 0] * S[2, 1] - S[1, 1] * S[2, 0]))
+    if d == 0:
+        return np.zeros((3, 3))
+    d = 1. / d
+    t = np.empty(9)
+    t[0] = (S[1, 1] * S[2, 2] - S[1, 2] * S[2, 1]) * d
+    t[1] = (S[0, 2] * S[2, 1] - S[0, 1] * S[2, 2]) * d
+    t[2] = (S[0, 1] * S[1, 2] - S[0, 2] * S[1, 1]) * d
+    t[3] = (S[1, 2] * S[2, 0] - S[1, 0] * S[2, 2]) * d
+    t[4] = (S[0, 0] * S[2, 2] - S[0, 2] * S[2, 0]) * d
+    t[5] = (S[0, 2] * S[1, 0] - S[0, 0] * S[1, 2]) * d
+    t[6] = (S[1, 0] * S[2, 1] - S[1, 1] * S[2, 0]) * d
+    t[7] = (S[0, 1] * S[2, 0] - S[0, 0] * S[2, 1]) * d
+    t[8] = (S[0, 0] * S[1, 1] - S[0, 1] * S[1, 0]) * d
+    return t.reshape(3, 3)
+
+
+WP_BLOCK_W = 64     # bw0 for a 128-wide image with BLOCK_SZ = 32 (imgwarp.cpp warpPerspective)
+
+
+def warp_perspective_coords(Minv9, w, h):
+    m = np.asarray(Minv9, dtype=np.float64).reshape(9)
+    xs = np.arange(w)
+    bx = (xs // WP_BLOCK_W) * WP_BLOCK_W
+    x1 = (xs - bx).astype(np.float64)
+    bx = bx.astype(np.float64)
+    ys = np.arange(h, dtype=np.float64)[:, None]
+    X0 = m[0] * bx[None, :] + m[1] * ys + m[2]
+    Y0 = m[3] * bx[None, :] + m[4] * ys + m[5]
+    W0 = m[6] * bx[None, :] + m[7] * ys + m[8]
+    Wv = W0 + m[6] * x1[None, :]
+    with np.errstate(divide='ignore'):
+        Wv = np.where(Wv != 0, 1. / Wv, 0.)
+    lim_lo, lim_hi = float(-2 ** 31), float(2 ** 31 - 1)
+    fX = np.maximum(lim_lo, np.minimum(lim_hi, (X0 + m[0] * x1[None, :]) * Wv))
+    fY = np.maximum(lim_lo, np.minimum(lim_hi, (Y0 + m[3] * x1[None, :]) * Wv))
+    X = np.clip(cv_round(fX), -32768, 32767)       # saturate_cast<short>
+    Y = np.clip(cv_round(fY), -32768, 32767)
+    return X, Y
+
+
+def warp_perspective_nn(src, M33, border=0.):
+    h, w = src.shape
+    X, Y = warp_perspective_coords(invert_3x3(M33), w, h)
+    return _gather(src, X, Y, border)
+
+
+# --------------------------------------------------------------------------- HandDetector warps
+def recrop_hand(crop, M, Mnew, com, size, fx, fy, background_value=0., nv_val=32000.):
+    """recropHand, handdetector.py:782-803 (argument names as in the reference: the warp matrix is
+    dot(M, Mnew))."""
+    warped = warp_perspective_nn(crop, np.dot(M, Mnew), border=float(background_value))
+    warped[np.isclose(warped, nv_val)] = background_value
+    _, _, _, _, zstart, zend = com_to_bounds(com, size, fx, fy)
+    msk1 = np.logical_and(warped < zstart, warped != 0)
+    msk2 = np.logical_and(warped > zend, warped != 0)
+    warped[msk1] = zstart
+    warped[msk2] = 0.
+    return warped
+
+
+def move_com(dpt, cube, com, off, joints3D, M, cam, fx, fy):
+    """moveCoM, handdetector.py:678-710."""
+    if np.allclose(off, 0.):
+        return dpt, joints3D, com, M
+    new_com = cam.joint3DToImg(cam.jointImgTo3D(com) + off)
+    if not (np.allclose(com[2], 0.) or np.allclose(new_com[2], 0.)):
+        Mnew = com_to_transform(new_com, cube, fx, fy, dpt.shape)
+        new_dpt = recrop_hand(dpt, Mnew, np.linalg.inv(np.asarray(M, dtype=np.float64)), new_com, cube, fx, fy)
+    else:
+        Mnew = M
+        new_dpt = dpt
+    new_joints3D = joints3D + cam.jointImgTo3D(com) - cam.jointImgTo3D(new_com)
+    return new_dpt, new_joints3D, new_com, Mnew
+
+
+def rotate_hand(dpt, cube, com, rot, joints3D, cam):
+    """rotateHand, handdetector.py:712-747."""
+    if np.allclose(rot, 0.):
+        return dpt, joints3D, rot
+    rot = np.mod(rot, 360)
+    M = rotation_matrix_2d((dpt.shape[1] // 2, dpt.shape[0] // 2), -rot, 1)
+    new_dpt = warp_affine_nn(dpt, M, border=0.)
+    com3D = cam.jointImgTo3D(com)
+    joint_2D = cam.joints3DToImg(joints3D + com3D)
+    data_2D = np.zeros_like(joint_2D)
+    for k in range(data_2D.shape[0]):
+        data_2D[k] = rotate_point_2d(joint_2D[k], com[0:2], rot)
+    new_joints3D = (cam.jointsImgTo3D(data_2D) - com3D)
+    return new_dpt, new_joints3D, rot
+
+
+def scale_hand(dpt, cube, com, sc, joints3D, M, fx, fy):
+    """scaleHand, handdetector.py:750-780 (z-threshold uses the OLD cube)."""
+    if np.allclose(sc, 1.):
+        return dpt, joints3D, cube, M
+    new_cube = [s * sc for s in cube]
+    if not np.allclose(com[2], 0.):
+        Mnew = com_to_transform(com, new_cube, fx, fy, dpt.shape)
+        new_dpt = recrop_hand(dpt, Mnew, np.linalg.inv(np.asarray(M, dtype=np.float64)), com, cube, fx, fy)
+    else:
+        Mnew = M
+        new_dpt = dpt
+    return new_dpt, joints3D, new_cube, Mnew
+
+
+def augment_crop(img, gt3Dcrop, com, cube, M, mode, off, rot, sc, cam, fx, fy, normZeroOne=False):
+    """
+    augmentCrop, nettrainer.py:919-997, with the random draws (mode, off, rot, sc) passed in
+    explicitly (the reference's worker RNG is re-seeded from OS entropy, nettrainer.py:611, so
+    parity is defined per sample on explicit parameters).  mode in {'com','rot','sc','none'}.
+    Returns (imgD, curLabel, cube, com, M, rot) like the reference's return tuple (minus the None).
+    """
+    assert len(img.shape) == 2
+    cube = [float(c) for c in cube]
+    if normZeroOne:
+        img = img * cube[2] + (com[2] - (cube[2] / 2.))
+    else:
+        img = img * (cube[2] / 2.) + com[2]
+    premax = img.max()
+    if mode == 'com':
+        rot, sc = 0., 1.
+        imgD, new_joints3D, com, M = move_com(img.astype('float32'), cube, com, off, gt3Dcrop, M, cam, fx, fy)
+        curLabel = new_joints3D / (cube[2] / 2.)
+    elif mode == 'rot':
+        off, sc = np.zeros((3,)), 1.
+        imgD, new_joints3D, rot = rotate_hand(img.astype('float32'), cube, com, rot, gt3Dcrop, cam)
+        curLabel = new_joints3D / (cube[2] / 2.)
+    elif mode == 'sc':
+        off, rot = np.zeros((3,)), 0.
+        imgD, new_joints3D, cube, M = scale_hand(img.astype('float32'), cube, com, sc, gt3Dcrop, M, fx, fy)
+        curLabel = new_joints3D / (cube[2] / 2.)
+    elif mode == 'none':
+        off, sc, rot = np.zeros((3,)), 1., 0.
+        imgD = img
+        curLabel = gt3Dcrop / (cube[2] / 2.)
+    else:
+        raise NotImplementedError()
+    imgD = np.array(imgD, copy=True)
+    far = com[2] + (cube[2] / 2.)
+    near = com[2] - (cube[2] / 2.)
+    imgD[imgD == premax] = far
+    imgD[imgD == 0] = far
+    imgD[imgD >= far] = far
+    imgD[imgD <= near] = near
+    if normZeroOne:
+        imgD -= near
+        imgD /= cube[2]
+    else:
+        imgD -= com[2]
+        imgD /= (cube[2] / 2.)
+    return imgD, curLabel, np.asarray(cube), com, M, rot
+
+
+def pca_transform(label, mean, components):
+    """sklearn PCA.transform (no whitening): (x - mean_) . components_^T."""
+    return (label.reshape(1, -1) - mean) @ components.T
+
+
+# --------------------------------------------------------------------------- synthetic samples
+def synthetic_augment_inputs(rng, n, cam, cube=(250., 250., 250.), joints=16, dsize=128):
+    """SURVEY.md section 8(d) cfg 3: per sample com=(u,v,d), M = comToTransform(com, cube), joints ~
+    N(0, 35^2 mm) clipped to +-cube/2, and a normalised crop with a blob."""
+    from .nets import synthetic_crops
+    fx, fy = abs(cam.fx), abs(cam.fy)
+    imgs = synthetic_crops(rng, n, dsize, dsize, np.float32)[:, 0]
+    coms = np.zeros((n, 3), np.float32)
+    cubes = np.tile(np.asarray(cube, np.float32), (n, 1))
+    Ms = np.zeros((n, 3, 3), np.float32)
+    gts = np.zeros((n, joints, 3), np.float32)
+    for i in range(n):
+        com2d = np.array([rng.uniform(60, 260), rng.uniform(40, 200), rng.uniform(300, 600)], np.float32)
+        coms[i] = cam.jointImgTo3D(com2d)
+        Ms[i] = com_to_transform(cam.joint3DToImg(coms[i]), cube, fx, fy, (dsize, dsize))
+        gts[i] = np.clip(rng.normal(0, 35., (joints, 3)), -cube[0] / 2., cube[0] / 2.)
+    return imgs, coms, cubes, Ms, gts
+
+
+def draw_params(rng, n, n_modes, sigma_com=5., sigma_sc=0.02, rot_range=180.):
+    """The four draws of augmentCrop in the reference's order, nettrainer.py:954-957."""
+    modes = np.zeros(n, np.int32)
+    offs = np.zeros((n, 3))
+    rots = np.zeros(n)
+    scs = np.zeros(n)
+    for i in range(n):
+        modes[i] = rng.randint(0, n_modes)
+        offs[i] = rng.randn(3) * sigma_com
+        rots[i] = rng.uniform(-rot_range, rot_range)
+        scs[i] = abs(1. + rng.randn() * sigma_sc)
+    return modes, offs, rots, scs

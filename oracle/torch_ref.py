@@ -1,0 +1,132 @@
+"""
+oracle/torch_ref.py -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+An INDEPENDENT restatement of the same graphs on PyTorch-CPU ops with autograd.
+Two jobs:
+  1. cross-check oracle/nets.py (hand-written analytic backward) against autograd
+     in float64 -- the pin that replaces the reference's missing tests;
+  2. the reported-only CPU baseline of bench.py ("CPU restatement (PyTorch-CPU),
+     not Theano"): the identical fp32 graph, BN in training mode,
+     sum-squared-error loss, the reference's ADAM.
+
+Semantics follow the same reference lines as oracle/layers.py; torch's conv2d is a
+cross-correlation, so kernels are flipped to get Theano's true convolution.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = float(np.float32(1e-4))
+
+
+def to_torch(P, dtype=torch.float64, requires_grad=True):
+    T = {}
+    for i, v in P.items():
+        T[i] = [torch.tensor(np.asarray(a), dtype=dtype) for a in v]
+        for t in T[i][:2]:
+            t.requires_grad_(requires_grad)
+    return T
+
+
+def _conv(a, W, stride, border):
+    kh, kw = W.shape[2], W.shape[3]
+    pad = (kh // 2, kw // 2) if border in ('half', 'same') else (0, 0)
+    full = F.conv2d(a, torch.flip(W, dims=(2, 3)), None, stride=1, padding=pad)
+    return full[:, :, ::stride[0], ::stride[1]]        # Theano subsample
+
+
+def forward(net, T, x, train):
+    vals, stats = {}, {}
+
+    def get(ref):
+        if ref[0] == 'input':
+            return x
+        if ref[0] == 'layer':
+            return vals[ref[1]]
+        if ref[0] == 'add':
+            return get(ref[1]) + get(ref[2])
+        if ref[0] == 'flatten':
+            return get(ref[1]).flatten(1)
+        raise ValueError(ref)
+
+    for i, l in enumerate(net['layers']):
+        a = get(l['src'])
+        k = l['kind']
+        if k == 'convpool':
+            c = _conv(a, T[i][0], l['stride'], l['border'])
+            if tuple(l['pool']) != (1, 1):
+                c = F.max_pool2d(c, kernel_size=l['pool'], stride=l['pool'])
+            c = c + T[i][1][None, :, None, None]
+            vals[i] = torch.clamp_min(c, 0) if l['act'] == 'relu' else c
+        elif k == 'conv':
+            vals[i] = _conv(a, T[i][0], l['stride'], l['border']) + T[i][1][None, :, None, None]
+        elif k == 'bn':
+            beta, gamma, rm, ris = T[i]
+            if train:
+                mean = a.mean(dim=(0, 2, 3))
+                var = a.var(dim=(0, 2, 3), unbiased=False)
+                inv_std = 1.0 / torch.sqrt(var + BN_EPS)
+                stats[i] = (mean.detach(), inv_std.detach())
+            else:
+                mean, inv_std = rm, ris
+            vals[i] = (a - mean[None, :, None, None]) * (gamma * inv_std)[None, :, None, None] \
+                + beta[None, :, None, None]
+        elif k == 'relu':
+            vals[i] = torch.clamp_min(a, 0)
+        elif k == 'fc':
+            pre = a @ T[i][0] + T[i][1]
+            vals[i] = torch.clamp_min(pre, 0) if l['act'] == 'relu' else pre
+        elif k == 'dropout':
+            vals[i] = a * float(np.float32(1.0 - l['p'])) if not train else a   # masks not modelled here
+        else:
+            raise NotImplementedError(k)
+    return get(net['out']), stats
+
+
+def cost_and_grads(net, P, x, y, dtype=torch.float64):
+    """Returns (cost, {layer: [g0, g1]}, out) with autograd gradients (numpy arrays)."""
+    T = to_torch(P, dtype)
+    xt = torch.tensor(x, dtype=dtype)
+    yt = torch.tensor(y, dtype=dtype)
+    out, _ = forward(net, T, xt, True)
+    cost = ((out - yt) ** 2).sum(dim=1).mean()
+    cost.backward()
+    G = {i: [T[i][0].grad.numpy(), T[i][1].grad.numpy()] for i in T}
+    return float(cost), G, out.detach().numpy()
+
+
+class TorchTrainer(object):
+    """fp32 train step on PyTorch-CPU for the CPU baseline: forward (BN batch stats) + autograd
+    backward + the reference's ADAM (optimizer.py:58-90) + BN running-stat EMA."""
+
+    def __init__(self, net, P, dtype=torch.float32):
+        self.net = net
+        self.T = to_torch(P, dtype)
+        self.params = [t for i in sorted(self.T) for t in self.T[i][:2]]
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.t = 1.0
+        self.dtype = dtype
+
+    def step(self, x, y, lr):
+        out, stats = forward(self.net, self.T, x, True)
+        cost = ((out - y) ** 2).sum(dim=1).mean()
+        grads = torch.autograd.grad(cost, self.params)
+        b1, b2, eps = float(np.float32(0.9)), float(np.float32(0.999)), float(np.float32(1e-8))
+        with torch.no_grad():
+            c1 = 1.0 - b1 ** self.t
+            c2 = 1.0 - b2 ** self.t
+            for p, g, m, v in zip(self.params, grads, self.m, self.v):
+                m.mul_(b1).add_(g, alpha=1.0 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                p.sub_(lr * (m / c1) / (torch.sqrt(v / c2) + eps))
+            for i, (mean, inv_std) in stats.items():
+                self.T[i][2].mul_(0.9).add_(mean, alpha=0.1)
+                self.T[i][3].mul_(0.9).add_(inv_std, alpha=0.1)
+        self.t += 1.0
+        return float(cost)
+
+    def forward_eval(self, x):
+        with torch.no_grad():
+            out, _ = forward(self.net, self.T, x, False)
+        return out

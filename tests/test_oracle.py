@@ -1,0 +1,213 @@
+"""Pins for the oracle: the reference-generated golden fixtures (tests/golden/make_golden.py) and the
+independent torch-autograd cross-check.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import augment as A
+from oracle import layers as L
+from oracle import nets, torch_ref
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def shapes():
+    return json.load(open(os.path.join(GOLD, 'shapes.json')))
+
+
+@pytest.mark.parametrize('name', ['resnet_t0_128', 'resnet_t1_128', 'resnet_t1_256', 'resnet_t0_64_b4'])
+def test_resnet_shapes_match_reference_layerparams(shapes, name):
+    g = shapes[name]
+    net = nets.build_resnet(**g['args'])
+    assert len(net['layers']) == len(g['layers'])
+    for l, r in zip(net['layers'], g['layers']):
+        assert list(l['in_dim']) == r['inputDim']
+        assert list(l['out_dim']) == r['outputDim'], (l, r)
+        if l['kind'] in ('conv', 'convpool'):
+            assert [l['nf'], l['in_dim'][1], l['k'][0], l['k'][1]] == r['filter_shape']
+
+
+@pytest.mark.parametrize('name', ['poseregnet_t0', 'poseregnet_t11', 'poseregnet_t0_b16'])
+def test_poseregnet_layers_match_reference_params(shapes, name):
+    g = shapes[name]
+    net = nets.build_poseregnet(**g['args'])
+    kinds = {'ConvPoolLayerParams': 'convpool', 'HiddenLayerParams': 'fc', 'DropoutLayerParams': 'dropout'}
+    assert [l['kind'] for l in net['layers']] == [kinds[r['cls']] for r in g['layers']]
+    for l, r in zip(net['layers'], g['layers']):
+        assert list(l['out_dim']) == r['outputDim']
+        if l['kind'] == 'convpool':
+            assert list(l['pool']) == r['poolsize'] and r['border_mode'] == l['border']
+            assert r['activation'] == 'ReLU'
+        if l['kind'] == 'fc':
+            assert (r['activation'] == 'ReLU') == (l['act'] == 'relu')
+    assert list(net['out_dim']) == g['outputDim']
+
+
+def test_param_count_matches_survey():
+    net = nets.build_resnet(type=1, numJoints=14, nDims=3)
+    P = nets.init_params(net, np.random.RandomState(0))
+    n = sum(int(np.prod(a.shape)) for v in P.values() for a in v[:2])
+    assert n == 18714452          # 18.714 M, SURVEY.md section 8(d)
+    assert len(net['layers']) == 190
+
+
+def test_geometry_against_reference():
+    g = np.load(os.path.join(GOLD, 'geometry.npz'))
+    for i in range(32):
+        out = A.rotate_point_2d(g['rot_pts'][i].astype('float64'), g['rot_ctr'][i], g['rot_ang'][i])
+        np.testing.assert_allclose(out, g['rot_out64'][i], rtol=0, atol=1e-9)
+        out32 = A.rotate_point_2d(g['rot_pts'][i], g['rot_ctr'][i], g['rot_ang'][i])
+        np.testing.assert_allclose(out32, g['rot_out'][i], rtol=2e-6, atol=2e-5)
+    cams = dict(icvl=A.Camera.icvl(), msra=A.Camera.msra(), nyu=A.Camera.nyu())
+    for nm, cam in cams.items():
+        s64 = g['proj_in_float64']
+        x3 = np.stack([cam.jointImgTo3D(p) for p in s64])
+        assert np.array_equal(x3, g['to3d_%s_float64' % nm])          # float64 inputs: bit-exact
+        back = np.stack([cam.joint3DToImg(p) for p in x3.astype('float64')])
+        assert np.array_equal(back, g['toimg_%s_float64' % nm])
+        # float32 inputs: the fixture ran under NumPy-2 scalar rules (all-float32), the oracle keeps the
+        # NumPy-1.x float64 intermediates of the reference's own environment -> 1 ulp tolerance
+        s32 = g['proj_in_float32']
+        x3 = np.stack([cam.jointImgTo3D(p) for p in s32])
+        np.testing.assert_allclose(x3, g['to3d_%s_float32' % nm], rtol=3e-7, atol=1e-5)
+    for nm, (fx, fy) in (('icvl', (241.42, 241.42)), ('nyu', (588.03, 587.07))):
+        for i in range(64):
+            b = A.com_to_bounds(g['ctb_com'][i], (g['ctb_cube'][i],) * 3, fx, fy)
+            np.testing.assert_allclose(np.array(b, 'float64'), g['ctb_' + nm][i], rtol=0, atol=0)
+
+
+def test_chunks_partition():
+    for c in json.load(open(os.path.join(GOLD, 'chunks.json'))):
+        n, k = c['n'], c['k']
+        mine = [[i, min(i + k, n)] for i in range(0, n, k)]
+        assert mine == c['chunks']
+
+
+def test_conv_is_true_convolution():
+    rng = np.random.RandomState(1)
+    x = rng.normal(size=(2, 3, 9, 8))
+    W = rng.normal(size=(4, 3, 3, 3))
+    y = L.conv2d_fwd(x, W, None, (1, 1), 'valid')
+    import scipy.signal
+    ref = np.zeros_like(y)
+    for n in range(2):
+        for f in range(4):
+            for c in range(3):
+                ref[n, f] += scipy.signal.convolve2d(x[n, c], W[f, c], mode='valid')
+    np.testing.assert_allclose(y, ref, atol=1e-12)
+    # 'half' + stride 2 == every second output of the stride-1 'half' result
+    y1 = L.conv2d_fwd(x, W, None, (1, 1), 'half')
+    y2 = L.conv2d_fwd(x, W, None, (2, 2), 'half')
+    np.testing.assert_allclose(y2, y1[:, :, ::2, ::2], atol=1e-12)
+    assert y2.shape[2:] == (5, 4)
+
+
+def test_numpy_backward_matches_torch_autograd():
+    rng = np.random.RandomState(23455)
+    net = nets.build_resnet(type=1, wIn=32, hIn=32, batchSize=4, numJoints=14, nDims=3)
+    P = nets.perturb_bn(nets.init_params(net, rng, np.float64), net, rng)
+    x = nets.synthetic_crops(rng, 4, 32, 32, np.float64)
+    y = rng.normal(0, .3, (4, 42))
+    cost, G, _, out = nets.cost_and_grads(net, P, x, y)
+    c2, G2, out2 = torch_ref.cost_and_grads(net, P, x, y)
+    assert abs(cost - c2) < 1e-12 * abs(c2)
+    np.testing.assert_allclose(out, out2, atol=1e-12)
+    gmax = max(np.abs(G2[i][s]).max() for i in G2 for s in range(2))
+    for i in G:
+        for s in range(2):
+            np.testing.assert_allclose(G[i][s], G2[i][s], rtol=1e-8, atol=1e-12 * gmax)
+
+
+def test_poseregnet_backward_matches_torch_autograd():
+    rng = np.random.RandomState(5)
+    net = nets.build_poseregnet(type=11, batchSize=3, numJoints=14, nDims=3, wIn=64, hIn=64)
+    # dropout in eval form on both sides (0.7 * x is linear): exercises conv-pool / fc backward
+    for l in net['layers']:
+        if l['kind'] == 'dropout':
+            l['kind'] = 'relu'       # keep graph shape; relu of a relu output is the identity
+    P = nets.init_params(net, rng, np.float64)
+    P = nets.perturb_bn(P, net, rng)
+    x = nets.synthetic_crops(rng, 3, 64, 64, np.float64)
+    y = rng.normal(0, .3, (3, 42))
+    cost, G, _, out = nets.cost_and_grads(net, P, x, y)
+    c2, G2, out2 = torch_ref.cost_and_grads(net, P, x, y)
+    assert abs(cost - c2) < 1e-12 * abs(c2)
+    for i in G:
+        for s in range(2):
+            np.testing.assert_allclose(G[i][s], G2[i][s], rtol=1e-8, atol=1e-13)
+
+
+def test_adam_constants_are_float32_rounded():
+    p = [np.array([1.0, -2.0], np.float64)]
+    g = [np.array([0.5, 0.25], np.float64)]
+    m = [np.zeros(2)]
+    v = [np.zeros(2)]
+    t = L.adam_step(p, g, m, v, 1.0, 1e-3)
+    b1, b2 = float(np.float32(0.9)), float(np.float32(0.999))
+    np.testing.assert_allclose(m[0], (1 - b1) * g[0], rtol=1e-15)
+    np.testing.assert_allclose(v[0], (1 - b2) * g[0] ** 2, rtol=1e-15)
+    assert t == 2.0
+    # first step of ADAM moves every weight by ~lr
+    np.testing.assert_allclose(p[0], [1.0 - 1e-3, -2.0 - 1e-3], atol=1e-9)
+    assert L.lr_of_ep(1e-3, 1) == np.float32(1e-4) and L.lr_of_ep(1e-3, 2) == np.float32(1e-3 / 3.)
+    assert L.lr_of_ep(1e-3, 3) == np.float32(1e-3 * np.exp(-0.12))
+
+
+def test_compute_output_padding():
+    rng = np.random.RandomState(2)
+    net = nets.build_poseregnet(type=0, batchSize=4, numJoints=1, nDims=30, wIn=64, hIn=64)
+    P = nets.init_params(net, rng, np.float64)
+    x = nets.synthetic_crops(rng, 6, 64, 64, np.float64)
+    out = nets.compute_output(net, P, x)
+    assert out.shape == (6, 30)
+    o2, _ = nets.forward(net, P, np.concatenate([x[4:], x[5:], x[5:]], 0), False)
+    np.testing.assert_allclose(out[4:], o2[:2], atol=1e-12)
+
+
+def test_augment_modes_run_and_are_consistent():
+    rng = np.random.RandomState(7)
+    cam = A.Camera.icvl()
+    fx, fy = cam.fx, cam.fy
+    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, 4, cam)
+    for i, mode in enumerate(['com', 'rot', 'sc', 'none']):
+        com2d = cam.joint3DToImg(coms[i])
+        off = rng.randn(3) * 5.
+        imgD, lab, cube, com, M, rot = A.augment_crop(imgs[i].copy(), gts[i].copy(), com2d, cubes[i], Ms[i], mode,
+                                                      off, 33.3, 1.03, cam, fx, fy)
+        assert imgD.shape == (128, 128) and imgD.dtype == np.float32
+        assert imgD.min() >= -1.0 and imgD.max() <= 1.0
+        assert lab.shape == (16, 3)
+        if mode == 'none':
+            np.testing.assert_allclose(imgD, imgs[i], atol=2e-6)
+            np.testing.assert_allclose(lab, gts[i] / 125., rtol=1e-6)
+        if mode == 'sc':
+            np.testing.assert_allclose(cube, cubes[i] * 1.03, rtol=1e-6)
+    # rotating by 0 / offset 0 / scale 1 is the identity (the reference's early returns)
+    com2d = cam.joint3DToImg(coms[0])
+    for mode in ('com', 'rot', 'sc'):
+        imgD, lab, *_ = A.augment_crop(imgs[0].copy(), gts[0].copy(), com2d, cubes[0], Ms[0], mode,
+                                       np.zeros(3), 0., 1., cam, fx, fy)
+        np.testing.assert_allclose(imgD, imgs[0], atol=2e-6)
+
+
+def test_warp_restatements_identity_and_shift():
+    rng = np.random.RandomState(3)
+    src = rng.uniform(1, 2, (128, 128)).astype('float32')
+    np.testing.assert_array_equal(A.warp_perspective_nn(src, np.eye(3)), src)
+    np.testing.assert_array_equal(A.warp_affine_nn(src, np.eye(3)[:2]), src)
+    T = np.eye(3)
+    T[0, 2], T[1, 2] = 3, -2           # forward map: dst(x, y) = src(x - 3, y + 2)
+    w = A.warp_perspective_nn(src, T)
+    np.testing.assert_array_equal(w[0:126, 3:], src[2:128, 0:125])
+    assert (w[:, :3] == 0).all() and (w[126:, :] == 0).all()
+    w2 = A.warp_affine_nn(src, T[:2])
+    np.testing.assert_array_equal(w, w2)
+    # 90-degree rotation about (64, 64) is an exact pixel permutation
+    R = A.rotation_matrix_2d((64, 64), 90.)
+    w3 = A.warp_affine_nn(src, R)
+    # cv2 convention: positive angle = counter-clockwise; dst(x, y) = src(128 - y, x) inside the image
+    yy, xx = np.mgrid[1:128, 0:128]
+    np.testing.assert_array_equal(w3[yy, xx], src[xx, 128 - yy])
