@@ -1,0 +1,87 @@
+"""
+ctypes binding of the C ABI declared in include/dpp_hip.h.
+
+`load()` returns the product library deep-prior-pp_amd/lib/libdpp_hip.so and raises (loudly) when it is
+missing -- there is no CPU fallback in the product.  `load(path)` lets the CPU-side kernel-logic tests
+hand in the emulator build of the very same sources (tests/emu/_build/libdpp_emu.so).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'lib', 'libdpp_hip.so')
+
+ABI_VERSION = 1
+c_float_p = C.c_void_p      # device pointers travel as integers
+stream_t = C.c_void_p
+
+
+class RowMap(C.Structure):
+    _fields_ = [('s', C.c_int), ('Wo', C.c_int), ('HoWo', C.c_int), ('Wi', C.c_int), ('HiWi', C.c_int)]
+
+    @staticmethod
+    def identity():
+        return RowMap(1, 0, 0, 0, 0)
+
+    @staticmethod
+    def strided(s, Ho, Wo, Hi, Wi):
+        return RowMap(s, Wo, Ho * Wo, Wi, Hi * Wi)
+
+
+class Act(C.Structure):
+    _fields_ = [('mean', C.c_void_p), ('scale', C.c_void_p), ('beta', C.c_void_p), ('mode', C.c_int), ('cmod', C.c_int)]
+
+    NONE, RELU, BN, BN_RELU = 0, 1, 2, 3
+
+    @staticmethod
+    def none():
+        return Act(None, None, None, 0, 1)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('lda', C.c_int), ('a_kc', C.c_int), ('mapA', RowMap), ('actA', Act),
+                ('B', C.c_void_p), ('ldb', C.c_int), ('b_kc', C.c_int), ('mapB', RowMap), ('actB', Act),
+                ('C', C.c_void_p), ('ldc', C.c_int), ('mapC', RowMap),
+                ('bias', C.c_void_p), ('residual', C.c_void_p),
+                ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
+                ('splitk', C.c_int), ('partial', C.c_void_p),
+                ('bm', C.c_int), ('bn', C.c_int), ('wm', C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/dpp_hip.h declares must be listed here
+SIGNATURES = {
+    'dpp_abi_version': (C.c_int, []),
+    'dpp_gemm': (C.c_int, [C.POINTER(GemmDesc), stream_t]),
+    'dpp_reduce_partials': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
+}
+
+
+class DppError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status != 0:
+        raise DppError("%s failed with status %d" % (what, status))
+
+
+_cache = {}
+
+
+def load(path=None):
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _cache:
+        return _cache[path]
+    if not os.path.exists(path):
+        raise DppError("HIP kernel library not found: %s (build it with __graft_entry__.build() or "
+                       "`make -C deep-prior-pp_amd/csrc hip`); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.dpp_abi_version()
+    if v != ABI_VERSION:
+        raise DppError("ABI version mismatch: library %d, binding %d" % (v, ABI_VERSION))
+    _cache[path] = lib
+    return lib

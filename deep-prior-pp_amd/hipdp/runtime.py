@@ -1,0 +1,120 @@
+"""
+Device-memory plumbing for the kernel library.  PyTorch-ROCm is used for allocation, host<->device
+copies and the stream only; every computation goes through libdpp_hip.so.
+
+`TorchHipRuntime` is the product runtime and refuses to start without a GPU (no CPU fallback).
+The CPU-side kernel-logic tests inject `tests/emu/emu_runtime.EmuRuntime` (host memory + the emulator
+build of the same kernel sources) through the same small interface.
+"""
+import numpy as np
+
+from . import lib as _lib
+
+
+class Buffer(object):
+    """A typed view of device memory: `ptr` (int), `shape`, `dtype`; `owner` keeps the allocation alive."""
+    __slots__ = ('ptr', 'shape', 'dtype', 'owner', 'rt')
+
+    def __init__(self, rt, ptr, shape, dtype, owner):
+        self.rt, self.ptr, self.shape, self.dtype, self.owner = rt, int(ptr), tuple(int(s) for s in shape), np.dtype(dtype), owner
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape)) if len(self.shape) else 1
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    def view(self, offset, shape, dtype=None):
+        """A sub-view starting `offset` ELEMENTS in, with a new shape."""
+        dt = np.dtype(dtype or self.dtype)
+        n = int(np.prod(shape)) if len(shape) else 1
+        assert offset >= 0 and offset * self.dtype.itemsize + n * dt.itemsize <= self.nbytes, "view out of range"
+        return Buffer(self.rt, self.ptr + offset * self.dtype.itemsize, shape, dt, self.owner)
+
+    def reshape(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        assert int(np.prod(shape)) == self.size
+        return Buffer(self.rt, self.ptr, shape, self.dtype, self.owner)
+
+    def get(self):
+        return self.rt.download(self)
+
+    def set(self, arr):
+        self.rt.copy_in(self, arr)
+
+    def zero(self):
+        self.rt.zero(self)
+
+
+class TorchHipRuntime(object):
+    def __init__(self, device=None, lib_path=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.DppError("no MI355X visible to PyTorch-ROCm: the DeepPrior++ HIP path needs a GPU "
+                                "(there is no CPU fallback)")
+        self.torch = torch
+        self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
+        self.lib = _lib.load(lib_path)
+        self.is_emulator = False
+
+    _TD = {'float32': 'float32', 'int32': 'int32', 'uint8': 'uint8', 'float64': 'float64', 'int64': 'int64'}
+
+    def alloc(self, shape, dtype=np.float32, zero=True):
+        t = self.torch
+        shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        td = getattr(t, self._TD[np.dtype(dtype).name])
+        ten = (t.zeros if zero else t.empty)(max(1, int(np.prod(shape))), dtype=td, device=self.device)
+        return Buffer(self, ten.data_ptr(), shape, dtype, ten)
+
+    def upload(self, arr, dtype=None):
+        arr = np.ascontiguousarray(arr, dtype=dtype or arr.dtype)
+        b = self.alloc(arr.shape, arr.dtype, zero=False)
+        self.copy_in(b, arr)
+        return b
+
+    def _tensor(self, buf):
+        base = buf.owner
+        off = (buf.ptr - base.data_ptr()) // base.element_size()
+        if buf.dtype.itemsize != base.element_size():
+            raise ValueError("dtype-changing views are not downloadable")
+        return base[off:off + buf.size]
+
+    def copy_in(self, buf, arr):
+        arr = np.ascontiguousarray(arr, dtype=buf.dtype).reshape(-1)
+        assert arr.size == buf.size, (arr.shape, buf.shape)
+        self._tensor(buf).copy_(self.torch.from_numpy(arr), non_blocking=False)
+
+    def download(self, buf):
+        return self._tensor(buf).cpu().numpy().reshape(buf.shape).copy()
+
+    def zero(self, buf):
+        self._tensor(buf).zero_()
+
+    def copy(self, dst, src):
+        self._tensor(dst).copy_(self._tensor(src))
+
+    @property
+    def stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+_default = None
+
+
+def default_runtime():
+    """The process-wide product runtime (one per process / GPU)."""
+    global _default
+    if _default is None:
+        _default = TorchHipRuntime()
+    return _default
+
+
+def set_default_runtime(rt):
+    global _default
+    _default = rt

@@ -1,0 +1,150 @@
+"""dpp_gemm against NumPy float64 on the same seeded inputs (tolerance: f32 round-off of a K-term dot
+product, 1e-5 relative to sum|a||b|), every operand layout / row map / prologue / epilogue variant."""
+import numpy as np
+import pytest
+
+from hipdp import ops
+from hipdp.lib import Act, RowMap
+from tests.backends import BACKENDS, get_runtime
+
+
+def _tol(K):
+    return 2e-6 * max(8, K) ** 0.5
+
+
+def _check(out, ref, K, scale=1.0):
+    np.testing.assert_allclose(out, ref, rtol=0, atol=_tol(K) * scale * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('tile', [(0, 0, 0), (128, 64, 4), (64, 16, 4), (128, 32, 4), (16, 64, 1), (32, 64, 1)])
+def test_gemm_kc_kc(backend, tile):
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(1)
+    M, N, K = 200, 48, 40
+    A = rng.normal(size=(M, K)).astype('float32')
+    B = rng.normal(size=(N, K)).astype('float32')
+    bias = rng.normal(size=N).astype('float32')
+    dA, dB, db, dC = rt.upload(A), rt.upload(B), rt.upload(bias), rt.alloc((M, N), zero=False)
+    ops.gemm(rt, dA, dB, dC, M, N, K, 1, 1, K, K, N, bias=db, tile=tile)(rt.stream)
+    rt.synchronize()
+    _check(dC.get(), A.astype('f8') @ B.astype('f8').T + bias, K, 4)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_gemm_unaligned_scalar_paths(backend):
+    """FC 1024->30 and 30->42 shapes: N, K not multiples of 4 -> scalar loads, zero fill."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(2)
+    for (M, N, K) in ((37, 30, 50), (20, 42, 30), (5, 7, 3)):
+        A = rng.normal(size=(M, K)).astype('float32')
+        W = rng.normal(size=(K, N)).astype('float32')
+        dA, dW, dC = rt.upload(A), rt.upload(W), rt.alloc((M, N), zero=False)
+        ops.gemm(rt, dA, dW, dC, M, N, K, 1, 0, K, N, N)(rt.stream)           # x . W   (B is [K][N])
+        rt.synchronize()
+        _check(dC.get(), A.astype('f8') @ W.astype('f8'), K, 4)
+        dY = rng.normal(size=(M, N)).astype('float32')
+        dYb, dX = rt.upload(dY), rt.alloc((M, K), zero=False)
+        ops.gemm(rt, dYb, dW, dX, M, K, N, 1, 1, N, N, K)(rt.stream)          # dy . W^T (B is [n=K][k=N])
+        rt.synchronize()
+        _check(dX.get(), dY.astype('f8') @ W.astype('f8').T, N, 4)
+        dWg = rt.alloc((K, N), zero=False)
+        ops.gemm(rt, dA, dYb, dWg, K, N, M, 0, 0, K, N, N)(rt.stream)         # x^T . dy (both [kred][mn])
+        rt.synchronize()
+        _check(dWg.get(), A.astype('f8').T @ dY.astype('f8'), M, 4)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_conv1x1_stride2_fwd_with_bn_relu_bias_residual(backend):
+    """1x1/s2 ConvLayer on relu(bn(x)): A rows gathered with the stride-2 row map."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(3)
+    Nb, Hi, Wi, Ci, Co, s = 3, 8, 6, 32, 16, 2
+    Ho, Wo = Hi // s, Wi // s
+    X = rng.normal(size=(Nb, Hi, Wi, Ci)).astype('float32')
+    Wk = rng.normal(size=(Co, Ci)).astype('float32')
+    mean, scale, beta = (rng.normal(size=Ci).astype('float32') for _ in range(3))
+    bias = rng.normal(size=Co).astype('float32')
+    res = rng.normal(size=(Nb, Ho, Wo, Co)).astype('float32')
+    d = {k: rt.upload(v) for k, v in dict(X=X, Wk=Wk, mean=mean, scale=scale, beta=beta, bias=bias, res=res).items()}
+    Y = rt.alloc((Nb, Ho, Wo, Co), zero=False)
+    M = Nb * Ho * Wo
+    ops.gemm(rt, d['X'], d['Wk'], Y, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=RowMap.strided(s, Ho, Wo, Hi, Wi),
+             actA=ops.act(Act.BN_RELU, d['mean'], d['scale'], d['beta'], Ci), bias=d['bias'], residual=d['res'])(rt.stream)
+    rt.synchronize()
+    A = np.maximum((X.astype('f8') - mean) * scale + beta, 0)[:, ::s, ::s, :]
+    ref = A.reshape(M, Ci) @ Wk.astype('f8').T + bias + res.reshape(M, Co)
+    _check(Y.get().reshape(M, Co), ref, Ci, 8)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_conv1x1_stride2_dgrad_scatter_accumulate(backend):
+    """Data gradient of two 1x1/s2 convs sharing their input: scatter to even pixels, second call adds."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(4)
+    Nb, Hi, Wi, Ci, s = 2, 8, 8, 32, 2
+    Ho, Wo = Hi // s, Wi // s
+    M = Nb * Ho * Wo
+    dY1 = rng.normal(size=(M, 16)).astype('float32')
+    dY2 = rng.normal(size=(M, 64)).astype('float32')
+    W1 = rng.normal(size=(16, Ci)).astype('float32')
+    W2 = rng.normal(size=(64, Ci)).astype('float32')
+    dH = rt.alloc((Nb, Hi, Wi, Ci), zero=True)
+    mp = RowMap.strided(s, Ho, Wo, Hi, Wi)
+    b = {k: rt.upload(v) for k, v in dict(dY1=dY1, dY2=dY2, W1=W1, W2=W2).items()}
+    ops.gemm(rt, b['dY2'], b['W2'], dH, M, Ci, 64, 1, 0, 64, Ci, Ci, mapC=mp)(rt.stream)
+    ops.gemm(rt, b['dY1'], b['W1'], dH, M, Ci, 16, 1, 0, 16, Ci, Ci, mapC=mp, residual=dH)(rt.stream)
+    rt.synchronize()
+    ref = np.zeros((Nb, Hi, Wi, Ci))
+    ref[:, ::s, ::s, :] = (dY1.astype('f8') @ W1 + dY2.astype('f8') @ W2).reshape(Nb, Ho, Wo, Ci)
+    _check(dH.get(), ref, 80, 8)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('tile', [(0, 0, 0), (16, 64, 1), (64, 64, 4)])
+def test_conv1x1_wgrad_splitk_with_prologue(backend, tile):
+    """Filter gradient dW[o][c] = sum_m dY[m][o] * relu(bn(X))[map(m)][c]: both operands [kred][mn],
+    prologue on B, stride-2 row map on the reduction index, split-K + deterministic reduce."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(5)
+    Nb, Hi, Wi, Ci, Co, s = 4, 8, 8, 64, 16, 2
+    Ho, Wo = Hi // s, Wi // s
+    M = Nb * Ho * Wo
+    X = rng.normal(size=(Nb, Hi, Wi, Ci)).astype('float32')
+    dY = rng.normal(size=(M, Co)).astype('float32')
+    mean, scale, beta = (rng.normal(size=Ci).astype('float32') for _ in range(3))
+    b = {k: rt.upload(v) for k, v in dict(X=X, dY=dY, mean=mean, scale=scale, beta=beta).items()}
+    splitk = 3
+    part = rt.alloc((splitk, Co, Ci), zero=False)
+    dW = rt.alloc((Co, Ci), zero=False)
+    ops.gemm(rt, b['dY'], b['X'], None, Co, Ci, M, 0, 0, Co, Ci, mapB=RowMap.strided(s, Ho, Wo, Hi, Wi),
+             actB=ops.act(Act.BN_RELU, b['mean'], b['scale'], b['beta'], Ci), splitk=splitk, partial=part, tile=tile)(rt.stream)
+    ops.reduce_partials(rt, part, splitk, Co * Ci, dW)(rt.stream)
+    rt.synchronize()
+    A = np.maximum((X.astype('f8') - mean) * scale + beta, 0)[:, ::s, ::s, :].reshape(M, Ci)
+    _check(dW.get(), dY.astype('f8').T @ A, M, 8)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_fc_prologue_channel_modulo(backend):
+    """FC1 on the flattened NHWC map: BN+ReLU prologue with channel = k % C."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(6)
+    M, Cc, HW, N = 6, 16, 4, 24
+    K = Cc * HW
+    X = rng.normal(size=(M, K)).astype('float32')
+    W = rng.normal(size=(K, N)).astype('float32')
+    mean, scale, beta = (rng.normal(size=Cc).astype('float32') for _ in range(3))
+    b = {k: rt.upload(v) for k, v in dict(X=X, W=W, mean=mean, scale=scale, beta=beta).items()}
+    Y = rt.alloc((M, N), zero=False)
+    a = ops.act(Act.BN_RELU, b['mean'], b['scale'], b['beta'], Cc)
+    ops.gemm(rt, b['X'], b['W'], Y, M, N, K, 1, 0, K, N, N, actA=a)(rt.stream)
+    rt.synchronize()
+    A = np.maximum((X.astype('f8').reshape(M, HW, Cc) - mean) * scale + beta, 0).reshape(M, K)
+    _check(Y.get(), A @ W.astype('f8'), K, 8)
+    # weight gradient: A operand is [kred = sample][i = k], prologue channel = i % C
+    dY = rng.normal(size=(M, N)).astype('float32')
+    dYb, dW = rt.upload(dY), rt.alloc((K, N), zero=False)
+    ops.gemm(rt, b['X'], dYb, dW, K, N, M, 0, 0, K, N, N, actA=a)(rt.stream)
+    rt.synchronize()
+    _check(dW.get(), A.T @ dY.astype('f8'), M, 8)
