@@ -1,0 +1,397 @@
+// augment.hip -- the online depth-crop augmentation (rotate / scale / translate CoM) fused for gfx950.
+//
+// Replaces the per-sample Python + cv2 loop that the reference runs in 8 worker processes:
+//   NetTrainer.augmentCrop                 /root/reference/src/trainer/nettrainer.py:919-997
+//   HandDetector.moveCoM / rotateHand / scaleHand / recropHand / comToBounds / comToTransform
+//                                          /root/reference/src/util/handdetector.py:204-258, 678-803
+//   importer (un)projection                /root/reference/src/data/importers.py:80-119, 1187-1224
+//   rotatePoint2D                          /root/reference/src/data/transformations.py:71-88
+//   proj.transform(label) (PCA prior)      /root/reference/src/trainer/poseregnettrainer.py:262
+// cv2.warpAffine / warpPerspective (INTER_NEAREST, BORDER_CONSTANT 0) are restated from OpenCV 2.4's
+// imgwarp.cpp exactly as oracle/augment.py documents (10-bit fixed point for the affine warp, cvRound of the
+// double coordinate on 64-wide blocks for the perspective warp).
+//
+// Two launches per batch:
+//   augment_prepare_kernel  one workgroup per crop: wave-shuffle max of the crop (the reference's `premax`),
+//                           then lane 0 does the per-sample geometry in f64 (new CoM, crop transform, inverse
+//                           warp matrix, z-thresholds, joint labels) and the workgroup projects the label onto
+//                           the PCA prior;
+//   augment_warp_kernel     one thread per output pixel: de-normalise, gather through the inverse map, z-clamp,
+//                           far-plane fill, re-normalise.  HBM traffic = read 64 KB + write 64 KB per crop; the
+//                           gather hits L2 (a 64 KB crop is resident).
+// Compiled with -ffp-contract=off: the reference's NumPy/OpenCV arithmetic rounds after every operation, so no
+// fused multiply-add may be formed here (pixel coordinates at rounding boundaries would move).
+#include "dpp_common.h"
+
+namespace {
+
+constexpr int AUG_NONE = 0, AUG_COM = 1, AUG_ROT = 2, AUG_SC = 3;
+constexpr int WARP_NONE = 0, WARP_AFFINE = 1, WARP_PERSP = 2;
+constexpr int MAXJ3 = 192;     // up to 64 joints x 3
+
+struct AugRec {                // per-sample record written by prepare, read by warp
+    double m[9];               // inverse map (affine uses m[0..5])
+    int warp;
+    int thresh;                // apply the 32000 / z-threshold rules of recropHand
+    float zlo, zhi;            // zstart / zend
+    float den_scale, den_off;  // img * (cz/2) + com_z  (old cube / old com)
+    float premax;
+    float far_v, near_v;       // com_z' +- cz'/2
+    float norm_off, norm_div;  // (v - com_z') / (cz'/2)
+};
+
+struct AugCam {
+    double fx, fy, ux, uy;
+    int flip_y;
+};
+
+__device__ __forceinline__ void to3d(const AugCam& c, double u, double v, double d, float out[3]) {
+    out[0] = (float)((u - c.ux) * d / c.fx);
+    out[1] = (float)((c.flip_y ? (c.uy - v) : (v - c.uy)) * d / c.fy);
+    out[2] = (float)d;
+}
+
+// joint3DToImg; f32in: the sample is a float32 array, so sample[0]/sample[2] is a float32 division
+__device__ __forceinline__ void toimg(const AugCam& c, double x, double y, double z, bool f32in, float out[3]) {
+    if (z == 0.0) { out[0] = (float)c.ux; out[1] = (float)c.uy; out[2] = 0.0f; return; }
+    double q0 = x / z, q1 = y / z;
+    if (f32in) { q0 = (double)((float)x / (float)z); q1 = (double)((float)y / (float)z); }
+    out[0] = (float)(q0 * c.fx + c.ux);
+    out[1] = (float)(c.flip_y ? (c.uy - q1 * c.fy) : (q1 * c.fy + c.uy));
+    out[2] = (float)z;
+}
+
+__device__ __forceinline__ void com_to_bounds(const float com[3], const double size[3], double fx, double fy, int b[4]) {
+    double c0 = com[0], c1 = com[1], c2 = com[2];
+    b[0] = (int)floor((c0 * c2 / fx - size[0] / 2.) / c2 * fx + 0.5);
+    b[1] = (int)floor((c0 * c2 / fx + size[0] / 2.) / c2 * fx + 0.5);
+    b[2] = (int)floor((c1 * c2 / fy - size[1] / 2.) / c2 * fy + 0.5);
+    b[3] = (int)floor((c1 * c2 / fy + size[1] / 2.) / c2 * fy + 0.5);
+}
+
+__device__ __forceinline__ long long floordiv(long long a, long long b) {   // python-2 integer division
+    long long q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+    return q;
+}
+
+// comToTransform: off . scale . trans  (3x3, row-major)
+__device__ void com_to_transform(const float com[3], const double size[3], double fx, double fy, int dsz, double T[9]) {
+    int b[4];
+    com_to_bounds(com, size, fx, fy, b);
+    int wb = b[1] - b[0], hb = b[3] - b[2];
+    double s;
+    long long sz0, sz1;
+    if (wb > hb) { s = (double)dsz / (double)wb; sz0 = dsz; sz1 = floordiv((long long)hb * dsz, wb); }
+    else { s = (double)dsz / (double)hb; sz0 = floordiv((long long)wb * dsz, hb); sz1 = dsz; }
+    double xs = floor(dsz / 2. - sz1 / 2.);
+    double ys = floor(dsz / 2. - sz0 / 2.);
+    // off * (scale * trans): scale*trans = [[s,0,-s*xstart],[0,s,-s*ystart],[0,0,1]]
+    T[0] = s; T[1] = 0.; T[2] = s * (double)(-b[0]) + xs;
+    T[3] = 0.; T[4] = s; T[5] = s * (double)(-b[2]) + ys;
+    T[6] = 0.; T[7] = 0.; T[8] = 1.;
+}
+
+__device__ void mat3_mul(const double A[9], const double B[9], double C[9]) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 3; ++k) s += A[i * 3 + k] * B[k * 3 + j];
+            C[i * 3 + j] = s;
+        }
+}
+
+__device__ void mat3_inv(const double S[9], double t[9]) {     // cv::invert, 3x3 cofactor branch
+    double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+    if (d == 0.0) { for (int i = 0; i < 9; ++i) t[i] = 0.0; return; }
+    d = 1. / d;
+    t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+    t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+    t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+    t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+    t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+    t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+    t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+    t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+    t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+}
+
+// ---- counter-based RNG for on-device parameter draws (Philox-4x32-10) -----------------------------------
+__device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
+    const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    unsigned hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    unsigned hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ void philox4(unsigned long long seed, unsigned long long ctr, unsigned sub, unsigned out[4]) {
+    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = sub, c3 = 0;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double u01(unsigned a, unsigned b) {       // (0,1), 53 bits
+    unsigned long long v = (((unsigned long long)a << 32) | b) >> 11;
+    return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+struct PrepArgs {
+    const float* img;        // [B][H*W] normalised crops
+    const float* com3d;      // [B][3]
+    const float* cube;       // [B][3]
+    const float* Mcrop;      // [B][9]
+    const float* gt3d;       // [B][J][3] joints relative to the CoM (mm)
+    const int* mode;         // [B] or null -> drawn on device
+    const double* off;       // [B][3]
+    const double* rot;       // [B]
+    const double* sc;        // [B]
+    const int* mode_table;   // [n_modes] aug_modes as AUG_* codes (device draws index into it)
+    int n_modes;
+    unsigned long long seed, counter;
+    double sigma_com, sigma_sc, rot_range;
+    AugCam cam;
+    int B, J, dsz;
+    const float* pca_mean;   // [J*3] or null
+    const float* pca_comp;   // [E][J*3]
+    int E;
+    AugRec* rec;             // [B]
+    float* out_y;            // [B][E] or [B][J*3]
+    int* out_mode;           // [B] (optional: the mode actually used)
+};
+
+__global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a) {
+    __shared__ float s_red[DPP_THREADS / DPP_WAVE];
+    __shared__ float s_label[MAXJ3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int npix = a.dsz * a.dsz;
+    // premax: max of the crop (monotone under the f32 de-normalisation, so max first, de-normalise after)
+    float mx = -3.4e38f;
+    const float* im = a.img + (size_t)b * npix;
+    for (int i = tid; i < npix; i += DPP_THREADS) mx = fmaxf(mx, im[i]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < DPP_THREADS / DPP_WAVE; ++w) mx = fmaxf(mx, s_red[w]);
+        const AugCam cam = a.cam;
+        const double fx = fabs(cam.fx), fy = fabs(cam.fy);      // HandDetector(..., abs(di.fx), abs(di.fy))
+        // ---- the four draws of augmentCrop (nettrainer.py:954-957) ----
+        int mode; double off[3], rot, sc;
+        if (a.mode) {
+            mode = a.mode[b]; off[0] = a.off[b * 3]; off[1] = a.off[b * 3 + 1]; off[2] = a.off[b * 3 + 2]; rot = a.rot[b]; sc = a.sc[b];
+        } else {
+            unsigned r0[4], r1[4], r2[4];
+            unsigned long long ctr = a.counter * (unsigned long long)a.B + b;
+            philox4(a.seed, ctr, 0, r0); philox4(a.seed, ctr, 1, r1); philox4(a.seed, ctr, 2, r2);
+            mode = a.mode_table[r0[0] % (unsigned)a.n_modes];
+            double u1 = u01(r0[1], r0[2]), u2 = u01(r0[3], r1[0]), u3 = u01(r1[1], r1[2]), u4 = u01(r1[3], r2[0]);
+            double ra = sqrt(-2.0 * log(u1)), rb = sqrt(-2.0 * log(u3));
+            const double TWO_PI = 6.283185307179586;
+            off[0] = ra * cos(TWO_PI * u2) * a.sigma_com;
+            off[1] = ra * sin(TWO_PI * u2) * a.sigma_com;
+            off[2] = rb * cos(TWO_PI * u4) * a.sigma_com;
+            rot = (2.0 * u01(r2[1], r2[2]) - 1.0) * a.rot_range;
+            sc = fabs(1.0 + rb * sin(TWO_PI * u4) * a.sigma_sc);
+        }
+        if (a.out_mode) a.out_mode[b] = mode;
+
+        double cube[3] = {(double)a.cube[b * 3], (double)a.cube[b * 3 + 1], (double)a.cube[b * 3 + 2]};
+        float com[3];           // CoM in image coordinates (float32 array in the reference)
+        toimg(cam, a.com3d[b * 3], a.com3d[b * 3 + 1], a.com3d[b * 3 + 2], true, com);
+        double Mold[9];
+        for (int i = 0; i < 9; ++i) Mold[i] = (double)a.Mcrop[b * 9 + i];
+
+        AugRec r;
+        r.warp = WARP_NONE; r.thresh = 0; r.zlo = 0.f; r.zhi = 0.f;
+        for (int i = 0; i < 9; ++i) r.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        r.den_scale = (float)(cube[2] / 2.);
+        r.den_off = com[2];
+        r.premax = mx * r.den_scale + r.den_off;      // two roundings (contraction is off)
+        float ncom[3] = {com[0], com[1], com[2]};
+        double ncube[3] = {cube[0], cube[1], cube[2]};
+        const int J = a.J;
+        const float half_old = (float)(cube[2] / 2.);
+
+        if (mode == AUG_COM) {
+            bool zero = fabs(off[0]) <= 1e-8 && fabs(off[1]) <= 1e-8 && fabs(off[2]) <= 1e-8;
+            float c3[3];
+            to3d(cam, com[0], com[1], com[2], c3);
+            if (!zero) {
+                toimg(cam, (double)c3[0] + off[0], (double)c3[1] + off[1], (double)c3[2] + off[2], false, ncom);
+                if (!(fabs((double)com[2]) <= 1e-8 || fabs((double)ncom[2]) <= 1e-8)) {
+                    double Mn[9], Mi[9], Mt[9];
+                    com_to_transform(ncom, cube, fx, fy, a.dsz, Mn);
+                    mat3_inv(Mold, Mi);                 // numpy.linalg.inv(M) restated as cofactor inverse (f64)
+                    mat3_mul(Mn, Mi, Mt);
+                    mat3_inv(Mt, r.m);                  // warpPerspective inverts the forward matrix
+                    r.warp = WARP_PERSP; r.thresh = 1;
+                    r.zlo = (float)((double)ncom[2] - cube[2] / 2.);
+                    r.zhi = (float)((double)ncom[2] + cube[2] / 2.);
+                }
+            }
+            float n3[3];
+            to3d(cam, ncom[0], ncom[1], ncom[2], n3);
+            for (int j = 0; j < J; ++j)
+                for (int d = 0; d < 3; ++d) {
+                    float g = a.gt3d[((size_t)b * J + j) * 3 + d];
+                    float nj = zero ? g : ((g + c3[d]) - n3[d]);
+                    s_label[j * 3 + d] = nj / half_old;
+                }
+        } else if (mode == AUG_ROT) {
+            bool zero = fabs(rot) <= 1e-8;
+            if (!zero) {
+                rot = rot - floor(rot / 360.0) * 360.0;                 // numpy.mod(rot, 360)
+                // cv2.getRotationMatrix2D((W//2, H//2), -rot, 1) then the inversion at the top of cv::warpAffine
+                double ang = -rot * 3.141592653589793 / 180.;
+                double al = cos(ang), be = sin(ang);
+                double cx = (double)(a.dsz / 2), cy = (double)(a.dsz / 2);
+                double F[6] = {al, be, (1 - al) * cx - be * cy, -be, al, be * cx + (1 - al) * cy};
+                double D = F[0] * F[4] - F[1] * F[3];
+                D = D != 0 ? 1. / D : 0.;
+                double A11 = F[4] * D, A22 = F[0] * D;
+                r.m[0] = A11; r.m[1] = F[1] * (-D); r.m[3] = F[3] * (-D); r.m[4] = A22;
+                r.m[2] = -r.m[0] * F[2] - r.m[1] * F[5];
+                r.m[5] = -r.m[3] * F[2] - r.m[4] * F[5];
+                r.warp = WARP_AFFINE;
+            }
+            float c3[3];
+            to3d(cam, com[0], com[1], com[2], c3);
+            double alpha = rot * 3.141592653589793 / 180.;
+            double ca = cos(alpha), sa = sin(alpha);
+            for (int j = 0; j < J; ++j) {
+                float g[3], p3[3], p2[3], pr[3], q3[3];
+                for (int d = 0; d < 3; ++d) g[d] = a.gt3d[((size_t)b * J + j) * 3 + d];
+                if (zero) { for (int d = 0; d < 3; ++d) s_label[j * 3 + d] = g[d] / half_old; continue; }
+                for (int d = 0; d < 3; ++d) p3[d] = g[d] + c3[d];
+                toimg(cam, p3[0], p3[1], p3[2], true, p2);
+                float px = p2[0] - com[0], py = p2[1] - com[1];          // rotatePoint2D on float32 arrays
+                pr[0] = (float)((double)px * ca - (double)py * sa);
+                pr[1] = (float)((double)px * sa + (double)py * ca);
+                pr[0] = pr[0] + com[0]; pr[1] = pr[1] + com[1]; pr[2] = p2[2];
+                to3d(cam, pr[0], pr[1], pr[2], q3);
+                for (int d = 0; d < 3; ++d) s_label[j * 3 + d] = (q3[d] - c3[d]) / half_old;
+            }
+        } else if (mode == AUG_SC) {
+            bool one = fabs(sc - 1.0) <= (1e-8 + 1e-5);                  // numpy.allclose(sc, 1.)
+            if (!one) {
+                for (int d = 0; d < 3; ++d) ncube[d] = cube[d] * sc;
+                if (!(fabs((double)com[2]) <= 1e-8)) {
+                    double Mn[9], Mi[9], Mt[9];
+                    com_to_transform(com, ncube, fx, fy, a.dsz, Mn);
+                    mat3_inv(Mold, Mi);
+                    mat3_mul(Mn, Mi, Mt);
+                    mat3_inv(Mt, r.m);
+                    r.warp = WARP_PERSP; r.thresh = 1;
+                    r.zlo = (float)((double)com[2] - cube[2] / 2.);      // thresholds use the OLD cube
+                    r.zhi = (float)((double)com[2] + cube[2] / 2.);
+                }
+            }
+            const float half_new = (float)(ncube[2] / 2.);
+            for (int i = 0; i < J * 3; ++i) s_label[i] = a.gt3d[(size_t)b * J * 3 + i] / half_new;
+        } else {
+            for (int i = 0; i < J * 3; ++i) s_label[i] = a.gt3d[(size_t)b * J * 3 + i] / half_old;
+        }
+        double far_d = (double)ncom[2] + ncube[2] / 2., near_d = (double)ncom[2] - ncube[2] / 2.;
+        r.far_v = (float)far_d; r.near_v = (float)near_d;
+        r.norm_off = ncom[2]; r.norm_div = (float)(ncube[2] / 2.);
+        a.rec[b] = r;
+    }
+    __syncthreads();
+    // label -> PCA prior (poseregnettrainer.py:262) or the raw normalised joints
+    const int D = a.J * 3;
+    if (a.pca_comp) {
+        for (int e = tid; e < a.E; e += DPP_THREADS) {
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) s += ((double)s_label[d] - (double)a.pca_mean[d]) * (double)a.pca_comp[(size_t)e * D + d];
+            a.out_y[(size_t)b * a.E + e] = (float)s;
+        }
+    } else {
+        for (int d = tid; d < D; d += DPP_THREADS) a.out_y[(size_t)b * D + d] = s_label[d];
+    }
+}
+
+__device__ __forceinline__ long long cv_round(double v) { return (long long)rint(v); }
+
+__global__ __launch_bounds__(DPP_THREADS) void augment_warp_kernel(const float* __restrict__ img, const AugRec* __restrict__ rec, int dsz,
+                                                                   float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * DPP_THREADS + threadIdx.x;
+    const int npix = dsz * dsz;
+    if (p >= npix) return;
+    const AugRec r = rec[b];
+    const float* im = img + (size_t)b * npix;
+    const int y = p / dsz, x = p - y * dsz;
+    float v;
+    if (r.warp == WARP_NONE) {
+        v = im[p] * r.den_scale + r.den_off;
+    } else {
+        long long X, Y;
+        if (r.warp == WARP_AFFINE) {
+            long long ad = cv_round(r.m[0] * (double)x * 1024.), bd = cv_round(r.m[3] * (double)x * 1024.);
+            long long X0 = cv_round((r.m[1] * (double)y + r.m[2]) * 1024.) + 512;
+            long long Y0 = cv_round((r.m[4] * (double)y + r.m[5]) * 1024.) + 512;
+            X = (X0 + ad) >> 10; Y = (Y0 + bd) >> 10;
+        } else {
+            const int bx = (x >> 6) << 6;                       // 64-wide destination blocks of cv::warpPerspective
+            const double x1 = (double)(x - bx), fbx = (double)bx, fy_ = (double)y;
+            double X0 = r.m[0] * fbx + r.m[1] * fy_ + r.m[2];
+            double Y0 = r.m[3] * fbx + r.m[4] * fy_ + r.m[5];
+            double W0 = r.m[6] * fbx + r.m[7] * fy_ + r.m[8];
+            double Wv = W0 + r.m[6] * x1;
+            Wv = (Wv != 0.0) ? 1. / Wv : 0.;
+            double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + r.m[0] * x1) * Wv));
+            double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + r.m[3] * x1) * Wv));
+            X = cv_round(fX); Y = cv_round(fY);
+            X = X < -32768 ? -32768 : (X > 32767 ? 32767 : X);
+            Y = Y < -32768 ? -32768 : (Y > 32767 ? 32767 : Y);
+        }
+        v = 0.0f;                                                // BORDER_CONSTANT 0
+        if (X >= 0 && X < dsz && Y >= 0 && Y < dsz) v = im[(int)Y * dsz + (int)X] * r.den_scale + r.den_off;
+        if (r.thresh) {
+            if (fabs((double)v - 32000.0) <= 1e-8 + 1e-5 * 32000.0) v = 0.0f;     // numpy.isclose(warped, nv_val)
+            if (v < r.zlo && v != 0.0f) v = r.zlo;
+            else if (v > r.zhi && v != 0.0f) v = 0.0f;
+        }
+    }
+    if (v == r.premax) v = r.far_v;
+    if (v == 0.0f) v = r.far_v;
+    if (v >= r.far_v) v = r.far_v;
+    if (v <= r.near_v) v = r.near_v;
+    out[(size_t)b * npix + p] = (v - r.norm_off) / r.norm_div;
+}
+
+}  // namespace
+
+extern "C" size_t dpp_augment_record_bytes(void) { return sizeof(AugRec); }
+
+extern "C" int dpp_augment_prepare(const float* img, const float* com3d, const float* cube, const float* Mcrop, const float* gt3d,
+                                   int B, int J, int dsz, const int* mode, const double* off, const double* rot, const double* sc,
+                                   const int* mode_table, int n_modes, unsigned long long seed, unsigned long long counter,
+                                   double sigma_com, double sigma_sc, double rot_range, double fx, double fy, double ux, double uy,
+                                   int flip_y, const float* pca_mean, const float* pca_comp, int E, void* records, float* out_y,
+                                   int* out_mode, dpp_stream_t stream) {
+    if (!img || !com3d || !cube || !Mcrop || !gt3d || !records || !out_y || B < 1 || J < 1 || J * 3 > MAXJ3 || dsz < 1) return DPP_E_BADARG;
+    if (!mode && (!mode_table || n_modes < 1)) return DPP_E_BADARG;
+    if (mode && (!off || !rot || !sc)) return DPP_E_BADARG;
+    if (pca_comp && (!pca_mean || E < 1)) return DPP_E_BADARG;
+    PrepArgs a;
+    a.img = img; a.com3d = com3d; a.cube = cube; a.Mcrop = Mcrop; a.gt3d = gt3d;
+    a.mode = mode; a.off = off; a.rot = rot; a.sc = sc; a.mode_table = mode_table; a.n_modes = n_modes;
+    a.seed = seed; a.counter = counter; a.sigma_com = sigma_com; a.sigma_sc = sigma_sc; a.rot_range = rot_range;
+    a.cam.fx = fx; a.cam.fy = fy; a.cam.ux = ux; a.cam.uy = uy; a.cam.flip_y = flip_y;
+    a.B = B; a.J = J; a.dsz = dsz; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
+    a.rec = static_cast<AugRec*>(records); a.out_y = out_y; a.out_mode = out_mode;
+    hipLaunchKernelGGL(augment_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_augment_warp(const float* img, const void* records, int B, int dsz, float* out, dpp_stream_t stream) {
+    if (!img || !records || !out || B < 1 || dsz < 1 || img == out) return DPP_E_BADARG;
+    dim3 grid(dpp_cdiv(dsz * dsz, DPP_THREADS), B);
+    hipLaunchKernelGGL(augment_warp_kernel, grid, dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), img,
+                       static_cast<const AugRec*>(records), dsz, out);
+    return dpp_launch_status();
+}

@@ -1,0 +1,259 @@
+// bn.hip -- BatchNormLayer statistics, coefficients and backward for gfx950 (HBM-bound kernels).
+//
+// Reference arithmetic: /root/reference/src/net/batchnormlayer.py:119-194
+//   train: mean / BIASED variance over (N,H,W); inv_std = 1/sqrt(var + 1e-4); y = (x-mean)*(gamma*inv_std)+beta;
+//          running mean / running INV-STD EMA with alpha = 0.1;   eval: stored mean / inv_std.
+// The normalisation itself is never materialised: consumers apply it as an operand prologue (dpp_act).
+//
+// All tensors are pixel-major [M][C] (C % 4 == 0), so a wave reads whole 64..1024-byte rows with float4
+// lanes (coalesced).  Statistics are two-level: per-thread shifted sums -> per-block (mean, M2) combined
+// with Chan's parallel formula in f64 -> a finalize kernel that walks the per-block partials in a FIXED
+// order (deterministic, no atomics).  This keeps the variance accurate when |mean| >> std.
+#include "dpp_common.h"
+
+namespace {
+
+constexpr int MAXQ = 256;   // float4 lanes per row => C <= 1024
+
+__global__ __launch_bounds__(DPP_THREADS) void bn_stats_partial_kernel(const float* __restrict__ X, int M, int C,
+                                                                       int rpb, float* __restrict__ partial) {
+    __shared__ float s_mean[DPP_THREADS * 4];
+    __shared__ float s_m2[DPP_THREADS * 4];
+    __shared__ float s_n[DPP_THREADS];
+    const int Q = C >> 2;                    // float4 lanes per row
+    const int RP = DPP_THREADS / Q;          // rows per pass
+    const int tid = threadIdx.x;
+    const int q = tid % Q, rr = tid / Q;
+    const int r_begin = blockIdx.x * rpb;
+    const int r_end = (r_begin + rpb < M) ? r_begin + rpb : M;
+    float4 K = make_float4(0.f, 0.f, 0.f, 0.f), s1 = K, s2 = K;
+    int n = 0;
+    if (rr < RP) {
+        for (int r = r_begin + rr; r < r_end; r += RP) {
+            float4 v = *reinterpret_cast<const float4*>(X + (size_t)r * C + q * 4);
+            if (n == 0) K = v;
+            float dx = v.x - K.x, dy = v.y - K.y, dz = v.z - K.z, dw = v.w - K.w;
+            s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+            s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
+            ++n;
+        }
+    }
+    float inv = n > 0 ? 1.0f / (float)n : 0.0f;
+    s_n[tid] = (float)n;
+    s_mean[tid * 4 + 0] = K.x + s1.x * inv; s_m2[tid * 4 + 0] = s2.x - s1.x * s1.x * inv;
+    s_mean[tid * 4 + 1] = K.y + s1.y * inv; s_m2[tid * 4 + 1] = s2.y - s1.y * s1.y * inv;
+    s_mean[tid * 4 + 2] = K.z + s1.z * inv; s_m2[tid * 4 + 2] = s2.z - s1.z * s1.z * inv;
+    s_mean[tid * 4 + 3] = K.w + s1.w * inv; s_m2[tid * 4 + 3] = s2.w - s1.w * s1.w * inv;
+    __syncthreads();
+    for (int c = tid; c < C; c += DPP_THREADS) {
+        int cq = c >> 2, ce = c & 3;
+        double cn = 0.0, mean = 0.0, m2 = 0.0;
+        for (int j = 0; j < RP; ++j) {
+            int t = j * Q + cq;
+            double nb = (double)s_n[t];
+            if (nb == 0.0) continue;
+            double mb = (double)s_mean[t * 4 + ce], m2b = (double)s_m2[t * 4 + ce];
+            double delta = mb - mean, tot = cn + nb;
+            mean += delta * nb / tot;
+            m2 += m2b + delta * delta * cn * nb / tot;
+            cn = tot;
+        }
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = (float)mean;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = (float)m2;
+    }
+}
+
+__global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* __restrict__ partial, int nb, int M, int rpb,
+                                                                  int C, const float* __restrict__ gamma, float eps,
+                                                                  float* __restrict__ mean_o, float* __restrict__ inv_std_o,
+                                                                  float* __restrict__ scale_o, float* __restrict__ run_mean,
+                                                                  float* __restrict__ run_inv_std, float alpha) {
+    int c = blockIdx.x * DPP_THREADS + threadIdx.x;
+    if (c >= C) return;
+    double cn = 0.0, mean = 0.0, m2 = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        int rows = (b * rpb + rpb <= M) ? rpb : (M - b * rpb);
+        double nbk = (double)rows;
+        double mb = (double)partial[((size_t)b * 2 + 0) * C + c], m2b = (double)partial[((size_t)b * 2 + 1) * C + c];
+        double delta = mb - mean, tot = cn + nbk;
+        mean += delta * nbk / tot;
+        m2 += m2b + delta * delta * cn * nbk / tot;
+        cn = tot;
+    }
+    double var = m2 / (double)M;                       // biased, T.var
+    float meanf = (float)mean;
+    float inv_std = (float)(1.0 / sqrt(var + (double)eps));
+    mean_o[c] = meanf;
+    inv_std_o[c] = inv_std;
+    scale_o[c] = gamma[c] * inv_std;
+    if (alpha > 0.0f && run_mean != nullptr) {
+        float oma = 1.0f - alpha;                        // (1. - alpha) in floatX, batchnormlayer.py:165-172
+        run_mean[c] = oma * run_mean[c] + alpha * meanf;
+        run_inv_std[c] = oma * run_inv_std[c] + alpha * inv_std;
+    }
+}
+
+__global__ __launch_bounds__(DPP_THREADS) void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ run_mean,
+                                                                     const float* __restrict__ run_inv_std, int C,
+                                                                     float* __restrict__ mean_o, float* __restrict__ inv_std_o,
+                                                                     float* __restrict__ scale_o) {
+    int c = blockIdx.x * DPP_THREADS + threadIdx.x;
+    if (c >= C) return;
+    mean_o[c] = run_mean[c];
+    inv_std_o[c] = run_inv_std[c];
+    scale_o[c] = gamma[c] * run_inv_std[c];
+}
+
+// G = dA * [bn(x) >= 0]  (Theano's Maximum.grad passes the gradient where out == x, i.e. v >= 0) and the
+// per-block partial sums of  sum(G), sum(G * xhat)  needed by the BN backward.
+__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float* dA, const float* __restrict__ X, int M, int C,
+                                                                    const float* __restrict__ mean, const float* __restrict__ inv_std,
+                                                                    const float* __restrict__ scale, const float* __restrict__ beta,
+                                                                    int relu, float* G, int rpb, float* __restrict__ partial) {
+    __shared__ float s_a[DPP_THREADS * 4];
+    __shared__ float s_b[DPP_THREADS * 4];
+    const int Q = C >> 2, RP = DPP_THREADS / Q;
+    const int tid = threadIdx.x, q = tid % Q, rr = tid / Q;
+    const int r_begin = blockIdx.x * rpb;
+    const int r_end = (r_begin + rpb < M) ? r_begin + rpb : M;
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+    if (rr < RP) {
+        const float4 mu = *reinterpret_cast<const float4*>(mean + q * 4);
+        const float4 is = *reinterpret_cast<const float4*>(inv_std + q * 4);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4);
+        const float4 be = *reinterpret_cast<const float4*>(beta + q * 4);
+        for (int r = r_begin + rr; r < r_end; r += RP) {
+            size_t o = (size_t)r * C + q * 4;
+            float4 x = *reinterpret_cast<const float4*>(X + o);
+            float4 g = *reinterpret_cast<const float4*>(dA + o);
+            float dx = x.x - mu.x, dy = x.y - mu.y, dz = x.z - mu.z, dw = x.w - mu.w;
+            if (relu) {
+                if (dx * sc.x + be.x < 0.0f) g.x = 0.0f;
+                if (dy * sc.y + be.y < 0.0f) g.y = 0.0f;
+                if (dz * sc.z + be.z < 0.0f) g.z = 0.0f;
+                if (dw * sc.w + be.w < 0.0f) g.w = 0.0f;
+            }
+            *reinterpret_cast<float4*>(G + o) = g;
+            sa.x += g.x; sa.y += g.y; sa.z += g.z; sa.w += g.w;
+            sb.x += g.x * (dx * is.x); sb.y += g.y * (dy * is.y); sb.z += g.z * (dz * is.z); sb.w += g.w * (dw * is.w);
+        }
+    }
+    s_a[tid * 4 + 0] = sa.x; s_a[tid * 4 + 1] = sa.y; s_a[tid * 4 + 2] = sa.z; s_a[tid * 4 + 3] = sa.w;
+    s_b[tid * 4 + 0] = sb.x; s_b[tid * 4 + 1] = sb.y; s_b[tid * 4 + 2] = sb.z; s_b[tid * 4 + 3] = sb.w;
+    __syncthreads();
+    for (int c = tid; c < C; c += DPP_THREADS) {
+        int cq = c >> 2, ce = c & 3;
+        double a = 0.0, b = 0.0;
+        for (int j = 0; j < RP; ++j) {
+            int t = j * Q + cq;
+            a += (double)s_a[t * 4 + ce];
+            b += (double)s_b[t * 4 + ce];
+        }
+        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = (float)a;
+        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = (float)b;
+    }
+}
+
+__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int M, int C,
+                                                                      float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                                      float* __restrict__ c1, float* __restrict__ c2) {
+    int c = blockIdx.x * DPP_THREADS + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        a += (double)partial[((size_t)k * 2 + 0) * C + c];
+        b += (double)partial[((size_t)k * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)a;
+    dgamma[c] = (float)b;
+    c1[c] = (float)(a / (double)M);
+    c2[c] = (float)(b / (double)M);
+}
+
+// dX = scale * (G - c1 - xhat * c2) (+ add): gradient through the batch statistics.
+__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ X,
+                                                                   size_t n4, int C, const float* __restrict__ mean,
+                                                                   const float* __restrict__ inv_std, const float* __restrict__ scale,
+                                                                   const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                   const float* add, float* dX) {
+    const int Q = C >> 2;
+    for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * DPP_THREADS) {
+        int q = (int)(i % Q);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + q * 4);
+        const float4 is = *reinterpret_cast<const float4*>(inv_std + q * 4);
+        const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4);
+        const float4 a1 = *reinterpret_cast<const float4*>(c1 + q * 4);
+        const float4 a2 = *reinterpret_cast<const float4*>(c2 + q * 4);
+        float4 g = reinterpret_cast<const float4*>(G)[i];
+        float4 x = reinterpret_cast<const float4*>(X)[i];
+        float4 o;
+        o.x = sc.x * (g.x - a1.x - (x.x - mu.x) * is.x * a2.x);
+        o.y = sc.y * (g.y - a1.y - (x.y - mu.y) * is.y * a2.y);
+        o.z = sc.z * (g.z - a1.z - (x.z - mu.z) * is.z * a2.z);
+        o.w = sc.w * (g.w - a1.w - (x.w - mu.w) * is.w * a2.w);
+        if (add) {
+            float4 r = reinterpret_cast<const float4*>(add)[i];
+            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        reinterpret_cast<float4*>(dX)[i] = o;
+    }
+}
+
+bool ok_c(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= MAXQ && (DPP_THREADS % (C >> 2) == 0 || (C >> 2) > DPP_THREADS); }
+
+}  // namespace
+
+extern "C" int dpp_bn_stats_partial(const float* X, int M, int C, int rows_per_block, float* partial, dpp_stream_t stream) {
+    if (!X || !partial || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS) return DPP_E_BADARG;
+    int nb = dpp_cdiv(M, rows_per_block);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), X, M, C,
+                       rows_per_block, partial);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_bn_finalize(const float* partial, int nb, int M, int rows_per_block, int C, const float* gamma, float eps,
+                               float* mean, float* inv_std, float* scale, float* run_mean, float* run_inv_std, float alpha,
+                               dpp_stream_t stream) {
+    if (!partial || !gamma || !mean || !inv_std || !scale || nb != dpp_cdiv(M, rows_per_block)) return DPP_E_BADARG;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dpp_cdiv(C, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+                       partial, nb, M, rows_per_block, C, gamma, eps, mean, inv_std, scale, run_mean, run_inv_std, alpha);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, const float* run_inv_std, int C, float* mean,
+                                  float* inv_std, float* scale, dpp_stream_t stream) {
+    if (!gamma || !run_mean || !run_inv_std || !mean || !inv_std || !scale || C < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(dpp_cdiv(C, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+                       gamma, run_mean, run_inv_std, C, mean, inv_std, scale);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, const float* mean, const float* inv_std,
+                                 const float* scale, const float* beta, int relu, float* G, int rows_per_block, float* partial,
+                                 dpp_stream_t stream) {
+    if (!dA || !X || !G || !partial || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS) return DPP_E_BADARG;
+    int nb = dpp_cdiv(M, rows_per_block);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dA, X, M, C, mean,
+                       inv_std, scale, beta, relu, G, rows_per_block, partial);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int M, int C, float* dbeta, float* dgamma, float* c1, float* c2,
+                                   dpp_stream_t stream) {
+    if (!partial || !dbeta || !dgamma || !c1 || !c2 || nb < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dpp_cdiv(C, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+                       partial, nb, M, C, dbeta, dgamma, c1, c2);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
+                                const float* scale, const float* c1, const float* c2, const float* add, float* dX,
+                                dpp_stream_t stream) {
+    if (!G || !X || !dX || M < 1 || !ok_c(C)) return DPP_E_BADARG;
+    size_t n4 = (size_t)M * (C >> 2);
+    int blocks = (int)((n4 + DPP_THREADS - 1) / DPP_THREADS);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), G, X, n4, C, mean,
+                       inv_std, scale, c1, c2, add, dX);
+    return dpp_launch_status();
+}

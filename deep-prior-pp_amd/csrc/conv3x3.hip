@@ -1,0 +1,337 @@
+// conv3x3.hip -- 3x3 'half' stride-1 ConvLayer on NHWC maps for gfx950: implicit GEMM on f32 MFMA.
+//
+// Reference arithmetic: conv2d(border_mode='half') + bias, /root/reference/src/net/convlayer.py:230-240 (the
+// bottleneck 3x3 of res_block, /root/reference/src/net/resnet.py:365-368, 394-397), its data gradient and its
+// filter gradient (T.grad, /root/reference/src/trainer/poseregnettrainer.py:110-111).
+//
+// Forward / data gradient (conv3x3_kernel): a workgroup owns IMG x TH x TW output pixels (BM = 64 or 128
+// rows).  The input halo (TH+2)x(TW+2) is staged ONCE into LDS with the BatchNorm+ReLU prologue applied (zero
+// padding is applied AFTER the activation, as conv2d pads its already-activated input); the 9 taps then read
+// shifted rows of that tile, so every input element is fetched from HBM/L2 once per workgroup instead of 9x.
+// Per tap the [BN][Cin] weight slice is staged, and each wave issues v_mfma_f32_16x16x4_f32 with one
+// ds_read_b128 per operand per 4 k-steps (lane (i,kq) owns channels 16*chunk + 4*kq + t).
+// The data gradient is the same kernel run on dY with the mirrored/transposed weights produced by
+// conv3x3_wtrans_kernel.
+//
+// Filter gradient (conv3x3_wgrad_kernel): same halo tile + the dY tile in LDS; the reduction runs over the
+// tile's pixels, out tile = [Cout][Cin] per tap, (tap, 16x16 tile) pairs are dealt round-robin to the 4
+// waves; per-workgroup partials are summed by dpp_reduce_partials in a fixed order.
+#include "dpp_common.h"
+
+namespace {
+
+struct Conv3Args {
+    const float* X;       // [N][H][W][Ci]
+    int N, H, W, Ci, Co;
+    dpp_act act;
+    const float* Wk;      // [Co][9][Ci]
+    const float* bias;    // [Co] or null
+    const float* residual;
+    float* Y;             // [N][H][W][Co]
+    int lth, ltw;         // log2 of tile height / width
+    int img;              // images per workgroup
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ void tile_origin(const Conv3Args& a, int bid, int& n0, int& y0, int& x0) {
+    int bx = bid % a.tiles_x;
+    int t = bid / a.tiles_x;
+    int by = t % a.tiles_y;
+    int bn = t / a.tiles_y;
+    n0 = bn * a.img;
+    y0 = by << a.lth;
+    x0 = bx << a.ltw;
+}
+
+// Stage the activated input halo of the tile into LDS: Ah[(img*(TH+2)+hy)*(TW+2)+hx][Ci+4].
+__device__ __forceinline__ void stage_halo(const float* __restrict__ X, int N, int H, int W, int Ci, const dpp_act& act, int n0,
+                                           int y0, int x0, int TH, int TW, int IMG, float* Ah, int LDA) {
+    const int q = Ci >> 2;
+    const int HW2 = (TH + 2) * (TW + 2);
+    const int total = IMG * HW2 * q;
+    for (int s = threadIdx.x; s < total; s += DPP_THREADS) {
+        int hp = s / q, c4 = s - hp * q;
+        int im = hp / HW2, rem = hp - im * HW2;
+        int hy = rem / (TW + 2), hx = rem - hy * (TW + 2);
+        int n = n0 + im, y = y0 + hy - 1, x = x0 + hx - 1;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N && y >= 0 && y < H && x >= 0 && x < W) {
+            v = *reinterpret_cast<const float4*>(X + (((size_t)n * H + y) * W + x) * Ci + c4 * 4);
+            if (act.mode) v = dpp_act4(v, act, c4 * 4);
+        }
+        *reinterpret_cast<float4*>(&Ah[hp * LDA + c4 * 4]) = v;
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
+    HIP_DYNAMIC_SHARED(float4, smem4)
+    float* smem = reinterpret_cast<float*>(smem4);
+    constexpr int RM = BM / 64;
+    constexpr int CN = BN / 16;
+    const int TH = 1 << a.lth, TW = 1 << a.ltw;
+    const int Ci = a.Ci, LDA = Ci + 4;
+    const int HP = a.img * (TH + 2) * (TW + 2);
+    float* Ah = smem;
+    float* Bs = smem + HP * LDA;                 // [BN][Ci+4]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    int n0, y0, x0;
+    tile_origin(a, blockIdx.x, n0, y0, x0);
+    const int col0 = blockIdx.y * BN;
+
+    stage_halo(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA);
+
+    // halo index of this lane's A rows (centre tap)
+    int hbase[RM];
+#pragma unroll
+    for (int rt = 0; rt < RM; ++rt) {
+        int row = wave * (BM / 4) + rt * 16 + l15;
+        int im = row >> (a.lth + a.ltw);
+        int ty = (row >> a.ltw) & (TH - 1);
+        int tx = row & (TW - 1);
+        hbase[rt] = (im * (TH + 2) + ty + 1) * (TW + 2) + tx + 1;
+    }
+
+    f32x4 acc[RM][CN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int q = Ci >> 2;
+    for (int tap = 0; tap < 9; ++tap) {
+        // stage the weight slice of this tap: Bs[j][c] = Wk[col0+j][tap][c]
+        for (int s = tid; s < BN * q; s += DPP_THREADS) {
+            int j = s / q, c4 = s - j * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col0 + j < a.Co) v = *reinterpret_cast<const float4*>(a.Wk + ((size_t)(col0 + j) * 9 + tap) * Ci + c4 * 4);
+            *reinterpret_cast<float4*>(&Bs[j * LDA + c4 * 4]) = v;
+        }
+        __syncthreads();            // also orders the halo staging before the first tap
+        const int toff = (tap / 3 - 1) * (TW + 2) + (tap % 3 - 1);
+        for (int kc = 0; kc < Ci; kc += 16) {
+            float4 av[RM], bv[CN];
+#pragma unroll
+            for (int rt = 0; rt < RM; ++rt)
+                av[rt] = *reinterpret_cast<const float4*>(&Ah[(hbase[rt] + toff) * LDA + kc + kq * 4]);
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct)
+                bv[ct] = *reinterpret_cast<const float4*>(&Bs[(ct * 16 + l15) * LDA + kc + kq * 4]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CN; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t),
+                                                                           acc[rt][ct], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int rt = 0; rt < RM; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = wave * (BM / 4) + rt * 16 + kq * 4 + r;
+            int im = row >> (a.lth + a.ltw);
+            int ty = (row >> a.ltw) & (TH - 1);
+            int tx = row & (TW - 1);
+            int n = n0 + im, y = y0 + ty, x = x0 + tx;
+            if (im >= a.img || n >= a.N || y >= a.H || x >= a.W) continue;
+            size_t o = (((size_t)n * a.H + y) * a.W + x) * a.Co;
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                int col = col0 + ct * 16 + l15;
+                if (col < a.Co) {
+                    float v = acc[rt][ct][r];
+                    if (a.bias) v += a.bias[col];
+                    if (a.residual) v += a.residual[o + col];
+                    a.Y[o + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// Wd[c][8 - tap][o] = Wk[o][tap][c]: the weights of the data-gradient correlation (mirrored taps, channels swapped)
+__global__ __launch_bounds__(DPP_THREADS) void conv3x3_wtrans_kernel(const float* __restrict__ Wk, int Co, int Ci, float* __restrict__ Wd) {
+    int n = Co * 9 * Ci;
+    for (int i = blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += gridDim.x * DPP_THREADS) {
+        int o = i % Co;
+        int t = (i / Co) % 9;
+        int c = i / (Co * 9);
+        Wd[i] = Wk[((size_t)o * 9 + (8 - t)) * Ci + c];      // i indexes Wd[c][t][o]
+    }
+}
+
+struct Wgrad3Args {
+    const float* X;       // [N][H][W][Ci] forward input of the conv (pre-activation source)
+    int N, H, W, Ci, Co;
+    dpp_act act;
+    const float* dY;      // [N][H][W][Co]
+    float* partial;       // [nblk][Co][9][Ci]
+    int lth, ltw, img, tiles_x, tiles_y;
+    int taps_pb;          // taps per blockIdx.y
+};
+
+template <int BM, int MAXACC>
+__global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a) {
+    HIP_DYNAMIC_SHARED(float4, smem4)
+    float* smem = reinterpret_cast<float*>(smem4);
+    const int TH = 1 << a.lth, TW = 1 << a.ltw;
+    const int Ci = a.Ci, Co = a.Co, LDA = Ci + 4, LDY = Co + 4;
+    const int HP = a.img * (TH + 2) * (TW + 2);
+    float* Ah = smem;                 // [HP][Ci+4]
+    float* Ys = smem + HP * LDA;      // [BM][Co+4]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    Conv3Args ta;                      // reuse tile_origin
+    ta.tiles_x = a.tiles_x; ta.tiles_y = a.tiles_y; ta.img = a.img; ta.lth = a.lth; ta.ltw = a.ltw;
+    int n0, y0, x0;
+    tile_origin(ta, blockIdx.x, n0, y0, x0);
+
+    stage_halo(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA);
+    {   // stage dY rows of the tile (zeros for out-of-range rows)
+        const int q = Co >> 2;
+        for (int s = tid; s < BM * q; s += DPP_THREADS) {
+            int row = s / q, c4 = s - row * q;
+            int im = row >> (a.lth + a.ltw);
+            int ty = (row >> a.ltw) & (TH - 1);
+            int tx = row & (TW - 1);
+            int n = n0 + im, y = y0 + ty, x = x0 + tx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (im < a.img && n < a.N && y < a.H && x < a.W)
+                v = *reinterpret_cast<const float4*>(a.dY + (((size_t)n * a.H + y) * a.W + x) * Co + c4 * 4);
+            *reinterpret_cast<float4*>(&Ys[row * LDY + c4 * 4]) = v;
+        }
+    }
+    __syncthreads();
+
+    const int nto = Co >> 4, ntc = Ci >> 4, NT = nto * ntc;
+    const int tap0 = blockIdx.y * a.taps_pb;
+    const int pairs = a.taps_pb * NT;
+    f32x4 acc[MAXACC];
+#pragma unroll
+    for (int i = 0; i < MAXACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int rc = 0; rc < BM; rc += 16) {
+        // halo index of the 4 reduction rows this lane feeds: r = rc + 4*kq + t
+        int hb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int row = rc + kq * 4 + t;
+            int im = row >> (a.lth + a.ltw);
+            int ty = (row >> a.ltw) & (TH - 1);
+            int tx = row & (TW - 1);
+            hb[t] = (im * (TH + 2) + ty + 1) * (TW + 2) + tx + 1;
+        }
+#pragma unroll
+        for (int i = 0; i < MAXACC; ++i) {
+            int p = wave + 4 * i;
+            if (p < pairs) {
+                int tap = tap0 + p / NT, tile = p % NT;
+                int to = tile / ntc, tc = tile - to * ntc;
+                int toff = (tap / 3 - 1) * (TW + 2) + (tap % 3 - 1);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float av = Ys[(rc + kq * 4 + t) * LDY + to * 16 + l15];
+                    float bv = Ah[(hb[t] + toff) * LDA + tc * 16 + l15];
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    float* out = a.partial + (size_t)blockIdx.x * Co * 9 * Ci;
+#pragma unroll
+    for (int i = 0; i < MAXACC; ++i) {
+        int p = wave + 4 * i;
+        if (p < pairs) {
+            int tap = tap0 + p / NT, tile = p % NT;
+            int to = tile / ntc, tc = tile - to * ntc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int o = to * 16 + kq * 4 + r, c = tc * 16 + l15;
+                out[((size_t)o * 9 + tap) * Ci + c] = acc[i][r];
+            }
+        }
+    }
+}
+
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// tile geometry: TH x TW x IMG = BM output pixels per workgroup
+void pick_tile(int N, int H, int W, int bm, int& lth, int& ltw, int& img) {
+    int tw = 1; while (tw * 2 <= W && tw < 16) tw *= 2;
+    int th = 1; while (th * 2 <= H && th < 8 && th * tw * 2 <= bm) th *= 2;
+    while (th * tw > bm) tw /= 2;
+    img = bm / (th * tw);
+    lth = ilog2(th); ltw = ilog2(tw);
+}
+
+}  // namespace
+
+extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
+                           const float* bias, const float* residual, float* Y, int bm, dpp_stream_t stream) {
+    if (!X || !Wk || !Y || N < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15)) return DPP_E_BADARG;
+    Conv3Args a;
+    a.X = X; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+    if (act) a.act = *act; else { a.act.mode = 0; a.act.cmod = 1; a.act.mean = a.act.scale = a.act.beta = nullptr; }
+    a.Wk = Wk; a.bias = bias; a.residual = residual; a.Y = Y;
+    long pixels = (long)N * H * W;
+    if (bm == 0) bm = (pixels / 128) * dpp_cdiv(Co, 64) >= 512 ? 128 : 64;
+    pick_tile(N, H, W, bm, a.lth, a.ltw, a.img);
+    int TH = 1 << a.lth, TW = 1 << a.ltw;
+    a.tiles_x = dpp_cdiv(W, TW); a.tiles_y = dpp_cdiv(H, TH);
+    int nblk = a.tiles_x * a.tiles_y * dpp_cdiv(N, a.img);
+    int bn = Co >= 64 ? 64 : (Co >= 32 ? 32 : 16);
+    size_t lds = ((size_t)a.img * (TH + 2) * (TW + 2) + bn) * (Ci + 4) * sizeof(float);
+    if (lds > 64 * 1024) return DPP_E_UNSUPPORTED;
+    dim3 grid(nblk, dpp_cdiv(Co, bn));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define DPP_C3(BM_, BN_) if (bm == BM_ && bn == BN_) { hipLaunchKernelGGL((conv3x3_kernel<BM_, BN_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
+    DPP_C3(128, 64) DPP_C3(128, 32) DPP_C3(128, 16) DPP_C3(64, 64) DPP_C3(64, 32) DPP_C3(64, 16)
+#undef DPP_C3
+    return DPP_E_UNSUPPORTED;
+}
+
+extern "C" int dpp_conv3x3_wtrans(const float* Wk, int Co, int Ci, float* Wd, dpp_stream_t stream) {
+    if (!Wk || !Wd || Co < 1 || Ci < 1) return DPP_E_BADARG;
+    int n = Co * 9 * Ci;
+    hipLaunchKernelGGL(conv3x3_wtrans_kernel, dim3(dpp_cdiv(n, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), Wk, Co, Ci, Wd);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int bm) {
+    int lth, ltw, img;
+    if (bm != 64 && bm != 128) return -1;
+    pick_tile(N, H, W, bm, lth, ltw, img);
+    return dpp_cdiv(W, 1 << ltw) * dpp_cdiv(H, 1 << lth) * dpp_cdiv(N, img);
+}
+
+extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
+                                 float* partial, int bm, dpp_stream_t stream) {
+    if (!X || !dY || !partial || N < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15) || (bm != 64 && bm != 128)) return DPP_E_BADARG;
+    Wgrad3Args a;
+    a.X = X; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.dY = dY; a.partial = partial;
+    if (act) a.act = *act; else { a.act.mode = 0; a.act.cmod = 1; a.act.mean = a.act.scale = a.act.beta = nullptr; }
+    pick_tile(N, H, W, bm, a.lth, a.ltw, a.img);
+    int TH = 1 << a.lth, TW = 1 << a.ltw;
+    a.tiles_x = dpp_cdiv(W, TW); a.tiles_y = dpp_cdiv(H, TH);
+    int nblk = a.tiles_x * a.tiles_y * dpp_cdiv(N, a.img);
+    int NT = (Co >> 4) * (Ci >> 4);
+    // (tap, tile) pairs per workgroup <= 4 waves * MAXACC accumulators
+    int taps_pb = NT <= 4 ? 9 : (NT <= 16 ? 3 : 1);
+    int pairs = taps_pb * NT;
+    int maxacc = dpp_cdiv(pairs, 4);
+    a.taps_pb = taps_pb;
+    size_t lds = ((size_t)a.img * (TH + 2) * (TW + 2) * (Ci + 4) + (size_t)bm * (Co + 4)) * sizeof(float);
+    if (lds > 64 * 1024) return DPP_E_UNSUPPORTED;
+    dim3 grid(nblk, 9 / taps_pb);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM_, MA_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
+    DPP_W3(128, 3) DPP_W3(128, 9) DPP_W3(128, 12) DPP_W3(128, 16)
+    DPP_W3(64, 3) DPP_W3(64, 9) DPP_W3(64, 12) DPP_W3(64, 16)
+#undef DPP_W3
+    return DPP_E_UNSUPPORTED;
+}

@@ -1,0 +1,203 @@
+// elementwise.hip -- loss, ADAM, column sums and small helpers for gfx950 (all HBM-bound, float4 lanes).
+#include "dpp_common.h"
+
+namespace {
+
+// ---- column sums: bias gradients db[c] = sum_m dY[m][c] (T.grad of `+ b.dimshuffle`, convlayer.py:238) ----
+__global__ __launch_bounds__(DPP_THREADS) void colsum_partial_kernel(const float* __restrict__ X, int M, int C, int rpb,
+                                                                     float* __restrict__ partial) {
+    __shared__ float s[DPP_THREADS];
+    const int tid = threadIdx.x;
+    const int RP = DPP_THREADS / C > 0 ? DPP_THREADS / C : 1;   // rows per pass when C <= 256
+    const int r_begin = blockIdx.x * rpb;
+    const int r_end = (r_begin + rpb < M) ? r_begin + rpb : M;
+    for (int c0 = 0; c0 < C; c0 += DPP_THREADS) {               // C > 256: several column passes
+        int cw = (C - c0 < DPP_THREADS) ? C - c0 : DPP_THREADS;
+        int rp = DPP_THREADS / cw;
+        int c = tid % cw, rr = tid / cw;
+        float acc = 0.0f;
+        if (rr < rp)
+            for (int r = r_begin + rr; r < r_end; r += rp) acc += X[(size_t)r * C + c0 + c];
+        s[tid] = acc;
+        __syncthreads();
+        if (tid < cw) {
+            double a = 0.0;
+            for (int j = 0; j < rp; ++j) a += (double)s[j * cw + tid];
+            partial[(size_t)blockIdx.x * C + c0 + tid] = (float)a;
+        }
+        __syncthreads();
+    }
+    (void)RP;
+}
+
+// ---- loss: cost = (1/denom) * sum_n sum_d (out - y)^2 ; dout = (2/denom) * (out - y) -----------------------
+// embedding case denom = B, joints case denom = B*J (poseregnettrainer.py:92-99).  One block.
+__global__ __launch_bounds__(DPP_THREADS) void loss_sse_kernel(const float* __restrict__ out, const float* __restrict__ y, int n,
+                                                               float inv_denom, float* __restrict__ cost,
+                                                               float* __restrict__ dout) {
+    __shared__ double s[DPP_THREADS];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += DPP_THREADS) {
+        float d = out[i] - y[i];
+        acc += (double)d * (double)d;
+        if (dout) dout[i] = 2.0f * inv_denom * d;
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = DPP_THREADS / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cost[0] = (float)(s[0] * (double)inv_denom);
+}
+
+// mean_n sqrt(sum_d (out-y)^2): the monitor of poseregnettrainer.py:114-129 (embedding / joints).
+__global__ __launch_bounds__(DPP_THREADS) void error_l2_kernel(const float* __restrict__ out, const float* __restrict__ y, int rows,
+                                                               int d, float* __restrict__ err) {
+    __shared__ double s[DPP_THREADS];
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < rows; r += DPP_THREADS) {
+        double q = 0.0;
+        for (int j = 0; j < d; ++j) {
+            double e = (double)out[r * d + j] - (double)y[r * d + j];
+            q += e * e;
+        }
+        acc += sqrt(q);
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = DPP_THREADS / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) err[0] = (float)(s[0] / (double)rows);
+}
+
+// ---- ADAM (optimizer.py:58-90), one launch over the flat parameter buffer -------------------------------
+// hyper (device, 8 floats): lr, beta1_t, 1-beta1_t, beta2, 1-beta2, 1-beta1^t, 1-beta2^t, epsilon
+__global__ __launch_bounds__(DPP_THREADS) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, size_t n, const float* __restrict__ hyper) {
+    const float lr = hyper[0], b1 = hyper[1], ob1 = hyper[2], b2 = hyper[3], ob2 = hyper[4], c1 = hyper[5], c2 = hyper[6],
+                eps = hyper[7];
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * DPP_THREADS) {
+        float4 W = reinterpret_cast<float4*>(w)[i], G = reinterpret_cast<const float4*>(g)[i];
+        float4 Mv = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+#define DPP_ADAM1(f)                                            \
+        Mv.f = b1 * Mv.f + ob1 * G.f;                           \
+        V.f = b2 * V.f + ob2 * (G.f * G.f);                     \
+        W.f = W.f - (lr * (Mv.f / c1)) / (sqrtf(V.f / c2) + eps);
+        DPP_ADAM1(x) DPP_ADAM1(y) DPP_ADAM1(z) DPP_ADAM1(w)
+        reinterpret_cast<float4*>(w)[i] = W;
+        reinterpret_cast<float4*>(m)[i] = Mv;
+        reinterpret_cast<float4*>(v)[i] = V;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        size_t i = (n4 << 2) + threadIdx.x;
+        float mm = b1 * m[i] + ob1 * g[i];
+        float vv = b2 * v[i] + ob2 * (g[i] * g[i]);
+        w[i] = w[i] - (lr * (mm / c1)) / (sqrtf(vv / c2) + eps);
+        m[i] = mm;
+        v[i] = vv;
+    }
+#undef DPP_ADAM1
+}
+
+// y[i] += alpha * x[i]   (L2 weight-decay gradient 2*wd*W, poseregnettrainer.py:101-107)
+__global__ __launch_bounds__(DPP_THREADS) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DPP_THREADS) y[i] += alpha * x[i];
+}
+
+// out[0] (+)= alpha * sum x^2 -- single block, deterministic (the wd * sum(W^2) term of the cost)
+__global__ __launch_bounds__(DPP_THREADS) void sumsq_kernel(const float* __restrict__ x, size_t n, float alpha, float* out, int accumulate) {
+    __shared__ double s[DPP_THREADS];
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += DPP_THREADS) acc += (double)x[i] * (double)x[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = DPP_THREADS / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0f) + (float)(s[0] * (double)alpha);
+}
+
+// y = a * x  elementwise with optional relu first: the deterministic DropoutLayer (prob_keep * x,
+// dropoutlayer.py:104) applied to relu(pre) ; mask variant: y = mask * relu?(x)
+__global__ __launch_bounds__(DPP_THREADS) void scale_kernel(const float* __restrict__ x, const float* __restrict__ mask, float a, int relu,
+                                                            float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DPP_THREADS) {
+        float v = x[i];
+        if (relu) v = fmaxf(v, 0.0f);
+        y[i] = mask ? mask[i] * v : a * v;
+    }
+}
+
+// g = dy * [pre >= 0]  (ReLU backward on a stored pre-activation), optional extra factor (dropout mask or keep prob)
+__global__ __launch_bounds__(DPP_THREADS) void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre,
+                                                               const float* __restrict__ mask, float a, float* __restrict__ g, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DPP_THREADS) {
+        float v = dy[i] * (mask ? mask[i] : a);
+        g[i] = (pre[i] >= 0.0f) ? v : 0.0f;
+    }
+}
+
+int grid_for(size_t n) {
+    size_t b = (n + DPP_THREADS - 1) / DPP_THREADS;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int dpp_colsum_partial(const float* X, int M, int C, int rows_per_block, float* partial, dpp_stream_t stream) {
+    if (!X || !partial || M < 1 || C < 1 || rows_per_block < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+                       X, M, C, rows_per_block, partial);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_loss_sse(const float* out, const float* y, int rows, int d, int denom, float* cost, float* dout,
+                            dpp_stream_t stream) {
+    if (!out || !y || !cost || rows < 1 || d < 1 || denom < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(loss_sse_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), out, y, rows * d,
+                       1.0f / (float)denom, cost, dout);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_error_l2(const float* out, const float* y, int rows, int d, float* err, dpp_stream_t stream) {
+    if (!out || !y || !err || rows < 1 || d < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(error_l2_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), out, y, rows, d, err);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_adam(float* w, const float* g, float* m, float* v, size_t n, const float* hyper, dpp_stream_t stream) {
+    if (!w || !g || !m || !v || !hyper || n < 1) return DPP_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
+        return DPP_E_BADARG;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n >> 2)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), w, g, m, v, n, hyper);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_axpy(float* y, const float* x, float alpha, size_t n, dpp_stream_t stream) {
+    if (!y || !x || n < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), y, x, alpha, n);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_sumsq(const float* x, size_t n, float alpha, float* out, int accumulate, dpp_stream_t stream) {
+    if (!x || !out || n < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), x, n, alpha, out, accumulate);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_scale(const float* x, const float* mask, float a, int relu, float* y, size_t n, dpp_stream_t stream) {
+    if (!x || !y || n < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), x, mask, a, relu, y, n);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_relu_bwd(const float* dy, const float* pre, const float* mask, float a, float* g, size_t n, dpp_stream_t stream) {
+    if (!dy || !pre || !g || n < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dy, pre, mask, a, g, n);
+    return dpp_launch_status();
+}

@@ -53,6 +53,42 @@ SIGNATURES = {
     'dpp_abi_version': (C.c_int, []),
     'dpp_gemm': (C.c_int, [C.POINTER(GemmDesc), stream_t]),
     'dpp_reduce_partials': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
+    'dpp_conv3x3': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, stream_t]),
+    'dpp_conv3x3_wtrans': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_conv3x3_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'dpp_conv3x3_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_int, stream_t]),
+    'dpp_stem_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                               C.c_void_p, stream_t]),
+    'dpp_stem_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'dpp_stem_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_int, stream_t]),
+    'dpp_bn_stats_partial': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_bn_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, stream_t]),
+    'dpp_bn_eval_coeffs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     stream_t]),
+    'dpp_bn_bwd_reduce': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
+    'dpp_bn_bwd_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, stream_t]),
+    'dpp_bn_bwd_apply': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
+    'dpp_colsum_partial': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_loss_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, stream_t]),
+    'dpp_error_l2': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, stream_t]),
+    'dpp_axpy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_size_t, stream_t]),
+    'dpp_sumsq': (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_int, stream_t]),
+    'dpp_scale': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_size_t, stream_t]),
+    'dpp_relu_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, stream_t]),
+    'dpp_augment_record_bytes': (C.c_size_t, []),
+    'dpp_augment_prepare': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 5 + [C.c_int, C.c_ulonglong,
+                                      C.c_ulonglong, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, stream_t]),
+    'dpp_augment_warp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
 }
 
 

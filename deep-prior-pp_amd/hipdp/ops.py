@@ -76,3 +76,108 @@ def gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, mapA=None, mapB=N
 def reduce_partials(rt, partial, nz, n, out, bias=None, nbias=1, name='reduce_partials'):
     return Launch(rt.lib.dpp_reduce_partials, (partial.ptr, int(nz), int(n), _p(bias), int(nbias), out.ptr),
                   (partial, out, bias), name)
+
+
+def _actp(a):
+    return C.byref(a) if a is not None else None
+
+
+def conv3x3(rt, X, N, H, W, Ci, Wk, Co, Y, actX=None, bias=None, residual=None, bm=0, name='conv3x3'):
+    return Launch(rt.lib.dpp_conv3x3, (X.ptr, N, H, W, Ci, _actp(actX), Wk.ptr, Co, _p(bias), _p(residual), Y.ptr, bm),
+                  (X, Wk, Y, actX, bias, residual), name)
+
+
+def conv3x3_wtrans(rt, Wk, Co, Ci, Wd, name='conv3x3_wtrans'):
+    return Launch(rt.lib.dpp_conv3x3_wtrans, (Wk.ptr, Co, Ci, Wd.ptr), (Wk, Wd), name)
+
+
+def conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, partial, actX=None, bm=64, name='conv3x3_wgrad'):
+    return Launch(rt.lib.dpp_conv3x3_wgrad, (X.ptr, N, H, W, Ci, _actp(actX), dY.ptr, Co, partial.ptr, bm),
+                  (X, dY, partial, actX), name)
+
+
+def stem_fwd(rt, X, N, H, W, Wk, bias, Co, Y, argmax, name='stem_fwd'):
+    return Launch(rt.lib.dpp_stem_fwd, (X.ptr, N, H, W, Wk.ptr, bias.ptr, Co, Y.ptr, _p(argmax)), (X, Wk, bias, Y, argmax), name)
+
+
+def stem_wgrad(rt, X, N, H, W, dY, argmax, Co, partial, tiles_per_block, name='stem_wgrad'):
+    return Launch(rt.lib.dpp_stem_wgrad, (X.ptr, N, H, W, dY.ptr, argmax.ptr, Co, partial.ptr, tiles_per_block),
+                  (X, dY, argmax, partial), name)
+
+
+def bn_stats_partial(rt, X, M, Cc, rpb, partial, name='bn_stats_partial'):
+    return Launch(rt.lib.dpp_bn_stats_partial, (X.ptr, M, Cc, rpb, partial.ptr), (X, partial), name)
+
+
+def bn_finalize(rt, partial, nb, M, rpb, Cc, gamma, eps, mean, inv_std, scale, run_mean=None, run_inv_std=None, alpha=0.0,
+                name='bn_finalize'):
+    return Launch(rt.lib.dpp_bn_finalize, (partial.ptr, nb, M, rpb, Cc, gamma.ptr, float(eps), mean.ptr, inv_std.ptr, scale.ptr,
+                                           _p(run_mean), _p(run_inv_std), float(alpha)),
+                  (partial, gamma, mean, inv_std, scale, run_mean, run_inv_std), name)
+
+
+def bn_eval_coeffs(rt, gamma, run_mean, run_inv_std, Cc, mean, inv_std, scale, name='bn_eval_coeffs'):
+    return Launch(rt.lib.dpp_bn_eval_coeffs, (gamma.ptr, run_mean.ptr, run_inv_std.ptr, Cc, mean.ptr, inv_std.ptr, scale.ptr),
+                  (gamma, run_mean, run_inv_std, mean, inv_std, scale), name)
+
+
+def bn_bwd_reduce(rt, dA, X, M, Cc, mean, inv_std, scale, beta, relu, G, rpb, partial, name='bn_bwd_reduce'):
+    return Launch(rt.lib.dpp_bn_bwd_reduce, (dA.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, beta.ptr, int(relu), G.ptr, rpb,
+                                             partial.ptr), (dA, X, mean, inv_std, scale, beta, G, partial), name)
+
+
+def bn_bwd_finalize(rt, partial, nb, M, Cc, dbeta, dgamma, c1, c2, name='bn_bwd_finalize'):
+    return Launch(rt.lib.dpp_bn_bwd_finalize, (partial.ptr, nb, M, Cc, dbeta.ptr, dgamma.ptr, c1.ptr, c2.ptr),
+                  (partial, dbeta, dgamma, c1, c2), name)
+
+
+def bn_bwd_apply(rt, G, X, M, Cc, mean, inv_std, scale, c1, c2, dX, add=None, name='bn_bwd_apply'):
+    return Launch(rt.lib.dpp_bn_bwd_apply, (G.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, c1.ptr, c2.ptr, _p(add), dX.ptr),
+                  (G, X, mean, inv_std, scale, c1, c2, add, dX), name)
+
+
+def colsum_partial(rt, X, M, Cc, rpb, partial, name='colsum_partial'):
+    return Launch(rt.lib.dpp_colsum_partial, (X.ptr, M, Cc, rpb, partial.ptr), (X, partial), name)
+
+
+def loss_sse(rt, out, y, rows, d, denom, cost, dout=None, name='loss_sse'):
+    return Launch(rt.lib.dpp_loss_sse, (out.ptr, y.ptr, rows, d, denom, cost.ptr, _p(dout)), (out, y, cost, dout), name)
+
+
+def error_l2(rt, out, y, rows, d, err, name='error_l2'):
+    return Launch(rt.lib.dpp_error_l2, (out.ptr, y.ptr, rows, d, err.ptr), (out, y, err), name)
+
+
+def adam(rt, w, g, m, v, n, hyper, name='adam'):
+    return Launch(rt.lib.dpp_adam, (w.ptr, g.ptr, m.ptr, v.ptr, n, hyper.ptr), (w, g, m, v, hyper), name)
+
+
+def axpy(rt, y, x, alpha, n, name='axpy'):
+    return Launch(rt.lib.dpp_axpy, (y.ptr, x.ptr, float(alpha), n), (y, x), name)
+
+
+def sumsq(rt, x, n, alpha, out, accumulate, name='sumsq'):
+    return Launch(rt.lib.dpp_sumsq, (x.ptr, n, float(alpha), out.ptr, int(accumulate)), (x, out), name)
+
+
+def scale(rt, x, y, n, a=1.0, relu=False, mask=None, name='scale'):
+    return Launch(rt.lib.dpp_scale, (x.ptr, _p(mask), float(a), int(relu), y.ptr, n), (x, y, mask), name)
+
+
+def relu_bwd(rt, dy, pre, g, n, a=1.0, mask=None, name='relu_bwd'):
+    return Launch(rt.lib.dpp_relu_bwd, (dy.ptr, pre.ptr, _p(mask), float(a), g.ptr, n), (dy, pre, g, mask), name)
+
+
+def augment_prepare(rt, img, com3d, cube, Mcrop, gt3d, B, J, dsz, cam, records, out_y, mode=None, off=None, rot=None, sc=None,
+                    mode_table=None, n_modes=0, seed=0, counter=0, sigma_com=5., sigma_sc=0.02, rot_range=180.,
+                    pca_mean=None, pca_comp=None, E=0, out_mode=None, name='augment_prepare'):
+    fx, fy, ux, uy, flip = cam
+    return Launch(rt.lib.dpp_augment_prepare,
+                  (img.ptr, com3d.ptr, cube.ptr, Mcrop.ptr, gt3d.ptr, B, J, dsz, _p(mode), _p(off), _p(rot), _p(sc), _p(mode_table),
+                   n_modes, seed, counter, float(sigma_com), float(sigma_sc), float(rot_range), float(fx), float(fy), float(ux),
+                   float(uy), int(flip), _p(pca_mean), _p(pca_comp), E, records.ptr, out_y.ptr, _p(out_mode)),
+                  (img, com3d, cube, Mcrop, gt3d, mode, off, rot, sc, mode_table, pca_mean, pca_comp, records, out_y, out_mode), name)
+
+
+def augment_warp(rt, img, records, B, dsz, out, name='augment_warp'):
+    return Launch(rt.lib.dpp_augment_warp, (img.ptr, records.ptr, B, dsz, out.ptr), (img, records, out), name)

@@ -85,6 +85,90 @@ int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);
 int dpp_reduce_partials(const float* partial, int nz, int n, const float* bias, int nbias, float* out,
                         dpp_stream_t stream);
 
+
+/* ---- 3x3 'half' stride-1 ConvLayer on NHWC maps (implicit GEMM, halo tile in LDS) --------------------------
+ * Y[n,y,x,o] = sum_{tap,c} act(X)[n, y+dy, x+dx, c] * Wk[o][tap][c] + bias[o] + residual[n,y,x,o], zero padding applied
+ * after `act`.  conv2d 3x3 of res_block, /root/reference/src/net/resnet.py:365-368,394-397 via
+ * /root/reference/src/net/convlayer.py:230-240.  The data gradient is the same call on dY with the weights from
+ * dpp_conv3x3_wtrans.  bm = 64 | 128 rows per workgroup (0 = choose).  Ci, Co multiples of 16. */
+int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
+                const float* bias, const float* residual, float* Y, int bm, dpp_stream_t stream);
+/* Wd[c][8-tap][o] = Wk[o][tap][c] (mirrored taps, channels swapped): weights of the data-gradient correlation. */
+int dpp_conv3x3_wtrans(const float* Wk, int Co, int Ci, float* Wd, dpp_stream_t stream);
+/* Filter gradient partials: partial[blk][o][tap][c] = sum over the workgroup's pixels of dY[.,o] * act(X)[.+tap, c];
+ * blk < dpp_conv3x3_wgrad_blocks(N,H,W,bm); sum over blk with dpp_reduce_partials.  (T.grad, poseregnettrainer.py:110-111) */
+int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int bm);
+int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
+                      float* partial, int bm, dpp_stream_t stream);
+
+/* ---- ResNet stem: ConvPoolLayer 5x5 'half' 1 -> Co (<= 32), 2x2 max-pool, bias AFTER the pool ----------------
+ * /root/reference/src/net/convpoollayer.py:251-282 as built at /root/reference/src/net/resnet.py:128-133.
+ * X: [N][H][W] single-channel crops (NCHW == NHWC); Wk: [Co][25]; Y: [N][H/2][W/2][Co]; argmax: first maximum of
+ * each 2x2 window in row-major scan order (0..3), kept for the filter gradient. */
+int dpp_stem_fwd(const float* X, int N, int H, int W, const float* Wk, const float* bias, int Co, float* Y, uint8_t* argmax,
+                 dpp_stream_t stream);
+int dpp_stem_wgrad_blocks(int N, int H, int W, int tiles_per_block);
+int dpp_stem_wgrad(const float* X, int N, int H, int W, const float* dY, const uint8_t* argmax, int Co, float* partial,
+                   int tiles_per_block, dpp_stream_t stream);
+
+/* ---- BatchNormLayer, /root/reference/src/net/batchnormlayer.py:119-194 (tensors pixel-major [M][C], C % 4 == 0) ----
+ * stats_partial: per row-chunk (mean_b, M2_b) -> partial[nb][2][C], nb = ceil(M / rows_per_block)
+ * finalize:      batch mean, inv_std = 1/sqrt(var_biased + eps), scale = gamma*inv_std; running mean / inv_std EMA
+ *                (alpha = 0 or run_mean == NULL: no update)
+ * eval_coeffs:   deterministic mode: mean = run_mean, inv_std = run_inv_std, scale = gamma*run_inv_std
+ * bwd_reduce:    G = dA * [ (x-mean)*scale+beta >= 0 ] (relu != 0) or dA; partial[nb][2][C] = sum G, sum G*xhat
+ * bwd_finalize:  dbeta, dgamma and c1 = dbeta/M, c2 = dgamma/M
+ * bwd_apply:     dX = scale * (G - c1 - xhat*c2) + add      (gradient through the batch statistics) */
+int dpp_bn_stats_partial(const float* X, int M, int C, int rows_per_block, float* partial, dpp_stream_t stream);
+int dpp_bn_finalize(const float* partial, int nb, int M, int rows_per_block, int C, const float* gamma, float eps,
+                    float* mean, float* inv_std, float* scale, float* run_mean, float* run_inv_std, float alpha,
+                    dpp_stream_t stream);
+int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, const float* run_inv_std, int C, float* mean,
+                       float* inv_std, float* scale, dpp_stream_t stream);
+int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, const float* mean, const float* inv_std,
+                      const float* scale, const float* beta, int relu, float* G, int rows_per_block, float* partial,
+                      dpp_stream_t stream);
+int dpp_bn_bwd_finalize(const float* partial, int nb, int M, int C, float* dbeta, float* dgamma, float* c1, float* c2,
+                        dpp_stream_t stream);
+int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
+                     const float* scale, const float* c1, const float* c2, const float* add, float* dX,
+                     dpp_stream_t stream);
+
+/* ---- loss / optimiser / small elementwise ------------------------------------------------------------------ */
+/* partial[b][c] = sum of rows of chunk b (bias gradients; reduce with dpp_reduce_partials) */
+int dpp_colsum_partial(const float* X, int M, int C, int rows_per_block, float* partial, dpp_stream_t stream);
+/* cost = (1/denom) sum (out-y)^2, dout = (2/denom)(out-y): /root/reference/src/trainer/poseregnettrainer.py:92-99
+ * (denom = batch for the embedding loss, batch*numJoints for the joint loss); dout may be NULL */
+int dpp_loss_sse(const float* out, const float* y, int rows, int d, int denom, float* cost, float* dout, dpp_stream_t stream);
+/* err = mean_rows sqrt(sum_d (out-y)^2): poseregnettrainer.py:114-129 */
+int dpp_error_l2(const float* out, const float* y, int rows, int d, float* err, dpp_stream_t stream);
+/* The reference's ADAM (/root/reference/src/trainer/optimizer.py:58-90) over a flat parameter buffer.
+ * hyper (device, 8 floats): lr, beta1_t, 1-beta1_t, beta2, 1-beta2, 1-beta1^t, 1-beta2^t, epsilon */
+int dpp_adam(float* w, const float* g, float* m, float* v, size_t n, const float* hyper, dpp_stream_t stream);
+int dpp_axpy(float* y, const float* x, float alpha, size_t n, dpp_stream_t stream);              /* y += alpha x */
+int dpp_sumsq(const float* x, size_t n, float alpha, float* out, int accumulate, dpp_stream_t stream);
+/* y = mask ? mask*relu?(x) : a*relu?(x): DropoutLayer, /root/reference/src/net/dropoutlayer.py:98-104 */
+int dpp_scale(const float* x, const float* mask, float a, int relu, float* y, size_t n, dpp_stream_t stream);
+/* g = (mask ? mask : a) * dy * [pre >= 0] */
+int dpp_relu_bwd(const float* dy, const float* pre, const float* mask, float a, float* g, size_t n, dpp_stream_t stream);
+
+/* ---- online crop augmentation, NetTrainer.augmentCrop (/root/reference/src/trainer/nettrainer.py:919-997) -------
+ * prepare: per crop, the geometry of HandDetector.moveCoM / rotateHand / scaleHand
+ *          (/root/reference/src/util/handdetector.py:678-780): new CoM, crop transform, inverse warp matrix,
+ *          z-thresholds, augmented joint labels, PCA-prior projection (poseregnettrainer.py:262) -> records, out_y.
+ *          mode codes: 0 none, 1 com, 2 rot, 3 sc.  mode == NULL: (mode, off, rot, sc) are drawn on the device from
+ *          Philox(seed, counter, sample) with mode = mode_table[u % n_modes].
+ * warp:    per pixel, cv2.warpAffine / warpPerspective (NEAREST, constant 0) + recropHand's z-clamp
+ *          (handdetector.py:782-803) + the far-plane fill / clamp / re-normalisation of nettrainer.py:982-995. */
+size_t dpp_augment_record_bytes(void);
+int dpp_augment_prepare(const float* img, const float* com3d, const float* cube, const float* Mcrop, const float* gt3d,
+                        int B, int J, int dsz, const int* mode, const double* off, const double* rot, const double* sc,
+                        const int* mode_table, int n_modes, unsigned long long seed, unsigned long long counter,
+                        double sigma_com, double sigma_sc, double rot_range, double fx, double fy, double ux, double uy,
+                        int flip_y, const float* pca_mean, const float* pca_comp, int E, void* records, float* out_y,
+                        int* out_mode, dpp_stream_t stream);
+int dpp_augment_warp(const float* img, const void* records, int B, int dsz, float* out, dpp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

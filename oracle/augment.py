@@ -24,6 +24,10 @@ vectors).  `warp_affine_nn` / `warp_perspective_nn` restate OpenCV 2.4's imgwarp
 Bit-exactness versus real cv2 is claimed only for pixels whose source coordinate is at least
 2^-9 away from a rounding boundary.
 
+`numpy.linalg.inv(M)` (LAPACK, on the float32 M of the reference: handdetector.py:701,772) is restated with
+the same f64 cofactor inverse as cv::invert, and 3x3 products are written out in plain IEEE double, so that the
+HIP kernel (compiled with -ffp-contract=off) can reproduce this oracle bit for bit.
+
 Python-2 integer division in com_to_transform (handdetector.py:246,249) is kept with `//`.
 NumPy-1.x scalar semantics are kept: float32 scalar (op) python float evaluates in float64 and
 is rounded to float32 only when stored into the float32 result array.
@@ -130,10 +134,11 @@ def com_to_transform(com, size, fx, fy, dsize=(128, 128)):
     scale[2, 2] = 1
     xs = int(np.floor(dsize[0] / 2. - sz[1] / 2.))    # the x/y swap of handdetector.py:252-253 is kept
     ys = int(np.floor(dsize[1] / 2. - sz[0] / 2.))
-    off = np.eye(3)
-    off[0, 2] = xs
-    off[1, 2] = ys
-    return np.dot(off, np.dot(scale, trans))
+    # off . (scale . trans) written out (plain IEEE double products/sums, no BLAS fused multiply-adds)
+    sc = float(scale[0, 0])
+    return np.array([[sc, 0., sc * float(-xstart) + float(xs)],
+                     [0., sc, sc * float(-ystart) + float(ys)],
+                     [0., 0., 1.]], dtype=np.float64)
 
 
 # --------------------------------------------------------------------------- cv2 restatements
@@ -214,6 +219,20 @@ def invert_3x3(M):
     return t.reshape(3, 3)
 
 
+def mat3_mul(A, B):
+    """3x3 product with python-float arithmetic in k = 0,1,2 order (one rounding per operation)."""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64)
+    C = np.zeros((3, 3))
+    for i in range(3):
+        for j in range(3):
+            acc = 0.0
+            for k in range(3):
+                acc = acc + float(A[i, k]) * float(B[k, j])
+            C[i, j] = acc
+    return C
+
+
 WP_BLOCK_W = 64     # bw0 for a 128-wide image with BLOCK_SZ = 32 (imgwarp.cpp warpPerspective)
 
 
@@ -248,7 +267,7 @@ def warp_perspective_nn(src, M33, border=0.):
 def recrop_hand(crop, M, Mnew, com, size, fx, fy, background_value=0., nv_val=32000.):
     """recropHand, handdetector.py:782-803 (argument names as in the reference: the warp matrix is
     dot(M, Mnew))."""
-    warped = warp_perspective_nn(crop, np.dot(M, Mnew), border=float(background_value))
+    warped = warp_perspective_nn(crop, mat3_mul(M, Mnew), border=float(background_value))
     warped[np.isclose(warped, nv_val)] = background_value
     _, _, _, _, zstart, zend = com_to_bounds(com, size, fx, fy)
     msk1 = np.logical_and(warped < zstart, warped != 0)
@@ -265,7 +284,7 @@ def move_com(dpt, cube, com, off, joints3D, M, cam, fx, fy):
     new_com = cam.joint3DToImg(cam.jointImgTo3D(com) + off)
     if not (np.allclose(com[2], 0.) or np.allclose(new_com[2], 0.)):
         Mnew = com_to_transform(new_com, cube, fx, fy, dpt.shape)
-        new_dpt = recrop_hand(dpt, Mnew, np.linalg.inv(np.asarray(M, dtype=np.float64)), new_com, cube, fx, fy)
+        new_dpt = recrop_hand(dpt, Mnew, invert_3x3(np.asarray(M, dtype=np.float64)), new_com, cube, fx, fy)
     else:
         Mnew = M
         new_dpt = dpt
@@ -296,7 +315,7 @@ def scale_hand(dpt, cube, com, sc, joints3D, M, fx, fy):
     new_cube = [s * sc for s in cube]
     if not np.allclose(com[2], 0.):
         Mnew = com_to_transform(com, new_cube, fx, fy, dpt.shape)
-        new_dpt = recrop_hand(dpt, Mnew, np.linalg.inv(np.asarray(M, dtype=np.float64)), com, cube, fx, fy)
+        new_dpt = recrop_hand(dpt, Mnew, invert_3x3(np.asarray(M, dtype=np.float64)), com, cube, fx, fy)
     else:
         Mnew = M
         new_dpt = dpt
@@ -335,19 +354,20 @@ def augment_crop(img, gt3Dcrop, com, cube, M, mode, off, rot, sc, cam, fx, fy, n
         curLabel = gt3Dcrop / (cube[2] / 2.)
     else:
         raise NotImplementedError()
-    imgD = np.array(imgD, copy=True)
-    far = com[2] + (cube[2] / 2.)
-    near = com[2] - (cube[2] / 2.)
+    imgD = np.array(imgD, dtype=np.float32, copy=True)
+    # scalar (float64) thresholds are cast to the float32 array dtype by NumPy for comparison and assignment
+    far = np.float32(float(com[2]) + (cube[2] / 2.))
+    near = np.float32(float(com[2]) - (cube[2] / 2.))
     imgD[imgD == premax] = far
     imgD[imgD == 0] = far
     imgD[imgD >= far] = far
     imgD[imgD <= near] = near
     if normZeroOne:
         imgD -= near
-        imgD /= cube[2]
+        imgD /= np.float32(cube[2])
     else:
-        imgD -= com[2]
-        imgD /= (cube[2] / 2.)
+        imgD -= np.float32(com[2])
+        imgD /= np.float32(cube[2] / 2.)
     return imgD, curLabel, np.asarray(cube), com, M, rot
 
 

@@ -1,0 +1,96 @@
+"""Fused augmentation kernels vs the oracle's restatement of augmentCrop / moveCoM / rotateHand / scaleHand on
+explicit per-sample (mode, off, rot, sc).  Pixels: bit-exact (both sides evaluate the same IEEE-double coordinate
+arithmetic without FMA contraction); 'rot' may differ on a handful of pixels whose coordinate sits on a rounding
+boundary if the device cos/sin differ from libm by an ulp.  Labels: 1e-6 (f32 storage)."""
+import numpy as np
+import pytest
+
+from hipdp import ops
+from oracle import augment as A
+from tests.backends import BACKENDS, get_runtime
+
+MODES = {'none': 0, 'com': 1, 'rot': 2, 'sc': 3}
+
+
+def _run(rt, cam, imgs, coms, cubes, Ms, gts, modes, offs, rots, scs, pca=None):
+    B, J = gts.shape[0], gts.shape[1]
+    f32 = lambda a: rt.upload(np.asarray(a, np.float32))
+    d = dict(img=f32(imgs), com=f32(coms), cube=f32(cubes), M=f32(Ms.reshape(B, 9)), gt=f32(gts))
+    mode = rt.upload(np.asarray(modes, np.int32))
+    off, rot, sc = rt.upload(np.asarray(offs, np.float64)), rt.upload(np.asarray(rots, np.float64)), rt.upload(np.asarray(scs, np.float64))
+    rec = rt.alloc(B * rt.lib.dpp_augment_record_bytes(), np.uint8)
+    E = pca[1].shape[0] if pca else 0
+    out_y = rt.alloc((B, E if pca else J * 3), zero=False)
+    out = rt.alloc((B, 128, 128), zero=False)
+    pm = f32(pca[0]) if pca else None
+    pc = f32(pca[1]) if pca else None
+    ops.augment_prepare(rt, d['img'], d['com'], d['cube'], d['M'], d['gt'], B, J, 128, (cam.fx, cam.fy, cam.ux, cam.uy, cam.flip_y),
+                        rec, out_y, mode=mode, off=off, rot=rot, sc=sc, pca_mean=pm, pca_comp=pc, E=E)(rt.stream)
+    ops.augment_warp(rt, d['img'], rec, B, 128, out)(rt.stream)
+    rt.synchronize()
+    return out.get(), out_y.get()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('camname', ['icvl', 'nyu'])
+def test_augment_matches_oracle(backend, camname):
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(21)
+    cam = getattr(A.Camera, camname)()
+    J = 16 if camname == 'icvl' else 14
+    cube = (250.,) * 3 if camname == 'icvl' else (300.,) * 3
+    B = 12
+    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, B, cam, cube=cube, joints=J)
+    names = ['com', 'rot', 'sc', 'none'] * 3
+    names[8], names[9], names[10] = 'com', 'rot', 'sc'
+    modes = [MODES[n] for n in names]
+    _, offs, rots, scs = A.draw_params(rng, B, 4)
+    offs[8] = 0.0          # the reference's early-outs
+    rots[9] = 0.0
+    scs[10] = 1.0 + 5e-6   # inside numpy.allclose(sc, 1.)
+    mean = rng.normal(0, 0.1, J * 3).astype(np.float32)
+    comp = rng.normal(0, 0.2, (30, J * 3)).astype(np.float32)
+    out, out_y = _run(rt, cam, imgs, coms, cubes, Ms, gts, modes, offs, rots, scs, pca=(mean, comp))
+    for i in range(B):
+        com2d = cam.joint3DToImg(coms[i])
+        ref, lab, *_ = A.augment_crop(imgs[i].copy(), gts[i].copy(), com2d, cubes[i], Ms[i], names[i], offs[i], rots[i], scs[i],
+                                      cam, abs(cam.fx), abs(cam.fy))
+        nbad = int((out[i] != ref).sum())
+        assert nbad <= (6 if names[i] == 'rot' else 0), (i, names[i], nbad)
+        yref = A.pca_transform(lab.astype('f8'), mean.astype('f8'), comp.astype('f8'))[0]
+        np.testing.assert_allclose(out_y[i], yref, rtol=0, atol=2e-6 * max(1.0, np.abs(yref).max()))
+    # the warps really moved pixels (guards against a degenerate pass)
+    assert (out[0] != imgs[0]).mean() > 0.01 and (out[1] != imgs[1]).mean() > 0.01 and (out[2] != imgs[2]).mean() > 0.001
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_augment_raw_labels_and_device_rng(backend):
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(22)
+    cam = A.Camera.msra()
+    B, J = 64, 21
+    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, B, cam, cube=(200.,) * 3, joints=J)
+    f32 = lambda a: rt.upload(np.asarray(a, np.float32))
+    rec = rt.alloc(B * rt.lib.dpp_augment_record_bytes(), np.uint8)
+    out_y, out = rt.alloc((B, J * 3), zero=False), rt.alloc((B, 128, 128), zero=False)
+    out_mode = rt.alloc(B, np.int32)
+    table = rt.upload(np.array([1, 2, 0], np.int32))          # aug_modes = ['com', 'rot', 'none']
+    img = f32(imgs)
+    ops.augment_prepare(rt, img, f32(coms), f32(cubes), f32(Ms.reshape(B, 9)), f32(gts), B, J, 128,
+                        (cam.fx, cam.fy, cam.ux, cam.uy, cam.flip_y), rec, out_y, mode_table=table, n_modes=3, seed=1234, counter=7,
+                        out_mode=out_mode)(rt.stream)
+    ops.augment_warp(rt, img, rec, B, 128, out)(rt.stream)
+    rt.synchronize()
+    o, m = out.get(), out_mode.get()
+    assert set(np.unique(m)) <= {0, 1, 2} and len(np.unique(m)) == 3
+    assert np.isfinite(o).all() and o.min() >= -1.0 - 2e-6 and o.max() <= 1.0 + 2e-6
+    none = np.where(m == 0)[0]
+    np.testing.assert_allclose(o[none], imgs[none], atol=2e-6)
+    np.testing.assert_allclose(out_y.get()[none], (gts[none] / 100.).reshape(len(none), -1), rtol=1e-6)
+    # same (seed, counter) -> same draws; different counter -> different
+    out2 = rt.alloc((B, 128, 128), zero=False)
+    ops.augment_prepare(rt, img, f32(coms), f32(cubes), f32(Ms.reshape(B, 9)), f32(gts), B, J, 128,
+                        (cam.fx, cam.fy, cam.ux, cam.uy, cam.flip_y), rec, out_y, mode_table=table, n_modes=3, seed=1234, counter=7)(rt.stream)
+    ops.augment_warp(rt, img, rec, B, 128, out2)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_array_equal(out2.get(), o)

@@ -1,0 +1,208 @@
+"""Kernel parity: conv3x3 / stem / BatchNorm / loss / ADAM against the NumPy oracle (float64) on the same
+seeded inputs.  Tolerances are f32 round-off bounds written next to each check.  Runs on the SIMT emulator
+in the CPU tier and through the C ABI of libdpp_hip.so on the MI355X (`-m gpu`)."""
+import numpy as np
+import pytest
+
+from hipdp import layout, ops
+from hipdp.lib import Act
+from oracle import layers as L
+from tests.backends import BACKENDS, get_runtime
+
+
+def up(rt, **kw):
+    return {k: rt.upload(np.asarray(v, np.float32)) for k, v in kw.items()}
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(3, 8, 8, 16, 16, 64), (2, 16, 16, 32, 32, 128), (5, 4, 4, 64, 64, 64), (2, 6, 10, 16, 32, 128),
+                                 (20, 2, 2, 16, 16, 64)])
+def test_conv3x3_fwd_dgrad_wgrad(backend, cfg):
+    rt = get_runtime(backend)
+    N, H, W, Ci, Co, bm = cfg
+    rng = np.random.RandomState(11)
+    x = rng.normal(size=(N, Ci, H, W))
+    Wr = rng.normal(size=(Co, Ci, 3, 3)) * 0.2
+    b = rng.normal(size=Co)
+    mean, scale, beta = rng.normal(size=Ci) * 0.3, rng.uniform(0.5, 1.5, Ci), rng.normal(size=Ci) * 0.3
+    res = rng.normal(size=(N, Co, H, W))
+    a = np.maximum((x - mean[None, :, None, None]) * scale[None, :, None, None] + beta[None, :, None, None], 0)
+    y_ref = L.conv2d_fwd(a, Wr, b, (1, 1), 'half') + res
+    d = up(rt, X=layout.nchw_to_nhwc(x), Wk=layout.conv_w_to_kernel(Wr), b=b, mean=mean, scale=scale, beta=beta,
+           res=layout.nchw_to_nhwc(res))
+    act = ops.act(Act.BN_RELU, d['mean'], d['scale'], d['beta'], Ci)
+    Y = rt.alloc((N, H, W, Co), zero=False)
+    ops.conv3x3(rt, d['X'], N, H, W, Ci, d['Wk'], Co, Y, actX=act, bias=d['b'], residual=d['res'], bm=bm)(rt.stream)
+    rt.synchronize()
+    tol = 3e-6 * np.sqrt(9 * Ci) * np.abs(y_ref).max()
+    np.testing.assert_allclose(layout.nhwc_to_nchw(Y.get()), y_ref, rtol=0, atol=tol)
+    # data gradient = same kernel on dY with the transposed / mirrored weights
+    dy = rng.normal(size=(N, Co, H, W))
+    da_ref, dW_ref, _ = L.conv2d_bwd(a, Wr, dy, (1, 1), 'half')
+    dYb = rt.upload(layout.nchw_to_nhwc(dy).astype(np.float32))
+    Wd = rt.alloc((Ci, 9, Co), zero=False)
+    dA = rt.alloc((N, H, W, Ci), zero=False)
+    ops.conv3x3_wtrans(rt, d['Wk'], Co, Ci, Wd)(rt.stream)
+    ops.conv3x3(rt, dYb, N, H, W, Co, Wd, Ci, dA, bm=bm)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_allclose(layout.nhwc_to_nchw(dA.get()), da_ref, rtol=0, atol=3e-6 * np.sqrt(9 * Co) * np.abs(da_ref).max())
+    # filter gradient: per-workgroup partials + fixed-order reduce
+    nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, bm)
+    part = rt.alloc((nblk, Co, 9, Ci), zero=False)
+    dWk = rt.alloc((Co, 9, Ci), zero=False)
+    ops.conv3x3_wgrad(rt, d['X'], N, H, W, Ci, dYb, Co, part, actX=act, bm=bm)(rt.stream)
+    ops.reduce_partials(rt, part, nblk, Co * 9 * Ci, dWk)(rt.stream)
+    rt.synchronize()
+    dW = layout.conv_w_from_kernel(dWk.get(), (Co, Ci, 3, 3))
+    np.testing.assert_allclose(dW, dW_ref, rtol=0, atol=3e-6 * np.sqrt(N * H * W) * np.abs(dW_ref).max())
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(2, 32, 32, 32), (3, 16, 48, 32), (1, 36, 20, 16)])
+def test_stem_fwd_and_wgrad(backend, cfg):
+    rt = get_runtime(backend)
+    N, H, W, Co = cfg
+    rng = np.random.RandomState(12)
+    x = rng.uniform(-1, 1, size=(N, 1, H, W))
+    Wr = rng.normal(size=(Co, 1, 5, 5)) * 0.3
+    b = rng.normal(size=Co)
+    y_ref, cache = L.convpool_fwd(x, Wr, b, (1, 1), 'half', (2, 2), False)
+    d = up(rt, X=x[:, 0], Wk=layout.conv_w_to_kernel(Wr).reshape(Co, 25), b=b)
+    Y = rt.alloc((N, H // 2, W // 2, Co), zero=False)
+    arg = rt.alloc((N, H // 2, W // 2, Co), np.uint8, zero=False)
+    ops.stem_fwd(rt, d['X'], N, H, W, d['Wk'], d['b'], Co, Y, arg)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_allclose(layout.nhwc_to_nchw(Y.get()), y_ref, rtol=0, atol=3e-6 * 5 * np.abs(y_ref).max())
+    # argmax agrees with the oracle wherever the window maximum is unique to f32 resolution
+    cshape, arg_ref, _ = cache
+    c = L.conv2d_fwd(x, Wr, None, (1, 1), 'half')
+    cv = c.reshape(N, Co, H // 2, 2, W // 2, 2).transpose(0, 1, 2, 4, 3, 5).reshape(N, Co, H // 2, W // 2, 4)
+    srt = np.sort(cv, axis=4)
+    clear = (srt[..., 3] - srt[..., 2]) > 1e-4
+    got = layout.nhwc_to_nchw(arg.get())
+    assert clear.mean() > 0.95
+    assert (got[clear] == arg_ref[clear]).all()
+    # filter gradient with the device's own argmax
+    dy = rng.normal(size=y_ref.shape)
+    dyb = rt.upload(layout.nchw_to_nhwc(dy).astype(np.float32))
+    tpb = 2
+    nblk = rt.lib.dpp_stem_wgrad_blocks(N, H, W, tpb)
+    part = rt.alloc((nblk, Co, 25), zero=False)
+    dWk = rt.alloc((Co, 25), zero=False)
+    ops.stem_wgrad(rt, d['X'], N, H, W, dyb, arg, Co, part, tpb)(rt.stream)
+    ops.reduce_partials(rt, part, nblk, Co * 25, dWk)(rt.stream)
+    rt.synchronize()
+    _, dW_ref, _ = L.convpool_bwd(x, Wr, dy, (cshape, got, y_ref), (1, 1), 'half', (2, 2), False, need_dx=False)
+    dW = layout.conv_w_from_kernel(dWk.get().reshape(Co, 25, 1), (Co, 1, 5, 5))
+    np.testing.assert_allclose(dW, dW_ref, rtol=0, atol=3e-6 * np.sqrt(N * H * W / 4) * np.abs(dW_ref).max())
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(700, 16, 128), (333, 64, 64), (130, 256, 32), (1000, 32, 1000)])
+def test_batchnorm_forward_stats_and_backward(backend, cfg):
+    rt = get_runtime(backend)
+    M, Cc, rpb = cfg
+    rng = np.random.RandomState(13)
+    # large mean / std ratio on purpose: the shifted two-level statistics must survive it
+    x = (rng.normal(size=(M, Cc)) * rng.uniform(0.05, 2.0, Cc) + rng.normal(size=Cc) * 20.0).astype(np.float32)
+    gamma, beta = rng.uniform(0.5, 1.5, Cc).astype(np.float32), (rng.normal(size=Cc) * 0.3).astype(np.float32)
+    rm, ris = rng.normal(size=Cc).astype(np.float32), rng.uniform(0.5, 2, Cc).astype(np.float32)
+    x4 = x.astype('f8').T.reshape(1, Cc, M, 1)
+    y_ref, mean_ref, istd_ref = L.bn_fwd_train(x4, gamma.astype('f8'), beta.astype('f8'))
+    d = up(rt, x=x, gamma=gamma, beta=beta, rm=rm, ris=ris)
+    nb = -(-M // rpb)
+    part = rt.alloc((nb, 2, Cc), zero=False)
+    mean, istd, scale = (rt.alloc(Cc, zero=False) for _ in range(3))
+    ops.bn_stats_partial(rt, d['x'], M, Cc, rpb, part)(rt.stream)
+    ops.bn_finalize(rt, part, nb, M, rpb, Cc, d['gamma'], 1e-4, mean, istd, scale, d['rm'], d['ris'], 0.1)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_allclose(mean.get(), mean_ref, rtol=2e-7, atol=1e-7)          # f32 rounding of an f64 result
+    np.testing.assert_allclose(istd.get(), istd_ref, rtol=2e-6)
+    np.testing.assert_allclose(scale.get(), gamma * istd_ref, rtol=2e-6)
+    rm2, ris2 = L.bn_running_update(rm, ris, mean_ref.astype(np.float32), istd_ref.astype(np.float32))
+    np.testing.assert_allclose(d['rm'].get(), rm2, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(d['ris'].get(), ris2, rtol=2e-6)
+    # backward with ReLU mask
+    dA = rng.normal(size=(M, Cc)).astype(np.float32)
+    dAb = rt.upload(dA)
+    G = rt.alloc((M, Cc), zero=False)
+    part2 = rt.alloc((nb, 2, Cc), zero=False)
+    dbeta, dgamma, c1, c2 = (rt.alloc(Cc, zero=False) for _ in range(4))
+    add = rng.normal(size=(M, Cc)).astype(np.float32)
+    addb = rt.upload(add)
+    dX = rt.alloc((M, Cc), zero=False)
+    ops.bn_bwd_reduce(rt, dAb, d['x'], M, Cc, mean, istd, scale, d['beta'], 1, G, rpb, part2)(rt.stream)
+    ops.bn_bwd_finalize(rt, part2, nb, M, Cc, dbeta, dgamma, c1, c2)(rt.stream)
+    ops.bn_bwd_apply(rt, G, d['x'], M, Cc, mean, istd, scale, c1, c2, dX, add=addb)(rt.stream)
+    rt.synchronize()
+    v = y_ref[0, :, :, 0].T                           # bn output (M, C)
+    # the mask is decided on the device's own f32 bn value; exclude elements within f32 noise of zero
+    safe = np.abs(v) > 1e-4
+    g_ref = dA.astype('f8') * (v >= 0)
+    assert (G.get()[safe] == g_ref[safe].astype(np.float32)).all()
+    gdev = G.get().astype('f8')
+    dx_ref, dgamma_ref, dbeta_ref = L.bn_bwd_train(x4, gamma.astype('f8'), mean_ref, istd_ref, gdev.T.reshape(1, Cc, M, 1))
+    np.testing.assert_allclose(dbeta.get(), dbeta_ref, rtol=0, atol=2e-6 * np.sqrt(M) * np.abs(gdev).max())
+    np.testing.assert_allclose(dgamma.get(), dgamma_ref, rtol=0, atol=2e-5 * np.sqrt(M) * np.abs(gdev).max())
+    np.testing.assert_allclose(dX.get(), dx_ref[0, :, :, 0].T + add, rtol=0, atol=2e-5 * np.abs(dx_ref).max())
+    # deterministic-mode coefficients
+    ops.bn_eval_coeffs(rt, d['gamma'], d['rm'], d['ris'], Cc, mean, istd, scale)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_array_equal(mean.get(), d['rm'].get())
+    np.testing.assert_allclose(scale.get(), gamma * d['ris'].get(), rtol=1e-7)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_loss_colsum_adam_elementwise(backend):
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(14)
+    B, D = 128, 30
+    out, y = rng.normal(size=(B, D)).astype(np.float32), rng.normal(size=(B, D)).astype(np.float32)
+    ob, yb = rt.upload(out), rt.upload(y)
+    cost, err, dout = rt.alloc(1), rt.alloc(1), rt.alloc((B, D), zero=False)
+    ops.loss_sse(rt, ob, yb, B, D, B, cost, dout)(rt.stream)
+    ops.error_l2(rt, ob, yb, B, D, err)(rt.stream)
+    rt.synchronize()
+    c_ref, d_ref = L.loss_embedding(out.astype('f8'), y.astype('f8'))
+    np.testing.assert_allclose(cost.get()[0], c_ref, rtol=1e-6)
+    np.testing.assert_allclose(dout.get(), d_ref, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(err.get()[0], L.error_embedding(out.astype('f8'), y.astype('f8')), rtol=1e-6)
+    # column sums (bias gradients)
+    for (M, Cc, rpb) in ((1000, 64, 128), (77, 30, 16), (40, 1024, 8)):
+        X = rng.normal(size=(M, Cc)).astype(np.float32)
+        nb = -(-M // rpb)
+        part, s = rt.alloc((nb, Cc), zero=False), rt.alloc(Cc, zero=False)
+        ops.colsum_partial(rt, rt.upload(X), M, Cc, rpb, part)(rt.stream)
+        ops.reduce_partials(rt, part, nb, Cc, s)(rt.stream)
+        rt.synchronize()
+        np.testing.assert_allclose(s.get(), X.astype('f8').sum(0), rtol=0, atol=2e-6 * np.sqrt(M) * 4)
+    # ADAM: three steps against the oracle's float32 restatement
+    n = 1003
+    w = rng.normal(size=n).astype(np.float32)
+    wb, m, v = rt.upload(w), rt.alloc(n), rt.alloc(n)
+    P, Mo, Vo, t = [w.copy()], [np.zeros(n, np.float32)], [np.zeros(n, np.float32)], 1.0
+    hyper = rt.alloc(8)
+    for step in range(3):
+        g = (rng.normal(size=n) * 10 ** rng.uniform(-6, 0, n)).astype(np.float32)
+        lr = np.float32(1e-3)
+        b1, b2, eps = np.float32(0.9), np.float32(0.999), np.float32(1e-8)
+        b1t = b1 * np.float32(1.0) ** np.float32(t - 1)
+        hyper.set(np.array([lr, b1t, np.float32(1) - b1t, b2, np.float32(1) - b2, np.float32(1) - b1 ** np.float32(t),
+                            np.float32(1) - b2 ** np.float32(t), eps], np.float32))
+        ops.adam(rt, wb, rt.upload(g), m, v, n, hyper)(rt.stream)
+        rt.synchronize()
+        t = L.adam_step(P, [g], Mo, Vo, t, lr)
+        np.testing.assert_allclose(wb.get(), P[0], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(m.get(), Mo[0], rtol=2e-6, atol=1e-12)
+        np.testing.assert_allclose(v.get(), Vo[0], rtol=2e-6, atol=1e-20)
+    # dropout forward (deterministic + mask) and relu backward
+    pre = rng.normal(size=500).astype(np.float32)
+    mask = (rng.uniform(size=500) < 0.7).astype(np.float32)
+    pb, mb, o1, o2, g1 = rt.upload(pre), rt.upload(mask), rt.alloc(500), rt.alloc(500), rt.alloc(500)
+    ops.scale(rt, pb, o1, 500, a=np.float32(0.7), relu=True)(rt.stream)
+    ops.scale(rt, pb, o2, 500, relu=True, mask=mb)(rt.stream)
+    ops.relu_bwd(rt, pb, pb, g1, 500, mask=mb)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_allclose(o1.get(), np.float32(0.7) * np.maximum(pre, 0), rtol=1e-7)
+    np.testing.assert_array_equal(o2.get(), mask * np.maximum(pre, 0))
+    np.testing.assert_array_equal(g1.get(), pre * mask * (pre >= 0))
