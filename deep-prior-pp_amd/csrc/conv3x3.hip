@@ -286,10 +286,13 @@ extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dp
     int nblk = a.tiles_x * a.tiles_y * dpp_cdiv(N, a.img);
     int bn = Co >= 64 ? 64 : (Co >= 32 ? 32 : 16);
     size_t lds = ((size_t)a.img * (TH + 2) * (TW + 2) + bn) * (Ci + 4) * sizeof(float);
-    if (lds > 64 * 1024) return DPP_E_UNSUPPORTED;
+    if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, dpp_cdiv(Co, bn));
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DPP_C3(BM_, BN_) if (bm == BM_ && bn == BN_) { hipLaunchKernelGGL((conv3x3_kernel<BM_, BN_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
+    // gfx950 has 160 KiB of LDS per CU; requests above the default 64 KiB window need the opt-in attribute
+#define DPP_C3(BM_, BN_) if (bm == BM_ && bn == BN_) { \
+        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((conv3x3_kernel<BM_, BN_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
     DPP_C3(128, 64) DPP_C3(128, 32) DPP_C3(128, 16) DPP_C3(64, 64) DPP_C3(64, 32) DPP_C3(64, 16)
 #undef DPP_C3
     return DPP_E_UNSUPPORTED;
@@ -326,10 +329,12 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     int maxacc = dpp_cdiv(pairs, 4);
     a.taps_pb = taps_pb;
     size_t lds = ((size_t)a.img * (TH + 2) * (TW + 2) * (Ci + 4) + (size_t)bm * (Co + 4)) * sizeof(float);
-    if (lds > 64 * 1024) return DPP_E_UNSUPPORTED;
+    if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, 9 / taps_pb);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM_, MA_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
+#define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { \
+        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<BM_, MA_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM_, MA_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
     DPP_W3(128, 3) DPP_W3(128, 9) DPP_W3(128, 12) DPP_W3(128, 16)
     DPP_W3(64, 3) DPP_W3(64, 9) DPP_W3(64, 12) DPP_W3(64, 16)
 #undef DPP_W3

@@ -142,6 +142,20 @@ __global__ __launch_bounds__(DPP_THREADS) void relu_bwd_kernel(const float* __re
     }
 }
 
+// Bernoulli(keep) mask from a counter-based generator (splitmix64 of (seed, counter, index)): the dropout mask of
+// dropoutlayer.py:98-103 (the reference's MRG31k3p stream is not reproduced bit for bit)
+__global__ __launch_bounds__(DPP_THREADS) void bernoulli_mask_kernel(float* __restrict__ mask, size_t n, float keep, unsigned long long seed,
+                                                                     unsigned long long counter) {
+    for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DPP_THREADS) {
+        unsigned long long z = seed * 0x9E3779B97F4A7C15ull + counter * 0xD1B54A32D192ED03ull + i + 0x632BE59BD9B4E019ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+        mask[i] = u < keep ? 1.0f : 0.0f;
+    }
+}
+
 int grid_for(size_t n) {
     size_t b = (n + DPP_THREADS - 1) / DPP_THREADS;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -199,5 +213,19 @@ extern "C" int dpp_scale(const float* x, const float* mask, float a, int relu, f
 extern "C" int dpp_relu_bwd(const float* dy, const float* pre, const float* mask, float a, float* g, size_t n, dpp_stream_t stream) {
     if (!dy || !pre || !g || n < 1) return DPP_E_BADARG;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dy, pre, mask, a, g, n);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_fill_zero(void* p, size_t nbytes, dpp_stream_t stream) {
+    if (!p) return DPP_E_BADARG;
+    hipError_t e = hipMemsetAsync(p, 0, nbytes, static_cast<hipStream_t>(stream));
+    return e == hipSuccess ? DPP_OK : (int)e;
+}
+
+extern "C" int dpp_bernoulli_mask(float* mask, size_t n, float keep, unsigned long long seed, unsigned long long counter,
+                                  dpp_stream_t stream) {
+    if (!mask || n < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(bernoulli_mask_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), mask, n, keep, seed,
+                       counter);
     return dpp_launch_status();
 }

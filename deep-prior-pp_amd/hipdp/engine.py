@@ -1,0 +1,727 @@
+"""
+hipdp.engine -- compiles a net (the graph reachable from `net.output`) into HIP kernel launch plans.
+
+What the reference gets from `theano.function` (one fused device function per call:
+/root/reference/src/net/netbase.py:257-282 for inference, /root/reference/src/trainer/poseregnettrainer.py:146-170
+for train_model) is produced here as three replayable plans:
+    forward   stem -> [BN stats -> finalize -> conv with BN+ReLU prologue (+bias, +residual)]* -> FC head
+    backward  loss gradient -> per layer: data gradient, BN backward (mask, sums, apply), filter/bias gradients
+    update    one fused ADAM launch over the flat parameter buffer
+BatchNorm / ReLU layers are never materialised: they become "views" (base tensor + pending BN + pending ReLU)
+that the consuming conv / FC applies while staging its operand.  A residual `a + conv(...)` is fused into the
+conv's epilogue.  Activations are NHWC; parameters live in ONE flat device buffer in kernel layout (so ADAM and a
+data-parallel gradient all-reduce are single operations), with get_value()/set_value() converting to the
+reference's layouts on the fly.
+"""
+import numpy as np
+
+from . import layout, ops
+from .lib import Act, RowMap
+from .ops import Plan
+from .runtime import default_runtime
+
+BN_RPB_TARGET_BLOCKS = 256
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class TensorV(object):
+    """A materialised device tensor: NHWC (N,H,W,C) or (N,D)."""
+
+    def __init__(self, buf, shape, name):
+        self.buf, self.shape, self.name = buf, tuple(shape), name
+        self.grad = None
+        self.grad_written = False
+        self.pending = []              # gradient buffers to be added (identity paths of fused residuals)
+
+    @property
+    def rows(self):
+        return int(np.prod(self.shape[:-1]))
+
+    @property
+    def C(self):
+        return self.shape[-1]
+
+
+class BNState(object):
+    def __init__(self, layer, C, M):
+        self.layer, self.C, self.M = layer, C, M
+        self.rpb = max(32, -(-M // BN_RPB_TARGET_BLOCKS))
+        self.nb = -(-M // self.rpb)
+
+
+class View(object):
+    """base tensor + pending BatchNorm + pending ReLU; `shape` may be the flattened 2-D shape."""
+
+    def __init__(self, base, bn=None, relu=False, shape=None, chan=None):
+        self.base, self.bn, self.relu = base, bn, relu
+        self.shape = tuple(shape) if shape is not None else base.shape
+        self.chan = chan if chan is not None else base.C      # channel modulus along the contiguous dim
+
+    @property
+    def plain(self):
+        return self.bn is None and not self.relu
+
+    def key(self):
+        return (id(self.base), id(self.bn) if self.bn is not None else 0, self.relu)
+
+
+class ParamStore(object):
+    """Flat device buffers for all parameters of a net.
+    w / g / m / v : trained parameters (kernel layouts), gradients, ADAM moments; nt: running BN statistics."""
+
+    def __init__(self, rt, slots_spec):
+        self.rt = rt
+        self.slots = []
+        off = {'w': 0, 'nt': 0}
+        for (param, kind, info, trained) in slots_spec:
+            size = int(np.prod(param.shape))
+            space = 'w' if trained else 'nt'
+            self.slots.append(dict(param=param, kind=kind, info=info, trained=trained, off=off[space], size=size,
+                                   shape=tuple(param.shape)))
+            off[space] += _pad4(size)
+        self.n_w, self.n_nt = max(4, off['w']), max(4, off['nt'])
+        self.w = rt.alloc(self.n_w)
+        self.nt = rt.alloc(self.n_nt)
+        self.g = self.m = self.v = None
+        self.by_param = {}
+        for i, s in enumerate(self.slots):
+            self.by_param[s['param'].auto_name] = i
+            host = s['param']._host
+            s['param']._binding = None
+            self._write(i, host)
+        for i, s in enumerate(self.slots):
+            s['param']._binding = (self, i)
+
+    def ensure_train_buffers(self):
+        if self.g is None:
+            self.g = self.rt.alloc(self.n_w)
+            self.m = self.rt.alloc(self.n_w)
+            self.v = self.rt.alloc(self.n_w)
+
+    def view(self, param, space=None):
+        s = self.slots[self.by_param[param.auto_name]]
+        base = {'w': self.w, 'g': self.g, 'm': self.m, 'v': self.v, 'nt': self.nt}[space or ('w' if s['trained'] else 'nt')]
+        return base.view(s['off'], (s['size'],))
+
+    def _to_kernel(self, s, value):
+        value = np.asarray(value, np.float32)
+        if s['kind'] == 'conv_w':
+            return layout.conv_w_to_kernel(value).reshape(-1)
+        if s['kind'] == 'fc_w' and s['info'] is not None:
+            return layout.fc_rows_nchw_to_nhwc(value, *s['info']).reshape(-1)
+        return value.reshape(-1)
+
+    def _from_kernel(self, s, flat):
+        if s['kind'] == 'conv_w':
+            return layout.conv_w_from_kernel(flat, s['shape'])
+        if s['kind'] == 'fc_w' and s['info'] is not None:
+            return layout.fc_rows_nhwc_to_nchw(flat.reshape(s['shape']), *s['info'])
+        return flat.reshape(s['shape']).copy()
+
+    def _write(self, i, value):
+        s = self.slots[i]
+        base = self.w if s['trained'] else self.nt
+        base.view(s['off'], (s['size'],)).set(self._to_kernel(s, value))
+
+    # SharedParam binding interface
+    def read_param(self, i):
+        s = self.slots[i]
+        base = self.w if s['trained'] else self.nt
+        return self._from_kernel(s, base.view(s['off'], (s['size'],)).get())
+
+    def write_param(self, i, value):
+        self._write(i, value)
+
+    def read_grad(self, param):
+        s = self.slots[self.by_param[param.auto_name]]
+        return self._from_kernel(s, self.g.view(s['off'], (s['size'],)).get())
+
+    def release(self):
+        """Pull every value back to the host copies and unbind (before the store is rebuilt)."""
+        for i, s in enumerate(self.slots):
+            s['param']._host = np.asarray(self.read_param(i), np.float32)
+            s['param']._binding = None
+
+
+def _layer_kind(layer):
+    return layer.__class__.__name__
+
+
+def _collect(net):
+    """Vars reachable from net.output, consumer counts, and the layers in list (= topological) order."""
+    consumers = {}
+    seen = {}
+    order = []
+
+    def walk(v):
+        if id(v) in seen:
+            return
+        seen[id(v)] = v
+        for i in v.inputs:
+            consumers.setdefault(id(i), []).append(v)
+            walk(i)
+        order.append(v)
+
+    walk(net.output)
+    used = set(id(v.layer) for v in order if v.kind == 'layer')
+    layers = [l for l in net.layers if id(l) in used]
+    return order, consumers, layers
+
+
+def _param_specs(net, layers):
+    specs = []
+    for l in layers:
+        k = _layer_kind(l)
+        if k in ('ConvLayer', 'ConvPoolLayer'):
+            specs.append((l.W, 'conv_w', None, True))
+            specs.append((l.b, 'vec', None, True))
+        elif k == 'HiddenLayer':
+            info = None
+            iv = l.inputVar
+            if iv.kind == 'flatten' and iv.inputs[0].shape is not None and len(iv.inputs[0].shape) == 4:
+                _, Cc, H, W = iv.inputs[0].shape
+                if H * W > 1:
+                    info = (Cc, H, W)
+            specs.append((l.W, 'fc_w', info, True))
+            specs.append((l.b, 'vec', None, True))
+        elif k == 'BatchNormLayer':
+            specs.append((l.beta, 'vec', None, True))
+            specs.append((l.gamma, 'vec', None, True))
+            specs.append((l.mean, 'vec', None, False))
+            specs.append((l.inv_std, 'vec', None, False))
+    return specs
+
+
+def get_store(net, rt, layers):
+    specs = _param_specs(net, layers)
+    names = [p.auto_name for (p, _, _, _) in specs]
+    store = getattr(net, '_param_store', None)
+    if store is not None and store.rt is rt and [s['param'].auto_name for s in store.slots] == names and \
+            [s['info'] for s in store.slots] == [i for (_, _, i, _) in specs]:
+        return store
+    if store is not None:
+        store.release()
+    store = ParamStore(rt, specs)
+    net._param_store = store
+    return store
+
+
+def gemm_plan(M, N, K, allow_split=True):
+    """(tile, splitk) heuristics: fill >= 256 workgroups, split K when the output tile grid is small."""
+    if M <= 16:
+        bm, bn, wm = 16, 64, 1
+    elif M <= 32:
+        bm, bn, wm = 32, 64, 1
+    else:
+        wm = 4
+        bn = 64 if N > 32 else (32 if N > 16 else 16)
+        bm = 128 if (-(-M // 128)) * (-(-N // bn)) >= 512 else 64
+    tiles = (-(-M // bm)) * (-(-N // bn))
+    splitk = 1
+    if allow_split and tiles < 256 and K >= 256:
+        splitk = int(min(max(1, 512 // tiles), max(1, K // 128)))
+    return (bm, bn, wm), splitk
+
+
+class CompiledNet(object):
+    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0):
+        """
+        :param train: True -> BatchNorm uses batch statistics (and updates the running ones), dropout uses masks,
+                      and the loss / backward / ADAM plans are built; False -> deterministic forward only.
+        :param loss:  None, or dict(kind='embedding'|'joints', numJoints=, nDims=) -- the cost of
+                      poseregnettrainer.py:92-99; also available in eval mode (validation cost / error).
+        """
+        self.rt = rt = runtime or default_runtime()
+        self.net, self.train = net, train
+        self.N = net.cfgParams.batch_size
+        self.key = None
+        self.weight_decay = float(weight_decay)
+        self.order, self.consumers, self.layers = _collect(net)
+        self.store = get_store(net, rt, self.layers)
+        self.fwd, self.bwd, self.upd = Plan('forward'), Plan('backward'), Plan('update')
+        self.views = {}
+        self.tensors = []
+        self.bn_states = {}
+        self.layer_io = {}          # id(layer) -> dict(in_view, out_tensor, extra)
+        self.view_grads = {}        # view key -> dict(view, dA, written)
+        self._scratch = None
+        self._bn_scratch = None
+        self.dropout_masks = {}
+        in_dim = net.cfgParams.inputDim
+        self.in_shape = (in_dim[0], in_dim[2], in_dim[3], in_dim[1])
+        self.x_in = TensorV(rt.alloc(self.in_shape), self.in_shape, 'x')
+        self._memo = {}
+        out_view = self._emit(net.output)
+        self.out = self._materialize_plain(out_view)
+        self.out_dim = int(np.prod(self.out.shape[1:]))
+        self.loss_cfg = loss
+        if loss is not None:
+            self.y_in = rt.alloc((self.N, self.out_dim))
+            self.cost = rt.alloc(1)
+            self.err = rt.alloc(1)
+            self.lossplan = Plan('loss')
+            denom = self.N if loss.get('kind', 'embedding') == 'embedding' else self.N * loss['numJoints']
+            if train:
+                self.out.grad = rt.alloc(self.out.shape)
+                self.out.grad_written = True
+            self.lossplan.add(ops.loss_sse(rt, self.out.buf, self.y_in, self.N, self.out_dim, denom, self.cost,
+                                           self.out.grad if train else None))
+            if not train:
+                d = loss['nDims'] if loss.get('kind', 'embedding') != 'embedding' else self.out_dim
+                rows = self.N * (loss['numJoints'] if loss.get('kind', 'embedding') != 'embedding' else 1)
+                self.lossplan.add(ops.error_l2(rt, self.out.buf, self.y_in, rows, d, self.err))
+        if train:
+            if loss is None:
+                raise ValueError("a training engine needs a loss")
+            self.store.ensure_train_buffers()
+            self.hyper = rt.alloc(8)
+            self._emit_backward()
+            self.upd.add(ops.adam(rt, self.store.w, self.store.g, self.store.m, self.store.v, self.store.n_w, self.hyper))
+            self.adam_t = 1.0
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def scratch(self, nfloats):
+        if self._scratch is None or self._scratch.size < nfloats:
+            self._scratch = self.rt.alloc(max(nfloats, 1 << 20), zero=False)
+        return self._scratch
+
+    def _new_tensor(self, shape, name):
+        t = TensorV(self.rt.alloc(shape, zero=False), shape, name)
+        self.tensors.append(t)
+        return t
+
+    def _act(self, view):
+        mode = (Act.BN if view.bn is not None else 0) | (Act.RELU if view.relu else 0)
+        if mode == 0:
+            return None
+        if view.bn is not None:
+            b = view.bn
+            return ops.act(mode, b.mean, b.scale, b.beta_buf, view.chan)
+        return ops.act(mode, None, None, None, view.chan)
+
+    def _single_consumer(self, var):
+        return len(self.consumers.get(id(var), [])) == 1
+
+    def _materialize_plain(self, view):
+        if view.plain:
+            return view.base
+        raise NotImplementedError("the net output must be a materialised tensor (conv / hidden layer output)")
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _emit(self, var, residual=None):
+        if residual is None and id(var) in self._memo:
+            return self._memo[id(var)]
+        k = var.kind
+        if k == 'input':
+            v = View(self.x_in)
+        elif k == 'flatten':
+            src = self._emit(var.inputs[0])
+            n = src.shape[0]
+            v = View(src.base, src.bn, src.relu, shape=(n, int(np.prod(src.shape[1:]))), chan=src.base.C)
+        elif k == 'relu':
+            src = self._emit(var.inputs[0], residual)
+            if src.relu:
+                v = src
+            else:
+                v = View(src.base, src.bn, True, shape=src.shape, chan=src.chan)
+        elif k == 'add':
+            v = self._emit_add(var)
+        elif k == 'layer':
+            v = self._emit_layer(var, residual)
+        else:
+            raise NotImplementedError("graph node '%s'" % k)
+        if residual is None:
+            self._memo[id(var)] = v
+        return v
+
+    def _emit_add(self, var):
+        a, b = var.inputs
+
+        def fusable(x):
+            return x.kind == 'layer' and _layer_kind(x.layer) in ('ConvLayer',) and self._single_consumer(x) \
+                and x.layer.cfgParams.activation is None
+
+        cand = [x for x in (a, b) if fusable(x)]
+        if not cand:
+            raise NotImplementedError("residual add whose operands are not conv outputs")
+        q = max(cand, key=lambda x: x.layer.layerNum)        # the later conv absorbs the add in its epilogue
+        p = b if q is a else a
+        pv = self._emit(p)
+        if not pv.plain:
+            raise NotImplementedError("residual add on a non-materialised operand")
+        out = self._emit(q, residual=pv.base)
+        self._memo[id(q)] = out
+        return out
+
+    def _emit_layer(self, var, residual):
+        layer = var.layer
+        kind = _layer_kind(layer)
+        rt, st = self.rt, self.store
+        src = self._emit(var.inputs[0])
+        if kind == 'BatchNormLayer':
+            if not src.plain:
+                raise NotImplementedError("BatchNorm on a non-materialised input")
+            C = src.base.C
+            M = src.base.rows
+            b = BNState(layer, C, M)
+            b.mean, b.inv_std, b.scale = (rt.alloc(_pad4(C)) for _ in range(3))
+            b.beta_buf, b.gamma_buf = st.view(layer.beta), st.view(layer.gamma)
+            b.run_mean, b.run_inv_std = st.view(layer.mean), st.view(layer.inv_std)
+            self.bn_states[id(layer)] = b
+            if self.train:
+                part = self.scratch(b.nb * 2 * C)
+                self.fwd.add(ops.bn_stats_partial(rt, src.base.buf, M, C, b.rpb, part))
+                self.fwd.add(ops.bn_finalize(rt, part, b.nb, M, b.rpb, C, b.gamma_buf, layer.cfgParams.epsilon, b.mean, b.inv_std,
+                                             b.scale, b.run_mean, b.run_inv_std, layer.cfgParams.alpha))
+            else:
+                self.fwd.add(ops.bn_eval_coeffs(rt, b.gamma_buf, b.run_mean, b.run_inv_std, C, b.mean, b.inv_std, b.scale))
+            return View(src.base, b, False, shape=src.shape, chan=src.chan)
+        if kind == 'NonlinearityLayer':
+            if layer.cfgParams.activation is None:
+                return src
+            if layer.cfgParams.activation_str != 'ReLU':
+                raise NotImplementedError("only ReLU is on the hot path")
+            return View(src.base, src.bn, True, shape=src.shape, chan=src.chan)
+        if kind == 'ConvPoolLayer':
+            return self._emit_stem(layer, src)
+        if kind == 'ConvLayer':
+            return self._emit_conv(layer, src, residual)
+        if kind == 'HiddenLayer':
+            return self._emit_fc(layer, src)
+        if kind == 'DropoutLayer':
+            return self._emit_dropout(layer, src)
+        raise NotImplementedError(kind)
+
+    def _emit_stem(self, layer, src):
+        c = layer.cfgParams
+        N, H, W, Ci = src.base.shape
+        ok = (src.base is self.x_in and Ci == 1 and tuple(c.filterDim) == (5, 5) and c.border_mode == 'half' and
+              tuple(c.poolsize) == (2, 2) and tuple(c.stride) == (1, 1) and c.activation is None and c.nFilters <= 32)
+        if not ok:
+            raise NotImplementedError("ConvPoolLayer other than the ResNet stem (5x5 'same', pool 2, 1 input channel) -- "
+                                      "PoseRegNet's conv-pool stack is scheduled next (SURVEY.md 8(d))")
+        Co = c.nFilters
+        out = self._new_tensor((N, H // 2, W // 2, Co), 'stem')
+        arg = self.rt.alloc((N, H // 2, W // 2, Co), np.uint8, zero=False) if self.train else None
+        self.fwd.add(ops.stem_fwd(self.rt, src.base.buf.reshape(N, H, W), N, H, W, self.store.view(layer.W), self.store.view(layer.b), Co,
+                                  out.buf, arg))
+        self.layer_io[id(layer)] = dict(in_view=src, out=out, argmax=arg)
+        return View(out)
+
+    def _emit_conv(self, layer, src, residual):
+        c = layer.cfgParams
+        N, Hi, Wi, Ci = src.base.shape
+        _, Co, Ho, Wo = c.outputDim
+        k, s = tuple(c.filterDim), tuple(c.stride)
+        if c.border_mode != 'half' or k not in ((1, 1), (3, 3)) or s[0] != s[1] or (k == (3, 3) and s != (1, 1)):
+            raise NotImplementedError("ConvLayer %s stride %s border %s" % (k, s, c.border_mode))
+        out = self._new_tensor((N, Ho, Wo, Co), 'conv%d' % layer.layerNum)
+        act = self._act(src)
+        rt, st = self.rt, self.store
+        res = residual.buf if residual is not None else None
+        if k == (1, 1):
+            M = N * Ho * Wo
+            tile, _ = gemm_plan(M, Co, Ci, allow_split=False)
+            mp = RowMap.strided(s[0], Ho, Wo, Hi, Wi) if s[0] != 1 else None
+            self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
+                                  bias=st.view(layer.b), residual=res, tile=tile, name='conv1x1_%d' % layer.layerNum))
+        else:
+            self.fwd.add(ops.conv3x3(rt, src.base.buf, N, Hi, Wi, Ci, st.view(layer.W), Co, out.buf, actX=act, bias=st.view(layer.b),
+                                     residual=res, name='conv3x3_%d' % layer.layerNum))
+        self.layer_io[id(layer)] = dict(in_view=src, out=out, residual=residual)
+        return View(out)
+
+    def _emit_fc(self, layer, src):
+        c = layer.cfgParams
+        if len(src.shape) != 2:
+            raise NotImplementedError("HiddenLayer on a non-flattened input")
+        Nb, K = src.shape
+        Nout = c.outputDim[1]
+        assert K == c.inputDim[1], (K, c.inputDim)
+        out = self._new_tensor((Nb, Nout), 'fc%d' % layer.layerNum)
+        rt, st = self.rt, self.store
+        tile, splitk = gemm_plan(Nb, Nout, K)
+        act = self._act(src)
+        if splitk > 1:
+            part = self.scratch(splitk * Nb * Nout)
+            self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), None, Nb, Nout, K, 1, 0, K, Nout, Nout, actA=act, splitk=splitk,
+                                  partial=part, tile=tile, name='fc_%d' % layer.layerNum))
+            self.fwd.add(ops.reduce_partials(rt, part, splitk, Nb * Nout, out.buf, bias=st.view(layer.b), nbias=Nout))
+        else:
+            self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, Nb, Nout, K, 1, 0, K, Nout, Nout, actA=act,
+                                  bias=st.view(layer.b), tile=tile, name='fc_%d' % layer.layerNum))
+        self.layer_io[id(layer)] = dict(in_view=src, out=out)
+        return View(out)
+
+    def _emit_dropout(self, layer, src):
+        if src.bn is not None or len(src.shape) != 2:
+            raise NotImplementedError("DropoutLayer after BatchNorm / on a 4-D map")
+        n = int(np.prod(src.shape))
+        out = self._new_tensor(src.shape, 'drop%d' % layer.layerNum)
+        keep = np.float32(1.0 - layer.cfgParams.p)
+        mask = None
+        if self.train:
+            mask = self.rt.alloc(src.shape)
+            self.dropout_masks[id(layer)] = (mask, float(keep), layer.mask_seed)
+        self.fwd.add(ops.scale(self.rt, src.base.buf, out.buf, n, a=keep, relu=src.relu, mask=mask))
+        self.layer_io[id(layer)] = dict(in_view=src, out=out, mask=mask)
+        return View(out)
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _view_grad(self, view):
+        """The buffer holding d(cost)/d(view value); plain views write straight into the base tensor's gradient."""
+        if view.plain:
+            t = view.base
+            if t.grad is None:
+                t.grad = self.rt.alloc(t.shape, zero=False)
+            return t, t.grad
+        key = view.key()
+        vg = self.view_grads.get(key)
+        if vg is None:
+            vg = TensorV(self.rt.alloc(view.base.shape, zero=False), view.base.shape, 'dA')
+            vg.grad = vg.buf
+            vg.view = view
+            self.view_grads[key] = vg
+        return vg, vg.grad
+
+    def _grad_of(self, t):
+        """Materialised gradient of tensor t (None if nothing flows into it)."""
+        rt = self.rt
+        if t.grad_written:
+            for p in t.pending:
+                self.bwd.add(ops.axpy(rt, t.grad, p, 1.0, t.grad.size))
+            t.pending = []
+            return t.grad
+        if len(t.pending) == 1:
+            g = t.pending[0]
+            t.pending = []
+            t.grad, t.grad_written = g, True
+            return g
+        if len(t.pending) > 1:
+            t.grad = rt.alloc(t.shape, zero=True)
+            t.grad_written = True
+            return self._grad_of(t)
+        return None
+
+    def _resolve_view(self, vg):
+        """Back-propagate an accumulated view gradient through its pending ReLU / BatchNorm into the base tensor."""
+        view, rt, st = vg.view, self.rt, self.store
+        t = view.base
+        if not vg.grad_written:
+            return
+        n = int(np.prod(t.shape))
+        if view.bn is None:
+            # ReLU only (hidden-layer activation): g = dA * [pre >= 0], in place
+            self.bwd.add(ops.relu_bwd(rt, vg.grad, t.buf, vg.grad, n))
+            t.pending.append(vg.grad)
+            return
+        b = view.bn
+        M, C = b.M, b.C
+        part = self.scratch(b.nb * 2 * C)
+        c1, c2 = rt.alloc(_pad4(C)), rt.alloc(_pad4(C))
+        self.bwd.add(ops.bn_bwd_reduce(rt, vg.grad, t.buf, M, C, b.mean, b.inv_std, b.scale, b.beta_buf, int(view.relu), vg.grad, b.rpb, part))
+        self.bwd.add(ops.bn_bwd_finalize(rt, part, b.nb, M, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2))
+        addends = ([t.grad] if t.grad_written else []) + t.pending
+        t.pending = []
+        if t.grad is None:
+            t.grad = rt.alloc(t.shape, zero=False)
+        add = None
+        if addends:
+            add = addends[0]
+            for extra in addends[1:]:
+                raise NotImplementedError("more than one extra gradient path into a BatchNorm input")
+        self.bwd.add(ops.bn_bwd_apply(rt, vg.grad, t.buf, M, C, b.mean, b.inv_std, b.scale, c1, c2, t.grad, add=add))
+        t.grad_written = True
+
+    def _emit_backward(self):
+        rt, st = self.rt, self.store
+        # views are resolved at the layer that created them, walking the layer list backwards
+        created_by = {}
+        for var in self.order:
+            if var.kind == 'layer' and _layer_kind(var.layer) in ('NonlinearityLayer', 'BatchNormLayer'):
+                created_by[id(var.layer)] = self._memo[id(var)]
+            if var.kind == 'relu':
+                created_by[('relu', id(var.inputs[0].layer))] = self._memo[id(var)]
+        for layer in reversed(self.layers):
+            kind = _layer_kind(layer)
+            if kind in ('NonlinearityLayer', 'BatchNormLayer'):
+                v = created_by.get(id(layer))
+                if v is not None and v.key() in self.view_grads:
+                    vg = self.view_grads.pop(v.key())
+                    self._resolve_view(vg)
+                continue
+            io = self.layer_io[id(layer)]
+            v = created_by.get(('relu', id(layer)))          # activation wrapped around this layer's output
+            if v is not None and v.key() in self.view_grads:
+                self._resolve_view(self.view_grads.pop(v.key()))
+            out = io['out']
+            dY = self._grad_of(out)
+            if dY is None:
+                continue
+            src = io['in_view']
+            if kind == 'ConvLayer':
+                self._bwd_conv(layer, io, src, dY)
+            elif kind == 'HiddenLayer':
+                self._bwd_fc(layer, io, src, dY)
+            elif kind == 'ConvPoolLayer':
+                self._bwd_stem(layer, io, dY)
+            elif kind == 'DropoutLayer':
+                tgt, dst = self._view_grad(src)
+                if tgt.grad_written:
+                    raise NotImplementedError("dropout input with several consumers")
+                n = int(np.prod(src.shape))
+                self.bwd.add(ops.scale(rt, dY, dst, n, relu=False, mask=io['mask']))
+                tgt.grad_written = True
+            else:
+                raise NotImplementedError(kind)
+        if self.weight_decay and not self.net.hasDropout():
+            for l in self.layers:                             # cost += wd * sum(W^2): gradient 2*wd*W
+                if hasattr(l, 'W'):
+                    self.bwd.add(ops.axpy(rt, st.view(l.W, 'g'), st.view(l.W), 2.0 * self.weight_decay, int(np.prod(l.W.shape))))
+
+    def _bias_grad(self, dY, rows, C, gslot):
+        rpb = max(32, -(-rows // 256))
+        nb = -(-rows // rpb)
+        part = self.scratch(nb * C)
+        self.bwd.add(ops.colsum_partial(self.rt, dY, rows, C, rpb, part))
+        self.bwd.add(ops.reduce_partials(self.rt, part, nb, C, gslot))
+
+    def _bwd_conv(self, layer, io, src, dY):
+        rt, st = self.rt, self.store
+        c = layer.cfgParams
+        N, Hi, Wi, Ci = src.base.shape
+        _, Co, Ho, Wo = c.outputDim
+        k, s = tuple(c.filterDim), c.stride[0]
+        M = N * Ho * Wo
+        act = self._act(src)
+        gW, gb = st.view(layer.W, 'g'), st.view(layer.b, 'g')
+        if io.get('residual') is not None:
+            io['residual'].pending.append(dY)                 # identity path of the fused residual add
+        self._bias_grad(dY, M, Co, gb)
+        need_dx = src.base is not self.x_in
+        if k == (1, 1):
+            mp = RowMap.strided(s, Ho, Wo, Hi, Wi) if s != 1 else None
+            # filter gradient dW[o][c] = sum_m dY[m][o] * act(X)[map(m)][c]
+            tile, splitk = gemm_plan(Co, Ci, M)
+            part = self.scratch(splitk * Co * Ci)
+            self.bwd.add(ops.gemm(rt, dY, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actB=act,
+                                  splitk=splitk, partial=part if splitk > 1 else None, tile=tile, name='wgrad1x1_%d' % layer.layerNum))
+            if splitk > 1:
+                self.bwd.add(ops.reduce_partials(rt, part, splitk, Co * Ci, gW))
+            if need_dx:
+                tgt, dst = self._view_grad(src)
+                acc = tgt.grad_written
+                if s != 1 and not acc:
+                    self.bwd.add(ops.fill_zero(rt, dst))
+                tile, _ = gemm_plan(M, Ci, Co, allow_split=False)
+                self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp,
+                                      residual=dst if acc else None, tile=tile, name='dgrad1x1_%d' % layer.layerNum))
+                tgt.grad_written = True
+        else:
+            bm = 64
+            nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, Hi, Wi, bm)
+            part = self.scratch(nblk * Co * 9 * Ci)
+            self.bwd.add(ops.conv3x3_wgrad(rt, src.base.buf, N, Hi, Wi, Ci, dY, Co, part, actX=act, bm=bm))
+            self.bwd.add(ops.reduce_partials(rt, part, nblk, Co * 9 * Ci, gW))
+            if need_dx:
+                tgt, dst = self._view_grad(src)
+                acc = tgt.grad_written
+                Wd = rt.alloc(Co * 9 * Ci, zero=False)
+                self.bwd.add(ops.conv3x3_wtrans(rt, st.view(layer.W), Co, Ci, Wd))
+                self.bwd.add(ops.conv3x3(rt, dY, N, Hi, Wi, Co, Wd, Ci, dst, residual=dst if acc else None,
+                                         name='dgrad3x3_%d' % layer.layerNum))
+                tgt.grad_written = True
+
+    def _bwd_fc(self, layer, io, src, dY):
+        rt, st = self.rt, self.store
+        Nb, K = src.shape
+        Nout = layer.cfgParams.outputDim[1]
+        gW, gb = st.view(layer.W, 'g'), st.view(layer.b, 'g')
+        act = self._act(src)
+        self._bias_grad(dY, Nb, Nout, gb)
+        tile, _ = gemm_plan(K, Nout, Nb, allow_split=False)
+        self.bwd.add(ops.gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, tile=tile,
+                              name='fc_wgrad_%d' % layer.layerNum))
+        if src.base is not self.x_in:
+            tgt, dst = self._view_grad(src)
+            acc = tgt.grad_written
+            tile, _ = gemm_plan(Nb, K, Nout, allow_split=False)
+            self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, Nb, K, Nout, 1, 1, Nout, Nout, K, residual=dst if acc else None, tile=tile,
+                                  name='fc_dgrad_%d' % layer.layerNum))
+            tgt.grad_written = True
+
+    def _bwd_stem(self, layer, io, dY):
+        rt, st = self.rt, self.store
+        N, H, W, _ = self.in_shape
+        Co = layer.cfgParams.nFilters
+        out = io['out']
+        self._bias_grad(dY, out.rows, Co, st.view(layer.b, 'g'))
+        tpb = 8
+        nblk = rt.lib.dpp_stem_wgrad_blocks(N, H, W, tpb)
+        part = self.scratch(nblk * Co * 25)
+        self.bwd.add(ops.stem_wgrad(rt, self.x_in.buf, N, H, W, dY, io['argmax'], Co, part, tpb))
+        self.bwd.add(ops.reduce_partials(rt, part, nblk, Co * 25, st.view(layer.W, 'g')))
+
+    # ------------------------------------------------------------------------------------------ execution
+    def set_input(self, x):
+        """x: (N, C, H, W) host array (the reference's NCHW crops)."""
+        x = np.asarray(x, np.float32)
+        if tuple(x.shape) != tuple(self.net.cfgParams.inputDim):
+            raise ValueError("input shape %s, expected %s" % (x.shape, self.net.cfgParams.inputDim))
+        self.x_in.buf.set(x if x.shape[1] == 1 else layout.nchw_to_nhwc(x))
+
+    def forward(self, x=None):
+        if x is not None:
+            self.set_input(x)
+        self.fwd.run(self.rt.stream)
+        return self.out.buf.get()
+
+    def adam_hyper(self, lr):
+        """The scalar terms of optimizer.py:69-84 in float32 (python-float constants become floatX constants)."""
+        f = np.float32
+        t = f(self.adam_t)
+        b1, b2, eps, gamma = f(0.9), f(0.999), f(1e-8), f(1 - 1e-8)
+        b1t = b1 * gamma ** (t - f(1.))
+        return np.array([f(lr), b1t, f(1.) - b1t, b2, f(1.) - b2, f(1.) - b1 ** t, f(1.) - b2 ** t, eps], np.float32)
+
+    def train_step_device(self, lr, allreduce=None):
+        """forward + loss + backward (+ gradient all-reduce) + ADAM on the data already in x_in / y_in."""
+        st = self.rt.stream
+        self.hyper.set(self.adam_hyper(lr))
+        self.fwd.run(st)
+        self.lossplan.run(st)
+        self.bwd.run(st)
+        if allreduce is not None:
+            allreduce(self.store.g)
+        self.upd.run(st)
+        self.adam_t += 1.0
+
+    def train_step(self, x, y, lr):
+        self.set_input(x)
+        self.y_in.set(np.asarray(y, np.float32).reshape(self.N, self.out_dim))
+        self.train_step_device(lr)
+        return float(self.cost.get()[0])
+
+    def cost_and_grads(self, x, y):
+        """forward + loss + backward only (for the parity tests): returns (cost, out)."""
+        self.set_input(x)
+        self.y_in.set(np.asarray(y, np.float32).reshape(self.N, self.out_dim))
+        st = self.rt.stream
+        self.fwd.run(st)
+        self.lossplan.run(st)
+        self.bwd.run(st)
+        return float(self.cost.get()[0]), self.out.buf.get()
+
+    def evaluate(self, x, y):
+        """Deterministic forward + cost + error on one batch (validation functions of setupValidate)."""
+        self.set_input(x)
+        self.y_in.set(np.asarray(y, np.float32).reshape(self.N, self.out_dim))
+        self.fwd.run(self.rt.stream)
+        self.lossplan.run(self.rt.stream)
+        return float(self.cost.get()[0]), float(self.err.get()[0])
+
+    def num_launches(self):
+        return dict(forward=len(self.fwd), backward=len(self.bwd), update=len(self.upd))

@@ -181,3 +181,11 @@ def augment_prepare(rt, img, com3d, cube, Mcrop, gt3d, B, J, dsz, cam, records, 
 
 def augment_warp(rt, img, records, B, dsz, out, name='augment_warp'):
     return Launch(rt.lib.dpp_augment_warp, (img.ptr, records.ptr, B, dsz, out.ptr), (img, records, out), name)
+
+
+def fill_zero(rt, buf, name='fill_zero'):
+    return Launch(rt.lib.dpp_fill_zero, (buf.ptr, buf.nbytes), (buf,), name)
+
+
+def bernoulli_mask(rt, mask, n, keep, seed, counter, name='bernoulli_mask'):
+    return Launch(rt.lib.dpp_bernoulli_mask, (mask.ptr, n, float(keep), int(seed), int(counter)), (mask,), name)

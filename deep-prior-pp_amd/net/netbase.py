@@ -1,0 +1,275 @@
+"""
+NetBase / NetBaseParams (API of /root/reference/src/net/netbase.py:52-477): the net container the scripts use --
+`layers`, `output`, `params`, `weights`, `computeOutput`, deterministic-mode toggles, `weightVals`, and the
+pickle checkpoint format {'class', 'network': str(net), '<layerNum>-values': [params..., params_nontrained...]}.
+
+Execution is delegated to hipdp.engine, which compiles the graph reachable from `self.output` into HIP kernel
+launches (and is recompiled whenever `output` / `layers` are re-pointed, as main_*_posereg_embedding.py does
+when it appends the PCA-prior layer).
+"""
+import difflib
+import gzip
+import pickle
+import time
+
+import numpy
+
+from net.batchnormlayer import BatchNormLayer, BatchNormLayerParams
+from net.convlayer import ConvLayer, ConvLayerParams
+from net.convpoollayer import ConvPoolLayer, ConvPoolLayerParams
+from net.dropoutlayer import DropoutLayer, DropoutLayerParams
+from net.hiddenlayer import HiddenLayer, HiddenLayerParams
+from net.nonlinearitylayer import NonlinearityLayer, NonlinearityLayerParams
+from net.poollayer import PoolLayer, PoolLayerParams
+
+_LAYER_CLASSES = dict(ConvPoolLayer=ConvPoolLayer, ConvLayer=ConvLayer, HiddenLayer=HiddenLayer, PoolLayer=PoolLayer,
+                      DropoutLayer=DropoutLayer, BatchNormLayer=BatchNormLayer, NonlinearityLayer=NonlinearityLayer)
+
+
+class NetBaseParams(object):
+    def __init__(self):
+        self.numInputs = 1
+        self.numOutputs = 1
+        self.layers = []
+        self.inputDim = None
+        self.outputDim = None
+        self.loadFile = None
+
+    def getMemoryRequirement(self):
+        return sum(l.getMemoryRequirement() for l in self.layers)
+
+
+def _unique(prms):
+    seen, out = set(), []
+    for p in prms:
+        if p.auto_name not in seen:
+            seen.add(p.auto_name)
+            out.append(p)
+    return out
+
+
+class NetBase(object):
+    def __init__(self, rng, inputVar, cfgParams, twin=None):
+        self._params_filter = []
+        self._weights_filter = []
+        self.inputVar = inputVar
+        self.cfgParams = cfgParams
+        self.rng = rng
+        self.layers = []
+        for i, layerParam in enumerate(cfgParams.layers):
+            if i == 0:
+                inp = inputVar
+            else:
+                prev_out = self.layers[-1].cfgParams.outputDim
+                if len(prev_out) == 4 and len(layerParam.inputDim) == 2:
+                    inp = self.layers[-1].output.flatten(2)
+                    inp.name = "input_layer_{}".format(i)
+                elif len(layerParam.inputDim) == 4 and len(prev_out) == 2:
+                    inp = self.layers[-1].output.reshape(layerParam.inputDim, ndim=4)
+                    inp.name = "input_layer_{}".format(i)
+                else:
+                    inp = self.layers[-1].output
+            ctor = _LAYER_CLASSES[layerParam.__class__.__name__[:-6]]     # '<X>LayerParams' -> '<X>Layer'
+            self.layers.append(ctor(rng, inputVar=inp, cfgParams=layerParam,
+                                    copyLayer=None if (twin is None) else twin.layers[i], layerNum=i))
+        self.output = self.layers[-1].output
+        self.load(self.cfgParams.loadFile)
+
+    def __str__(self):
+        cfg = "Network configuration:\n"
+        for i, l in enumerate(self.layers):
+            cfg += "Layer {}: {} with {} \n".format(i, l.__class__.__name__, l)
+        return cfg
+
+    # ---- parameter enumeration -------------------------------------------------------------------------
+    @property
+    def all_params(self):
+        return _unique([p for l in self.layers for p in l.params])
+
+    @property
+    def params(self):
+        if not hasattr(self, '_params_filter'):
+            self._params_filter = []
+        blocked = [an.auto_name for an in self._params_filter]
+        return _unique([p for l in self.layers for p in l.params if p.auto_name not in blocked])
+
+    @property
+    def params_filter(self):
+        return self._params_filter
+
+    @params_filter.setter
+    def params_filter(self, bl):
+        names = [p.auto_name for l in self.layers for p in l.params]
+        for b in bl:
+            if b.auto_name not in names:
+                raise UserWarning("Param {} not in model!".format(b))
+        self._params_filter = bl
+
+    @property
+    def all_weights(self):
+        return _unique([p for l in self.layers for p in l.weights])
+
+    @property
+    def weights(self):
+        if not hasattr(self, '_weights_filter'):
+            self._weights_filter = []
+        blocked = [an.auto_name for an in self._weights_filter]
+        return _unique([p for l in self.layers for p in l.weights if p.name not in blocked])
+
+    @property
+    def weights_filter(self):
+        return self._weights_filter
+
+    @weights_filter.setter
+    def weights_filter(self, bl):
+        names = [p.auto_name for l in self.layers for p in l.weights]
+        for b in bl:
+            if b.auto_name not in names:
+                raise UserWarning("Weight {} not in model!".format(b))
+        self._weights_filter = bl
+
+    # ---- inference ---------------------------------------------------------------------------------------
+    def _engine(self, runtime=None):
+        """The compiled inference engine for the CURRENT graph (recompiled when output/layers were re-pointed)."""
+        from hipdp import engine as _engine
+        key = (id(self.output), len(self.layers), tuple(self.cfgParams.outputDim))
+        eng = getattr(self, '_compiled', None)
+        if eng is None or eng.key != key or (runtime is not None and eng.rt is not runtime):
+            eng = _engine.CompiledNet(self, train=False, runtime=runtime)
+            eng.key = key
+            self._compiled = eng
+        return eng
+
+    def computeOutput(self, inputs, timeit=False):
+        """Batched deterministic forward; the last batch is padded by repeating the last sample
+        (/root/reference/src/net/netbase.py:217-316)."""
+        if not isinstance(inputs, list):
+            inputs = [inputs]
+        assert all(i.shape[0] == inputs[0].shape[0] for i in inputs[1:])
+        if len(inputs) != 1 or isinstance(self.output, list):
+            raise NotImplementedError("multi-input / multi-output nets (ScaleNet) are listed under 'next' in SURVEY.md 8(f)")
+        if not self.isDeterministic():
+            print("WARNING: network is probabilistic for testing, DISABLING")
+            self.setDeterministic()
+        x = inputs[0]
+        batch_size = self.cfgParams.batch_size
+        nSamp = x.shape[0]
+        padSize = int(batch_size * numpy.ceil(nSamp / float(batch_size)))
+        outSize = list(self.cfgParams.outputDim)
+        outSize[0] = padSize
+        out = numpy.zeros(tuple(outSize), dtype='float32')
+        eng = self._engine()
+        n_test_batches = padSize // batch_size
+        start = time.time()
+        for i in range(n_test_batches):
+            chunk = x[i * batch_size:(i + 1) * batch_size]
+            if chunk.shape[0] < batch_size:
+                pad = numpy.zeros((batch_size,) + tuple(x.shape[1:]), dtype=x.dtype)
+                pad[0:chunk.shape[0]] = chunk
+                pad[chunk.shape[0]:] = x[-1]
+                chunk = pad
+            o = eng.forward(chunk)
+            out[i * batch_size:(i + 1) * batch_size] = o.reshape(self.cfgParams.outputDim)
+        end = time.time()
+        if timeit:
+            print("{} in {}s, {}ms per frame".format(padSize, end - start, (end - start) * 1000. / padSize))
+        return out[0:nSamp]
+
+    # ---- mode toggles ------------------------------------------------------------------------------------
+    def unsetDeterministic(self):
+        for layer in self.layers:
+            if isinstance(layer, (DropoutLayer, BatchNormLayer)):
+                layer.unsetDeterministic()
+
+    def setDeterministic(self):
+        for layer in self.layers:
+            if isinstance(layer, (DropoutLayer, BatchNormLayer)):
+                layer.setDeterministic()
+
+    def isDeterministic(self):
+        for layer in self.layers:
+            if isinstance(layer, (DropoutLayer, BatchNormLayer)) and not layer.isDeterministic():
+                return False
+        return True
+
+    def hasDropout(self):
+        return any(isinstance(layer, DropoutLayer) for layer in self.layers)
+
+    # ---- weight values -----------------------------------------------------------------------------------
+    @property
+    def weightVals(self):
+        return self.recGetWeightVals(self.all_params)
+
+    @weightVals.setter
+    def weightVals(self, value):
+        self.recSetWeightVals(self.all_params, value)
+
+    def recSetWeightVals(self, param, value):
+        if isinstance(value, list):
+            assert isinstance(param, list), "tried to assign a list of weights to params, which is not a list {}".format(type(param))
+            assert len(param) == len(value), "tried to assign unequal list of weights {} != {}".format(len(param), len(value))
+            for i in range(len(value)):
+                self.recSetWeightVals(param[i], value[i])
+        else:
+            param.set_value(value)
+
+    def recGetWeightVals(self, param):
+        if isinstance(param, list):
+            return [self.recGetWeightVals(p) for p in param]
+        return param.get_value()
+
+    # ---- checkpoints -------------------------------------------------------------------------------------
+    def save(self, filename):
+        state = dict([('class', self.__class__.__name__), ('network', self.__str__())])
+        for layer in self.layers:
+            key = '{}-values'.format(layer.layerNum)
+            state[key] = [numpy.array(p.get_value()) for p in layer.params]
+            state[key].extend([numpy.array(p.get_value()) for p in layer.params_nontrained])
+        opener = gzip.open if filename.lower().endswith('.gz') else open
+        with opener(filename, 'wb') as handle:
+            pickle.dump(state, handle, 2)          # protocol 2 = what cPickle wrote; readable by the reference
+        print('Saved model parameter to {}'.format(filename))
+
+    def load(self, filename, raise_on_error=True):
+        if filename is None:
+            return
+        print('Loading model parameters from {}'.format(filename))
+        opener = gzip.open if filename.lower().endswith('.gz') else open
+        with opener(filename, 'rb') as handle:
+            saved = pickle.load(handle, encoding='latin1')     # py2 cPickle files
+        if saved['network'] != self.__str__():
+            print("Possibly not matching network configuration!")
+            differences = list(difflib.Differ().compare(saved['network'].splitlines(), self.__str__().splitlines()))
+            print("Differences are:")
+            print("\n".join(differences))
+        for layer in self.layers:
+            key = '{}-values'.format(layer.layerNum)
+            if key not in saved:
+                if raise_on_error:
+                    raise ImportError("{} not in saved variables!".format(key))
+                print("WARNING: {} not in saved variables!".format(key))
+                continue
+            mine = layer.params + layer.params_nontrained
+            if len(mine) != len(saved[key]):
+                print("Warning: Layer parameters for layer {} do not match. Trying to fit on shape!".format(layer.layerNum))
+                n_assigned = 0
+                for p in mine:
+                    for v in saved[key]:
+                        if p.get_value().shape == v.shape:
+                            p.set_value(v)
+                            n_assigned += 1
+                if n_assigned != len(mine):
+                    if raise_on_error:
+                        raise ImportError("Could not load all necessary variables!")
+                    print("WARNING: Could not load all necessary variables!")
+                else:
+                    print("Found fitting parameters!")
+            else:
+                for p, v in zip(mine, saved[key]):
+                    if p.get_value().shape == v.shape:
+                        p.set_value(v)
+                    elif raise_on_error:
+                        raise ImportError("Skipping parameter for {}! Shape {} does not fit {}.".format(p.name, p.get_value().shape, v.shape))
+                    else:
+                        print("WARNING: Skipping parameter for {}! Shape {} does not fit {}.".format(p.name, p.get_value().shape, v.shape))
+        print('Done')

@@ -152,6 +152,11 @@ int dpp_scale(const float* x, const float* mask, float a, int relu, float* y, si
 /* g = (mask ? mask : a) * dy * [pre >= 0] */
 int dpp_relu_bwd(const float* dy, const float* pre, const float* mask, float a, float* g, size_t n, dpp_stream_t stream);
 
+int dpp_fill_zero(void* p, size_t nbytes, dpp_stream_t stream);
+/* mask[i] = 1 with probability keep (counter-based generator keyed by seed, counter, i): DropoutLayer masks */
+int dpp_bernoulli_mask(float* mask, size_t n, float keep, unsigned long long seed, unsigned long long counter,
+                       dpp_stream_t stream);
+
 /* ---- online crop augmentation, NetTrainer.augmentCrop (/root/reference/src/trainer/nettrainer.py:919-997) -------
  * prepare: per crop, the geometry of HandDetector.moveCoM / rotateHand / scaleHand
  *          (/root/reference/src/util/handdetector.py:678-780): new CoM, crop transform, inverse warp matrix,

@@ -191,9 +191,11 @@ def test_loss_colsum_adam_elementwise(backend):
                             np.float32(1) - b2 ** np.float32(t), eps], np.float32))
         ops.adam(rt, wb, rt.upload(g), m, v, n, hyper)(rt.stream)
         rt.synchronize()
+        m_prev = Mo[0].copy()
         t = L.adam_step(P, [g], Mo, Vo, t, lr)
         np.testing.assert_allclose(wb.get(), P[0], rtol=2e-6, atol=1e-9)
-        np.testing.assert_allclose(m.get(), Mo[0], rtol=2e-6, atol=1e-12)
+        # b1*m + (1-b1)*g may cancel: the round-off bound is relative to the terms, not to the result
+        assert (np.abs(m.get() - Mo[0]) <= 2e-7 * (np.abs(m_prev) + np.abs(g)) + 1e-30).all()
         np.testing.assert_allclose(v.get(), Vo[0], rtol=2e-6, atol=1e-20)
     # dropout forward (deterministic + mask) and relu backward
     pre = rng.normal(size=500).astype(np.float32)
