@@ -151,6 +151,7 @@ struct PrepArgs {
     const int* mode_table;   // [n_modes] aug_modes as AUG_* codes (device draws index into it)
     int n_modes;
     unsigned long long seed, counter;
+    const unsigned long long* counter_dev;
     double sigma_com, sigma_sc, rot_range;
     AugCam cam;
     int B, J, dsz;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a
             mode = a.mode[b]; off[0] = a.off[b * 3]; off[1] = a.off[b * 3 + 1]; off[2] = a.off[b * 3 + 2]; rot = a.rot[b]; sc = a.sc[b];
         } else {
             unsigned r0[4], r1[4], r2[4];
-            unsigned long long ctr = a.counter * (unsigned long long)a.B + b;
+            unsigned long long ctr = (a.counter + (a.counter_dev ? *a.counter_dev : 0ull)) * (unsigned long long)a.B + b;
             philox4(a.seed, ctr, 0, r0); philox4(a.seed, ctr, 1, r1); philox4(a.seed, ctr, 2, r2);
             mode = a.mode_table[r0[0] % (unsigned)a.n_modes];
             double u1 = u01(r0[1], r0[2]), u2 = u01(r0[3], r1[0]), u3 = u01(r1[1], r1[2]), u4 = u01(r1[3], r2[0]);
@@ -372,7 +373,7 @@ extern "C" int dpp_augment_prepare(const float* img, const float* com3d, const f
                                    const int* mode_table, int n_modes, unsigned long long seed, unsigned long long counter,
                                    double sigma_com, double sigma_sc, double rot_range, double fx, double fy, double ux, double uy,
                                    int flip_y, const float* pca_mean, const float* pca_comp, int E, void* records, float* out_y,
-                                   int* out_mode, dpp_stream_t stream) {
+                                   int* out_mode, const unsigned long long* counter_dev, dpp_stream_t stream) {
     if (!img || !com3d || !cube || !Mcrop || !gt3d || !records || !out_y || B < 1 || J < 1 || J * 3 > MAXJ3 || dsz < 1) return DPP_E_BADARG;
     if (!mode && (!mode_table || n_modes < 1)) return DPP_E_BADARG;
     if (mode && (!off || !rot || !sc)) return DPP_E_BADARG;
@@ -380,11 +381,23 @@ extern "C" int dpp_augment_prepare(const float* img, const float* com3d, const f
     PrepArgs a;
     a.img = img; a.com3d = com3d; a.cube = cube; a.Mcrop = Mcrop; a.gt3d = gt3d;
     a.mode = mode; a.off = off; a.rot = rot; a.sc = sc; a.mode_table = mode_table; a.n_modes = n_modes;
-    a.seed = seed; a.counter = counter; a.sigma_com = sigma_com; a.sigma_sc = sigma_sc; a.rot_range = rot_range;
+    a.seed = seed; a.counter = counter; a.counter_dev = counter_dev; a.sigma_com = sigma_com; a.sigma_sc = sigma_sc; a.rot_range = rot_range;
     a.cam.fx = fx; a.cam.fy = fy; a.cam.ux = ux; a.cam.uy = uy; a.cam.flip_y = flip_y;
     a.B = B; a.J = J; a.dsz = dsz; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
     a.rec = static_cast<AugRec*>(records); a.out_y = out_y; a.out_mode = out_mode;
     hipLaunchKernelGGL(augment_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    return dpp_launch_status();
+}
+
+namespace {
+__global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *c += inc;
+}
+}  // namespace
+
+extern "C" int dpp_counter_add(unsigned long long* counter, unsigned long long inc, dpp_stream_t stream) {
+    if (!counter) return DPP_E_BADARG;
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, inc);
     return dpp_launch_status();
 }
 

@@ -63,23 +63,37 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_stats_partial_kernel(const flo
     }
 }
 
+// One wave per channel: lane l combines partials l, l+64, ... (Chan), then a 6-step shuffle tree combines the lanes --
+// a fixed, data-independent order (deterministic).  4 channels per 256-thread workgroup.
+__device__ __forceinline__ void chan_combine(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
+    if (nb == 0.0) return;
+    double tot = n + nb, delta = mb - mean;
+    mean += delta * nb / tot;
+    m2 += m2b + delta * delta * n * nb / tot;
+    n = tot;
+}
+
 __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* __restrict__ partial, int nb, int M, int rpb,
                                                                   int C, const float* __restrict__ gamma, float eps,
                                                                   float* __restrict__ mean_o, float* __restrict__ inv_std_o,
                                                                   float* __restrict__ scale_o, float* __restrict__ run_mean,
                                                                   float* __restrict__ run_inv_std, float alpha) {
-    int c = blockIdx.x * DPP_THREADS + threadIdx.x;
-    if (c >= C) return;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
+    const int cc = c < C ? c : C - 1;                  // keep every lane in the shuffles
     double cn = 0.0, mean = 0.0, m2 = 0.0;
-    for (int b = 0; b < nb; ++b) {
+    for (int b = lane; b < nb; b += DPP_WAVE) {
         int rows = (b * rpb + rpb <= M) ? rpb : (M - b * rpb);
-        double nbk = (double)rows;
-        double mb = (double)partial[((size_t)b * 2 + 0) * C + c], m2b = (double)partial[((size_t)b * 2 + 1) * C + c];
-        double delta = mb - mean, tot = cn + nbk;
-        mean += delta * nbk / tot;
-        m2 += m2b + delta * delta * cn * nbk / tot;
-        cn = tot;
+        chan_combine(cn, mean, m2, (double)rows, (double)partial[((size_t)b * 2 + 0) * C + cc],
+                     (double)partial[((size_t)b * 2 + 1) * C + cc]);
     }
+    for (int o = 1; o < DPP_WAVE; o <<= 1) {
+        double on = __shfl_xor(cn, o), om = __shfl_xor(mean, o), o2 = __shfl_xor(m2, o);
+        // combine in a lane-symmetric order so that both partners compute the same value
+        if (lane & o) { double tn = on, tm = om, t2 = o2; chan_combine(tn, tm, t2, cn, mean, m2); cn = tn; mean = tm; m2 = t2; }
+        else chan_combine(cn, mean, m2, on, om, o2);
+    }
+    if (lane != 0 || c >= C) return;
     double var = m2 / (double)M;                       // biased, T.var
     float meanf = (float)mean;
     float inv_std = (float)(1.0 / sqrt(var + (double)eps));
@@ -157,13 +171,16 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float*
 __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int M, int C,
                                                                       float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                                       float* __restrict__ c1, float* __restrict__ c2) {
-    int c = blockIdx.x * DPP_THREADS + threadIdx.x;
-    if (c >= C) return;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
+    const int cc = c < C ? c : C - 1;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < nb; ++k) {
-        a += (double)partial[((size_t)k * 2 + 0) * C + c];
-        b += (double)partial[((size_t)k * 2 + 1) * C + c];
+    for (int k = lane; k < nb; k += DPP_WAVE) {
+        a += (double)partial[((size_t)k * 2 + 0) * C + cc];
+        b += (double)partial[((size_t)k * 2 + 1) * C + cc];
     }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (lane != 0 || c >= C) return;
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
     c1[c] = (float)(a / (double)M);
@@ -215,7 +232,7 @@ extern "C" int dpp_bn_finalize(const float* partial, int nb, int M, int rows_per
                                float* mean, float* inv_std, float* scale, float* run_mean, float* run_inv_std, float alpha,
                                dpp_stream_t stream) {
     if (!partial || !gamma || !mean || !inv_std || !scale || nb != dpp_cdiv(M, rows_per_block)) return DPP_E_BADARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dpp_cdiv(C, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dpp_cdiv(C, DPP_THREADS / DPP_WAVE)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
                        partial, nb, M, rows_per_block, C, gamma, eps, mean, inv_std, scale, run_mean, run_inv_std, alpha);
     return dpp_launch_status();
 }
@@ -241,7 +258,7 @@ extern "C" int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, 
 extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int M, int C, float* dbeta, float* dgamma, float* c1, float* c2,
                                    dpp_stream_t stream) {
     if (!partial || !dbeta || !dgamma || !c1 || !c2 || nb < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dpp_cdiv(C, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dpp_cdiv(C, DPP_THREADS / DPP_WAVE)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
                        partial, nb, M, C, dbeta, dgamma, c1, c2);
     return dpp_launch_status();
 }

@@ -98,16 +98,39 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
 #pragma unroll
         for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // weight slices are double-buffered in LDS: the slice of tap t+1 is fetched into registers before the MFMAs of tap t
+    // and written to the other buffer after them, so one barrier per tap suffices and the fetch latency is hidden.
     const int q = Ci >> 2;
-    for (int tap = 0; tap < 9; ++tap) {
-        // stage the weight slice of this tap: Bs[j][c] = Wk[col0+j][tap][c]
-        for (int s = tid; s < BN * q; s += DPP_THREADS) {
-            int j = s / q, c4 = s - j * q;
+    constexpr int WSLOTS = (BN * 16 + DPP_THREADS - 1) / DPP_THREADS;      // Ci <= 64 -> at most BN*16 float4 per slice
+    float4 wreg[WSLOTS];
+    auto wfetch = [&](int tap) {
+#pragma unroll
+        for (int s = 0; s < WSLOTS; ++s) {
+            int slot = tid + s * DPP_THREADS;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col0 + j < a.Co) v = *reinterpret_cast<const float4*>(a.Wk + ((size_t)(col0 + j) * 9 + tap) * Ci + c4 * 4);
-            *reinterpret_cast<float4*>(&Bs[j * LDA + c4 * 4]) = v;
+            if (slot < BN * q) {
+                int j = slot / q, c4 = slot - j * q;
+                if (col0 + j < a.Co) v = *reinterpret_cast<const float4*>(a.Wk + ((size_t)(col0 + j) * 9 + tap) * Ci + c4 * 4);
+            }
+            wreg[s] = v;
         }
-        __syncthreads();            // also orders the halo staging before the first tap
+    };
+    auto wcommit = [&](float* dst) {
+#pragma unroll
+        for (int s = 0; s < WSLOTS; ++s) {
+            int slot = tid + s * DPP_THREADS;
+            if (slot < BN * q) {
+                int j = slot / q, c4 = slot - j * q;
+                *reinterpret_cast<float4*>(&dst[j * LDA + c4 * 4]) = wreg[s];
+            }
+        }
+    };
+    wfetch(0);
+    wcommit(Bs);
+    __syncthreads();                // halo + first slice visible
+    for (int tap = 0; tap < 9; ++tap) {
+        const float* Bcur = Bs + (tap & 1) * BN * LDA;
+        if (tap + 1 < 9) wfetch(tap + 1);
         const int toff = (tap / 3 - 1) * (TW + 2) + (tap % 3 - 1);
         for (int kc = 0; kc < Ci; kc += 16) {
             float4 av[RM], bv[CN];
@@ -116,7 +139,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
                 av[rt] = *reinterpret_cast<const float4*>(&Ah[(hbase[rt] + toff) * LDA + kc + kq * 4]);
 #pragma unroll
             for (int ct = 0; ct < CN; ++ct)
-                bv[ct] = *reinterpret_cast<const float4*>(&Bs[(ct * 16 + l15) * LDA + kc + kq * 4]);
+                bv[ct] = *reinterpret_cast<const float4*>(&Bcur[(ct * 16 + l15) * LDA + kc + kq * 4]);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -126,6 +149,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t),
                                                                            acc[rt][ct], 0, 0, 0);
         }
+        if (tap + 1 < 9) wcommit(Bs + ((tap + 1) & 1) * BN * LDA);
         __syncthreads();
     }
 
@@ -172,6 +196,7 @@ struct Wgrad3Args {
     const float* dY;      // [N][H][W][Co]
     float* partial;       // [nblk][Co][9][Ci]
     int lth, ltw, img, tiles_x, tiles_y;
+    int ntiles;           // spatial tiles in total (a workgroup walks several)
     int taps_pb;          // taps per blockIdx.y
 };
 
@@ -187,26 +212,6 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     Conv3Args ta;                      // reuse tile_origin
     ta.tiles_x = a.tiles_x; ta.tiles_y = a.tiles_y; ta.img = a.img; ta.lth = a.lth; ta.ltw = a.ltw;
-    int n0, y0, x0;
-    tile_origin(ta, blockIdx.x, n0, y0, x0);
-
-    stage_halo(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA);
-    {   // stage dY rows of the tile (zeros for out-of-range rows)
-        const int q = Co >> 2;
-        for (int s = tid; s < BM * q; s += DPP_THREADS) {
-            int row = s / q, c4 = s - row * q;
-            int im = row >> (a.lth + a.ltw);
-            int ty = (row >> a.ltw) & (TH - 1);
-            int tx = row & (TW - 1);
-            int n = n0 + im, y = y0 + ty, x = x0 + tx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (im < a.img && n < a.N && y < a.H && x < a.W)
-                v = *reinterpret_cast<const float4*>(a.dY + (((size_t)n * a.H + y) * a.W + x) * Co + c4 * 4);
-            *reinterpret_cast<float4*>(&Ys[row * LDY + c4 * 4]) = v;
-        }
-    }
-    __syncthreads();
-
     const int nto = Co >> 4, ntc = Ci >> 4, NT = nto * ntc;
     const int tap0 = blockIdx.y * a.taps_pb;
     const int pairs = a.taps_pb * NT;
@@ -214,29 +219,53 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a
 #pragma unroll
     for (int i = 0; i < MAXACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int rc = 0; rc < BM; rc += 16) {
-        // halo index of the 4 reduction rows this lane feeds: r = rc + 4*kq + t
-        int hb[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            int row = rc + kq * 4 + t;
-            int im = row >> (a.lth + a.ltw);
-            int ty = (row >> a.ltw) & (TH - 1);
-            int tx = row & (TW - 1);
-            hb[t] = (im * (TH + 2) + ty + 1) * (TW + 2) + tx + 1;
+    // a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... keeping its accumulators in registers, so the
+    // number of partial slices (and the traffic of the reduce) is bounded by the grid size, not by the tile count
+    for (int tile_id = blockIdx.x; tile_id < a.ntiles; tile_id += gridDim.x) {
+        int n0, y0, x0;
+        tile_origin(ta, tile_id, n0, y0, x0);
+        __syncthreads();               // previous tile's fragments are consumed before LDS is overwritten
+        stage_halo(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA);
+        {   // stage dY rows of the tile (zeros for out-of-range rows)
+            const int q = Co >> 2;
+            for (int s = tid; s < BM * q; s += DPP_THREADS) {
+                int row = s / q, c4 = s - row * q;
+                int im = row >> (a.lth + a.ltw);
+                int ty = (row >> a.ltw) & (TH - 1);
+                int tx = row & (TW - 1);
+                int n = n0 + im, y = y0 + ty, x = x0 + tx;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (im < a.img && n < a.N && y < a.H && x < a.W)
+                    v = *reinterpret_cast<const float4*>(a.dY + (((size_t)n * a.H + y) * a.W + x) * Co + c4 * 4);
+                *reinterpret_cast<float4*>(&Ys[row * LDY + c4 * 4]) = v;
+            }
         }
+        __syncthreads();
+
+        for (int rc = 0; rc < BM; rc += 16) {
+            // halo index of the 4 reduction rows this lane feeds: r = rc + 4*kq + t
+            int hb[4];
 #pragma unroll
-        for (int i = 0; i < MAXACC; ++i) {
-            int p = wave + 4 * i;
-            if (p < pairs) {
-                int tap = tap0 + p / NT, tile = p % NT;
-                int to = tile / ntc, tc = tile - to * ntc;
-                int toff = (tap / 3 - 1) * (TW + 2) + (tap % 3 - 1);
+            for (int t = 0; t < 4; ++t) {
+                int row = rc + kq * 4 + t;
+                int im = row >> (a.lth + a.ltw);
+                int ty = (row >> a.ltw) & (TH - 1);
+                int tx = row & (TW - 1);
+                hb[t] = (im * (TH + 2) + ty + 1) * (TW + 2) + tx + 1;
+            }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float av = Ys[(rc + kq * 4 + t) * LDY + to * 16 + l15];
-                    float bv = Ah[(hb[t] + toff) * LDA + tc * 16 + l15];
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+            for (int i = 0; i < MAXACC; ++i) {
+                int p = wave + 4 * i;
+                if (p < pairs) {
+                    int tap = tap0 + p / NT, tile = p % NT;
+                    int to = tile / ntc, tc = tile - to * ntc;
+                    int toff = (tap / 3 - 1) * (TW + 2) + (tap % 3 - 1);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float av = Ys[(rc + kq * 4 + t) * LDY + to * 16 + l15];
+                        float bv = Ah[(hb[t] + toff) * LDA + tc * 16 + l15];
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -257,6 +286,8 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a
         }
     }
 }
+
+constexpr int WGRAD_MAX_BLOCKS = 256;   // partial slices of the 3x3 filter gradient
 
 int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -284,8 +315,10 @@ extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dp
     int TH = 1 << a.lth, TW = 1 << a.ltw;
     a.tiles_x = dpp_cdiv(W, TW); a.tiles_y = dpp_cdiv(H, TH);
     int nblk = a.tiles_x * a.tiles_y * dpp_cdiv(N, a.img);
+    if (Ci > 64) return DPP_E_UNSUPPORTED;          // weight-slice register staging is sized for Ci <= 64
     int bn = Co >= 64 ? 64 : (Co >= 32 ? 32 : 16);
-    size_t lds = ((size_t)a.img * (TH + 2) * (TW + 2) + bn) * (Ci + 4) * sizeof(float);
+    while (bn > 16 && (long)nblk * dpp_cdiv(Co, bn) < 256) bn >>= 1;      // fill the 256 CUs
+    size_t lds = ((size_t)a.img * (TH + 2) * (TW + 2) + 2 * bn) * (Ci + 4) * sizeof(float);
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, dpp_cdiv(Co, bn));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -309,7 +342,8 @@ extern "C" int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int bm) {
     int lth, ltw, img;
     if (bm != 64 && bm != 128) return -1;
     pick_tile(N, H, W, bm, lth, ltw, img);
-    return dpp_cdiv(W, 1 << ltw) * dpp_cdiv(H, 1 << lth) * dpp_cdiv(N, img);
+    int tiles = dpp_cdiv(W, 1 << ltw) * dpp_cdiv(H, 1 << lth) * dpp_cdiv(N, img);
+    return tiles < WGRAD_MAX_BLOCKS ? tiles : WGRAD_MAX_BLOCKS;
 }
 
 extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
@@ -321,7 +355,8 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     pick_tile(N, H, W, bm, a.lth, a.ltw, a.img);
     int TH = 1 << a.lth, TW = 1 << a.ltw;
     a.tiles_x = dpp_cdiv(W, TW); a.tiles_y = dpp_cdiv(H, TH);
-    int nblk = a.tiles_x * a.tiles_y * dpp_cdiv(N, a.img);
+    a.ntiles = a.tiles_x * a.tiles_y * dpp_cdiv(N, a.img);
+    int nblk = a.ntiles < WGRAD_MAX_BLOCKS ? a.ntiles : WGRAD_MAX_BLOCKS;
     int NT = (Co >> 4) * (Ci >> 4);
     // (tap, tile) pairs per workgroup <= 4 waves * MAXACC accumulators
     int taps_pb = NT <= 4 ? 9 : (NT <= 16 ? 3 : 1);

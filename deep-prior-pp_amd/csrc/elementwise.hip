@@ -74,11 +74,15 @@ __global__ __launch_bounds__(DPP_THREADS) void error_l2_kernel(const float* __re
 }
 
 // ---- ADAM (optimizer.py:58-90), one launch over the flat parameter buffer -------------------------------
-// hyper (device, 8 floats): lr, beta1_t, 1-beta1_t, beta2, 1-beta2, 1-beta1^t, 1-beta2^t, epsilon
+// state (device, 8 floats): lr, t, beta1, beta2, epsilon, gamma, -, -.  The scalar terms of optimizer.py:69-84 are evaluated
+// here in float32 (beta1_t = beta1*gamma^(t-1), 1-beta1^t, 1-beta2^t) so that a captured step can be replayed without
+// any host upload; adam_tick_kernel advances t after the update (the reference's `t <- t + 1`).
 __global__ __launch_bounds__(DPP_THREADS) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
-                                                           float* __restrict__ v, size_t n, const float* __restrict__ hyper) {
-    const float lr = hyper[0], b1 = hyper[1], ob1 = hyper[2], b2 = hyper[3], ob2 = hyper[4], c1 = hyper[5], c2 = hyper[6],
-                eps = hyper[7];
+                                                           float* __restrict__ v, size_t n, const float* __restrict__ state) {
+    const float lr = state[0], t = state[1], beta1 = state[2], b2 = state[3], eps = state[4], gamma = state[5];
+    const float b1 = beta1 * powf(gamma, t - 1.0f);
+    const float ob1 = 1.0f - b1, ob2 = 1.0f - b2;
+    const float c1 = 1.0f - powf(beta1, t), c2 = 1.0f - powf(b2, t);
     const size_t n4 = n >> 2;
     for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * DPP_THREADS) {
         float4 W = reinterpret_cast<float4*>(w)[i], G = reinterpret_cast<const float4*>(g)[i];
@@ -101,6 +105,10 @@ __global__ __launch_bounds__(DPP_THREADS) void adam_kernel(float* __restrict__ w
         v[i] = vv;
     }
 #undef DPP_ADAM1
+}
+
+__global__ void adam_tick_kernel(float* state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += 1.0f;
 }
 
 // y[i] += alpha * x[i]   (L2 weight-decay gradient 2*wd*W, poseregnettrainer.py:101-107)
@@ -181,6 +189,12 @@ extern "C" int dpp_loss_sse(const float* out, const float* y, int rows, int d, i
 extern "C" int dpp_error_l2(const float* out, const float* y, int rows, int d, float* err, dpp_stream_t stream) {
     if (!out || !y || !err || rows < 1 || d < 1) return DPP_E_BADARG;
     hipLaunchKernelGGL(error_l2_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), out, y, rows, d, err);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_adam_tick(float* state, dpp_stream_t stream) {
+    if (!state) return DPP_E_BADARG;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), state);
     return dpp_launch_status();
 }
 

@@ -19,13 +19,12 @@
 
 namespace {
 
-constexpr int BK = 16;
-constexpr int LDK = BK + 4;
 
 struct GemmArgs {
     dpp_gemm_desc d;
     int vecA, vecB;   // float4 loads legal for the operand
-    int Kper;         // K-slice length per blockIdx.z (multiple of BK)
+    int Kper;         // K-slice length per blockIdx.z (multiple of the chunk depth)
+    int bk;           // chunk depth for K-contiguous A: 16 or 32 (both-MN-contiguous layout always uses 64)
 };
 
 // Load 4 consecutive floats p[0..3] where element e is valid iff (idx0 + e) < limit.
@@ -52,16 +51,27 @@ __device__ __forceinline__ float4 act4_masked(float4 v, const dpp_act& a, int c0
     return o;
 }
 
-template <int BM, int BN, int WM, bool AKC, bool BKC>
+// Global -> register fetch of one float4 staging slot (with the operand prologue applied), and its LDS address.
+// K-contiguous operand: slot = (row r, k-quad c4); MN-contiguous operand: slot = (k row rk, mn-quad c4).
+template <int ROWS, int BKT, bool KC>
+struct Stager {
+    static constexpr int QK = BKT / 4;                       // float4 per row (KC)
+    static constexpr int SLOTS = (ROWS * QK + DPP_THREADS - 1) / DPP_THREADS;
+    static constexpr int LD = KC ? (BKT + 4) : (ROWS + 4);
+};
+
+template <int BM, int BN, int WM, int BKT, bool AKC, bool BKC>
 __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     const dpp_gemm_desc& d = ga.d;
     constexpr int WN = 4 / WM;
     constexpr int RM = BM / (16 * WM);
     constexpr int CN = BN / (16 * WN);
-    constexpr int LDAM = BM + 4;
-    constexpr int LDBN = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[AKC ? BM * LDK : BK * LDAM];
-    __shared__ __attribute__((aligned(16))) float Bs[BKC ? BN * LDK : BK * LDBN];
+    using SA = Stager<BM, BKT, AKC>;
+    using SB = Stager<BN, BKT, BKC>;
+    constexpr int LDA_ = SA::LD, LDB_ = SB::LD;
+    constexpr int KL = BKT / 4;                              // k-values owned by one lane per chunk: kq*KL + e
+    __shared__ __attribute__((aligned(16))) float As[AKC ? BM * LDA_ : BKT * LDA_];
+    __shared__ __attribute__((aligned(16))) float Bs[BKC ? BN * LDB_ : BKT * LDB_];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -72,27 +82,83 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     const int k_begin = blockIdx.z * ga.Kper;
     const int k_end = (k_begin + ga.Kper < d.K) ? (k_begin + ga.Kper) : d.K;
 
-    // ---- staging slots --------------------------------------------------------------------------
-    constexpr int A_SLOTS = (BM * 4 + DPP_THREADS - 1) / DPP_THREADS;   // float4 slots per thread (either layout)
-    constexpr int B_SLOTS = (BN * 4 + DPP_THREADS - 1) / DPP_THREADS;
-    const float* a_base[A_SLOTS];
-    const float* b_base[B_SLOTS];
-    if (AKC) {
+    // ---- per-thread staging slots: base pointers that do not depend on the chunk -----------------------
+    const float* a_base[SA::SLOTS];
+    const float* b_base[SB::SLOTS];
 #pragma unroll
-        for (int s = 0; s < A_SLOTS; ++s) {
-            int slot = tid + s * DPP_THREADS;
-            int gi = row0 + (slot >> 2);
-            a_base[s] = (slot < BM * 4 && gi < M) ? d.A + (size_t)dpp_map_row(d.mapA, gi) * d.lda : nullptr;
+    for (int s = 0; s < SA::SLOTS; ++s) {
+        int slot = tid + s * DPP_THREADS;
+        a_base[s] = nullptr;
+        if (AKC) {
+            int gi = row0 + slot / SA::QK;
+            if (slot < BM * SA::QK && gi < M) a_base[s] = d.A + (size_t)dpp_map_row(d.mapA, gi) * d.lda;
+        } else {
+            int gi = row0 + (slot % (BM / 4)) * 4;
+            if (slot < BKT * (BM / 4) && gi < M) a_base[s] = d.A + gi;
         }
     }
-    if (BKC) {
 #pragma unroll
-        for (int s = 0; s < B_SLOTS; ++s) {
-            int slot = tid + s * DPP_THREADS;
-            int gj = col0 + (slot >> 2);
-            b_base[s] = (slot < BN * 4 && gj < N) ? d.B + (size_t)gj * d.ldb : nullptr;
+    for (int s = 0; s < SB::SLOTS; ++s) {
+        int slot = tid + s * DPP_THREADS;
+        b_base[s] = nullptr;
+        if (BKC) {
+            int gj = col0 + slot / SB::QK;
+            if (slot < BN * SB::QK && gj < N) b_base[s] = d.B + (size_t)gj * d.ldb;
+        } else {
+            int gj = col0 + (slot % (BN / 4)) * 4;
+            if (slot < BKT * (BN / 4) && gj < N) b_base[s] = d.B + gj;
         }
     }
+
+    float4 ra[SA::SLOTS], rb[SB::SLOTS];
+    auto fetch = [&](int kc) {
+#pragma unroll
+        for (int s = 0; s < SA::SLOTS; ++s) {
+            int slot = tid + s * DPP_THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_base[s] != nullptr) {
+                if (AKC) {
+                    int k = kc + (slot % SA::QK) * 4;
+                    if (k < k_end) v = act4_masked(load4(a_base[s] + k, k, k_end, ga.vecA), d.actA, k, k_end);
+                } else {
+                    int k = kc + slot / (BM / 4), gi = row0 + (slot % (BM / 4)) * 4;
+                    if (k < k_end)
+                        v = act4_masked(load4(a_base[s] + (size_t)dpp_map_row(d.mapA, k) * d.lda, gi, M, ga.vecA), d.actA, gi, M);
+                }
+            }
+            ra[s] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < SB::SLOTS; ++s) {
+            int slot = tid + s * DPP_THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_base[s] != nullptr) {
+                if (BKC) {
+                    int k = kc + (slot % SB::QK) * 4;
+                    if (k < k_end) v = act4_masked(load4(b_base[s] + k, k, k_end, ga.vecB), d.actB, k, k_end);
+                } else {
+                    int k = kc + slot / (BN / 4), gj = col0 + (slot % (BN / 4)) * 4;
+                    if (k < k_end)
+                        v = act4_masked(load4(b_base[s] + (size_t)dpp_map_row(d.mapB, k) * d.ldb, gj, N, ga.vecB), d.actB, gj, N);
+                }
+            }
+            rb[s] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int s = 0; s < SA::SLOTS; ++s) {
+            int slot = tid + s * DPP_THREADS;
+            if (AKC) { if (slot < BM * SA::QK) *reinterpret_cast<float4*>(&As[(slot / SA::QK) * LDA_ + (slot % SA::QK) * 4]) = ra[s]; }
+            else { if (slot < BKT * (BM / 4)) *reinterpret_cast<float4*>(&As[(slot / (BM / 4)) * LDA_ + (slot % (BM / 4)) * 4]) = ra[s]; }
+        }
+#pragma unroll
+        for (int s = 0; s < SB::SLOTS; ++s) {
+            int slot = tid + s * DPP_THREADS;
+            if (BKC) { if (slot < BN * SB::QK) *reinterpret_cast<float4*>(&Bs[(slot / SB::QK) * LDB_ + (slot % SB::QK) * 4]) = rb[s]; }
+            else { if (slot < BKT * (BN / 4)) *reinterpret_cast<float4*>(&Bs[(slot / (BN / 4)) * LDB_ + (slot % (BN / 4)) * 4]) = rb[s]; }
+        }
+    };
 
     f32x4 acc[RM][CN];
 #pragma unroll
@@ -100,106 +166,46 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
 #pragma unroll
         for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int kc = k_begin; kc < k_end; kc += BK) {
-        // ---- stage A ----
-        if (AKC) {
-#pragma unroll
-            for (int s = 0; s < A_SLOTS; ++s) {
-                int slot = tid + s * DPP_THREADS;
-                if (slot < BM * 4) {
-                    int r = slot >> 2, c4 = slot & 3;
-                    int k = kc + c4 * 4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a_base[s] != nullptr && k < k_end) {
-                        v = load4(a_base[s] + k, k, k_end, ga.vecA);
-                        v = act4_masked(v, d.actA, k, k_end);
-                    }
-                    *reinterpret_cast<float4*>(&As[r * LDK + c4 * 4]) = v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < A_SLOTS; ++s) {
-                int slot = tid + s * DPP_THREADS;
-                if (slot < BM * 4) {
-                    int rk = slot / (BM / 4), c4 = slot % (BM / 4);
-                    int k = kc + rk, gi = row0 + c4 * 4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k < k_end && gi < M) {
-                        const float* p = d.A + (size_t)dpp_map_row(d.mapA, k) * d.lda + gi;
-                        v = load4(p, gi, M, ga.vecA);
-                        v = act4_masked(v, d.actA, gi, M);
-                    }
-                    *reinterpret_cast<float4*>(&As[rk * LDAM + c4 * 4]) = v;
-                }
-            }
-        }
-        // ---- stage B ----
-        if (BKC) {
-#pragma unroll
-            for (int s = 0; s < B_SLOTS; ++s) {
-                int slot = tid + s * DPP_THREADS;
-                if (slot < BN * 4) {
-                    int r = slot >> 2, c4 = slot & 3;
-                    int k = kc + c4 * 4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (b_base[s] != nullptr && k < k_end) {
-                        v = load4(b_base[s] + k, k, k_end, ga.vecB);
-                        v = act4_masked(v, d.actB, k, k_end);
-                    }
-                    *reinterpret_cast<float4*>(&Bs[r * LDK + c4 * 4]) = v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < B_SLOTS; ++s) {
-                int slot = tid + s * DPP_THREADS;
-                if (slot < BN * 4) {
-                    int rk = slot / (BN / 4), c4 = slot % (BN / 4);
-                    int k = kc + rk, gj = col0 + c4 * 4;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (k < k_end && gj < N) {
-                        const float* p = d.B + (size_t)dpp_map_row(d.mapB, k) * d.ldb + gj;
-                        v = load4(p, gj, N, ga.vecB);
-                        v = act4_masked(v, d.actB, gj, N);
-                    }
-                    *reinterpret_cast<float4*>(&Bs[rk * LDBN + c4 * 4]) = v;
-                }
-            }
-        }
+    // Software pipeline: the global loads of chunk k+1 are issued right after the barrier that publishes chunk k and
+    // stay in flight under chunk k's MFMAs; their LDS write happens after the next barrier.
+    if (k_begin < k_end) fetch(k_begin);
+    for (int kc = k_begin; kc < k_end; kc += BKT) {
+        commit();
         __syncthreads();
-
-        // ---- fragments + MFMA: lane (l15, kq) owns k = 4*kq + t ----
-        float af[RM][4], bf[CN][4];
+        if (kc + BKT < k_end) fetch(kc + BKT);
 #pragma unroll
-        for (int rt = 0; rt < RM; ++rt) {
-            int r = wm * (BM / WM) + rt * 16 + l15;
-            if (AKC) {
-                float4 v = *reinterpret_cast<const float4*>(&As[r * LDK + kq * 4]);
-                af[rt][0] = v.x; af[rt][1] = v.y; af[rt][2] = v.z; af[rt][3] = v.w;
-            } else {
+        for (int e4 = 0; e4 < KL; e4 += 4) {
+            float af[RM][4], bf[CN][4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) af[rt][t] = As[(kq * 4 + t) * LDAM + r];
+            for (int rt = 0; rt < RM; ++rt) {
+                int r = wm * (BM / WM) + rt * 16 + l15;
+                if (AKC) {
+                    float4 v = *reinterpret_cast<const float4*>(&As[r * LDA_ + kq * KL + e4]);
+                    af[rt][0] = v.x; af[rt][1] = v.y; af[rt][2] = v.z; af[rt][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) af[rt][t] = As[(kq * KL + e4 + t) * LDA_ + r];
+                }
             }
-        }
 #pragma unroll
-        for (int ct = 0; ct < CN; ++ct) {
-            int c = wn * (BN / WN) + ct * 16 + l15;
-            if (BKC) {
-                float4 v = *reinterpret_cast<const float4*>(&Bs[c * LDK + kq * 4]);
-                bf[ct][0] = v.x; bf[ct][1] = v.y; bf[ct][2] = v.z; bf[ct][3] = v.w;
-            } else {
+            for (int ct = 0; ct < CN; ++ct) {
+                int c = wn * (BN / WN) + ct * 16 + l15;
+                if (BKC) {
+                    float4 v = *reinterpret_cast<const float4*>(&Bs[c * LDB_ + kq * KL + e4]);
+                    bf[ct][0] = v.x; bf[ct][1] = v.y; bf[ct][2] = v.z; bf[ct][3] = v.w;
+                } else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bf[ct][t] = Bs[(kq * 4 + t) * LDBN + c];
+                    for (int t = 0; t < 4; ++t) bf[ct][t] = Bs[(kq * KL + e4 + t) * LDB_ + c];
+                }
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CN; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][t], bf[ct][t], acc[rt][ct], 0, 0, 0);
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int rt = 0; rt < RM; ++rt)
-#pragma unroll
-                for (int ct = 0; ct < CN; ++ct)
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][t], bf[ct][t], acc[rt][ct], 0, 0, 0);
         __syncthreads();
     }
 
@@ -234,14 +240,32 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     }
 }
 
+// out[i] = sum_z partial[z][i] (+ bias).  Threads are laid out as CB columns x ZL z-lanes: lane zl sums z = zl, zl+ZL, ...
+// (a fixed order), then the ZL partial sums are combined through LDS in a fixed order: deterministic, and parallel in z
+// when there are many slices of a small output (filter gradients: hundreds of slices of a few thousand elements).
 __global__ __launch_bounds__(DPP_THREADS) void reduce_partials_kernel(const float* __restrict__ partial, int nz, int n,
                                                                       const float* __restrict__ bias, int nbias,
-                                                                      float* __restrict__ out) {
-    for (int i = blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += gridDim.x * DPP_THREADS) {
-        float s = partial[i];
-        for (int z = 1; z < nz; ++z) s += partial[(size_t)z * n + i];
-        if (bias) s += bias[i % nbias];
-        out[i] = s;
+                                                                      float* __restrict__ out, int ZL) {
+    __shared__ float red[DPP_THREADS];
+    const int CB = DPP_THREADS / ZL;
+    const int col = threadIdx.x % CB, zl = threadIdx.x / CB;
+    for (int i0 = blockIdx.x * CB; i0 < n; i0 += gridDim.x * CB) {
+        int i = i0 + col;
+        float s = 0.0f;
+        if (i < n)
+            for (int z = zl; z < nz; z += ZL) s += partial[(size_t)z * n + i];
+        if (ZL > 1) {
+            red[threadIdx.x] = s;
+            __syncthreads();
+            if (zl == 0) {
+                for (int j = 1; j < ZL; ++j) s += red[j * CB + col];
+            }
+        }
+        if (zl == 0 && i < n) {
+            if (bias) s += bias[i % nbias];
+            out[i] = s;
+        }
+        if (ZL > 1) __syncthreads();
     }
 }
 
@@ -249,13 +273,17 @@ template <int BM, int BN, int WM>
 int launch_layout(const GemmArgs& ga, hipStream_t st) {
     const dpp_gemm_desc& d = ga.d;
     dim3 grid(dpp_cdiv(d.M, BM), dpp_cdiv(d.N, BN), d.splitk);
-    if (d.a_kc && d.b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, true, true>), grid, dim3(DPP_THREADS), 0, st, ga);
-    else if (d.a_kc && !d.b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, true, false>), grid, dim3(DPP_THREADS), 0, st, ga);
-    else if (!d.a_kc && !d.b_kc)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, false, false>), grid, dim3(DPP_THREADS), 0, st, ga);
-    else
+    const bool k32 = ga.bk == 32;
+    if (d.a_kc && d.b_kc) {
+        if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+    } else if (d.a_kc && !d.b_kc) {
+        if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, false>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, false>), grid, dim3(DPP_THREADS), 0, st, ga);
+    } else if (!d.a_kc && !d.b_kc) {
+        // reduction over pixels / samples: long K, both operands [k][mn] -> 64-deep chunks keep 20+ KB per workgroup in flight
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false>), grid, dim3(DPP_THREADS), 0, st, ga);
+    } else
         return DPP_E_UNSUPPORTED;
     return dpp_launch_status();
 }
@@ -280,10 +308,12 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     ga.vecB = aligned16(d.B) && (d.ldb % 4 == 0);
     if ((d.actA.mode & 2) && !(aligned16(d.actA.mean) && aligned16(d.actA.scale) && aligned16(d.actA.beta))) return DPP_E_BADARG;
     if ((d.actB.mode & 2) && !(aligned16(d.actB.mean) && aligned16(d.actB.scale) && aligned16(d.actB.beta))) return DPP_E_BADARG;
+    const bool red_layout = !d.a_kc && !d.b_kc;
+    ga.bk = (d.K > 16) ? 32 : 16;
+    const int chunk = red_layout ? 64 : ga.bk;
     int kper = dpp_cdiv(d.K, d.splitk);
-    ga.Kper = dpp_cdiv(kper, BK) * BK;
-    d.splitk = dpp_cdiv(d.K, ga.Kper);          // drop empty slices
-    if (d.splitk < 1) d.splitk = 1;
+    ga.Kper = dpp_cdiv(kper, chunk) * chunk;
+    // every requested slice is written (slices beyond K hold zeros), so the caller's reduce over `splitk` slices is exact
     int bm = d.bm, bn = d.bn, wm = d.wm;
     if (bm == 0) {
         if (d.M <= 16) { bm = 16; bn = 64; wm = 1; }
@@ -313,9 +343,11 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
 extern "C" int dpp_reduce_partials(const float* partial, int nz, int n, const float* bias, int nbias, float* out,
                                    dpp_stream_t stream) {
     if (!partial || !out || nz < 1 || n < 1) return DPP_E_BADARG;
-    int blocks = dpp_cdiv(n, DPP_THREADS);
+    int ZL = 1;                                   // z-lanes: trade column parallelism for slice parallelism on small outputs
+    while (ZL < 16 && ZL * 2 <= nz && dpp_cdiv(n, DPP_THREADS / ZL) < 512) ZL *= 2;
+    int blocks = dpp_cdiv(n, DPP_THREADS / ZL);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
-                       partial, nz, n, bias, nbias > 0 ? nbias : 1, out);
+                       partial, nz, n, bias, nbias > 0 ? nbias : 1, out, ZL);
     return dpp_launch_status();
 }

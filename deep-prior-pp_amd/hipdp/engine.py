@@ -222,8 +222,17 @@ def gemm_plan(M, N, K, allow_split=True):
     tiles = (-(-M // bm)) * (-(-N // bn))
     splitk = 1
     if allow_split and tiles < 256 and K >= 256:
-        splitk = int(min(max(1, 512 // tiles), max(1, K // 128)))
+        splitk = int(min(max(1, 512 // tiles), max(1, K // 128), 256))
     return (bm, bn, wm), splitk
+
+
+def wgrad_plan(Co, Ci, K):
+    """Filter gradients reduce over K = pixels (1e4..1e5) into a small [Co][Ci] tile: the reduction is split until about
+    a thousand workgroups are in flight (these kernels are HBM/latency-bound, not MFMA-bound), capped at 1024 slices."""
+    tile, _ = gemm_plan(Co, Ci, K, allow_split=False)
+    tiles = (-(-Co // tile[0])) * (-(-Ci // tile[1]))
+    splitk = int(max(1, min(1024 // tiles, K // 256, 1024)))
+    return tile, splitk
 
 
 class CompiledNet(object):
@@ -280,13 +289,21 @@ class CompiledNet(object):
             self.hyper = rt.alloc(8)
             self._emit_backward()
             self.upd.add(ops.adam(rt, self.store.w, self.store.g, self.store.m, self.store.v, self.store.n_w, self.hyper))
-            self.adam_t = 1.0
+            self.upd.add(ops.adam_tick(rt, self.hyper))
+            self._lr = None
+            self.reset_optimizer()
 
     # ------------------------------------------------------------------------------------------ helpers
     def scratch(self, nfloats):
         if self._scratch is None or self._scratch.size < nfloats:
             self._scratch = self.rt.alloc(max(nfloats, 1 << 20), zero=False)
         return self._scratch
+
+    def scratch_side(self, nfloats):
+        """Scratch of the parameter-gradient branch (runs on the side stream, so it must not share the main arena)."""
+        if getattr(self, '_scratch2', None) is None or self._scratch2.size < nfloats:
+            self._scratch2 = self.rt.alloc(max(nfloats, 1 << 20), zero=False)
+        return self._scratch2
 
     def _new_tensor(self, shape, name):
         t = TensorV(self.rt.alloc(shape, zero=False), shape, name)
@@ -577,6 +594,7 @@ class CompiledNet(object):
                 tgt.grad_written = True
             else:
                 raise NotImplementedError(kind)
+        self.bwd.join()
         if self.weight_decay and not self.net.hasDropout():
             for l in self.layers:                             # cost += wd * sum(W^2): gradient 2*wd*W
                 if hasattr(l, 'W'):
@@ -585,9 +603,9 @@ class CompiledNet(object):
     def _bias_grad(self, dY, rows, C, gslot):
         rpb = max(32, -(-rows // 256))
         nb = -(-rows // rpb)
-        part = self.scratch(nb * C)
-        self.bwd.add(ops.colsum_partial(self.rt, dY, rows, C, rpb, part))
-        self.bwd.add(ops.reduce_partials(self.rt, part, nb, C, gslot))
+        part = self.scratch_side(nb * C)
+        self.bwd.add(ops.colsum_partial(self.rt, dY, rows, C, rpb, part), side=True)
+        self.bwd.add(ops.reduce_partials(self.rt, part, nb, C, gslot), side=True)
 
     def _bwd_conv(self, layer, io, src, dY):
         rt, st = self.rt, self.store
@@ -600,17 +618,21 @@ class CompiledNet(object):
         gW, gb = st.view(layer.W, 'g'), st.view(layer.b, 'g')
         if io.get('residual') is not None:
             io['residual'].pending.append(dY)                 # identity path of the fused residual add
+        # parameter gradients only READ dY / the forward activations, so they run as a parallel branch on the side
+        # stream while the main stream continues with the data-gradient chain
+        self.bwd.fork()
         self._bias_grad(dY, M, Co, gb)
         need_dx = src.base is not self.x_in
         if k == (1, 1):
             mp = RowMap.strided(s, Ho, Wo, Hi, Wi) if s != 1 else None
             # filter gradient dW[o][c] = sum_m dY[m][o] * act(X)[map(m)][c]
-            tile, splitk = gemm_plan(Co, Ci, M)
-            part = self.scratch(splitk * Co * Ci)
+            tile, splitk = wgrad_plan(Co, Ci, M)
+            part = self.scratch_side(splitk * Co * Ci)
             self.bwd.add(ops.gemm(rt, dY, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actB=act,
-                                  splitk=splitk, partial=part if splitk > 1 else None, tile=tile, name='wgrad1x1_%d' % layer.layerNum))
+                                  splitk=splitk, partial=part if splitk > 1 else None, tile=tile, name='wgrad1x1_%d' % layer.layerNum),
+                         side=True)
             if splitk > 1:
-                self.bwd.add(ops.reduce_partials(rt, part, splitk, Co * Ci, gW))
+                self.bwd.add(ops.reduce_partials(rt, part, splitk, Co * Ci, gW), side=True)
             if need_dx:
                 tgt, dst = self._view_grad(src)
                 acc = tgt.grad_written
@@ -623,9 +645,9 @@ class CompiledNet(object):
         else:
             bm = 64
             nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, Hi, Wi, bm)
-            part = self.scratch(nblk * Co * 9 * Ci)
-            self.bwd.add(ops.conv3x3_wgrad(rt, src.base.buf, N, Hi, Wi, Ci, dY, Co, part, actX=act, bm=bm))
-            self.bwd.add(ops.reduce_partials(rt, part, nblk, Co * 9 * Ci, gW))
+            part = self.scratch_side(nblk * Co * 9 * Ci)
+            self.bwd.add(ops.conv3x3_wgrad(rt, src.base.buf, N, Hi, Wi, Ci, dY, Co, part, actX=act, bm=bm), side=True)
+            self.bwd.add(ops.reduce_partials(rt, part, nblk, Co * 9 * Ci, gW), side=True)
             if need_dx:
                 tgt, dst = self._view_grad(src)
                 acc = tgt.grad_written
@@ -641,16 +663,23 @@ class CompiledNet(object):
         Nout = layer.cfgParams.outputDim[1]
         gW, gb = st.view(layer.W, 'g'), st.view(layer.b, 'g')
         act = self._act(src)
+        self.bwd.fork()
         self._bias_grad(dY, Nb, Nout, gb)
         tile, _ = gemm_plan(K, Nout, Nb, allow_split=False)
         self.bwd.add(ops.gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, tile=tile,
-                              name='fc_wgrad_%d' % layer.layerNum))
+                              name='fc_wgrad_%d' % layer.layerNum), side=True)
         if src.base is not self.x_in:
             tgt, dst = self._view_grad(src)
             acc = tgt.grad_written
-            tile, _ = gemm_plan(Nb, K, Nout, allow_split=False)
-            self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, Nb, K, Nout, 1, 1, Nout, Nout, K, residual=dst if acc else None, tile=tile,
-                                  name='fc_dgrad_%d' % layer.layerNum))
+            tile, splitk = gemm_plan(Nb, K, Nout, allow_split=not acc)
+            if splitk > 1:
+                part = self.scratch(splitk * Nb * K)
+                self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), None, Nb, K, Nout, 1, 1, Nout, Nout, K, splitk=splitk, partial=part,
+                                      tile=tile, name='fc_dgrad_%d' % layer.layerNum))
+                self.bwd.add(ops.reduce_partials(rt, part, splitk, Nb * K, dst))
+            else:
+                self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, Nb, K, Nout, 1, 1, Nout, Nout, K, residual=dst if acc else None,
+                                      tile=tile, name='fc_dgrad_%d' % layer.layerNum))
             tgt.grad_written = True
 
     def _bwd_stem(self, layer, io, dY):
@@ -658,12 +687,13 @@ class CompiledNet(object):
         N, H, W, _ = self.in_shape
         Co = layer.cfgParams.nFilters
         out = io['out']
+        self.bwd.fork()
         self._bias_grad(dY, out.rows, Co, st.view(layer.b, 'g'))
         tpb = 8
         nblk = rt.lib.dpp_stem_wgrad_blocks(N, H, W, tpb)
-        part = self.scratch(nblk * Co * 25)
-        self.bwd.add(ops.stem_wgrad(rt, self.x_in.buf, N, H, W, dY, io['argmax'], Co, part, tpb))
-        self.bwd.add(ops.reduce_partials(rt, part, nblk, Co * 25, st.view(layer.W, 'g')))
+        part = self.scratch_side(nblk * Co * 25)
+        self.bwd.add(ops.stem_wgrad(rt, self.x_in.buf, N, H, W, dY, io['argmax'], Co, part, tpb), side=True)
+        self.bwd.add(ops.reduce_partials(rt, part, nblk, Co * 25, st.view(layer.W, 'g')), side=True)
 
     # ------------------------------------------------------------------------------------------ execution
     def set_input(self, x):
@@ -676,28 +706,37 @@ class CompiledNet(object):
     def forward(self, x=None):
         if x is not None:
             self.set_input(x)
-        self.fwd.run(self.rt.stream)
+        self.fwd.run(self.rt)
         return self.out.buf.get()
 
-    def adam_hyper(self, lr):
-        """The scalar terms of optimizer.py:69-84 in float32 (python-float constants become floatX constants)."""
+    def reset_optimizer(self, lr=0.0):
+        """ADAM state of optimizer.py:58-90: t = 1, m = v = 0; python-float constants become floatX (float32) constants,
+        so gamma = 1 - 1e-8 is exactly 1 as in the reference."""
         f = np.float32
-        t = f(self.adam_t)
-        b1, b2, eps, gamma = f(0.9), f(0.999), f(1e-8), f(1 - 1e-8)
-        b1t = b1 * gamma ** (t - f(1.))
-        return np.array([f(lr), b1t, f(1.) - b1t, b2, f(1.) - b2, f(1.) - b1 ** t, f(1.) - b2 ** t, eps], np.float32)
+        self.hyper.set(np.array([f(lr), f(1.0), f(0.9), f(0.999), f(1e-8), f(1 - 1e-8), 0, 0], np.float32))
+        self.store.m.zero()
+        self.store.v.zero()
+        self._lr = float(lr)
 
-    def train_step_device(self, lr, allreduce=None):
-        """forward + loss + backward (+ gradient all-reduce) + ADAM on the data already in x_in / y_in."""
-        st = self.rt.stream
-        self.hyper.set(self.adam_hyper(lr))
+    def set_lr(self, lr):
+        if self._lr != float(np.float32(lr)):
+            self.hyper.view(0, (1,)).set(np.array([lr], np.float32))
+            self._lr = float(np.float32(lr))
+
+    def run_step_plans(self, allreduce=None):
+        """forward + loss + backward (+ gradient all-reduce) + ADAM on x_in / y_in; no host<->device traffic, so the
+        whole sequence can be captured into a hipGraph (runtime.capture) and replayed."""
+        st = self.rt
         self.fwd.run(st)
         self.lossplan.run(st)
         self.bwd.run(st)
         if allreduce is not None:
             allreduce(self.store.g)
         self.upd.run(st)
-        self.adam_t += 1.0
+
+    def train_step_device(self, lr, allreduce=None):
+        self.set_lr(lr)
+        self.run_step_plans(allreduce)
 
     def train_step(self, x, y, lr):
         self.set_input(x)
@@ -709,7 +748,7 @@ class CompiledNet(object):
         """forward + loss + backward only (for the parity tests): returns (cost, out)."""
         self.set_input(x)
         self.y_in.set(np.asarray(y, np.float32).reshape(self.N, self.out_dim))
-        st = self.rt.stream
+        st = self.rt
         self.fwd.run(st)
         self.lossplan.run(st)
         self.bwd.run(st)
@@ -719,9 +758,13 @@ class CompiledNet(object):
         """Deterministic forward + cost + error on one batch (validation functions of setupValidate)."""
         self.set_input(x)
         self.y_in.set(np.asarray(y, np.float32).reshape(self.N, self.out_dim))
-        self.fwd.run(self.rt.stream)
-        self.lossplan.run(self.rt.stream)
+        self.fwd.run(self.rt)
+        self.lossplan.run(self.rt)
         return float(self.cost.get()[0]), float(self.err.get()[0])
 
     def num_launches(self):
         return dict(forward=len(self.fwd), backward=len(self.bwd), update=len(self.upd))
+
+    def all_launches(self):
+        return [('fwd', o) for o in self.fwd.launches()] + [('loss', o) for o in self.lossplan.launches()] + \
+               [('bwd', o) for o in self.bwd.launches()] + [('upd', o) for o in self.upd.launches()]

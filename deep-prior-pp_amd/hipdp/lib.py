@@ -79,6 +79,8 @@ SIGNATURES = {
     'dpp_loss_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_error_l2': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, stream_t]),
+    'dpp_adam_tick': (C.c_int, [C.c_void_p, stream_t]),
+    'dpp_counter_add': (C.c_int, [C.c_void_p, C.c_ulonglong, stream_t]),
     'dpp_axpy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_size_t, stream_t]),
     'dpp_sumsq': (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_int, stream_t]),
     'dpp_scale': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_size_t, stream_t]),
@@ -89,7 +91,7 @@ SIGNATURES = {
     'dpp_augment_prepare': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 5 + [C.c_int, C.c_ulonglong,
                                       C.c_ulonglong, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                                      C.c_void_p, C.c_void_p, stream_t]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_augment_warp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
 }
 

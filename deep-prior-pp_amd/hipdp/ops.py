@@ -11,10 +11,12 @@ from .lib import Act, GemmDesc, RowMap, check
 
 
 class Launch(object):
-    __slots__ = ('fn', 'args', 'keep', 'name')
+    """One prepared kernel launch.  `meta` = dict(kernel=<family>, flops=<algorithmic flops>, bytes=<algorithmic HBM
+    bytes>) is what bench.py's roofline accounting reads."""
+    __slots__ = ('fn', 'args', 'keep', 'name', 'meta')
 
-    def __init__(self, fn, args, keep, name):
-        self.fn, self.args, self.keep, self.name = fn, args, keep, name
+    def __init__(self, fn, args, keep, name, meta=None):
+        self.fn, self.args, self.keep, self.name, self.meta = fn, args, keep, name, meta
 
     def __call__(self, stream):
         st = self.fn(*self.args, stream)
@@ -22,28 +24,64 @@ class Launch(object):
             check(st, self.name)
 
 
+class Fork(object):
+    """Marker: from here on, launches added with side=True run on the side stream, which first waits for everything
+    issued so far on the main stream."""
+    name = 'fork'
+    meta = None
+
+
+class Join(object):
+    """Marker: the main stream waits for everything issued so far on the side stream."""
+    name = 'join'
+    meta = None
+
+
 class Plan(object):
-    """An ordered list of launches replayed on one stream."""
+    """An ordered list of launches.  Every launch belongs to the main stream or (side=True) to an auxiliary stream that
+    the runtime provides; Fork / Join markers order the two (event wait), which is also what a hipGraph capture records
+    as parallel branches."""
 
     def __init__(self, name=''):
         self.name = name
-        self.ops = []
+        self.ops = []          # (op, side)
+        self.uses_side = False
 
-    def add(self, op):
+    def add(self, op, side=False):
         if op is not None:
-            self.ops.append(op)
+            self.ops.append((op, side))
+            self.uses_side = self.uses_side or side
         return op
 
-    def extend(self, ops):
-        for o in ops:
-            self.add(o)
+    def fork(self):
+        self.ops.append((Fork(), False))
 
-    def run(self, stream):
-        for op in self.ops:
-            op(stream)
+    def join(self):
+        self.ops.append((Join(), False))
+
+    def launches(self):
+        return [o for (o, _) in self.ops if isinstance(o, Launch)]
+
+    def run(self, rt_or_stream):
+        """rt_or_stream: a runtime (multi-stream aware) or a raw stream handle (single stream, side ops inline)."""
+        rt = rt_or_stream if hasattr(rt_or_stream, 'stream') else None
+        if rt is None or not self.uses_side or not getattr(rt, 'has_side_stream', False):
+            st = rt.stream if rt is not None else rt_or_stream
+            for op, _ in self.ops:
+                if isinstance(op, Launch):
+                    op(st)
+            return
+        main, side = rt.stream, rt.side_stream
+        for op, on_side in self.ops:
+            if isinstance(op, Launch):
+                op(side if on_side else main)
+            elif isinstance(op, Fork):
+                rt.side_wait_main()
+            else:
+                rt.main_wait_side()
 
     def __len__(self):
-        return len(self.ops)
+        return len(self.launches())
 
 
 def _p(buf):
@@ -70,12 +108,14 @@ def gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, mapA=None, mapB=N
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.splitk, d.partial = int(splitk), _p(partial)
     d.bm, d.bn, d.wm = tile
-    return Launch(rt.lib.dpp_gemm, (C.byref(d),), (d, A, B, Cbuf, bias, residual, partial, actA, actB), name)
+    meta = dict(kernel='gemm_mfma_f32', flops=2.0 * M * N * K,
+                bytes=4.0 * (M * K + K * N + M * N * (max(1, splitk) if splitk > 1 else 1) + (M * N if residual is not None else 0)))
+    return Launch(rt.lib.dpp_gemm, (C.byref(d),), (d, A, B, Cbuf, bias, residual, partial, actA, actB), name, meta)
 
 
 def reduce_partials(rt, partial, nz, n, out, bias=None, nbias=1, name='reduce_partials'):
     return Launch(rt.lib.dpp_reduce_partials, (partial.ptr, int(nz), int(n), _p(bias), int(nbias), out.ptr),
-                  (partial, out, bias), name)
+                  (partial, out, bias), name, dict(kernel='reduce_partials', flops=float(nz) * n, bytes=4.0 * (nz + 1) * n))
 
 
 def _actp(a):
@@ -83,8 +123,11 @@ def _actp(a):
 
 
 def conv3x3(rt, X, N, H, W, Ci, Wk, Co, Y, actX=None, bias=None, residual=None, bm=0, name='conv3x3'):
+    px = float(N) * H * W
+    meta = dict(kernel='conv3x3_mfma_f32', flops=2.0 * px * 9 * Ci * Co,
+                bytes=4.0 * (px * (Ci + Co + (Co if residual is not None else 0)) + 9 * Ci * Co))
     return Launch(rt.lib.dpp_conv3x3, (X.ptr, N, H, W, Ci, _actp(actX), Wk.ptr, Co, _p(bias), _p(residual), Y.ptr, bm),
-                  (X, Wk, Y, actX, bias, residual), name)
+                  (X, Wk, Y, actX, bias, residual), name, meta)
 
 
 def conv3x3_wtrans(rt, Wk, Co, Ci, Wd, name='conv3x3_wtrans'):
@@ -92,28 +135,36 @@ def conv3x3_wtrans(rt, Wk, Co, Ci, Wd, name='conv3x3_wtrans'):
 
 
 def conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, partial, actX=None, bm=64, name='conv3x3_wgrad'):
+    px = float(N) * H * W
+    nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, bm)
+    meta = dict(kernel='conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co, bytes=4.0 * (px * (Ci + Co) + nblk * 9.0 * Ci * Co))
     return Launch(rt.lib.dpp_conv3x3_wgrad, (X.ptr, N, H, W, Ci, _actp(actX), dY.ptr, Co, partial.ptr, bm),
-                  (X, dY, partial, actX), name)
+                  (X, dY, partial, actX), name, meta)
 
 
 def stem_fwd(rt, X, N, H, W, Wk, bias, Co, Y, argmax, name='stem_fwd'):
-    return Launch(rt.lib.dpp_stem_fwd, (X.ptr, N, H, W, Wk.ptr, bias.ptr, Co, Y.ptr, _p(argmax)), (X, Wk, bias, Y, argmax), name)
+    px = float(N) * H * W
+    return Launch(rt.lib.dpp_stem_fwd, (X.ptr, N, H, W, Wk.ptr, bias.ptr, Co, Y.ptr, _p(argmax)), (X, Wk, bias, Y, argmax), name,
+                  dict(kernel='stem_fwd_mfma_f32', flops=2.0 * px * 25 * Co, bytes=4.0 * px + px / 4 * Co * 5.0))
 
 
 def stem_wgrad(rt, X, N, H, W, dY, argmax, Co, partial, tiles_per_block, name='stem_wgrad'):
+    px = float(N) * H * W
     return Launch(rt.lib.dpp_stem_wgrad, (X.ptr, N, H, W, dY.ptr, argmax.ptr, Co, partial.ptr, tiles_per_block),
-                  (X, dY, argmax, partial), name)
+                  (X, dY, argmax, partial), name, dict(kernel='stem_wgrad', flops=2.0 * px / 4 * Co * 25, bytes=4.0 * px + px / 4 * Co * 5.0))
 
 
 def bn_stats_partial(rt, X, M, Cc, rpb, partial, name='bn_stats_partial'):
-    return Launch(rt.lib.dpp_bn_stats_partial, (X.ptr, M, Cc, rpb, partial.ptr), (X, partial), name)
+    return Launch(rt.lib.dpp_bn_stats_partial, (X.ptr, M, Cc, rpb, partial.ptr), (X, partial), name,
+                  dict(kernel='bn_stats_partial', flops=3.0 * M * Cc, bytes=4.0 * M * Cc))
 
 
 def bn_finalize(rt, partial, nb, M, rpb, Cc, gamma, eps, mean, inv_std, scale, run_mean=None, run_inv_std=None, alpha=0.0,
                 name='bn_finalize'):
     return Launch(rt.lib.dpp_bn_finalize, (partial.ptr, nb, M, rpb, Cc, gamma.ptr, float(eps), mean.ptr, inv_std.ptr, scale.ptr,
                                            _p(run_mean), _p(run_inv_std), float(alpha)),
-                  (partial, gamma, mean, inv_std, scale, run_mean, run_inv_std), name)
+                  (partial, gamma, mean, inv_std, scale, run_mean, run_inv_std), name,
+                  dict(kernel='bn_finalize', flops=0.0, bytes=8.0 * nb * Cc))
 
 
 def bn_eval_coeffs(rt, gamma, run_mean, run_inv_std, Cc, mean, inv_std, scale, name='bn_eval_coeffs'):
@@ -123,21 +174,24 @@ def bn_eval_coeffs(rt, gamma, run_mean, run_inv_std, Cc, mean, inv_std, scale, n
 
 def bn_bwd_reduce(rt, dA, X, M, Cc, mean, inv_std, scale, beta, relu, G, rpb, partial, name='bn_bwd_reduce'):
     return Launch(rt.lib.dpp_bn_bwd_reduce, (dA.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, beta.ptr, int(relu), G.ptr, rpb,
-                                             partial.ptr), (dA, X, mean, inv_std, scale, beta, G, partial), name)
+                                             partial.ptr), (dA, X, mean, inv_std, scale, beta, G, partial), name,
+                  dict(kernel='bn_bwd_reduce', flops=8.0 * M * Cc, bytes=12.0 * M * Cc))
 
 
 def bn_bwd_finalize(rt, partial, nb, M, Cc, dbeta, dgamma, c1, c2, name='bn_bwd_finalize'):
     return Launch(rt.lib.dpp_bn_bwd_finalize, (partial.ptr, nb, M, Cc, dbeta.ptr, dgamma.ptr, c1.ptr, c2.ptr),
-                  (partial, dbeta, dgamma, c1, c2), name)
+                  (partial, dbeta, dgamma, c1, c2), name, dict(kernel='bn_bwd_finalize', flops=0.0, bytes=8.0 * nb * Cc))
 
 
 def bn_bwd_apply(rt, G, X, M, Cc, mean, inv_std, scale, c1, c2, dX, add=None, name='bn_bwd_apply'):
     return Launch(rt.lib.dpp_bn_bwd_apply, (G.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, c1.ptr, c2.ptr, _p(add), dX.ptr),
-                  (G, X, mean, inv_std, scale, c1, c2, add, dX), name)
+                  (G, X, mean, inv_std, scale, c1, c2, add, dX), name,
+                  dict(kernel='bn_bwd_apply', flops=6.0 * M * Cc, bytes=(16.0 if add is not None else 12.0) * M * Cc))
 
 
 def colsum_partial(rt, X, M, Cc, rpb, partial, name='colsum_partial'):
-    return Launch(rt.lib.dpp_colsum_partial, (X.ptr, M, Cc, rpb, partial.ptr), (X, partial), name)
+    return Launch(rt.lib.dpp_colsum_partial, (X.ptr, M, Cc, rpb, partial.ptr), (X, partial), name,
+                  dict(kernel='colsum_partial', flops=1.0 * M * Cc, bytes=4.0 * M * Cc))
 
 
 def loss_sse(rt, out, y, rows, d, denom, cost, dout=None, name='loss_sse'):
@@ -149,7 +203,8 @@ def error_l2(rt, out, y, rows, d, err, name='error_l2'):
 
 
 def adam(rt, w, g, m, v, n, hyper, name='adam'):
-    return Launch(rt.lib.dpp_adam, (w.ptr, g.ptr, m.ptr, v.ptr, n, hyper.ptr), (w, g, m, v, hyper), name)
+    return Launch(rt.lib.dpp_adam, (w.ptr, g.ptr, m.ptr, v.ptr, n, hyper.ptr), (w, g, m, v, hyper), name,
+                  dict(kernel='adam', flops=12.0 * n, bytes=28.0 * n))
 
 
 def axpy(rt, y, x, alpha, n, name='axpy'):
@@ -170,17 +225,19 @@ def relu_bwd(rt, dy, pre, g, n, a=1.0, mask=None, name='relu_bwd'):
 
 def augment_prepare(rt, img, com3d, cube, Mcrop, gt3d, B, J, dsz, cam, records, out_y, mode=None, off=None, rot=None, sc=None,
                     mode_table=None, n_modes=0, seed=0, counter=0, sigma_com=5., sigma_sc=0.02, rot_range=180.,
-                    pca_mean=None, pca_comp=None, E=0, out_mode=None, name='augment_prepare'):
+                    pca_mean=None, pca_comp=None, E=0, out_mode=None, counter_dev=None, name='augment_prepare'):
     fx, fy, ux, uy, flip = cam
     return Launch(rt.lib.dpp_augment_prepare,
                   (img.ptr, com3d.ptr, cube.ptr, Mcrop.ptr, gt3d.ptr, B, J, dsz, _p(mode), _p(off), _p(rot), _p(sc), _p(mode_table),
                    n_modes, seed, counter, float(sigma_com), float(sigma_sc), float(rot_range), float(fx), float(fy), float(ux),
-                   float(uy), int(flip), _p(pca_mean), _p(pca_comp), E, records.ptr, out_y.ptr, _p(out_mode)),
-                  (img, com3d, cube, Mcrop, gt3d, mode, off, rot, sc, mode_table, pca_mean, pca_comp, records, out_y, out_mode), name)
+                   float(uy), int(flip), _p(pca_mean), _p(pca_comp), E, records.ptr, out_y.ptr, _p(out_mode), _p(counter_dev)),
+                  (img, com3d, cube, Mcrop, gt3d, mode, off, rot, sc, mode_table, pca_mean, pca_comp, records, out_y, out_mode,
+                   counter_dev), name)
 
 
 def augment_warp(rt, img, records, B, dsz, out, name='augment_warp'):
-    return Launch(rt.lib.dpp_augment_warp, (img.ptr, records.ptr, B, dsz, out.ptr), (img, records, out), name)
+    return Launch(rt.lib.dpp_augment_warp, (img.ptr, records.ptr, B, dsz, out.ptr), (img, records, out), name,
+                  dict(kernel='augment_warp', flops=40.0 * B * dsz * dsz, bytes=8.0 * B * dsz * dsz))
 
 
 def fill_zero(rt, buf, name='fill_zero'):
@@ -189,3 +246,11 @@ def fill_zero(rt, buf, name='fill_zero'):
 
 def bernoulli_mask(rt, mask, n, keep, seed, counter, name='bernoulli_mask'):
     return Launch(rt.lib.dpp_bernoulli_mask, (mask.ptr, n, float(keep), int(seed), int(counter)), (mask,), name)
+
+
+def adam_tick(rt, state, name='adam_tick'):
+    return Launch(rt.lib.dpp_adam_tick, (state.ptr,), (state,), name)
+
+
+def counter_add(rt, counter, inc=1, name='counter_add'):
+    return Launch(rt.lib.dpp_counter_add, (counter.ptr, int(inc)), (counter,), name)

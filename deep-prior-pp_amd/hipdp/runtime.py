@@ -59,6 +59,8 @@ class TorchHipRuntime(object):
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
         self.lib = _lib.load(lib_path)
         self.is_emulator = False
+        self.has_side_stream = True
+        self._side = torch.cuda.Stream(self.device)
 
     _TD = {'float32': 'float32', 'int32': 'int32', 'uint8': 'uint8', 'float64': 'float64', 'int64': 'int64'}
 
@@ -99,6 +101,33 @@ class TorchHipRuntime(object):
     @property
     def stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    @property
+    def side_stream(self):
+        return self._side.cuda_stream
+
+    def side_wait_main(self):
+        self._side.wait_stream(self.torch.cuda.current_stream(self.device))
+
+    def main_wait_side(self):
+        self.torch.cuda.current_stream(self.device).wait_stream(self._side)
+
+    def capture(self, fn, warmup=1):
+        """Capture everything `fn` launches (on the current stream and on the forked side stream) into a hipGraph and
+        return it; `graph.replay()` re-issues the whole step with one host call."""
+        t = self.torch
+        cur = t.cuda.current_stream(self.device)
+        s = t.cuda.Stream(self.device)
+        s.wait_stream(cur)
+        with t.cuda.stream(s):
+            for _ in range(warmup):
+                fn()
+        cur.wait_stream(s)
+        t.cuda.synchronize(self.device)
+        g = t.cuda.CUDAGraph()
+        with t.cuda.graph(g):
+            fn()
+        return g
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)

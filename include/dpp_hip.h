@@ -143,8 +143,10 @@ int dpp_loss_sse(const float* out, const float* y, int rows, int d, int denom, f
 /* err = mean_rows sqrt(sum_d (out-y)^2): poseregnettrainer.py:114-129 */
 int dpp_error_l2(const float* out, const float* y, int rows, int d, float* err, dpp_stream_t stream);
 /* The reference's ADAM (/root/reference/src/trainer/optimizer.py:58-90) over a flat parameter buffer.
- * hyper (device, 8 floats): lr, beta1_t, 1-beta1_t, beta2, 1-beta2, 1-beta1^t, 1-beta2^t, epsilon */
-int dpp_adam(float* w, const float* g, float* m, float* v, size_t n, const float* hyper, dpp_stream_t stream);
+ * state (device, 8 floats): lr, t, beta1, beta2, epsilon, gamma, 0, 0 -- the bias-correction terms are evaluated on the
+ * device in float32; dpp_adam_tick performs `t <- t + 1` (optimizer.py:88) after the update. */
+int dpp_adam(float* w, const float* g, float* m, float* v, size_t n, const float* state, dpp_stream_t stream);
+int dpp_adam_tick(float* state, dpp_stream_t stream);
 int dpp_axpy(float* y, const float* x, float alpha, size_t n, dpp_stream_t stream);              /* y += alpha x */
 int dpp_sumsq(const float* x, size_t n, float alpha, float* out, int accumulate, dpp_stream_t stream);
 /* y = mask ? mask*relu?(x) : a*relu?(x): DropoutLayer, /root/reference/src/net/dropoutlayer.py:98-104 */
@@ -171,7 +173,10 @@ int dpp_augment_prepare(const float* img, const float* com3d, const float* cube,
                         const int* mode_table, int n_modes, unsigned long long seed, unsigned long long counter,
                         double sigma_com, double sigma_sc, double rot_range, double fx, double fy, double ux, double uy,
                         int flip_y, const float* pca_mean, const float* pca_comp, int E, void* records, float* out_y,
-                        int* out_mode, dpp_stream_t stream);
+                        int* out_mode, const unsigned long long* counter_dev, dpp_stream_t stream);
+/* *counter += inc (device-resident draw counter added to `counter` when counter_dev != NULL, so replayed graphs draw fresh
+ * augmentation parameters every step) */
+int dpp_counter_add(unsigned long long* counter, unsigned long long inc, dpp_stream_t stream);
 int dpp_augment_warp(const float* img, const void* records, int B, int dsz, float* out, dpp_stream_t stream);
 
 #ifdef __cplusplus

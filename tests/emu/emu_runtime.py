@@ -24,6 +24,7 @@ class EmuRuntime(object):
         self.lib = _lib.load(EMU_LIB)
         self.stream = None
         self.is_emulator = True
+        self.has_side_stream = False
 
     def alloc(self, shape, dtype=np.float32, zero=True):
         shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
@@ -32,7 +33,7 @@ class EmuRuntime(object):
         off = (-raw.ctypes.data) % 64
         arr = raw[off:off + n * np.dtype(dtype).itemsize].view(dtype)
         if not zero:
-            arr.view(np.uint8)[:] = 0xA5          # poison
+            arr.view(np.uint8)[:] = 0x7F          # poison: 0x7F7F7F7F = 3.4e38 as float32 (0x7F for uint8)
         return Buffer(self, arr.ctypes.data, shape, dtype, (raw, arr))
 
     def upload(self, arr, dtype=None):

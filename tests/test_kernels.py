@@ -181,16 +181,14 @@ def test_loss_colsum_adam_elementwise(backend):
     w = rng.normal(size=n).astype(np.float32)
     wb, m, v = rt.upload(w), rt.alloc(n), rt.alloc(n)
     P, Mo, Vo, t = [w.copy()], [np.zeros(n, np.float32)], [np.zeros(n, np.float32)], 1.0
-    hyper = rt.alloc(8)
+    lr = np.float32(1e-3)
+    hyper = rt.upload(np.array([lr, 1.0, 0.9, 0.999, 1e-8, 1 - 1e-8, 0, 0], np.float32))
     for step in range(3):
         g = (rng.normal(size=n) * 10 ** rng.uniform(-6, 0, n)).astype(np.float32)
-        lr = np.float32(1e-3)
-        b1, b2, eps = np.float32(0.9), np.float32(0.999), np.float32(1e-8)
-        b1t = b1 * np.float32(1.0) ** np.float32(t - 1)
-        hyper.set(np.array([lr, b1t, np.float32(1) - b1t, b2, np.float32(1) - b2, np.float32(1) - b1 ** np.float32(t),
-                            np.float32(1) - b2 ** np.float32(t), eps], np.float32))
         ops.adam(rt, wb, rt.upload(g), m, v, n, hyper)(rt.stream)
+        ops.adam_tick(rt, hyper)(rt.stream)
         rt.synchronize()
+        assert hyper.get()[1] == step + 2
         m_prev = Mo[0].copy()
         t = L.adam_step(P, [g], Mo, Vo, t, lr)
         np.testing.assert_allclose(wb.get(), P[0], rtol=2e-6, atol=1e-9)
