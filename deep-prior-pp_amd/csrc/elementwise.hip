@@ -51,26 +51,34 @@ __global__ __launch_bounds__(DPP_THREADS) void loss_sse_kernel(const float* __re
     if (threadIdx.x == 0) cost[0] = (float)(s[0] * (double)inv_denom);
 }
 
-// mean_n sqrt(sum_d (out-y)^2): the monitor of poseregnettrainer.py:114-129 (embedding / joints).
+// err[0] = mean_rows sqrt(sum_d (out-y)^2), err[1] = max_rows of the same: the monitors of poseregnettrainer.py:114-129
+// (errors / errors_avg / errors_max).
 __global__ __launch_bounds__(DPP_THREADS) void error_l2_kernel(const float* __restrict__ out, const float* __restrict__ y, int rows,
                                                                int d, float* __restrict__ err) {
     __shared__ double s[DPP_THREADS];
-    double acc = 0.0;
+    __shared__ double smax[DPP_THREADS];
+    double acc = 0.0, mx = 0.0;
     for (int r = threadIdx.x; r < rows; r += DPP_THREADS) {
         double q = 0.0;
         for (int j = 0; j < d; ++j) {
-            double e = (double)out[r * d + j] - (double)y[r * d + j];
+            double e = (double)out[(size_t)r * d + j] - (double)y[(size_t)r * d + j];
             q += e * e;
         }
-        acc += sqrt(q);
+        q = sqrt(q);
+        acc += q;
+        mx = q > mx ? q : mx;
     }
     s[threadIdx.x] = acc;
+    smax[threadIdx.x] = mx;
     __syncthreads();
     for (int w = DPP_THREADS / 2; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        if ((int)threadIdx.x < w) {
+            s[threadIdx.x] += s[threadIdx.x + w];
+            smax[threadIdx.x] = smax[threadIdx.x + w] > smax[threadIdx.x] ? smax[threadIdx.x + w] : smax[threadIdx.x];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) err[0] = (float)(s[0] / (double)rows);
+    if (threadIdx.x == 0) { err[0] = (float)(s[0] / (double)rows); err[1] = (float)smax[0]; }
 }
 
 // ---- ADAM (optimizer.py:58-90), one launch over the flat parameter buffer -------------------------------

@@ -1,0 +1,57 @@
+"""
+Device-side crop augmentation for a whole (macro-)batch: the two fused kernels of csrc/augment.hip behind one object.
+This is what replaces the 8 worker processes + shared-memory macro-batch protocol of the reference
+(/root/reference/src/trainer/nettrainer.py:601-628, 666-689) and the per-sample loop of
+PoseRegNetTrainer.augment_poses (/root/reference/src/trainer/poseregnettrainer.py:221-264).
+"""
+import numpy as np
+
+from . import ops
+
+MODE_CODE = {'none': 0, 'com': 1, 'rot': 2, 'sc': 3}
+
+
+def camera_tuple(importer):
+    """(fx, fy, ux, uy, flip_y) of an importer object (data.importers.*) -- flip_y for the NYU / MSRA conventions."""
+    flip = bool(getattr(importer, 'flip_y', importer.__class__.__name__ in ('NYUImporter', 'MSRA15Importer')))
+    return (float(importer.fx), float(importer.fy), float(importer.ux), float(importer.uy), flip)
+
+
+class DeviceAugmenter(object):
+    def __init__(self, rt, importer, aug_modes, n, J, dsz=128, proj=None, sigma_com=None, sigma_sc=None, rot_range=None, seed=0):
+        for m in aug_modes:
+            if m not in MODE_CODE:
+                raise NotImplementedError("augmentation mode %r" % (m,))
+        self.rt, self.n, self.J, self.dsz = rt, int(n), int(J), int(dsz)
+        self.cam = camera_tuple(importer)
+        self.table = rt.upload(np.array([MODE_CODE[m] for m in aug_modes], np.int32))
+        self.n_modes = len(aug_modes)
+        self.sigma_com = 5. if sigma_com is None else sigma_com          # nettrainer.py:939-946
+        self.sigma_sc = 0.02 if sigma_sc is None else sigma_sc
+        self.rot_range = 180. if rot_range is None else rot_range
+        self.seed = int(seed)
+        self.rec = rt.alloc(self.n * rt.lib.dpp_augment_record_bytes(), np.uint8)
+        self.counter = rt.alloc(1, np.int64)
+        self.pm = self.pc = None
+        self.E = 0
+        if proj is not None:                                             # sklearn PCA: (x - mean_) . components_^T
+            self.pm = rt.upload(np.asarray(proj.mean_, np.float32))
+            self.pc = rt.upload(np.asarray(proj.components_, np.float32))
+            self.E = int(proj.components_.shape[0])
+        self.out_dim = self.E if proj is not None else self.J * 3
+
+    def build(self, img, com3d, cube, Mcrop, gt3d, out_x, out_y, explicit=None):
+        """The launch list augmenting `n` crops from the *DB buffers into out_x / out_y.  explicit = dict(mode, off, rot, sc)
+        of device buffers pins the draws (parity tests); otherwise they come from the device generator."""
+        rt = self.rt
+        kw = dict(mode_table=self.table, n_modes=self.n_modes, seed=self.seed, counter=0, counter_dev=self.counter)
+        if explicit is not None:
+            kw = dict(mode=explicit['mode'], off=explicit['off'], rot=explicit['rot'], sc=explicit['sc'])
+        a = ops.augment_prepare(rt, img, com3d, cube, Mcrop, gt3d, self.n, self.J, self.dsz, self.cam, self.rec, out_y,
+                                sigma_com=self.sigma_com, sigma_sc=self.sigma_sc, rot_range=self.rot_range, pca_mean=self.pm,
+                                pca_comp=self.pc, E=self.E, **kw)
+        w = ops.augment_warp(rt, img, self.rec, self.n, self.dsz, out_x)
+        lst = [a, w]
+        if explicit is None:
+            lst.append(ops.counter_add(rt, self.counter, 1))
+        return lst

@@ -270,7 +270,7 @@ class CompiledNet(object):
         if loss is not None:
             self.y_in = rt.alloc((self.N, self.out_dim))
             self.cost = rt.alloc(1)
-            self.err = rt.alloc(1)
+            self.err = rt.alloc(2)
             self.lossplan = Plan('loss')
             denom = self.N if loss.get('kind', 'embedding') == 'embedding' else self.N * loss['numJoints']
             if train:

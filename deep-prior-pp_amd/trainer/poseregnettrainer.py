@@ -1,1 +1,164 @@
-"""placeholder replaced below"""
+"""
+PoseRegNetTrainer / PoseRegNetTrainerParams (API of /root/reference/src/trainer/poseregnettrainer.py:44-264).
+
+setupFunctions/compileFunctions build, instead of Theano functions, two compiled engines over the SAME device-resident
+parameters: a training engine (forward with batch statistics, sum-squared-error cost, backward, ADAM) behind
+`train_model(index, lr)`, and a deterministic engine behind the validation functions.  `augment_poses` augments the
+whole resident macro-batch with the fused HIP kernels and writes `train_data_x` / `train_data_y` in place.
+"""
+import numpy
+
+from hipdp import engine, ops
+from hipdp.augmenter import DeviceAugmenter
+from net.poseregnet import PoseRegNet, PoseRegNetParams      # noqa: F401  (re-exported like the reference module)
+from trainer.nettrainer import NetTrainer, NetTrainerParams
+from trainer.optimizer import Optimizer
+
+
+class PoseRegNetTrainerParams(NetTrainerParams):
+    def __init__(self):
+        super(PoseRegNetTrainerParams, self).__init__()
+
+
+class PoseRegNetTrainer(NetTrainer):
+    def __init__(self, poseNet=None, cfgParams=None, rng=None, subfolder='./eval/', numChunks=1, runtime=None):
+        super(PoseRegNetTrainer, self).__init__(cfgParams, 5, subfolder, numChunks, runtime=runtime)
+        self.poseNet = poseNet
+        self.rng = rng if rng is not None else self.rng
+        if not isinstance(cfgParams, PoseRegNetTrainerParams):
+            raise ValueError("cfgParams must be an instance of PoseRegNetTrainerParams")
+        self.setupFunctions()
+
+    def setupFunctions(self):
+        """Cost selection of poseregnettrainer.py:84-107: numJoints == 1 -> mean_n sum_d (out-y)^2 (the PCA-embedding
+        target); otherwise mean_n mean_j sum_d; L2 weight decay only for nets without dropout."""
+        cfg = self.poseNet.cfgParams
+        if cfg.numJoints == 1 and cfg.nDims == 1:
+            raise NotImplementedError("scalar regression target")
+        if cfg.numJoints == 1:
+            self.loss_cfg = dict(kind='embedding')
+        else:
+            self.loss_cfg = dict(kind='joints', numJoints=cfg.numJoints, nDims=cfg.nDims)
+        self.params = self.poseNet.params
+        self.grads = ['d(cost)/d(%s)' % p.name for p in self.params]
+        self._augmenter = None
+
+    def compileFunctions(self, compileDebugFcts=False):
+        self.setupTrain()
+        self.compileDebugFcts = compileDebugFcts
+        if compileDebugFcts:
+            self.setupDebugFunctions()
+        self.setupValidate()
+
+    # ---- train ------------------------------------------------------------------------------------------
+    def setupTrain(self):
+        opt = Optimizer(self.grads, self.params)
+        self.updates = opt.ADAM(self.cfgParams.learning_rate)
+        print("compiling train_model() ... ")
+        wd = self.cfgParams.weightreg_factor if not self.poseNet.hasDropout() else 0.0
+        self.train_engine = engine.CompiledNet(self.poseNet, train=True, runtime=self.rt, loss=self.loss_cfg, weight_decay=wd)
+        self.eval_engine = engine.CompiledNet(self.poseNet, train=False, runtime=self.rt, loss=self.loss_cfg)
+        print("done.")
+        B = self.cfgParams.batch_size
+        te = self.train_engine
+        self._allreduce = None
+
+        def train_model(index, learning_rate):
+            self.rt.copy(te.x_in.buf, self.train_data_x.rows(index * B, B))
+            self.rt.copy(te.y_in, self.train_data_y.rows(index * B, B))
+            te.train_step_device(learning_rate, allreduce=self._allreduce)
+            return float(te.cost.get()[0])
+
+        def test_model_on_train(index):
+            return self._eval(self.train_data_x, self.train_data_y, index)[1]
+
+        self.train_model = train_model
+        self.test_model_on_train = test_model_on_train
+
+    def _eval(self, xs, ys, index):
+        B = self.cfgParams.batch_size
+        ee = self.eval_engine
+        self.rt.copy(ee.x_in.buf, xs.rows(index * B, B))
+        self.rt.copy(ee.y_in, ys.rows(index * B, B))
+        ee.fwd.run(self.rt)
+        ee.lossplan.run(self.rt)
+        return float(ee.cost.get()[0]), float(ee.err.get()[0])
+
+    # ---- validate ---------------------------------------------------------------------------------------
+    def setupValidate(self):
+        print("compiling validation_cost() ... ")
+        self.validation_cost = lambda index: self._eval(self.val_data_x, self.val_data_y, index)[0]
+        self.validation_observer.append(self.validation_cost)
+        print("compiling validation_error() ... ")
+        self.validation_error = lambda index: self._eval(self.val_data_x, self.val_data_y, index)[1]
+        self.validation_observer.append(self.validation_error)
+        print("compiling validation_error_avg() ... ")
+        if hasattr(self, 'val_data_y3D'):
+            # errors_avg / errors_max of poseregnettrainer.py:122-126: back-project through the PCA prior on the device
+            B = self.cfgParams.batch_size
+            E, D = self.pca_dataDB.shape
+            self._pca_out = self.rt.alloc((B, D))
+            self._err3d = self.rt.alloc(2)
+            ee = self.eval_engine
+            self._pca_gemm = ops.gemm(self.rt, ee.out.buf, self.pca_data.buf, self._pca_out, B, D, E, 1, 0, E, D, D, bias=self.mean_data.buf,
+                                      name='pca_backproject')
+
+            def _avgmax(index):
+                self._eval(self.val_data_x, self.val_data_y, index)
+                self._pca_gemm(self.rt.stream)
+                ops.error_l2(self.rt, self._pca_out, self.val_data_y3D.rows(index * B, B), B * (D // 3), 3, self._err3d)(self.rt.stream)
+                e = self._err3d.get()
+                return float(e[0]), float(e[1])
+
+            self.validation_error_avg = lambda index: _avgmax(index)[0]
+            self.validation_error_max = lambda index: _avgmax(index)[1]
+            self.validation_observer.append(self.validation_error_avg)
+            self.validation_observer.append(self.validation_error_max)
+        print("done.")
+
+    def setupDebugFunctions(self):
+        B = self.cfgParams.batch_size
+
+        def compute_train_descr(index):
+            ee = self.eval_engine
+            self.rt.copy(ee.x_in.buf, self.train_data_x.rows(index * B, B))
+            ee.fwd.run(self.rt)
+            return ee.out.buf.get()
+
+        self.compute_train_descr = compute_train_descr
+
+    # ---- augmentation hook ------------------------------------------------------------------------------
+    def augment_poses(self, macro_params, macro_idx, last, tidxs, idxs, new_data):
+        """Augment the samples `idxs` of the resident training set into positions `tidxs` of train_data_x / train_data_y
+        (poseregnettrainer.py:221-264).  The reference calls this per worker on a slice; here the hook is invoked once
+        per macro-batch with the full range, and two kernel launches process all of it."""
+        args = macro_params['args']
+        if args.get('normZeroOne'):
+            raise NotImplementedError("normZeroOne crops are not used by the posereg_embedding path")
+        if args.get('binarizeImage'):
+            raise NotImplementedError("binarizeImage")
+        n = len(idxs)
+        if n == 0:
+            return
+        if list(tidxs) != list(range(tidxs[0], tidxs[0] + n)) or list(idxs) != list(range(idxs[0], idxs[0] + n)):
+            raise NotImplementedError("augment_poses expects contiguous index ranges")
+        if not hasattr(self, '_aug_src'):
+            # the un-augmented crops stay resident next to the augmented macro-batch (the reference's train_data_xDB)
+            from trainer.nettrainer import DeviceData
+            self._aug_src = DeviceData(self.rt, self.train_data_xDB, 'train_data_x_orig')
+        gt = self.train_gt3Dcrop
+        J = gt.shape[1]
+        proj = args.get('proj')
+        key = (idxs[0], tidxs[0], n)
+        if self._augmenter is None or self._augmenter[0] != key:
+            aug = DeviceAugmenter(self.rt, args['di'], args['aug_modes'], n, J, dsz=self.train_data_xDB.shape[-1], proj=proj,
+                                  sigma_com=args.get('sigma_com'), sigma_sc=args.get('sigma_sc'), rot_range=args.get('rot_range'),
+                                  seed=int(self.rng.randint(1 << 30)))
+            launches = aug.build(self._aug_src.rows(idxs[0], n).reshape(n, *self.train_data_xDB.shape[-2:]),
+                                 self.train_data_com.rows(idxs[0], n), self.train_data_cube.rows(idxs[0], n),
+                                 self.train_data_M.rows(idxs[0], n).reshape(n, 9), gt.rows(idxs[0], n),
+                                 self.train_data_x.rows(tidxs[0], n).reshape(n, *self.train_data_xDB.shape[-2:]),
+                                 self.train_data_y.rows(tidxs[0], n))
+            self._augmenter = (key, aug, launches)
+        for op in self._augmenter[2]:
+            op(self.rt.stream)

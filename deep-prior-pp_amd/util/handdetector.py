@@ -1,0 +1,177 @@
+"""
+HandDetector -- the augmentation slice of /root/reference/src/util/handdetector.py (comToBounds / comToTransform
+:204-258, moveCoM / rotateHand / scaleHand / recropHand :678-803, sampleRandomPoses :805-909).
+
+The crop warps run on the MI355X through the fused augmentation kernels (csrc/augment.hip); this class keeps the
+reference's per-crop method signatures for callers and computes only the tiny 3x3 crop geometry on the host.  The
+detector / tracker / initial cropping part of the reference class (cropArea3D, detect, track, refineCoM, ...) is the
+"next" row of SURVEY.md section 8(f) and is not provided yet.
+"""
+import numpy
+
+from data.transformations import rotatePoints2D
+
+
+class HandDetector(object):
+    RESIZE_BILINEAR = 0
+    RESIZE_CV2_NN = 1
+    RESIZE_CV2_LINEAR = 2
+
+    def __init__(self, dpt, fx, fy, importer=None, refineNet=None):
+        self.dpt = dpt
+        self.maxDepth = min(1500, dpt.max())
+        self.minDepth = max(10, dpt.min())
+        self.dpt[self.dpt > self.maxDepth] = 0.
+        self.dpt[self.dpt < self.minDepth] = 0.
+        self.fx, self.fy = fx, fy
+        self.refineNet = refineNet
+        self.importer = importer
+        self.resizeMethod = self.RESIZE_CV2_NN
+
+    # ---- crop geometry (host, a handful of flops) -----------------------------------------------------------
+    def comToBounds(self, com, size):
+        """Project the metric cube around the CoM back to pixel bounds (handdetector.py:204-226)."""
+        if numpy.isclose(com[2], 0.):
+            print("Warning: CoM ill-defined!")
+            xstart = self.dpt.shape[0] // 4
+            xend = xstart + self.dpt.shape[0] // 2
+            ystart = self.dpt.shape[1] // 4
+            yend = ystart + self.dpt.shape[1] // 2
+            return xstart, xend, ystart, yend, self.minDepth, self.maxDepth
+        c0, c1, c2 = float(com[0]), float(com[1]), float(com[2])
+        zstart, zend = c2 - size[2] / 2., c2 + size[2] / 2.
+        xstart = int(numpy.floor((c0 * c2 / self.fx - size[0] / 2.) / c2 * self.fx + 0.5))
+        xend = int(numpy.floor((c0 * c2 / self.fx + size[0] / 2.) / c2 * self.fx + 0.5))
+        ystart = int(numpy.floor((c1 * c2 / self.fy - size[1] / 2.) / c2 * self.fy + 0.5))
+        yend = int(numpy.floor((c1 * c2 / self.fy + size[1] / 2.) / c2 * self.fy + 0.5))
+        return xstart, xend, ystart, yend, zstart, zend
+
+    def comToTransform(self, com, size, dsize=(128, 128)):
+        """Affine crop transform off . scale . trans (handdetector.py:228-258); the reference's Python-2 integer
+        divisions are kept as floor divisions."""
+        xstart, xend, ystart, yend, _, _ = self.comToBounds(com, size)
+        wb, hb = (xend - xstart), (yend - ystart)
+        if wb > hb:
+            s = dsize[0] / float(wb)
+            sz = (dsize[0], hb * dsize[0] // wb)
+        else:
+            s = dsize[1] / float(hb)
+            sz = (wb * dsize[1] // hb, dsize[1])
+        xs = int(numpy.floor(dsize[0] / 2. - sz[1] / 2.))
+        ys = int(numpy.floor(dsize[1] / 2. - sz[0] / 2.))
+        return numpy.array([[s, 0., s * float(-xstart) + xs], [0., s, s * float(-ystart) + ys], [0., 0., 1.]])
+
+    # ---- single-crop warps on the device ----------------------------------------------------------------------
+    def _run(self, dpt_norm, cube, com, joints3D, M, mode, off=(0., 0., 0.), rot=0., sc=1.):
+        from hipdp import ops
+        from hipdp.augmenter import MODE_CODE, camera_tuple
+        from hipdp.runtime import default_runtime
+        rt = default_runtime()
+        J = joints3D.shape[0]
+        dsz = dpt_norm.shape[0]
+        f32 = lambda a: rt.upload(numpy.ascontiguousarray(a, numpy.float32))       # noqa: E731
+        com3d = self.importer.jointImgTo3D(com)
+        rec = rt.alloc(rt.lib.dpp_augment_record_bytes(), numpy.uint8)
+        out_y, out_x = rt.alloc((1, J * 3)), rt.alloc((1, dsz, dsz))
+        img = f32(dpt_norm[None])
+        ops.augment_prepare(rt, img, f32(com3d[None]), f32(numpy.asarray(cube)[None]), f32(numpy.asarray(M).reshape(1, 9)),
+                            f32(joints3D.reshape(1, J, 3)), 1, J, dsz, camera_tuple(self.importer), rec, out_y,
+                            mode=rt.upload(numpy.array([MODE_CODE[mode]], numpy.int32)), off=rt.upload(numpy.asarray(off, numpy.float64)),
+                            rot=rt.upload(numpy.array([rot], numpy.float64)), sc=rt.upload(numpy.array([sc], numpy.float64)))(rt.stream)
+        ops.augment_warp(rt, img, rec, 1, dsz, out_x)(rt.stream)
+        rt.synchronize()
+        return out_x.get()[0], out_y.get().reshape(J, 3)
+
+    def _normalise(self, dpt, cube, com):
+        d = numpy.asarray(dpt, numpy.float32).copy()
+        d[d == 0] = com[2] + cube[2] / 2.
+        return (d - com[2]) / (cube[2] / 2.)
+
+    def moveCoM(self, dpt, cube, com, off, joints3D, M, pad_value=0):
+        """Simulate a different CoM on an already cropped image (handdetector.py:678-710).  dpt is in mm like in the
+        reference; returns (new_dpt [normalised to the NEW CoM, far plane filled], new_joints3D, new_com, Mnew)."""
+        if numpy.allclose(off, 0.):
+            return dpt, joints3D, com, M
+        new_com = self.importer.joint3DToImg(self.importer.jointImgTo3D(com) + off)
+        img, lab = self._run(self._normalise(dpt, cube, com), cube, com, numpy.asarray(joints3D, numpy.float32), M, 'com', off=off)
+        Mnew = self.comToTransform(new_com, cube, dpt.shape) if not (numpy.allclose(com[2], 0.) or numpy.allclose(new_com[2], 0.)) else M
+        return img, lab * (cube[2] / 2.), new_com, Mnew
+
+    def rotateHand(self, dpt, cube, com, rot, joints3D, pad_value=0):
+        """In-plane rotation about the crop centre (handdetector.py:712-747)."""
+        if numpy.allclose(rot, 0.):
+            return dpt, joints3D, rot
+        M = self.comToTransform(com, cube, dpt.shape)
+        img, lab = self._run(self._normalise(dpt, cube, com), cube, com, numpy.asarray(joints3D, numpy.float32), M, 'rot', rot=rot)
+        return img, lab * (cube[2] / 2.), numpy.mod(rot, 360)
+
+    def scaleHand(self, dpt, cube, com, sc, joints3D, M, pad_value=0):
+        """Re-crop with a scaled metric cube (handdetector.py:750-780)."""
+        if numpy.allclose(sc, 1.):
+            return dpt, joints3D, cube, M
+        new_cube = [s * sc for s in cube]
+        img, _ = self._run(self._normalise(dpt, cube, com), cube, com, numpy.asarray(joints3D, numpy.float32), M, 'sc', sc=sc)
+        Mnew = self.comToTransform(com, new_cube, dpt.shape) if not numpy.allclose(com[2], 0.) else M
+        return img, joints3D, new_cube, Mnew
+
+    # ---- pose-space sampling for the PCA prior (one-off set-up, host) ------------------------------------------------
+    @staticmethod
+    def sampleRandomPoses(importer, rng, base_poses, base_com, base_cube, num_poses, aug_modes, retall=False, rot3D=False,
+                          sigma_com=None, sigma_sc=None, rot_range=None):
+        """Random pose augmentation in label space only, used once to fit the 30-D PCA prior
+        (handdetector.py:805-909; main_nyu_posereg_embedding.py:86-88).  Same draws from `rng`, in the same order."""
+        sigma_com = 5. if sigma_com is None else sigma_com
+        sigma_sc = 0.02 if sigma_sc is None else sigma_sc
+        rot_range = 180. if rot_range is None else rot_range
+        if rot3D:
+            raise NotImplementedError("3-D rotation sampling needs transforms3d and is not used by the embedding scripts")
+        simple = ('none', 'rot', 'sc', 'com')
+        combo = ('rot+com', 'com+rot')
+        combo_sc = ('rot+com+sc', 'rot+sc+com')
+        assert all(m in simple + combo + combo_sc + ('sc+rot+com', 'sc+com+rot', 'com+sc+rot', 'com+rot+sc') for m in aug_modes)
+        n = int(num_poses)
+        new_poses = numpy.zeros((n, base_poses.shape[1], base_poses.shape[2]), dtype=base_poses.dtype)
+        new_com = numpy.zeros((n, 3), dtype=base_poses.dtype)
+        new_cube = numpy.zeros((n, 3), dtype=base_poses.dtype)
+        modes = rng.randint(0, len(aug_modes), n)
+        ridxs = rng.randint(0, base_poses.shape[0], n)
+        off = rng.randn(n, 3) * sigma_com
+        sc = numpy.fabs(rng.randn(n) * sigma_sc + 1.)
+        rot = rng.uniform(-rot_range, rot_range, size=(n, 3))
+        if aug_modes == ['none']:
+            out = base_poses / (base_cube[:, 2] / 2.)[:, None, None]
+            return (out, base_com, base_cube) if retall else out
+        for i in range(n):
+            mode = aug_modes[modes[i]]
+            cube, com3D, pose = base_cube[ridxs[i]], base_com[ridxs[i]], base_poses[ridxs[i]]
+            if mode == 'com':
+                new_com[i], new_cube[i] = com3D + off[i], cube
+                new_poses[i] = (pose + com3D - new_com[i]) / (new_cube[i][2] / 2.)
+            elif mode == 'rot':
+                new_com[i], new_cube[i] = com3D, cube
+                joint_2D = importer.joints3DToImg(pose + new_com[i])
+                data_2D = rotatePoints2D(joint_2D, importer.joint3DToImg(com3D)[0:2], rot[i, 0])
+                new_poses[i] = (importer.jointsImgTo3D(data_2D) - new_com[i]) / (new_cube[i][2] / 2.)
+            elif mode == 'sc':
+                new_com[i], new_cube[i] = com3D, cube * sc[i]
+                new_poses[i] = pose / (new_cube[i][2] / 2.)
+            elif mode == 'none':
+                new_com[i], new_cube[i] = com3D, cube
+                new_poses[i] = pose / (new_cube[i][2] / 2.)
+            elif mode in combo or mode in combo_sc:
+                new_com[i], new_cube[i] = com3D + off[i], cube
+                p = pose + com3D - new_com[i]
+                if mode in combo_sc:
+                    p = p * sc[i]
+                joint_2D = importer.joints3DToImg(p + com3D)
+                data_2D = rotatePoints2D(joint_2D, importer.joint3DToImg(new_com[i])[0:2], rot[i, 0])
+                new_poses[i] = (importer.jointsImgTo3D(data_2D) - com3D) / (new_cube[i][2] / 2.)
+            else:
+                raise NotImplementedError()
+        return (new_poses, new_com, new_cube, rot) if retall else new_poses
+
+    # ---- not part of the hot path yet ----------------------------------------------------------------------------------
+    def cropArea3D(self, *args, **kwargs):
+        raise NotImplementedError("initial cropping / detection is the 'next' row of SURVEY.md section 8(f)")
+
+    detect = track = refineCoM = cropArea3D

@@ -140,7 +140,7 @@ int dpp_colsum_partial(const float* X, int M, int C, int rows_per_block, float* 
 /* cost = (1/denom) sum (out-y)^2, dout = (2/denom)(out-y): /root/reference/src/trainer/poseregnettrainer.py:92-99
  * (denom = batch for the embedding loss, batch*numJoints for the joint loss); dout may be NULL */
 int dpp_loss_sse(const float* out, const float* y, int rows, int d, int denom, float* cost, float* dout, dpp_stream_t stream);
-/* err = mean_rows sqrt(sum_d (out-y)^2): poseregnettrainer.py:114-129 */
+/* err[0] = mean_rows sqrt(sum_d (out-y)^2), err[1] = max_rows: poseregnettrainer.py:114-129 (errors, errors_avg, errors_max) */
 int dpp_error_l2(const float* out, const float* y, int rows, int d, float* err, dpp_stream_t stream);
 /* The reference's ADAM (/root/reference/src/trainer/optimizer.py:58-90) over a flat parameter buffer.
  * state (device, 8 floats): lr, t, beta1, beta2, epsilon, gamma, 0, 0 -- the bias-correction terms are evaluated on the

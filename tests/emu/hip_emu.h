@@ -16,6 +16,7 @@
 //                 row=(r&3)+8*(r>>2)+4*(l>>5)
 // with a k-ordered fmaf chain (bitwise what the hardware computes).
 #pragma once
+#include <setjmp.h>
 #include <ucontext.h>
 #include <cmath>
 #include <cstdint>
@@ -59,8 +60,10 @@ enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMe
 namespace emu {
 struct Fiber {
     ucontext_t ctx;
+    jmp_buf jb;
     char* stack = nullptr;
     bool done = false;
+    bool started = false;
     dim3 tid;
     int lin = 0;
 };
@@ -69,6 +72,7 @@ struct Wave {
     int count = 0, gen = 0, alive = 0;
 };
 inline ucontext_t g_sched;
+inline jmp_buf g_sched_jb;
 inline Fiber* g_cur = nullptr;
 inline std::vector<Fiber> g_fibers;
 inline std::vector<Wave> g_waves;
@@ -80,7 +84,15 @@ inline unsigned char* g_dyn_smem = nullptr;
 inline int g_last_error = 0;
 constexpr size_t kStack = 96 * 1024;
 
-inline void yield() { swapcontext(&g_cur->ctx, &g_sched); }
+// Fibers are entered once through makecontext/setcontext; every later switch is a _setjmp/_longjmp pair (no signal-mask
+// system call), which is what makes barrier-heavy kernels emulate in reasonable time.
+inline void yield() { if (_setjmp(g_cur->jb) == 0) _longjmp(g_sched_jb, 1); }
+inline void resume(Fiber* f) {
+    if (_setjmp(g_sched_jb) == 0) {
+        if (!f->started) { f->started = true; setcontext(&f->ctx); }
+        else _longjmp(f->jb, 1);
+    }
+}
 
 inline void fiber_entry() {
     Fiber* f = g_cur;
@@ -90,7 +102,7 @@ inline void fiber_entry() {
     g_waves[f->lin >> 6].alive--;
     g_progress++;
     if (g_bar_count > 0 && g_bar_count == g_alive) { g_bar_count = 0; g_bar_gen++; }
-    swapcontext(&f->ctx, &g_sched);
+    _longjmp(g_sched_jb, 1);
 }
 
 inline void syncthreads() {
@@ -130,7 +142,7 @@ inline void run_block(std::function<void()>& body, dim3 bid, dim3 bdim, dim3 gdi
     g_alive = n; g_bar_count = 0; g_bar_gen = 0;
     for (int i = 0; i < n; ++i) {
         Fiber& f = g_fibers[i];
-        f.done = false; f.lin = i;
+        f.done = false; f.started = false; f.lin = i;
         f.tid = dim3(i % bdim.x, (i / bdim.x) % bdim.y, i / (bdim.x * bdim.y));
         g_waves[i >> 6].alive++;
         getcontext(&f.ctx);
@@ -145,7 +157,7 @@ inline void run_block(std::function<void()>& body, dim3 bid, dim3 bdim, dim3 gdi
         for (int i = 0; i < n; ++i) {
             if (g_fibers[i].done) continue;
             g_cur = &g_fibers[i];
-            swapcontext(&g_sched, &g_fibers[i].ctx);
+            resume(&g_fibers[i]);
         }
         if (g_progress == before) {
             if (++stalled > 4) { fprintf(stderr, "emu: deadlock (divergent barrier / collective) in block (%u,%u,%u)\n", bid.x, bid.y, bid.z); abort(); }

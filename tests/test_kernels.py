@@ -159,7 +159,7 @@ def test_loss_colsum_adam_elementwise(backend):
     B, D = 128, 30
     out, y = rng.normal(size=(B, D)).astype(np.float32), rng.normal(size=(B, D)).astype(np.float32)
     ob, yb = rt.upload(out), rt.upload(y)
-    cost, err, dout = rt.alloc(1), rt.alloc(1), rt.alloc((B, D), zero=False)
+    cost, err, dout = rt.alloc(1), rt.alloc(2), rt.alloc((B, D), zero=False)
     ops.loss_sse(rt, ob, yb, B, D, B, cost, dout)(rt.stream)
     ops.error_l2(rt, ob, yb, B, D, err)(rt.stream)
     rt.synchronize()
@@ -167,6 +167,7 @@ def test_loss_colsum_adam_elementwise(backend):
     np.testing.assert_allclose(cost.get()[0], c_ref, rtol=1e-6)
     np.testing.assert_allclose(dout.get(), d_ref, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(err.get()[0], L.error_embedding(out.astype('f8'), y.astype('f8')), rtol=1e-6)
+    np.testing.assert_allclose(err.get()[1], np.sqrt(((out.astype('f8') - y) ** 2).sum(1)).max(), rtol=1e-6)
     # column sums (bias gradients)
     for (M, Cc, rpb) in ((1000, 64, 128), (77, 30, 16), (40, 1024, 8)):
         X = rng.normal(size=(M, Cc)).astype(np.float32)

@@ -1,0 +1,108 @@
+"""The drop-in boundary end to end, following /root/reference/src/main_nyu_posereg_embedding.py:97-158 step by step on
+synthetic data: PoseRegNetTrainerParams / PoseRegNetTrainer.setData / addStaticData / addManagedData / compileFunctions /
+train, then the script's post-training surgery (append the PCA-prior HiddenLayer, re-point net.output, save, reload,
+computeOutput)."""
+import os
+
+import numpy as np
+import pytest
+from sklearn.decomposition import PCA
+
+from data.importers import ICVLImporter
+from hipdp import runtime as R
+from net.hiddenlayer import HiddenLayer, HiddenLayerParams
+from net.resnet import ResNet, ResNetParams
+from oracle import augment as A
+from tests.backends import BACKENDS, get_runtime
+from trainer.poseregnettrainer import PoseRegNetTrainer, PoseRegNetTrainerParams
+from util.handdetector import HandDetector
+
+
+def synth(n, size, J, seed):
+    rng = np.random.RandomState(seed)
+    cam = A.Camera.icvl()
+    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, n, cam, cube=(250., 250., 250.), joints=J, dsize=size)
+    return imgs[:, None], coms, cubes, Ms, gts
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_main_script_flow(backend, tmp_path):
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    rng = np.random.RandomState(23455)
+    size, J, B, E = 32, 16, 4, 8
+    di = ICVLImporter('../data/ICVL/')
+    train_data, train_com, train_cube, train_M, train_gt3Dcrop = synth(6, size, J, 1)
+    val_data, _, val_cube, _, val_gt3Dcrop = synth(4, size, J, 2)
+    train_gt3D = (train_gt3Dcrop / (train_cube[:, 2] / 2.)[:, None, None]).astype('float32')
+    val_gt3D = (val_gt3Dcrop / (val_cube[:, 2] / 2.)[:, None, None]).astype('float32')
+    aug_modes = ['com', 'rot', 'none']
+    pca = PCA(n_components=E)
+    pca.fit(HandDetector.sampleRandomPoses(di, rng, train_gt3Dcrop, train_com, train_cube, 200, aug_modes).reshape((-1, J * 3)))
+    train_embed = pca.transform(train_gt3D.reshape((-1, J * 3))).astype('float32')
+    val_embed = pca.transform(val_gt3D.reshape((-1, J * 3))).astype('float32')
+
+    poseNetParams = ResNetParams(type=0, nChan=1, wIn=size, hIn=size, batchSize=B, numJoints=1, nDims=E)
+    poseNet = ResNet(rng, cfgParams=poseNetParams)
+    p = PoseRegNetTrainerParams()
+    p.batch_size = B
+    p.learning_rate = 0.001
+    p.weightreg_factor = 0.0
+    p.force_macrobatch_reload = True
+    p.para_augment = True
+    p.validation_frequency = 2
+    p.snapshot_last = 1
+    p.augment_fun_params = {'fun': 'augment_poses', 'args': {'normZeroOne': False, 'di': di, 'aug_modes': aug_modes,
+                                                             'hd': HandDetector(train_data[0, 0].copy(), abs(di.fx), abs(di.fy), importer=di),
+                                                             'proj': pca}}
+    with pytest.raises(ValueError):
+        PoseRegNetTrainer(poseNet, object(), rng, str(tmp_path))
+    tr = PoseRegNetTrainer(poseNet, p, rng, str(tmp_path))
+    tr.setData(train_data, train_embed, val_data, val_embed)
+    tr.addStaticData({'val_data_y3D': val_gt3D})
+    tr.addStaticData({'pca_data': pca.components_.astype('float32'), 'mean_data': pca.mean_.astype('float32')})
+    with pytest.raises(ValueError):
+        tr.addManagedData({'train_data_cube': train_cube[:5]})
+    tr.addManagedData({'train_data_cube': train_cube, 'train_data_com': train_com, 'train_data_M': train_M.astype('float32'),
+                       'train_gt3Dcrop': train_gt3Dcrop})
+    assert tr.getNumMiniBatches() == 2 and tr.train_data_xDB.shape[0] == 8           # padded with seeded random samples
+    pad_rng = np.random.RandomState(6)
+    assert np.array_equal(tr.train_data_xDB[6], train_data[pad_rng.randint(0, 6)])
+    tr.compileFunctions(compileDebugFcts=False)
+    x_before = tr.train_data_x.get_value().copy()
+    costs, wvals, val_obs = tr.train(n_epochs=1)
+    assert len(costs) == 2 and np.all(np.isfinite(costs))
+    assert len(val_obs) == 3 and all(len(v) == 2 for v in val_obs)        # error, error_avg, error_max: initial + 1 validation
+    x_after = tr.train_data_x.get_value()
+    assert x_after.shape == x_before.shape and np.isfinite(x_after).all()
+    assert (x_after != x_before).mean() > 0.01                               # the resident macro-batch was re-augmented in place
+    assert x_after.min() >= -1.0 - 1e-5 and x_after.max() <= 1.0 + 1e-5
+    assert os.path.exists(os.path.join(str(tmp_path), 'net_last.pkl'))
+
+    # ---- post-training surgery of the script (main_nyu_posereg_embedding.py:143-158) ----
+    out_embed = poseNet.computeOutput(val_data)
+    assert out_embed.shape == (4, E)
+    cfg = HiddenLayerParams(inputDim=(B, E), outputDim=(B, J * 3), activation=None)
+    pcalayer = HiddenLayer(rng, poseNet.layers[-1].output, cfg, layerNum=len(poseNet.layers))
+    pcalayer.W.set_value(pca.components_.astype('float32'))
+    pcalayer.b.set_value(pca.mean_.astype('float32'))
+    poseNet.layers.append(pcalayer)
+    poseNet.output = pcalayer.output
+    poseNet.cfgParams.numJoints = J
+    poseNet.cfgParams.nDims = 3
+    poseNet.cfgParams.outputDim = pcalayer.cfgParams.outputDim
+    fn = os.path.join(str(tmp_path), 'network_prior.pkl')
+    poseNet.save(fn)
+    jts = poseNet.computeOutput(val_data)
+    assert jts.shape == (4, J * 3)
+    np.testing.assert_allclose(jts, out_embed.astype('f8') @ pca.components_ + pca.mean_, rtol=0, atol=2e-5)
+    # reload into a freshly built net with the same surgery: identical outputs
+    net2 = ResNet(np.random.RandomState(1), cfgParams=ResNetParams(type=0, nChan=1, wIn=size, hIn=size, batchSize=B, numJoints=1, nDims=E))
+    l2 = HiddenLayer(rng, net2.layers[-1].output, HiddenLayerParams(inputDim=(B, E), outputDim=(B, J * 3), activation=None),
+                     layerNum=len(net2.layers))
+    net2.layers.append(l2)
+    net2.output = l2.output
+    net2.cfgParams.numJoints, net2.cfgParams.nDims, net2.cfgParams.outputDim = J, 3, l2.cfgParams.outputDim
+    net2.load(fn)
+    net2.setDeterministic()
+    np.testing.assert_allclose(net2.computeOutput(val_data), jts, rtol=0, atol=1e-6)
