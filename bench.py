@@ -71,31 +71,29 @@ def main():
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--no-augment', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sync-bn', action='store_true', help='all-gather BatchNorm partial statistics across ranks (parity mode)')
     ap.add_argument('--eager', action='store_true', help='launch every kernel from Python instead of replaying hipGraphs')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-kernel-family time table to stderr')
     args = ap.parse_args()
 
     import torch
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    from hipdp import engine, ops, parallel
+    from hipdp.runtime import TorchHipRuntime
+    from net.resnet import ResNet, ResNetParams
+
+    rank, world = parallel.init_from_env('nccl')          # "nccl" is RCCL on ROCm; one rank per GPU
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
     else:
         dist = None
         torch.cuda.set_device(0)
-
-    from hipdp import engine, ops
-    from hipdp.runtime import TorchHipRuntime
-    from net.resnet import ResNet, ResNetParams
 
     rt = TorchHipRuntime()
     B = args.batch
     net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, nChan=1, wIn=128, hIn=128, batchSize=B,
                                                                       numJoints=1, nDims=30))
-    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    dp = parallel.DataParallel(rt, sync_bn=args.sync_bn) if world > 1 else None
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), dp=dp)
 
     # ---- device-resident data (different per rank: each rank owns its shard of the global minibatch) ----
     NDB, J = 8 * B, 14
@@ -141,16 +139,11 @@ def main():
     if args.no_augment:
         eng.y_in.set(np.random.RandomState(5).normal(0, 0.3, (B, 30)).astype(np.float32))
 
-    gtensor = rt._tensor(eng.store.g)
-
-    def allreduce(_buf):
-        dist.all_reduce(gtensor, op=dist.ReduceOp.AVG)
-
     eng.set_lr(1e-3)
 
     def step_body(i):
         augment(i)
-        eng.run_step_plans(allreduce=allreduce if world > 1 else None)
+        eng.run_step_plans()          # with --gpus N the flat-gradient all-reduce (RCCL) is a step of the update plan
 
     # One hipGraph per resident data slice (pointers are baked into a graph; draw counter and ADAM step count live on the
     # device, so every replay sees fresh augmentation draws and the right bias correction).  Multi-GPU runs stay eager:
@@ -253,7 +246,7 @@ def main():
                    config=dict(workload='NYU posereg_embedding ResNet (type 0, 30-D PCA prior) train step: fused augment + fwd + bwd + ADAM, '
                                         'bs%d/GPU fp32, 128x128x1 crops' % B,
                                global_batch=world * B, parallelism='dp%d' % world, augment=not args.no_augment,
-                               bn='local per-GPU batch statistics', launches=eng.num_launches(), launch_mode=mode,
+                               bn='sync (global batch statistics)' if (world > 1 and args.sync_bn) else 'local per-GPU batch statistics', launches=eng.num_launches(), launch_mode=mode,
                                step_mfma_frac=round(value / world * FLOP_PER_CROP / PEAK_MFMA_F32, 4), final_cost=round(cost, 5)),
                    roofline=roof)
         if world == 1 and not args.no_cpu_baseline:

@@ -46,10 +46,18 @@ class TensorV(object):
 
 
 class BNState(object):
-    def __init__(self, layer, C, M):
+    def __init__(self, layer, C, M, world=1):
         self.layer, self.C, self.M = layer, C, M
         self.rpb = max(32, -(-M // BN_RPB_TARGET_BLOCKS))
+        if world > 1:
+            # sync-BN concatenates the partials of all ranks: every block must hold exactly rpb rows
+            self.rpb = M if M < 32 else 32
+            while self.rpb * 2 <= max(32, M // BN_RPB_TARGET_BLOCKS) and M % (self.rpb * 2) == 0:
+                self.rpb *= 2
+            if M % self.rpb:
+                raise NotImplementedError("sync-BN needs the per-rank pixel count to be a multiple of %d" % self.rpb)
         self.nb = -(-M // self.rpb)
+        self.world = world
 
 
 class View(object):
@@ -236,7 +244,7 @@ def wgrad_plan(Co, Ci, K):
 
 
 class CompiledNet(object):
-    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0):
+    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None):
         """
         :param train: True -> BatchNorm uses batch statistics (and updates the running ones), dropout uses masks,
                       and the loss / backward / ADAM plans are built; False -> deterministic forward only.
@@ -244,6 +252,7 @@ class CompiledNet(object):
                       poseregnettrainer.py:92-99; also available in eval mode (validation cost / error).
         """
         self.rt = rt = runtime or default_runtime()
+        self.dp = dp                                  # hipdp.parallel.DataParallel or None
         self.net, self.train = net, train
         self.N = net.cfgParams.batch_size
         self.key = None
@@ -272,7 +281,8 @@ class CompiledNet(object):
             self.cost = rt.alloc(1)
             self.err = rt.alloc(2)
             self.lossplan = Plan('loss')
-            denom = self.N if loss.get('kind', 'embedding') == 'embedding' else self.N * loss['numJoints']
+            gN = self.N * (dp.world if (dp is not None and train) else 1)      # cost normalised by the GLOBAL batch
+            denom = gN if loss.get('kind', 'embedding') == 'embedding' else gN * loss['numJoints']
             if train:
                 self.out.grad = rt.alloc(self.out.shape)
                 self.out.grad_written = True
@@ -288,6 +298,11 @@ class CompiledNet(object):
             self.store.ensure_train_buffers()
             self.hyper = rt.alloc(8)
             self._emit_backward()
+            self._grad_allreduce = None
+            if dp is not None:
+                dp.broadcast_store(self.store)
+                self._grad_allreduce = dp.allreduce_sum_op(self.store.g, 'grad_allreduce')
+                self.upd.add(self._grad_allreduce)
             self.upd.add(ops.adam(rt, self.store.w, self.store.g, self.store.m, self.store.v, self.store.n_w, self.hyper))
             self.upd.add(ops.adam_tick(rt, self.hyper))
             self._lr = None
@@ -383,15 +398,21 @@ class CompiledNet(object):
                 raise NotImplementedError("BatchNorm on a non-materialised input")
             C = src.base.C
             M = src.base.rows
-            b = BNState(layer, C, M)
+            sync = self.train and self.dp is not None and self.dp.sync_bn
+            b = BNState(layer, C, M, self.dp.world if sync else 1)
             b.mean, b.inv_std, b.scale = (rt.alloc(_pad4(C)) for _ in range(3))
             b.beta_buf, b.gamma_buf = st.view(layer.beta), st.view(layer.gamma)
             b.run_mean, b.run_inv_std = st.view(layer.mean), st.view(layer.inv_std)
             self.bn_states[id(layer)] = b
             if self.train:
-                part = self.scratch(b.nb * 2 * C)
+                W = b.world
+                part = self.scratch(b.nb * 2 * C * (W + 1)).view(0, (b.nb * 2 * C,))
                 self.fwd.add(ops.bn_stats_partial(rt, src.base.buf, M, C, b.rpb, part))
-                self.fwd.add(ops.bn_finalize(rt, part, b.nb, M, b.rpb, C, b.gamma_buf, layer.cfgParams.epsilon, b.mean, b.inv_std,
+                if W > 1:
+                    allp = self.scratch(b.nb * 2 * C * (W + 1)).view(b.nb * 2 * C, (W * b.nb * 2 * C,))
+                    self.fwd.add(self.dp.all_gather_op(part, allp, 'bn_stats_allgather'))
+                    part = allp
+                self.fwd.add(ops.bn_finalize(rt, part, b.nb * W, M * W, b.rpb, C, b.gamma_buf, layer.cfgParams.epsilon, b.mean, b.inv_std,
                                              b.scale, b.run_mean, b.run_inv_std, layer.cfgParams.alpha))
             else:
                 self.fwd.add(ops.bn_eval_coeffs(rt, b.gamma_buf, b.run_mean, b.run_inv_std, C, b.mean, b.inv_std, b.scale))
@@ -536,11 +557,21 @@ class CompiledNet(object):
             t.pending.append(vg.grad)
             return
         b = view.bn
-        M, C = b.M, b.C
-        part = self.scratch(b.nb * 2 * C)
+        M, C, W = b.M, b.C, b.world
+        part = self.scratch(b.nb * 2 * C * (W + 1)).view(0, (b.nb * 2 * C,))
         c1, c2 = rt.alloc(_pad4(C)), rt.alloc(_pad4(C))
         self.bwd.add(ops.bn_bwd_reduce(rt, vg.grad, t.buf, M, C, b.mean, b.inv_std, b.scale, b.beta_buf, int(view.relu), vg.grad, b.rpb, part))
-        self.bwd.add(ops.bn_bwd_finalize(rt, part, b.nb, M, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2))
+        if W > 1:
+            allp = self.scratch(b.nb * 2 * C * (W + 1)).view(b.nb * 2 * C, (W * b.nb * 2 * C,))
+            self.bwd.add(self.dp.all_gather_op(part, allp, 'bn_bwd_allgather'))
+            part = allp
+        # with sync-BN dbeta / dgamma are already global sums on every rank: pre-divide so that the gradient all-reduce
+        # (a sum over ranks) leaves them unchanged
+        self.bwd.add(ops.bn_bwd_finalize(rt, part, b.nb * W, M * W, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2))
+        if W > 1:
+            for prm in (b.layer.beta, b.layer.gamma):
+                gv = st.view(prm, 'g')
+                self.bwd.add(ops.scale(rt, gv, gv, C, a=1.0 / W))
         addends = ([t.grad] if t.grad_written else []) + t.pending
         t.pending = []
         if t.grad is None:
@@ -753,6 +784,11 @@ class CompiledNet(object):
         self.lossplan.run(st)
         self.bwd.run(st)
         return float(self.cost.get()[0]), self.out.buf.get()
+
+    def allreduce_grads(self):
+        """Sum the flat gradient buffer over the data-parallel ranks (no-op without dp)."""
+        if self._grad_allreduce is not None:
+            self._grad_allreduce(self.rt.stream)
 
     def evaluate(self, x, y):
         """Deterministic forward + cost + error on one batch (validation functions of setupValidate)."""

@@ -62,23 +62,26 @@ class Plan(object):
     def launches(self):
         return [o for (o, _) in self.ops if isinstance(o, Launch)]
 
+    def steps(self):
+        return [o for (o, _) in self.ops if not isinstance(o, (Fork, Join))]
+
     def run(self, rt_or_stream):
         """rt_or_stream: a runtime (multi-stream aware) or a raw stream handle (single stream, side ops inline)."""
         rt = rt_or_stream if hasattr(rt_or_stream, 'stream') else None
         if rt is None or not self.uses_side or not getattr(rt, 'has_side_stream', False):
             st = rt.stream if rt is not None else rt_or_stream
             for op, _ in self.ops:
-                if isinstance(op, Launch):
+                if not isinstance(op, (Fork, Join)):
                     op(st)
             return
         main, side = rt.stream, rt.side_stream
         for op, on_side in self.ops:
-            if isinstance(op, Launch):
-                op(side if on_side else main)
-            elif isinstance(op, Fork):
+            if isinstance(op, Fork):
                 rt.side_wait_main()
-            else:
+            elif isinstance(op, Join):
                 rt.main_wait_side()
+            else:
+                op(side if on_side else main)
 
     def __len__(self):
         return len(self.launches())

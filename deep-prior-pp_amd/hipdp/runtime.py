@@ -84,6 +84,10 @@ class TorchHipRuntime(object):
             raise ValueError("dtype-changing views are not downloadable")
         return base[off:off + buf.size]
 
+    def tensor(self, buf):
+        """A flat torch tensor aliasing the buffer (for torch.distributed collectives)."""
+        return self._tensor(buf)
+
     def copy_in(self, buf, arr):
         arr = np.ascontiguousarray(arr, dtype=buf.dtype).reshape(-1)
         assert arr.size == buf.size, (arr.shape, buf.shape)

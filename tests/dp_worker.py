@@ -1,0 +1,49 @@
+"""Worker of tests/test_data_parallel.py: one data-parallel rank (gloo, emulator runtime) computing the gradients of its
+shard of a global batch with sync-BN, then one full train step.  Usage: dp_worker.py <out.npz> <sync_bn 0|1>"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'deep-prior-pp_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+from hipdp import engine, parallel  # noqa: E402
+from net.resnet import ResNet, ResNetParams  # noqa: E402
+from oracle import nets  # noqa: E402
+from tests.emu.emu_runtime import EmuRuntime  # noqa: E402
+
+
+def main():
+    out, sync = sys.argv[1], bool(int(sys.argv[2]))
+    rank, world = parallel.init_from_env('gloo')
+    rt = EmuRuntime()
+    B = 4
+    net = ResNet(np.random.RandomState(23455 + rank), cfgParams=ResNetParams(type=0, wIn=32, hIn=32, batchSize=B, numJoints=1, nDims=30))
+    dp = parallel.DataParallel(rt, sync_bn=sync)
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), dp=dp)   # broadcasts rank 0's parameters
+    rng = np.random.RandomState(99)
+    x = nets.synthetic_crops(rng, B * world, 32, 32, np.float32)
+    y = rng.normal(0, 0.3, (B * world, 30)).astype(np.float32)
+    xs, ys = x[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B]
+    cost, _ = eng.cost_and_grads(xs, ys)
+    eng.allreduce_grads()
+    G = {}
+    for i, l in enumerate(net.layers):
+        for s, p in enumerate(l.params):
+            G['g_%d_%d' % (i, s)] = eng.store.read_grad(p)
+    G['cost'] = np.array([cost])
+    eng.train_step(xs, ys, 1e-3)
+    last = net.layers[-1]
+    G['w_last'] = last.W.get_value()
+    G['bn_mean'] = [l for l in net.layers if l.__class__.__name__ == 'BatchNormLayer'][0].mean.get_value()
+    np.savez(out, **G)
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

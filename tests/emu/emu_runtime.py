@@ -47,6 +47,10 @@ class EmuRuntime(object):
         off = buf.ptr - arr.ctypes.data
         return arr.view(np.uint8)[off:off + buf.nbytes].view(buf.dtype)
 
+    def tensor(self, buf):
+        import torch
+        return torch.from_numpy(self._arr(buf))
+
     def copy_in(self, buf, arr):
         arr = np.ascontiguousarray(arr, dtype=buf.dtype).reshape(-1)
         assert arr.size == buf.size, (arr.shape, buf.shape)

@@ -1,0 +1,74 @@
+"""Data-parallel train step on 2 ranks (gloo, CPU; the real kernels under the SIMT emulator): with sync-BN the
+all-reduced gradients equal the single-process gradients on the same global batch; with local BN the replicas still
+stay bit-identical to each other after a full step (same all-reduced gradient, replicated ADAM)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from hipdp import engine
+from net.resnet import ResNet, ResNetParams
+from oracle import nets
+from tests.backends import get_runtime
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(tmp_path, sync, world=2):
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        out = os.path.join(str(tmp_path), 'rank%d_%d.npz' % (r, int(sync)))
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), out, str(int(sync))], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        log = p.communicate(timeout=900)[0].decode()
+        assert p.returncode == 0, log[-3000:]
+    return [np.load(o) for o in outs]
+
+
+def test_sync_bn_gradients_equal_single_process(tmp_path):
+    r0, r1 = _run_ranks(tmp_path, sync=True)
+    rt = get_runtime('emu')
+    net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, wIn=32, hIn=32, batchSize=8, numJoints=1, nDims=30))
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    rng = np.random.RandomState(99)
+    x = nets.synthetic_crops(rng, 8, 32, 32, np.float32)
+    y = rng.normal(0, 0.3, (8, 30)).astype(np.float32)
+    cost, _ = eng.cost_and_grads(x, y)
+    # the per-rank cost is the rank's share of the global mean
+    assert abs(float(r0['cost'][0] + r1['cost'][0]) - cost) < 1e-5 * abs(cost)
+    gmax = 0.0
+    ref = {}
+    for i, l in enumerate(net.layers):
+        for s, p in enumerate(l.params):
+            ref['g_%d_%d' % (i, s)] = eng.store.read_grad(p)
+            gmax = max(gmax, np.abs(ref['g_%d_%d' % (i, s)]).max())
+    for k, g in ref.items():
+        assert np.array_equal(r0[k], r1[k]), k                         # both ranks hold the same reduced gradient
+        np.testing.assert_allclose(r0[k], g, rtol=0, atol=2e-4 * max(np.abs(g).max(), 5e-3 * gmax), err_msg=k)
+    eng.train_step(x, y, 1e-3)
+    np.testing.assert_allclose(r0['bn_mean'], [l for l in net.layers if l.__class__.__name__ == 'BatchNormLayer'][0].mean.get_value(),
+                               rtol=1e-5, atol=1e-6)
+    assert np.array_equal(r0['w_last'], r1['w_last'])
+
+
+def test_local_bn_replicas_stay_identical(tmp_path):
+    r0, r1 = _run_ranks(tmp_path, sync=False)
+    for k in r0.files:
+        if k.startswith('g_') or k == 'w_last':
+            assert np.array_equal(r0[k], r1[k]), k
+    assert not np.array_equal(r0['bn_mean'], r1['bn_mean'])            # per-GPU running statistics differ by design
