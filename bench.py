@@ -72,9 +72,13 @@ def main():
     ap.add_argument('--no-augment', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sync-bn', action='store_true', help='all-gather BatchNorm partial statistics across ranks (parity mode)')
-    ap.add_argument('--eager', action='store_true', help='launch every kernel from Python instead of replaying hipGraphs')
+    ap.add_argument('--launch', choices=['auto', 'eager', 'graph'], default='auto',
+                    help='eager = every kernel launched from Python (two concurrent HIP streams); graph = replay captured hipGraphs; auto = probe both')
+    ap.add_argument('--eager', action='store_true', help='same as --launch eager')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-kernel-family time table to stderr')
     args = ap.parse_args()
+    if args.eager:
+        args.launch = 'eager'
 
     import torch
     from hipdp import engine, ops, parallel
@@ -150,7 +154,7 @@ def main():
     # the RCCL all-reduce sits between backward and ADAM.
     graphs = {}
     mode = 'eager'
-    if world == 1 and not args.eager:
+    if world == 1 and args.launch != 'eager':
         try:
             for sl in range(NDB // B):
                 graphs[sl] = rt.capture(lambda sl=sl: step_body(sl))
@@ -158,6 +162,22 @@ def main():
         except Exception as e:          # noqa: BLE001
             print('graph capture failed, running eager: %r' % (e,), file=sys.stderr)
             graphs = {}
+    if graphs and args.launch == 'auto':
+        # eager launches keep the two HIP streams genuinely concurrent; a replayed graph removes the host cost per launch.
+        # Which wins depends on the driver: time a few untimed steps of each and keep the faster mode.
+        def _probe(use_graph, n=6):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for k in range(n):
+                if use_graph:
+                    graphs[k % (NDB // B)].replay()
+                else:
+                    step_body(k)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t
+        _probe(True, 2), _probe(False, 2)
+        if _probe(False) < _probe(True):
+            graphs, mode = {}, 'eager'
 
     def step():
         i = step_no[0]

@@ -187,32 +187,51 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const floa
     c2[c] = (float)(b / (double)M);
 }
 
-// dX = scale * (G - c1 - xhat * c2) (+ add): gradient through the batch statistics.
+// dX = scale * (G - c1 - xhat * c2) (+ add): gradient through the batch statistics.  Row-chunked like the reductions so
+// that the column sums of dX -- the bias gradient of the conv that produced X (T.grad of `+ b.dimshuffle`,
+// convlayer.py:238) -- can be emitted as per-block partials in the same pass (colsum != nullptr).
 __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ X,
-                                                                   size_t n4, int C, const float* __restrict__ mean,
+                                                                   int M, int C, const float* __restrict__ mean,
                                                                    const float* __restrict__ inv_std, const float* __restrict__ scale,
                                                                    const float* __restrict__ c1, const float* __restrict__ c2,
-                                                                   const float* add, float* dX) {
-    const int Q = C >> 2;
-    for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * DPP_THREADS) {
-        int q = (int)(i % Q);
+                                                                   const float* add, float* dX, int rpb, float* __restrict__ colsum) {
+    __shared__ float s_a[DPP_THREADS * 4];
+    const int Q = C >> 2, RP = DPP_THREADS / Q;
+    const int tid = threadIdx.x, q = tid % Q, rr = tid / Q;
+    const int r_begin = blockIdx.x * rpb;
+    const int r_end = (r_begin + rpb < M) ? r_begin + rpb : M;
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rr < RP) {
         const float4 mu = *reinterpret_cast<const float4*>(mean + q * 4);
         const float4 is = *reinterpret_cast<const float4*>(inv_std + q * 4);
         const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4);
         const float4 a1 = *reinterpret_cast<const float4*>(c1 + q * 4);
         const float4 a2 = *reinterpret_cast<const float4*>(c2 + q * 4);
-        float4 g = reinterpret_cast<const float4*>(G)[i];
-        float4 x = reinterpret_cast<const float4*>(X)[i];
-        float4 o;
-        o.x = sc.x * (g.x - a1.x - (x.x - mu.x) * is.x * a2.x);
-        o.y = sc.y * (g.y - a1.y - (x.y - mu.y) * is.y * a2.y);
-        o.z = sc.z * (g.z - a1.z - (x.z - mu.z) * is.z * a2.z);
-        o.w = sc.w * (g.w - a1.w - (x.w - mu.w) * is.w * a2.w);
-        if (add) {
-            float4 r = reinterpret_cast<const float4*>(add)[i];
-            o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        for (int r = r_begin + rr; r < r_end; r += RP) {
+            size_t i = (size_t)r * Q + q;
+            float4 g = reinterpret_cast<const float4*>(G)[i];
+            float4 x = reinterpret_cast<const float4*>(X)[i];
+            float4 o;
+            o.x = sc.x * (g.x - a1.x - (x.x - mu.x) * is.x * a2.x);
+            o.y = sc.y * (g.y - a1.y - (x.y - mu.y) * is.y * a2.y);
+            o.z = sc.z * (g.z - a1.z - (x.z - mu.z) * is.z * a2.z);
+            o.w = sc.w * (g.w - a1.w - (x.w - mu.w) * is.w * a2.w);
+            if (add) {
+                float4 r4 = reinterpret_cast<const float4*>(add)[i];
+                o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
+            }
+            reinterpret_cast<float4*>(dX)[i] = o;
+            sa.x += o.x; sa.y += o.y; sa.z += o.z; sa.w += o.w;
         }
-        reinterpret_cast<float4*>(dX)[i] = o;
+    }
+    if (colsum == nullptr) return;
+    s_a[tid * 4 + 0] = sa.x; s_a[tid * 4 + 1] = sa.y; s_a[tid * 4 + 2] = sa.z; s_a[tid * 4 + 3] = sa.w;
+    __syncthreads();
+    for (int c = tid; c < C; c += DPP_THREADS) {
+        int cq = c >> 2, ce = c & 3;
+        double a = 0.0;
+        for (int j = 0; j < RP; ++j) a += (double)s_a[(j * Q + cq) * 4 + ce];
+        colsum[(size_t)blockIdx.x * C + c] = (float)a;
     }
 }
 
@@ -265,12 +284,9 @@ extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int M, int C, f
 
 extern "C" int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
                                 const float* scale, const float* c1, const float* c2, const float* add, float* dX,
-                                dpp_stream_t stream) {
-    if (!G || !X || !dX || M < 1 || !ok_c(C)) return DPP_E_BADARG;
-    size_t n4 = (size_t)M * (C >> 2);
-    int blocks = (int)((n4 + DPP_THREADS - 1) / DPP_THREADS);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), G, X, n4, C, mean,
-                       inv_std, scale, c1, c2, add, dX);
+                                int rows_per_block, float* colsum_partial, dpp_stream_t stream) {
+    if (!G || !X || !dX || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS) return DPP_E_BADARG;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), G, X,
+                       M, C, mean, inv_std, scale, c1, c2, add, dX, rows_per_block, colsum_partial);
     return dpp_launch_status();
 }

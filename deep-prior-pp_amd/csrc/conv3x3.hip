@@ -28,6 +28,7 @@ struct Conv3Args {
     const float* bias;    // [Co] or null
     const float* residual;
     float* Y;             // [N][H][W][Co]
+    dpp_epilogue epi;     // fused BatchNorm statistics / BatchNorm-backward epilogue
     int lth, ltw;         // log2 of tile height / width
     int img;              // images per workgroup
     int tiles_x, tiles_y;
@@ -153,6 +154,11 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
         __syncthreads();
     }
 
+    const dpp_epilogue& ep = a.epi;
+    const bool fused = ep.stats != nullptr || ep.bn_x != nullptr;
+    float sx[CN], sy[CN];
+#pragma unroll
+    for (int ct = 0; ct < CN; ++ct) { sx[ct] = 0.0f; sy[ct] = 0.0f; }
 #pragma unroll
     for (int rt = 0; rt < RM; ++rt) {
 #pragma unroll
@@ -162,16 +168,88 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
             int ty = (row >> a.ltw) & (TH - 1);
             int tx = row & (TW - 1);
             int n = n0 + im, y = y0 + ty, x = x0 + tx;
-            if (im >= a.img || n >= a.N || y >= a.H || x >= a.W) continue;
-            size_t o = (((size_t)n * a.H + y) * a.W + x) * a.Co;
+            bool ok = !(im >= a.img || n >= a.N || y >= a.H || x >= a.W);
+            size_t o = ok ? (((size_t)n * a.H + y) * a.W + x) * a.Co : 0;
 #pragma unroll
             for (int ct = 0; ct < CN; ++ct) {
                 int col = col0 + ct * 16 + l15;
-                if (col < a.Co) {
-                    float v = acc[rt][ct][r];
+                float v = 0.0f;
+                if (ok && col < a.Co) {
+                    v = acc[rt][ct][r];
                     if (a.bias) v += a.bias[col];
                     if (a.residual) v += a.residual[o + col];
+                    if (ep.bn_x != nullptr) {
+                        float dx = ep.bn_x[o + col] - ep.bn_mean[col];
+                        if (ep.bn_relu && dx * ep.bn_scale[col] + ep.bn_beta[col] < 0.0f) v = 0.0f;
+                        sx[ct] += v;
+                        sy[ct] += v * (dx * ep.bn_inv_std[col]);
+                    }
                     a.Y[o + col] = v;
+                }
+                acc[rt][ct][r] = v;
+            }
+        }
+    }
+    if (fused) {
+        float* red = Bs;                               // weight slices are dead after the last tap's barrier
+        const int cbase = col0 + l15;
+        if (ep.bn_x != nullptr && ep.bn_partial != nullptr) {
+            dpp_tile_colsum<CN, 4, 1, BN>(sx, red, wave, 0, l15, kq);
+            dpp_tile_colsum<CN, 4, 1, BN>(sy, red, wave, 0, l15, kq);
+            if (kq == 0 && wave == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    int col = cbase + ct * 16;
+                    if (col < a.Co) {
+                        ep.bn_partial[((size_t)blockIdx.x * 2 + 0) * a.Co + col] = sx[ct];
+                        ep.bn_partial[((size_t)blockIdx.x * 2 + 1) * a.Co + col] = sy[ct];
+                    }
+                }
+            }
+        }
+        if (ep.stats != nullptr) {
+            const int vi = (a.N - n0 < a.img) ? (a.N - n0) : a.img;
+            const int vy = (a.H - y0 < TH) ? (a.H - y0) : TH;
+            const int vx = (a.W - x0 < TW) ? (a.W - x0) : TW;
+            const float nvalid = (float)(vi * vy * vx);
+            float sm[CN], m2[CN];
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                float t = 0.0f;
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t += acc[rt][ct][r];
+                sm[ct] = t;
+            }
+            dpp_tile_colsum<CN, 4, 1, BN>(sm, red, wave, 0, l15, kq);
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                sm[ct] = sm[ct] / nvalid;
+                float t = 0.0f;
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = wave * (BM / 4) + rt * 16 + kq * 4 + r;
+                        int im = row >> (a.lth + a.ltw);
+                        int ty = (row >> a.ltw) & (TH - 1);
+                        int tx = row & (TW - 1);
+                        bool ok = !(im >= a.img || n0 + im >= a.N || y0 + ty >= a.H || x0 + tx >= a.W);
+                        float dv = acc[rt][ct][r] - sm[ct];
+                        if (ok) t += dv * dv;
+                    }
+                m2[ct] = t;
+            }
+            dpp_tile_colsum<CN, 4, 1, BN>(m2, red, wave, 0, l15, kq);
+            if (kq == 0 && wave == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    int col = cbase + ct * 16;
+                    if (col < a.Co) {
+                        ep.stats[((size_t)blockIdx.x * 2 + 0) * a.Co + col] = sm[ct];
+                        ep.stats[((size_t)blockIdx.x * 2 + 1) * a.Co + col] = m2[ct];
+                    }
                 }
             }
         }
@@ -302,13 +380,25 @@ void pick_tile(int N, int H, int W, int bm, int& lth, int& ltw, int& img) {
 
 }  // namespace
 
+extern "C" int dpp_conv3x3_tiling(int N, int H, int W, int bm, int* th, int* tw, int* img) {
+    int lth, ltw, im;
+    if (bm != 64 && bm != 128) return -1;
+    pick_tile(N, H, W, bm, lth, ltw, im);
+    if (th) *th = 1 << lth;
+    if (tw) *tw = 1 << ltw;
+    if (img) *img = im;
+    return dpp_cdiv(W, 1 << ltw) * dpp_cdiv(H, 1 << lth) * dpp_cdiv(N, im);
+}
+
 extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
-                           const float* bias, const float* residual, float* Y, int bm, dpp_stream_t stream) {
+                           const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream) {
     if (!X || !Wk || !Y || N < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15)) return DPP_E_BADARG;
     Conv3Args a;
     a.X = X; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
     if (act) a.act = *act; else { a.act.mode = 0; a.act.cmod = 1; a.act.mean = a.act.scale = a.act.beta = nullptr; }
     a.Wk = Wk; a.bias = bias; a.residual = residual; a.Y = Y;
+    if (epi) a.epi = *epi; else { a.epi.stats = nullptr; a.epi.bn_x = nullptr; a.epi.bn_partial = nullptr; }
+    if (a.epi.bn_x && !(a.epi.bn_mean && a.epi.bn_inv_std && a.epi.bn_scale && a.epi.bn_beta && a.epi.bn_partial)) return DPP_E_BADARG;
     long pixels = (long)N * H * W;
     if (bm == 0) bm = (pixels / 128) * dpp_cdiv(Co, 64) >= 512 ? 128 : 64;
     pick_tile(N, H, W, bm, a.lth, a.ltw, a.img);

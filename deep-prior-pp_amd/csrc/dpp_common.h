@@ -58,3 +58,32 @@ __device__ __forceinline__ float4 dpp_act4(float4 x, const dpp_act& a, int c) {
 __device__ __forceinline__ float dpp_f4_get(const float4& v, int i) {
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
+
+// ---- column reductions of an MFMA output tile in the D layout ----------------------------------------------------------
+// A wave holds RM x CN tiles of 16x16: lane (l15 = column, kq = row quad), register r -> row kq*4 + r.  `s[ct]` enters as
+// this lane's partial sum for column tile ct and leaves as the sum over ALL rows of the workgroup tile (every lane of the
+// column gets it).  WM waves stack along rows (they share columns), WN waves sit side by side.  `red` is LDS scratch of at
+// least WM*BN floats that nobody else uses during the call.
+template <int CN, int WM, int WN, int BN>
+__device__ __forceinline__ void dpp_tile_colsum(float (&s)[CN], float* red, int wm, int wn, int l15, int kq) {
+#pragma unroll
+    for (int ct = 0; ct < CN; ++ct) {
+        s[ct] += __shfl_xor(s[ct], 16);
+        s[ct] += __shfl_xor(s[ct], 32);
+    }
+    if (WM > 1) {
+        __syncthreads();
+        if (kq == 0) {
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) red[wm * BN + wn * (BN / WN) + ct * 16 + l15] = s[ct];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) t += red[w * BN + wn * (BN / WN) + ct * 16 + l15];
+            s[ct] = t;
+        }
+    }
+}

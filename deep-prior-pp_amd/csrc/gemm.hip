@@ -51,6 +51,119 @@ __device__ __forceinline__ float4 act4_masked(float4 v, const dpp_act& a, int c0
     return o;
 }
 
+// Shared epilogue of the GEMM kernels: bias / residual / fused BatchNorm-backward mask, stores (or split-K partial stores),
+// and the fused column statistics.  acc is in the MFMA D layout; `red` is LDS scratch of >= WM*BN floats.
+template <int RM, int CN, int WM, int WN, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[RM][CN], const dpp_gemm_desc& d, int row0, int col0, int wm, int wn,
+                                              int l15, int kq, float* As) {
+    const int M = d.M, N = d.N;
+    // ---- epilogue: D layout col = lane&15, row = (lane>>4)*4 + r --------------------------------
+    const dpp_epilogue& ep = d.epi;
+    const bool fused = d.splitk == 1 && (ep.stats != nullptr || ep.bn_x != nullptr);
+    float sx[CN], sy[CN];            // fused BatchNorm-backward sums (sum G, sum G*xhat)
+#pragma unroll
+    for (int ct = 0; ct < CN; ++ct) { sx[ct] = 0.0f; sy[ct] = 0.0f; }
+#pragma unroll
+    for (int rt = 0; rt < RM; ++rt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = row0 + wm * (BM / WM) + rt * 16 + kq * 4 + r;
+            if (row >= M) {
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) acc[rt][ct][r] = 0.0f;
+                continue;
+            }
+            if (d.splitk > 1) {
+                float* prow = d.partial + ((size_t)blockIdx.z * M + row) * N;
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    int col = col0 + wn * (BN / WN) + ct * 16 + l15;
+                    if (col < N) prow[col] = acc[rt][ct][r];
+                }
+            } else {
+                size_t o = (size_t)dpp_map_row(d.mapC, row) * d.ldc;
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    int col = col0 + wn * (BN / WN) + ct * 16 + l15;
+                    float v = 0.0f;
+                    if (col < N) {
+                        v = acc[rt][ct][r];
+                        if (d.bias) v += d.bias[col];
+                        if (d.residual) v += d.residual[o + col];
+                        if (ep.bn_x != nullptr) {
+                            float dx = ep.bn_x[o + col] - ep.bn_mean[col];
+                            if (ep.bn_relu && dx * ep.bn_scale[col] + ep.bn_beta[col] < 0.0f) v = 0.0f;
+                            sx[ct] += v;
+                            sy[ct] += v * (dx * ep.bn_inv_std[col]);
+                        }
+                        d.C[o + col] = v;
+                    }
+                    acc[rt][ct][r] = v;
+                }
+            }
+        }
+    }
+    if (fused) {
+        float* red = As;                                   // the operand tiles are dead after the last barrier of the K loop
+        const int cbase = col0 + wn * (BN / WN) + l15;
+        if (ep.bn_x != nullptr && ep.bn_partial != nullptr) {
+            dpp_tile_colsum<CN, WM, WN, BN>(sx, red, wm, wn, l15, kq);
+            dpp_tile_colsum<CN, WM, WN, BN>(sy, red, wm, wn, l15, kq);
+            if (kq == 0 && wm == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    int col = cbase + ct * 16;
+                    if (col < N) {
+                        ep.bn_partial[((size_t)blockIdx.x * 2 + 0) * N + col] = sx[ct];
+                        ep.bn_partial[((size_t)blockIdx.x * 2 + 1) * N + col] = sy[ct];
+                    }
+                }
+            }
+        }
+        if (ep.stats != nullptr) {
+            // two passes over the registers: block mean first, then M2 about it (no cancellation when |mean| >> std)
+            const int nvalid = (M - row0 < BM) ? (M - row0) : BM;
+            float sm[CN];
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                float t = 0.0f;
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t += acc[rt][ct][r];       // invalid rows were zeroed above
+                sm[ct] = t;
+            }
+            dpp_tile_colsum<CN, WM, WN, BN>(sm, red, wm, wn, l15, kq);
+            float m2[CN];
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                sm[ct] = sm[ct] / (float)nvalid;
+                float t = 0.0f;
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int row = row0 + wm * (BM / WM) + rt * 16 + kq * 4 + r;
+                        float dv = acc[rt][ct][r] - sm[ct];
+                        if (row < M) t += dv * dv;
+                    }
+                m2[ct] = t;
+            }
+            dpp_tile_colsum<CN, WM, WN, BN>(m2, red, wm, wn, l15, kq);
+            if (kq == 0 && wm == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    int col = cbase + ct * 16;
+                    if (col < N) {
+                        ep.stats[((size_t)blockIdx.x * 2 + 0) * N + col] = sm[ct];
+                        ep.stats[((size_t)blockIdx.x * 2 + 1) * N + col] = m2[ct];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Global -> register fetch of one float4 staging slot (with the operand prologue applied), and its LDS address.
 // K-contiguous operand: slot = (row r, k-quad c4); MN-contiguous operand: slot = (k row rk, mn-quad c4).
 template <int ROWS, int BKT, bool KC>
@@ -60,7 +173,7 @@ struct Stager {
     static constexpr int LD = KC ? (BKT + 4) : (ROWS + 4);
 };
 
-template <int BM, int BN, int WM, int BKT, bool AKC, bool BKC>
+template <int BM, int BN, int WM, int BKT, bool AKC, bool BKC, int DEPTH>
 __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     const dpp_gemm_desc& d = ga.d;
     constexpr int WN = 4 / WM;
@@ -110,8 +223,10 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         }
     }
 
-    float4 ra[SA::SLOTS], rb[SB::SLOTS];
-    auto fetch = [&](int kc) {
+    // DEPTH chunks are kept in flight per workgroup (a ring of register sets): what bounds these skinny GEMMs is the
+    // latency of the dependent load -> barrier -> MFMA chain, not bandwidth or the MFMA rate.
+    float4 ra[DEPTH][SA::SLOTS], rb[DEPTH][SB::SLOTS];
+    auto fetch = [&](float4* ra_, float4* rb_, int kc) {
 #pragma unroll
         for (int s = 0; s < SA::SLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
@@ -126,7 +241,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
                         v = act4_masked(load4(a_base[s] + (size_t)dpp_map_row(d.mapA, k) * d.lda, gi, M, ga.vecA), d.actA, gi, M);
                 }
             }
-            ra[s] = v;
+            ra_[s] = v;
         }
 #pragma unroll
         for (int s = 0; s < SB::SLOTS; ++s) {
@@ -142,21 +257,21 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
                         v = act4_masked(load4(b_base[s] + (size_t)dpp_map_row(d.mapB, k) * d.ldb, gj, N, ga.vecB), d.actB, gj, N);
                 }
             }
-            rb[s] = v;
+            rb_[s] = v;
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](const float4* ra_, const float4* rb_) {
 #pragma unroll
         for (int s = 0; s < SA::SLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
-            if (AKC) { if (slot < BM * SA::QK) *reinterpret_cast<float4*>(&As[(slot / SA::QK) * LDA_ + (slot % SA::QK) * 4]) = ra[s]; }
-            else { if (slot < BKT * (BM / 4)) *reinterpret_cast<float4*>(&As[(slot / (BM / 4)) * LDA_ + (slot % (BM / 4)) * 4]) = ra[s]; }
+            if (AKC) { if (slot < BM * SA::QK) *reinterpret_cast<float4*>(&As[(slot / SA::QK) * LDA_ + (slot % SA::QK) * 4]) = ra_[s]; }
+            else { if (slot < BKT * (BM / 4)) *reinterpret_cast<float4*>(&As[(slot / (BM / 4)) * LDA_ + (slot % (BM / 4)) * 4]) = ra_[s]; }
         }
 #pragma unroll
         for (int s = 0; s < SB::SLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
-            if (BKC) { if (slot < BN * SB::QK) *reinterpret_cast<float4*>(&Bs[(slot / SB::QK) * LDB_ + (slot % SB::QK) * 4]) = rb[s]; }
-            else { if (slot < BKT * (BN / 4)) *reinterpret_cast<float4*>(&Bs[(slot / (BN / 4)) * LDB_ + (slot % (BN / 4)) * 4]) = rb[s]; }
+            if (BKC) { if (slot < BN * SB::QK) *reinterpret_cast<float4*>(&Bs[(slot / SB::QK) * LDB_ + (slot % SB::QK) * 4]) = rb_[s]; }
+            else { if (slot < BKT * (BN / 4)) *reinterpret_cast<float4*>(&Bs[(slot / (BN / 4)) * LDB_ + (slot % (BN / 4)) * 4]) = rb_[s]; }
         }
     };
 
@@ -166,78 +281,136 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
 #pragma unroll
         for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // Software pipeline: the global loads of chunk k+1 are issued right after the barrier that publishes chunk k and
-    // stay in flight under chunk k's MFMAs; their LDS write happens after the next barrier.
-    if (k_begin < k_end) fetch(k_begin);
-    for (int kc = k_begin; kc < k_end; kc += BKT) {
-        commit();
-        __syncthreads();
-        if (kc + BKT < k_end) fetch(kc + BKT);
+    // Software pipeline: DEPTH chunks are fetched ahead; chunk c is written to LDS from ring slot c % DEPTH, and as soon
+    // as the barrier publishes it the slot is refilled with chunk c + DEPTH, whose loads stay in flight under the MFMAs.
+    const int nchunks = (k_end > k_begin) ? (k_end - k_begin + BKT - 1) / BKT : 0;
 #pragma unroll
-        for (int e4 = 0; e4 < KL; e4 += 4) {
-            float af[RM][4], bf[CN][4];
+    for (int dd = 0; dd < DEPTH; ++dd)
+        if (dd < nchunks) fetch(ra[dd], rb[dd], k_begin + dd * BKT);
+    for (int c0 = 0; c0 < nchunks; c0 += DEPTH) {
 #pragma unroll
-            for (int rt = 0; rt < RM; ++rt) {
-                int r = wm * (BM / WM) + rt * 16 + l15;
-                if (AKC) {
-                    float4 v = *reinterpret_cast<const float4*>(&As[r * LDA_ + kq * KL + e4]);
-                    af[rt][0] = v.x; af[rt][1] = v.y; af[rt][2] = v.z; af[rt][3] = v.w;
-                } else {
+        for (int dd = 0; dd < DEPTH; ++dd) {
+            const int c = c0 + dd;
+            if (c < nchunks) {
+                commit(ra[dd], rb[dd]);
+                __syncthreads();
+                if (c + DEPTH < nchunks) fetch(ra[dd], rb[dd], k_begin + (c + DEPTH) * BKT);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) af[rt][t] = As[(kq * KL + e4 + t) * LDA_ + r];
+                for (int e4 = 0; e4 < KL; e4 += 4) {
+                    float af[RM][4], bf[CN][4];
+#pragma unroll
+                    for (int rt = 0; rt < RM; ++rt) {
+                        int r = wm * (BM / WM) + rt * 16 + l15;
+                        if (AKC) {
+                            float4 v = *reinterpret_cast<const float4*>(&As[r * LDA_ + kq * KL + e4]);
+                            af[rt][0] = v.x; af[rt][1] = v.y; af[rt][2] = v.z; af[rt][3] = v.w;
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) af[rt][t] = As[(kq * KL + e4 + t) * LDA_ + r];
+                        }
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < CN; ++ct) {
+                        int cc = wn * (BN / WN) + ct * 16 + l15;
+                        if (BKC) {
+                            float4 v = *reinterpret_cast<const float4*>(&Bs[cc * LDB_ + kq * KL + e4]);
+                            bf[ct][0] = v.x; bf[ct][1] = v.y; bf[ct][2] = v.z; bf[ct][3] = v.w;
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) bf[ct][t] = Bs[(kq * KL + e4 + t) * LDB_ + cc];
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                            for (int ct = 0; ct < CN; ++ct)
+                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][t], bf[ct][t], acc[rt][ct], 0, 0, 0);
                 }
+                __syncthreads();
             }
-#pragma unroll
-            for (int ct = 0; ct < CN; ++ct) {
-                int c = wn * (BN / WN) + ct * 16 + l15;
-                if (BKC) {
-                    float4 v = *reinterpret_cast<const float4*>(&Bs[c * LDB_ + kq * KL + e4]);
-                    bf[ct][0] = v.x; bf[ct][1] = v.y; bf[ct][2] = v.z; bf[ct][3] = v.w;
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) bf[ct][t] = Bs[(kq * KL + e4 + t) * LDB_ + c];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int rt = 0; rt < RM; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < CN; ++ct)
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][t], bf[ct][t], acc[rt][ct], 0, 0, 0);
         }
-        __syncthreads();
     }
 
-    // ---- epilogue: D layout col = lane&15, row = (lane>>4)*4 + r --------------------------------
-#pragma unroll
-    for (int rt = 0; rt < RM; ++rt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int row = row0 + wm * (BM / WM) + rt * 16 + kq * 4 + r;
-            if (row >= M) continue;
-            if (d.splitk > 1) {
-                float* prow = d.partial + ((size_t)blockIdx.z * M + row) * N;
-#pragma unroll
-                for (int ct = 0; ct < CN; ++ct) {
-                    int col = col0 + wn * (BN / WN) + ct * 16 + l15;
-                    if (col < N) prow[col] = acc[rt][ct][r];
-                }
-            } else {
-                size_t o = (size_t)dpp_map_row(d.mapC, row) * d.ldc;
-#pragma unroll
-                for (int ct = 0; ct < CN; ++ct) {
-                    int col = col0 + wn * (BN / WN) + ct * 16 + l15;
-                    if (col < N) {
-                        float v = acc[rt][ct][r];
-                        if (d.bias) v += d.bias[col];
-                        if (d.residual) v += d.residual[o + col];
-                        d.C[o + col] = v;
-                    }
-                }
-            }
+    gemm_epilogue<RM, CN, WM, WN, BM, BN>(acc, d, row0, col0, wm, wn, l15, kq, As);
+}
+
+// ---- row-streaming variant for the skinny conv GEMMs (M = pixels >> K, N) -------------------------------------------------
+// Each wave owns 16*RM output rows and ALL BN columns of the workgroup: its A fragments are loaded straight from global
+// memory into registers (lane (i, kq) reads 16 B of row i; the four kq lanes of a row cover one 64-B segment), the small B
+// slice (weights, K x BN) is staged in LDS ONCE, and there is no barrier in the K loop at all -- waves never wait for each
+// other, so the CU hides HBM latency purely with its 8-16 resident waves.  Requires a K-contiguous A, splitk == 1.
+template <int RM, int CN, bool BKC>
+__global__ __launch_bounds__(DPP_THREADS) void gemm_rowstream_kernel(GemmArgs ga) {
+    const dpp_gemm_desc& d = ga.d;
+    HIP_DYNAMIC_SHARED(float4, smem4)
+    float* Bs = reinterpret_cast<float*>(smem4);
+    constexpr int BM = 64 * RM, BN = 16 * CN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+    const int M = d.M, N = d.N, K = d.K;
+    const int K16 = (K + 15) & ~15;
+    const int LDB = BKC ? (K16 + 4) : (BN + 4);
+    // ---- stage the B slice (zero padded to K16 x BN) ----
+    if (BKC) {
+        const int q = K16 >> 2;
+        for (int s = tid; s < BN * q; s += DPP_THREADS) {
+            int j = s / q, c4 = s - j * q, k = c4 * 4, gj = col0 + j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gj < N && k < K) v = act4_masked(load4(d.B + (size_t)gj * d.ldb + k, k, K, ga.vecB), d.actB, k, K);
+            *reinterpret_cast<float4*>(&Bs[j * LDB + k]) = v;
+        }
+    } else {
+        constexpr int q = BN / 4;
+        for (int s = tid; s < K16 * q; s += DPP_THREADS) {
+            int k = s / q, c4 = s - k * q, gj = col0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < K && gj < N) v = act4_masked(load4(d.B + (size_t)dpp_map_row(d.mapB, k) * d.ldb + gj, gj, N, ga.vecB), d.actB, gj, N);
+            *reinterpret_cast<float4*>(&Bs[k * LDB + c4 * 4]) = v;
         }
     }
+    const float* arow[RM];
+#pragma unroll
+    for (int rt = 0; rt < RM; ++rt) {
+        int gi = row0 + wave * (16 * RM) + rt * 16 + l15;
+        arow[rt] = gi < M ? d.A + (size_t)dpp_map_row(d.mapA, gi) * d.lda : nullptr;
+    }
+    f32x4 acc[RM][CN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int kc = 0; kc < K16; kc += 16) {
+        const int k = kc + kq * 4;
+        float4 av[RM];
+#pragma unroll
+        for (int rt = 0; rt < RM; ++rt) {
+            av[rt] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (arow[rt] != nullptr && k < K) av[rt] = act4_masked(load4(arow[rt] + k, k, K, ga.vecA), d.actA, k, K);
+        }
+        float bf[CN][4];
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            if (BKC) {
+                float4 v = *reinterpret_cast<const float4*>(&Bs[(ct * 16 + l15) * LDB + k]);
+                bf[ct][0] = v.x; bf[ct][1] = v.y; bf[ct][2] = v.z; bf[ct][3] = v.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bf[ct][t] = Bs[(k + t) * LDB + ct * 16 + l15];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), bf[ct][t], acc[rt][ct], 0, 0, 0);
+    }
+    __syncthreads();                        // the B slice is dead: the epilogue reuses LDS for its column reductions
+    gemm_epilogue<RM, CN, 4, 1, BM, BN>(acc, d, row0, col0, wave, 0, l15, kq, Bs);
 }
 
 // out[i] = sum_z partial[z][i] (+ bias).  Threads are laid out as CB columns x ZL z-lanes: lane zl sums z = zl, zl+ZL, ...
@@ -269,20 +442,56 @@ __global__ __launch_bounds__(DPP_THREADS) void reduce_partials_kernel(const floa
     }
 }
 
+// Many independent partial reductions in ONE launch: job j sums nz slices of n floats into out (the filter / bias gradient
+// partials of the whole backward pass).  A workgroup finds its job from the block-offset table, then works exactly like
+// reduce_partials_kernel with 16 z-lanes x 16 columns.
+struct ReduceJob {
+    const float* partial;
+    float* out;
+    int nz, n, block0, pad;
+};
+
+__global__ __launch_bounds__(DPP_THREADS) void reduce_multi_kernel(const ReduceJob* __restrict__ jobs, int njobs) {
+    __shared__ float red[DPP_THREADS];
+    __shared__ int s_job;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;                   // last job whose block0 <= blockIdx.x
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        s_job = lo;
+    }
+    __syncthreads();
+    const ReduceJob jb = jobs[s_job];
+    constexpr int ZL = 16, CB = DPP_THREADS / ZL;
+    const int col = threadIdx.x % CB, zl = threadIdx.x / CB;
+    const int i = ((int)blockIdx.x - jb.block0) * CB + col;
+    float s = 0.0f;
+    if (i < jb.n)
+        for (int z = zl; z < jb.nz; z += ZL) s += jb.partial[(size_t)z * jb.n + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (zl == 0 && i < jb.n) {
+        for (int j = 1; j < ZL; ++j) s += red[j * CB + col];
+        jb.out[i] = s;
+    }
+}
+
 template <int BM, int BN, int WM>
 int launch_layout(const GemmArgs& ga, hipStream_t st) {
     const dpp_gemm_desc& d = ga.d;
     dim3 grid(dpp_cdiv(d.M, BM), dpp_cdiv(d.N, BN), d.splitk);
     const bool k32 = ga.bk == 32;
     if (d.a_kc && d.b_kc) {
-        if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, true>), grid, dim3(DPP_THREADS), 0, st, ga);
-        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else if (d.a_kc && !d.b_kc) {
-        if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, false>), grid, dim3(DPP_THREADS), 0, st, ga);
-        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, false>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else if (!d.a_kc && !d.b_kc) {
         // reduction over pixels / samples: long K, both operands [k][mn] -> 64-deep chunks keep 20+ KB per workgroup in flight
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false>), grid, dim3(DPP_THREADS), 0, st, ga);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else
         return DPP_E_UNSUPPORTED;
     return dpp_launch_status();
@@ -301,6 +510,8 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     dpp_gemm_desc& d = ga.d;
     if (d.splitk < 1) d.splitk = 1;
     if (d.splitk > 1 && !d.partial) return DPP_E_BADARG;
+    if (d.splitk > 1 && (d.epi.stats || d.epi.bn_x)) return DPP_E_BADARG;
+    if (d.epi.bn_x && !(d.epi.bn_mean && d.epi.bn_inv_std && d.epi.bn_scale && d.epi.bn_beta && d.epi.bn_partial)) return DPP_E_BADARG;
     if (d.splitk == 1 && !d.C) return DPP_E_BADARG;
     if (d.actA.mode && d.actA.cmod <= 0) return DPP_E_BADARG;
     if (d.actB.mode && d.actB.cmod <= 0) return DPP_E_BADARG;
@@ -326,6 +537,24 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
         }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d.variant == 1) {
+        // row-streaming kernel: bm in {64, 128} rows per workgroup, bn in {16, 32, 64} columns, whole K staged for B
+        if (!d.a_kc || d.splitk != 1) return DPP_E_UNSUPPORTED;
+        if (bm != 64 && bm != 128) bm = 64;
+        if (bn != 16 && bn != 32 && bn != 64) bn = d.N > 32 ? 64 : (d.N > 16 ? 32 : 16);
+        const int K16 = (d.K + 15) & ~15;
+        size_t lds = (d.b_kc ? (size_t)bn * (K16 + 4) : (size_t)K16 * (bn + 4)) * sizeof(float);
+        if (lds < (size_t)4 * bn * sizeof(float)) lds = (size_t)4 * bn * sizeof(float);
+        if (lds > 64 * 1024) return DPP_E_UNSUPPORTED;
+        dim3 grid(dpp_cdiv(d.M, bm), dpp_cdiv(d.N, bn), 1);
+#define DPP_RS(RM_, CN_) if (bm == 64 * RM_ && bn == 16 * CN_) { \
+            if (d.b_kc) hipLaunchKernelGGL((gemm_rowstream_kernel<RM_, CN_, true>), grid, dim3(DPP_THREADS), lds, st, ga); \
+            else hipLaunchKernelGGL((gemm_rowstream_kernel<RM_, CN_, false>), grid, dim3(DPP_THREADS), lds, st, ga); \
+            return dpp_launch_status(); }
+        DPP_RS(1, 1) DPP_RS(1, 2) DPP_RS(1, 4) DPP_RS(2, 1) DPP_RS(2, 2) DPP_RS(2, 4)
+#undef DPP_RS
+        return DPP_E_UNSUPPORTED;
+    }
 #define DPP_TILE(BM_, BN_, WM_) if (bm == BM_ && bn == BN_ && wm == WM_) return launch_layout<BM_, BN_, WM_>(ga, st);
     DPP_TILE(128, 64, 4)
     DPP_TILE(128, 32, 4)
@@ -338,6 +567,15 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     DPP_TILE(16, 128, 1)
 #undef DPP_TILE
     return DPP_E_UNSUPPORTED;
+}
+
+extern "C" size_t dpp_reduce_job_bytes(void) { return sizeof(ReduceJob); }
+
+extern "C" int dpp_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, dpp_stream_t stream) {
+    if (!jobs_dev || njobs < 1 || total_blocks < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3(total_blocks), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const ReduceJob*>(jobs_dev), njobs);
+    return dpp_launch_status();
 }
 
 extern "C" int dpp_reduce_partials(const float* partial, int nz, int n, const float* bias, int nbias, float* out,

@@ -13,6 +13,9 @@ conv's epilogue.  Activations are NHWC; parameters live in ONE flat device buffe
 data-parallel gradient all-reduce are single operations), with get_value()/set_value() converting to the
 reference's layouts on the fly.
 """
+import os
+from ctypes import c_int as C_int
+
 import numpy as np
 
 from . import layout, ops
@@ -217,21 +220,58 @@ def get_store(net, rt, layers):
     return store
 
 
+GEMM_TARGET_BLOCKS = int(os.environ.get('DPP_GEMM_TARGET_BLOCKS', '1024'))
+
+
 def gemm_plan(M, N, K, allow_split=True):
-    """(tile, splitk) heuristics: fill >= 256 workgroups, split K when the output tile grid is small."""
+    """(tile, splitk) heuristics.  These GEMMs are latency / HBM-bound (K and N of 16..256), so the tile is the LARGEST one
+    that still gives about GEMM_TARGET_BLOCKS workgroups (4 per CU: enough loads in flight to hide HBM latency); K is split
+    when even the smallest tile leaves the grid short."""
     if M <= 16:
         bm, bn, wm = 16, 64, 1
     elif M <= 32:
         bm, bn, wm = 32, 64, 1
     else:
         wm = 4
-        bn = 64 if N > 32 else (32 if N > 16 else 16)
-        bm = 128 if (-(-M // 128)) * (-(-N // bn)) >= 512 else 64
+        cands = [(128, 64), (64, 64), (128, 32), (64, 32), (128, 16), (64, 16)]
+        cands = [(a, b) for (a, b) in cands if b <= max(16, 16 * (-(-N // 16))) or b == 16]
+        bm, bn = cands[-1]
+        for (a, b) in cands:
+            if (-(-M // a)) * (-(-N // b)) >= GEMM_TARGET_BLOCKS:
+                bm, bn = a, b
+                break
     tiles = (-(-M // bm)) * (-(-N // bn))
     splitk = 1
-    if allow_split and tiles < 256 and K >= 256:
-        splitk = int(min(max(1, 512 // tiles), max(1, K // 128), 256))
+    if allow_split and tiles < 512 and K >= 256:
+        # few output tiles, long K (the FC layers): split K until ~2048 workgroups with >= 128 of K each
+        splitk = int(min(max(1, 2048 // tiles), max(1, K // 128), 256))
     return (bm, bn, wm), splitk
+
+
+ROWSTREAM = os.environ.get('DPP_ROWSTREAM', '0') != '0'      # measured: no gain over the LDS-tiled kernel yet
+
+
+def rowstream_plan(M, N, K, b_kc):
+    """Tile of the barrier-free row-streaming GEMM variant for conv-shaped problems (M = pixels >> K, N), or None when it
+    does not apply: the whole K x bn weight slice must fit the 64 KB LDS window, and the grid should fill the chip."""
+    if not ROWSTREAM or M < 2048:
+        return None
+    K16 = (K + 15) // 16 * 16
+    for bn in (64, 32, 16):
+        if bn > 16 and bn >= 2 * N:
+            continue
+        lds = (bn * (K16 + 4) if b_kc else K16 * (bn + 4)) * 4
+        if lds > 48 * 1024:
+            continue
+        bm = 128 if (M // 128) * (-(-N // bn)) >= 1024 else 64
+        return (bm, bn, 4)
+    return None
+
+
+def conv3x3_bm(pixels, Co):
+    """Rows per workgroup of the 3x3 kernel (the choice dpp_conv3x3 makes for bm = 0, made explicit so that the host knows
+    the row-block count of the fused epilogue partials)."""
+    return 128 if (pixels // 128) * (-(-Co // 64)) >= 512 else 64
 
 
 def wgrad_plan(Co, Ci, K):
@@ -244,7 +284,7 @@ def wgrad_plan(Co, Ci, K):
 
 
 class CompiledNet(object):
-    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None):
+    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None, fuse_bn=True):
         """
         :param train: True -> BatchNorm uses batch statistics (and updates the running ones), dropout uses masks,
                       and the loss / backward / ADAM plans are built; False -> deterministic forward only.
@@ -253,6 +293,9 @@ class CompiledNet(object):
         """
         self.rt = rt = runtime or default_runtime()
         self.dp = dp                                  # hipdp.parallel.DataParallel or None
+        # BatchNorm statistics / backward sums produced by the conv epilogues (off with sync-BN, whose partials are
+        # all-gathered by row block, and for tests that want the stand-alone BatchNorm kernels)
+        self.fuse_bn = bool(fuse_bn) and not (dp is not None and dp.sync_bn)
         self.net, self.train = net, train
         self.N = net.cfgParams.batch_size
         self.key = None
@@ -267,6 +310,8 @@ class CompiledNet(object):
         self.view_grads = {}        # view key -> dict(view, dA, written)
         self._scratch = None
         self._bn_scratch = None
+        self.colsum_of = {}                 # dY buffer ptr -> (column-sum partials, nb, C) emitted by bn_bwd_apply
+        self.reduce_jobs = ops.ReduceJobs(rt)
         self.dropout_masks = {}
         in_dim = net.cfgParams.inputDim
         self.in_shape = (in_dim[0], in_dim[2], in_dim[3], in_dim[1])
@@ -343,7 +388,7 @@ class CompiledNet(object):
         raise NotImplementedError("the net output must be a materialised tensor (conv / hidden layer output)")
 
     # ------------------------------------------------------------------------------------------ forward
-    def _emit(self, var, residual=None):
+    def _emit(self, var, residual=None, out_var=None):
         if residual is None and id(var) in self._memo:
             return self._memo[id(var)]
         k = var.kind
@@ -362,7 +407,7 @@ class CompiledNet(object):
         elif k == 'add':
             v = self._emit_add(var)
         elif k == 'layer':
-            v = self._emit_layer(var, residual)
+            v = self._emit_layer(var, residual, out_var)
         else:
             raise NotImplementedError("graph node '%s'" % k)
         if residual is None:
@@ -384,11 +429,18 @@ class CompiledNet(object):
         pv = self._emit(p)
         if not pv.plain:
             raise NotImplementedError("residual add on a non-materialised operand")
-        out = self._emit(q, residual=pv.base)
+        out = self._emit(q, residual=pv.base, out_var=var)      # the conv's output tensor IS the sum
         self._memo[id(q)] = out
         return out
 
-    def _emit_layer(self, var, residual):
+    def _feeds_batchnorm(self, var):
+        """Does a BatchNorm consume the tensor this var denotes?  Then its producer emits the statistics partials."""
+        for c in self.consumers.get(id(var), []):
+            if c.kind == 'layer' and _layer_kind(c.layer) == 'BatchNormLayer':
+                return True
+        return False
+
+    def _emit_layer(self, var, residual, out_var=None):
         layer = var.layer
         kind = _layer_kind(layer)
         rt, st = self.rt, self.store
@@ -404,7 +456,13 @@ class CompiledNet(object):
             b.beta_buf, b.gamma_buf = st.view(layer.beta), st.view(layer.gamma)
             b.run_mean, b.run_inv_std = st.view(layer.mean), st.view(layer.inv_std)
             self.bn_states[id(layer)] = b
-            if self.train:
+            fused = getattr(src.base, 'stats', None) if self.train else None
+            if fused is not None:
+                # the producing conv already wrote per-block (mean, M2): only the combine is left
+                part, nblk, rows = fused
+                self.fwd.add(ops.bn_finalize(rt, part, nblk, M, rows, C, b.gamma_buf, layer.cfgParams.epsilon, b.mean, b.inv_std,
+                                             b.scale, b.run_mean, b.run_inv_std, layer.cfgParams.alpha))
+            elif self.train:
                 W = b.world
                 part = self.scratch(b.nb * 2 * C * (W + 1)).view(0, (b.nb * 2 * C,))
                 self.fwd.add(ops.bn_stats_partial(rt, src.base.buf, M, C, b.rpb, part))
@@ -416,17 +474,21 @@ class CompiledNet(object):
                                              b.scale, b.run_mean, b.run_inv_std, layer.cfgParams.alpha))
             else:
                 self.fwd.add(ops.bn_eval_coeffs(rt, b.gamma_buf, b.run_mean, b.run_inv_std, C, b.mean, b.inv_std, b.scale))
-            return View(src.base, b, False, shape=src.shape, chan=src.chan)
+            v = View(src.base, b, False, shape=src.shape, chan=src.chan)
+            v.var = var
+            return v
         if kind == 'NonlinearityLayer':
             if layer.cfgParams.activation is None:
                 return src
             if layer.cfgParams.activation_str != 'ReLU':
                 raise NotImplementedError("only ReLU is on the hot path")
-            return View(src.base, src.bn, True, shape=src.shape, chan=src.chan)
+            v = View(src.base, src.bn, True, shape=src.shape, chan=src.chan)
+            v.var = var
+            return v
         if kind == 'ConvPoolLayer':
             return self._emit_stem(layer, src)
         if kind == 'ConvLayer':
-            return self._emit_conv(layer, src, residual)
+            return self._emit_conv(layer, src, residual, out_var if out_var is not None else var)
         if kind == 'HiddenLayer':
             return self._emit_fc(layer, src)
         if kind == 'DropoutLayer':
@@ -449,7 +511,7 @@ class CompiledNet(object):
         self.layer_io[id(layer)] = dict(in_view=src, out=out, argmax=arg)
         return View(out)
 
-    def _emit_conv(self, layer, src, residual):
+    def _emit_conv(self, layer, src, residual, out_var=None):
         c = layer.cfgParams
         N, Hi, Wi, Ci = src.base.shape
         _, Co, Ho, Wo = c.outputDim
@@ -460,15 +522,33 @@ class CompiledNet(object):
         act = self._act(src)
         rt, st = self.rt, self.store
         res = residual.buf if residual is not None else None
+        # fused BatchNorm statistics of the tensor being written (not with sync-BN: its partials are all-gathered by block)
+        want_stats = self.train and self.fuse_bn and out_var is not None and self._feeds_batchnorm(out_var)
+        M = N * Ho * Wo
+        epi = None
         if k == (1, 1):
-            M = N * Ho * Wo
             tile, _ = gemm_plan(M, Co, Ci, allow_split=False)
+            rs = rowstream_plan(M, Co, Ci, True)
+            if rs is not None:
+                tile = rs
+            if want_stats:
+                nblk = -(-M // tile[0])
+                out.stats = (rt.alloc((nblk, 2, Co), zero=False), nblk, tile[0])
+                epi = ops.epilogue(stats=out.stats[0])
             mp = RowMap.strided(s[0], Ho, Wo, Hi, Wi) if s[0] != 1 else None
             self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
-                                  bias=st.view(layer.b), residual=res, tile=tile, name='conv1x1_%d' % layer.layerNum))
+                                  bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=1 if rs is not None else 0,
+                                  name='conv1x1_%d' % layer.layerNum))
         else:
+            bm = conv3x3_bm(M, Co)
+            if want_stats:
+                th, tw, img = (C_int() for _ in range(3))
+                nblk = rt.lib.dpp_conv3x3_tiling(N, Hi, Wi, bm, th, tw, img)
+                if Hi % th.value == 0 and Wi % tw.value == 0 and (N % img.value == 0 or nblk == 1):   # every block holds bm pixels
+                    out.stats = (rt.alloc((nblk, 2, Co), zero=False), nblk, bm)
+                    epi = ops.epilogue(stats=out.stats[0])
             self.fwd.add(ops.conv3x3(rt, src.base.buf, N, Hi, Wi, Ci, st.view(layer.W), Co, out.buf, actX=act, bias=st.view(layer.b),
-                                     residual=res, name='conv3x3_%d' % layer.layerNum))
+                                     residual=res, bm=bm, epi=epi, name='conv3x3_%d' % layer.layerNum))
         self.layer_io[id(layer)] = dict(in_view=src, out=out, residual=residual)
         return View(out)
 
@@ -558,16 +638,24 @@ class CompiledNet(object):
             return
         b = view.bn
         M, C, W = b.M, b.C, b.world
-        part = self.scratch(b.nb * 2 * C * (W + 1)).view(0, (b.nb * 2 * C,))
         c1, c2 = rt.alloc(_pad4(C)), rt.alloc(_pad4(C))
-        self.bwd.add(ops.bn_bwd_reduce(rt, vg.grad, t.buf, M, C, b.mean, b.inv_std, b.scale, b.beta_buf, int(view.relu), vg.grad, b.rpb, part))
+        fused = getattr(vg, 'fused_reduce', None)
+        if fused is not None:
+            # the data-gradient kernel already masked vg.grad and wrote the per-block sums
+            part, nbp = fused
+            self.bwd.add(ops.bn_bwd_finalize(rt, part, nbp, M, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2))
+            W = 0
+        else:
+            part = self.scratch(b.nb * 2 * C * (W + 1)).view(0, (b.nb * 2 * C,))
+            self.bwd.add(ops.bn_bwd_reduce(rt, vg.grad, t.buf, M, C, b.mean, b.inv_std, b.scale, b.beta_buf, int(view.relu), vg.grad, b.rpb, part))
         if W > 1:
             allp = self.scratch(b.nb * 2 * C * (W + 1)).view(b.nb * 2 * C, (W * b.nb * 2 * C,))
             self.bwd.add(self.dp.all_gather_op(part, allp, 'bn_bwd_allgather'))
             part = allp
         # with sync-BN dbeta / dgamma are already global sums on every rank: pre-divide so that the gradient all-reduce
         # (a sum over ranks) leaves them unchanged
-        self.bwd.add(ops.bn_bwd_finalize(rt, part, b.nb * W, M * W, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2))
+        if fused is None:
+            self.bwd.add(ops.bn_bwd_finalize(rt, part, b.nb * W, M * W, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2))
         if W > 1:
             for prm in (b.layer.beta, b.layer.gamma):
                 gv = st.view(prm, 'g')
@@ -581,7 +669,10 @@ class CompiledNet(object):
             add = addends[0]
             for extra in addends[1:]:
                 raise NotImplementedError("more than one extra gradient path into a BatchNorm input")
-        self.bwd.add(ops.bn_bwd_apply(rt, vg.grad, t.buf, M, C, b.mean, b.inv_std, b.scale, c1, c2, t.grad, add=add))
+        # t.grad is the dY of the conv(s) that produced t: emit its column sums (their bias gradients) in the same pass
+        cs = rt.alloc((b.nb, C), zero=False)
+        self.bwd.add(ops.bn_bwd_apply(rt, vg.grad, t.buf, M, C, b.mean, b.inv_std, b.scale, c1, c2, t.grad, add=add, rpb=b.rpb, colsum=cs))
+        self.colsum_of[t.grad.ptr] = (cs, b.nb, C)
         t.grad_written = True
 
     def _emit_backward(self):
@@ -626,12 +717,26 @@ class CompiledNet(object):
             else:
                 raise NotImplementedError(kind)
         self.bwd.join()
+        self.bwd.add(self.reduce_jobs.launch())       # every filter / bias gradient partial of the pass, one launch
         if self.weight_decay and not self.net.hasDropout():
             for l in self.layers:                             # cost += wd * sum(W^2): gradient 2*wd*W
                 if hasattr(l, 'W'):
                     self.bwd.add(ops.axpy(rt, st.view(l.W, 'g'), st.view(l.W), 2.0 * self.weight_decay, int(np.prod(l.W.shape))))
 
+    def _sole_consumer_bn_view(self, view):
+        """A BatchNorm(+ReLU) view read by exactly one conv: that conv's data-gradient epilogue may finish the BatchNorm
+        backward reduction itself (no other contribution will be accumulated into the view's gradient)."""
+        if view.bn is None or not self.fuse_bn:
+            return False
+        var = getattr(view, 'var', None)
+        return var is not None and self._single_consumer(var) and len(view.shape) == 4
+
     def _bias_grad(self, dY, rows, C, gslot):
+        if dY.ptr in self.colsum_of:
+            cs, nb, cc = self.colsum_of[dY.ptr]
+            assert cc == C
+            self.reduce_jobs.add(cs, nb, C, gslot)
+            return
         rpb = max(32, -(-rows // 256))
         nb = -(-rows // rpb)
         part = self.scratch_side(nb * C)
@@ -658,33 +763,48 @@ class CompiledNet(object):
             mp = RowMap.strided(s, Ho, Wo, Hi, Wi) if s != 1 else None
             # filter gradient dW[o][c] = sum_m dY[m][o] * act(X)[map(m)][c]
             tile, splitk = wgrad_plan(Co, Ci, M)
-            part = self.scratch_side(splitk * Co * Ci)
+            part = rt.alloc(splitk * Co * Ci, zero=False) if splitk > 1 else None     # persistent: reduced at the end of backward
             self.bwd.add(ops.gemm(rt, dY, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actB=act,
-                                  splitk=splitk, partial=part if splitk > 1 else None, tile=tile, name='wgrad1x1_%d' % layer.layerNum),
-                         side=True)
+                                  splitk=splitk, partial=part, tile=tile, name='wgrad1x1_%d' % layer.layerNum), side=True)
             if splitk > 1:
-                self.bwd.add(ops.reduce_partials(rt, part, splitk, Co * Ci, gW), side=True)
+                self.reduce_jobs.add(part, splitk, Co * Ci, gW)
             if need_dx:
                 tgt, dst = self._view_grad(src)
                 acc = tgt.grad_written
                 if s != 1 and not acc:
                     self.bwd.add(ops.fill_zero(rt, dst))
                 tile, _ = gemm_plan(M, Ci, Co, allow_split=False)
+                rs = rowstream_plan(M, Ci, Co, False)
+                if rs is not None:
+                    tile = rs
+                epi = None
+                if s == 1 and not acc and self._sole_consumer_bn_view(src):
+                    # ReLU mask + (sum G, sum G*xhat) of the BatchNorm backward in this kernel's epilogue
+                    nb2 = -(-M // tile[0])
+                    tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
+                    epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
                 self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp,
-                                      residual=dst if acc else None, tile=tile, name='dgrad1x1_%d' % layer.layerNum))
+                                      residual=dst if acc else None, tile=tile, epi=epi, variant=1 if rs is not None else 0,
+                                      name='dgrad1x1_%d' % layer.layerNum))
                 tgt.grad_written = True
         else:
             bm = 64
             nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, Hi, Wi, bm)
-            part = self.scratch_side(nblk * Co * 9 * Ci)
+            part = rt.alloc(nblk * Co * 9 * Ci, zero=False)
             self.bwd.add(ops.conv3x3_wgrad(rt, src.base.buf, N, Hi, Wi, Ci, dY, Co, part, actX=act, bm=bm), side=True)
-            self.bwd.add(ops.reduce_partials(rt, part, nblk, Co * 9 * Ci, gW), side=True)
+            self.reduce_jobs.add(part, nblk, Co * 9 * Ci, gW)
             if need_dx:
                 tgt, dst = self._view_grad(src)
                 acc = tgt.grad_written
                 Wd = rt.alloc(Co * 9 * Ci, zero=False)
                 self.bwd.add(ops.conv3x3_wtrans(rt, st.view(layer.W), Co, Ci, Wd))
-                self.bwd.add(ops.conv3x3(rt, dY, N, Hi, Wi, Co, Wd, Ci, dst, residual=dst if acc else None,
+                bmd = conv3x3_bm(N * Hi * Wi, Ci)
+                epi = None
+                if not acc and self._sole_consumer_bn_view(src):
+                    nb2 = rt.lib.dpp_conv3x3_tiling(N, Hi, Wi, bmd, None, None, None)
+                    tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
+                    epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
+                self.bwd.add(ops.conv3x3(rt, dY, N, Hi, Wi, Co, Wd, Ci, dst, residual=dst if acc else None, bm=bmd, epi=epi,
                                          name='dgrad3x3_%d' % layer.layerNum))
                 tgt.grad_written = True
 
@@ -722,9 +842,9 @@ class CompiledNet(object):
         self._bias_grad(dY, out.rows, Co, st.view(layer.b, 'g'))
         tpb = 8
         nblk = rt.lib.dpp_stem_wgrad_blocks(N, H, W, tpb)
-        part = self.scratch_side(nblk * Co * 25)
+        part = rt.alloc(nblk * Co * 25, zero=False)
         self.bwd.add(ops.stem_wgrad(rt, self.x_in.buf, N, H, W, dY, io['argmax'], Co, part, tpb), side=True)
-        self.bwd.add(ops.reduce_partials(rt, part, nblk, Co * 25, st.view(layer.W, 'g')), side=True)
+        self.reduce_jobs.add(part, nblk, Co * 25, st.view(layer.W, 'g'))
 
     # ------------------------------------------------------------------------------------------ execution
     def set_input(self, x):

@@ -38,6 +38,12 @@ class Act(C.Structure):
         return Act(None, None, None, 0, 1)
 
 
+class Epilogue(C.Structure):
+    _fields_ = [('stats', C.c_void_p), ('bn_x', C.c_void_p), ('bn_mean', C.c_void_p), ('bn_inv_std', C.c_void_p),
+                ('bn_scale', C.c_void_p), ('bn_beta', C.c_void_p), ('bn_relu', C.c_int), ('pad_', C.c_int),
+                ('bn_partial', C.c_void_p)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [('A', C.c_void_p), ('lda', C.c_int), ('a_kc', C.c_int), ('mapA', RowMap), ('actA', Act),
                 ('B', C.c_void_p), ('ldb', C.c_int), ('b_kc', C.c_int), ('mapB', RowMap), ('actB', Act),
@@ -45,7 +51,7 @@ class GemmDesc(C.Structure):
                 ('bias', C.c_void_p), ('residual', C.c_void_p),
                 ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
                 ('splitk', C.c_int), ('partial', C.c_void_p),
-                ('bm', C.c_int), ('bn', C.c_int), ('wm', C.c_int)]
+                ('bm', C.c_int), ('bn', C.c_int), ('wm', C.c_int), ('variant', C.c_int), ('epi', Epilogue)]
 
 
 # name -> (restype, argtypes); every symbol include/dpp_hip.h declares must be listed here
@@ -54,7 +60,8 @@ SIGNATURES = {
     'dpp_gemm': (C.c_int, [C.POINTER(GemmDesc), stream_t]),
     'dpp_reduce_partials': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
     'dpp_conv3x3': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
-                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, stream_t]),
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Epilogue), stream_t]),
+    'dpp_conv3x3_tiling': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'dpp_conv3x3_wtrans': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_conv3x3_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'dpp_conv3x3_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
@@ -74,7 +81,9 @@ SIGNATURES = {
     'dpp_bn_bwd_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, stream_t]),
     'dpp_bn_bwd_apply': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
+    'dpp_reduce_job_bytes': (C.c_size_t, []),
+    'dpp_reduce_multi': (C.c_int, [C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_colsum_partial': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_loss_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_error_l2': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from .lib import Act, GemmDesc, RowMap, check
+from .lib import Act, Epilogue, GemmDesc, RowMap, check
 
 
 class Launch(object):
@@ -95,8 +95,20 @@ def act(mode=0, mean=None, scale=None, beta=None, cmod=1):
     return Act(_p(mean), _p(scale), _p(beta), int(mode), int(cmod))
 
 
+def epilogue(stats=None, bn=None, bn_x=None, bn_relu=True, bn_partial=None):
+    """dpp_epilogue: fused BatchNorm statistics (`stats`) and/or BatchNorm-backward mask + sums (`bn` = an object with
+    mean / inv_std / scale / beta_buf buffers, `bn_x` the BatchNorm input, `bn_partial` the per-block sums)."""
+    e = Epilogue()
+    e.stats = _p(stats)
+    if bn is not None:
+        e.bn_x, e.bn_mean, e.bn_inv_std, e.bn_scale, e.bn_beta = bn_x.ptr, bn.mean.ptr, bn.inv_std.ptr, bn.scale.ptr, bn.beta_buf.ptr
+        e.bn_relu, e.bn_partial = int(bn_relu), bn_partial.ptr
+    e._keep = (stats, bn, bn_x, bn_partial)
+    return e
+
+
 def gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, mapA=None, mapB=None, mapC=None, actA=None, actB=None,
-         bias=None, residual=None, splitk=1, partial=None, tile=(0, 0, 0), name='gemm'):
+         bias=None, residual=None, splitk=1, partial=None, tile=(0, 0, 0), epi=None, variant=0, name='gemm'):
     """C = A_op . B_op, see dpp_gemm in include/dpp_hip.h."""
     d = GemmDesc()
     d.A, d.lda, d.a_kc = A.ptr, lda, int(a_kc)
@@ -111,9 +123,12 @@ def gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, mapA=None, mapB=N
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.splitk, d.partial = int(splitk), _p(partial)
     d.bm, d.bn, d.wm = tile
+    d.variant = int(variant)
+    if epi is not None:
+        d.epi = epi
     meta = dict(kernel='gemm_mfma_f32', flops=2.0 * M * N * K,
                 bytes=4.0 * (M * K + K * N + M * N * (max(1, splitk) if splitk > 1 else 1) + (M * N if residual is not None else 0)))
-    return Launch(rt.lib.dpp_gemm, (C.byref(d),), (d, A, B, Cbuf, bias, residual, partial, actA, actB), name, meta)
+    return Launch(rt.lib.dpp_gemm, (C.byref(d),), (d, A, B, Cbuf, bias, residual, partial, actA, actB, epi), name, meta)
 
 
 def reduce_partials(rt, partial, nz, n, out, bias=None, nbias=1, name='reduce_partials'):
@@ -125,12 +140,13 @@ def _actp(a):
     return C.byref(a) if a is not None else None
 
 
-def conv3x3(rt, X, N, H, W, Ci, Wk, Co, Y, actX=None, bias=None, residual=None, bm=0, name='conv3x3'):
+def conv3x3(rt, X, N, H, W, Ci, Wk, Co, Y, actX=None, bias=None, residual=None, bm=0, epi=None, name='conv3x3'):
     px = float(N) * H * W
     meta = dict(kernel='conv3x3_mfma_f32', flops=2.0 * px * 9 * Ci * Co,
                 bytes=4.0 * (px * (Ci + Co + (Co if residual is not None else 0)) + 9 * Ci * Co))
-    return Launch(rt.lib.dpp_conv3x3, (X.ptr, N, H, W, Ci, _actp(actX), Wk.ptr, Co, _p(bias), _p(residual), Y.ptr, bm),
-                  (X, Wk, Y, actX, bias, residual), name, meta)
+    return Launch(rt.lib.dpp_conv3x3, (X.ptr, N, H, W, Ci, _actp(actX), Wk.ptr, Co, _p(bias), _p(residual), Y.ptr, bm,
+                                       C.byref(epi) if epi is not None else None),
+                  (X, Wk, Y, actX, bias, residual, epi), name, meta)
 
 
 def conv3x3_wtrans(rt, Wk, Co, Ci, Wd, name='conv3x3_wtrans'):
@@ -186,9 +202,11 @@ def bn_bwd_finalize(rt, partial, nb, M, Cc, dbeta, dgamma, c1, c2, name='bn_bwd_
                   (partial, dbeta, dgamma, c1, c2), name, dict(kernel='bn_bwd_finalize', flops=0.0, bytes=8.0 * nb * Cc))
 
 
-def bn_bwd_apply(rt, G, X, M, Cc, mean, inv_std, scale, c1, c2, dX, add=None, name='bn_bwd_apply'):
-    return Launch(rt.lib.dpp_bn_bwd_apply, (G.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, c1.ptr, c2.ptr, _p(add), dX.ptr),
-                  (G, X, mean, inv_std, scale, c1, c2, add, dX), name,
+def bn_bwd_apply(rt, G, X, M, Cc, mean, inv_std, scale, c1, c2, dX, add=None, rpb=None, colsum=None, name='bn_bwd_apply'):
+    rpb = rpb or max(32, -(-M // 1024))
+    return Launch(rt.lib.dpp_bn_bwd_apply, (G.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, c1.ptr, c2.ptr, _p(add), dX.ptr,
+                                            int(rpb), _p(colsum)),
+                  (G, X, mean, inv_std, scale, c1, c2, add, dX, colsum), name,
                   dict(kernel='bn_bwd_apply', flops=6.0 * M * Cc, bytes=(16.0 if add is not None else 12.0) * M * Cc))
 
 
@@ -257,3 +275,29 @@ def adam_tick(rt, state, name='adam_tick'):
 
 def counter_add(rt, counter, inc=1, name='counter_add'):
     return Launch(rt.lib.dpp_counter_add, (counter.ptr, int(inc)), (counter,), name)
+
+
+class ReduceJobs(object):
+    """Collects (partial, nz, n, out) reductions and emits ONE dpp_reduce_multi launch for all of them."""
+
+    def __init__(self, rt):
+        self.rt = rt
+        self.jobs = []
+
+    def add(self, partial, nz, n, out):
+        self.jobs.append((partial, int(nz), int(n), out))
+
+    def launch(self, name='reduce_multi'):
+        if not self.jobs:
+            return None
+        import struct
+        rt = self.rt
+        assert rt.lib.dpp_reduce_job_bytes() == 32
+        raw, block0 = b'', 0
+        for (partial, nz, n, out) in self.jobs:
+            raw += struct.pack('<QQiiii', partial.ptr, out.ptr, nz, n, block0, 0)
+            block0 += -(-n // 16)
+        table = rt.upload(np.frombuffer(raw, np.uint8).copy())
+        flops = float(sum(nz * n for (_, nz, n, _) in self.jobs))
+        return Launch(rt.lib.dpp_reduce_multi, (table.ptr, len(self.jobs), block0), (table, list(self.jobs)), name,
+                      dict(kernel='reduce_multi', flops=flops, bytes=4.0 * flops))

@@ -6,6 +6,8 @@ copies and the stream only; every computation goes through libdpp_hip.so.
 The CPU-side kernel-logic tests inject `tests/emu/emu_runtime.EmuRuntime` (host memory + the emulator
 build of the same kernel sources) through the same small interface.
 """
+import os
+
 import numpy as np
 
 from . import lib as _lib
@@ -59,7 +61,7 @@ class TorchHipRuntime(object):
         self.device = torch.device('cuda', torch.cuda.current_device() if device is None else device)
         self.lib = _lib.load(lib_path)
         self.is_emulator = False
-        self.has_side_stream = True
+        self.has_side_stream = os.environ.get('DPP_NO_SIDE_STREAM', '0') != '1'
         self._side = torch.cuda.Stream(self.device)
 
     _TD = {'float32': 'float32', 'int32': 'int32', 'uint8': 'uint8', 'float64': 'float64', 'int64': 'int64'}

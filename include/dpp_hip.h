@@ -55,6 +55,25 @@ typedef struct {
     int cmod;
 } dpp_act;
 
+/* Optional fused epilogue work on the output tile (both NULL = plain epilogue).
+ *   stats      [row_blocks][2][N]: per-workgroup-row-block (mean, M2) of every output column, i.e. the partial BatchNorm
+ *              statistics of the tensor being written (batchnormlayer.py:154-155) -- saves the separate statistics pass;
+ *              combine with dpp_bn_finalize(partial = stats, nb = row_blocks, rows_per_block = tile rows).
+ *   bn_x ...   BatchNorm-backward fusion for a data-gradient call: the value written is G = acc * [ (x-mean)*scale+beta >= 0 ]
+ *              (bn_relu != 0) with x = bn_x at the output's index, and bn_partial [row_blocks][2][N] receives the per-block
+ *              (sum G, sum G*xhat), xhat = (x-mean)*inv_std: exactly what dpp_bn_bwd_reduce would produce. */
+typedef struct {
+    float* stats;
+    const float* bn_x;
+    const float* bn_mean;
+    const float* bn_inv_std;
+    const float* bn_scale;
+    const float* bn_beta;
+    int bn_relu;
+    int pad_;
+    float* bn_partial;
+} dpp_epilogue;
+
 /*
  * Generic f32 MFMA GEMM  C[M x N] = A_op[M x K] * B_op[K x N]  (v_mfma_f32_16x16x4_f32, LDS-staged).
  *   a_kc = 1: A_op(i,k) = A[mapA(i)*lda + k]      a_kc = 0: A_op(i,k) = A[mapA(k)*lda + i]
@@ -78,6 +97,10 @@ typedef struct {
     int splitk;
     float* partial;
     int bm, bn, wm; /* tile: rows, cols, waves along M (4 or 1); 0 = choose */
+    int variant;    /* 0: LDS-tiled kernel (any layout, split-K); 1: row-streaming kernel for skinny conv GEMMs (a_kc = 1,
+                       splitk = 1, bm in {64,128}, bn in {16,32,64}): A fragments straight from global memory, no barrier
+                       in the K loop */
+    dpp_epilogue epi; /* fused statistics / BatchNorm-backward epilogue (requires splitk == 1) */
 } dpp_gemm_desc;
 int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);
 
@@ -86,13 +109,21 @@ int dpp_reduce_partials(const float* partial, int nz, int n, const float* bias, 
                         dpp_stream_t stream);
 
 
+/* Batched form: jobs_dev = device array of { const float* partial; float* out; int nz, n, block0, pad; } sorted by block0,
+ * job j owning workgroups [block0_j, block0_j + ceil(n_j / 16)); total_blocks = sum.  One launch reduces every filter /
+ * bias gradient partial of a backward pass. */
+size_t dpp_reduce_job_bytes(void);
+int dpp_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, dpp_stream_t stream);
+
 /* ---- 3x3 'half' stride-1 ConvLayer on NHWC maps (implicit GEMM, halo tile in LDS) --------------------------
  * Y[n,y,x,o] = sum_{tap,c} act(X)[n, y+dy, x+dx, c] * Wk[o][tap][c] + bias[o] + residual[n,y,x,o], zero padding applied
  * after `act`.  conv2d 3x3 of res_block, /root/reference/src/net/resnet.py:365-368,394-397 via
  * /root/reference/src/net/convlayer.py:230-240.  The data gradient is the same call on dY with the weights from
  * dpp_conv3x3_wtrans.  bm = 64 | 128 rows per workgroup (0 = choose).  Ci, Co multiples of 16. */
 int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
-                const float* bias, const float* residual, float* Y, int bm, dpp_stream_t stream);
+                const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream);
+/* tile geometry chosen for (N,H,W,bm): returns the number of workgroup row blocks, writes tile height / width / images */
+int dpp_conv3x3_tiling(int N, int H, int W, int bm, int* th, int* tw, int* img);
 /* Wd[c][8-tap][o] = Wk[o][tap][c] (mirrored taps, channels swapped): weights of the data-gradient correlation. */
 int dpp_conv3x3_wtrans(const float* Wk, int Co, int Ci, float* Wd, dpp_stream_t stream);
 /* Filter gradient partials: partial[blk][o][tap][c] = sum over the workgroup's pixels of dY[.,o] * act(X)[.+tap, c];
@@ -132,7 +163,7 @@ int dpp_bn_bwd_finalize(const float* partial, int nb, int M, int C, float* dbeta
                         dpp_stream_t stream);
 int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
                      const float* scale, const float* c1, const float* c2, const float* add, float* dX,
-                     dpp_stream_t stream);
+                     int rows_per_block, float* colsum_partial /* [nb][C] column sums of dX, or NULL */, dpp_stream_t stream);
 
 /* ---- loss / optimiser / small elementwise ------------------------------------------------------------------ */
 /* partial[b][c] = sum of rows of chunk b (bias gradients; reduce with dpp_reduce_partials) */

@@ -44,7 +44,9 @@ def test_sync_bn_gradients_equal_single_process(tmp_path):
     r0, r1 = _run_ranks(tmp_path, sync=True)
     rt = get_runtime('emu')
     net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, wIn=32, hIn=32, batchSize=8, numJoints=1, nDims=30))
-    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    # the single-process reference runs the same stand-alone BatchNorm kernels as the sync-BN ranks: in this deep, tiny-batch
+    # net f32 rounding differences between kernel variants are amplified enough to flip ReLU masks of near-zero elements
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), fuse_bn=False)
     rng = np.random.RandomState(99)
     x = nets.synthetic_crops(rng, 8, 32, 32, np.float32)
     y = rng.normal(0, 0.3, (8, 30)).astype(np.float32)

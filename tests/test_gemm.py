@@ -148,3 +148,46 @@ def test_fc_prologue_channel_modulo(backend):
     ops.gemm(rt, b['X'], dYb, dW, K, N, M, 0, 0, K, N, N, actA=a)(rt.stream)
     rt.synchronize()
     _check(dW.get(), A.T @ dY.astype('f8'), M, 8)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(64, 16, 32, 16), (64, 32, 256, 64), (128, 32, 64, 128), (128, 64, 16, 64), (64, 16, 40, 24)])
+def test_rowstream_variant_fwd_and_dgrad(backend, cfg):
+    """The barrier-free row-streaming kernel (variant 1): 1x1 conv forward with BN+ReLU prologue, bias, residual and fused
+    statistics, and the data gradient (B in [k][n] layout) with stride-2 scatter."""
+    rt = get_runtime(backend)
+    bm, bn, K, N = cfg
+    rng = np.random.RandomState(8)
+    Nb, Hi, Wi, s = 3, 10, 6, 2
+    M = Nb * Hi * Wi
+    X = rng.normal(size=(M, K)).astype('float32')
+    Wk = (rng.normal(size=(N, K)) * 0.3).astype('float32')
+    cm = K if K % 4 == 0 else 1
+    mean, scale, beta = (rng.normal(size=K).astype('float32') for _ in range(3))
+    bias = rng.normal(size=N).astype('float32')
+    res = rng.normal(size=(M, N)).astype('float32')
+    b = {k: rt.upload(v) for k, v in dict(X=X, Wk=Wk, mean=mean, scale=scale, beta=beta, bias=bias, res=res).items()}
+    Y = rt.alloc((M, N), zero=False)
+    nblk = -(-M // bm)
+    stats = rt.alloc((nblk, 2, N), zero=False)
+    ops.gemm(rt, b['X'], b['Wk'], Y, M, N, K, 1, 1, K, K, N, actA=ops.act(Act.BN_RELU, b['mean'], b['scale'], b['beta'], K),
+             bias=b['bias'], residual=b['res'], tile=(bm, bn, 4), variant=1, epi=ops.epilogue(stats=stats))(rt.stream)
+    gamma, mo, io, so = rt.upload(np.ones(N, 'float32')), rt.alloc(N), rt.alloc(N), rt.alloc(N)
+    ops.bn_finalize(rt, stats, nblk, M, bm, N, gamma, 1e-4, mo, io, so)(rt.stream)
+    rt.synchronize()
+    A = np.maximum((X.astype('f8') - mean) * scale + beta, 0)
+    ref = A @ Wk.astype('f8').T + bias + res
+    _check(Y.get(), ref, K, 8)
+    np.testing.assert_allclose(mo.get(), ref.mean(0), rtol=0, atol=3e-6 * np.abs(ref).max())
+    np.testing.assert_allclose(io.get(), 1 / np.sqrt(ref.var(0) + np.float32(1e-4)), rtol=3e-5)
+    # data gradient: dA[m][c] = sum_o dY[m][o] Wk[o][c], scattered to the stride-2 positions of a zeroed map
+    Ho, Wo = Hi // s, Wi // s
+    Mo = Nb * Ho * Wo
+    dY = rng.normal(size=(Mo, N)).astype('float32')
+    dH = rt.alloc((M, K), zero=True)
+    mp = RowMap.strided(s, Ho, Wo, Hi, Wi)
+    ops.gemm(rt, rt.upload(dY), b['Wk'], dH, Mo, K, N, 1, 0, N, K, K, mapC=mp, tile=(bm, 16 if K < 32 else 32, 4), variant=1)(rt.stream)
+    rt.synchronize()
+    refd = np.zeros((Nb, Hi, Wi, K))
+    refd[:, ::s, ::s, :] = (dY.astype('f8') @ Wk.astype('f8')).reshape(Nb, Ho, Wo, K)
+    _check(dH.get().reshape(Nb, Hi, Wi, K), refd, N, 8)

@@ -98,7 +98,7 @@ def test_stem_fwd_and_wgrad(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('cfg', [(700, 16, 128), (333, 64, 64), (130, 256, 32), (1000, 32, 1000)])
+@pytest.mark.parametrize('cfg', [(700, 16, 128), (333, 64, 64), (130, 256, 32), (1000, 32, 1000), (1024, 16, 32), (256, 64, 32)])
 def test_batchnorm_forward_stats_and_backward(backend, cfg):
     rt = get_runtime(backend)
     M, Cc, rpb = cfg
@@ -133,8 +133,15 @@ def test_batchnorm_forward_stats_and_backward(backend, cfg):
     dX = rt.alloc((M, Cc), zero=False)
     ops.bn_bwd_reduce(rt, dAb, d['x'], M, Cc, mean, istd, scale, d['beta'], 1, G, rpb, part2)(rt.stream)
     ops.bn_bwd_finalize(rt, part2, nb, M, Cc, dbeta, dgamma, c1, c2)(rt.stream)
-    ops.bn_bwd_apply(rt, G, d['x'], M, Cc, mean, istd, scale, c1, c2, dX, add=addb)(rt.stream)
+    csp = rt.alloc((nb, Cc), zero=False)
+    csum = rt.alloc(Cc, zero=False)
+    ops.bn_bwd_apply(rt, G, d['x'], M, Cc, mean, istd, scale, c1, c2, dX, add=addb, rpb=rpb, colsum=csp)(rt.stream)
+    jobs = ops.ReduceJobs(rt)
+    jobs.add(csp, nb, Cc, csum)
+    jobs.add(part2, nb, 2 * Cc, part2.view(0, (2 * Cc,)) if False else rt.alloc(2 * Cc))       # a second, unrelated job
+    jobs.launch()(rt.stream)
     rt.synchronize()
+    np.testing.assert_allclose(csum.get(), dX.get().astype('f8').sum(0), rtol=0, atol=3e-6 * np.sqrt(M) * np.abs(dX.get()).max())
     v = y_ref[0, :, :, 0].T                           # bn output (M, C)
     # the mask is decided on the device's own f32 bn value; exclude elements within f32 noise of zero
     safe = np.abs(v) > 1e-4
@@ -207,3 +214,84 @@ def test_loss_colsum_adam_elementwise(backend):
     np.testing.assert_allclose(o1.get(), np.float32(0.7) * np.maximum(pre, 0), rtol=1e-7)
     np.testing.assert_array_equal(o2.get(), mask * np.maximum(pre, 0))
     np.testing.assert_array_equal(g1.get(), pre * mask * (pre >= 0))
+
+
+class _BN(object):
+    pass
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('kind', ['gemm', 'conv3x3'])
+def test_fused_epilogues_stats_and_bn_backward(backend, kind):
+    """Fused epilogues: (a) per-block BatchNorm statistics of the tensor a conv writes == a separate statistics pass;
+    (b) the data-gradient epilogue's ReLU mask + (sum G, sum G*xhat) == dpp_bn_bwd_reduce."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(31)
+    if kind == 'gemm':
+        N, H, W, Ci, Co, bm = 3, 10, 10, 32, 48, 64          # 300 rows: 5 row blocks, the last one partial
+    else:
+        N, H, W, Ci, Co, bm = 3, 8, 8, 16, 32, 64
+    M = N * H * W
+    x = (rng.normal(size=(M, Ci)) + 3.0).astype(np.float32)
+    res = rng.normal(size=(M, Co)).astype(np.float32)
+    bias = rng.normal(size=Co).astype(np.float32)
+    xb, resb, bb = rt.upload(x), rt.upload(res), rt.upload(bias)
+    Y = rt.alloc((M, Co), zero=False)
+    if kind == 'gemm':
+        Wk = (rng.normal(size=(Co, Ci)) * 0.2).astype(np.float32)
+        nblk = -(-M // bm)
+        stats = rt.alloc((nblk, 2, Co), zero=False)
+        ops.gemm(rt, xb, rt.upload(Wk), Y, M, Co, Ci, 1, 1, Ci, Ci, Co, bias=bb, residual=resb, tile=(bm, 16, 4),
+                 epi=ops.epilogue(stats=stats))(rt.stream)
+        y_ref = x.astype('f8') @ Wk.astype('f8').T + bias + res
+        rpb = bm
+    else:
+        Wr = (rng.normal(size=(Co, Ci, 3, 3)) * 0.2).astype(np.float32)
+        nblk = rt.lib.dpp_conv3x3_tiling(N, H, W, bm, None, None, None)
+        stats = rt.alloc((nblk, 2, Co), zero=False)
+        ops.conv3x3(rt, xb, N, H, W, Ci, rt.upload(layout.conv_w_to_kernel(Wr)), Co, Y, bias=bb, residual=resb, bm=bm,
+                    epi=ops.epilogue(stats=stats))(rt.stream)
+        xn = layout.nhwc_to_nchw(x.reshape(N, H, W, Ci).astype('f8'))
+        y_ref = layout.nchw_to_nhwc(L.conv2d_fwd(xn, Wr.astype('f8'), bias.astype('f8'), (1, 1), 'half')).reshape(M, Co) + res
+        rpb = bm
+    gamma = rng.uniform(0.5, 1.5, Co).astype(np.float32)
+    mean, istd, scale = (rt.alloc(Co, zero=False) for _ in range(3))
+    ops.bn_finalize(rt, stats, nblk, M, rpb, Co, rt.upload(gamma), 1e-4, mean, istd, scale)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_allclose(Y.get(), y_ref, rtol=0, atol=3e-5 * np.abs(y_ref).max())
+    np.testing.assert_allclose(mean.get(), y_ref.mean(0), rtol=0, atol=3e-6 * np.abs(y_ref).max())
+    np.testing.assert_allclose(istd.get(), 1 / np.sqrt(y_ref.var(0) + np.float32(1e-4)), rtol=3e-5)
+
+    # (b) data gradient with the BatchNorm-backward fusion: out channels = Ci of the forward conv
+    dy = rng.normal(size=(M, Co)).astype(np.float32)
+    dyb = rt.upload(dy)
+    bn = _BN()
+    mu, sg, be = x.mean(0).astype(np.float32), rng.uniform(0.5, 1.5, Ci).astype(np.float32), (rng.normal(size=Ci) * 0.5).astype(np.float32)
+    isd = (1 / np.sqrt(x.var(0) + 1e-4)).astype(np.float32)
+    bn.mean, bn.inv_std, bn.scale, bn.beta_buf = rt.upload(mu), rt.upload(isd), rt.upload(sg * isd), rt.upload(be)
+    G = rt.alloc((M, Ci), zero=False)
+    if kind == 'gemm':
+        nb2 = -(-M // bm)
+        part = rt.alloc((nb2, 2, Ci), zero=False)
+        ops.gemm(rt, dyb, rt.upload(Wk), G, M, Ci, Co, 1, 0, Co, Ci, Ci, tile=(bm, 32, 4),
+                 epi=ops.epilogue(bn=bn, bn_x=xb, bn_relu=True, bn_partial=part))(rt.stream)
+        da_ref = dy.astype('f8') @ Wk.astype('f8')
+    else:
+        nb2 = nblk
+        part = rt.alloc((nb2, 2, Ci), zero=False)
+        Wd = rt.alloc(Ci * 9 * Co, zero=False)
+        ops.conv3x3_wtrans(rt, rt.upload(layout.conv_w_to_kernel(Wr)), Co, Ci, Wd)(rt.stream)
+        ops.conv3x3(rt, dyb, N, H, W, Co, Wd, Ci, G, bm=bm, epi=ops.epilogue(bn=bn, bn_x=xb, bn_relu=True, bn_partial=part))(rt.stream)
+        dyn = layout.nhwc_to_nchw(dy.reshape(N, H, W, Co).astype('f8'))
+        da_ref = layout.nchw_to_nhwc(L.conv2d_bwd(xn, Wr.astype('f8'), dyn, (1, 1), 'half')[0]).reshape(M, Ci)
+    dbeta, dgamma, c1, c2 = (rt.alloc(Ci, zero=False) for _ in range(4))
+    ops.bn_bwd_finalize(rt, part, nb2, M, Ci, dbeta, dgamma, c1, c2)(rt.stream)
+    rt.synchronize()
+    v = (x.astype('f8') - mu) * (sg * isd) + be
+    safe = np.abs(v) > 1e-4
+    g_ref = da_ref * (v >= 0)
+    got = G.get()
+    np.testing.assert_allclose(got[safe], g_ref[safe], rtol=0, atol=3e-5 * np.abs(da_ref).max())
+    xhat = (x.astype('f8') - mu) * isd
+    np.testing.assert_allclose(dbeta.get(), got.astype('f8').sum(0), rtol=0, atol=3e-5 * np.sqrt(M) * np.abs(got).max())
+    np.testing.assert_allclose(dgamma.get(), (got.astype('f8') * xhat).sum(0), rtol=0, atol=3e-4 * np.sqrt(M) * np.abs(got).max())
