@@ -234,6 +234,8 @@ def gemm_plan(M, N, K, allow_split=True):
     else:
         wm = 4
         cands = [(128, 64), (64, 64), (128, 32), (64, 32), (128, 16), (64, 16)]
+        if os.environ.get('DPP_NO_128x64', '1') != '0':
+            cands = cands[1:]          # measured: 64x64 beats 128x64 on every conv shape of the net (gemm_micro.py)
         cands = [(a, b) for (a, b) in cands if b <= max(16, 16 * (-(-N // 16))) or b == 16]
         bm, bn = cands[-1]
         for (a, b) in cands:
@@ -562,6 +564,9 @@ class CompiledNet(object):
         out = self._new_tensor((Nb, Nout), 'fc%d' % layer.layerNum)
         rt, st = self.rt, self.store
         tile, splitk = gemm_plan(Nb, Nout, K)
+        if K >= 4096 and Nb <= 128 and Nout >= 64:
+            # weight-streaming shape (FC1: 67 MB of W for 128 rows): wide column tiles read W in 256 B rows, K split 512 deep
+            tile, splitk = (64, 64, 4), max(1, K // 512)
         act = self._act(src)
         if splitk > 1:
             part = self.scratch(splitk * Nb * Nout)

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single kernels of the hot path on the GPU (back-to-back launches, HIP events):
+   python tools/gemm_micro.py      -> one line per (shape, variant, feature set) with us/launch and GB/s"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'deep-prior-pp_amd'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from hipdp import ops  # noqa: E402
+from hipdp.lib import Act  # noqa: E402
+from hipdp.runtime import TorchHipRuntime  # noqa: E402
+
+rt = TorchHipRuntime()
+REP = 200
+
+
+def timeit(launch, rep=REP):
+    for _ in range(10):
+        launch(rt.stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(rep):
+        launch(rt.stream)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / rep
+
+
+class BN(object):
+    pass
+
+
+def bench_gemm(M, N, K, b_kc, tile, variant, feats, label):
+    A = rt.alloc((M, K), zero=False)
+    rt.tensor(A).normal_()
+    B = rt.alloc((N, K) if b_kc else (K, N), zero=False)
+    rt.tensor(B).normal_()
+    Cb = rt.alloc((M, N), zero=False)
+    kw = {}
+    if 'act' in feats:
+        mean, scale, beta = rt.alloc(K), rt.alloc(K), rt.alloc(K)
+        a = Act(mean.ptr, scale.ptr, beta.ptr, 3, K)
+        a._keep = (mean, scale, beta)
+        kw['actA'] = a
+    if 'bias' in feats:
+        kw['bias'] = rt.alloc(N)
+    if 'res' in feats:
+        kw['residual'] = rt.alloc((M, N))
+    if 'stats' in feats:
+        nblk = -(-M // tile[0])
+        kw['epi'] = ops.epilogue(stats=rt.alloc((nblk, 2, N), zero=False))
+    if 'bnbwd' in feats:
+        nblk = -(-M // tile[0])
+        bn = BN()
+        bn.mean, bn.inv_std, bn.scale, bn.beta_buf = rt.alloc(N), rt.alloc(N), rt.alloc(N), rt.alloc(N)
+        kw['epi'] = ops.epilogue(bn=bn, bn_x=rt.alloc((M, N)), bn_partial=rt.alloc((nblk, 2, N), zero=False))
+    L = ops.gemm(rt, A, B, Cb, M, N, K, 1, int(b_kc), K, K if b_kc else N, N, tile=tile, variant=variant, **kw)
+    us = timeit(L)
+    byts = 4.0 * (M * K + K * N + M * N * (2 if 'res' in feats else 1) + (M * N if 'bnbwd' in feats else 0))
+    print('%-34s M=%6d N=%4d K=%4d tile=%-12s v%d %-22s %7.2f us  %6.0f GB/s' %
+          (label, M, N, K, tile, variant, '+'.join(feats) or '-', us, byts / us * 1e-3))
+
+
+def bench_fc(label, M, N, K, a_kc, b_kc, tile, splitk):
+    A = rt.alloc((M, K), zero=False)
+    rt.tensor(A).normal_()
+    B = rt.alloc((K, N), zero=False)
+    rt.tensor(B).normal_()
+    Cb = rt.alloc((M, N), zero=False)
+    lda = K if a_kc else M
+    ldb = K if b_kc else N
+    try:
+        if splitk > 1:
+            part = rt.alloc((splitk, M, N), zero=False)
+            L1 = ops.gemm(rt, A, B, None, M, N, K, a_kc, b_kc, lda, ldb, N, splitk=splitk, partial=part, tile=tile)
+            L2 = ops.reduce_partials(rt, part, splitk, M * N, Cb)
+            us1, us2 = timeit(L1, 50), timeit(L2, 50)
+        else:
+            us1, us2 = timeit(ops.gemm(rt, A, B, Cb, M, N, K, a_kc, b_kc, lda, ldb, N, tile=tile), 50), 0.0
+    except Exception as e:
+        print('%-12s tile=%s splitk=%d: %s' % (label, tile, splitk, e))
+        return
+    byts = 4.0 * (M * K + K * N + M * N)
+    print('%-12s M=%6d N=%6d K=%6d akc=%d bkc=%d tile=%-13s splitk=%3d  gemm %7.2f + reduce %6.2f us  (%5.0f GB/s algorithmic)' %
+          (label, M, N, K, a_kc, b_kc, tile, splitk, us1, us2, byts / (us1 + us2) * 1e-3))
+
+
+def main_fc():
+    for tile in ((64, 16, 4), (64, 32, 4), (64, 64, 4), (128, 64, 4), (128, 32, 4)):
+        for sk in (8, 16, 32, 64):
+            bench_fc('fc1 fwd', 128, 1024, 16384, 1, 0, tile, sk)
+    for tile in ((64, 16, 4), (64, 32, 4), (64, 64, 4), (128, 64, 4), (128, 32, 4)):
+        for sk in (1, 2, 4):
+            bench_fc('fc1 dgrad', 128, 16384, 1024, 1, 1, tile, sk)
+    for tile in ((64, 64, 4), (128, 64, 4), (128, 32, 4), (64, 32, 4)):
+        bench_fc('fc1 wgrad', 16384, 1024, 128, 0, 0, tile, 1)
+    for tile in ((64, 16, 4), (64, 32, 4), (64, 64, 4), (128, 32, 4)):
+        for sk in (1, 4, 8):
+            bench_fc('fc2 fwd', 128, 1024, 1024, 1, 0, tile, sk)
+            bench_fc('fc2 dgrad', 128, 1024, 1024, 1, 1, tile, sk)
+        bench_fc('fc2 wgrad', 1024, 1024, 128, 0, 0, tile, 1)
+
+
+def main():
+    if 'fc' in sys.argv[1:]:
+        return main_fc()
+    z = rt.alloc(4)
+    print('launch floor (fill_zero 4 floats): %.2f us' % timeit(ops.fill_zero(rt, z, 4)))
+    shapes = [('stage3/4 conv a 256->64', 8192, 64, 256), ('stage3/4 conv c 64->256', 8192, 256, 64),
+              ('stage2 conv a 128->32', 32768, 32, 128), ('stage2 conv c 32->128', 32768, 128, 32),
+              ('stage1 conv a 64->16', 131072, 16, 64), ('stage1 conv c 16->64', 131072, 64, 16)]
+    for label, M, N, K in shapes:
+        for variant in (0, 1):
+            for tile in ((64, min(64, max(16, N)), 4), (128, min(64, max(16, N)), 4), (64, 16, 4)):
+                for feats in ((), ('act', 'bias', 'res', 'stats')):
+                    try:
+                        bench_gemm(M, N, K, True, tile, variant, feats, label)
+                    except Exception as e:      # unsupported tile for the variant
+                        print('%-34s tile=%s v%d: %s' % (label, tile, variant, e))
+
+
+if __name__ == '__main__':
+    main()

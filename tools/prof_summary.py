@@ -5,15 +5,23 @@ import re
 import sqlite3
 import sys
 
-db = sqlite3.connect(sys.argv[1])
-steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-rows = db.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3, "
-                  "max(vgpr_count), max(lds_size) from kernels group by name order by 3 desc").fetchall()
+by_grid = '--by-grid' in sys.argv                # one line per (kernel, grid) instead of per kernel
+argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+db = sqlite3.connect(argv[0])
+steps = float(argv[1]) if len(argv) > 1 else 1.0
+key = "name || ' <' || (grid_x/workgroup_x) || ',' || (grid_y/workgroup_y) || ',' || (grid_z/workgroup_z) || '>'" if by_grid else "name"
+rows = db.execute("select %s, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3, "
+                  "max(vgpr_count), max(lds_size) from kernels group by 1 order by 3 desc" % key).fetchall()
 tot = sum(r[2] for r in rows)
 print("rocprofv3 --kernel-trace summary: %d kernels, %d dispatches, total %.1f us (%.1f us per step over %g steps)" %
       (len(rows), sum(r[1] for r in rows), tot, tot / steps, steps))
 print("%-66s %7s %11s %9s %9s %9s %6s %5s %6s" % ('kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%', 'vgpr', 'lds'))
 for r in rows:
     name = re.sub(r'\(anonymous namespace\)::', '', r[0])
+    grid = ''
+    if by_grid:
+        name, grid = name.rsplit(' <', 1)
+        grid = ' <' + grid
     name = re.sub(r'\(.*$', '', name) if not name.startswith('void') else re.sub(r'\(.*$', '', name[5:])
+    name = name[:66 - len(grid)] + grid
     print("%-66s %7d %11.1f %9.2f %9.2f %9.2f %6.1f %5d %6d" % (name[:66], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot, r[6] or 0, r[7] or 0))
