@@ -161,7 +161,9 @@ __global__ __launch_bounds__(DPP_THREADS) void relu_bwd_kernel(const float* __re
 // Bernoulli(keep) mask from a counter-based generator (splitmix64 of (seed, counter, index)): the dropout mask of
 // dropoutlayer.py:98-103 (the reference's MRG31k3p stream is not reproduced bit for bit)
 __global__ __launch_bounds__(DPP_THREADS) void bernoulli_mask_kernel(float* __restrict__ mask, size_t n, float keep, unsigned long long seed,
-                                                                     unsigned long long counter) {
+                                                                     unsigned long long counter,
+                                                                     const unsigned long long* __restrict__ counter_dev) {
+    if (counter_dev) counter += *counter_dev;
     for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DPP_THREADS) {
         unsigned long long z = seed * 0x9E3779B97F4A7C15ull + counter * 0xD1B54A32D192ED03ull + i + 0x632BE59BD9B4E019ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -245,9 +247,9 @@ extern "C" int dpp_fill_zero(void* p, size_t nbytes, dpp_stream_t stream) {
 }
 
 extern "C" int dpp_bernoulli_mask(float* mask, size_t n, float keep, unsigned long long seed, unsigned long long counter,
-                                  dpp_stream_t stream) {
+                                  const unsigned long long* counter_dev, dpp_stream_t stream) {
     if (!mask || n < 1) return DPP_E_BADARG;
     hipLaunchKernelGGL(bernoulli_mask_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), mask, n, keep, seed,
-                       counter);
+                       counter, counter_dev);
     return dpp_launch_status();
 }

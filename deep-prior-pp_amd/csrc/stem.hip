@@ -7,12 +7,14 @@
 // Forward (stem_fwd_kernel): implicit GEMM on v_mfma_f32_16x16x4_f32 with K = 25 taps (padded to 28).
 // A workgroup owns a 16x16 patch of conv pixels (8x8 pooled outputs); the 20x20 input halo and the weights
 // live in LDS.  The 16 rows of an MFMA tile are ordered as 4 pooling windows x 4 window pixels, so the
-// four D registers of a lane are exactly one pooling window: max-pool + argmax happen in registers, the
-// 128x128x32 conv map never touches memory.  The single input channel makes NCHW == NHWC: loads are the
+// four D registers of a lane are exactly one pooling window: the max-pool and its tie mask (bit j set = window
+// element j equals the maximum; Theano's MaxPoolGrad gives the gradient to every tied element, and the constant
+// background of a depth crop does tie) happen in registers, the 128x128x32 conv map never touches memory.  The single input channel makes NCHW == NHWC: loads are the
 // reference's own NCHW depth patches, coalesced along x.
 //
-// Filter gradient (stem_wgrad_kernel): dW[o][tap] = sum over pooled outputs of dY[p][o] * x[argmax(p,o) + tap]
-// (the max-pool routes each gradient to one conv pixel that differs per channel, so this is not a GEMM);
+// Filter gradient (stem_wgrad_kernel): dW[o][tap] = sum over pooled outputs p and tied window elements j of
+// dY[p][o] * x[pixel(p, j) + tap] (the max-pool routes each gradient to conv pixels that differ per channel, so this is
+// not a GEMM);
 // VALU kernel, thread = (channel, pixel group), per-workgroup partials, fixed-order reduce.
 #include "dpp_common.h"
 
@@ -87,13 +89,12 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_fwd_kernel(const float* __re
             for (int ct = 0; ct < CN; ++ct) {
                 int col = ct * 16 + l15;
                 if (col < Co) {
-                    float best = acc[ct][0];
-                    int bi = 0;
+                    float best = fmaxf(fmaxf(acc[ct][0], acc[ct][1]), fmaxf(acc[ct][2], acc[ct][3]));
+                    int ties = 0;
 #pragma unroll
-                    for (int r = 1; r < 4; ++r)
-                        if (acc[ct][r] > best) { best = acc[ct][r]; bi = r; }    // first maximum in scan order
+                    for (int r = 0; r < 4; ++r) ties |= (acc[ct][r] == best) ? (1 << r) : 0;
                     Y[o + col] = best + bias[col];
-                    if (arg) arg[o + col] = (uint8_t)bi;
+                    if (arg) arg[o + col] = (uint8_t)ties;
                 }
             }
         }
@@ -132,10 +133,13 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_wgrad_kernel(const float* __
                 if (py >= Hp || px >= Wp) continue;
                 size_t idx = (((size_t)n * Hp + py) * Wp + px) * Co + o;
                 float g = dY[idx];
-                int a = arg[idx];
-                const float* base = &xs[(2 * ply + (a >> 1)) * LXP + 2 * plx + (a & 1)];
+                int ties = arg[idx];
+                for (int a = 0; a < 4; ++a) {
+                    if (!((ties >> a) & 1)) continue;
+                    const float* base = &xs[(2 * ply + (a >> 1)) * LXP + 2 * plx + (a & 1)];
 #pragma unroll
-                for (int k = 0; k < NTAP; ++k) acc[k] += g * base[(k / KS) * LXP + (k % KS)];
+                    for (int k = 0; k < NTAP; ++k) acc[k] += g * base[(k / KS) * LXP + (k % KS)];
+                }
             }
         }
     }

@@ -315,6 +315,7 @@ class CompiledNet(object):
         self.colsum_of = {}                 # dY buffer ptr -> (column-sum partials, nb, C) emitted by bn_bwd_apply
         self.reduce_jobs = ops.ReduceJobs(rt)
         self.dropout_masks = {}
+        self.step_ctr = rt.alloc(1, np.int64) if train else None     # device-resident step counter (dropout mask streams)
         in_dim = net.cfgParams.inputDim
         self.in_shape = (in_dim[0], in_dim[2], in_dim[3], in_dim[1])
         self.x_in = TensorV(rt.alloc(self.in_shape), self.in_shape, 'x')
@@ -352,6 +353,8 @@ class CompiledNet(object):
                 self.upd.add(self._grad_allreduce)
             self.upd.add(ops.adam(rt, self.store.w, self.store.g, self.store.m, self.store.v, self.store.n_w, self.hyper))
             self.upd.add(ops.adam_tick(rt, self.hyper))
+            if self.dropout_masks:
+                self.upd.add(ops.counter_add(rt, self.step_ctr, 1))
             self._lr = None
             self.reset_optimizer()
 
@@ -503,14 +506,38 @@ class CompiledNet(object):
         ok = (src.base is self.x_in and Ci == 1 and tuple(c.filterDim) == (5, 5) and c.border_mode == 'half' and
               tuple(c.poolsize) == (2, 2) and tuple(c.stride) == (1, 1) and c.activation is None and c.nFilters <= 32)
         if not ok:
-            raise NotImplementedError("ConvPoolLayer other than the ResNet stem (5x5 'same', pool 2, 1 input channel) -- "
-                                      "PoseRegNet's conv-pool stack is scheduled next (SURVEY.md 8(d))")
+            return self._emit_convpool(layer, src)
         Co = c.nFilters
         out = self._new_tensor((N, H // 2, W // 2, Co), 'stem')
         arg = self.rt.alloc((N, H // 2, W // 2, Co), np.uint8, zero=False) if self.train else None
         self.fwd.add(ops.stem_fwd(self.rt, src.base.buf.reshape(N, H, W), N, H, W, self.store.view(layer.W), self.store.view(layer.b), Co,
                                   out.buf, arg))
-        self.layer_io[id(layer)] = dict(in_view=src, out=out, argmax=arg)
+        self.layer_io[id(layer)] = dict(in_view=src, out=out, argmax=arg, stem=True)
+        return View(out)
+
+    def _emit_convpool(self, layer, src):
+        """Generic ConvPoolLayer (PoseRegNet's front end, poseregnet.py:62-78): VALU conv + max-pool + bias kernels."""
+        c = layer.cfgParams
+        N, H, W, Ci = src.base.shape
+        kh, kw = c.filterDim[0], c.filterDim[1]
+        if len(src.shape) != 4:
+            raise NotImplementedError("ConvPoolLayer on a flattened input")
+        if c.border_mode not in ('valid', 'half') or tuple(c.stride) != (1, 1) or c.poolsize[0] != c.poolsize[1]:
+            raise NotImplementedError("ConvPoolLayer border %s stride %s pool %s" % (c.border_mode, c.stride, c.poolsize))
+        if c.border_mode == 'half' and (kh % 2 == 0 or kw % 2 == 0):
+            raise NotImplementedError("'half' padding with an even filter size")
+        pad = kh // 2 if c.border_mode == 'half' else 0
+        if c.border_mode == 'half' and kh != kw:
+            raise NotImplementedError("'half' padding with a non-square filter")
+        pool, Co = int(c.poolsize[0]), c.nFilters
+        _, Co_, Hp, Wp = c.outputDim
+        assert Co_ == Co
+        out = self._new_tensor((N, Hp, Wp, Co), 'convpool%d' % layer.layerNum)
+        ties = self.rt.alloc((N, Hp, Wp, Co), np.uint16, zero=False) if (self.train and pool > 1) else None
+        geom = dict(N=N, H=H, W=W, Ci=Ci, kh=kh, kw=kw, pad=pad, Co=Co, pool=pool, Hp=Hp, Wp=Wp)
+        self.fwd.add(ops.convpool_fwd(self.rt, src.base.buf, N, H, W, Ci, self.store.view(layer.W), kh, kw, pad, Co, pool,
+                                      self.store.view(layer.b), out.buf, ties, actX=self._act(src), name='convpool_%d' % layer.layerNum))
+        self.layer_io[id(layer)] = dict(in_view=src, out=out, ties=ties, geom=geom, stem=False)
         return View(out)
 
     def _emit_conv(self, layer, src, residual, out_var=None):
@@ -589,6 +616,8 @@ class CompiledNet(object):
         if self.train:
             mask = self.rt.alloc(src.shape)
             self.dropout_masks[id(layer)] = (mask, float(keep), layer.mask_seed)
+            # a fresh Bernoulli(1-p) mask per step (dropoutlayer.py:98-103): stream keyed by (layer seed, layer, device step counter)
+            self.fwd.add(ops.bernoulli_mask(self.rt, mask, n, float(keep), layer.mask_seed, layer.layerNum << 40, self.step_ctr))
         self.fwd.add(ops.scale(self.rt, src.base.buf, out.buf, n, a=keep, relu=src.relu, mask=mask))
         self.layer_io[id(layer)] = dict(in_view=src, out=out, mask=mask)
         return View(out)
@@ -838,7 +867,28 @@ class CompiledNet(object):
                                       tile=tile, name='fc_dgrad_%d' % layer.layerNum))
             tgt.grad_written = True
 
+    def _bwd_convpool(self, layer, io, dY):
+        rt, st = self.rt, self.store
+        g, src = io['geom'], io['in_view']
+        nW = g['Co'] * g['kh'] * g['kw'] * g['Ci']
+        self.bwd.fork()
+        self._bias_grad(dY, io['out'].rows, g['Co'], st.view(layer.b, 'g'))
+        nblk = rt.lib.dpp_convpool_wgrad_blocks(g['N'], g['Hp'], g['Wp'])
+        part = rt.alloc(nblk * nW, zero=False)
+        self.bwd.add(ops.convpool_wgrad(rt, src.base.buf, g['N'], g['H'], g['W'], g['Ci'], dY, io['ties'], g['kh'], g['kw'], g['pad'],
+                                        g['Co'], g['pool'], part, actX=self._act(src), name='convpool_wgrad_%d' % layer.layerNum), side=True)
+        self.reduce_jobs.add(part, nblk, nW, st.view(layer.W, 'g'))
+        if src.base is not self.x_in:
+            tgt, dst = self._view_grad(src)
+            if tgt.grad_written:
+                raise NotImplementedError("ConvPoolLayer input with several consumers")
+            self.bwd.add(ops.convpool_dgrad(rt, dY, io['ties'], g['N'], g['H'], g['W'], g['Ci'], st.view(layer.W), g['kh'], g['kw'],
+                                            g['pad'], g['Co'], g['pool'], dst, name='convpool_dgrad_%d' % layer.layerNum))
+            tgt.grad_written = True
+
     def _bwd_stem(self, layer, io, dY):
+        if not io.get('stem', True):
+            return self._bwd_convpool(layer, io, dY)
         rt, st = self.rt, self.store
         N, H, W, _ = self.in_shape
         Co = layer.cfgParams.nFilters

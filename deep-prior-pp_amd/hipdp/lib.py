@@ -71,6 +71,13 @@ SIGNATURES = {
     'dpp_stem_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'dpp_stem_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_int, stream_t]),
+    'dpp_convpool_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
+    'dpp_convpool_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'dpp_convpool_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_convpool_dgrad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_bn_stats_partial': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_bn_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, stream_t]),
@@ -95,7 +102,7 @@ SIGNATURES = {
     'dpp_scale': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_size_t, stream_t]),
     'dpp_relu_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, stream_t]),
     'dpp_fill_zero': (C.c_int, [C.c_void_p, C.c_size_t, stream_t]),
-    'dpp_bernoulli_mask': (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_ulonglong, C.c_ulonglong, stream_t]),
+    'dpp_bernoulli_mask': (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_ulonglong, C.c_ulonglong, C.c_void_p, stream_t]),
     'dpp_augment_record_bytes': (C.c_size_t, []),
     'dpp_augment_prepare': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 5 + [C.c_int, C.c_ulonglong,
                                       C.c_ulonglong, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -173,6 +173,26 @@ def stem_wgrad(rt, X, N, H, W, dY, argmax, Co, partial, tiles_per_block, name='s
                   (X, dY, argmax, partial), name, dict(kernel='stem_wgrad', flops=2.0 * px / 4 * Co * 25, bytes=4.0 * px + px / 4 * Co * 5.0))
 
 
+def convpool_fwd(rt, X, N, H, W, Ci, Wk, kh, kw, pad, Co, pool, bias, Y, ties=None, actX=None, name='convpool_fwd'):
+    px = float(N) * (H + 2 * pad - kh + 1) * (W + 2 * pad - kw + 1)
+    return Launch(rt.lib.dpp_convpool_fwd, (X.ptr, N, H, W, Ci, _actp(actX), Wk.ptr, kh, kw, pad, Co, pool, bias.ptr, Y.ptr, _p(ties)),
+                  (X, Wk, bias, Y, ties, actX), name,
+                  dict(kernel='convpool_fwd', flops=2.0 * px * kh * kw * Ci * Co, bytes=4.0 * N * H * W * Ci + 6.0 * px / (pool * pool) * Co))
+
+
+def convpool_wgrad(rt, X, N, H, W, Ci, dY, ties, kh, kw, pad, Co, pool, partial, actX=None, name='convpool_wgrad'):
+    px = float(N) * (H + 2 * pad - kh + 1) * (W + 2 * pad - kw + 1) / (pool * pool)
+    return Launch(rt.lib.dpp_convpool_wgrad, (X.ptr, N, H, W, Ci, _actp(actX), dY.ptr, _p(ties), kh, kw, pad, Co, pool, partial.ptr),
+                  (X, dY, ties, partial, actX), name,
+                  dict(kernel='convpool_wgrad', flops=2.0 * px * kh * kw * Ci * Co, bytes=4.0 * N * H * W * Ci + 6.0 * px * Co))
+
+
+def convpool_dgrad(rt, dY, ties, N, H, W, Ci, Wk, kh, kw, pad, Co, pool, dX, name='convpool_dgrad'):
+    px = float(N) * (H + 2 * pad - kh + 1) * (W + 2 * pad - kw + 1) / (pool * pool)
+    return Launch(rt.lib.dpp_convpool_dgrad, (dY.ptr, _p(ties), N, H, W, Ci, Wk.ptr, kh, kw, pad, Co, pool, dX.ptr), (dY, ties, Wk, dX), name,
+                  dict(kernel='convpool_dgrad', flops=2.0 * px * kh * kw * Ci * Co, bytes=4.0 * N * H * W * Ci + 6.0 * px * Co))
+
+
 def bn_stats_partial(rt, X, M, Cc, rpb, partial, name='bn_stats_partial'):
     return Launch(rt.lib.dpp_bn_stats_partial, (X.ptr, M, Cc, rpb, partial.ptr), (X, partial), name,
                   dict(kernel='bn_stats_partial', flops=3.0 * M * Cc, bytes=4.0 * M * Cc))
@@ -265,8 +285,8 @@ def fill_zero(rt, buf, name='fill_zero'):
     return Launch(rt.lib.dpp_fill_zero, (buf.ptr, buf.nbytes), (buf,), name)
 
 
-def bernoulli_mask(rt, mask, n, keep, seed, counter, name='bernoulli_mask'):
-    return Launch(rt.lib.dpp_bernoulli_mask, (mask.ptr, n, float(keep), int(seed), int(counter)), (mask,), name)
+def bernoulli_mask(rt, mask, n, keep, seed, counter, counter_dev=None, name='bernoulli_mask'):
+    return Launch(rt.lib.dpp_bernoulli_mask, (mask.ptr, n, float(keep), int(seed), int(counter), _p(counter_dev)), (mask, counter_dev), name)
 
 
 def adam_tick(rt, state, name='adam_tick'):

@@ -64,7 +64,7 @@ class TorchHipRuntime(object):
         self.has_side_stream = os.environ.get('DPP_NO_SIDE_STREAM', '0') != '1'
         self._side = torch.cuda.Stream(self.device)
 
-    _TD = {'float32': 'float32', 'int32': 'int32', 'uint8': 'uint8', 'float64': 'float64', 'int64': 'int64'}
+    _TD = {'float32': 'float32', 'int32': 'int32', 'uint8': 'uint8', 'uint16': 'uint16', 'float64': 'float64', 'int64': 'int64'}
 
     def alloc(self, shape, dtype=np.float32, zero=True):
         t = self.torch

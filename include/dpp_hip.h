@@ -134,13 +134,32 @@ int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act
 
 /* ---- ResNet stem: ConvPoolLayer 5x5 'half' 1 -> Co (<= 32), 2x2 max-pool, bias AFTER the pool ----------------
  * /root/reference/src/net/convpoollayer.py:251-282 as built at /root/reference/src/net/resnet.py:128-133.
- * X: [N][H][W] single-channel crops (NCHW == NHWC); Wk: [Co][25]; Y: [N][H/2][W/2][Co]; argmax: first maximum of
- * each 2x2 window in row-major scan order (0..3), kept for the filter gradient. */
+ * X: [N][H][W] single-channel crops (NCHW == NHWC); Wk: [Co][25]; Y: [N][H/2][W/2][Co]; argmax: the TIE MASK of each
+ * 2x2 window (bit j set = window element j, row-major, equals the maximum), kept for the filter gradient: Theano's
+ * MaxPoolGrad gives the gradient to every element equal to the maximum, and the constant background of a depth crop
+ * makes whole windows tie. */
 int dpp_stem_fwd(const float* X, int N, int H, int W, const float* Wk, const float* bias, int Co, float* Y, uint8_t* argmax,
                  dpp_stream_t stream);
 int dpp_stem_wgrad_blocks(int N, int H, int W, int tiles_per_block);
 int dpp_stem_wgrad(const float* X, int N, int H, int W, const float* dY, const uint8_t* argmax, int Co, float* partial,
                    int tiles_per_block, dpp_stream_t stream);
+
+/* ---- generic ConvPoolLayer: kh x kw conv ('valid': pad 0, 'half': pad k/2), pool x pool max-pool (ignore_border), bias
+ * AFTER the pool; the activation is the consumer's operand prologue.  /root/reference/src/net/convpoollayer.py:251-282
+ * as built by PoseRegNet, /root/reference/src/net/poseregnet.py:62-78 (5x5/pool 4, 5x5/pool 2, 3x3/no pool, 8 filters).
+ * X: [N][H][W][Ci] with the optional ReLU / BN prologue `act`; Wk: [Co][kh*kw][Ci] (flipped, layout.py);
+ * Y: [N][Hp][Wp][Co], Hp = (H + 2 pad - kh + 1) / pool; ties: [N][Hp][Wp][Co] uint16 tie masks of the pool windows
+ * (bit j = window element j, row-major, equals the maximum; NULL allowed when pool == 1 or in inference).
+ * wgrad: partial[blk][Co][kh*kw][Ci], blk < dpp_convpool_wgrad_blocks(N, Hp, Wp); sum with dpp_reduce_multi.
+ * dgrad: dX[N][H][W][Ci] = gradient w.r.t. the (activated) input operand.  Limits: Co <= 32, Ci <= 32, pool <= 4, k <= 7.
+ * These layers are 12.8 MFLOP / sample in total: VALU kernels, one thread per output pixel. */
+int dpp_convpool_fwd(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int kh, int kw, int pad,
+                     int Co, int pool, const float* bias, float* Y, uint16_t* ties, dpp_stream_t stream);
+int dpp_convpool_wgrad_blocks(int N, int Hp, int Wp);
+int dpp_convpool_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, const uint16_t* ties,
+                       int kh, int kw, int pad, int Co, int pool, float* partial, dpp_stream_t stream);
+int dpp_convpool_dgrad(const float* dY, const uint16_t* ties, int N, int H, int W, int Ci, const float* Wk, int kh, int kw,
+                       int pad, int Co, int pool, float* dX, dpp_stream_t stream);
 
 /* ---- BatchNormLayer, /root/reference/src/net/batchnormlayer.py:119-194 (tensors pixel-major [M][C], C % 4 == 0) ----
  * stats_partial: per row-chunk (mean_b, M2_b) -> partial[nb][2][C], nb = ceil(M / rows_per_block)
@@ -186,9 +205,10 @@ int dpp_scale(const float* x, const float* mask, float a, int relu, float* y, si
 int dpp_relu_bwd(const float* dy, const float* pre, const float* mask, float a, float* g, size_t n, dpp_stream_t stream);
 
 int dpp_fill_zero(void* p, size_t nbytes, dpp_stream_t stream);
-/* mask[i] = 1 with probability keep (counter-based generator keyed by seed, counter, i): DropoutLayer masks */
+/* mask[i] = 1 with probability keep (counter-based generator keyed by seed, counter + *counter_dev, i): DropoutLayer
+ * masks; counter_dev (may be NULL) is a device-resident step counter so that a recorded launch draws a new mask per step */
 int dpp_bernoulli_mask(float* mask, size_t n, float keep, unsigned long long seed, unsigned long long counter,
-                       dpp_stream_t stream);
+                       const unsigned long long* counter_dev, dpp_stream_t stream);
 
 /* ---- online crop augmentation, NetTrainer.augmentCrop (/root/reference/src/trainer/nettrainer.py:919-997) -------
  * prepare: per crop, the geometry of HandDetector.moveCoM / rotateHand / scaleHand

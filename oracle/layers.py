@@ -93,23 +93,24 @@ def conv2d_bwd(x, W, dy, stride=(1, 1), border_mode='valid', need_dx=True):
 # --------------------------------------------------------------------------- pool
 def maxpool_fwd(x, ds):
     """pool_2d(ds, ignore_border=True, mode='max'), /root/reference/src/net/convpoollayer.py:261.
-    Returns (y, arg) with arg = index of the (first) maximum inside each window, row-major."""
+    Returns (y, ties): ties[..., j] is True where window element j (row-major) EQUALS the window maximum.  Theano's
+    gradient op (theano/tensor/signal/pool.py, MaxPoolGrad: `if (a == maximum) gx += gz`) gives the gradient to every
+    tied element, which matters here: the constant far-plane background of a depth crop makes whole windows tie."""
     N, C, H, W = x.shape
     ph, pw = ds
     oh, ow = H // ph, W // pw
     xv = x[:, :, :oh * ph, :ow * pw].reshape(N, C, oh, ph, ow, pw).transpose(0, 1, 2, 4, 3, 5)
     xv = xv.reshape(N, C, oh, ow, ph * pw)
-    arg = xv.argmax(axis=4)
-    y = np.take_along_axis(xv, arg[..., None], axis=4)[..., 0]
-    return np.ascontiguousarray(y), arg
+    y = xv.max(axis=4)
+    ties = xv == y[..., None]
+    return np.ascontiguousarray(y), ties
 
 
-def maxpool_bwd(dy, arg, ds, in_hw):
+def maxpool_bwd(dy, ties, ds, in_hw):
     N, C, oh, ow = dy.shape
     ph, pw = ds
     H, W = in_hw
-    dxv = np.zeros((N, C, oh, ow, ph * pw), dtype=dy.dtype)
-    np.put_along_axis(dxv, arg[..., None], dy[..., None], axis=4)
+    dxv = ties * dy[..., None]
     dxv = dxv.reshape(N, C, oh, ow, ph, pw).transpose(0, 1, 2, 4, 3, 5).reshape(N, C, oh * ph, ow * pw)
     dx = np.zeros((N, C, H, W), dtype=dy.dtype)
     dx[:, :, :oh * ph, :ow * pw] = dxv

@@ -35,6 +35,29 @@ def _conv(a, W, stride, border):
     return full[:, :, ::stride[0], ::stride[1]]        # Theano subsample
 
 
+class _MaxPoolTies(torch.autograd.Function):
+    """Non-overlapping max-pool whose gradient goes to EVERY window element equal to the maximum (Theano's MaxPoolGrad;
+    torch's own max_pool2d picks one index, which differs on the constant background of a depth crop)."""
+
+    @staticmethod
+    def forward(ctx, c, ph, pw):
+        N, C, H, W = c.shape
+        oh, ow = H // ph, W // pw
+        v = c[:, :, :oh * ph, :ow * pw].reshape(N, C, oh, ph, ow, pw)
+        y = v.amax(dim=(3, 5))
+        ctx.save_for_backward(v == y[:, :, :, None, :, None])
+        ctx.dims = (N, C, H, W, oh, ph, ow, pw)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (ties,) = ctx.saved_tensors
+        N, C, H, W, oh, ph, ow, pw = ctx.dims
+        g = torch.zeros((N, C, H, W), dtype=gy.dtype)
+        g[:, :, :oh * ph, :ow * pw] = (ties * gy[:, :, :, None, :, None]).reshape(N, C, oh * ph, ow * pw)
+        return g, None, None
+
+
 def forward(net, T, x, train):
     vals, stats = {}, {}
 
@@ -55,7 +78,7 @@ def forward(net, T, x, train):
         if k == 'convpool':
             c = _conv(a, T[i][0], l['stride'], l['border'])
             if tuple(l['pool']) != (1, 1):
-                c = F.max_pool2d(c, kernel_size=l['pool'], stride=l['pool'])
+                c = _MaxPoolTies.apply(c, int(l['pool'][0]), int(l['pool'][1]))
             c = c + T[i][1][None, :, None, None]
             vals[i] = torch.clamp_min(c, 0) if l['act'] == 'relu' else c
         elif k == 'conv':

@@ -64,6 +64,7 @@ def test_stem_fwd_and_wgrad(backend, cfg):
     N, H, W, Co = cfg
     rng = np.random.RandomState(12)
     x = rng.uniform(-1, 1, size=(N, 1, H, W))
+    x[:, :, :, W // 2:] = 1.0                        # constant far-plane background: whole pooling windows tie
     Wr = rng.normal(size=(Co, 1, 5, 5)) * 0.3
     b = rng.normal(size=Co)
     y_ref, cache = L.convpool_fwd(x, Wr, b, (1, 1), 'half', (2, 2), False)
@@ -73,16 +74,17 @@ def test_stem_fwd_and_wgrad(backend, cfg):
     ops.stem_fwd(rt, d['X'], N, H, W, d['Wk'], d['b'], Co, Y, arg)(rt.stream)
     rt.synchronize()
     np.testing.assert_allclose(layout.nhwc_to_nchw(Y.get()), y_ref, rtol=0, atol=3e-6 * 5 * np.abs(y_ref).max())
-    # argmax agrees with the oracle wherever the window maximum is unique to f32 resolution
-    cshape, arg_ref, _ = cache
+    # the tie mask agrees with the oracle wherever the oracle's window is either clearly decided or exactly tied
+    cshape, ties_ref, _ = cache
     c = L.conv2d_fwd(x, Wr, None, (1, 1), 'half')
     cv = c.reshape(N, Co, H // 2, 2, W // 2, 2).transpose(0, 1, 2, 4, 3, 5).reshape(N, Co, H // 2, W // 2, 4)
-    srt = np.sort(cv, axis=4)
-    clear = (srt[..., 3] - srt[..., 2]) > 1e-4
-    got = layout.nhwc_to_nchw(arg.get())
-    assert clear.mean() > 0.95
-    assert (got[clear] == arg_ref[clear]).all()
-    # filter gradient with the device's own argmax
+    gap = cv.max(axis=4, keepdims=True) - cv
+    clear = ((gap == 0) | (gap > 1e-4)).all(axis=4)
+    got_bits = layout.nhwc_to_nchw(arg.get())
+    got = ((got_bits[..., None] >> np.arange(4)) & 1).astype(bool)
+    assert clear.mean() > 0.9 and ties_ref.sum(axis=4).max() == 4
+    assert (got[clear] == ties_ref[clear]).all()
+    # filter gradient with the device's own tie mask
     dy = rng.normal(size=y_ref.shape)
     dyb = rt.upload(layout.nchw_to_nhwc(dy).astype(np.float32))
     tpb = 2
@@ -295,3 +297,81 @@ def test_fused_epilogues_stats_and_bn_backward(backend, kind):
     xhat = (x.astype('f8') - mu) * isd
     np.testing.assert_allclose(dbeta.get(), got.astype('f8').sum(0), rtol=0, atol=3e-5 * np.sqrt(M) * np.abs(got).max())
     np.testing.assert_allclose(dgamma.get(), (got.astype('f8') * xhat).sum(0), rtol=0, atol=3e-4 * np.sqrt(M) * np.abs(got).max())
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [
+    # N, H, W, Ci, Co, k, border, pool, relu_in
+    (2, 44, 44, 1, 8, 5, 'valid', 4, False),      # PoseRegNet conv-pool 1 (poseregnet.py:62-66), reduced map
+    (3, 31, 31, 8, 8, 5, 'valid', 2, True),       # conv-pool 2: odd conv map 27 -> pool ignores the border
+    (3, 13, 13, 8, 8, 3, 'valid', 1, True),       # conv-pool 3: no pooling (poolType -1)
+    (2, 20, 18, 3, 12, 3, 'half', 3, True),       # odd sizes: 'half' padding, pool 3, channel counts off the wave grid
+])
+def test_convpool_fwd_wgrad_dgrad(backend, cfg):
+    """Generic ConvPoolLayer kernels against the oracle, incl. Theano's gradient-to-every-tied-maximum rule on a constant
+    background region."""
+    rt = get_runtime(backend)
+    N, H, W, Ci, Co, k, border, pool, relu_in = cfg
+    pad = k // 2 if border == 'half' else 0
+    rng = np.random.RandomState(31)
+    pre = rng.uniform(-1, 1, size=(N, Ci, H, W))
+    pre[:, :, :, W // 2:] = 0.75                       # constant region: conv output ties inside whole pooling windows
+    x = np.maximum(pre, 0) if relu_in else pre         # the previous layer's ReLU is this layer's operand prologue
+    Wr = rng.normal(size=(Co, Ci, k, k)) * 0.3
+    b = rng.normal(size=Co)
+    y_ref, cache = L.convpool_fwd(x, Wr, b, (1, 1), border, (pool, pool), False)
+    cshape, ties_ref, _ = cache
+    Hp, Wp = y_ref.shape[2:]
+    d = up(rt, X=layout.nchw_to_nhwc(pre), Wk=layout.conv_w_to_kernel(Wr), b=b)
+    act = ops.act(mode=1) if relu_in else None
+    Y = rt.alloc((N, Hp, Wp, Co), zero=False)
+    ties = rt.alloc((N, Hp, Wp, Co), np.uint16, zero=False) if pool > 1 else None
+    ops.convpool_fwd(rt, d['X'], N, H, W, Ci, d['Wk'], k, k, pad, Co, pool, d['b'], Y, ties, actX=act)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_allclose(layout.nhwc_to_nchw(Y.get()), y_ref, rtol=0, atol=3e-6 * np.sqrt(k * k * Ci) * np.abs(y_ref).max())
+    if pool > 1:
+        c = L.conv2d_fwd(x, Wr, None, (1, 1), border)
+        cv = c[:, :, :Hp * pool, :Wp * pool].reshape(N, Co, Hp, pool, Wp, pool).transpose(0, 1, 2, 4, 3, 5).reshape(N, Co, Hp, Wp, pool * pool)
+        gap = cv.max(axis=4, keepdims=True) - cv
+        clear = ((gap == 0) | (gap > 1e-4)).all(axis=4)
+        got = ((layout.nhwc_to_nchw(ties.get())[..., None] >> np.arange(pool * pool)) & 1).astype(bool)
+        assert clear.mean() > 0.9 and ties_ref.sum(axis=4).max() == pool * pool
+        assert (got[clear] == ties_ref[clear]).all()
+    else:
+        got = None
+    # gradients with the device's own tie masks
+    dy = rng.normal(size=y_ref.shape)
+    dyb = rt.upload(layout.nchw_to_nhwc(dy).astype(np.float32))
+    nblk = rt.lib.dpp_convpool_wgrad_blocks(N, Hp, Wp)
+    nW = Co * k * k * Ci
+    part = rt.alloc((nblk, nW), zero=False)
+    dWk = rt.alloc(nW, zero=False)
+    dX = rt.alloc((N, H, W, Ci), zero=False)
+    ops.convpool_wgrad(rt, d['X'], N, H, W, Ci, dyb, ties, k, k, pad, Co, pool, part, actX=act)(rt.stream)
+    ops.reduce_partials(rt, part, nblk, nW, dWk)(rt.stream)
+    ops.convpool_dgrad(rt, dyb, ties, N, H, W, Ci, d['Wk'], k, k, pad, Co, pool, dX)(rt.stream)
+    rt.synchronize()
+    dx_ref, dW_ref, _ = L.convpool_bwd(x, Wr, dy, (cshape, got, y_ref), (1, 1), border, (pool, pool), False)
+    dW = layout.conv_w_from_kernel(dWk.get().reshape(Co, k * k, Ci), (Co, Ci, k, k))
+    np.testing.assert_allclose(dW, dW_ref, rtol=0, atol=3e-6 * np.sqrt(N * Hp * Wp) * np.abs(dW_ref).max())
+    np.testing.assert_allclose(layout.nhwc_to_nchw(dX.get()), dx_ref, rtol=0, atol=3e-6 * np.sqrt(k * k * Co) * np.abs(dx_ref).max())
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_bernoulli_mask_streams(backend):
+    """Dropout masks (dropoutlayer.py:98-103): Bernoulli(keep), reproducible per (seed, counter), advanced by the
+    device-resident step counter so that a recorded launch draws a new mask every step."""
+    rt = get_runtime(backend)
+    n, keep = 1 << 16, 0.7
+    m = [rt.alloc(n, zero=False) for _ in range(4)]
+    ctr = rt.alloc(1, np.int64)
+    ops.bernoulli_mask(rt, m[0], n, keep, 1234, 5)(rt.stream)
+    ops.bernoulli_mask(rt, m[1], n, keep, 1234, 5, ctr)(rt.stream)          # counter_dev = 0: same stream
+    ops.counter_add(rt, ctr, 1)(rt.stream)
+    ops.bernoulli_mask(rt, m[2], n, keep, 1234, 5, ctr)(rt.stream)          # = host counter 6
+    ops.bernoulli_mask(rt, m[3], n, keep, 1234, 6)(rt.stream)
+    rt.synchronize()
+    a, b, c, d = (x.get() for x in m)
+    assert set(np.unique(a)) == {0.0, 1.0}
+    assert abs(a.mean() - keep) < 4 * np.sqrt(keep * (1 - keep) / n)
+    assert np.array_equal(a, b) and np.array_equal(c, d) and (a != c).mean() > 0.3

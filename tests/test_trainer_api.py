@@ -11,6 +11,7 @@ from sklearn.decomposition import PCA
 from data.importers import ICVLImporter
 from hipdp import runtime as R
 from net.hiddenlayer import HiddenLayer, HiddenLayerParams
+from net.poseregnet import PoseRegNet, PoseRegNetParams
 from net.resnet import ResNet, ResNetParams
 from oracle import augment as A
 from tests.backends import BACKENDS, get_runtime
@@ -25,12 +26,22 @@ def synth(n, size, J, seed):
     return imgs[:, None], coms, cubes, Ms, gts
 
 
+FAMILIES = {
+    # the ResNet of BASELINE configs 2-4, and the DeepPose-style PoseRegNet the shipped mains literally build
+    # (main_nyu_posereg_embedding.py:97-98); sizes are the smallest maps the two architectures admit
+    'resnet': (ResNet, ResNetParams, 32),
+    'poseregnet': (PoseRegNet, PoseRegNetParams, 48),
+}
+
+
 @pytest.mark.parametrize('backend', BACKENDS)
-def test_main_script_flow(backend, tmp_path):
+@pytest.mark.parametrize('family', sorted(FAMILIES))
+def test_main_script_flow(backend, family, tmp_path):
     rt = get_runtime(backend)
     R.set_default_runtime(rt)
     rng = np.random.RandomState(23455)
-    size, J, B, E = 32, 16, 4, 8
+    Net, NetParams, size = FAMILIES[family]
+    J, B, E = 16, 4, 8
     di = ICVLImporter('../data/ICVL/')
     train_data, train_com, train_cube, train_M, train_gt3Dcrop = synth(6, size, J, 1)
     val_data, _, val_cube, _, val_gt3Dcrop = synth(4, size, J, 2)
@@ -42,8 +53,8 @@ def test_main_script_flow(backend, tmp_path):
     train_embed = pca.transform(train_gt3D.reshape((-1, J * 3))).astype('float32')
     val_embed = pca.transform(val_gt3D.reshape((-1, J * 3))).astype('float32')
 
-    poseNetParams = ResNetParams(type=0, nChan=1, wIn=size, hIn=size, batchSize=B, numJoints=1, nDims=E)
-    poseNet = ResNet(rng, cfgParams=poseNetParams)
+    poseNetParams = NetParams(type=0, nChan=1, wIn=size, hIn=size, batchSize=B, numJoints=1, nDims=E)
+    poseNet = Net(rng, cfgParams=poseNetParams)
     p = PoseRegNetTrainerParams()
     p.batch_size = B
     p.learning_rate = 0.001
@@ -97,7 +108,7 @@ def test_main_script_flow(backend, tmp_path):
     assert jts.shape == (4, J * 3)
     np.testing.assert_allclose(jts, out_embed.astype('f8') @ pca.components_ + pca.mean_, rtol=0, atol=2e-5)
     # reload into a freshly built net with the same surgery: identical outputs
-    net2 = ResNet(np.random.RandomState(1), cfgParams=ResNetParams(type=0, nChan=1, wIn=size, hIn=size, batchSize=B, numJoints=1, nDims=E))
+    net2 = Net(np.random.RandomState(1), cfgParams=NetParams(type=0, nChan=1, wIn=size, hIn=size, batchSize=B, numJoints=1, nDims=E))
     l2 = HiddenLayer(rng, net2.layers[-1].output, HiddenLayerParams(inputDim=(B, E), outputDim=(B, J * 3), activation=None),
                      layerNum=len(net2.layers))
     net2.layers.append(l2)
