@@ -257,6 +257,21 @@ def main():
             ach = dom['bytes'] / dom['n'] / per_launch_t / 1e9
             roof = dict(bound='hbm', kernel=dom_name, achieved=round(ach, 1), peak=PEAK_HBM / 1e9, unit='GB/s',
                         frac=round(ach * 1e9 / PEAK_HBM, 4), traffic=None)
+        # HBM bytes per launch of that kernel family from the PMC counters: they cannot be read inside this process, so the
+        # number is the one measured with rocprofv3 --pmc on this same build and workload (separate FETCH_SIZE / WRITE_SIZE
+        # passes, calibrated on adam_kernel; tools/pmc_summary.py -> profiles/r01_hbm_traffic.json)
+        pmc_family = {'gemm_mfma_f32': 'gemm_kernel', 'conv3x3_mfma_f32': 'conv3x3_kernel', 'bn_bwd_apply': 'bn_bwd_apply_kernel',
+                      'adam': 'adam_kernel'}.get(dom_name)
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')) as fh:
+                pj = json.load(fh)
+            if B == 128 and pmc_family in pj:
+                roof['traffic'] = round(pj[pmc_family]['bytes_per_launch'])
+                roof['traffic_source'] = 'profiles/r01_hbm_traffic.txt'
+        except (OSError, ValueError):
+            pass
+        roof['algorithmic_bytes'] = round(dom['bytes'] / dom['n'])
+        roof['hbm_frac'] = round(dom['bytes'] / dom['n'] / per_launch_t / PEAK_HBM, 4)
         roof['launches_per_step'] = dom['n']
         roof['avg_launch_us'] = round(per_launch_t * 1e6, 2)
         roof['share_of_step'] = round(dom['ms'] / sum(f['ms'] for f in fam.values()), 3)
