@@ -276,12 +276,21 @@ def conv3x3_bm(pixels, Co):
     return 128 if (pixels // 128) * (-(-Co // 64)) >= 512 else 64
 
 
+WGRAD_TARGET_BLOCKS = int(os.environ.get('DPP_WGRAD_TARGET_BLOCKS', '256'))
+
+
 def wgrad_plan(Co, Ci, K):
-    """Filter gradients reduce over K = pixels (1e4..1e5) into a small [Co][Ci] tile: the reduction is split until about
-    a thousand workgroups are in flight (these kernels are HBM/latency-bound, not MFMA-bound), capped at 1024 slices."""
-    tile, _ = gemm_plan(Co, Ci, K, allow_split=False)
+    """Filter gradients reduce over K = pixels (1e4..1e5) into a small [Co][Ci] matrix.  Measured (tools/gemm_micro.py wgrad):
+    the fewest, largest tiles that cover [Co][Ci] win, with the pixel reduction split until 512..1024 workgroups are in
+    flight but no slice shorter than ~128 pixels."""
+    if Co <= 16:
+        tile = (16, 64, 1)
+    elif Co <= 32:
+        tile = (32, 64, 1)
+    else:
+        tile = (64, 64 if Ci > 32 else (32 if Ci > 16 else 16), 4)
     tiles = (-(-Co // tile[0])) * (-(-Ci // tile[1]))
-    splitk = int(max(1, min(1024 // tiles, K // 256, 1024)))
+    splitk = int(max(1, min(WGRAD_TARGET_BLOCKS // tiles, max(K // 128, min(128, K // 64)))))
     return tile, splitk
 
 
@@ -345,7 +354,12 @@ class CompiledNet(object):
                 raise ValueError("a training engine needs a loss")
             self.store.ensure_train_buffers()
             self.hyper = rt.alloc(8)
+            self.early_side = []
             self._emit_backward()
+            if self.early_side:
+                self.fwd.ops[0:0] = [(ops.Fork(), False)] + [(o, True) for o in self.early_side]
+                self.fwd.uses_side = True
+                self.bwd.ops[0:0] = [(ops.Join(), False)]
             self._grad_allreduce = None
             if dp is not None:
                 dp.broadcast_store(self.store)
@@ -831,7 +845,9 @@ class CompiledNet(object):
                 tgt, dst = self._view_grad(src)
                 acc = tgt.grad_written
                 Wd = rt.alloc(Co * 9 * Ci, zero=False)
-                self.bwd.add(ops.conv3x3_wtrans(rt, st.view(layer.W), Co, Ci, Wd))
+                # the mirrored weights only depend on the parameters: they are prepared on the side stream while the forward
+                # pass runs (the side stream is idle then) instead of sitting in the data-gradient chain
+                self.early_side.append(ops.conv3x3_wtrans(rt, st.view(layer.W), Co, Ci, Wd))
                 bmd = conv3x3_bm(N * Hi * Wi, Ci)
                 epi = None
                 if not acc and self._sole_consumer_bn_view(src):

@@ -105,9 +105,25 @@ def main_fc():
         bench_fc('fc2 wgrad', 1024, 1024, 128, 0, 0, tile, 1)
 
 
+def main_wgrad():
+    # 1x1 filter gradients: dW[Co][Ci] = dY^T . act(X), reduction over pixels
+    for label, Co, Ci, px in (('stage1 a', 16, 64, 131072), ('stage1 c', 64, 16, 131072), ('stage2 a', 32, 128, 32768),
+                              ('stage2 c', 128, 32, 32768), ('stage3 a', 64, 256, 8192), ('stage3 c', 256, 64, 8192)):
+        tiles = [(16, 64, 1), (32, 64, 1), (64, 16, 4), (64, 64, 4), (64, 32, 4)]
+        for tile in tiles:
+            if tile[0] > max(16, Co) or tile[1] > max(16, Ci):
+                continue
+            for sk in (128, 256, 512, 1024, 2048):
+                if px // sk < 64:
+                    continue
+                bench_fc(label, Co, Ci, px, 0, 0, tile, sk)
+
+
 def main():
     if 'fc' in sys.argv[1:]:
         return main_fc()
+    if 'wgrad' in sys.argv[1:]:
+        return main_wgrad()
     z = rt.alloc(4)
     print('launch floor (fill_zero 4 floats): %.2f us' % timeit(ops.fill_zero(rt, z, 4)))
     shapes = [('stage3/4 conv a 256->64', 8192, 64, 256), ('stage3/4 conv c 64->256', 8192, 256, 64),
