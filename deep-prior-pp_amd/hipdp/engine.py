@@ -23,7 +23,7 @@ from .lib import Act, RowMap
 from .ops import Plan
 from .runtime import default_runtime
 
-BN_RPB_TARGET_BLOCKS = 256
+BN_RPB_TARGET_BLOCKS = int(os.environ.get('DPP_BN_BLOCKS', '1024'))
 
 
 def _pad4(n):

@@ -119,7 +119,16 @@ def main_wgrad():
                 bench_fc(label, Co, Ci, px, 0, 0, tile, sk)
 
 
+def main_feats():
+    for label, M, N, K, tile in (('stage3/4 conv c 64->256', 8192, 256, 64, (64, 64, 4)), ('stage1 conv c 16->64', 131072, 64, 16, (64, 64, 4)),
+                                 ('stage3/4 conv a 256->64', 8192, 64, 256, (64, 16, 4)), ('stage1 conv a 64->16', 131072, 16, 64, (128, 16, 4))):
+        for feats in ((), ('act',), ('bias',), ('res',), ('stats',), ('act', 'bias', 'res'), ('act', 'bias', 'res', 'stats'), ('bnbwd',)):
+            bench_gemm(M, N, K, True, tile, 0, feats, label)
+
+
 def main():
+    if 'feats' in sys.argv[1:]:
+        return main_feats()
     if 'fc' in sys.argv[1:]:
         return main_fc()
     if 'wgrad' in sys.argv[1:]:
