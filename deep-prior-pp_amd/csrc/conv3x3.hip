@@ -159,6 +159,19 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     float sx[CN], sy[CN];
 #pragma unroll
     for (int ct = 0; ct < CN; ++ct) { sx[ct] = 0.0f; sy[ct] = 0.0f; }
+    // per-column vectors are read once (the stores to Y below could alias them as far as the compiler knows)
+    float cbias[CN], cmean[CN], cscale[CN], cbeta[CN], cistd[CN];
+#pragma unroll
+    for (int ct = 0; ct < CN; ++ct) {
+        const int col = col0 + ct * 16 + l15;
+        const bool in = col < a.Co;
+        cbias[ct] = (in && a.bias) ? a.bias[col] : 0.0f;
+        const bool bn = in && ep.bn_x != nullptr;
+        cmean[ct] = bn ? ep.bn_mean[col] : 0.0f;
+        cscale[ct] = bn ? ep.bn_scale[col] : 0.0f;
+        cbeta[ct] = bn ? ep.bn_beta[col] : 0.0f;
+        cistd[ct] = bn ? ep.bn_inv_std[col] : 0.0f;
+    }
 #pragma unroll
     for (int rt = 0; rt < RM; ++rt) {
 #pragma unroll
@@ -175,14 +188,13 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
                 int col = col0 + ct * 16 + l15;
                 float v = 0.0f;
                 if (ok && col < a.Co) {
-                    v = acc[rt][ct][r];
-                    if (a.bias) v += a.bias[col];
+                    v = acc[rt][ct][r] + cbias[ct];
                     if (a.residual) v += a.residual[o + col];
                     if (ep.bn_x != nullptr) {
-                        float dx = ep.bn_x[o + col] - ep.bn_mean[col];
-                        if (ep.bn_relu && dx * ep.bn_scale[col] + ep.bn_beta[col] < 0.0f) v = 0.0f;
+                        float dx = ep.bn_x[o + col] - cmean[ct];
+                        if (ep.bn_relu && dx * cscale[ct] + cbeta[ct] < 0.0f) v = 0.0f;
                         sx[ct] += v;
-                        sy[ct] += v * (dx * ep.bn_inv_std[col]);
+                        sy[ct] += v * (dx * cistd[ct]);
                     }
                     a.Y[o + col] = v;
                 }

@@ -785,6 +785,10 @@ class CompiledNet(object):
             assert cc == C
             self.reduce_jobs.add(cs, nb, C, gslot)
             return
+        if rows <= 256:
+            # few rows (the FC layers: one row per sample): dY itself is the list of partials of the fused reduction launch
+            self.reduce_jobs.add(dY, rows, C, gslot)
+            return
         rpb = max(32, -(-rows // 256))
         nb = -(-rows // rpb)
         part = self.scratch_side(nb * C)
