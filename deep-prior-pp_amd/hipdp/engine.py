@@ -250,6 +250,8 @@ def gemm_plan(M, N, K, allow_split=True):
     return (bm, bn, wm), splitk
 
 
+OVERLAP_ALLREDUCE = os.environ.get('DPP_OVERLAP_ALLREDUCE', '1') != '0'
+EARLY_BUCKET_MIN = int(os.environ.get('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elements; FC1 of the 128x128 ResNet has 16.8 M
 ROWSTREAM = os.environ.get('DPP_ROWSTREAM', '0') != '0'      # measured: no gain over the LDS-tiled kernel yet
 
 
@@ -355,16 +357,25 @@ class CompiledNet(object):
             self.store.ensure_train_buffers()
             self.hyper = rt.alloc(8)
             self.early_side = []
+            self._early_slice, self._early_work = None, [None]
             self._emit_backward()
             if self.early_side:
                 self.fwd.ops[0:0] = [(ops.Fork(), False)] + [(o, True) for o in self.early_side]
                 self.fwd.uses_side = True
                 self.bwd.ops[0:0] = [(ops.Join(), False)]
-            self._grad_allreduce = None
+            self._grad_allreduce = []
             if dp is not None:
                 dp.broadcast_store(self.store)
-                self._grad_allreduce = dp.allreduce_sum_op(self.store.g, 'grad_allreduce')
-                self.upd.add(self._grad_allreduce)
+                # what the early bucket (started inside the backward plan, see _bwd_fc) does not cover
+                lo, hi = self._early_slice if self._early_slice is not None else (0, 0)
+                n = self.store.g.size
+                if self._early_slice is not None:
+                    self._grad_allreduce.append(dp.wait_op(self._early_work, 'grad_allreduce_wait_early'))
+                for a, b in ((0, lo), (hi, n)) if self._early_slice is not None else ((0, n),):
+                    if b > a:
+                        self._grad_allreduce.append(dp.allreduce_sum_op(self.store.g.view(a, (b - a,)), 'grad_allreduce'))
+                for op in self._grad_allreduce:
+                    self.upd.add(op)
             self.upd.add(ops.adam(rt, self.store.w, self.store.g, self.store.m, self.store.v, self.store.n_w, self.hyper))
             self.upd.add(ops.adam_tick(rt, self.hyper))
             if self.dropout_masks:
@@ -873,6 +884,12 @@ class CompiledNet(object):
         tile, _ = gemm_plan(K, Nout, Nb, allow_split=False)
         self.bwd.add(ops.gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, tile=tile,
                               name='fc_wgrad_%d' % layer.layerNum), side=True)
+        if self.dp is not None and self._early_slice is None and K * Nout >= EARLY_BUCKET_MIN and OVERLAP_ALLREDUCE:
+            # data parallel: this gradient (FC1: 90 % of all parameter bytes) is final now -- start its all-reduce from the
+            # side stream so that it overlaps the rest of the backward pass
+            off = (gW.ptr - st.g.ptr) // 4
+            self._early_slice = (off, off + K * Nout)
+            self.bwd.add(self.dp.allreduce_sum_async_op(gW, self._early_work, 'grad_allreduce_early'), side=True)
         if src.base is not self.x_in:
             tgt, dst = self._view_grad(src)
             acc = tgt.grad_written
@@ -981,9 +998,10 @@ class CompiledNet(object):
         return float(self.cost.get()[0]), self.out.buf.get()
 
     def allreduce_grads(self):
-        """Sum the flat gradient buffer over the data-parallel ranks (no-op without dp)."""
-        if self._grad_allreduce is not None:
-            self._grad_allreduce(self.rt.stream)
+        """Finish summing the flat gradient buffer over the data-parallel ranks after a backward pass (no-op without dp):
+        joins the early bucket started inside the backward plan and all-reduces the rest."""
+        for op in self._grad_allreduce:
+            op(self.rt.stream)
 
     def evaluate(self, x, y):
         """Deterministic forward + cost + error on one batch (validation functions of setupValidate)."""

@@ -8,6 +8,8 @@ for p in (ROOT, os.path.join(ROOT, 'deep-prior-pp_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ['DPP_EARLY_BUCKET_MIN'] = str(1 << 18)      # the test net's FC layers (1 M weights) take the overlapped early-bucket path
+
 import numpy as np  # noqa: E402
 
 from hipdp import engine, parallel  # noqa: E402
@@ -29,7 +31,9 @@ def main():
     y = rng.normal(0, 0.3, (B * world, 30)).astype(np.float32)
     xs, ys = x[rank * B:(rank + 1) * B], y[rank * B:(rank + 1) * B]
     cost, _ = eng.cost_and_grads(xs, ys)
+    assert eng._early_slice is not None and eng._early_work[0] is not None      # the early bucket is in flight
     eng.allreduce_grads()
+    assert eng._early_work[0] is None
     G = {}
     for i, l in enumerate(net.layers):
         for s, p in enumerate(l.params):
