@@ -364,6 +364,117 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_warp_kernel(const float* 
     out[(size_t)b * npix + p] = (v - r.norm_off) / r.norm_div;
 }
 
+
+// ---- initial crop: HandDetector.cropArea3D (docom = False) + Dataset.imgStackDepthOnly ------------------------------
+// /root/reference/src/util/handdetector.py:53-68 (depth range of the detector), :204-226 (comToBounds), :260-296 (getCrop),
+// :382-490 (cropArea3D), cv2.resize INTER_NEAREST (OpenCV 2.4 resizeNN), /root/reference/src/data/dataset.py:97-103.
+// Two launches per batch of full depth frames, like the augmentation: crop_prepare (one workgroup per frame: min / max of
+// the frame -> the detector's valid depth range, then lane 0 does the bounds / resize geometry in f64) and crop_warp (one
+// thread per output pixel: gather through the nearest-neighbour resize map, range clamp, z-threshold, background,
+// optional normalisation to [-1, 1]).
+struct CropRec {
+    int xstart, ystart, cw, ch;    // crop window in the frame (may leave the frame: zero padding)
+    int szw, szh, xs, ys;          // resized size and paste offset inside the dsz x dsz output
+    double ifx, ify;               // resizeNN: source index = min(floor(x * ifx), cw - 1)
+    float min_depth, max_depth;    // detector range: outside -> 0
+    float zstart, zend;
+    float far_v, norm_off, norm_div;
+};
+
+__global__ __launch_bounds__(DPP_THREADS) void crop_prepare_kernel(const float* __restrict__ frames, int H, int W,
+                                                                   const float* __restrict__ com, const float* __restrict__ cube,
+                                                                   double fx, double fy, int dsz, CropRec* __restrict__ rec,
+                                                                   float* __restrict__ M_out) {
+    __shared__ float s_mn[DPP_THREADS / DPP_WAVE], s_mx[DPP_THREADS / DPP_WAVE];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* f = frames + (size_t)b * H * W;
+    float mn = 3.4e38f, mx = -3.4e38f;
+    const int npx = H * W;
+    int i0 = 0;
+    if ((npx & 3) == 0 && (reinterpret_cast<uintptr_t>(f) & 15) == 0) {          // 16-byte loads, 4 independent chains
+        const float4* f4 = reinterpret_cast<const float4*>(f);
+        const int n4 = npx >> 2;
+        float4 lo = make_float4(mn, mn, mn, mn), hi = make_float4(mx, mx, mx, mx);
+#pragma unroll 4
+        for (int i = tid; i < n4; i += DPP_THREADS) {
+            float4 v = f4[i];
+            lo.x = fminf(lo.x, v.x); lo.y = fminf(lo.y, v.y); lo.z = fminf(lo.z, v.z); lo.w = fminf(lo.w, v.w);
+            hi.x = fmaxf(hi.x, v.x); hi.y = fmaxf(hi.y, v.y); hi.z = fmaxf(hi.z, v.z); hi.w = fmaxf(hi.w, v.w);
+        }
+        mn = fminf(fminf(lo.x, lo.y), fminf(lo.z, lo.w));
+        mx = fmaxf(fmaxf(hi.x, hi.y), fmaxf(hi.z, hi.w));
+        i0 = npx;
+    }
+    for (int i = i0 + tid; i < npx; i += DPP_THREADS) { float v = f[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if ((tid & 63) == 0) { s_mn[tid >> 6] = mn; s_mx[tid >> 6] = mx; }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int w = 1; w < DPP_THREADS / DPP_WAVE; ++w) { mn = fminf(mn, s_mn[w]); mx = fmaxf(mx, s_mx[w]); }
+    CropRec r;
+    r.max_depth = fminf(1500.0f, mx);                          // handdetector.py:60-61
+    r.min_depth = fmaxf(10.0f, mn);
+    const float c[3] = {com[b * 3], com[b * 3 + 1], com[b * 3 + 2]};
+    const double size[3] = {(double)cube[b * 3], (double)cube[b * 3 + 1], (double)cube[b * 3 + 2]};
+    int bd[4];
+    com_to_bounds(c, size, fx, fy, bd);
+    r.xstart = bd[0]; r.ystart = bd[2];
+    const int wb = bd[1] - bd[0], hb = bd[3] - bd[2];
+    r.cw = wb; r.ch = hb;
+    r.zstart = (float)((double)c[2] - size[2] / 2.);
+    r.zend = (float)((double)c[2] + size[2] / 2.);
+    long long sz0, sz1;                                         // (width, height) of the resized crop
+    if (wb > hb) { sz0 = dsz; sz1 = floordiv((long long)hb * dsz, wb); }
+    else { sz0 = floordiv((long long)wb * dsz, hb); sz1 = dsz; }
+    r.szw = (int)sz0; r.szh = (int)sz1;
+    const double sc = (hb > wb) ? (double)sz1 / (double)hb : (double)sz0 / (double)wb;     // cropped.shape = (hb, wb)
+    r.ifx = 1. / ((double)sz0 / (double)wb);
+    r.ify = 1. / ((double)sz1 / (double)hb);
+    r.xs = (int)floor(dsz / 2. - (double)sz0 / 2.);
+    r.ys = (int)floor(dsz / 2. - (double)sz1 / 2.);
+    r.far_v = c[2] + (float)(size[2] / 2.);
+    r.norm_off = c[2];
+    r.norm_div = (float)(size[2] / 2.);
+    rec[b] = r;
+    if (M_out) {
+        float* M = M_out + (size_t)b * 9;
+        M[0] = (float)sc; M[1] = 0.f; M[2] = (float)(sc * (double)(-bd[0]) + (double)r.xs);
+        M[3] = 0.f; M[4] = (float)sc; M[5] = (float)(sc * (double)(-bd[2]) + (double)r.ys);
+        M[6] = 0.f; M[7] = 0.f; M[8] = 1.f;
+    }
+}
+
+__global__ __launch_bounds__(DPP_THREADS) void crop_warp_kernel(const float* __restrict__ frames, int H, int W, const CropRec* __restrict__ rec,
+                                                                int dsz, int normalize, float nd_value, float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * DPP_THREADS + threadIdx.x;
+    if (p >= dsz * dsz) return;
+    const CropRec r = rec[b];
+    const int y = p / dsz, x = p - y * dsz;
+    float v = nd_value;
+    const int rx = x - r.xs, ry = y - r.ys;
+    if (rx >= 0 && rx < r.szw && ry >= 0 && ry < r.szh) {
+        long long sx = (long long)floor((double)rx * r.ifx), sy = (long long)floor((double)ry * r.ify);
+        if (sx > r.cw - 1) sx = r.cw - 1;
+        if (sy > r.ch - 1) sy = r.ch - 1;
+        const long long gx = r.xstart + sx, gy = r.ystart + sy;
+        v = 0.0f;                                                // getCrop pads with 0 outside the frame
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+            v = frames[((size_t)b * H + gy) * W + gx];
+            if (v > r.max_depth || v < r.min_depth) v = 0.0f;    // the detector's valid range
+        }
+        if (v != 0.0f) {
+            if (v < r.zstart) v = r.zstart;
+            else if (v > r.zend) v = 0.0f;
+        }
+    }
+    if (normalize) {
+        if (v == 0.0f) v = r.far_v;                              // dataset.py:98-100
+        v = (v - r.norm_off) / r.norm_div;
+    }
+    out[(size_t)b * dsz * dsz + p] = v;
+}
+
 }  // namespace
 
 extern "C" size_t dpp_augment_record_bytes(void) { return sizeof(AugRec); }
@@ -406,5 +517,24 @@ extern "C" int dpp_augment_warp(const float* img, const void* records, int B, in
     dim3 grid(dpp_cdiv(dsz * dsz, DPP_THREADS), B);
     hipLaunchKernelGGL(augment_warp_kernel, grid, dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), img,
                        static_cast<const AugRec*>(records), dsz, out);
+    return dpp_launch_status();
+}
+
+extern "C" size_t dpp_crop_record_bytes(void) { return sizeof(CropRec); }
+
+extern "C" int dpp_crop_prepare(const float* frames, int B, int H, int W, const float* com, const float* cube, double fx, double fy,
+                                int dsz, void* records, float* M_out, dpp_stream_t stream) {
+    if (!frames || !com || !cube || !records || B < 1 || H < 1 || W < 1 || dsz < 1 || fx == 0.0 || fy == 0.0) return DPP_E_BADARG;
+    hipLaunchKernelGGL(crop_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W, com, cube,
+                       fabs(fx), fabs(fy), dsz, static_cast<CropRec*>(records), M_out);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_crop_warp(const float* frames, const void* records, int B, int H, int W, int dsz, int normalize, float nd_value,
+                             float* out, dpp_stream_t stream) {
+    if (!frames || !records || !out || B < 1 || H < 1 || W < 1 || dsz < 1) return DPP_E_BADARG;
+    dim3 grid(dpp_cdiv(dsz * dsz, DPP_THREADS), B);
+    hipLaunchKernelGGL(crop_warp_kernel, grid, dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W,
+                       static_cast<const CropRec*>(records), dsz, normalize, nd_value, out);
     return dpp_launch_status();
 }

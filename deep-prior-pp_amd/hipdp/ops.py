@@ -281,6 +281,16 @@ def augment_warp(rt, img, records, B, dsz, out, name='augment_warp'):
                   dict(kernel='augment_warp', flops=40.0 * B * dsz * dsz, bytes=8.0 * B * dsz * dsz))
 
 
+def crop_prepare(rt, frames, B, H, W, com, cube, fx, fy, dsz, records, M_out=None, name='crop_prepare'):
+    return Launch(rt.lib.dpp_crop_prepare, (frames.ptr, B, H, W, com.ptr, cube.ptr, float(fx), float(fy), dsz, records.ptr, _p(M_out)),
+                  (frames, com, cube, records, M_out), name, dict(kernel='crop_prepare', flops=2.0 * B * H * W, bytes=4.0 * B * H * W))
+
+
+def crop_warp(rt, frames, records, B, H, W, dsz, out, normalize=True, nd_value=0.0, name='crop_warp'):
+    return Launch(rt.lib.dpp_crop_warp, (frames.ptr, records.ptr, B, H, W, dsz, int(bool(normalize)), float(nd_value), out.ptr),
+                  (frames, records, out), name, dict(kernel='crop_warp', flops=10.0 * B * dsz * dsz, bytes=8.0 * B * dsz * dsz))
+
+
 def fill_zero(rt, buf, name='fill_zero'):
     return Launch(rt.lib.dpp_fill_zero, (buf.ptr, buf.nbytes), (buf,), name)
 

@@ -3,9 +3,10 @@ HandDetector -- the augmentation slice of /root/reference/src/util/handdetector.
 :204-258, moveCoM / rotateHand / scaleHand / recropHand :678-803, sampleRandomPoses :805-909).
 
 The crop warps run on the MI355X through the fused augmentation kernels (csrc/augment.hip); this class keeps the
-reference's per-crop method signatures for callers and computes only the tiny 3x3 crop geometry on the host.  The
-detector / tracker / initial cropping part of the reference class (cropArea3D, detect, track, refineCoM, ...) is the
-"next" row of SURVEY.md section 8(f) and is not provided yet.
+reference's per-crop method signatures for callers and computes only the tiny 3x3 crop geometry on the host.
+cropArea3D (handdetector.py:382-490, docom=False: the call the importers make for every frame) runs on the device too;
+`crop_frames` is its batched form fused with Dataset.imgStackDepthOnly.  Detection / tracking / CoM refinement
+(detect, track, refineCoM, docom=True) are not provided yet.
 """
 import numpy
 
@@ -170,8 +171,52 @@ class HandDetector(object):
                 raise NotImplementedError()
         return (new_poses, new_com, new_cube, rot) if retall else new_poses
 
-    # ---- not part of the hot path yet ----------------------------------------------------------------------------------
-    def cropArea3D(self, *args, **kwargs):
-        raise NotImplementedError("initial cropping / detection is the 'next' row of SURVEY.md section 8(f)")
+    # ---- initial crop on the device ---------------------------------------------------------------------------------------
+    def getNDValue(self):
+        """Value of 'not defined' depth (handdetector.py:122-130): the most frequent out-of-range value -- 0 after the
+        constructor zeroed everything outside [minDepth, maxDepth]."""
+        lo, hi = self.dpt[self.dpt < self.minDepth], self.dpt[self.dpt > self.maxDepth]
+        vals = lo if lo.shape[0] > hi.shape[0] else hi
+        if vals.shape[0] == 0:
+            return 0.
+        u, c = numpy.unique(vals, return_counts=True)
+        return u[numpy.argmax(c)]
 
-    detect = track = refineCoM = cropArea3D
+    def cropArea3D(self, com=None, size=(250, 250, 250), dsize=(128, 128), docom=False):
+        """Crop the metric cube `size` (mm) around `com` (image coordinates, z in mm) and resize it to `dsize`
+        (handdetector.py:382-490).  Returns (crop in mm, crop transform M, com) like the reference."""
+        if len(size) != 3 or len(dsize) != 2:
+            raise ValueError("Size must be 3D and dsize 2D bounding box")
+        if com is None or docom:
+            raise NotImplementedError("CoM detection / refinement (calculateCoM, docom=True) is not provided yet")
+        if dsize[0] != dsize[1]:
+            raise NotImplementedError("square destination sizes only")
+        crops, Ms = crop_frames(numpy.asarray(self.dpt, numpy.float32)[None], numpy.asarray(com, numpy.float32)[None],
+                                numpy.asarray(size, numpy.float32)[None], self.fx, self.fy, dsize[0], normalize=False,
+                                nd_value=self.getNDValue())
+        return crops[0], Ms[0].astype(numpy.float64), com
+
+    def detect(self, *args, **kwargs):
+        raise NotImplementedError("hand detection / tracking is a 'next' row of SURVEY.md section 8(f)")
+
+    track = refineCoM = detect
+
+
+def crop_frames(frames, coms, cubes, fx, fy, dsize=128, normalize=True, nd_value=0., runtime=None):
+    """Batched cropArea3D (+ Dataset.imgStackDepthOnly when normalize): frames (B, H, W) raw depth in mm, coms (B, 3) crop
+    centres in image coordinates, cubes (B, 3) in mm -> (crops (B, dsize, dsize) float32, M (B, 3, 3) float32).  Two kernel
+    launches for the whole batch (csrc/augment.hip: crop_prepare / crop_warp)."""
+    from hipdp import ops
+    from hipdp.runtime import default_runtime
+    rt = runtime or default_runtime()
+    frames = numpy.ascontiguousarray(frames, numpy.float32)
+    B, H, W = frames.shape
+    fr = rt.upload(frames)
+    co = rt.upload(numpy.ascontiguousarray(coms, numpy.float32).reshape(B, 3))
+    cu = rt.upload(numpy.ascontiguousarray(cubes, numpy.float32).reshape(B, 3))
+    rec = rt.alloc(B * rt.lib.dpp_crop_record_bytes(), numpy.uint8)
+    out, M = rt.alloc((B, dsize, dsize), zero=False), rt.alloc((B, 9), zero=False)
+    ops.crop_prepare(rt, fr, B, H, W, co, cu, fx, fy, dsize, rec, M)(rt.stream)
+    ops.crop_warp(rt, fr, rec, B, H, W, dsize, out, normalize=normalize, nd_value=nd_value)(rt.stream)
+    rt.synchronize()
+    return out.get(), M.get().reshape(B, 3, 3)

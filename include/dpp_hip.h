@@ -230,6 +230,20 @@ int dpp_augment_prepare(const float* img, const float* com3d, const float* cube,
 int dpp_counter_add(unsigned long long* counter, unsigned long long inc, dpp_stream_t stream);
 int dpp_augment_warp(const float* img, const void* records, int B, int dsz, float* out, dpp_stream_t stream);
 
+/* ---- initial crop: HandDetector.cropArea3D (docom = False) fused with Dataset.imgStackDepthOnly -------------------------
+ * /root/reference/src/util/handdetector.py:53-68, 204-226, 260-296, 382-490; /root/reference/src/data/dataset.py:97-103.
+ * frames: [B][H][W] raw depth in mm (0 = not defined); com: [B][3] crop centre in IMAGE coordinates (u, v, d mm);
+ * cube: [B][3] metric crop size in mm.  prepare: per frame the detector's valid depth range [max(10, min), min(1500, max)],
+ * the crop window (comToBounds), the aspect-preserving nearest-neighbour resize geometry (cv2.resize INTER_NEAREST) and the
+ * crop transform M_out [B][9] (= comToTransform; may be NULL).  warp: out [B][dsz][dsz]: the crop in mm with background
+ * nd_value (normalize == 0, what cropArea3D returns) or normalised like the training stacks: 0 -> com_z + cube_z/2, then
+ * (d - com_z) / (cube_z / 2) (normalize != 0). */
+size_t dpp_crop_record_bytes(void);
+int dpp_crop_prepare(const float* frames, int B, int H, int W, const float* com, const float* cube, double fx, double fy,
+                     int dsz, void* records, float* M_out, dpp_stream_t stream);
+int dpp_crop_warp(const float* frames, const void* records, int B, int H, int W, int dsz, int normalize, float nd_value,
+                  float* out, dpp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -407,3 +407,95 @@ def draw_params(rng, n, n_modes, sigma_com=5., sigma_sc=0.02, rot_range=180.):
         rots[i] = rng.uniform(-rot_range, rot_range)
         scs[i] = abs(1. + rng.randn() * sigma_sc)
     return modes, offs, rots, scs
+
+
+# --------------------------------------------------------------------------- initial crop
+def detector_preprocess(dpt):
+    """HandDetector.__init__, handdetector.py:53-68: depth outside [max(10, min), min(1500, max)] is 'not defined' (0)."""
+    d = np.asarray(dpt, np.float32).copy()
+    max_depth = min(1500, d.max())
+    min_depth = max(10, d.min())
+    d[d > max_depth] = 0.
+    d[d < min_depth] = 0.
+    return d, min_depth, max_depth
+
+
+def get_crop(dpt, xstart, xend, ystart, yend, zstart, zend, background=0.):
+    """getCrop, handdetector.py:260-296: the window of the frame, zero-padded where it leaves the frame, then the
+    z-threshold (nearer than the cube -> front face, farther -> 0)."""
+    H, W = dpt.shape
+    cropped = dpt[max(ystart, 0):min(yend, H), max(xstart, 0):min(xend, W)].copy()
+    cropped = np.pad(cropped, ((abs(ystart) - max(ystart, 0), abs(yend) - min(yend, H)),
+                               (abs(xstart) - max(xstart, 0), abs(xend) - min(xend, W))), mode='constant', constant_values=background)
+    msk1 = np.logical_and(cropped < zstart, cropped != 0)
+    msk2 = np.logical_and(cropped > zend, cropped != 0)
+    cropped[msk1] = zstart
+    cropped[msk2] = 0.
+    return cropped
+
+
+def resize_nn(src, dsize_wh):
+    """cv2.resize(src, (w, h), interpolation=INTER_NEAREST) as in OpenCV 2.4 imgwarp.cpp resizeNN:
+    inv_scale = (double)dsize / ssize, ifx = 1. / inv_scale, sx = min(cvFloor(x * ifx), ssize - 1)."""
+    w, h = int(dsize_wh[0]), int(dsize_wh[1])
+    sh, sw = src.shape
+    ifx = 1. / (float(w) / float(sw))
+    ify = 1. / (float(h) / float(sh))
+    sx = np.minimum(np.floor(np.arange(w) * ifx).astype(np.int64), sw - 1)
+    sy = np.minimum(np.floor(np.arange(h) * ify).astype(np.int64), sh - 1)
+    return src[sy][:, sx]
+
+
+def crop_area_3d(dpt, com, size, fx, fy, dsize=(128, 128), nd_value=0.):
+    """cropArea3D with docom=False, handdetector.py:382-490: metric cube around `com` (image coordinates, z in mm) ->
+    dsize crop (mm, background = nd_value) + the crop transform M.  `dpt` is the detector-preprocessed frame."""
+    xstart, xend, ystart, yend, zstart, zend = com_to_bounds(com, size, fx, fy)
+    cropped = get_crop(dpt, xstart, xend, ystart, yend, zstart, zend)
+    wb, hb = (xend - xstart), (yend - ystart)
+    if wb > hb:
+        sz = (dsize[0], hb * dsize[0] // wb)          # py2 integer division, handdetector.py:447-450
+    else:
+        sz = (wb * dsize[1] // hb, dsize[1])
+    if cropped.shape[0] > cropped.shape[1]:
+        sc = sz[1] / float(cropped.shape[0])
+    else:
+        sc = sz[0] / float(cropped.shape[1])
+    rz = resize_nn(cropped, sz)
+    ret = np.ones(dsize, np.float32) * np.float32(nd_value)
+    xs = int(np.floor(dsize[0] / 2. - rz.shape[1] / 2.))
+    ys = int(np.floor(dsize[1] / 2. - rz.shape[0] / 2.))
+    ret[ys:ys + rz.shape[0], xs:xs + rz.shape[1]] = rz
+    M = np.array([[sc, 0., sc * float(-xstart) + float(xs)], [0., sc, sc * float(-ystart) + float(ys)], [0., 0., 1.]], dtype=np.float64)
+    return ret, M, com
+
+
+def normalize_crop(crop_mm, com_z, cube_z):
+    """Dataset.imgStackDepthOnly, dataset.py:97-103: undefined depth (0) -> far plane, then (d - com_z) / (cube_z / 2)."""
+    d = np.asarray(crop_mm, np.float32).copy()
+    d[d == 0] = com_z + (cube_z / 2.)
+    d -= com_z
+    d /= (cube_z / 2.)
+    return d
+
+
+def synthetic_frames(rng, n, cam, H=240, W=320, cube=(250., 250., 250.)):
+    """Full depth frames for the crop tests: a far wall with holes (0 = not defined), a hand-sized blob around a CoM that
+    may sit close to the image border, some pixels nearer / farther than the cube."""
+    frames = np.zeros((n, H, W), np.float32)
+    coms = np.zeros((n, 3), np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for i in range(n):
+        d = rng.uniform(350., 900.)
+        u = rng.uniform(-10., W + 10.) if i % 3 == 0 else rng.uniform(60., W - 60.)
+        v = rng.uniform(-10., H + 10.) if i % 3 == 0 else rng.uniform(50., H - 50.)
+        f = np.full((H, W), 1400., np.float32) + rng.normal(0, 3., (H, W)).astype(np.float32)
+        f[rng.uniform(size=(H, W)) < 0.05] = 0.
+        r = cube[0] / 2. * cam.fx / d * rng.uniform(0.5, 0.9)
+        blob = (xx - u) ** 2 + (yy - v) ** 2 < r * r
+        f[blob] = (d + rng.normal(0, 30., (H, W)))[blob].astype(np.float32)
+        stick = np.abs(xx - u - r / 2) < 3
+        f[stick & (rng.uniform(size=(H, W)) < 0.5)] = np.float32(d - cube[2])       # nearer than the cube's front face
+        f[rng.uniform(size=(H, W)) < 0.01] = 2500.                                      # beyond maxDepth
+        frames[i] = f
+        coms[i] = (u, v, d)
+    return frames, coms

@@ -94,3 +94,43 @@ def test_augment_raw_labels_and_device_rng(backend):
     ops.augment_warp(rt, img, rec, B, 128, out2)(rt.stream)
     rt.synchronize()
     np.testing.assert_array_equal(out2.get(), o)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_crop_area_3d_matches_oracle(backend):
+    """The initial crop (cropArea3D + imgStackDepthOnly) bit for bit against the oracle, on frames whose
+    crop window leaves the image, contains undefined pixels, and pixels nearer / farther than the cube."""
+    from hipdp import runtime as R
+    from util.handdetector import HandDetector, crop_frames
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    rng = np.random.RandomState(11)
+    for cam, cube, (H, W) in ((A.Camera.icvl(), (250., 250., 250.), (240, 320)), (A.Camera.nyu(), (300., 300., 300.), (120, 160))):
+        B = 7
+        frames, coms = A.synthetic_frames(rng, B, cam, H, W, cube)
+        cubes = np.tile(np.asarray(cube, np.float32), (B, 1))
+        cubes[1] = (200., 220., 180.)                                   # a non-cubic, non-square window
+        fx, fy = abs(cam.fx), abs(cam.fy)
+        crops_n, Ms = crop_frames(frames, coms, cubes, fx, fy, 128, normalize=True, runtime=rt)
+        crops_mm, _ = crop_frames(frames, coms, cubes, fx, fy, 128, normalize=False, runtime=rt)
+        for i in range(B):
+            d, _, _ = A.detector_preprocess(frames[i])
+            ref, M, _ = A.crop_area_3d(d, coms[i], cubes[i], fx, fy)
+            assert np.array_equal(crops_mm[i], ref), i
+            assert np.array_equal(crops_n[i], A.normalize_crop(ref, coms[i][2], cubes[i][2])), i
+            assert np.array_equal(Ms[i].astype(np.float32), M.astype(np.float32)), i
+            # for a square pixel window the transform cropArea3D returns is comToTransform's (handdetector.py:228-258), the
+            # one augmentation consumes; for a non-square window the reference's two functions differ by comToTransform's
+            # x/y swap (handdetector.py:252-253), and so do the restatements
+            xs_, xe_, ys_, ye_, _, _ = A.com_to_bounds(coms[i], cubes[i], fx, fy)
+            if xe_ - xs_ == ye_ - ys_:
+                np.testing.assert_array_equal(M, A.com_to_transform(coms[i], cubes[i], fx, fy))
+            assert crops_n[i].min() >= -1.0 and crops_n[i].max() <= 1.0 + 1e-6
+        # the reference's per-frame method
+        hd = HandDetector(frames[2].copy(), fx, fy)
+        crop, M, com = hd.cropArea3D(com=coms[2], size=tuple(cubes[2]), dsize=(128, 128))
+        d, _, _ = A.detector_preprocess(frames[2])
+        ref, Mref, _ = A.crop_area_3d(d, coms[2], cubes[2], fx, fy)
+        assert np.array_equal(crop, ref) and np.allclose(M, Mref, rtol=1e-6) and hd.getNDValue() == 0.
+        with pytest.raises(NotImplementedError):
+            hd.cropArea3D(com=None)
