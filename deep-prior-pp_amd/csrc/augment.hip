@@ -444,6 +444,57 @@ __global__ __launch_bounds__(DPP_THREADS) void crop_prepare_kernel(const float* 
     }
 }
 
+// value of getCrop's window at window coordinates (sx, sy): zero padding outside the frame, the detector's valid depth
+// range, then the z-threshold (handdetector.py:260-296)
+__device__ __forceinline__ float crop_window_value(const float* __restrict__ frame, int H, int W, const CropRec& r, long long sx, long long sy) {
+    const long long gx = r.xstart + sx, gy = r.ystart + sy;
+    float v = 0.0f;
+    if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+        v = frame[(size_t)gy * W + gx];
+        if (v > r.max_depth || v < r.min_depth) v = 0.0f;
+    }
+    if (v != 0.0f) {
+        if (v < r.zstart) v = r.zstart;
+        else if (v > r.zend) v = 0.0f;
+    }
+    return v;
+}
+
+// calculateCoM of the crop window (handdetector.py:91-108, as called by cropArea3D with docom=True, :413-421): mean
+// column, mean row and mean depth of the pixels inside the detector's range, moved back to frame coordinates; an empty
+// window falls back to the depth of its centre pixel, then to 300 mm.
+__global__ __launch_bounds__(DPP_THREADS) void crop_com_kernel(const float* __restrict__ frames, int H, int W, const CropRec* __restrict__ rec,
+                                                               float* __restrict__ com_out) {
+    __shared__ double s_red[4][DPP_THREADS / DPP_WAVE];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const CropRec r = rec[b];
+    const float* f = frames + (size_t)b * H * W;
+    double sx = 0.0, sy = 0.0, sd = 0.0, cnt = 0.0;
+    const int n = r.cw * r.ch;
+    for (int i = tid; i < n; i += DPP_THREADS) {
+        int y = i / r.cw, x = i - y * r.cw;
+        float v = crop_window_value(f, H, W, r, x, y);
+        if (v < r.min_depth || v > r.max_depth) v = 0.0f;       // calculateCoM's own range test
+        if (v > 0.0f) { sx += x; sy += y; sd += (double)v; cnt += 1.0; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sd += __shfl_xor(sd, o); cnt += __shfl_xor(cnt, o);
+    }
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = sx; s_red[1][tid >> 6] = sy; s_red[2][tid >> 6] = sd; s_red[3][tid >> 6] = cnt; }
+    __syncthreads();
+    if (tid != 0) return;
+    for (int w = 1; w < DPP_THREADS / DPP_WAVE; ++w) { sx += s_red[0][w]; sy += s_red[1][w]; sd += s_red[2][w]; cnt += s_red[3][w]; }
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    if (cnt > 0.0) { c0 = sx / cnt; c1 = sy / cnt; c2 = sd / cnt; }
+    if (fabs(c0) <= 1e-8 && fabs(c1) <= 1e-8 && fabs(c2) <= 1e-8) {       // numpy.allclose(com, 0.)
+        c2 = (double)crop_window_value(f, H, W, r, r.cw / 2, r.ch / 2);
+        if (fabs(c2) <= 1e-8) c2 = 300.0;
+    }
+    com_out[b * 3 + 0] = (float)(c0 + (double)r.xstart);
+    com_out[b * 3 + 1] = (float)(c1 + (double)r.ystart);
+    com_out[b * 3 + 2] = (float)c2;
+}
+
 __global__ __launch_bounds__(DPP_THREADS) void crop_warp_kernel(const float* __restrict__ frames, int H, int W, const CropRec* __restrict__ rec,
                                                                 int dsz, int normalize, float nd_value, float* __restrict__ out) {
     const int b = blockIdx.y;
@@ -457,16 +508,7 @@ __global__ __launch_bounds__(DPP_THREADS) void crop_warp_kernel(const float* __r
         long long sx = (long long)floor((double)rx * r.ifx), sy = (long long)floor((double)ry * r.ify);
         if (sx > r.cw - 1) sx = r.cw - 1;
         if (sy > r.ch - 1) sy = r.ch - 1;
-        const long long gx = r.xstart + sx, gy = r.ystart + sy;
-        v = 0.0f;                                                // getCrop pads with 0 outside the frame
-        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
-            v = frames[((size_t)b * H + gy) * W + gx];
-            if (v > r.max_depth || v < r.min_depth) v = 0.0f;    // the detector's valid range
-        }
-        if (v != 0.0f) {
-            if (v < r.zstart) v = r.zstart;
-            else if (v > r.zend) v = 0.0f;
-        }
+        v = crop_window_value(frames + (size_t)b * H * W, H, W, r, sx, sy);
     }
     if (normalize) {
         if (v == 0.0f) v = r.far_v;                              // dataset.py:98-100
@@ -536,5 +578,12 @@ extern "C" int dpp_crop_warp(const float* frames, const void* records, int B, in
     dim3 grid(dpp_cdiv(dsz * dsz, DPP_THREADS), B);
     hipLaunchKernelGGL(crop_warp_kernel, grid, dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W,
                        static_cast<const CropRec*>(records), dsz, normalize, nd_value, out);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_crop_com(const float* frames, const void* records, int B, int H, int W, float* com_out, dpp_stream_t stream) {
+    if (!frames || !records || !com_out || B < 1 || H < 1 || W < 1) return DPP_E_BADARG;
+    hipLaunchKernelGGL(crop_com_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W,
+                       static_cast<const CropRec*>(records), com_out);
     return dpp_launch_status();
 }

@@ -286,6 +286,10 @@ def crop_prepare(rt, frames, B, H, W, com, cube, fx, fy, dsz, records, M_out=Non
                   (frames, com, cube, records, M_out), name, dict(kernel='crop_prepare', flops=2.0 * B * H * W, bytes=4.0 * B * H * W))
 
 
+def crop_com(rt, frames, records, B, H, W, com_out, name='crop_com'):
+    return Launch(rt.lib.dpp_crop_com, (frames.ptr, records.ptr, B, H, W, com_out.ptr), (frames, records, com_out), name)
+
+
 def crop_warp(rt, frames, records, B, H, W, dsz, out, normalize=True, nd_value=0.0, name='crop_warp'):
     return Launch(rt.lib.dpp_crop_warp, (frames.ptr, records.ptr, B, H, W, dsz, int(bool(normalize)), float(nd_value), out.ptr),
                   (frames, records, out), name, dict(kernel='crop_warp', flops=10.0 * B * dsz * dsz, bytes=8.0 * B * dsz * dsz))

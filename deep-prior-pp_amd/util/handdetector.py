@@ -187,14 +187,16 @@ class HandDetector(object):
         (handdetector.py:382-490).  Returns (crop in mm, crop transform M, com) like the reference."""
         if len(size) != 3 or len(dsize) != 2:
             raise ValueError("Size must be 3D and dsize 2D bounding box")
-        if com is None or docom:
-            raise NotImplementedError("CoM detection / refinement (calculateCoM, docom=True) is not provided yet")
+        if com is None:
+            raise NotImplementedError("whole-frame CoM detection (calculateCoM(self.dpt), detect) is not provided yet")
+        if docom and self.refineNet is not None:
+            raise NotImplementedError("CoM refinement by a ScaleNet (refineCoM) is not provided yet")
         if dsize[0] != dsize[1]:
             raise NotImplementedError("square destination sizes only")
-        crops, Ms = crop_frames(numpy.asarray(self.dpt, numpy.float32)[None], numpy.asarray(com, numpy.float32)[None],
-                                numpy.asarray(size, numpy.float32)[None], self.fx, self.fy, dsize[0], normalize=False,
-                                nd_value=self.getNDValue())
-        return crops[0], Ms[0].astype(numpy.float64), com
+        crops, Ms, coms = crop_frames(numpy.asarray(self.dpt, numpy.float32)[None], numpy.asarray(com, numpy.float32)[None],
+                                      numpy.asarray(size, numpy.float32)[None], self.fx, self.fy, dsize[0], normalize=False,
+                                      nd_value=self.getNDValue(), docom=docom, return_com=True)
+        return crops[0], Ms[0].astype(numpy.float64), (coms[0].astype(numpy.float64) if docom else com)
 
     def detect(self, *args, **kwargs):
         raise NotImplementedError("hand detection / tracking is a 'next' row of SURVEY.md section 8(f)")
@@ -202,10 +204,11 @@ class HandDetector(object):
     track = refineCoM = detect
 
 
-def crop_frames(frames, coms, cubes, fx, fy, dsize=128, normalize=True, nd_value=0., runtime=None):
+def crop_frames(frames, coms, cubes, fx, fy, dsize=128, normalize=True, nd_value=0., runtime=None, docom=False, return_com=False):
     """Batched cropArea3D (+ Dataset.imgStackDepthOnly when normalize): frames (B, H, W) raw depth in mm, coms (B, 3) crop
-    centres in image coordinates, cubes (B, 3) in mm -> (crops (B, dsize, dsize) float32, M (B, 3, 3) float32).  Two kernel
-    launches for the whole batch (csrc/augment.hip: crop_prepare / crop_warp)."""
+    centres in image coordinates, cubes (B, 3) in mm -> (crops (B, dsize, dsize) float32, M (B, 3, 3) float32[, coms]).
+    Two kernel launches for the whole batch (csrc/augment.hip: crop_prepare / crop_warp); docom=True re-centres every crop
+    on the centre of mass of its first window (two more launches), as handdetector.py:413-427 does."""
     from hipdp import ops
     from hipdp.runtime import default_runtime
     rt = runtime or default_runtime()
@@ -217,6 +220,13 @@ def crop_frames(frames, coms, cubes, fx, fy, dsize=128, normalize=True, nd_value
     rec = rt.alloc(B * rt.lib.dpp_crop_record_bytes(), numpy.uint8)
     out, M = rt.alloc((B, dsize, dsize), zero=False), rt.alloc((B, 9), zero=False)
     ops.crop_prepare(rt, fr, B, H, W, co, cu, fx, fy, dsize, rec, M)(rt.stream)
+    if docom:
+        co2 = rt.alloc((B, 3), zero=False)
+        ops.crop_com(rt, fr, rec, B, H, W, co2)(rt.stream)
+        ops.crop_prepare(rt, fr, B, H, W, co2, cu, fx, fy, dsize, rec, M)(rt.stream)
+        co = co2
     ops.crop_warp(rt, fr, rec, B, H, W, dsize, out, normalize=normalize, nd_value=nd_value)(rt.stream)
     rt.synchronize()
+    if return_com:
+        return out.get(), M.get().reshape(B, 3, 3), co.get()
     return out.get(), M.get().reshape(B, 3, 3)

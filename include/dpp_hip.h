@@ -243,6 +243,9 @@ int dpp_crop_prepare(const float* frames, int B, int H, int W, const float* com,
                      int dsz, void* records, float* M_out, dpp_stream_t stream);
 int dpp_crop_warp(const float* frames, const void* records, int B, int H, int W, int dsz, int normalize, float nd_value,
                   float* out, dpp_stream_t stream);
+/* docom = True (handdetector.py:413-427): the centre of mass (calculateCoM, :91-108) of the crop window described by
+ * `records`, in image coordinates -> com_out [B][3]; re-run dpp_crop_prepare with it, then dpp_crop_warp. */
+int dpp_crop_com(const float* frames, const void* records, int B, int H, int W, float* com_out, dpp_stream_t stream);
 
 #ifdef __cplusplus
 }

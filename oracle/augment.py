@@ -469,6 +469,34 @@ def crop_area_3d(dpt, com, size, fx, fy, dsize=(128, 128), nd_value=0.):
     return ret, M, com
 
 
+def calculate_com(dpt, min_depth, max_depth):
+    """calculateCoM, handdetector.py:91-108: (mean column, mean row, mean depth) of the pixels inside the depth range."""
+    dc = np.asarray(dpt, np.float32).copy()
+    dc[dc < min_depth] = 0
+    dc[dc > max_depth] = 0
+    ys, xs = np.nonzero(dc > 0)
+    num = np.count_nonzero(dc)
+    if num == 0:
+        return np.array((0., 0., 0.))
+    return np.array((xs.mean() * num, ys.mean() * num, dc.sum(dtype=np.float64)), np.float64) / num
+
+
+def crop_area_3d_docom(dpt, com, size, fx, fy, min_depth, max_depth, dsize=(128, 128), nd_value=0.):
+    """cropArea3D with docom=True and no refinement net, handdetector.py:413-427: re-centre on the CoM of the first window."""
+    xstart, xend, ystart, yend, zstart, zend = com_to_bounds(com, size, fx, fy)
+    cropped = get_crop(dpt, xstart, xend, ystart, yend, zstart, zend)
+    com2 = calculate_com(cropped, min_depth, max_depth)
+    if np.allclose(com2, 0.):
+        com2[2] = cropped[cropped.shape[0] // 2, cropped.shape[1] // 2]
+        if np.isclose(com2[2], 0):
+            com2[2] = 300
+    com2[0] += xstart
+    com2[1] += ystart
+    com2 = com2.astype(np.float32)           # the device keeps image coordinates in float32 (as the importers' arrays do)
+    ret, M, _ = crop_area_3d(dpt, com2, size, fx, fy, dsize, nd_value)
+    return ret, M, com2
+
+
 def normalize_crop(crop_mm, com_z, cube_z):
     """Dataset.imgStackDepthOnly, dataset.py:97-103: undefined depth (0) -> far plane, then (d - com_z) / (cube_z / 2)."""
     d = np.asarray(crop_mm, np.float32).copy()

@@ -134,3 +134,37 @@ def test_crop_area_3d_matches_oracle(backend):
         assert np.array_equal(crop, ref) and np.allclose(M, Mref, rtol=1e-6) and hd.getNDValue() == 0.
         with pytest.raises(NotImplementedError):
             hd.cropArea3D(com=None)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_crop_area_3d_docom(backend):
+    """cropArea3D(docom=True): the crop is re-centred on the centre of mass of its first window (calculateCoM).  The device
+    sums depth in float64 (the reference's float32 pairwise sum is not reproducible): CoM within 1e-3 mm / 1e-4 px, and the
+    crop bit-exact whenever that does not move a window bound across a rounding boundary."""
+    from hipdp import runtime as R
+    from util.handdetector import HandDetector, crop_frames
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    rng = np.random.RandomState(12)
+    cam, cube, (H, W) = A.Camera.icvl(), (250., 250., 250.), (240, 320)
+    B = 9
+    frames, coms = A.synthetic_frames(rng, B, cam, H, W, cube)
+    coms[:, :2] += rng.uniform(-12, 12, (B, 2)).astype(np.float32)          # a sloppy initial centre
+    frames[4] = 0.
+    frames[4, 100, 100] = 700.                                               # an (almost) empty frame: the fall-back branch
+    cubes = np.tile(np.asarray(cube, np.float32), (B, 1))
+    fx, fy = abs(cam.fx), abs(cam.fy)
+    crops, Ms, com2 = crop_frames(frames, coms, cubes, fx, fy, 128, normalize=False, runtime=rt, docom=True, return_com=True)
+    exact = 0
+    for i in range(B):
+        d, mn, mx = A.detector_preprocess(frames[i])
+        ref, M, cref = A.crop_area_3d_docom(d, coms[i], cubes[i], fx, fy, mn, mx)
+        np.testing.assert_allclose(com2[i], cref, rtol=0, atol=1e-3)
+        if A.com_to_bounds(com2[i], cubes[i], fx, fy) == A.com_to_bounds(cref, cubes[i], fx, fy):
+            assert np.array_equal(crops[i], ref), i
+            exact += 1
+    assert exact >= B - 1
+    hd = HandDetector(frames[1].copy(), fx, fy)
+    crop, M, c = hd.cropArea3D(com=coms[1], size=cube, dsize=(128, 128), docom=True)
+    np.testing.assert_allclose(c, com2[1], rtol=0, atol=1e-6)
+    assert np.array_equal(crop, crops[1])
