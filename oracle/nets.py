@@ -64,11 +64,14 @@ def _res_block(layers, src, in_dim, out_filters, stride):
 
 
 def build_resnet(type=0, nChan=1, wIn=128, hIn=128, batchSize=128, numJoints=16, nDims=3):
-    """ResNet types 0/1, /root/reference/src/net/resnet.py:120-195.  n = (47-2)/9 = 5 (py2 int div)."""
-    if type not in (0, 1):
-        raise NotImplementedError("oracle restates ResNet types 0 and 1")
+    """ResNet types 0-4, /root/reference/src/net/resnet.py:120-336.  n = (47-2)/9 = 5 (py2 int div).  Types 2-4 put a
+    DropoutLayer behind each 1024-wide layer (:221, :231); type 3 narrows stages 3-4 to 128 filters (:249), which makes
+    stage 3 a run of identity blocks without down-sampling; types 1 and 4 add the 30-D bottleneck."""
+    if type not in (0, 1, 2, 3, 4):
+        raise NotImplementedError("ResNet type %r" % (type,))
     n = (47 - 2) // 9
-    st = [32, 64, 128, 256, 256]
+    st = [32, 64, 128, 128, 128] if type == 3 else [32, 64, 128, 256, 256]
+    dropout, bottleneck = type in (2, 3, 4), type in (1, 4)
     layers = []
     in_dim = (batchSize, nChan, hIn, wIn)
     cd = _conv_out(in_dim, st[0], (5, 5), (1, 1), 'half')
@@ -83,12 +86,15 @@ def build_resnet(type=0, nChan=1, wIn=128, hIn=128, batchSize=128, numJoints=16,
     layers.append(dict(kind='bn', src=ref, in_dim=dim, out_dim=dim))
     layers.append(dict(kind='relu', src=('layer', len(layers) - 1), in_dim=dim, out_dim=dim))
     flat = (dim[0], int(np.prod(dim[1:])))
-    widths = [1024, 1024] + ([30] if type == 1 else []) + [numJoints * nDims]
-    acts = ['relu', 'relu'] + ([None] if type == 1 else []) + [None]
+    widths = [1024, 1024] + ([30] if bottleneck else []) + [numJoints * nDims]
+    acts = ['relu', 'relu'] + ([None] if bottleneck else []) + [None]
     src, d = ('flatten', ('layer', len(layers) - 1)), flat
     for w, a in zip(widths, acts):
         layers.append(dict(kind='fc', src=src, in_dim=d, out_dim=(batchSize, w), act=a))
         src, d = ('layer', len(layers) - 1), (batchSize, w)
+        if dropout and w == 1024:
+            layers.append(dict(kind='dropout', src=src, in_dim=d, out_dim=d, p=0.3))
+            src = ('layer', len(layers) - 1)
     return dict(layers=layers, out=('layer', len(layers) - 1), batch_size=batchSize,
                 in_dim=in_dim, out_dim=(batchSize, numJoints * nDims), name='ResNet')
 

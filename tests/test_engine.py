@@ -26,13 +26,14 @@ def make_net(rt, type_, batch, size, numJoints, nDims, seed=23455):
     # running statistics of a "trained" net: the batch statistics of a calibration batch (random running stats would not
     # normalise anything and the deterministic forward would blow up to 1e6)
     xc = nets.synthetic_crops(np.random.RandomState(seed + 2), batch, size, size, np.float64)
-    _, cache = nets.forward(onet, nets.cast_params(P, np.float64), xc, True)
+    ones = {i: np.ones(l['out_dim']) for i, l in enumerate(onet['layers']) if l['kind'] == 'dropout'}     # calibration only
+    _, cache = nets.forward(onet, nets.cast_params(P, np.float64), xc, True, ones)
     for i, l in enumerate(onet['layers']):
         if l['kind'] == 'bn':
             P[i][2], P[i][3] = cache[i][1].astype(np.float32), cache[i][2].astype(np.float32)
     # last layer scaled so that outputs are O(0.3) like normalised joint coordinates
     last = max(P)
-    out_c, _ = nets.forward(onet, nets.cast_params(P, np.float64), xc, True)
+    out_c, _ = nets.forward(onet, nets.cast_params(P, np.float64), xc, True, ones)
     P[last][0] = (P[last][0] * (0.3 / max(1e-6, np.abs(out_c).max()))).astype(np.float32)
     for i, l in enumerate(net.layers):
         if i in P:
@@ -147,3 +148,38 @@ def test_resnet_train_steps_match_oracle(backend):
           if l.params}
     ref = nets.compute_output(onet, Pd, xt.astype(np.float64))
     assert np.abs(out - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_resnet_type3_dropout_narrow_stages(backend):
+    """ResNet type 3 (resnet.py:243-288): stages 3-4 narrowed to 128 filters -- stage 3 becomes identity blocks without
+    down-sampling -- and a DropoutLayer behind each 1024-wide layer; gradients against the oracle with the device's masks."""
+    rt = get_runtime(backend)
+    net, onet, P = make_net(rt, 3, 4, 32, 1, 30)
+    assert [l.__class__.__name__ for l in net.layers].count('DropoutLayer') == 2
+    rng = np.random.RandomState(7)
+    x = nets.synthetic_crops(rng, 4, 32, 32, np.float32)
+    y = rng.normal(0, 0.3, (4, 30)).astype(np.float32)
+    # deterministic mode first (the train-mode pass below moves the running statistics): dropout is the 0.7 scale
+    # (dropoutlayer.py:100-104)
+    from hipdp import runtime as R
+    R.set_default_runtime(rt)
+    net.setDeterministic()
+    ref = nets.compute_output(onet, nets.cast_params(P, np.float64), x.astype(np.float64))
+    noise = np.abs(nets.compute_output(onet, P, x) - ref).max() * MM
+    assert np.abs(net.computeOutput(x) - ref).max() * MM < max(1e-3, 3 * noise)
+    net.unsetDeterministic()
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    cost, out = eng.cost_and_grads(x, y)
+    masks = {i: eng.dropout_masks[id(l)][0].get().astype(np.float64) for i, l in enumerate(net.layers) if id(l) in eng.dropout_masks}
+    assert len(masks) == 2
+    c_ref, G_ref, _, out_ref = nets.cost_and_grads(onet, nets.cast_params(P, np.float64), x.astype(np.float64), y.astype(np.float64), True, masks)
+    noise_mm = np.abs(nets.cost_and_grads(onet, P, x, y, True, {k: v.astype(np.float32) for k, v in masks.items()})[3] - out_ref).max() * MM
+    assert np.abs(out - out_ref).max() * MM < max(1e-3, 3 * noise_mm)
+    assert abs(cost - c_ref) < 1e-5 * abs(c_ref)
+    G = grads_from_store(eng, net)
+    gmax = max(np.abs(G_ref[i][s]).max() for i in G_ref for s in range(2))
+    for i in G_ref:
+        for s in range(2):
+            ref = G_ref[i][s]
+            np.testing.assert_allclose(G[i][s], ref, rtol=0, atol=2e-4 * max(np.abs(ref).max(), 5e-3 * gmax), err_msg='layer %d slot %d' % (i, s))
