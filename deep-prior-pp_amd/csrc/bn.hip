@@ -82,10 +82,25 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
     const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
     const int cc = c < C ? c : C - 1;                  // keep every lane in the shuffles
     double cn = 0.0, mean = 0.0, m2 = 0.0;
-    for (int b = lane; b < nb; b += DPP_WAVE) {
-        int rows = (b * rpb + rpb <= M) ? rpb : (M - b * rpb);
-        chan_combine(cn, mean, m2, (double)rows, (double)partial[((size_t)b * 2 + 0) * C + cc],
-                     (double)partial[((size_t)b * 2 + 1) * C + cc]);
+    // the loads of 8 partials are issued together (the Chan update is a dependent chain: one L2 round trip per step otherwise)
+    constexpr int U = 8;
+    for (int b0 = lane; b0 < nb; b0 += DPP_WAVE * U) {
+        float pm[U], pq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u * DPP_WAVE;
+            const int bb = b < nb ? b : nb - 1;
+            pm[u] = partial[((size_t)bb * 2 + 0) * C + cc];
+            pq[u] = partial[((size_t)bb * 2 + 1) * C + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u * DPP_WAVE;
+            if (b < nb) {
+                int rows = (b * rpb + rpb <= M) ? rpb : (M - b * rpb);
+                chan_combine(cn, mean, m2, (double)rows, (double)pm[u], (double)pq[u]);
+            }
+        }
     }
     for (int o = 1; o < DPP_WAVE; o <<= 1) {
         double on = __shfl_xor(cn, o), om = __shfl_xor(mean, o), o2 = __shfl_xor(m2, o);
@@ -175,9 +190,19 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const floa
     const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
     const int cc = c < C ? c : C - 1;
     double a = 0.0, b = 0.0;
-    for (int k = lane; k < nb; k += DPP_WAVE) {
-        a += (double)partial[((size_t)k * 2 + 0) * C + cc];
-        b += (double)partial[((size_t)k * 2 + 1) * C + cc];
+    constexpr int U = 8;
+    for (int k0 = lane; k0 < nb; k0 += DPP_WAVE * U) {
+        float pa[U], pb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * DPP_WAVE;
+            const int kk = k < nb ? k : nb - 1;
+            pa[u] = partial[((size_t)kk * 2 + 0) * C + cc];
+            pb[u] = partial[((size_t)kk * 2 + 1) * C + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k0 + u * DPP_WAVE < nb) { a += (double)pa[u]; b += (double)pb[u]; }
     }
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
     if (lane != 0 || c >= C) return;

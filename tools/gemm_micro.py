@@ -41,6 +41,8 @@ def bench_gemm(M, N, K, b_kc, tile, variant, feats, label):
     rt.tensor(B).normal_()
     Cb = rt.alloc((M, N), zero=False)
     kw = {}
+    if 'relu' in feats:
+        kw['actA'] = Act(None, None, None, 1, K)
     if 'act' in feats:
         mean, scale, beta = rt.alloc(K), rt.alloc(K), rt.alloc(K)
         a = Act(mean.ptr, scale.ptr, beta.ptr, 3, K)
@@ -122,7 +124,7 @@ def main_wgrad():
 def main_feats():
     for label, M, N, K, tile in (('stage3/4 conv c 64->256', 8192, 256, 64, (64, 64, 4)), ('stage1 conv c 16->64', 131072, 64, 16, (64, 64, 4)),
                                  ('stage3/4 conv a 256->64', 8192, 64, 256, (64, 16, 4)), ('stage1 conv a 64->16', 131072, 16, 64, (128, 16, 4))):
-        for feats in ((), ('act',), ('bias',), ('res',), ('stats',), ('act', 'bias', 'res'), ('act', 'bias', 'res', 'stats'), ('bnbwd',)):
+        for feats in ((), ('relu',), ('act',), ('bias',), ('res',), ('stats',), ('act', 'bias', 'res'), ('act', 'bias', 'res', 'stats'), ('bnbwd',)):
             bench_gemm(M, N, K, True, tile, 0, feats, label)
 
 
