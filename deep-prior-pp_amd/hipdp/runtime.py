@@ -51,6 +51,15 @@ class Buffer(object):
         self.rt.zero(self)
 
 
+class _AsyncRead(object):
+    def __init__(self, host, ev, shape):
+        self.host, self.ev, self.shape = host, ev, shape
+
+    def get(self):
+        self.ev.synchronize()
+        return self.host.numpy().reshape(self.shape).copy()
+
+
 class TorchHipRuntime(object):
     def __init__(self, device=None, lib_path=None):
         import torch
@@ -100,6 +109,18 @@ class TorchHipRuntime(object):
 
     def zero(self, buf):
         self._tensor(buf).zero_()
+
+    def read_async(self, buf):
+        """Start a device -> pinned-host copy of `buf` behind the work queued so far and return a handle whose .get() waits
+        for THAT copy only (an event), not for work queued afterwards: lets the host read step k's cost while step k+1 is
+        already in flight."""
+        t = self.torch
+        src = self._tensor(buf)
+        host = t.empty(src.shape, dtype=src.dtype, pin_memory=True)
+        host.copy_(src, non_blocking=True)
+        ev = t.cuda.Event()
+        ev.record(t.cuda.current_stream(self.device))
+        return _AsyncRead(host, ev, buf.shape)
 
     def copy(self, dst, src):
         self._tensor(dst).copy_(self._tensor(src))

@@ -307,6 +307,25 @@ class NetTrainer(object):
             validation_obs[vi - 1].append(numpy.nanmean([self.validation_observer[vi](i) for i in range(n_val_batches)]))
         self.poseNet.unsetDeterministic()
 
+        class _Now(object):                       # a trainer without an asynchronous step: the value is already there
+            def __init__(self, v):
+                self.v = v
+
+            def get(self):
+                return numpy.asarray([self.v])
+
+        train_async = getattr(self, 'train_model_async', None) or (lambda i, lr: _Now(self.train_model(i, lr)))
+        pending = None
+
+        def resolve(p):
+            idx, handle = p
+            minibatch_avg_cost = float(numpy.asarray(handle.get()).reshape(-1)[0])
+            print("minibatch {0:4d}, average cost: {1}".format(idx, minibatch_avg_cost))
+            if numpy.any(numpy.isnan(minibatch_avg_cost)):
+                self.checkNaNs()
+                assert False
+            train_costs.append(minibatch_avg_cost)
+
         while self.epoch < n_epochs:
             if self.epoch % self.cfgParams.snapshot_last == 0:
                 self.poseNet.save(self.subfolder + '/net_last.pkl')
@@ -322,15 +341,20 @@ class NetTrainer(object):
                     getattr(self, self.cfgParams.pre_minibatch_fn)()
                 self.poseNet.unsetDeterministic()
                 mini_idx = self.loadMiniBatch(minibatch_index)
-                minibatch_avg_cost = self.train_model(mini_idx, learning_rate)
-                print("minibatch {0:4d}, average cost: {1}".format(minibatch_index, minibatch_avg_cost))
-                if numpy.any(numpy.isnan(minibatch_avg_cost)):
-                    self.checkNaNs()
-                    assert False
-                train_costs.append(minibatch_avg_cost)
+                # The reference reads the cost of every minibatch right after the device call (nettrainer.py:844-849).  Here the
+                # next minibatch is queued first and the previous cost is read while it runs: same values, same order, the NaN
+                # check one step late -- the host round trip no longer sits between two steps.
+                launched = (minibatch_index, train_async(mini_idx, learning_rate))
+                if pending is not None:
+                    resolve(pending)
+                pending = launched
                 if self.cfgParams.post_minibatch_fn is not None:
                     getattr(self, self.cfgParams.post_minibatch_fn)()
                 iter_count = (self.epoch - 1) * self.getNumFullMiniBatches() + minibatch_index
+                last_of_epoch = minibatch_index == self.getNumFullMiniBatches() - 1
+                if last_of_epoch or (iter_count + 1) % self.cfgParams.validation_frequency == 0:
+                    resolve(pending)
+                    pending = None
                 if (iter_count + 1) % self.cfgParams.validation_frequency == 0:
                     if storeFilters:
                         for lay in self.poseNet.layers:

@@ -69,9 +69,18 @@ class PoseRegNetTrainer(NetTrainer):
             te.train_step_device(learning_rate, allreduce=self._allreduce)
             return float(te.cost.get()[0])
 
+        def train_model_async(index, learning_rate):
+            """Same step; the cost comes back through a handle (.get()) so that the epoch loop can queue the next minibatch
+            before it reads this one's cost (no host round trip between steps)."""
+            self.rt.copy(te.x_in.buf, self.train_data_x.rows(index * B, B))
+            self.rt.copy(te.y_in, self.train_data_y.rows(index * B, B))
+            te.train_step_device(learning_rate, allreduce=self._allreduce)
+            return self.rt.read_async(te.cost)
+
         def test_model_on_train(index):
             return self._eval(self.train_data_x, self.train_data_y, index)[1]
 
+        self.train_model_async = train_model_async
         self.train_model = train_model
         self.test_model_on_train = test_model_on_train
 
