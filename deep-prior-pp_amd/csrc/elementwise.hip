@@ -174,6 +174,28 @@ __global__ __launch_bounds__(DPP_THREADS) void bernoulli_mask_kernel(float* __re
     }
 }
 
+// dst[r][c] = relu?(src[r][c]) for a rows x cols block with independent row strides: packs the flattened tower outputs of
+// ScaleNet side by side (T.concatenate(..., axis=1), scalenet.py:167-171) and splits the gradient again.
+__global__ __launch_bounds__(DPP_THREADS) void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+                                                             int rows, int cols, int relu) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DPP_THREADS) {
+        const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+        float v = src[(size_t)r * lds + c];
+        dst[(size_t)r * ldd + c] = relu ? fmaxf(v, 0.0f) : v;
+    }
+}
+
+// centre h x w window of every [H][W] image of a batch (scalenettrainer.py:239-251, handdetector.py:654-666)
+__global__ __launch_bounds__(DPP_THREADS) void crop_center_kernel(const float* __restrict__ src, int B, int H, int W, float* __restrict__ dst,
+                                                                  int h, int w, int y0, int x0) {
+    const size_t n = (size_t)B * h * w;
+    for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DPP_THREADS) {
+        const int x = (int)(i % w), y = (int)((i / w) % h), b = (int)(i / ((size_t)w * h));
+        dst[i] = src[((size_t)b * H + y0 + y) * W + x0 + x];
+    }
+}
+
 int grid_for(size_t n) {
     size_t b = (n + DPP_THREADS - 1) / DPP_THREADS;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -251,5 +273,21 @@ extern "C" int dpp_bernoulli_mask(float* mask, size_t n, float keep, unsigned lo
     if (!mask || n < 1) return DPP_E_BADARG;
     hipLaunchKernelGGL(bernoulli_mask_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), mask, n, keep, seed,
                        counter, counter_dev);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, int relu, dpp_stream_t stream) {
+    if (!src || !dst || rows < 1 || cols < 1 || lds < cols || ldd < cols) return DPP_E_BADARG;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((size_t)rows * cols)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), src, lds,
+                       dst, ldd, rows, cols, relu);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_crop_center(const float* src, int B, int H, int W, float* dst, int h, int w, dpp_stream_t stream) {
+    if (!src || !dst || B < 1 || h < 1 || w < 1 || h > H || w > W) return DPP_E_BADARG;
+    // the reference's index arithmetic: start = int(size / 2 - dsize / 2) along each axis
+    int y0 = (int)(H / 2.0 - h / 2.0), x0 = (int)(W / 2.0 - w / 2.0);
+    hipLaunchKernelGGL(crop_center_kernel, dim3(grid_for((size_t)B * h * w)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), src, B,
+                       H, W, dst, h, w, y0, x0);
     return dpp_launch_status();
 }

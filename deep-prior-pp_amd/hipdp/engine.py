@@ -122,14 +122,14 @@ class ParamStore(object):
         if s['kind'] == 'conv_w':
             return layout.conv_w_to_kernel(value).reshape(-1)
         if s['kind'] == 'fc_w' and s['info'] is not None:
-            return layout.fc_rows_nchw_to_nhwc(value, *s['info']).reshape(-1)
+            return _fc_rows(value, s['info'], layout.fc_rows_nchw_to_nhwc).reshape(-1)
         return value.reshape(-1)
 
     def _from_kernel(self, s, flat):
         if s['kind'] == 'conv_w':
             return layout.conv_w_from_kernel(flat, s['shape'])
         if s['kind'] == 'fc_w' and s['info'] is not None:
-            return layout.fc_rows_nhwc_to_nchw(flat.reshape(s['shape']), *s['info'])
+            return _fc_rows(flat.reshape(s['shape']), s['info'], layout.fc_rows_nhwc_to_nchw)
         return flat.reshape(s['shape']).copy()
 
     def _write(self, i, value):
@@ -155,6 +155,20 @@ class ParamStore(object):
         for i, s in enumerate(self.slots):
             s['param']._host = np.asarray(self.read_param(i), np.float32)
             s['param']._binding = None
+
+
+def _fc_rows(W, info, fn):
+    """Row permutation between the reference's NCHW flatten order and the NHWC order of the activations: one (C, H, W)
+    block, or several side by side when the FC input is a concatenation of flattened maps (ScaleNet)."""
+    if isinstance(info[0], int):
+        return fn(W, *info)
+    out, o = [], 0
+    for (Cc, H, Wd) in info:
+        n = Cc * H * Wd
+        out.append(fn(W[o:o + n], Cc, H, Wd) if H * Wd > 1 else W[o:o + n])
+        o += n
+    assert o == W.shape[0]
+    return np.concatenate(out, axis=0)
 
 
 def _layer_kind(layer):
@@ -196,6 +210,8 @@ def _param_specs(net, layers):
                 _, Cc, H, W = iv.inputs[0].shape
                 if H * W > 1:
                     info = (Cc, H, W)
+            elif iv.kind == 'concat':
+                info = tuple(tuple(f.inputs[0].shape[1:]) for f in iv.inputs)
             specs.append((l.W, 'fc_w', info, True))
             specs.append((l.b, 'vec', None, True))
         elif k == 'BatchNormLayer':
@@ -327,9 +343,17 @@ class CompiledNet(object):
         self.reduce_jobs = ops.ReduceJobs(rt)
         self.dropout_masks = {}
         self.step_ctr = rt.alloc(1, np.int64) if train else None     # device-resident step counter (dropout mask streams)
-        in_dim = net.cfgParams.inputDim
-        self.in_shape = (in_dim[0], in_dim[2], in_dim[3], in_dim[1])
-        self.x_in = TensorV(rt.alloc(self.in_shape), self.in_shape, 'x')
+        in_dims = net.cfgParams.inputDim
+        in_vars = net.inputVar
+        if not isinstance(in_vars, (list, tuple)):
+            in_dims, in_vars = [in_dims], [in_vars]
+        self.x_ins, self.input_of = [], {}
+        for k, (d, v) in enumerate(zip(in_dims, in_vars)):                 # ScaleNet has three inputs (scalenet.py:150-156)
+            shp = (d[0], d[2], d[3], d[1])
+            t = TensorV(rt.alloc(shp), shp, 'x%d' % k)
+            self.x_ins.append(t)
+            self.input_of[id(v)] = t
+        self.x_in, self.in_shape = self.x_ins[0], self.x_ins[0].shape
         self._memo = {}
         out_view = self._emit(net.output)
         self.out = self._materialize_plain(out_view)
@@ -423,7 +447,7 @@ class CompiledNet(object):
             return self._memo[id(var)]
         k = var.kind
         if k == 'input':
-            v = View(self.x_in)
+            v = View(self.input_of.get(id(var), self.x_in))
         elif k == 'flatten':
             src = self._emit(var.inputs[0])
             n = src.shape[0]
@@ -436,6 +460,8 @@ class CompiledNet(object):
                 v = View(src.base, src.bn, True, shape=src.shape, chan=src.chan)
         elif k == 'add':
             v = self._emit_add(var)
+        elif k == 'concat':
+            v = self._emit_concat(var)
         elif k == 'layer':
             v = self._emit_layer(var, residual, out_var)
         else:
@@ -443,6 +469,37 @@ class CompiledNet(object):
         if residual is None:
             self._memo[id(var)] = v
         return v
+
+    def _emit_concat(self, var):
+        """T.concatenate of flattened tower outputs (scalenet.py:167-171): every part is packed (with its pending ReLU) into
+        its column range of one [N][sum] buffer, which the following HiddenLayer reads as a plain operand."""
+        parts = [self._emit(p) for p in var.inputs]
+        N = parts[0].shape[0]
+        widths = [int(p.shape[1]) for p in parts]
+        total = sum(widths)
+        cat = self._new_tensor((N, total), 'concat')
+        cat.concat_parts = []
+        off = 0
+        for p, w in zip(parts, widths):
+            if p.bn is not None or len(p.shape) != 2 or int(np.prod(p.base.shape[1:])) != w:
+                raise NotImplementedError("concatenation of anything but flattened (ReLU) maps")
+            self.fwd.add(ops.copy2d(self.rt, p.base.buf, w, cat.buf.view(off, (N * total - off,)), total, N, w, relu=p.relu,
+                                    name='concat_pack'))
+            cat.concat_parts.append((p, off, w))
+            off += w
+        return View(cat)
+
+    def _split_concat_grad(self, cat):
+        """Backward of the concatenation: the column ranges of d(concat) go back to the parts' view gradients."""
+        N, total = cat.shape
+        for p, off, w in cat.concat_parts:
+            if p.base in self.x_ins:
+                continue
+            tgt, dst = self._view_grad(p)
+            if tgt.grad_written:
+                raise NotImplementedError("concatenated value with another consumer")
+            self.bwd.add(ops.copy2d(self.rt, cat.grad.view(off, (N * total - off,)), total, dst, w, N, w, name='concat_split'))
+            tgt.grad_written = True
 
     def _emit_add(self, var):
         a, b = var.inputs
@@ -821,7 +878,7 @@ class CompiledNet(object):
         # stream while the main stream continues with the data-gradient chain
         self.bwd.fork()
         self._bias_grad(dY, M, Co, gb)
-        need_dx = src.base is not self.x_in
+        need_dx = src.base not in self.x_ins
         if k == (1, 1):
             mp = RowMap.strided(s, Ho, Wo, Hi, Wi) if s != 1 else None
             # filter gradient dW[o][c] = sum_m dY[m][o] * act(X)[map(m)][c]
@@ -890,7 +947,7 @@ class CompiledNet(object):
             off = (gW.ptr - st.g.ptr) // 4
             self._early_slice = (off, off + K * Nout)
             self.bwd.add(self.dp.allreduce_sum_async_op(gW, self._early_work, 'grad_allreduce_early'), side=True)
-        if src.base is not self.x_in:
+        if src.base not in self.x_ins:
             tgt, dst = self._view_grad(src)
             acc = tgt.grad_written
             tile, splitk = gemm_plan(Nb, K, Nout, allow_split=not acc)
@@ -903,6 +960,8 @@ class CompiledNet(object):
                 self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, Nb, K, Nout, 1, 1, Nout, Nout, K, residual=dst if acc else None,
                                       tile=tile, name='fc_dgrad_%d' % layer.layerNum))
             tgt.grad_written = True
+            if getattr(src.base, 'concat_parts', None) is not None:
+                self._split_concat_grad(src.base)
 
     def _bwd_convpool(self, layer, io, dY):
         rt, st = self.rt, self.store
@@ -915,7 +974,7 @@ class CompiledNet(object):
         self.bwd.add(ops.convpool_wgrad(rt, src.base.buf, g['N'], g['H'], g['W'], g['Ci'], dY, io['ties'], g['kh'], g['kw'], g['pad'],
                                         g['Co'], g['pool'], part, actX=self._act(src), name='convpool_wgrad_%d' % layer.layerNum), side=True)
         self.reduce_jobs.add(part, nblk, nW, st.view(layer.W, 'g'))
-        if src.base is not self.x_in:
+        if src.base not in self.x_ins:
             tgt, dst = self._view_grad(src)
             if tgt.grad_written:
                 raise NotImplementedError("ConvPoolLayer input with several consumers")
@@ -941,10 +1000,15 @@ class CompiledNet(object):
     # ------------------------------------------------------------------------------------------ execution
     def set_input(self, x):
         """x: (N, C, H, W) host array (the reference's NCHW crops)."""
-        x = np.asarray(x, np.float32)
-        if tuple(x.shape) != tuple(self.net.cfgParams.inputDim):
-            raise ValueError("input shape %s, expected %s" % (x.shape, self.net.cfgParams.inputDim))
-        self.x_in.buf.set(x if x.shape[1] == 1 else layout.nchw_to_nhwc(x))
+        xs = x if isinstance(x, (list, tuple)) else [x]
+        if len(xs) != len(self.x_ins):
+            raise ValueError("the net takes %d inputs, got %d" % (len(self.x_ins), len(xs)))
+        for t, a in zip(self.x_ins, xs):
+            a = np.asarray(a, np.float32)
+            want = (t.shape[0], t.shape[3], t.shape[1], t.shape[2])
+            if tuple(a.shape) != want:
+                raise ValueError("input shape %s, expected %s" % (a.shape, want))
+            t.buf.set(a if a.shape[1] == 1 else layout.nchw_to_nhwc(a))
 
     def forward(self, x=None):
         if x is not None:

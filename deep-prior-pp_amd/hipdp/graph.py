@@ -6,7 +6,7 @@ hipdp.engine compiles the graph reachable from `net.output` into kernel launches
 
 
 class Var(object):
-    """Symbolic value: kind in {'input', 'layer', 'add', 'flatten', 'reshape'}."""
+    """Symbolic value: kind in {'input', 'layer', 'add', 'flatten', 'reshape', 'relu', 'concat'}."""
 
     def __init__(self, kind, inputs=(), layer=None, shape=None, name=None):
         self.kind = kind
@@ -40,6 +40,16 @@ class Var(object):
 
 def tensor4(name='x'):
     return Var('input', name=name)
+
+
+def concatenate(vars_, axis=1):
+    """T.concatenate of flattened (2-D) values along the feature axis (scalenet.py:167-171)."""
+    if axis != 1:
+        raise NotImplementedError("only axis=1 concatenation is used by the reference nets")
+    shp = None
+    if all(v.shape is not None for v in vars_):
+        shp = (vars_[0].shape[0], sum(v.shape[1] for v in vars_))
+    return Var('concat', tuple(vars_), shape=shp)
 
 
 class SharedParam(object):

@@ -295,6 +295,14 @@ def crop_warp(rt, frames, records, B, H, W, dsz, out, normalize=True, nd_value=0
                   (frames, records, out), name, dict(kernel='crop_warp', flops=10.0 * B * dsz * dsz, bytes=8.0 * B * dsz * dsz))
 
 
+def copy2d(rt, src, lds, dst, ldd, rows, cols, relu=False, name='copy2d'):
+    return Launch(rt.lib.dpp_copy2d, (src.ptr, lds, dst.ptr, ldd, rows, cols, int(bool(relu))), (src, dst), name)
+
+
+def crop_center(rt, src, B, H, W, dst, h, w, name='crop_center'):
+    return Launch(rt.lib.dpp_crop_center, (src.ptr, B, H, W, dst.ptr, h, w), (src, dst), name)
+
+
 def fill_zero(rt, buf, name='fill_zero'):
     return Launch(rt.lib.dpp_fill_zero, (buf.ptr, buf.nbytes), (buf,), name)
 

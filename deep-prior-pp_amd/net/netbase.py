@@ -146,14 +146,13 @@ class NetBase(object):
         if not isinstance(inputs, list):
             inputs = [inputs]
         assert all(i.shape[0] == inputs[0].shape[0] for i in inputs[1:])
-        if len(inputs) != 1 or isinstance(self.output, list):
-            raise NotImplementedError("multi-input / multi-output nets (ScaleNet) are listed under 'next' in SURVEY.md 8(f)")
+        if isinstance(self.output, list):
+            raise NotImplementedError("multi-output nets")
         if not self.isDeterministic():
             print("WARNING: network is probabilistic for testing, DISABLING")
             self.setDeterministic()
-        x = inputs[0]
         batch_size = self.cfgParams.batch_size
-        nSamp = x.shape[0]
+        nSamp = inputs[0].shape[0]
         padSize = int(batch_size * numpy.ceil(nSamp / float(batch_size)))
         outSize = list(self.cfgParams.outputDim)
         outSize[0] = padSize
@@ -162,13 +161,16 @@ class NetBase(object):
         n_test_batches = padSize // batch_size
         start = time.time()
         for i in range(n_test_batches):
-            chunk = x[i * batch_size:(i + 1) * batch_size]
-            if chunk.shape[0] < batch_size:
-                pad = numpy.zeros((batch_size,) + tuple(x.shape[1:]), dtype=x.dtype)
-                pad[0:chunk.shape[0]] = chunk
-                pad[chunk.shape[0]:] = x[-1]
-                chunk = pad
-            o = eng.forward(chunk)
+            chunks = []
+            for x in inputs:                              # one array per network input (three for ScaleNet)
+                chunk = x[i * batch_size:(i + 1) * batch_size]
+                if chunk.shape[0] < batch_size:
+                    pad = numpy.zeros((batch_size,) + tuple(x.shape[1:]), dtype=x.dtype)
+                    pad[0:chunk.shape[0]] = chunk
+                    pad[chunk.shape[0]:] = x[-1]
+                    chunk = pad
+                chunks.append(chunk)
+            o = eng.forward(chunks if len(chunks) > 1 else chunks[0])
             out[i * batch_size:(i + 1) * batch_size] = o.reshape(self.cfgParams.outputDim)
         end = time.time()
         if timeit:

@@ -5,8 +5,9 @@ HandDetector -- the augmentation slice of /root/reference/src/util/handdetector.
 The crop warps run on the MI355X through the fused augmentation kernels (csrc/augment.hip); this class keeps the
 reference's per-crop method signatures for callers and computes only the tiny 3x3 crop geometry on the host.
 cropArea3D (handdetector.py:382-490, docom=False: the call the importers make for every frame) runs on the device too;
-`crop_frames` is its batched form fused with Dataset.imgStackDepthOnly.  Detection / tracking / CoM refinement
-(detect, track, refineCoM, docom=True) are not provided yet.
+`crop_frames` is its batched form fused with Dataset.imgStackDepthOnly.  CoM refinement by a ScaleNet (refineCoM,
+handdetector.py:634-676) goes through the net's computeOutput.  Whole-frame detection / tracking (detect, track) are not
+provided yet.
 """
 import numpy
 
@@ -189,19 +190,52 @@ class HandDetector(object):
             raise ValueError("Size must be 3D and dsize 2D bounding box")
         if com is None:
             raise NotImplementedError("whole-frame CoM detection (calculateCoM(self.dpt), detect) is not provided yet")
-        if docom and self.refineNet is not None:
-            raise NotImplementedError("CoM refinement by a ScaleNet (refineCoM) is not provided yet")
         if dsize[0] != dsize[1]:
             raise NotImplementedError("square destination sizes only")
-        crops, Ms, coms = crop_frames(numpy.asarray(self.dpt, numpy.float32)[None], numpy.asarray(com, numpy.float32)[None],
-                                      numpy.asarray(size, numpy.float32)[None], self.fx, self.fy, dsize[0], normalize=False,
-                                      nd_value=self.getNDValue(), docom=docom, return_com=True)
+        frame = numpy.asarray(self.dpt, numpy.float32)[None]
+        cube = numpy.asarray(size, numpy.float32)[None]
+        nd = self.getNDValue()
+        crops, Ms, coms = crop_frames(frame, numpy.asarray(com, numpy.float32)[None], cube, self.fx, self.fy, dsize[0], normalize=False,
+                                      nd_value=nd, docom=docom, return_com=True)
+        if docom and self.refineNet is not None and self.importer is not None:
+            # handdetector.py:429-440: a ScaleNet regresses the offset of the true CoM from the crop; crop again around it
+            newCom3D = self.refineCoM(crops[0], size, coms[0]) + self.importer.jointImgTo3D(coms[0])
+            com2 = numpy.asarray(self.importer.joint3DToImg(newCom3D), numpy.float64)
+            if numpy.allclose(com2, 0.):
+                com2[2] = crops[0][crops[0].shape[0] // 2, crops[0].shape[1] // 2]
+            crops, Ms, coms = crop_frames(frame, com2.astype(numpy.float32)[None], cube, self.fx, self.fy, dsize[0], normalize=False,
+                                          nd_value=nd, return_com=True)
         return crops[0], Ms[0].astype(numpy.float64), (coms[0].astype(numpy.float64) if docom else com)
+
+    def refineCoM(self, cropped, size, com):
+        """Offset (mm) of the hand centre predicted by the refinement net from a crop around `com` (handdetector.py:634-676):
+        normalise and clamp the crop to the cube, feed it with its 1/2 and 1/4 centre crops."""
+        imgD = numpy.asarray(cropped, 'float32').copy()
+        imgD[imgD == 0] = com[2] + (size[2] / 2.)
+        imgD[imgD >= com[2] + (size[2] / 2.)] = com[2] + (size[2] / 2.)
+        imgD[imgD <= com[2] - (size[2] / 2.)] = com[2] - (size[2] / 2.)
+        imgD -= com[2]
+        imgD /= (size[2] / 2.)
+        test_data = numpy.zeros((1, 1, cropped.shape[0], cropped.shape[1]), dtype='float32')
+        test_data[0, 0] = imgD
+        inputs = [test_data]
+        for k in (2, 4):
+            dsize = (int(test_data.shape[2] // k), int(test_data.shape[3] // k))
+            xstart = int(test_data.shape[2] / 2 - dsize[0] / 2)
+            ystart = int(test_data.shape[3] / 2 - dsize[1] / 2)
+            inputs.append(numpy.ascontiguousarray(test_data[:, :, ystart:ystart + dsize[1], xstart:xstart + dsize[0]]))
+        if self.refineNet.cfgParams.numInputs == 1:
+            jts = self.refineNet.computeOutput(test_data)
+        elif self.refineNet.cfgParams.numInputs == 3:
+            jts = self.refineNet.computeOutput(inputs)
+        else:
+            raise NotImplementedError("Number of inputs is {}".format(self.refineNet.cfgParams.numInputs))
+        return jts[0] * (size[2] / 2.)
 
     def detect(self, *args, **kwargs):
         raise NotImplementedError("hand detection / tracking is a 'next' row of SURVEY.md section 8(f)")
 
-    track = refineCoM = detect
+    track = detect
 
 
 def crop_frames(frames, coms, cubes, fx, fy, dsize=128, normalize=True, nd_value=0., runtime=None, docom=False, return_com=False):

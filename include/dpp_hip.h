@@ -205,6 +205,12 @@ int dpp_scale(const float* x, const float* mask, float a, int relu, float* y, si
 int dpp_relu_bwd(const float* dy, const float* pre, const float* mask, float a, float* g, size_t n, dpp_stream_t stream);
 
 int dpp_fill_zero(void* p, size_t nbytes, dpp_stream_t stream);
+/* dst[r][c] = relu ? max(src[r][c], 0) : src[r][c] over rows x cols with row strides lds / ldd: the column-wise
+ * concatenation of ScaleNet's flattened tower outputs (/root/reference/src/net/scalenet.py:167-171) and its gradient split */
+int dpp_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, int relu, dpp_stream_t stream);
+/* centre h x w window of each [H][W] image: ScaleNet's 1/2 and 1/4 inputs
+ * (/root/reference/src/trainer/scalenettrainer.py:239-251, /root/reference/src/util/handdetector.py:654-666) */
+int dpp_crop_center(const float* src, int B, int H, int W, float* dst, int h, int w, dpp_stream_t stream);
 /* mask[i] = 1 with probability keep (counter-based generator keyed by seed, counter + *counter_dev, i): DropoutLayer
  * masks; counter_dev (may be NULL) is a device-resident step counter so that a recorded launch draws a new mask per step */
 int dpp_bernoulli_mask(float* mask, size_t n, float keep, unsigned long long seed, unsigned long long counter,

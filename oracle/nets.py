@@ -126,6 +126,50 @@ def build_poseregnet(type=0, nChan=1, wIn=128, hIn=128, batchSize=128, numJoints
                 in_dim=(batchSize, nChan, hIn, wIn), out_dim=(batchSize, numJoints * nDims), name='PoseRegNet')
 
 
+def build_scalenet(type=1, nChan=1, wIn=128, hIn=128, batchSize=128, numJoints=1, nDims=3, resizeFactor=2):
+    """ScaleNet type 1, /root/reference/src/net/scalenet.py:49-127, 150-180: three conv-pool towers on the crop and its
+    1/2 and 1/4 centre crops, flattened and concatenated, then FC 1024 - dropout - FC 1024 - dropout - FC out."""
+    if type != 1:
+        raise NotImplementedError("not implemented")
+    layers, tails = [], []
+    towers = (((5, 5), (4, 4)), ((5, 5), (2, 2)), ((3, 3), (1, 1))), (((5, 5), (2, 2)), ((5, 5), (2, 2)), ((3, 3), (1, 1))), \
+        (((5, 5), (2, 2)), ((5, 5), (1, 1)), ((3, 3), (1, 1)))
+    in_dims = []
+    for t, tower in enumerate(towers):
+        d = (batchSize, nChan, hIn // resizeFactor ** t, wIn // resizeFactor ** t)
+        in_dims.append(d)
+        src = ('input', t)
+        for k, pool in tower:
+            cd = _conv_out(d, 8, k, (1, 1), 'valid')
+            od = (cd[0], cd[1], cd[2] // pool[0], cd[3] // pool[1])
+            layers.append(dict(kind='convpool', src=src, in_dim=d, out_dim=od, nf=8, k=k, stride=(1, 1), border='valid', pool=pool,
+                               act='relu'))
+            src, d = ('layer', len(layers) - 1), od
+        tails.append((src, d[1] * d[2] * d[3]))
+    src = ('concat',) + tuple(('flatten', r) for r, _ in tails)
+    d = (batchSize, sum(n for _, n in tails))
+    for _ in range(2):
+        layers.append(dict(kind='fc', src=src, in_dim=d, out_dim=(batchSize, 1024), act='relu'))
+        src, d = ('layer', len(layers) - 1), (batchSize, 1024)
+        layers.append(dict(kind='dropout', src=src, in_dim=d, out_dim=d, p=L.DROPOUT_P))
+        src = ('layer', len(layers) - 1)
+    layers.append(dict(kind='fc', src=src, in_dim=d, out_dim=(batchSize, numJoints * nDims), act=None))
+    return dict(layers=layers, out=('layer', len(layers) - 1), batch_size=batchSize, in_dim=in_dims,
+                out_dim=(batchSize, numJoints * nDims), name='ScaleNet')
+
+
+def scalenet_inputs(x):
+    """The three inputs of ScaleNet from the full crop: itself and its 1/2 and 1/4 CENTRE crops (no resampling),
+    /root/reference/src/trainer/scalenettrainer.py:239-251, /root/reference/src/util/handdetector.py:654-666."""
+    H, W = x.shape[2], x.shape[3]
+    out = [x]
+    for f in (2, 4):
+        h, w = H // f, W // f
+        xs, ys = int(H / 2 - h / 2), int(W / 2 - w / 2)
+        out.append(np.ascontiguousarray(x[:, :, ys:ys + w, xs:xs + h]))
+    return out
+
+
 def has_dropout(net):
     return any(l['kind'] == 'dropout' for l in net['layers'])
 
@@ -201,7 +245,7 @@ def forward(net, P, x, train, dropout_masks=None):
 
     def get(ref):
         if ref[0] == 'input':
-            return x
+            return x[ref[1]] if len(ref) > 1 else x        # multi-input nets (ScaleNet) pass a list of arrays
         if ref[0] == 'layer':
             return vals[ref[1]]
         if ref[0] == 'add':
@@ -211,6 +255,8 @@ def forward(net, P, x, train, dropout_masks=None):
         if ref[0] == 'flatten':
             v = get(ref[1])
             return v.reshape(v.shape[0], -1)
+        if ref[0] == 'concat':                              # T.concatenate(..., axis=1), scalenet.py:167-171
+            return np.concatenate([get(r) for r in ref[1:]], axis=1)
         raise ValueError(ref)
 
     for i, l in enumerate(net['layers']):
@@ -264,6 +310,9 @@ def backward(net, P, cache, dout, weight_decay=0.0):
         if ref[0] == 'flatten':
             s = shape_of(ref[1])
             return (s[0], int(np.prod(s[1:])))
+        if ref[0] == 'concat':
+            ss = [shape_of(r) for r in ref[1:]]
+            return (ss[0][0], sum(q[1] for q in ss))
         return None
 
     def push(ref, g):
@@ -276,6 +325,12 @@ def backward(net, P, cache, dout, weight_decay=0.0):
             push(ref[2], g)
         elif ref[0] == 'flatten':
             push(ref[1], g.reshape(shape_of(ref[1])))
+        elif ref[0] == 'concat':
+            o = 0
+            for r in ref[1:]:
+                n = shape_of(r)[1]
+                push(r, g[:, o:o + n])
+                o += n
 
     push(net['out'], dout)
     G = {}
@@ -360,14 +415,19 @@ def compute_output(net, P, inputs):
     """NetBase.computeOutput, /root/reference/src/net/netbase.py:217-316: deterministic forward in
     batches of batch_size, the last batch padded by repeating the last sample, result trimmed."""
     bs = net['batch_size']
-    n = inputs.shape[0]
+    multi = isinstance(inputs, (list, tuple))
+    ins = list(inputs) if multi else [inputs]
+    n = ins[0].shape[0]
     pad = int(bs * np.ceil(n / float(bs)))
-    out = np.zeros((pad,) + tuple(net['out_dim'][1:]), dtype=inputs.dtype)
+    out = np.zeros((pad,) + tuple(net['out_dim'][1:]), dtype=ins[0].dtype)
     for i in range(pad // bs):
-        chunk = inputs[i * bs:(i + 1) * bs]
-        if chunk.shape[0] < bs:
-            chunk = np.concatenate([chunk, np.repeat(inputs[-1:], bs - chunk.shape[0], axis=0)], axis=0)
-        o, _ = forward(net, P, chunk, train=False)
+        chunks = []
+        for a in ins:
+            chunk = a[i * bs:(i + 1) * bs]
+            if chunk.shape[0] < bs:
+                chunk = np.concatenate([chunk, np.repeat(a[-1:], bs - chunk.shape[0], axis=0)], axis=0)
+            chunks.append(chunk)
+        o, _ = forward(net, P, chunks if multi else chunks[0], train=False)
         out[i * bs:(i + 1) * bs] = o.reshape((bs,) + tuple(net['out_dim'][1:]))
     return out[:n]
 

@@ -63,13 +63,15 @@ def forward(net, T, x, train):
 
     def get(ref):
         if ref[0] == 'input':
-            return x
+            return x[ref[1]] if len(ref) > 1 else x
         if ref[0] == 'layer':
             return vals[ref[1]]
         if ref[0] == 'add':
             return get(ref[1]) + get(ref[2])
         if ref[0] == 'flatten':
             return get(ref[1]).flatten(1)
+        if ref[0] == 'concat':
+            return torch.cat([get(r) for r in ref[1:]], dim=1)
         raise ValueError(ref)
 
     for i, l in enumerate(net['layers']):
@@ -109,7 +111,7 @@ def forward(net, T, x, train):
 def cost_and_grads(net, P, x, y, dtype=torch.float64):
     """Returns (cost, {layer: [g0, g1]}, out) with autograd gradients (numpy arrays)."""
     T = to_torch(P, dtype)
-    xt = torch.tensor(x, dtype=dtype)
+    xt = [torch.as_tensor(a, dtype=dtype) for a in x] if isinstance(x, (list, tuple)) else torch.tensor(x, dtype=dtype)
     yt = torch.tensor(y, dtype=dtype)
     out, _ = forward(net, T, xt, True)
     cost = ((out - yt) ** 2).sum(dim=1).mean()

@@ -140,6 +140,25 @@ def test_poseregnet_backward_matches_torch_autograd():
             np.testing.assert_allclose(G[i][s], G2[i][s], rtol=1e-8, atol=1e-13)
 
 
+def test_scalenet_backward_matches_torch_autograd():
+    """ScaleNet (three towers, concatenation; scalenet.py:49-180): analytic backward of the multi-input graph vs autograd."""
+    rng = np.random.RandomState(6)
+    net = nets.build_scalenet(batchSize=3, numJoints=1, nDims=3, wIn=96, hIn=96)
+    for l in net['layers']:
+        if l['kind'] == 'dropout':
+            l['kind'] = 'relu'
+    P = nets.init_params(net, rng, np.float64)
+    xs = nets.scalenet_inputs(nets.synthetic_crops(rng, 3, 96, 96, np.float64))
+    assert [a.shape[2] for a in xs] == [96, 48, 24]
+    y = rng.normal(0, .3, (3, 3))
+    cost, G, _, out = nets.cost_and_grads(net, P, xs, y)
+    c2, G2, out2 = torch_ref.cost_and_grads(net, P, xs, y)
+    assert abs(cost - c2) < 1e-12 * abs(c2)
+    for i in G:
+        for s in range(2):
+            np.testing.assert_allclose(G[i][s], G2[i][s], rtol=1e-8, atol=1e-13)
+
+
 def test_adam_constants_are_float32_rounded():
     p = [np.array([1.0, -2.0], np.float64)]
     g = [np.array([0.5, 0.25], np.float64)]
