@@ -143,31 +143,71 @@ class HandDetector(object):
         if aug_modes == ['none']:
             out = base_poses / (base_cube[:, 2] / 2.)[:, None, None]
             return (out, base_com, base_cube) if retall else out
-        for i in range(n):
-            mode = aug_modes[modes[i]]
-            cube, com3D, pose = base_cube[ridxs[i]], base_com[ridxs[i]], base_poses[ridxs[i]]
+        # The reference loops over the n (= 1e6 in the scripts) samples in Python; the same arithmetic, in the same operation
+        # order and precision (float64 products rounded to the arrays' float32 where the reference rounds), is done here per
+        # augmentation mode on whole index sets.
+        f32 = numpy.float32
+        fx, fy, ux, uy, flip = float(importer.fx), float(importer.fy), float(importer.ux), float(importer.uy), bool(importer.flip_y)
+
+        def to_img(p):                      # joints3DToImg on (..., 3), DepthImporter.joint3DToImg
+            p = numpy.asarray(p, numpy.float64)
+            z = p[..., 2]
+            ok = z != 0.
+            zz = numpy.where(ok, z, 1.)
+            u = numpy.where(ok, p[..., 0] / zz * fx + ux, ux)
+            v = numpy.where(ok, (uy - p[..., 1] / zz * fy) if flip else (p[..., 1] / zz * fy + uy), uy)
+            return numpy.stack([u, v, numpy.where(ok, z, 0.)], axis=-1).astype(f32)
+
+        def to_3d(q):                       # jointsImgTo3D on (..., 3)
+            q = numpy.asarray(q, numpy.float64)
+            x = (q[..., 0] - ux) * q[..., 2] / fx
+            y = ((uy - q[..., 1]) if flip else (q[..., 1] - uy)) * q[..., 2] / fy
+            return numpy.stack([x, y, q[..., 2]], axis=-1).astype(f32)
+
+        def rot_2d(pts, center, angle):     # rotatePoints2D about per-sample centres, transformations.py:71-88
+            alpha = (angle * numpy.pi / 180.)[:, None]
+            pp0 = (pts[..., 0] - center[:, None, 0]).astype(f32)
+            pp1 = (pts[..., 1] - center[:, None, 1]).astype(f32)
+            r0 = (pp0.astype(numpy.float64) * numpy.cos(alpha) - pp1.astype(numpy.float64) * numpy.sin(alpha)).astype(f32)
+            r1 = (pp0.astype(numpy.float64) * numpy.sin(alpha) + pp1.astype(numpy.float64) * numpy.cos(alpha)).astype(f32)
+            out = pts.copy()
+            out[..., 0] = r0 + center[:, None, 0]
+            out[..., 1] = r1 + center[:, None, 1]
+            return out
+
+        dt = base_poses.dtype
+        mode_of = numpy.asarray([aug_modes[m] for m in range(len(aug_modes))])
+        mname = mode_of[modes]
+        cube_all, com_all, pose_all = base_cube[ridxs], base_com[ridxs], base_poses[ridxs]
+        for mode in sorted(set(mname.tolist())):
+            I = numpy.nonzero(mname == mode)[0]
+            cube, com3D, pose = cube_all[I], com_all[I], pose_all[I]
             if mode == 'com':
-                new_com[i], new_cube[i] = com3D + off[i], cube
-                new_poses[i] = (pose + com3D - new_com[i]) / (new_cube[i][2] / 2.)
+                nc = (com3D + off[I]).astype(dt)
+                new_com[I], new_cube[I] = nc, cube
+                new_poses[I] = (pose + com3D[:, None] - nc[:, None]) / (new_cube[I][:, 2] / 2.)[:, None, None]
             elif mode == 'rot':
-                new_com[i], new_cube[i] = com3D, cube
-                joint_2D = importer.joints3DToImg(pose + new_com[i])
-                data_2D = rotatePoints2D(joint_2D, importer.joint3DToImg(com3D)[0:2], rot[i, 0])
-                new_poses[i] = (importer.jointsImgTo3D(data_2D) - new_com[i]) / (new_cube[i][2] / 2.)
+                new_com[I], new_cube[I] = com3D, cube
+                nc = new_com[I]
+                joint_2D = to_img(pose + nc[:, None])
+                data_2D = rot_2d(joint_2D, to_img(com3D), rot[I, 0])
+                new_poses[I] = (to_3d(data_2D) - nc[:, None]) / (new_cube[I][:, 2] / 2.)[:, None, None]
             elif mode == 'sc':
-                new_com[i], new_cube[i] = com3D, cube * sc[i]
-                new_poses[i] = pose / (new_cube[i][2] / 2.)
+                new_com[I] = com3D
+                new_cube[I] = cube * sc[I].astype(f32)[:, None]          # float32 array x float64 scalar stays float32 in the reference's NumPy
+                new_poses[I] = pose / (new_cube[I][:, 2] / 2.)[:, None, None]
             elif mode == 'none':
-                new_com[i], new_cube[i] = com3D, cube
-                new_poses[i] = pose / (new_cube[i][2] / 2.)
+                new_com[I], new_cube[I] = com3D, cube
+                new_poses[I] = pose / (new_cube[I][:, 2] / 2.)[:, None, None]
             elif mode in combo or mode in combo_sc:
-                new_com[i], new_cube[i] = com3D + off[i], cube
-                p = pose + com3D - new_com[i]
+                nc = (com3D + off[I]).astype(dt)
+                new_com[I], new_cube[I] = nc, cube
+                p = pose + com3D[:, None] - new_com[I][:, None]
                 if mode in combo_sc:
-                    p = p * sc[i]
-                joint_2D = importer.joints3DToImg(p + com3D)
-                data_2D = rotatePoints2D(joint_2D, importer.joint3DToImg(new_com[i])[0:2], rot[i, 0])
-                new_poses[i] = (importer.jointsImgTo3D(data_2D) - com3D) / (new_cube[i][2] / 2.)
+                    p = p * sc[I].astype(f32)[:, None, None]
+                joint_2D = to_img(p + com3D[:, None])
+                data_2D = rot_2d(joint_2D, to_img(new_com[I]), rot[I, 0])
+                new_poses[I] = (to_3d(data_2D) - com3D[:, None]) / (new_cube[I][:, 2] / 2.)[:, None, None]
             else:
                 raise NotImplementedError()
         return (new_poses, new_com, new_cube, rot) if retall else new_poses

@@ -117,3 +117,55 @@ def test_main_script_flow(backend, family, tmp_path):
     net2.load(fn)
     net2.setDeterministic()
     np.testing.assert_allclose(net2.computeOutput(val_data), jts, rtol=0, atol=1e-6)
+
+
+def _sample_random_poses_loop(importer, rng, base_poses, base_com, base_cube, num_poses, aug_modes, sigma_com=5., sigma_sc=0.02, rot_range=180.):
+    """The reference's per-sample loop (handdetector.py:805-909) written out with the importer's scalar functions: the
+    yardstick for the vectorised HandDetector.sampleRandomPoses.  float32 arrays times float64 scalars stay float32, as in
+    the NumPy the reference ran on."""
+    from data.transformations import rotatePoints2D
+    n = int(num_poses)
+    new_poses = np.zeros((n, base_poses.shape[1], base_poses.shape[2]), dtype=base_poses.dtype)
+    modes = rng.randint(0, len(aug_modes), n)
+    ridxs = rng.randint(0, base_poses.shape[0], n)
+    off = rng.randn(n, 3) * sigma_com
+    sc = np.fabs(rng.randn(n) * sigma_sc + 1.)
+    rot = rng.uniform(-rot_range, rot_range, size=(n, 3))
+    for i in range(n):
+        mode = aug_modes[modes[i]]
+        cube, com3D, pose = base_cube[ridxs[i]], base_com[ridxs[i]], base_poses[ridxs[i]]
+        if mode == 'com':
+            nc = (com3D + off[i]).astype(np.float32)
+            new_poses[i] = (pose + com3D - nc) / (cube[2] / 2.)
+        elif mode == 'rot':
+            joint_2D = importer.joints3DToImg(pose + com3D)
+            data_2D = rotatePoints2D(joint_2D, importer.joint3DToImg(com3D)[0:2], rot[i, 0])
+            new_poses[i] = (importer.jointsImgTo3D(data_2D) - com3D) / (cube[2] / 2.)
+        elif mode == 'sc':
+            new_poses[i] = pose / ((cube * np.float32(sc[i]))[2] / 2.)
+        elif mode == 'none':
+            new_poses[i] = pose / (cube[2] / 2.)
+        else:
+            nc = (com3D + off[i]).astype(np.float32)
+            p = pose + com3D - nc
+            if 'sc' in mode:
+                p = p * np.float32(sc[i])
+            joint_2D = importer.joints3DToImg(p + com3D)
+            data_2D = rotatePoints2D(joint_2D, importer.joint3DToImg(nc)[0:2], rot[i, 0])
+            new_poses[i] = (importer.jointsImgTo3D(data_2D) - com3D) / (cube[2] / 2.)
+    return new_poses
+
+
+@pytest.mark.parametrize('flip', [False, True])
+def test_sample_random_poses_vectorised_equals_loop(flip):
+    from data.importers import ICVLImporter, NYUImporter
+    di = NYUImporter('../data/NYU/') if flip else ICVLImporter('../data/ICVL/')
+    J = 14 if flip else 16
+    cam = A.Camera.nyu() if flip else A.Camera.icvl()
+    _, coms, cubes, _, gts = A.synthetic_augment_inputs(np.random.RandomState(4), 20, cam, cube=(300., 300., 300.), joints=J)
+    cubes = (cubes * np.random.RandomState(5).uniform(0.8, 1.2, (20, 1))).astype(np.float32)
+    modes = ['com', 'rot', 'sc', 'none', 'rot+com', 'rot+com+sc']
+    got = HandDetector.sampleRandomPoses(di, np.random.RandomState(6), gts, coms, cubes, 600, modes)
+    ref = _sample_random_poses_loop(di, np.random.RandomState(6), gts, coms, cubes, 600, modes)
+    assert got.shape == ref.shape == (600, J, 3) and got.dtype == ref.dtype
+    assert np.array_equal(got, ref)
