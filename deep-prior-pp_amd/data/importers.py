@@ -1,10 +1,18 @@
 """
-Camera models of the dataset importers (API of /root/reference/src/data/importers.py:47-119, 187-210, 529-566, 756-793,
-878-914, 1187-1224): intrinsics, default crop cubes and the pinhole (un)projection that the augmentation and the
-evaluation use.  Reading the ICVL / MSRA15 / NYU files from disk (`loadSequence`) is listed under "next" in
-SURVEY.md section 8(f) and raises NotImplementedError.
+Dataset importers (API of /root/reference/src/data/importers.py:47-119, 187-420, 529-800, 878-1224): intrinsics, default
+crop cubes, the pinhole (un)projection that the augmentation and the evaluation use, and `loadSequence` for the ICVL, MSRA15
+and NYU file formats.  Where the reference crops every frame in Python (HandDetector.cropArea3D per frame), the frames of a
+sequence are cropped here in batches by the device kernels (util.handdetector.crop_frames); the per-sequence pickle cache
+keeps the reference's file naming.
 """
+import os
+import pickle
+import struct
+
 import numpy as np
+
+from data.basetypes import DepthFrame, NamedImgSequence
+from data.transformations import transformPoints2D
 
 
 class DepthImporter(object):
@@ -56,8 +64,82 @@ class DepthImporter(object):
         ret[0, 2], ret[1, 2], ret[3, 2] = self.ux, self.uy, 1.
         return ret
 
-    def loadSequence(self, *args, **kwargs):
-        raise NotImplementedError("dataset readers are scheduled after the hot path (SURVEY.md section 8(f) rank 3)")
+    def getDepthMapNV(self):
+        return 32001
+
+    # ---- shared by the loadSequence of the three datasets -------------------------------------------------------------
+    def _config(self, seqName, cube):
+        if cube is None:
+            return {'cube': self.default_cubes[seqName]}
+        assert isinstance(cube, tuple) and len(cube) == 3
+        return {'cube': cube}
+
+    def _cache_file(self, *parts):
+        return '{}/{}_cache.pkl'.format(self.cacheDir, '_'.join(str(p) for p in (self.__class__.__name__,) + parts))
+
+    def _from_cache(self, fn, Nmax, shuffle, rng):
+        if not (self.useCache and os.path.isfile(fn)):
+            return None
+        print("Loading cache data from {}".format(fn))
+        with open(fn, 'rb') as f:
+            seqName, data, config = pickle.load(f, encoding='latin1')
+        data = [DepthFrame(*d) for d in data]
+        if shuffle and rng is not None:
+            print("Shuffling")
+            rng.shuffle(data)
+        return NamedImgSequence(seqName, data if np.isinf(Nmax) else data[0:int(Nmax)], config)
+
+    def _to_cache(self, fn, seqName, data, config):
+        if not self.useCache:
+            return
+        print("Save cache data to {}".format(fn))
+        os.makedirs(os.path.dirname(fn) or '.', exist_ok=True)
+        with open(fn, 'wb') as f:
+            pickle.dump((seqName, [tuple(d) for d in data], config), f, protocol=2)
+
+    def _crop_records(self, records, config, docom, side, chunk=256):
+        """records: (dpt, gtorig, gt3Dorig, fileName, subSeqName) of the frames that survived the readers' checks.  Crops
+        them like `hd.cropArea3D(com=gtorig[crop_joint_idx], size=cube, docom=docom)` does (importers.py:382-396) -- in
+        batches on the device unless a refinement net has to look at every crop -- and builds the DepthFrames."""
+        from util.handdetector import HandDetector, crop_frames
+        data = []
+        cube = np.asarray(config['cube'], np.float32)
+        for i0 in range(0, len(records), chunk):
+            part = records[i0:i0 + chunk]
+            if docom and self.refineNet is not None:
+                crops, Ms, coms = [], [], []
+                for (dpt, gtorig, _, _, _) in part:
+                    hd = HandDetector(dpt, self.fx, self.fy, refineNet=self.refineNet, importer=self)
+                    c, M, com = hd.cropArea3D(com=gtorig[self.crop_joint_idx], size=config['cube'], docom=True)
+                    crops.append(c), Ms.append(M), coms.append(com)
+            else:
+                frames = np.stack([r[0] for r in part]).astype(np.float32)
+                c0 = np.stack([r[1][self.crop_joint_idx] for r in part]).astype(np.float32)
+                crops, Ms, coms = crop_frames(frames, c0, np.tile(cube, (len(part), 1)), self.fx, self.fy, 128, normalize=False,
+                                              docom=docom, return_com=True)
+                Ms = Ms.astype(np.float64)
+            for (dpt, gtorig, gt3Dorig, fileName, subSeqName), c, M, com in zip(part, crops, Ms, coms):
+                com3D = self.jointImgTo3D(com)
+                gt3Dcrop = gt3Dorig - com3D                              # normalize to com
+                gtcrop = transformPoints2D(gtorig, M)
+                data.append(DepthFrame(np.asarray(c, np.float32), gtorig, gtcrop, M, gt3Dorig, gt3Dcrop, com3D, fileName, subSeqName,
+                                       side, {}))
+        return data
+
+    @staticmethod
+    def _has_content(dpt, tol=1.):
+        """HandDetector.checkImage on the detector-preprocessed frame (handdetector.py:53-68, 110-120)."""
+        d = np.asarray(dpt, np.float32)
+        hi, lo = min(1500, d.max()), max(10, d.min())
+        d = np.where((d > hi) | (d < lo), np.float32(0), d)
+        return not (np.std(d) < tol)
+
+    def _finish(self, seqName, data, config, cache, shuffle, rng):
+        self._to_cache(cache, seqName, data, config)
+        if shuffle and rng is not None:
+            print("Shuffling")
+            rng.shuffle(data)
+        return NamedImgSequence(seqName, data, config)
 
 
 class ICVLImporter(DepthImporter):
@@ -70,6 +152,60 @@ class ICVLImporter(DepthImporter):
         self.refineNet = refineNet
         self.default_cubes = {'train': (250, 250, 250), 'test_seq_1': (250, 250, 250), 'test_seq_2': (250, 250, 250)}
         self.sides = {'train': 'right', 'test_seq1': 'right', 'test_seq_2': 'right'}
+
+    def loadDepthMap(self, filename):
+        """16-bit single-channel PNG, depth in mm (importers.py:213-223)."""
+        from PIL import Image
+        img = Image.open(filename)
+        assert len(img.getbands()) == 1                     # ensure depth image
+        return np.asarray(img, np.float32)
+
+    def loadSequence(self, seqName, subSeq=None, Nmax=float('inf'), shuffle=False, rng=None, docom=False, cube=None):
+        """<basepath>/<seqName>.txt: one line per frame, `relative/path.png u v d` x 16 joints; frames under <basepath>/Depth/
+        (importers.py:232-420)."""
+        from util.handdetector import HandDetector
+        if (subSeq is not None) and (not isinstance(subSeq, list)):
+            raise TypeError("subSeq must be None or list")
+        config = self._config(seqName, cube)
+        mode = HandDetector.detectionModeToString(docom, self.refineNet is not None)
+        cache = self._cache_file(seqName, self.hand, mode, config['cube'][0]) if subSeq is None else \
+            self._cache_file(seqName, ''.join(subSeq), self.hand, mode, config['cube'][0])
+        cached = self._from_cache(cache, Nmax, shuffle, rng)
+        if cached is not None:
+            return cached
+        if self.hand is not None and self.hand != self.sides[seqName]:
+            raise NotImplementedError()
+        objdir = '{}/Depth/'.format(self.basepath)
+        records = []
+        with open('{}/{}.txt'.format(self.basepath, seqName)) as inputfile:
+            for line in inputfile:
+                if len(records) >= Nmax:
+                    break
+                part = line.split(' ')
+                subSeqName = ''
+                if subSeq is not None:
+                    p = part[0].split('/')
+                    long_name = len(p[0]) > 6               # frames of the un-rotated sequence "0" live in long-named folders
+                    if (long_name and '0' not in subSeq) or (not long_name and p[0] not in subSeq):
+                        continue
+                    subSeqName = p[0] if not long_name else '0'
+                dptFileName = '{}/{}'.format(objdir, part[0])
+                if not os.path.isfile(dptFileName):
+                    print("File {} does not exist!".format(dptFileName))
+                    continue
+                dpt = self.loadDepthMap(dptFileName)
+                gtorig = np.zeros((self.numJoints, 3), np.float32)
+                for joint in range(self.numJoints):
+                    for xyz in range(0, 3):
+                        gtorig[joint, xyz] = part[joint * 3 + xyz + 1]
+                gt3Dorig = self.jointsImgTo3D(gtorig)        # normalized joints in 3D coordinates
+                if not self._has_content(dpt, 1):
+                    print("Skipping image {}, no content".format(dptFileName))
+                    continue
+                records.append((dpt, gtorig, gt3Dorig, dptFileName, subSeqName))
+        print("Loaded {} samples.".format(len(records)))
+        data = self._crop_records(records, config, docom, self.sides[seqName])
+        return self._finish(seqName, data, config, cache, shuffle, rng)
 
 
 class MSRA15Importer(DepthImporter):
@@ -85,6 +221,70 @@ class MSRA15Importer(DepthImporter):
         self.default_cubes = {'P0': (200, 200, 200), 'P1': (200, 200, 200), 'P2': (200, 200, 200), 'P3': (180, 180, 180),
                               'P4': (180, 180, 180), 'P5': (180, 180, 180), 'P6': (170, 170, 170), 'P7': (160, 160, 160),
                               'P8': (150, 150, 150)}
+        self.sides = {'P%d' % i: 'right' for i in range(9)}
+
+    def loadDepthMap(self, filename):
+        """Binary patch: int32 width, height, left, top, right, bottom, then float32 depth of the [top:bottom, left:right]
+        window (importers.py:570-587)."""
+        with open(filename, 'rb') as f:
+            width, height, left, top, right, bottom = struct.unpack('6i', f.read(24))
+            patch = np.fromfile(f, dtype='float32', sep="")
+        imgdata = np.zeros((height, width), dtype='float32')
+        imgdata[top:bottom, left:right] = patch.reshape([bottom - top, right - left])
+        return imgdata
+
+    def loadSequence(self, seqName, subSeq=None, Nmax=float('inf'), shuffle=False, rng=None, docom=False, cube=None):
+        """<basepath>/<subject>/<gesture>/joint.txt (count, then 21 x (x y z) per line, z negated) next to
+        NNNNNN_depth.bin (importers.py:596-700)."""
+        from util.handdetector import HandDetector
+        if (subSeq is not None) and (not isinstance(subSeq, list)):
+            raise TypeError("subSeq must be None or list")
+        config = self._config(seqName, cube)
+        mode = HandDetector.detectionModeToString(docom, self.refineNet is not None)
+        cache = self._cache_file(seqName, self.hand, mode, config['cube'][0]) if subSeq is None else \
+            self._cache_file(seqName, self.hand, ''.join(subSeq), mode, config['cube'][0])
+        cached = self._from_cache(cache, Nmax, shuffle, rng)
+        if cached is not None:
+            return cached
+        objdir = '{}/{}/'.format(self.basepath, seqName)
+        subdirs = sorted([name for name in os.listdir(objdir) if os.path.isdir(os.path.join(objdir, name))])
+        records = []
+        for subdir in subdirs:
+            subSeqName = ''
+            if subSeq is not None:
+                if subdir not in subSeq:
+                    continue
+                subSeqName = subdir
+            with open('{}/{}/joint.txt'.format(objdir, subdir)) as inputfile:
+                nImgs = int(inputfile.readline())
+                for i in range(nImgs):
+                    if len(records) >= Nmax:
+                        break
+                    part = inputfile.readline().split(' ')
+                    dptFileName = '{}/{}/{}_depth.bin'.format(objdir, subdir, str(i).zfill(6))
+                    if not os.path.isfile(dptFileName):
+                        print("File {} does not exist!".format(dptFileName))
+                        continue
+                    dpt = self.loadDepthMap(dptFileName)
+                    gt3Dorig = np.zeros((self.numJoints, 3), np.float32)
+                    for joint in range(gt3Dorig.shape[0]):
+                        for xyz in range(0, 3):
+                            gt3Dorig[joint, xyz] = part[joint * 3 + xyz]
+                    gt3Dorig[:, 2] *= (-1.)                  # the files hold -z
+                    gtorig = self.joints3DToImg(gt3Dorig)
+                    if self.hand is not None and self.hand != self.sides[seqName]:
+                        gtorig[:, 0] -= dpt.shape[1] / 2.
+                        gtorig[:, 0] *= (-1)
+                        gtorig[:, 0] += dpt.shape[1] / 2.
+                        gt3Dorig = self.jointsImgTo3D(gtorig)
+                        dpt = dpt[:, ::-1]
+                    if not self._has_content(dpt, 1.):
+                        print("Skipping image {}, no content".format(dptFileName))
+                        continue
+                    records.append((dpt, gtorig, gt3Dorig, dptFileName, subSeqName))
+        print("Loaded {} samples.".format(len(records)))
+        data = self._crop_records(records, config, docom, self.sides[seqName])
+        return self._finish(seqName, data, config, cache, shuffle, rng)
 
 
 class NYUImporter(DepthImporter):
@@ -106,3 +306,50 @@ class NYUImporter(DepthImporter):
         self.sides = {'train': 'right', 'test_1': 'right', 'test_2': 'right', 'test': 'right', 'train_synth': 'right',
                       'test_synth_1': 'right', 'test_synth_2': 'right', 'test_synth': 'right'}
         self.crop_joint_idx = 13 if not allJoints else 32
+
+    def loadDepthMap(self, filename):
+        """RGB PNG with the depth in the green (high byte) and blue (low byte) channels (importers.py:917-931)."""
+        from PIL import Image
+        img = Image.open(filename)
+        assert len(img.getbands()) == 3
+        _, g, b = img.split()
+        g, b = np.asarray(g, np.int32), np.asarray(b, np.int32)
+        return np.asarray(np.bitwise_or(np.left_shift(g, 8), b), np.float32)
+
+    def loadSequence(self, seqName, Nmax=float('inf'), shuffle=False, rng=None, docom=False, cube=None):
+        """<basepath>/<seqName>/joint_data.mat (joint_xyz, joint_uvd of camera 1) and depth_1_NNNNNNN.png
+        (importers.py:943-1064); the 14 evaluation joints unless allJoints."""
+        import scipy.io
+        from util.handdetector import HandDetector
+        config = self._config(seqName, cube)
+        cache = self._cache_file(seqName, self.hand, self.allJoints, HandDetector.detectionModeToString(docom, self.refineNet is not None),
+                                 config['cube'][0])
+        cached = self._from_cache(cache, Nmax, shuffle, rng)
+        if cached is not None:
+            return cached
+        if self.hand is not None and self.hand != self.sides[seqName]:
+            raise NotImplementedError()
+        objdir = '{}/{}/'.format(self.basepath, seqName)
+        mat = scipy.io.loadmat('{}/{}/joint_data.mat'.format(self.basepath, seqName))
+        joints3D = mat['joint_xyz'][0]
+        joints2D = mat['joint_uvd'][0]
+        eval_idxs = np.arange(36) if self.allJoints else np.asarray(self.restrictedJointsEval)
+        self.numJoints = len(eval_idxs)
+        records = []
+        for line in range(joints3D.shape[0]):
+            if len(records) >= Nmax:
+                break
+            dptFileName = '{0:s}/depth_1_{1:07d}.png'.format(objdir, line + 1)
+            if not os.path.isfile(dptFileName):
+                print("File {} does not exist!".format(dptFileName))
+                continue
+            dpt = self.loadDepthMap(dptFileName)
+            gtorig = np.asarray(joints2D[line, eval_idxs, 0:3], np.float32)     # joints in image coordinates
+            gt3Dorig = np.asarray(joints3D[line, eval_idxs, 0:3], np.float32)   # normalized joints in 3D coordinates
+            if not self._has_content(dpt, 1):
+                print("Skipping image {}, no content".format(dptFileName))
+                continue
+            records.append((dpt, gtorig, gt3Dorig, dptFileName, ''))
+        print("Loaded {} samples.".format(len(records)))
+        data = self._crop_records(records, config, docom, self.sides[seqName])
+        return self._finish(seqName, data, config, cache, shuffle, rng)

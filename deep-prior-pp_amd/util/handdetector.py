@@ -30,6 +30,21 @@ class HandDetector(object):
         self.importer = importer
         self.resizeMethod = self.RESIZE_CV2_NN
 
+    @staticmethod
+    def detectionModeToString(com, refineNet):
+        """Tag of the cache files (handdetector.py:72-89)."""
+        if com is False and refineNet is False:
+            return 'gt'
+        if com is True and refineNet is False:
+            return 'com'
+        if com is True and refineNet is True:
+            return 'comref'
+        raise NotImplementedError("com {}, refineNet {}".format(com, refineNet))
+
+    def checkImage(self, tol):
+        """Is there some content in the image (handdetector.py:110-120)."""
+        return not (numpy.std(self.dpt) < tol)
+
     # ---- crop geometry (host, a handful of flops) -----------------------------------------------------------
     def comToBounds(self, com, size):
         """Project the metric cube around the CoM back to pixel bounds (handdetector.py:204-226)."""

@@ -72,7 +72,8 @@ class SyntheticImporter(ICVLImporter):
         crops, Ms = crop_frames(frames, coms, cubes, self.fx, self.fy, 128, normalize=False)     # cropArea3D on the device
         data = []
         for i in range(Nmax):
-            data.append(DepthFrame(crops[i], gt3Dorig[i], None, Ms[i], gt3Dorig[i], gt3Dcrop[i], coms[i], '', seqName, 'right', {}))
+            # like the reference's importers (importers.py:388-396): .com is the crop centre in metric 3-D
+            data.append(DepthFrame(crops[i], gt3Dorig[i], None, Ms[i], gt3Dorig[i], gt3Dcrop[i], com3D[i], '', seqName, 'right', {}))
         if shuffle and rng is not None:
             rng.shuffle(data)
         return NamedImgSequence(seqName, data, {'cube': cube})
@@ -106,8 +107,8 @@ def main():
 
     # convert data to embedding
     pca = PCA(n_components=30)
-    pca.fit(HandDetector.sampleRandomPoses(di, rng, train_gt3Dcrop, numpy.asarray([di.jointImgTo3D(c) for c in train_data_com]),
-                                           train_data_cube, 20000, aug_modes).reshape((-1, train_gt3D.shape[1] * 3)))
+    pca.fit(HandDetector.sampleRandomPoses(di, rng, train_gt3Dcrop, train_data_com, train_data_cube, 20000,
+                                           aug_modes).reshape((-1, train_gt3D.shape[1] * 3)))
     train_gt3D_embed = pca.transform(train_gt3D.reshape((train_gt3D.shape[0], -1))).astype('float32')
     val_gt3D_embed = pca.transform(val_gt3D.reshape((val_gt3D.shape[0], -1))).astype('float32')
 
@@ -161,9 +162,9 @@ def main():
     print("Testing ...")
     gt3D = [j.gt3Dorig for j in Seq2.data]
     jts = poseNet.computeOutput(val_data)
-    joints = [jts[i].reshape((-1, 3)) * (Seq2.config['cube'][2] / 2.) + di.jointImgTo3D(Seq2.data[i].com) for i in range(val_data.shape[0])]
+    joints = [jts[i].reshape((-1, 3)) * (Seq2.config['cube'][2] / 2.) + Seq2.data[i].com for i in range(val_data.shape[0])]
     hpe = HandposeEvaluation(gt3D, joints)
-    mean_pose_err = HandposeEvaluation(gt3D, [di.mean_pose + di.jointImgTo3D(s.com) for s in Seq2.data]).getMeanError()
+    mean_pose_err = HandposeEvaluation(gt3D, [di.mean_pose + s.com for s in Seq2.data]).getMeanError()
     print("Mean error: {:.2f}mm, max error: {:.2f}mm  (predicting the mean pose: {:.2f}mm)".format(hpe.getMeanError(), hpe.getMaxError(), mean_pose_err))
 
 

@@ -1,0 +1,127 @@
+"""Dataset readers: ICVL / NYU / MSRA15 `loadSequence` on tiny datasets written in the original file
+formats (16-bit PNG + label lines; RGB-packed PNG + joint_data.mat; binary depth patches + joint.txt), cropped by the device
+kernels and compared with the oracle's restatement of what the reference does per frame (importers.py:232-420, 596-700,
+943-1064)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import scipy.io
+from PIL import Image
+
+from data.dataset import Dataset
+from data.importers import ICVLImporter, MSRA15Importer, NYUImporter
+from hipdp import runtime as R
+from oracle import augment as A
+from tests.backends import BACKENDS, get_runtime
+
+
+def _frames_and_joints(cam, n, J, H, W, cube, crop_idx, seed):
+    rng = np.random.RandomState(seed)
+    frames, coms = A.synthetic_frames(rng, n, cam, H, W, cube)
+    frames = np.round(frames)                                    # the file formats hold integer millimetres (ICVL / NYU)
+    com3d = np.stack([cam.jointImgTo3D(c) for c in coms])
+    gt3D = com3d[:, None, :] + rng.normal(0, 30., (n, J, 3)).astype(np.float32)
+    gt3D[:, crop_idx] = com3d
+    gtuvd = np.stack([np.stack([cam.joint3DToImg(j) for j in g]) for g in gt3D]).astype(np.float32)
+    return frames.astype(np.float32), gt3D.astype(np.float32), gtuvd
+
+
+def _check(seq, imp, cam, frames, gtuvd, gt3D, cube, names=None):
+    assert len(seq.data) == len(frames) and tuple(seq.config['cube']) == tuple(cube)
+    fx, fy = abs(cam.fx), abs(cam.fy)
+    for i, fr in enumerate(seq.data):
+        d, _, _ = A.detector_preprocess(frames[i])
+        ref, M, _ = A.crop_area_3d(d, fr.gtorig[imp.crop_joint_idx], cube, fx, fy)      # the centre as parsed from the label file
+        assert np.array_equal(fr.dpt, ref) and fr.dpt.dtype == np.float32
+        np.testing.assert_allclose(fr.T, M, rtol=1e-6, atol=1e-6)
+        com3D = imp.jointImgTo3D(fr.gtorig[imp.crop_joint_idx])
+        np.testing.assert_allclose(fr.com, com3D, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(fr.gtorig, gtuvd[i], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(fr.gt3Dorig, gt3D[i], rtol=0, atol=2e-2)
+        np.testing.assert_allclose(fr.gt3Dcrop, fr.gt3Dorig - fr.com, rtol=0, atol=1e-5)
+        uv1 = np.concatenate([fr.gtorig[:, :2], np.ones((fr.gtorig.shape[0], 1), np.float32)], axis=1)
+        np.testing.assert_allclose(fr.gtcrop[:, :2], (uv1 @ np.asarray(fr.T).T)[:, :2], rtol=0, atol=1e-3)
+    stack, labels = Dataset([seq]).imgStackDepthOnly(seq.name)
+    assert stack.shape == (len(frames), 1, 128, 128) and stack.min() >= -1.0 and stack.max() <= 1.0 + 1e-6
+    np.testing.assert_allclose(labels, np.stack([f.gt3Dcrop for f in seq.data]) / (cube[2] / 2.), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_icvl_reader(backend, tmp_path):
+    R.set_default_runtime(get_runtime(backend))
+    cam, cube = A.Camera.icvl(), (250, 250, 250)
+    frames, gt3D, gtuvd = _frames_and_joints(cam, 5, 16, 240, 320, (250., 250., 250.), 0, 1)
+    base = str(tmp_path / 'ICVL')
+    folders = ['201403121135', '201403121135', '45', '45', '22-5']
+    lines = []
+    for i in range(5):
+        os.makedirs(os.path.join(base, 'Depth', folders[i]), exist_ok=True)
+        rel = '{}/image_{:04d}.png'.format(folders[i], i)
+        Image.fromarray(frames[i].astype(np.uint16)).save(os.path.join(base, 'Depth', rel))
+        lines.append(rel + ' ' + ' '.join('%.4f' % v for v in gtuvd[i].reshape(-1)) + ' \n')
+    lines.insert(2, 'missing/none.png ' + ' '.join(['1.0'] * 48) + ' \n')          # a listed file that does not exist is skipped
+    with open(os.path.join(base, 'train.txt'), 'w') as f:
+        f.writelines(lines)
+    imp = ICVLImporter(base, useCache=True, cacheDir=str(tmp_path / 'cache'))
+    seq = imp.loadSequence('train')
+    _check(seq, imp, cam, frames, gtuvd, gt3D, cube)
+    assert [os.path.basename(f.fileName) for f in seq.data] == ['image_%04d.png' % i for i in range(5)]
+    # second call is served from the pickle cache (same content), Nmax and shuffle apply afterwards
+    seq2 = imp.loadSequence('train', Nmax=3, shuffle=True, rng=np.random.RandomState(0))
+    assert len(seq2.data) == 3 and os.path.isfile(str(tmp_path / 'cache' / 'ICVLImporter_train_None_gt_250_cache.pkl'))
+    # sub-sequences: '0' = the long-named (un-rotated) folders
+    imp2 = ICVLImporter(base, useCache=False)
+    assert [f.subSeqName for f in imp2.loadSequence('train', subSeq=['0']).data] == ['0', '0']
+    assert [f.subSeqName for f in imp2.loadSequence('train', subSeq=['45', '22-5']).data] == ['45', '45', '22-5']
+    with pytest.raises(TypeError):
+        imp2.loadSequence('train', subSeq='45')
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_nyu_reader(backend, tmp_path):
+    R.set_default_runtime(get_runtime(backend))
+    cam, cube = A.Camera.nyu(), (300, 300, 300)
+    n = 3
+    frames, gt3D14, gtuvd14 = _frames_and_joints(cam, n, 14, 480, 640, (300., 300., 300.), 13, 2)
+    imp = NYUImporter(str(tmp_path / 'NYU'), useCache=False)
+    xyz, uvd = np.zeros((1, n, 36, 3), np.float32), np.zeros((1, n, 36, 3), np.float32)
+    xyz[0][:, imp.restrictedJointsEval], uvd[0][:, imp.restrictedJointsEval] = gt3D14, gtuvd14
+    d = os.path.join(str(tmp_path / 'NYU'), 'train')
+    os.makedirs(d)
+    scipy.io.savemat(os.path.join(d, 'joint_data.mat'), {'joint_xyz': xyz, 'joint_uvd': uvd})
+    for i in range(n):
+        v = frames[i].astype(np.int32)
+        rgb = np.stack([np.zeros_like(v), v >> 8, v & 255], axis=2).astype(np.uint8)
+        Image.fromarray(rgb).save(os.path.join(d, 'depth_1_%07d.png' % (i + 1)))
+    seq = imp.loadSequence('train', docom=False)
+    assert imp.numJoints == 14
+    _check(seq, imp, cam, frames, gtuvd14, gt3D14, cube)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_msra_reader(backend, tmp_path):
+    R.set_default_runtime(get_runtime(backend))
+    cam, cube = A.Camera.msra(), (200, 200, 200)
+    n = 4
+    frames, gt3D, gtuvd = _frames_and_joints(cam, n, 21, 240, 320, (200., 200., 200.), 5, 3)
+    base = str(tmp_path / 'MSRA')
+    for g, idx in (('1', [0, 1]), ('IP', [2, 3])):
+        d = os.path.join(base, 'P0', g)
+        os.makedirs(d)
+        with open(os.path.join(d, 'joint.txt'), 'w') as f:
+            f.write('%d\n' % len(idx))
+            for k, i in enumerate(idx):
+                j = gt3D[i].copy()
+                j[:, 2] *= -1.                                   # the files hold -z
+                f.write(' '.join('%.4f' % v for v in j.reshape(-1)) + '\n')
+                ys, xs = np.nonzero(frames[i])
+                top, bottom, left, right = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+                with open(os.path.join(d, '%06d_depth.bin' % k), 'wb') as fb:
+                    fb.write(struct.pack('6i', 320, 240, left, top, right, bottom))
+                    frames[i][top:bottom, left:right].astype(np.float32).tofile(fb)
+    imp = MSRA15Importer(base, useCache=False)
+    seq = imp.loadSequence('P0')
+    _check(seq, imp, cam, frames, gtuvd, gt3D, cube)
+    assert [f.subSeqName for f in imp.loadSequence('P0', subSeq=['IP']).data] == ['IP', 'IP']
