@@ -88,12 +88,13 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            # NO device_id here: it makes torch create the RCCL communicator eagerly, BEFORE the engine's streams exist, and
-            # the side stream then shares a hardware queue with the main stream (measured on the MI355X: the two-stream
-            # step drops from 5.16 to 6.82 ms).  Created lazily by the first collective, after TorchHipRuntime() has its
-            # streams, it does not disturb them.
-            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        backend = os.environ.get('DPP_DIST_BACKEND', backend)      # e.g. gloo: several ranks on ONE GPU to test the control flow
+        if torch.cuda.is_available():
+            # NO device_id in init_process_group: it makes torch create the RCCL communicator eagerly, BEFORE the engine's
+            # streams exist, and the side stream then shares a hardware queue with the main stream (measured on the MI355X: the
+            # two-stream step drops from 5.16 to 6.82 ms).  Created lazily by the first collective, after TorchHipRuntime() has
+            # its streams, it does not disturb them.
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
         kw = {}
         dist.init_process_group(backend=backend, **kw)
     return rank, world
