@@ -72,7 +72,7 @@ def main():
     ap.add_argument('--no-augment', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sync-bn', action='store_true', help='all-gather BatchNorm partial statistics across ranks (parity mode)')
-    ap.add_argument('--launch', choices=['auto', 'eager', 'graph'], default='auto',
+    ap.add_argument('--launch', choices=['auto', 'eager', 'graph'], default='eager',
                     help='eager = every kernel launched from Python (two concurrent HIP streams); graph = replay captured hipGraphs; auto = probe both')
     ap.add_argument('--eager', action='store_true', help='same as --launch eager')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-kernel-family time table to stderr')
