@@ -74,3 +74,33 @@ def test_poseregnet_train_forward_backward_matches_oracle(backend):
     m1 = [eng.dropout_masks[id(l)][0].get() for l in net.layers if id(l) in eng.dropout_masks]
     assert all((a != b).any() for a, b in zip(m0, m1))
     assert m0[0].shape == m0[1].shape and (m1[0] != m1[1]).any()          # the two layers use different streams
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_joint_regression_cost_and_monitors(backend):
+    """Direct joint regression (numJoints > 1): cost = mean_n mean_j sum_d (out - y)^2 (poseregnettrainer.py:97), its gradients,
+    and the validation monitor mean_n mean_j ||out - y|| (poseregnettrainer.py:127-129)."""
+    rt = get_runtime(backend)
+    B, J = 4, 14
+    net, onet, P = make(rt, 0, B, 128, J, 3)
+    rng = np.random.RandomState(10)
+    x = nets.synthetic_crops(rng, B, 128, 128, np.float32)
+    y = rng.normal(0, 0.3, (B, J * 3)).astype(np.float32)
+    loss = dict(kind='joints', numJoints=J, nDims=3)
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=loss)
+    cost, out = eng.cost_and_grads(x, y)
+    masks = {i: eng.dropout_masks[id(l)][0].get().astype(np.float64) for i, l in enumerate(net.layers) if id(l) in eng.dropout_masks}
+    c_ref, G_ref, _, out_ref = nets.cost_and_grads(onet, nets.cast_params(P, np.float64), x.astype(np.float64), y.astype(np.float64), True,
+                                                   masks, joints=(J, 3))
+    assert abs(cost - c_ref) < 1e-5 * abs(c_ref) and np.abs(out - out_ref).max() * MM < 1e-3
+    gmax = max(np.abs(G_ref[i][s]).max() for i in G_ref for s in range(2))
+    for i in G_ref:
+        for s in range(2):
+            np.testing.assert_allclose(eng.store.read_grad(net.layers[i].params[s]), G_ref[i][s], rtol=0,
+                                       atol=2e-4 * max(np.abs(G_ref[i][s]).max(), 5e-3 * gmax), err_msg='layer %d slot %d' % (i, s))
+    ev = engine.CompiledNet(net, train=False, runtime=rt, loss=loss)
+    c_eval, err = ev.evaluate(x, y)
+    o_eval, _ = nets.forward(onet, nets.cast_params(P, np.float64), x.astype(np.float64), False)
+    d = (o_eval - y).reshape(B, J, 3)
+    assert abs(c_eval - (d * d).sum(axis=2).mean(axis=1).mean()) < 1e-5 * c_eval
+    assert abs(err - np.sqrt((d * d).sum(axis=2)).mean(axis=1).mean()) < 1e-5 * err
