@@ -287,8 +287,47 @@ class HandDetector(object):
             raise NotImplementedError("Number of inputs is {}".format(self.refineNet.cfgParams.numInputs))
         return jts[0] * (size[2] / 2.)
 
+    def calculateCoM(self, dpt):
+        """Centre of mass (mean column, mean row, mean depth) of the pixels inside [minDepth, maxDepth]
+        (handdetector.py:91-108); host NumPy -- the per-crop version used by cropArea3D(docom=True) runs on the device."""
+        dc = numpy.asarray(dpt).copy()
+        dc[dc < self.minDepth] = 0
+        dc[dc > self.maxDepth] = 0
+        ys, xs = numpy.nonzero(dc > 0)
+        num = numpy.count_nonzero(dc)
+        if num == 0:
+            return numpy.array((0, 0, 0), float)
+        return numpy.array((xs.mean() * num, ys.mean() * num, dc.sum()), float) / num
+
+    def getCrop(self, dpt, xstart, xend, ystart, yend, zstart, zend, thresh_z=True, background=0):
+        """Window of the frame, zero-padded where it leaves the frame, z-thresholded (handdetector.py:260-296)."""
+        if len(dpt.shape) != 2:
+            raise NotImplementedError()
+        H, W = dpt.shape
+        cropped = dpt[max(ystart, 0):min(yend, H), max(xstart, 0):min(xend, W)].copy()
+        cropped = numpy.pad(cropped, ((abs(ystart) - max(ystart, 0), abs(yend) - min(yend, H)),
+                                      (abs(xstart) - max(xstart, 0), abs(xend) - min(xend, W))), mode='constant', constant_values=background)
+        if thresh_z is True:
+            msk1 = numpy.logical_and(cropped < zstart, cropped != 0)
+            msk2 = numpy.logical_and(cropped > zend, cropped != 0)
+            cropped[msk1] = zstart
+            cropped[msk2] = 0.
+        return cropped
+
+    def refineCoMIterative(self, com, num_iter, size=(250, 250, 250)):
+        """Re-centre the cube on the centre of mass of its own content, num_iter times (handdetector.py:540-558)."""
+        for _ in range(num_iter):
+            xstart, xend, ystart, yend, zstart, zend = self.comToBounds(com, size)
+            cropped = self.getCrop(self.dpt, xstart, xend, ystart, yend, zstart, zend)
+            com = self.calculateCoM(cropped)
+            if numpy.allclose(com, 0.):
+                com[2] = cropped[cropped.shape[0] // 2, cropped.shape[1] // 2]
+            com[0] += max(xstart, 0)
+            com[1] += max(ystart, 0)
+        return com
+
     def detect(self, *args, **kwargs):
-        raise NotImplementedError("hand detection / tracking is a 'next' row of SURVEY.md section 8(f)")
+        raise NotImplementedError("hand detection / tracking (OpenCV contour analysis) is not provided (DESIGN.md section 8)")
 
     track = detect
 

@@ -168,3 +168,19 @@ def test_crop_area_3d_docom(backend):
     crop, M, c = hd.cropArea3D(com=coms[1], size=cube, dsize=(128, 128), docom=True)
     np.testing.assert_allclose(c, com2[1], rtol=0, atol=1e-6)
     assert np.array_equal(crop, crops[1])
+
+
+def test_host_com_helpers_match_oracle():
+    """HandDetector.calculateCoM / getCrop / refineCoMIterative (host NumPy, handdetector.py:91-108, 260-296, 540-558)."""
+    from util.handdetector import HandDetector
+    cam = A.Camera.icvl()
+    frames, coms = A.synthetic_frames(np.random.RandomState(21), 3, cam, 240, 320, (250., 250., 250.))
+    for i in range(3):
+        hd = HandDetector(frames[i].copy(), abs(cam.fx), abs(cam.fy))
+        d, mn, mx = A.detector_preprocess(frames[i])
+        assert hd.minDepth == mn and hd.maxDepth == mx and np.array_equal(hd.dpt, d)
+        np.testing.assert_allclose(hd.calculateCoM(hd.dpt), A.calculate_com(d, mn, mx), rtol=1e-6)
+        b = A.com_to_bounds(coms[i], (250., 250., 250.), abs(cam.fx), abs(cam.fy))
+        assert np.array_equal(hd.getCrop(hd.dpt, *b), A.get_crop(d, *b))
+        c5 = hd.refineCoMIterative(coms[i].astype(float), 5, (250., 250., 250.))
+        assert np.isfinite(c5).all() and abs(c5[2] - coms[i][2]) < 125.
