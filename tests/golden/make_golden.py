@@ -16,6 +16,11 @@ What the reference executes here, and what it pins:
                    (un)projections (data/importers.py:80-119, 756-793, 1187-1224) and
                    HandDetector.comToBounds (util/handdetector.py:204-226) on seeded inputs.
   chunks.json      util/helpers.py chunks() as used by NetTrainer.chunksForMP (nettrainer.py:726-744).
+  crop.npz         HandDetector.__init__ depth-range preprocessing, comToBounds, getCrop, calculateCoM and
+                   refineCoMIterative (util/handdetector.py:53-130, 204-226, 260-296, 540-558) on seeded synthetic frames
+                   (NumPy / SciPy only; the cv2 resize of cropArea3D cannot run here).
+  poses.npz        HandDetector.sampleRandomPoses (util/handdetector.py:805-909) with the ICVL and NYU importers.
+  shapes.json also holds the reference's real ScaleNetParams (net/scalenet.py:33-127).
 
 Python-2-only modules (netbase.py, handdetector.py, importers.py use print statements / cPickle) are
 converted IN MEMORY with lib2to3 and exec'd; nothing is written to disk.  `cv2`, `progressbar` and
@@ -141,8 +146,56 @@ def make_shapes():
                          inputDim=[int(v) for v in cfg.inputDim], outputDim=[int(v) for v in cfg.outputDim])
         # (NetBaseParams.getMemoryRequirement raises for nets with dropout in the reference itself:
         #  DropoutLayerParams has no getMemoryRequirement, net/netbase.py:65-73)
+    from net.scalenet import ScaleNetParams
+    for name, kw in (('scalenet_t1', dict(type=1, numJoints=1, nDims=3)),
+                     ('scalenet_t1_96_b8', dict(type=1, numJoints=1, nDims=3, wIn=96, hIn=96, batchSize=8))):
+        cfg = ScaleNetParams(**kw)
+        out[name] = dict(args=kw, layers=[describe(p) for p in cfg.layers], inputDim=[[int(v) for v in d] for d in cfg.inputDim],
+                         outputDim=[int(v) for v in cfg.outputDim])
     json.dump(out, open(os.path.join(HERE, 'shapes.json'), 'w'), indent=0, sort_keys=True)
     return out
+
+
+def make_crop_and_poses():
+    """Functions of the reference's HandDetector that are NumPy / SciPy only, on the oracle's seeded synthetic frames."""
+    from oracle import augment as A
+    hd_mod = sys.modules.get('util.handdetector') or load_py2_module('util.handdetector', 'util/handdetector.py')
+    imp = sys.modules.get('data.importers') or load_py2_module('data.importers', 'data/importers.py')
+    d = {}
+    cam = A.Camera.icvl()
+    frames, coms = A.synthetic_frames(numpy.random.RandomState(77), 4, cam, 120, 160, (250., 250., 250.))
+    d['frames'], d['coms'] = frames, coms
+    pre, rng_, nd, bounds, crops, com_full, com_crop, com_it = [], [], [], [], [], [], [], []
+    for i in range(4):
+        hd = hd_mod.HandDetector(frames[i].copy(), 241.42, 241.42)
+        pre.append(hd.dpt.copy())
+        rng_.append((hd.minDepth, hd.maxDepth))
+        nd.append(0.)       # getNDValue needs the scipy.stats.mode of 2014 (returns a scalar today): not taken from the reference
+        b = hd.comToBounds(coms[i], (250., 250., 250.))
+        bounds.append(b)
+        c = hd.getCrop(hd.dpt, *b)
+        crops.append(numpy.asarray(c.shape + (0,), 'float64'))          # ragged: keep shape, then the flat data
+        d['crop_%d' % i] = c
+        com_full.append(hd.calculateCoM(hd.dpt))
+        com_crop.append(hd.calculateCoM(c))
+        com_it.append(hd.refineCoMIterative(coms[i].astype('float64'), 3, (250., 250., 250.)))
+    d['pre'], d['range'], d['nd'] = numpy.stack(pre), numpy.asarray(rng_, 'float64'), numpy.asarray(nd, 'float64')
+    d['bounds'] = numpy.asarray(bounds, 'float64')
+    d['com_full'], d['com_crop'], d['com_it'] = numpy.stack(com_full), numpy.stack(com_crop), numpy.stack(com_it)
+    numpy.savez_compressed(os.path.join(HERE, 'crop.npz'), **d)
+
+    p = {}
+    for nm, cls, J, args in (('icvl', imp.ICVLImporter, 16, (241.42, 241.42, 160., 120.)), ('nyu', imp.NYUImporter, 14, (588.03, 587.07, 320., 240.))):
+        o = cls.__new__(cls)
+        imp.DepthImporter.__init__(o, *args)
+        camx = A.Camera.icvl() if nm == 'icvl' else A.Camera.nyu()
+        _, c3, cubes, _, gts = A.synthetic_augment_inputs(numpy.random.RandomState(5), 12, camx, cube=(250., 250., 250.), joints=J)
+        p['%s_com' % nm], p['%s_cube' % nm], p['%s_gt' % nm] = c3, cubes, gts
+        for tag, modes in (('main', ['com', 'rot', 'none']), ('all', ['com', 'rot', 'sc', 'none', 'rot+com', 'rot+com+sc'])):
+            out = hd_mod.HandDetector.sampleRandomPoses(o, numpy.random.RandomState(9), gts, c3, cubes, 300, modes)
+            p['%s_%s' % (nm, tag)] = out
+    numpy.savez_compressed(os.path.join(HERE, 'poses.npz'), **p)
+    return d, p
 
 
 def make_geometry():
@@ -207,3 +260,5 @@ if __name__ == '__main__':
     g = make_geometry()
     print('geometry:', sorted(g.keys()))
     print('chunks:', len(make_chunks()))
+    c, p = make_crop_and_poses()
+    print('crop:', sorted(c.keys())[:6], '... poses:', sorted(p.keys()))

@@ -46,6 +46,24 @@ def test_poseregnet_layers_match_reference_params(shapes, name):
     assert list(net['out_dim']) == g['outputDim']
 
 
+@pytest.mark.parametrize('name', ['scalenet_t1', 'scalenet_t1_96_b8'])
+def test_scalenet_layers_match_reference_params(shapes, name):
+    """The reference's real ScaleNetParams (net/scalenet.py:33-127) against the oracle's and the product's layer lists."""
+    from net.scalenet import ScaleNetParams
+    g = shapes[name]
+    net = nets.build_scalenet(**g['args'])
+    kinds = {'ConvPoolLayerParams': 'convpool', 'HiddenLayerParams': 'fc', 'DropoutLayerParams': 'dropout'}
+    assert [l['kind'] for l in net['layers']] == [kinds[r['cls']] for r in g['layers']]
+    cfg = ScaleNetParams(**g['args'])
+    assert [list(d) for d in cfg.inputDim] == g['inputDim'] == [list(d) for d in net['in_dim']]
+    for l, r, p in zip(net['layers'], g['layers'], cfg.layers):
+        assert list(l['out_dim']) == r['outputDim'] == list(p.outputDim) and list(l['in_dim']) == r['inputDim'] == list(p.inputDim)
+        if l['kind'] == 'convpool':
+            assert list(l['pool']) == r['poolsize'] == list(p.poolsize) and r['border_mode'] == l['border']
+            assert r['filter_shape'] == list(p.filter_shape)
+    assert list(net['out_dim']) == g['outputDim'] == list(cfg.outputDim)
+
+
 def test_param_count_matches_survey():
     net = nets.build_resnet(type=1, numJoints=14, nDims=3)
     P = nets.init_params(net, np.random.RandomState(0))
@@ -230,3 +248,62 @@ def test_warp_restatements_identity_and_shift():
     # cv2 convention: positive angle = counter-clockwise; dst(x, y) = src(128 - y, x) inside the image
     yy, xx = np.mgrid[1:128, 0:128]
     np.testing.assert_array_equal(w3[yy, xx], src[xx, 128 - yy])
+
+
+def _golden(name):
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', name))
+
+
+def test_crop_helpers_against_reference_outputs():
+    """tests/golden/crop.npz was produced by the reference's own HandDetector (util/handdetector.py:53-130, 204-226,
+    260-296, 540-558; NumPy / SciPy code that runs here): depth-range preprocessing, comToBounds, getCrop, calculateCoM,
+    refineCoMIterative -- the oracle restatement and the product's host helpers reproduce it."""
+    from oracle import augment as A
+    from util.handdetector import HandDetector
+    g = _golden('crop.npz')
+    frames, coms = g['frames'], g['coms']
+    for i in range(frames.shape[0]):
+        d, mn, mx = A.detector_preprocess(frames[i])
+        assert np.array_equal(d, g['pre'][i]) and (mn, mx) == tuple(g['range'][i])
+        b = A.com_to_bounds(coms[i], (250., 250., 250.), 241.42, 241.42)
+        # pixel bounds exactly; zstart / zend were evaluated in float32 by today's NumPy when the fixture was made (float32
+        # scalar + python float), in float64 by the NumPy of 2017 and by the restatement
+        assert tuple(b[:4]) == tuple(int(v) for v in g['bounds'][i][:4])
+        np.testing.assert_allclose(b[4:], g['bounds'][i][4:], rtol=1e-6)
+        assert np.array_equal(A.get_crop(d, *b), g['crop_%d' % i])
+        np.testing.assert_allclose(A.calculate_com(d, mn, mx), g['com_full'][i], rtol=1e-6)
+        np.testing.assert_allclose(A.calculate_com(g['crop_%d' % i], mn, mx), g['com_crop'][i], rtol=1e-6)
+        hd = HandDetector(frames[i].copy(), 241.42, 241.42)
+        assert np.array_equal(hd.dpt, g['pre'][i])
+        np.testing.assert_allclose(hd.comToBounds(coms[i], (250., 250., 250.)), g['bounds'][i], rtol=1e-6)
+        assert np.array_equal(hd.getCrop(hd.dpt, *b), g['crop_%d' % i])
+        np.testing.assert_allclose(hd.calculateCoM(hd.dpt), g['com_full'][i], rtol=1e-6)
+        np.testing.assert_allclose(hd.refineCoMIterative(coms[i].astype('float64'), 3, (250., 250., 250.)), g['com_it'][i], rtol=1e-5)
+
+
+def test_sample_random_poses_against_reference_outputs():
+    """tests/golden/poses.npz: the reference's HandDetector.sampleRandomPoses (util/handdetector.py:805-909) run here on seeded
+    inputs: same draws, same modes, same arithmetic.  Agreement is to float32 round-off, not bit for bit: the reference's
+    scalar projections (importers.py:80-119) mix float32 scalars with Python floats, which NumPy evaluated in float64 in 2017
+    and evaluates in float32 today (the fixture), while the product evaluates them in float64 throughout."""
+    from data.importers import ICVLImporter, NYUImporter
+    from util.handdetector import HandDetector
+    g = _golden('poses.npz')
+    for nm, di in (('icvl', ICVLImporter('x')), ('nyu', NYUImporter('x'))):
+        args = (g['%s_gt' % nm], g['%s_com' % nm], g['%s_cube' % nm], 300)
+        for tag, modes in (('main', ['com', 'rot', 'none']), ('all', ['com', 'rot', 'sc', 'none', 'rot+com', 'rot+com+sc'])):
+            got = HandDetector.sampleRandomPoses(di, np.random.RandomState(9), *args, modes)
+            assert got.shape == g['%s_%s' % (nm, tag)].shape and got.dtype == np.float32
+            np.testing.assert_allclose(got, g['%s_%s' % (nm, tag)], rtol=0, atol=2e-6)       # poses are O(1) normalised coordinates
+
+
+def test_pca_projection_is_sklearns():
+    """proj.transform(label) of poseregnettrainer.py:262 is scikit-learn's PCA.transform: (x - mean_) . components_^T."""
+    from oracle import augment as A
+    from sklearn.decomposition import PCA
+    rng = np.random.RandomState(3)
+    X = rng.normal(size=(500, 42)) @ rng.normal(size=(42, 42))
+    pca = PCA(n_components=30).fit(X)
+    x = rng.normal(size=(7, 42))
+    for i in range(x.shape[0]):
+        np.testing.assert_allclose(A.pca_transform(x[i], pca.mean_, pca.components_), pca.transform(x[i:i + 1]), rtol=1e-10, atol=1e-10)
