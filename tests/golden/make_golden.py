@@ -21,6 +21,7 @@ What the reference executes here, and what it pins:
                    (NumPy / SciPy only; the cv2 resize of cropArea3D cannot run here).
   poses.npz        HandDetector.sampleRandomPoses (util/handdetector.py:805-909) with the ICVL and NYU importers.
   shapes.json also holds the reference's real ScaleNetParams (net/scalenet.py:33-127).
+  trainer.json     NetTrainerParams.lr_of_ep and NetTrainer.alignData (trainer/nettrainer.py:47-72, 365-413).
 
 Python-2-only modules (netbase.py, handdetector.py, importers.py use print statements / cPickle) are
 converted IN MEMORY with lib2to3 and exec'd; nothing is written to disk.  `cv2`, `progressbar` and
@@ -254,6 +255,33 @@ def make_chunks():
     return out
 
 
+def make_trainer():
+    """NetTrainerParams.lr_of_ep and NetTrainer.alignData (trainer/nettrainer.py:47-72, 365-413): schedule and the seeded
+    padding of the last minibatch, from the reference's own code (Theano is only imported, never called)."""
+    for missing in ('sharedmem', 'psutil'):
+        if missing not in sys.modules:
+            try:
+                __import__(missing)
+            except ImportError:
+                sys.modules[missing] = types.ModuleType(missing)
+    for nm in ('net.convlayer', 'net.convpoollayer'):
+        __import__(nm)
+    mod = load_py2_module('trainer.nettrainer', 'trainer/nettrainer.py')
+    out = {}
+    p = mod.NetTrainerParams()
+    p.learning_rate = 0.001
+    out['lr_of_ep'] = [[ep, float(p.lr_of_ep(ep))] for ep in (0, 1, 1.5, 2, 3, 10, 50, 100)]
+    cases = []
+    for n, align, pad_random in ((6, 8, True), (300, 128, True), (300, 128, False), (256, 128, True), (1000, 1024, True), (5, 4, True)):
+        dummy = types.SimpleNamespace(cfgParams=types.SimpleNamespace(pad_random=pad_random, batch_size=4))
+        data = numpy.arange(n, dtype='float32').reshape(n, 1) + 1.          # sample i holds i + 1: the padding shows its source
+        padded = mod.NetTrainer.alignData(dummy, data, alignSize=align)
+        cases.append(dict(n=n, align=align, pad_random=pad_random, padded=[float(v) for v in padded[:, 0]]))
+    out['alignData'] = cases
+    json.dump(out, open(os.path.join(HERE, 'trainer.json'), 'w'))
+    return out
+
+
 if __name__ == '__main__':
     s = make_shapes()
     print('shapes:', {k: len(v['layers']) for k, v in s.items()})
@@ -262,3 +290,5 @@ if __name__ == '__main__':
     print('chunks:', len(make_chunks()))
     c, p = make_crop_and_poses()
     print('crop:', sorted(c.keys())[:6], '... poses:', sorted(p.keys()))
+    t = make_trainer()
+    print('trainer:', t['lr_of_ep'][:3], [(c['n'], c['align'], len(c['padded'])) for c in t['alignData']])

@@ -307,3 +307,21 @@ def test_pca_projection_is_sklearns():
     x = rng.normal(size=(7, 42))
     for i in range(x.shape[0]):
         np.testing.assert_allclose(A.pca_transform(x[i], pca.mean_, pca.components_), pca.transform(x[i:i + 1]), rtol=1e-10, atol=1e-10)
+
+
+def test_trainer_helpers_against_reference_outputs():
+    """tests/golden/trainer.json: the reference's NetTrainerParams.lr_of_ep and NetTrainer.alignData (trainer/nettrainer.py:47-72,
+    365-413) run here: learning-rate schedule, and the padding of the last minibatch with samples drawn by
+    RandomState(number of samples) (or by repeating the last sample)."""
+    import types
+    from trainer.nettrainer import NetTrainer, NetTrainerParams
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'trainer.json')))
+    p = NetTrainerParams()
+    p.learning_rate = 0.001
+    for ep, lr in g['lr_of_ep']:
+        assert float(p.lr_of_ep(ep)) == lr and float(L.lr_of_ep(0.001, ep)) == lr
+    for c in g['alignData']:
+        dummy = types.SimpleNamespace(cfgParams=types.SimpleNamespace(pad_random=c['pad_random'], batch_size=4))
+        data = np.arange(c['n'], dtype='float32').reshape(c['n'], 1) + 1.
+        padded = NetTrainer.alignData(dummy, data, alignSize=c['align'])
+        assert [float(v) for v in padded[:, 0]] == c['padded'], (c['n'], c['align'])
