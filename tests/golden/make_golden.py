@@ -21,6 +21,7 @@ What the reference executes here, and what it pins:
                    (NumPy / SciPy only; the cv2 resize of cropArea3D cannot run here).
   poses.npz        HandDetector.sampleRandomPoses (util/handdetector.py:805-909) with the ICVL and NYU importers.
   shapes.json also holds the reference's real ScaleNetParams (net/scalenet.py:33-127).
+  init.npz         Layer.getInitVals (net/layer.py:70-124) for the He / Xavier / sigmoid / tanh rules and the orthogonal option.
   trainer.json     NetTrainerParams.lr_of_ep and NetTrainer.alignData (trainer/nettrainer.py:47-72, 365-413).
 
 Python-2-only modules (netbase.py, handdetector.py, importers.py use print statements / cPickle) are
@@ -282,6 +283,22 @@ def make_trainer():
     return out
 
 
+def make_init():
+    """Layer.getInitVals (net/layer.py:70-124): the reference's own initialiser with a placeholder `theano.config.floatX`."""
+    sys.modules['theano'].config = types.SimpleNamespace(floatX='float32')
+    from net.layer import Layer
+    d = {}
+    for tag, shape, mode, act, method, orth in (('conv_he', (8, 1, 5, 5), 'conv', 'ReLU', 'He', False), ('conv_he_res', (64, 16, 3, 3), 'conv', None, 'He', False),
+                                                ('fc_he', (968, 64), 'fc', 'ReLU', None, False), ('fc_linear', (30, 42), 'fc', None, 'tanh', False),
+                                                ('conv_xavier', (16, 8, 3, 3), 'conv', None, 'Xavier', False), ('fc_sigmoid', (20, 10), 'fc', 'sigmoid', None, False),
+                                                ('conv_orth', (8, 4, 3, 3), 'conv', 'ReLU', 'He', True)):
+        lay = Layer(numpy.random.RandomState(23455))
+        d[tag] = lay.getInitVals(shape, mode, act_fn=act, method=method, orthogonal=orth)
+        d[tag + '_next'] = lay.rng.uniform(size=3)          # the generator state after the call
+    numpy.savez_compressed(os.path.join(HERE, 'init.npz'), **d)
+    return d
+
+
 if __name__ == '__main__':
     s = make_shapes()
     print('shapes:', {k: len(v['layers']) for k, v in s.items()})
@@ -290,5 +307,6 @@ if __name__ == '__main__':
     print('chunks:', len(make_chunks()))
     c, p = make_crop_and_poses()
     print('crop:', sorted(c.keys())[:6], '... poses:', sorted(p.keys()))
+    print('init:', sorted(make_init().keys())[:4])
     t = make_trainer()
     print('trainer:', t['lr_of_ep'][:3], [(c['n'], c['align'], len(c['padded'])) for c in t['alignData']])

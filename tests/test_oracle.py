@@ -325,3 +325,26 @@ def test_trainer_helpers_against_reference_outputs():
         data = np.arange(c['n'], dtype='float32').reshape(c['n'], 1) + 1.
         padded = NetTrainer.alignData(dummy, data, alignSize=c['align'])
         assert [float(v) for v in padded[:, 0]] == c['padded'], (c['n'], c['align'])
+
+
+def test_init_values_against_reference_outputs():
+    """tests/golden/init.npz: the reference's Layer.getInitVals (net/layer.py:70-124) -- the product's initialiser draws the
+    same numbers from the same generator, and the oracle's init_params follows the same rules."""
+    from net.layer import Layer
+    g = _golden('init.npz')
+    for tag, shape, mode, act, method, orth in (('conv_he', (8, 1, 5, 5), 'conv', 'ReLU', 'He', False), ('conv_he_res', (64, 16, 3, 3), 'conv', None, 'He', False),
+                                                ('fc_he', (968, 64), 'fc', 'ReLU', None, False), ('fc_linear', (30, 42), 'fc', None, 'tanh', False),
+                                                ('conv_xavier', (16, 8, 3, 3), 'conv', None, 'Xavier', False), ('fc_sigmoid', (20, 10), 'fc', 'sigmoid', None, False),
+                                                ('conv_orth', (8, 4, 3, 3), 'conv', 'ReLU', 'He', True)):
+        lay = Layer(np.random.RandomState(23455))
+        got = lay.getInitVals(shape, mode, act_fn=act, method=method, orthogonal=orth)
+        assert got.dtype == np.float32 and got.shape == g[tag].shape
+        if orth:
+            np.testing.assert_allclose(np.abs(got), np.abs(g[tag]), rtol=1e-4, atol=1e-6)     # SVD vectors: sign / LAPACK build
+        else:
+            assert np.array_equal(got, g[tag]), tag
+        assert np.array_equal(lay.rng.uniform(size=3), g[tag + '_next'])
+    # the oracle's net initialiser: conv-pool 1 of PoseRegNet is the first draw of RandomState(23455)
+    onet = nets.build_poseregnet(type=0, batchSize=2, numJoints=1, nDims=30)
+    P = nets.init_params(onet, np.random.RandomState(23455), np.float32)
+    assert np.array_equal(P[0][0], g['conv_he'])
