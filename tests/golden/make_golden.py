@@ -22,6 +22,7 @@ What the reference executes here, and what it pins:
   poses.npz        HandDetector.sampleRandomPoses (util/handdetector.py:805-909) with the ICVL and NYU importers.
   shapes.json also holds the reference's real ScaleNetParams (net/scalenet.py:33-127).
   init.npz         Layer.getInitVals (net/layer.py:70-124) for the He / Xavier / sigmoid / tanh rules and the orthogonal option.
+  evaluation.json  HandposeEvaluation metrics (util/handpose_evaluation.py:92-228).
   trainer.json     NetTrainerParams.lr_of_ep and NetTrainer.alignData (trainer/nettrainer.py:47-72, 365-413).
 
 Python-2-only modules (netbase.py, handdetector.py, importers.py use print statements / cPickle) are
@@ -283,6 +284,35 @@ def make_trainer():
     return out
 
 
+def make_eval():
+    """HandposeEvaluation's numeric metrics (util/handpose_evaluation.py:92-228) from the reference's own class."""
+    for m in ('vtk', 'matplotlib', 'matplotlib.pyplot', 'mpl_toolkits', 'mpl_toolkits.mplot3d', 'pylab'):
+        if m not in sys.modules:
+            try:
+                __import__(m)
+            except Exception:      # noqa: BLE001
+                sys.modules[m] = types.ModuleType(m)
+    for nm, rel in (('util.handdetector', 'util/handdetector.py'), ('data.importers', 'data/importers.py')):
+        if nm not in sys.modules:
+            load_py2_module(nm, rel)
+    mod = load_py2_module('util.handpose_evaluation', 'util/handpose_evaluation.py')
+    rng = numpy.random.RandomState(11)
+    gt = rng.normal(0, 60, (25, 14, 3))
+    jt = gt + rng.normal(0, 9, (25, 14, 3))
+    jt[3, 2] = numpy.nan                                    # the metrics are nan-aware
+    hpe = mod.HandposeEvaluation(list(gt), list(jt))
+    import scipy.stats
+    if not hasattr(scipy.stats, 'nanmedian'):
+        scipy.stats.nanmedian = numpy.nanmedian          # removed from SciPy; same definition
+    out = dict(gt=gt.tolist(), joints=jt.tolist(), mean=float(hpe.getMeanError()), std=float(hpe.getStdError()),
+               median=float(hpe.getMedianError()), max=float(hpe.getMaxError()),
+               mean_over_seq=[float(v) for v in hpe.getMeanErrorOverSeq()], max_over_seq=[float(v) for v in hpe.getMaxErrorOverSeq()],
+               joint_mean=[float(hpe.getJointMeanError(j)) for j in range(14)], joint_max=[float(hpe.getJointMaxError(j)) for j in range(14)],
+               within=[[d, int(hpe.getNumFramesWithinMaxDist(d))] for d in (10, 20, 30, 40)])
+    json.dump(out, open(os.path.join(HERE, 'evaluation.json'), 'w'))
+    return out
+
+
 def make_init():
     """Layer.getInitVals (net/layer.py:70-124): the reference's own initialiser with a placeholder `theano.config.floatX`."""
     sys.modules['theano'].config = types.SimpleNamespace(floatX='float32')
@@ -308,5 +338,7 @@ if __name__ == '__main__':
     c, p = make_crop_and_poses()
     print('crop:', sorted(c.keys())[:6], '... poses:', sorted(p.keys()))
     print('init:', sorted(make_init().keys())[:4])
+    e = make_eval()
+    print('evaluation: mean %.3f max %.3f' % (e['mean'], e['max']))
     t = make_trainer()
     print('trainer:', t['lr_of_ep'][:3], [(c['n'], c['align'], len(c['padded'])) for c in t['alignData']])

@@ -348,3 +348,23 @@ def test_init_values_against_reference_outputs():
     onet = nets.build_poseregnet(type=0, batchSize=2, numJoints=1, nDims=30)
     P = nets.init_params(onet, np.random.RandomState(23455), np.float32)
     assert np.array_equal(P[0][0], g['conv_he'])
+
+
+def test_evaluation_metrics_against_reference_outputs():
+    """tests/golden/evaluation.json: the reference's HandposeEvaluation (util/handpose_evaluation.py:92-228) on seeded joints with a
+    missing (NaN) joint."""
+    from util.handpose_evaluation import HandposeEvaluation
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'evaluation.json')))
+    gt, jt = np.asarray(g['gt']), np.asarray(g['joints'])
+    hpe = HandposeEvaluation(list(gt), list(jt))
+    r = dict(rtol=1e-12, atol=0)
+    np.testing.assert_allclose(hpe.getMeanError(), g['mean'], **r)
+    np.testing.assert_allclose(hpe.getStdError(), g['std'], **r)
+    np.testing.assert_allclose(hpe.getMedianError(), g['median'], **r)
+    np.testing.assert_allclose(hpe.getMaxError(), g['max'], **r)
+    np.testing.assert_allclose(hpe.getMeanErrorOverSeq(), g['mean_over_seq'], **r)
+    np.testing.assert_allclose(hpe.getMaxErrorOverSeq(), g['max_over_seq'], **r)
+    np.testing.assert_allclose([hpe.getJointMeanError(j) for j in range(14)], g['joint_mean'], **r)
+    np.testing.assert_allclose([hpe.getJointMaxError(j) for j in range(14)], g['joint_max'], **r)
+    assert [[d, int(hpe.getNumFramesWithinMaxDist(d))] for d in (10, 20, 30, 40)] == g['within']
+    np.testing.assert_allclose(L.mean_joint_error(gt, jt), g['mean'], **r)
