@@ -25,6 +25,7 @@ struct Conv3Args {
     int N, H, W, Ci, Co;
     dpp_act act;
     const float* Wk;      // [Co][9][Ci]
+    int allw;             // all nine weight slices staged in LDS up front
     const float* bias;    // [Co] or null
     const float* residual;
     float* Y;             // [N][H][W][Co]
@@ -126,12 +127,26 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
             }
         }
     };
-    wfetch(0);
-    wcommit(Bs);
-    __syncthreads();                // halo + first slice visible
+    // Narrow layers (stages 1-2: Ci = 16 / 32) have all nine weight slices staged up front (11-21 KB): one barrier for the
+    // whole workgroup instead of one per tap, which is what bounds these short K loops.
+    const bool allw = a.allw != 0;
+    if (allw) {
+        const int per_tap = BN * q;
+        for (int sidx = tid; sidx < 9 * per_tap; sidx += DPP_THREADS) {
+            const int tap = sidx / per_tap, slot = sidx - tap * per_tap;
+            const int j = slot / q, c4 = slot - j * q;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col0 + j < a.Co) v = *reinterpret_cast<const float4*>(a.Wk + ((size_t)(col0 + j) * 9 + tap) * Ci + c4 * 4);
+            *reinterpret_cast<float4*>(&Bs[(tap * BN + j) * LDA + c4 * 4]) = v;
+        }
+    } else {
+        wfetch(0);
+        wcommit(Bs);
+    }
+    __syncthreads();                // halo + first slice (or all slices) visible
     for (int tap = 0; tap < 9; ++tap) {
-        const float* Bcur = Bs + (tap & 1) * BN * LDA;
-        if (tap + 1 < 9) wfetch(tap + 1);
+        const float* Bcur = allw ? Bs + tap * BN * LDA : Bs + (tap & 1) * BN * LDA;
+        if (!allw && tap + 1 < 9) wfetch(tap + 1);
         const int toff = (tap / 3 - 1) * (TW + 2) + (tap % 3 - 1);
         for (int kc = 0; kc < Ci; kc += 16) {
             float4 av[RM], bv[CN];
@@ -150,9 +165,12 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
                         acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t),
                                                                            acc[rt][ct], 0, 0, 0);
         }
-        if (tap + 1 < 9) wcommit(Bs + ((tap + 1) & 1) * BN * LDA);
-        __syncthreads();
+        if (!allw) {
+            if (tap + 1 < 9) wcommit(Bs + ((tap + 1) & 1) * BN * LDA);
+            __syncthreads();
+        }
     }
+    if (allw) __syncthreads();      // the epilogue reuses Bs as scratch
 
     const dpp_epilogue& ep = a.epi;
     const bool fused = ep.stats != nullptr || ep.bn_x != nullptr;
@@ -420,7 +438,9 @@ extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dp
     if (Ci > 64) return DPP_E_UNSUPPORTED;          // weight-slice register staging is sized for Ci <= 64
     int bn = Co >= 64 ? 64 : (Co >= 32 ? 32 : 16);
     while (bn > 16 && (long)nblk * dpp_cdiv(Co, bn) < 1024) bn >>= 1;     // ~4 workgroups per CU (measured: 256 -> 1024 is ~0.5 % of the step)
-    size_t lds = ((size_t)a.img * (TH + 2) * (TW + 2) + 2 * bn) * (Ci + 4) * sizeof(float);
+    size_t halo = (size_t)a.img * (TH + 2) * (TW + 2);
+    a.allw = (halo + 9 * bn) * (Ci + 4) * sizeof(float) <= 48 * 1024;
+    size_t lds = (halo + (a.allw ? 9 : 2) * bn) * (Ci + 4) * sizeof(float);
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, dpp_cdiv(Co, bn));
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -128,7 +128,33 @@ def main_feats():
             bench_gemm(M, N, K, True, tile, 0, feats, label)
 
 
+def main_conv3():
+    for label, N, H, C in (('stage1 3x3 16->16', 128, 32, 16), ('stage2 3x3 32->32', 128, 16, 32), ('stage3/4 3x3 64->64', 128, 8, 64)):
+        X = rt.alloc((N, H, H, C), zero=False)
+        rt.tensor(X).normal_()
+        Wk = rt.alloc((C, 9, C), zero=False)
+        rt.tensor(Wk).normal_()
+        Y = rt.alloc((N, H, H, C), zero=False)
+        for bm in (64, 128):
+            try:
+                us = timeit(ops.conv3x3(rt, X, N, H, H, C, Wk, C, Y, bm=bm))
+            except Exception as e:      # noqa: BLE001
+                print(label, bm, e)
+                continue
+            px = N * H * H
+            print('%-22s bm=%3d plain  %7.2f us  %6.1f TFLOP/s  %6.0f GB/s' % (label, bm, us, 2.0 * px * 9 * C * C / us * 1e-6, 8.0 * px * C / us * 1e-3))
+            dY = rt.alloc((N, H, H, C), zero=False)
+            rt.tensor(dY).normal_()
+            nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, H, bm)
+            part = rt.alloc((nblk, C * 9 * C), zero=False)
+            us = timeit(ops.conv3x3_wgrad(rt, X, N, H, H, C, dY, C, part, bm=bm))
+            print('%-22s bm=%3d wgrad  %7.2f us  %6.1f TFLOP/s  %6.0f GB/s (%d partial blocks)' %
+                  (label, bm, us, 2.0 * px * 9 * C * C / us * 1e-6, 8.0 * px * C / us * 1e-3, nblk))
+
+
 def main():
+    if 'conv3' in sys.argv[1:]:
+        return main_conv3()
     if 'feats' in sys.argv[1:]:
         return main_feats()
     if 'fc' in sys.argv[1:]:
