@@ -847,6 +847,19 @@ class CompiledNet(object):
         var = getattr(view, 'var', None)
         return var is not None and self._single_consumer(var) and len(view.shape) == 4
 
+    def _two_conv1x1_consumers(self, view):
+        """A BatchNorm(+ReLU) view read by exactly two 1x1 convs with the same stride (the projection blocks)."""
+        if view.bn is None or not self.fuse_bn or len(view.shape) != 4:
+            return False
+        var = getattr(view, 'var', None)
+        cons = self.consumers.get(id(var), []) if var is not None else []
+        if len(cons) != 2:
+            return False
+        for c in cons:
+            if c.kind != 'layer' or _layer_kind(c.layer) != 'ConvLayer' or tuple(c.layer.cfgParams.filterDim) != (1, 1):
+                return False
+        return tuple(cons[0].layer.cfgParams.stride) == tuple(cons[1].layer.cfgParams.stride)
+
     def _bias_grad(self, dY, rows, C, gslot):
         if dY.ptr in self.colsum_of:
             cs, nb, cc = self.colsum_of[dY.ptr]
@@ -898,8 +911,11 @@ class CompiledNet(object):
                 if rs is not None:
                     tile = rs
                 epi = None
-                if s == 1 and not acc and self._sole_consumer_bn_view(src):
-                    # ReLU mask + (sum G, sum G*xhat) of the BatchNorm backward in this kernel's epilogue
+                if (s == 1 and not acc and self._sole_consumer_bn_view(src)) or (acc and self._two_conv1x1_consumers(src)):
+                    # ReLU mask + (sum G, sum G*xhat) of the BatchNorm backward in this kernel's epilogue.  A projection block
+                    # feeds its BatchNorm output to two 1x1 convs (main path and shortcut, resnet.py:380-414): the first data
+                    # gradient writes its share unmasked, the second accumulates onto it (residual = dst) and finishes the
+                    # reduction on the sum; pixels the stride-2 row map skips hold zeros and contribute nothing.
                     nb2 = -(-M // tile[0])
                     tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
                     epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
