@@ -28,7 +28,8 @@ constexpr int LXP = LX + 1;        // padded row
 template <int CN>   // CN = Co / 16 column tiles
 __global__ __launch_bounds__(DPP_THREADS) void stem_fwd_kernel(const float* __restrict__ X, int N, int H, int W, const float* __restrict__ Wk,
                                                                const float* __restrict__ bias, int Co, float* __restrict__ Y,
-                                                               uint8_t* __restrict__ arg, int tiles_x, int tiles_y) {
+                                                               uint8_t* __restrict__ arg, int tiles_x, int tiles_y,
+                                                               float* __restrict__ stats) {
     __shared__ float xs[LX * LXP];
     __shared__ float Ws[KPAD * CN * 16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
@@ -64,6 +65,11 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_fwd_kernel(const float* __re
         koff[t] = (kk / KS) * LXP + (kk % KS);
     }
 
+    float vals[4][CN];               // this lane's pooled outputs (kept for the fused BatchNorm statistics)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < CN; ++j) vals[i][j] = 0.0f;
     // wave w owns pooled rows 2w, 2w+1 of the 8x8 pooled tile: 4 row-tiles of (4 windows x 4 pixels)
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
@@ -94,7 +100,35 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_fwd_kernel(const float* __re
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ties |= (acc[ct][r] == best) ? (1 << r) : 0;
                     Y[o + col] = best + bias[col];
+                    vals[rt][ct] = best + bias[col];
                     if (arg) arg[o + col] = (uint8_t)ties;
+                }
+            }
+        }
+    }
+    if (stats != nullptr) {
+        // per-tile (mean, M2) of the 64 pooled outputs of every channel: the BatchNorm statistics partial of the tensor just
+        // written (the host only asks for it when all tiles are full), combined by dpp_bn_finalize with rows_per_block = 64
+        float sm[CN], m2[CN];
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) sm[ct] = vals[0][ct] + vals[1][ct] + vals[2][ct] + vals[3][ct];
+        dpp_tile_colsum<CN, 4, 1, CN * 16>(sm, xs, wave, 0, l15, kq);
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            sm[ct] *= (1.0f / 64.0f);
+            float t = 0.0f;
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) { float dv = vals[rt][ct] - sm[ct]; t += dv * dv; }
+            m2[ct] = t;
+        }
+        dpp_tile_colsum<CN, 4, 1, CN * 16>(m2, xs, wave, 0, l15, kq);
+        if (kq == 0 && wave == 0) {
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                int col = ct * 16 + l15;
+                if (col < Co) {
+                    stats[((size_t)blockIdx.x * 2 + 0) * Co + col] = sm[ct];
+                    stats[((size_t)blockIdx.x * 2 + 1) * Co + col] = m2[ct];
                 }
             }
         }
@@ -157,15 +191,17 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_wgrad_kernel(const float* __
 }  // namespace
 
 extern "C" int dpp_stem_fwd(const float* X, int N, int H, int W, const float* Wk, const float* bias, int Co, float* Y, uint8_t* argmax,
+                            float* stats,
                             dpp_stream_t stream) {
     if (!X || !Wk || !bias || !Y || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || Co < 1 || Co > 32) return DPP_E_BADARG;
+    if (stats && ((H % TC) || (W % TC))) return DPP_E_BADARG;     // per-tile statistics assume full 16x16 conv tiles
     int tiles_x = dpp_cdiv(W, TC), tiles_y = dpp_cdiv(H, TC);
     dim3 grid(tiles_x * tiles_y * N);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (Co <= 16)
-        hipLaunchKernelGGL((stem_fwd_kernel<1>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y);
+        hipLaunchKernelGGL((stem_fwd_kernel<1>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y, stats);
     else
-        hipLaunchKernelGGL((stem_fwd_kernel<2>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y);
+        hipLaunchKernelGGL((stem_fwd_kernel<2>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y, stats);
     return dpp_launch_status();
 }
 

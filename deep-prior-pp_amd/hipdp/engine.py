@@ -573,7 +573,7 @@ class CompiledNet(object):
             v.var = var
             return v
         if kind == 'ConvPoolLayer':
-            return self._emit_stem(layer, src)
+            return self._emit_stem(layer, src, out_var if out_var is not None else var)
         if kind == 'ConvLayer':
             return self._emit_conv(layer, src, residual, out_var if out_var is not None else var)
         if kind == 'HiddenLayer':
@@ -582,7 +582,7 @@ class CompiledNet(object):
             return self._emit_dropout(layer, src)
         raise NotImplementedError(kind)
 
-    def _emit_stem(self, layer, src):
+    def _emit_stem(self, layer, src, out_var=None):
         c = layer.cfgParams
         N, H, W, Ci = src.base.shape
         ok = (src.base is self.x_in and Ci == 1 and tuple(c.filterDim) == (5, 5) and c.border_mode == 'half' and
@@ -592,8 +592,13 @@ class CompiledNet(object):
         Co = c.nFilters
         out = self._new_tensor((N, H // 2, W // 2, Co), 'stem')
         arg = self.rt.alloc((N, H // 2, W // 2, Co), np.uint8, zero=False) if self.train else None
+        stats = None
+        if self.train and self.fuse_bn and H % 16 == 0 and W % 16 == 0 and out_var is not None and self._feeds_batchnorm(out_var):
+            nblk = N * (H // 16) * (W // 16)                   # one partial per workgroup = 64 pooled outputs
+            out.stats = (self.rt.alloc((nblk, 2, Co), zero=False), nblk, 64)
+            stats = out.stats[0]
         self.fwd.add(ops.stem_fwd(self.rt, src.base.buf.reshape(N, H, W), N, H, W, self.store.view(layer.W), self.store.view(layer.b), Co,
-                                  out.buf, arg))
+                                  out.buf, arg, stats))
         self.layer_io[id(layer)] = dict(in_view=src, out=out, argmax=arg, stem=True)
         return View(out)
 

@@ -161,9 +161,9 @@ def conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, partial, actX=None, bm=64, name='c
                   (X, dY, partial, actX), name, meta)
 
 
-def stem_fwd(rt, X, N, H, W, Wk, bias, Co, Y, argmax, name='stem_fwd'):
+def stem_fwd(rt, X, N, H, W, Wk, bias, Co, Y, argmax, stats=None, name='stem_fwd'):
     px = float(N) * H * W
-    return Launch(rt.lib.dpp_stem_fwd, (X.ptr, N, H, W, Wk.ptr, bias.ptr, Co, Y.ptr, _p(argmax)), (X, Wk, bias, Y, argmax), name,
+    return Launch(rt.lib.dpp_stem_fwd, (X.ptr, N, H, W, Wk.ptr, bias.ptr, Co, Y.ptr, _p(argmax), _p(stats)), (X, Wk, bias, Y, argmax, stats), name,
                   dict(kernel='stem_fwd_mfma_f32', flops=2.0 * px * 25 * Co, bytes=4.0 * px + px / 4 * Co * 5.0))
 
 

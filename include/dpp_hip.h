@@ -137,9 +137,11 @@ int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act
  * X: [N][H][W] single-channel crops (NCHW == NHWC); Wk: [Co][25]; Y: [N][H/2][W/2][Co]; argmax: the TIE MASK of each
  * 2x2 window (bit j set = window element j, row-major, equals the maximum), kept for the filter gradient: Theano's
  * MaxPoolGrad gives the gradient to every element equal to the maximum, and the constant background of a depth crop
- * makes whole windows tie. */
+ * makes whole windows tie.
+ * stats (may be NULL; needs H % 16 == W % 16 == 0): [N * H/16 * W/16][2][Co] per-tile (mean, M2) of the 64 pooled outputs a
+ * workgroup writes -- the BatchNorm statistics partial of Y, combined by dpp_bn_finalize(rows_per_block = 64). */
 int dpp_stem_fwd(const float* X, int N, int H, int W, const float* Wk, const float* bias, int Co, float* Y, uint8_t* argmax,
-                 dpp_stream_t stream);
+                 float* stats, dpp_stream_t stream);
 int dpp_stem_wgrad_blocks(int N, int H, int W, int tiles_per_block);
 int dpp_stem_wgrad(const float* X, int N, int H, int W, const float* dY, const uint8_t* argmax, int Co, float* partial,
                    int tiles_per_block, dpp_stream_t stream);

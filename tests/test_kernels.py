@@ -71,9 +71,22 @@ def test_stem_fwd_and_wgrad(backend, cfg):
     d = up(rt, X=x[:, 0], Wk=layout.conv_w_to_kernel(Wr).reshape(Co, 25), b=b)
     Y = rt.alloc((N, H // 2, W // 2, Co), zero=False)
     arg = rt.alloc((N, H // 2, W // 2, Co), np.uint8, zero=False)
-    ops.stem_fwd(rt, d['X'], N, H, W, d['Wk'], d['b'], Co, Y, arg)(rt.stream)
+    full = H % 16 == 0 and W % 16 == 0                 # the fused BatchNorm statistics need full 16x16 conv tiles
+    nblk_s = N * (H // 16) * (W // 16)
+    stats = rt.alloc((nblk_s, 2, Co), zero=False) if full else None
+    ops.stem_fwd(rt, d['X'], N, H, W, d['Wk'], d['b'], Co, Y, arg, stats)(rt.stream)
     rt.synchronize()
     np.testing.assert_allclose(layout.nhwc_to_nchw(Y.get()), y_ref, rtol=0, atol=3e-6 * 5 * np.abs(y_ref).max())
+    if full:
+        M = N * (H // 2) * (W // 2)
+        mean, istd, scale = (rt.alloc(Co, zero=False) for _ in range(3))
+        ops.bn_finalize(rt, stats, nblk_s, M, 64, Co, rt.upload(np.ones(Co, np.float32)), 1e-4, mean, istd, scale)(rt.stream)
+        rt.synchronize()
+        yv = Y.get().astype('f8').reshape(M, Co)
+        np.testing.assert_allclose(mean.get(), yv.mean(0), rtol=0, atol=1e-6 * np.abs(yv).max())
+        np.testing.assert_allclose(istd.get(), 1.0 / np.sqrt(yv.var(0) + 1e-4), rtol=1e-5)
+    else:
+        assert rt.lib.dpp_stem_fwd(d['X'].ptr, N, H, W, d['Wk'].ptr, d['b'].ptr, Co, Y.ptr, arg.ptr, rt.alloc((4, 2, Co)).ptr, rt.stream) != 0
     # the tie mask agrees with the oracle wherever the oracle's window is either clearly decided or exactly tied
     cshape, ties_ref, _ = cache
     c = L.conv2d_fwd(x, Wr, None, (1, 1), 'half')
