@@ -153,7 +153,7 @@ def test_batchnorm_forward_stats_and_backward(backend, cfg):
     ops.bn_bwd_apply(rt, G, d['x'], M, Cc, mean, istd, scale, c1, c2, dX, add=addb, rpb=rpb, colsum=csp)(rt.stream)
     jobs = ops.ReduceJobs(rt)
     jobs.add(csp, nb, Cc, csum)
-    jobs.add(part2, nb, 2 * Cc, part2.view(0, (2 * Cc,)) if False else rt.alloc(2 * Cc))       # a second, unrelated job
+    jobs.add(part2, nb, 2 * Cc, rt.alloc(2 * Cc))       # a second, unrelated job
     jobs.launch()(rt.stream)
     rt.synchronize()
     np.testing.assert_allclose(csum.get(), dX.get().astype('f8').sum(0), rtol=0, atol=3e-6 * np.sqrt(M) * np.abs(dX.get()).max())
