@@ -25,3 +25,18 @@ for r in rows:
     name = re.sub(r'\(.*$', '', name) if not name.startswith('void') else re.sub(r'\(.*$', '', name[5:])
     name = name[:66 - len(grid)] + grid
     print("%-66s %7d %11.1f %9.2f %9.2f %9.2f %6.1f %5d %6d" % (name[:66], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot, r[6] or 0, r[7] or 0))
+
+# per kernel family (all template instances / grids together): the figure bench.py's roofline.avg_launch_us corresponds to
+fam = {}
+for r in rows:
+    name = re.sub(r'\(anonymous namespace\)::', '', r[0])
+    name = re.sub(r'^void ', '', name)
+    key = re.sub(r'[<( ].*$', '', name)
+    a = fam.setdefault(key, [0, 0.0])
+    a[0] += r[1]
+    a[1] += r[2]
+print()
+print("per kernel family:")
+print("%-44s %9s %12s %9s %12s" % ('family', 'calls', 'total_us', 'avg_us', 'calls/step'))
+for key, (calls, t) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+    print("%-44s %9d %12.1f %9.2f %12.1f" % (key[:44], calls, t, t / calls, calls / steps))
