@@ -371,6 +371,12 @@ class CompiledNet(object):
                 self.out.grad_written = True
             self.lossplan.add(ops.loss_sse(rt, self.out.buf, self.y_in, self.N, self.out_dim, denom, self.cost,
                                            self.out.grad if train else None))
+            if self.weight_decay and not net.hasDropout():
+                # cost += weightreg_factor * sum(W^2) over the conv / FC weights, only for nets without dropout
+                # (poseregnettrainer.py:101-107); the kernel-layout W holds the same values in another order
+                for l in self.layers:
+                    if hasattr(l, 'W'):
+                        self.lossplan.add(ops.sumsq(rt, self.store.view(l.W), int(np.prod(l.W.shape)), self.weight_decay, self.cost, 1))
             if not train:
                 d = loss['nDims'] if loss.get('kind', 'embedding') != 'embedding' else self.out_dim
                 rows = self.N * (loss['numJoints'] if loss.get('kind', 'embedding') != 'embedding' else 1)

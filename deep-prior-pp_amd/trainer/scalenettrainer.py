@@ -42,7 +42,7 @@ class ScaleNetTrainer(PoseRegNetTrainer):
         print("compiling train_model() ... ")
         wd = self.cfgParams.weightreg_factor if not self.poseNet.hasDropout() else 0.0
         self.train_engine = engine.CompiledNet(self.poseNet, train=True, runtime=self.rt, loss=self.loss_cfg, weight_decay=wd)
-        self.eval_engine = engine.CompiledNet(self.poseNet, train=False, runtime=self.rt, loss=self.loss_cfg)
+        self.eval_engine = engine.CompiledNet(self.poseNet, train=False, runtime=self.rt, loss=self.loss_cfg, weight_decay=wd)
         print("done.")
         B = self.cfgParams.batch_size
         te = self.train_engine

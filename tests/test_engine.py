@@ -192,3 +192,38 @@ def test_resnet_type3_dropout_narrow_stages(backend):
             return
         failures.append((seed, bad[:4]))
     raise AssertionError("gradients off on every input: %r" % (failures,))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_weight_decay_cost_and_gradients(backend):
+    """weightreg_factor (poseregnettrainer.py:101-107): cost += wd * sum(W^2) over conv / FC weights for nets without dropout,
+    and 2 * wd * W in their gradients; a net with dropout ignores it."""
+    rt = get_runtime(backend)
+    wd = 1e-3
+    net, onet, P = make_net(rt, 0, 4, 32, 1, 30)
+    rng = np.random.RandomState(12)
+    x = nets.synthetic_crops(rng, 4, 32, 32, np.float32)
+    y = rng.normal(0, 0.3, (4, 30)).astype(np.float32)
+    P64 = nets.cast_params(P, np.float64)
+    # validation cost first (the training pass below moves the running statistics)
+    ev = engine.CompiledNet(net, train=False, runtime=rt, loss=dict(kind='embedding'), weight_decay=wd)
+    c_ev, _ = ev.evaluate(x, y)
+    o_ev, _ = nets.forward(onet, P64, x.astype(np.float64), False)
+    reg = sum(wd * (P64[i][0] ** 2).sum() for i, l in enumerate(onet['layers']) if l['kind'] in ('conv', 'convpool', 'fc'))
+    assert abs(c_ev - (((o_ev - y) ** 2).sum(axis=1).mean() + reg)) < 1e-5 * c_ev
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), weight_decay=wd)
+    cost, _ = eng.cost_and_grads(x, y)
+    c_ref, G_ref, _, _ = nets.cost_and_grads(onet, P64, x.astype(np.float64), y.astype(np.float64), weight_decay=wd)
+    c_plain, G_plain, _, _ = nets.cost_and_grads(onet, P64, x.astype(np.float64), y.astype(np.float64))
+    assert c_ref - c_plain > 1e-3 * c_plain                    # the regulariser is visible in the cost
+    assert abs(cost - c_ref) < 1e-5 * abs(c_ref)
+    G = grads_from_store(eng, net)
+    gmax = max(np.abs(G_ref[i][s]).max() for i in G_ref for s in range(2))
+    for i in G_ref:
+        np.testing.assert_allclose(G[i][0], G_ref[i][0], rtol=0, atol=2e-4 * max(np.abs(G_ref[i][0]).max(), 5e-3 * gmax), err_msg='layer %d' % i)
+    # dropout nets ignore the factor
+    net3, onet3, P3 = make_net(rt, 3, 4, 32, 1, 30)
+    e3 = engine.CompiledNet(net3, train=False, runtime=rt, loss=dict(kind='embedding'), weight_decay=wd)
+    c3, _ = e3.evaluate(x, y)
+    o3, _ = nets.forward(onet3, nets.cast_params(P3, np.float64), x.astype(np.float64), False)
+    assert abs(c3 - ((o3 - y) ** 2).sum(axis=1).mean()) < 1e-5 * c3
