@@ -155,6 +155,7 @@ struct PrepArgs {
     double sigma_com, sigma_sc, rot_range;
     AugCam cam;
     int B, J, dsz;
+    int norm01;              // crops normalised to [0, 1] (normZeroOne) instead of [-1, 1]
     const float* pca_mean;   // [J*3] or null
     const float* pca_comp;   // [E][J*3]
     int E;
@@ -208,8 +209,9 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a
         AugRec r;
         r.warp = WARP_NONE; r.thresh = 0; r.zlo = 0.f; r.zhi = 0.f;
         for (int i = 0; i < 9; ++i) r.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
-        r.den_scale = (float)(cube[2] / 2.);
-        r.den_off = com[2];
+        // de-normalisation of the stored crop (nettrainer.py:948-951): [-1, 1] about the CoM, or [0, 1] from the cube's front face
+        r.den_scale = a.norm01 ? (float)cube[2] : (float)(cube[2] / 2.);
+        r.den_off = a.norm01 ? (float)((double)com[2] - cube[2] / 2.) : com[2];
         r.premax = mx * r.den_scale + r.den_off;      // two roundings (contraction is off)
         float ncom[3] = {com[0], com[1], com[2]};
         double ncube[3] = {cube[0], cube[1], cube[2]};
@@ -297,7 +299,8 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a
         }
         double far_d = (double)ncom[2] + ncube[2] / 2., near_d = (double)ncom[2] - ncube[2] / 2.;
         r.far_v = (float)far_d; r.near_v = (float)near_d;
-        r.norm_off = ncom[2]; r.norm_div = (float)(ncube[2] / 2.);
+        r.norm_off = a.norm01 ? r.near_v : ncom[2];              // nettrainer.py:982-995
+        r.norm_div = a.norm01 ? (float)ncube[2] : (float)(ncube[2] / 2.);
         a.rec[b] = r;
     }
     __syncthreads();
@@ -525,8 +528,8 @@ extern "C" int dpp_augment_prepare(const float* img, const float* com3d, const f
                                    int B, int J, int dsz, const int* mode, const double* off, const double* rot, const double* sc,
                                    const int* mode_table, int n_modes, unsigned long long seed, unsigned long long counter,
                                    double sigma_com, double sigma_sc, double rot_range, double fx, double fy, double ux, double uy,
-                                   int flip_y, const float* pca_mean, const float* pca_comp, int E, void* records, float* out_y,
-                                   int* out_mode, const unsigned long long* counter_dev, dpp_stream_t stream) {
+                                   int flip_y, int norm_zero_one, const float* pca_mean, const float* pca_comp, int E, void* records,
+                                   float* out_y, int* out_mode, const unsigned long long* counter_dev, dpp_stream_t stream) {
     if (!img || !com3d || !cube || !Mcrop || !gt3d || !records || !out_y || B < 1 || J < 1 || J * 3 > MAXJ3 || dsz < 1) return DPP_E_BADARG;
     if (!mode && (!mode_table || n_modes < 1)) return DPP_E_BADARG;
     if (mode && (!off || !rot || !sc)) return DPP_E_BADARG;
@@ -536,7 +539,7 @@ extern "C" int dpp_augment_prepare(const float* img, const float* com3d, const f
     a.mode = mode; a.off = off; a.rot = rot; a.sc = sc; a.mode_table = mode_table; a.n_modes = n_modes;
     a.seed = seed; a.counter = counter; a.counter_dev = counter_dev; a.sigma_com = sigma_com; a.sigma_sc = sigma_sc; a.rot_range = rot_range;
     a.cam.fx = fx; a.cam.fy = fy; a.cam.ux = ux; a.cam.uy = uy; a.cam.flip_y = flip_y;
-    a.B = B; a.J = J; a.dsz = dsz; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
+    a.B = B; a.J = J; a.dsz = dsz; a.norm01 = norm_zero_one; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
     a.rec = static_cast<AugRec*>(records); a.out_y = out_y; a.out_mode = out_mode;
     hipLaunchKernelGGL(augment_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return dpp_launch_status();

@@ -18,7 +18,8 @@ def camera_tuple(importer):
 
 
 class DeviceAugmenter(object):
-    def __init__(self, rt, importer, aug_modes, n, J, dsz=128, proj=None, sigma_com=None, sigma_sc=None, rot_range=None, seed=0):
+    def __init__(self, rt, importer, aug_modes, n, J, dsz=128, proj=None, sigma_com=None, sigma_sc=None, rot_range=None, seed=0,
+                 normZeroOne=False):
         for m in aug_modes:
             if m not in MODE_CODE:
                 raise NotImplementedError("augmentation mode %r" % (m,))
@@ -30,6 +31,7 @@ class DeviceAugmenter(object):
         self.sigma_sc = 0.02 if sigma_sc is None else sigma_sc
         self.rot_range = 180. if rot_range is None else rot_range
         self.seed = int(seed)
+        self.normZeroOne = bool(normZeroOne)
         self.rec = rt.alloc(self.n * rt.lib.dpp_augment_record_bytes(), np.uint8)
         self.counter = rt.alloc(1, np.int64)
         self.pm = self.pc = None
@@ -49,7 +51,7 @@ class DeviceAugmenter(object):
             kw = dict(mode=explicit['mode'], off=explicit['off'], rot=explicit['rot'], sc=explicit['sc'])
         a = ops.augment_prepare(rt, img, com3d, cube, Mcrop, gt3d, self.n, self.J, self.dsz, self.cam, self.rec, out_y,
                                 sigma_com=self.sigma_com, sigma_sc=self.sigma_sc, rot_range=self.rot_range, pca_mean=self.pm,
-                                pca_comp=self.pc, E=self.E, **kw)
+                                pca_comp=self.pc, E=self.E, norm_zero_one=self.normZeroOne, **kw)
         w = ops.augment_warp(rt, img, self.rec, self.n, self.dsz, out_x)
         lst = [a, w]
         if explicit is None:

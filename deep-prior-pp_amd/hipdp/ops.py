@@ -266,12 +266,13 @@ def relu_bwd(rt, dy, pre, g, n, a=1.0, mask=None, name='relu_bwd'):
 
 def augment_prepare(rt, img, com3d, cube, Mcrop, gt3d, B, J, dsz, cam, records, out_y, mode=None, off=None, rot=None, sc=None,
                     mode_table=None, n_modes=0, seed=0, counter=0, sigma_com=5., sigma_sc=0.02, rot_range=180.,
-                    pca_mean=None, pca_comp=None, E=0, out_mode=None, counter_dev=None, name='augment_prepare'):
+                    pca_mean=None, pca_comp=None, E=0, out_mode=None, counter_dev=None, norm_zero_one=False, name='augment_prepare'):
     fx, fy, ux, uy, flip = cam
     return Launch(rt.lib.dpp_augment_prepare,
                   (img.ptr, com3d.ptr, cube.ptr, Mcrop.ptr, gt3d.ptr, B, J, dsz, _p(mode), _p(off), _p(rot), _p(sc), _p(mode_table),
                    n_modes, seed, counter, float(sigma_com), float(sigma_sc), float(rot_range), float(fx), float(fy), float(ux),
-                   float(uy), int(flip), _p(pca_mean), _p(pca_comp), E, records.ptr, out_y.ptr, _p(out_mode), _p(counter_dev)),
+                   float(uy), int(flip), int(bool(norm_zero_one)), _p(pca_mean), _p(pca_comp), E, records.ptr, out_y.ptr, _p(out_mode),
+                   _p(counter_dev)),
                   (img, com3d, cube, Mcrop, gt3d, mode, off, rot, sc, mode_table, pca_mean, pca_comp, records, out_y, out_mode,
                    counter_dev), name)
 

@@ -401,8 +401,6 @@ class NetTrainer(object):
         from hipdp.augmenter import MODE_CODE, camera_tuple
         assert len(img.shape) == 2
         assert isinstance(aug_modes, list)
-        if normZeroOne is True:
-            raise NotImplementedError("normZeroOne crops are not used by the posereg_embedding path")
         sigma_com = 5. if sigma_com is None else sigma_com
         sigma_sc = 0.02 if sigma_sc is None else sigma_sc
         rot_range = 180. if rot_range is None else rot_range
@@ -421,7 +419,7 @@ class NetTrainer(object):
                             f32(numpy.asarray(gt3Dcrop).reshape(1, J, 3)), 1, J, img.shape[0], camera_tuple(hd.importer), rec, out_y,
                             mode=rt.upload(numpy.array([MODE_CODE[aug_modes[mode]]], numpy.int32)),
                             off=rt.upload(numpy.asarray(off, numpy.float64)), rot=rt.upload(numpy.array([rot], numpy.float64)),
-                            sc=rt.upload(numpy.array([sc], numpy.float64)))(rt.stream)
+                            sc=rt.upload(numpy.array([sc], numpy.float64)), norm_zero_one=bool(normZeroOne))(rt.stream)
         ops.augment_warp(rt, imgb, rec, 1, img.shape[0], out_x)(rt.stream)
         rt.synchronize()
         new_cube = numpy.asarray(cube, numpy.float64) * (sc if aug_modes[mode] == 'sc' else 1.0)

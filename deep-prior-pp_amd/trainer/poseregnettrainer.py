@@ -142,8 +142,6 @@ class PoseRegNetTrainer(NetTrainer):
         (poseregnettrainer.py:221-264).  The reference calls this per worker on a slice; here the hook is invoked once
         per macro-batch with the full range, and two kernel launches process all of it."""
         args = macro_params['args']
-        if args.get('normZeroOne'):
-            raise NotImplementedError("normZeroOne crops are not used by the posereg_embedding path")
         if args.get('binarizeImage'):
             raise NotImplementedError("binarizeImage")
         n = len(idxs)
@@ -162,7 +160,7 @@ class PoseRegNetTrainer(NetTrainer):
         if self._augmenter is None or self._augmenter[0] != key:
             aug = DeviceAugmenter(self.rt, args['di'], args['aug_modes'], n, J, dsz=self.train_data_xDB.shape[-1], proj=proj,
                                   sigma_com=args.get('sigma_com'), sigma_sc=args.get('sigma_sc'), rot_range=args.get('rot_range'),
-                                  seed=int(self.rng.randint(1 << 30)))
+                                  seed=int(self.rng.randint(1 << 30)), normZeroOne=bool(args.get('normZeroOne')))
             launches = aug.build(self._aug_src.rows(idxs[0], n).reshape(n, *self.train_data_xDB.shape[-2:]),
                                  self.train_data_com.rows(idxs[0], n), self.train_data_cube.rows(idxs[0], n),
                                  self.train_data_M.rows(idxs[0], n).reshape(n, 9), gt.rows(idxs[0], n),

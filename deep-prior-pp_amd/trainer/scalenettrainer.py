@@ -102,8 +102,6 @@ class ScaleNetTrainer(PoseRegNetTrainer):
         """scalenettrainer.py:211-251: augment crop + offset label (one "joint": the label times cube_z/2), then cut the two
         centre crops out of the augmented crop."""
         args = macro_params['args']
-        if args.get('normZeroOne'):
-            raise NotImplementedError("normZeroOne crops")
         n = len(idxs)
         if n == 0:
             return
@@ -119,7 +117,8 @@ class ScaleNetTrainer(PoseRegNetTrainer):
         key = (idxs[0], tidxs[0], n)
         if self._augmenter is None or self._augmenter[0] != key:
             aug = DeviceAugmenter(self.rt, args['di'], args['aug_modes'], n, 1, dsz=H, proj=None, sigma_com=args.get('sigma_com'),
-                                  sigma_sc=args.get('sigma_sc'), rot_range=args.get('rot_range'), seed=int(self.rng.randint(1 << 30)))
+                                  sigma_sc=args.get('sigma_sc'), rot_range=args.get('rot_range'), seed=int(self.rng.randint(1 << 30)),
+                                  normZeroOne=bool(args.get('normZeroOne')))
             x_out = self.train_data_x.rows(tidxs[0], n).reshape(n, H, W)
             launches = aug.build(self._aug_src.rows(idxs[0], n).reshape(n, H, W), self.train_data_com.rows(idxs[0], n),
                                  self.train_data_cube.rows(idxs[0], n), self.train_data_M.rows(idxs[0], n).reshape(n, 9),

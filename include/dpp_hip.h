@@ -222,6 +222,7 @@ int dpp_bernoulli_mask(float* mask, size_t n, float keep, unsigned long long see
  * prepare: per crop, the geometry of HandDetector.moveCoM / rotateHand / scaleHand
  *          (/root/reference/src/util/handdetector.py:678-780): new CoM, crop transform, inverse warp matrix,
  *          z-thresholds, augmented joint labels, PCA-prior projection (poseregnettrainer.py:262) -> records, out_y.
+ *          norm_zero_one: the crops are normalised to [0, 1] (normZeroOne, nettrainer.py:948, 982-988) instead of [-1, 1].
  *          mode codes: 0 none, 1 com, 2 rot, 3 sc.  mode == NULL: (mode, off, rot, sc) are drawn on the device from
  *          Philox(seed, counter, sample) with mode = mode_table[u % n_modes].
  * warp:    per pixel, cv2.warpAffine / warpPerspective (NEAREST, constant 0) + recropHand's z-clamp
@@ -231,7 +232,7 @@ int dpp_augment_prepare(const float* img, const float* com3d, const float* cube,
                         int B, int J, int dsz, const int* mode, const double* off, const double* rot, const double* sc,
                         const int* mode_table, int n_modes, unsigned long long seed, unsigned long long counter,
                         double sigma_com, double sigma_sc, double rot_range, double fx, double fy, double ux, double uy,
-                        int flip_y, const float* pca_mean, const float* pca_comp, int E, void* records, float* out_y,
+                        int flip_y, int norm_zero_one, const float* pca_mean, const float* pca_comp, int E, void* records, float* out_y,
                         int* out_mode, const unsigned long long* counter_dev, dpp_stream_t stream);
 /* *counter += inc (device-resident draw counter added to `counter` when counter_dev != NULL, so replayed graphs draw fresh
  * augmentation parameters every step) */

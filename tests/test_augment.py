@@ -12,7 +12,7 @@ from tests.backends import BACKENDS, get_runtime
 MODES = {'none': 0, 'com': 1, 'rot': 2, 'sc': 3}
 
 
-def _run(rt, cam, imgs, coms, cubes, Ms, gts, modes, offs, rots, scs, pca=None):
+def _run(rt, cam, imgs, coms, cubes, Ms, gts, modes, offs, rots, scs, pca=None, norm01=False):
     B, J = gts.shape[0], gts.shape[1]
     f32 = lambda a: rt.upload(np.asarray(a, np.float32))
     d = dict(img=f32(imgs), com=f32(coms), cube=f32(cubes), M=f32(Ms.reshape(B, 9)), gt=f32(gts))
@@ -25,7 +25,7 @@ def _run(rt, cam, imgs, coms, cubes, Ms, gts, modes, offs, rots, scs, pca=None):
     pm = f32(pca[0]) if pca else None
     pc = f32(pca[1]) if pca else None
     ops.augment_prepare(rt, d['img'], d['com'], d['cube'], d['M'], d['gt'], B, J, 128, (cam.fx, cam.fy, cam.ux, cam.uy, cam.flip_y),
-                        rec, out_y, mode=mode, off=off, rot=rot, sc=sc, pca_mean=pm, pca_comp=pc, E=E)(rt.stream)
+                        rec, out_y, mode=mode, off=off, rot=rot, sc=sc, pca_mean=pm, pca_comp=pc, E=E, norm_zero_one=norm01)(rt.stream)
     ops.augment_warp(rt, d['img'], rec, B, 128, out)(rt.stream)
     rt.synchronize()
     return out.get(), out_y.get()
@@ -184,3 +184,26 @@ def test_host_com_helpers_match_oracle():
         assert np.array_equal(hd.getCrop(hd.dpt, *b), A.get_crop(d, *b))
         c5 = hd.refineCoMIterative(coms[i].astype(float), 5, (250., 250., 250.))
         assert np.isfinite(c5).all() and abs(c5[2] - coms[i][2]) < 125.
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_augment_norm_zero_one(backend):
+    """normZeroOne crops (values in [0, 1] from the cube's front face, nettrainer.py:948, 982-988): same kernels, other
+    de-normalisation / re-normalisation constants, bit for bit against the oracle."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(31)
+    cam = A.Camera.icvl()
+    J, B = 16, 8
+    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, B, cam, cube=(250.,) * 3, joints=J)
+    imgs01 = ((imgs + 1.0) * 0.5).astype(np.float32)          # the same crops stored in [0, 1]
+    names = ['com', 'rot', 'sc', 'none'] * 2
+    modes = [MODES[n] for n in names]
+    _, offs, rots, scs = A.draw_params(rng, B, 4)
+    out, out_y = _run(rt, cam, imgs01, coms, cubes, Ms, gts, modes, offs, rots, scs, norm01=True)
+    for i in range(B):
+        ref, lab, *_ = A.augment_crop(imgs01[i].copy(), gts[i].copy(), cam.joint3DToImg(coms[i]), cubes[i], Ms[i], names[i], offs[i],
+                                      rots[i], scs[i], cam, abs(cam.fx), abs(cam.fy), normZeroOne=True)
+        nbad = int((out[i] != ref).sum())
+        assert nbad <= (6 if names[i] == 'rot' else 0), (i, names[i], nbad)
+        assert out[i].min() >= 0.0 and out[i].max() <= 1.0 + 1e-6
+        np.testing.assert_allclose(out_y[i].reshape(J, 3), lab, rtol=0, atol=2e-6)
