@@ -16,6 +16,7 @@
 // Filter gradient (conv3x3_wgrad_kernel): same halo tile + the dY tile in LDS; the reduction runs over the
 // tile's pixels, out tile = [Cout][Cin] per tap, (tap, 16x16 tile) pairs are dealt round-robin to the 4
 // waves; per-workgroup partials are summed by dpp_reduce_partials in a fixed order.
+#include <stdlib.h>
 #include "dpp_common.h"
 
 namespace {
@@ -26,6 +27,7 @@ struct Conv3Args {
     dpp_act act;
     const float* Wk;      // [Co][9][Ci]
     int allw;             // all nine weight slices staged in LDS up front
+    int wide;             // 16-byte epilogue through an LDS image of the tile (dpp_epilogue_wide)
     const float* bias;    // [Co] or null
     const float* residual;
     float* Y;             // [N][H][W][Co]
@@ -81,6 +83,8 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     tile_origin(a, blockIdx.x, n0, y0, x0);
     const int col0 = blockIdx.y * BN;
 
+    dpp_wide_coef wco;
+    if (a.wide) wco.load<BN>(col0, a.Co, a.bias, a.epi);
     stage_halo(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA);
 
     // halo index of this lane's A rows (centre tap)
@@ -171,6 +175,22 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
         }
     }
     if (allw) __syncthreads();      // the epilogue reuses Bs as scratch
+
+    if (a.wide) {
+        const int vi = (a.N - n0 < a.img) ? (a.N - n0) : a.img;
+        const int vy = (a.H - y0 < TH) ? (a.H - y0) : TH;
+        const int vx = (a.W - x0 < TW) ? (a.W - x0) : TW;
+        dpp_epilogue_wide<RM, CN, 4, 1, BM, BN>(acc, smem, col0, a.Co, wco, a.residual, a.Y, a.epi, vi * vy * vx, wave, 0, l15, kq,
+                                                [&](int rl) {
+            const int im = rl >> (a.lth + a.ltw);
+            const int ty = (rl >> a.ltw) & (TH - 1);
+            const int tx = rl & (TW - 1);
+            const int n = n0 + im, y = y0 + ty, x = x0 + tx;
+            const bool ok = !(im >= a.img || n >= a.N || y >= a.H || x >= a.W);
+            return ok ? (long)((((size_t)n * a.H + y) * a.W + x) * a.Co) : -1L;
+        });
+        return;
+    }
 
     const dpp_epilogue& ep = a.epi;
     const bool fused = ep.stats != nullptr || ep.bn_x != nullptr;
@@ -441,12 +461,19 @@ extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dp
     size_t halo = (size_t)a.img * (TH + 2) * (TW + 2);
     a.allw = (halo + 9 * bn) * (Ci + 4) * sizeof(float) <= 48 * 1024;
     size_t lds = (halo + (a.allw ? 9 : 2) * bn) * (Ci + 4) * sizeof(float);
+    static const bool wide_ok = []() { const char* e = getenv("DPP_GEMM_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    a.wide = wide_ok && al16(Y) && al16(residual) && al16(a.epi.bn_x);
+    if (a.wide) {
+        size_t need = ((size_t)bm * (bn + 4) + 16 * bn) * sizeof(float);
+        if (lds < need) lds = need;
+    }
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, dpp_cdiv(Co, bn));
     hipStream_t st = static_cast<hipStream_t>(stream);
     // gfx950 has 160 KiB of LDS per CU; requests above the default 64 KiB window need the opt-in attribute
 #define DPP_C3(BM_, BN_) if (bm == BM_ && bn == BN_) { \
-        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((conv3x3_kernel<BM_, BN_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
     DPP_C3(128, 64) DPP_C3(128, 32) DPP_C3(128, 16) DPP_C3(64, 64) DPP_C3(64, 32) DPP_C3(64, 16)
 #undef DPP_C3
@@ -490,7 +517,7 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     dim3 grid(nblk, 9 / taps_pb);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { \
-        if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<BM_, MA_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<BM_, MA_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM_, MA_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
     DPP_W3(128, 3) DPP_W3(128, 9) DPP_W3(128, 12) DPP_W3(128, 16)
     DPP_W3(64, 3) DPP_W3(64, 9) DPP_W3(64, 12) DPP_W3(64, 16)

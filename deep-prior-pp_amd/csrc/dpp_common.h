@@ -87,3 +87,164 @@ __device__ __forceinline__ void dpp_tile_colsum(float (&s)[CN], float* red, int 
         }
     }
 }
+
+// The MFMA-tile epilogue (bias / residual / fused BatchNorm-backward mask / column statistics) with 16-byte global accesses.  In the MFMA D layout a lane owns single floats of 4 different rows, so
+// a direct epilogue reads residual / bn_x and writes C 4 bytes per lane -- about half the bandwidth the memory
+// pipeline gives 16-byte accesses, which is what bounds the GEMMs with wide outputs (expanding 1x1 convolutions and their
+// data gradients move 3-5 bytes through the epilogue for every byte of operand).  Here the waves drop their accumulators
+// into an LDS image of the BM x BN tile, and then every thread owns ONE column quad and walks down the rows: float4 in,
+// float4 out, the per-column coefficients in registers, and the column sums reduce over lanes first (xor shuffles between
+// the lanes that share a quad) and over the four waves through LDS.  Requires N % 4 == 0, row offsets that are multiples of 4
+// and 16-byte aligned C / residual / bn_x.  `smem` must hold BM*(BN+4) + 16*BN floats.
+// `rowoff(rl)` gives the element offset of tile row rl in C / residual / bn_x, or -1 for a row outside the problem; `nvalid` is
+// the number of rows it accepts (the divisor of the block mean).
+// The per-column coefficients of a thread's quad.  Kernels load them BEFORE their K loop: the loads are independent of everything
+// else, and issued late they put one more memory latency on the critical path of a short workgroup.
+struct dpp_wide_coef {
+    float cbias[4], cmean[4], cscale[4], cbeta[4], cistd[4];
+    template <int BN>
+    __device__ __forceinline__ void load(int col0, int N, const float* bias, const dpp_epilogue& ep) {
+        const int col = col0 + ((int)threadIdx.x % (BN / 4)) * 4;
+        const bool cin = col < N;
+        const bool bn = ep.bn_x != nullptr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cbias[j] = (cin && bias) ? bias[col + j] : 0.0f;
+            cmean[j] = (cin && bn) ? ep.bn_mean[col + j] : 0.0f;
+            cscale[j] = (cin && bn) ? ep.bn_scale[col + j] : 0.0f;
+            cbeta[j] = (cin && bn) ? ep.bn_beta[col + j] : 0.0f;
+            cistd[j] = (cin && bn) ? ep.bn_inv_std[col + j] : 0.0f;
+        }
+    }
+};
+
+template <int RM, int CN, int WM, int WN, int BM, int BN, class RowOff>
+__device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* smem, int col0, int N, const dpp_wide_coef& co,
+                                                  const float* residual, float* C, const dpp_epilogue& ep, int nvalid, int wm,
+                                                  int wn, int l15, int kq, RowOff rowoff) {
+    constexpr int LDT = BN + 4;
+    constexpr int Q = BN / 4;                                // column quads per tile row
+    constexpr int RSTEP = DPP_THREADS / Q;                   // rows covered by one sweep of the workgroup
+    constexpr int ITERS = (BM + RSTEP - 1) / RSTEP;
+    float* Ts = smem;
+    float* red = smem + BM * LDT;                            // 4 regions of 4*BN floats
+    // (the K loop ended on a barrier, so nobody reads the operand tiles any more)
+#pragma unroll
+    for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Ts[(wm * (BM / WM) + rt * 16 + kq * 4 + r) * LDT + wn * (BN / WN) + ct * 16 + l15] = acc[rt][ct][r];
+    __syncthreads();
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cq = tid % Q, rb = tid / Q;
+    const int col = col0 + cq * 4;
+    const bool cin = col < N;                                // N % 4 == 0: the quad is inside or outside as a whole
+    const bool bn = ep.bn_x != nullptr;
+    float vals[ITERS][4];
+    bool valid[ITERS];
+    float sx[4] = {0.f, 0.f, 0.f, 0.f}, sy[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int rl = rb + it * RSTEP;
+        const long ro = (rl < BM && cin) ? rowoff(rl) : -1L;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ro >= 0) {
+            const float4 t = *reinterpret_cast<const float4*>(&Ts[rl * LDT + cq * 4]);
+            v[0] = t.x + co.cbias[0]; v[1] = t.y + co.cbias[1]; v[2] = t.z + co.cbias[2]; v[3] = t.w + co.cbias[3];
+            const size_t o = (size_t)ro + col;
+            if (residual) {
+                const float4 rr = *reinterpret_cast<const float4*>(residual + o);
+                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
+            if (bn) {
+                const float4 xx = *reinterpret_cast<const float4*>(ep.bn_x + o);
+                const float x[4] = {xx.x, xx.y, xx.z, xx.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float dx = x[j] - co.cmean[j];
+                    if (ep.bn_relu && dx * co.cscale[j] + co.cbeta[j] < 0.0f) v[j] = 0.0f;
+                    sx[j] += v[j];
+                    sy[j] += v[j] * (dx * co.cistd[j]);
+                }
+            }
+            *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        valid[it] = ro >= 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vals[it][j] = v[j];
+    }
+    const bool do_bn = bn && ep.bn_partial != nullptr;
+    // lanes of a wave that share a quad differ in the bits >= log2(Q)
+    auto lanesum = [&](float (&s)[4]) {
+#pragma unroll
+        for (int off = Q; off < 64; off <<= 1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += __shfl_xor(s[j], off);
+    };
+    auto publish = [&](const float (&s)[4], float* region) {
+        if (lane < Q) *reinterpret_cast<float4*>(&region[wave * BN + cq * 4]) = make_float4(s[0], s[1], s[2], s[3]);
+    };
+    auto collect = [&](float (&s)[4], const float* region) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float4 t = *reinterpret_cast<const float4*>(&region[w * BN + cq * 4]);
+            s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+        }
+    };
+    if (do_bn) {
+        lanesum(sx);
+        lanesum(sy);
+        publish(sx, red);
+        publish(sy, red + 4 * BN);
+        __syncthreads();
+        collect(sx, red);
+        collect(sy, red + 4 * BN);
+        if (tid < Q && cin) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ep.bn_partial[((size_t)blockIdx.x * 2 + 0) * N + col + j] = sx[j];
+                ep.bn_partial[((size_t)blockIdx.x * 2 + 1) * N + col + j] = sy[j];
+            }
+        }
+    }
+    if (ep.stats != nullptr) {
+        // block mean first, then M2 about it (no cancellation when |mean| >> std)
+        float sm[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sm[j] += vals[it][j];
+        lanesum(sm);
+        publish(sm, red + 8 * BN);
+        __syncthreads();
+        collect(sm, red + 8 * BN);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[j] = sm[j] / (float)nvalid;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (valid[it]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float dv = vals[it][j] - sm[j];
+                    m2[j] += dv * dv;
+                }
+            }
+        }
+        lanesum(m2);
+        publish(m2, red + 12 * BN);
+        __syncthreads();
+        collect(m2, red + 12 * BN);
+        if (tid < Q && cin) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ep.stats[((size_t)blockIdx.x * 2 + 0) * N + col + j] = sm[j];
+                ep.stats[((size_t)blockIdx.x * 2 + 1) * N + col + j] = m2[j];
+            }
+        }
+    }
+}

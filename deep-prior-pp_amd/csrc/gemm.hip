@@ -15,6 +15,7 @@
 // Global loads are float4 (16 B/lane) along the contiguous dimension whenever alignment allows.
 // f32 MFMA runs at the f32 vector rate (157 TF), so these layers are HBM/L2-bound for the small-channel
 // stages; the kernel keeps LDS small (<= 15 KB) to run 8 blocks per CU and hide load latency with TLP.
+#include <stdlib.h>
 #include "dpp_common.h"
 
 namespace {
@@ -25,6 +26,7 @@ struct GemmArgs {
     int vecA, vecB;   // float4 loads legal for the operand
     int Kper;         // K-slice length per blockIdx.z (multiple of the chunk depth)
     int bk;           // chunk depth for K-contiguous A: 16 or 32 (both-MN-contiguous layout always uses 64)
+    int wide;         // epilogue goes through an LDS image of the tile and touches C / residual / bn_x with 16-B accesses
 };
 
 // Load 4 consecutive floats p[0..3] where element e is valid iff (idx0 + e) < limit.
@@ -195,8 +197,12 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     using SB = Stager<BN, BKT, BKC>;
     constexpr int LDA_ = SA::LD, LDB_ = SB::LD;
     constexpr int KL = BKT / 4;                              // k-values owned by one lane per chunk: kq*KL + e
-    __shared__ __attribute__((aligned(16))) float As[AKC ? BM * LDA_ : BKT * LDA_];
-    __shared__ __attribute__((aligned(16))) float Bs[BKC ? BN * LDB_ : BKT * LDB_];
+    constexpr int SZA = AKC ? BM * LDA_ : BKT * LDA_;
+    constexpr int SZB = BKC ? BN * LDB_ : BKT * LDB_;
+    constexpr int SZE = BM * (BN + 4) + 16 * BN;             // tile image + reduction scratch of the wide epilogue
+    __shared__ __attribute__((aligned(16))) float smem[(SZA + SZB > SZE) ? (SZA + SZB) : SZE];
+    float* const As = smem;
+    float* const Bs = smem + SZA;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -292,6 +298,8 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     for (int i = 0; i < RM; ++i)
 #pragma unroll
         for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dpp_wide_coef wco;
+    if (ga.wide) wco.load<BN>(col0, N, d.bias, d.epi);
 
     // Software pipeline: DEPTH chunks are fetched ahead; chunk c is written to LDS from ring slot c % DEPTH, and as soon
     // as the barrier publishes it the slot is refilled with chunk c + DEPTH, whose loads stay in flight under the MFMAs.
@@ -345,7 +353,14 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         }
     }
 
-    gemm_epilogue<RM, CN, WM, WN, BM, BN>(acc, d, row0, col0, wm, wn, l15, kq, As);
+    if (ga.wide) {
+        const int nvalid = (M - row0 < BM) ? (M - row0) : BM;
+        dpp_epilogue_wide<RM, CN, WM, WN, BM, BN>(acc, smem, col0, N, wco, d.residual, d.C, d.epi, nvalid, wm, wn, l15, kq, [&](int rl) {
+            const int row = row0 + rl;
+            return row < M ? (long)dpp_map_row(d.mapC, row) * d.ldc : -1L;
+        });
+    }
+    else gemm_epilogue<RM, CN, WM, WN, BM, BN>(acc, d, row0, col0, wm, wn, l15, kq, As);
 }
 
 // ---- row-streaming variant for the skinny conv GEMMs (M = pixels >> K, N) -------------------------------------------------
@@ -529,6 +544,9 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     if (d.actB.mode && d.actB.cmod <= 0) return DPP_E_BADARG;
     ga.vecA = aligned16(d.A) && (d.lda % 4 == 0);
     ga.vecB = aligned16(d.B) && (d.ldb % 4 == 0);
+    static const bool wide_ok = []() { const char* e = getenv("DPP_GEMM_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
+    ga.wide = wide_ok && d.splitk == 1 && d.N % 4 == 0 && d.ldc % 4 == 0 && aligned16(d.C) && aligned16(d.residual) &&
+              aligned16(d.epi.bn_x);
     if ((d.actA.mode & 2) && !(aligned16(d.actA.mean) && aligned16(d.actA.scale) && aligned16(d.actA.beta))) return DPP_E_BADARG;
     if ((d.actB.mode & 2) && !(aligned16(d.actB.mean) && aligned16(d.actB.scale) && aligned16(d.actB.beta))) return DPP_E_BADARG;
     const bool red_layout = !d.a_kc && !d.b_kc;
