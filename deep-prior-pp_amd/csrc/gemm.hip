@@ -478,8 +478,12 @@ struct ReduceJob {
     int nz, n, block0, pad;
 };
 
+constexpr int RM_COLS = 64;    // columns per workgroup of reduce_multi_kernel (dpp_reduce_multi_block_cols)
+
+// 16 z-lanes x 16 column quads per workgroup: a thread sums every 16th slice of its four columns with 16-byte loads (a row of
+// 16 quads is one 256-byte segment), four slices in flight, and the z-lanes meet in LDS.  The order of the sum is fixed.
 __global__ __launch_bounds__(DPP_THREADS) void reduce_multi_kernel(const ReduceJob* __restrict__ jobs, int njobs) {
-    __shared__ float red[DPP_THREADS];
+    __shared__ __attribute__((aligned(16))) float red[DPP_THREADS * 4];
     __shared__ int s_job;
     if (threadIdx.x == 0) {
         int lo = 0, hi = njobs - 1;                   // last job whose block0 <= blockIdx.x
@@ -491,17 +495,57 @@ __global__ __launch_bounds__(DPP_THREADS) void reduce_multi_kernel(const ReduceJ
     }
     __syncthreads();
     const ReduceJob jb = jobs[s_job];
-    constexpr int ZL = 16, CB = DPP_THREADS / ZL;
-    const int col = threadIdx.x % CB, zl = threadIdx.x / CB;
-    const int i = ((int)blockIdx.x - jb.block0) * CB + col;
-    float s = 0.0f;
-    if (i < jb.n)
-        for (int z = zl; z < jb.nz; z += ZL) s += jb.partial[(size_t)z * jb.n + i];
-    red[threadIdx.x] = s;
+    constexpr int ZL = 16, CQ = DPP_THREADS / ZL;
+    const int cq = threadIdx.x % CQ, zl = threadIdx.x / CQ;
+    const int i = ((int)blockIdx.x - jb.block0) * RM_COLS + cq * 4;
+    const int n = jb.n, nz = jb.nz;
+    const bool vec = (n & 3) == 0 && (reinterpret_cast<uintptr_t>(jb.partial) & 15) == 0;
+    float s[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[u][j] = 0.0f;
+    if (i < n) {
+        if (vec) {
+            const float* p = jb.partial + i;
+            int z = zl;
+            for (; z + 3 * ZL < nz; z += 4 * ZL) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(z + u * ZL) * n);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s[u][0] += v[u].x; s[u][1] += v[u].y; s[u][2] += v[u].z; s[u][3] += v[u].w; }
+            }
+            for (; z < nz; z += ZL) {
+                const float4 v = *reinterpret_cast<const float4*>(p + (size_t)z * n);
+                s[0][0] += v.x; s[0][1] += v.y; s[0][2] += v.z; s[0][3] += v.w;
+            }
+        } else {
+            for (int z = zl; z < nz; z += ZL)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i + j < n) s[0][j] += jb.partial[(size_t)z * n + i + j];
+        }
+    }
+    float4 t;
+    t.x = (s[0][0] + s[1][0]) + (s[2][0] + s[3][0]);
+    t.y = (s[0][1] + s[1][1]) + (s[2][1] + s[3][1]);
+    t.z = (s[0][2] + s[1][2]) + (s[2][2] + s[3][2]);
+    t.w = (s[0][3] + s[1][3]) + (s[2][3] + s[3][3]);
+    *reinterpret_cast<float4*>(&red[threadIdx.x * 4]) = t;
     __syncthreads();
-    if (zl == 0 && i < jb.n) {
-        for (int j = 1; j < ZL; ++j) s += red[j * CB + col];
-        jb.out[i] = s;
+    if (zl == 0 && i < n) {
+        for (int j = 1; j < ZL; ++j) {
+            const float4 o = *reinterpret_cast<const float4*>(&red[(j * CQ + cq) * 4]);
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        if (vec && (reinterpret_cast<uintptr_t>(jb.out) & 15) == 0) *reinterpret_cast<float4*>(jb.out + i) = t;
+        else {
+            const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i + j < n) jb.out[i + j] = tv[j];
+        }
     }
 }
 
@@ -600,6 +644,8 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
 }
 
 extern "C" size_t dpp_reduce_job_bytes(void) { return sizeof(ReduceJob); }
+
+extern "C" int dpp_reduce_multi_block_cols(void) { return RM_COLS; }
 
 extern "C" int dpp_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, dpp_stream_t stream) {
     if (!jobs_dev || njobs < 1 || total_blocks < 1) return DPP_E_BADARG;

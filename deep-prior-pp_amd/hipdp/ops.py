@@ -337,9 +337,10 @@ class ReduceJobs(object):
         rt = self.rt
         assert rt.lib.dpp_reduce_job_bytes() == 32
         raw, block0 = b'', 0
+        cols = rt.lib.dpp_reduce_multi_block_cols()
         for (partial, nz, n, out) in self.jobs:
             raw += struct.pack('<QQiiii', partial.ptr, out.ptr, nz, n, block0, 0)
-            block0 += -(-n // 16)
+            block0 += -(-n // cols)
         table = rt.upload(np.frombuffer(raw, np.uint8).copy())
         flops = float(sum(nz * n for (_, nz, n, _) in self.jobs))
         return Launch(rt.lib.dpp_reduce_multi, (table.ptr, len(self.jobs), block0), (table, list(self.jobs)), name,

@@ -110,9 +110,10 @@ int dpp_reduce_partials(const float* partial, int nz, int n, const float* bias, 
 
 
 /* Batched form: jobs_dev = device array of { const float* partial; float* out; int nz, n, block0, pad; } sorted by block0,
- * job j owning workgroups [block0_j, block0_j + ceil(n_j / 16)); total_blocks = sum.  One launch reduces every filter /
- * bias gradient partial of a backward pass. */
+ * job j owning workgroups [block0_j, block0_j + ceil(n_j / dpp_reduce_multi_block_cols())); total_blocks = sum.  One launch
+ * reduces every filter / bias gradient partial of a backward pass. */
 size_t dpp_reduce_job_bytes(void);
+int dpp_reduce_multi_block_cols(void);
 int dpp_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, dpp_stream_t stream);
 
 /* ---- 3x3 'half' stride-1 ConvLayer on NHWC maps (implicit GEMM, halo tile in LDS) --------------------------

@@ -388,3 +388,25 @@ def test_bernoulli_mask_streams(backend):
     assert set(np.unique(a)) == {0.0, 1.0}
     assert abs(a.mean() - keep) < 4 * np.sqrt(keep * (1 - keep) / n)
     assert np.array_equal(a, b) and np.array_equal(c, d) and (a != c).mean() > 0.3
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_reduce_multi_ragged_jobs(backend):
+    """One launch sums every job's slices: vector path (n % 4 == 0, aligned), scalar path (ragged n, outputs at odd offsets),
+    slice counts around the 4 x 16 unroll."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(5)
+    cases = [(1, 16), (5, 30), (37, 100), (64, 4096), (129, 63), (256, 64), (3, 1), (70, 260)]
+    flat = rt.alloc(sum(n for _, n in cases) + 3, zero=True)
+    jobs, refs, off = ops.ReduceJobs(rt), [], 3          # outputs start 12 bytes into the buffer
+    for nz, n in cases:
+        P = rng.normal(size=(nz, n)).astype(np.float32)
+        jobs.add(rt.upload(P), nz, n, flat.view(off, (n,)))
+        refs.append((off, n, P.astype('f8').sum(0)))
+        off += n
+    jobs.launch()(rt.stream)
+    rt.synchronize()
+    got = flat.get()
+    assert np.all(got[:3] == 0)
+    for off, n, ref in refs:
+        np.testing.assert_allclose(got[off:off + n], ref, rtol=1e-5, atol=1e-5)
