@@ -73,6 +73,7 @@ __device__ __forceinline__ void chan_combine(double& n, double& mean, double& m2
     n = tot;
 }
 
+template <int U>
 __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* __restrict__ partial, int nb, int M, int rpb,
                                                                   int C, const float* __restrict__ gamma, float eps,
                                                                   float* __restrict__ mean_o, float* __restrict__ inv_std_o,
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
     const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
     const int cc = c < C ? c : C - 1;                  // keep every lane in the shuffles
     double cn = 0.0, mean = 0.0, m2 = 0.0;
-    // the loads of 8 partials are issued together (the Chan update is a dependent chain: one L2 round trip per step otherwise)
-    constexpr int U = 8;
+    // the loads of U partials are issued together (the Chan update is a dependent chain: one L2 round trip per step otherwise);
+    // the launcher picks U so that a lane needs one or two batches
     for (int b0 = lane; b0 < nb; b0 += DPP_WAVE * U) {
         float pm[U], pq[U];
 #pragma unroll
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float*
     }
 }
 
+template <int U>
 __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int M, int C,
                                                                       float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                                       float* __restrict__ c1, float* __restrict__ c2) {
@@ -190,7 +192,6 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const floa
     const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
     const int cc = c < C ? c : C - 1;
     double a = 0.0, b = 0.0;
-    constexpr int U = 8;
     for (int k0 = lane; k0 < nb; k0 += DPP_WAVE * U) {
         float pa[U], pb[U];
 #pragma unroll
@@ -232,19 +233,40 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const float* 
         const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4);
         const float4 a1 = *reinterpret_cast<const float4*>(c1 + q * 4);
         const float4 a2 = *reinterpret_cast<const float4*>(c2 + q * 4);
-        for (int r = r_begin + rr; r < r_end; r += RP) {
-            size_t i = (size_t)r * Q + q;
-            float4 g = reinterpret_cast<const float4*>(G)[i];
-            float4 x = reinterpret_cast<const float4*>(X)[i];
+        auto one = [&](const float4& g, const float4& x, const float4& r4) {
             float4 o;
             o.x = sc.x * (g.x - a1.x - (x.x - mu.x) * is.x * a2.x);
             o.y = sc.y * (g.y - a1.y - (x.y - mu.y) * is.y * a2.y);
             o.z = sc.z * (g.z - a1.z - (x.z - mu.z) * is.z * a2.z);
             o.w = sc.w * (g.w - a1.w - (x.w - mu.w) * is.w * a2.w);
-            if (add) {
-                float4 r4 = reinterpret_cast<const float4*>(add)[i];
-                o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
+            if (add) { o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w; }
+            return o;
+        };
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int r = r_begin + rr;
+        // four rows in flight per thread: the loads of a row do not depend on the previous one
+        for (; r + 3 * RP < r_end; r += 4 * RP) {
+            float4 g[4], x[4], o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = (size_t)(r + u * RP) * Q + q;
+                g[u] = reinterpret_cast<const float4*>(G)[i];
+                x[u] = reinterpret_cast<const float4*>(X)[i];
+                o[u] = add ? reinterpret_cast<const float4*>(add)[i] : zero4;
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = (size_t)(r + u * RP) * Q + q;
+                o[u] = one(g[u], x[u], o[u]);
+                reinterpret_cast<float4*>(dX)[i] = o[u];
+                sa.x += o[u].x; sa.y += o[u].y; sa.z += o[u].z; sa.w += o[u].w;
+            }
+        }
+        for (; r < r_end; r += RP) {
+            const size_t i = (size_t)r * Q + q;
+            const float4 g = reinterpret_cast<const float4*>(G)[i];
+            const float4 x = reinterpret_cast<const float4*>(X)[i];
+            const float4 o = one(g, x, add ? reinterpret_cast<const float4*>(add)[i] : zero4);
             reinterpret_cast<float4*>(dX)[i] = o;
             sa.x += o.x; sa.y += o.y; sa.z += o.z; sa.w += o.w;
         }
@@ -276,8 +298,12 @@ extern "C" int dpp_bn_finalize(const float* partial, int nb, int M, int rows_per
                                float* mean, float* inv_std, float* scale, float* run_mean, float* run_inv_std, float alpha,
                                dpp_stream_t stream) {
     if (!partial || !gamma || !mean || !inv_std || !scale || nb != dpp_cdiv(M, rows_per_block)) return DPP_E_BADARG;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dpp_cdiv(C, DPP_THREADS / DPP_WAVE)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
-                       partial, nb, M, rows_per_block, C, gamma, eps, mean, inv_std, scale, run_mean, run_inv_std, alpha);
+    const dim3 grid(dpp_cdiv(C, DPP_THREADS / DPP_WAVE));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define DPP_BNF(U_) hipLaunchKernelGGL(bn_finalize_kernel<U_>, grid, dim3(DPP_THREADS), 0, st, partial, nb, M, rows_per_block, C, gamma, eps, \
+                                       mean, inv_std, scale, run_mean, run_inv_std, alpha)
+    if (nb <= 2 * DPP_WAVE) DPP_BNF(2); else if (nb <= 8 * DPP_WAVE) DPP_BNF(8); else DPP_BNF(32);
+#undef DPP_BNF
     return dpp_launch_status();
 }
 
@@ -302,8 +328,11 @@ extern "C" int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, 
 extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int M, int C, float* dbeta, float* dgamma, float* c1, float* c2,
                                    dpp_stream_t stream) {
     if (!partial || !dbeta || !dgamma || !c1 || !c2 || nb < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(dpp_cdiv(C, DPP_THREADS / DPP_WAVE)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
-                       partial, nb, M, C, dbeta, dgamma, c1, c2);
+    const dim3 grid(dpp_cdiv(C, DPP_THREADS / DPP_WAVE));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define DPP_BNBF(U_) hipLaunchKernelGGL(bn_bwd_finalize_kernel<U_>, grid, dim3(DPP_THREADS), 0, st, partial, nb, M, C, dbeta, dgamma, c1, c2)
+    if (nb <= 2 * DPP_WAVE) DPP_BNBF(2); else if (nb <= 8 * DPP_WAVE) DPP_BNBF(8); else DPP_BNBF(32);
+#undef DPP_BNBF
     return dpp_launch_status();
 }
 
