@@ -135,11 +135,16 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_fwd_kernel(const float* __re
     }
 }
 
-// thread = (o = tid % Co', pixel group); accumulates the 25 taps in registers
+// thread = (o = tid % Co', pixel group); accumulates the 25 taps in registers.  The kernel is bound by instruction issue (one
+// LDS read per FMA when every tap is fetched separately, and the constant background of a depth crop ties all four window
+// pixels, i.e. four passes over the taps), so the 6x6 input patch under a pooling window is read ONCE into registers with
+// 8-byte LDS reads (18 instead of up to 100) and the tied window pixels take their taps from there.
+constexpr int LXW = LX + 2;        // 22: even row pitch, so a window's patch rows start 8-byte aligned
+
 __global__ __launch_bounds__(DPP_THREADS) void stem_wgrad_kernel(const float* __restrict__ X, int N, int H, int W, const float* __restrict__ dY,
                                                                  const uint8_t* __restrict__ arg, int Co, float* __restrict__ partial,
                                                                  int tiles_x, int tiles_y, int tiles_per_block, int total_tiles) {
-    __shared__ float xs[LX * LXP];
+    __shared__ __attribute__((aligned(16))) float xs[LX * LXW];
     __shared__ float red[DPP_THREADS * NTAP];     // 25.6 KB
     const int tid = threadIdx.x;
     const int o = tid % Co, pg = tid / Co, npg = DPP_THREADS / Co;
@@ -153,26 +158,46 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_wgrad_kernel(const float* __
         const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int cy0 = by * TC, cx0 = bx * TC;
         const float* img = X + (size_t)n * H * W;
+        // pooled gradient and tie mask of pooled output p (0 when p is outside the tile / the map)
+        auto fetch = [&](int p, float& g, int& ties) {
+            const int py = (cy0 >> 1) + (p >> 3), px = (cx0 >> 1) + (p & 7);
+            const bool ok = p < 64 && py < Hp && px < Wp;
+            const size_t idx = ok ? (((size_t)n * Hp + py) * Wp + px) * Co + o : 0;
+            g = ok ? dY[idx] : 0.0f;
+            ties = ok ? (int)arg[idx] : 0;
+        };
+        float g_next = 0.0f;
+        int t_next = 0;
+        if (pg < npg) fetch(pg, g_next, t_next);
         __syncthreads();
         for (int s = tid; s < LX * LX; s += DPP_THREADS) {
             int hy = s / LX, hx = s - hy * LX;
             int y = cy0 + hy - PAD, x = cx0 + hx - PAD;
-            xs[hy * LXP + hx] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : 0.0f;
+            xs[hy * LXW + hx] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : 0.0f;
         }
         __syncthreads();
         if (pg < npg) {
+#pragma unroll 1
             for (int p = pg; p < 64; p += npg) {          // 8x8 pooled outputs of the tile
-                int ply = p >> 3, plx = p & 7;
-                int py = (cy0 >> 1) + ply, px = (cx0 >> 1) + plx;
-                if (py >= Hp || px >= Wp) continue;
-                size_t idx = (((size_t)n * Hp + py) * Wp + px) * Co + o;
-                float g = dY[idx];
-                int ties = arg[idx];
+                const float g = g_next;
+                const int ties = t_next;
+                fetch(p + npg, g_next, t_next);           // the next output's loads fly under this one's FMAs
+                if (ties == 0) continue;
+                const int ply = p >> 3, plx = p & 7;
+                float patch[6][6];
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c2 = 0; c2 < 3; ++c2) {
+                        const float2 v = *reinterpret_cast<const float2*>(&xs[(2 * ply + r) * LXW + 2 * plx + 2 * c2]);
+                        patch[r][2 * c2] = v.x;
+                        patch[r][2 * c2 + 1] = v.y;
+                    }
+#pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     if (!((ties >> a) & 1)) continue;
-                    const float* base = &xs[(2 * ply + (a >> 1)) * LXP + 2 * plx + (a & 1)];
 #pragma unroll
-                    for (int k = 0; k < NTAP; ++k) acc[k] += g * base[(k / KS) * LXP + (k % KS)];
+                    for (int k = 0; k < NTAP; ++k) acc[k] += g * patch[(a >> 1) + k / KS][(a & 1) + k % KS];
                 }
             }
         }
