@@ -58,8 +58,8 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_stats_partial_kernel(const flo
             m2 += m2b + delta * delta * cn * nb / tot;
             cn = tot;
         }
-        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = (float)mean;
-        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = (float)m2;
+        partial[dpp_partial_index(0, c, blockIdx.x, C, gridDim.x)] = (float)mean;
+        partial[dpp_partial_index(1, c, blockIdx.x, C, gridDim.x)] = (float)m2;
     }
 }
 
@@ -74,7 +74,7 @@ __device__ __forceinline__ void chan_combine(double& n, double& mean, double& m2
 }
 
 template <int U>
-__global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* __restrict__ partial, int nb, int M, int rpb,
+__global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* __restrict__ partial, int nbs, int nseg, int M, int rpb,
                                                                   int C, const float* __restrict__ gamma, float eps,
                                                                   float* __restrict__ mean_o, float* __restrict__ inv_std_o,
                                                                   float* __restrict__ scale_o, float* __restrict__ run_mean,
@@ -83,6 +83,12 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
     const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
     const int cc = c < C ? c : C - 1;                  // keep every lane in the shuffles
     double cn = 0.0, mean = 0.0, m2 = 0.0;
+    // partial block b of the whole batch = block b % nbs of segment b / nbs (segments: the ranks of a sync-BN all-gather)
+    const int nb = nbs * nseg, Mseg = M / nseg;
+    auto addr = [&](int s, int b) {
+        const int seg = b / nbs, bi = b - seg * nbs;
+        return (size_t)seg * 2 * C * nbs + dpp_partial_index(s, cc, bi, C, nbs);
+    };
     // the loads of U partials are issued together (the Chan update is a dependent chain: one L2 round trip per step otherwise);
     // the launcher picks U so that a lane needs one or two batches
     for (int b0 = lane; b0 < nb; b0 += DPP_WAVE * U) {
@@ -91,14 +97,15 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
         for (int u = 0; u < U; ++u) {
             const int b = b0 + u * DPP_WAVE;
             const int bb = b < nb ? b : nb - 1;
-            pm[u] = partial[((size_t)bb * 2 + 0) * C + cc];
-            pq[u] = partial[((size_t)bb * 2 + 1) * C + cc];
+            pm[u] = partial[addr(0, bb)];
+            pq[u] = partial[addr(1, bb)];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int b = b0 + u * DPP_WAVE;
             if (b < nb) {
-                int rows = (b * rpb + rpb <= M) ? rpb : (M - b * rpb);
+                const int bi = b % nbs;
+                int rows = (bi * rpb + rpb <= Mseg) ? rpb : (Mseg - bi * rpb);
                 chan_combine(cn, mean, m2, (double)rows, (double)pm[u], (double)pq[u]);
             }
         }
@@ -179,27 +186,32 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float*
             a += (double)s_a[t * 4 + ce];
             b += (double)s_b[t * 4 + ce];
         }
-        partial[((size_t)blockIdx.x * 2 + 0) * C + c] = (float)a;
-        partial[((size_t)blockIdx.x * 2 + 1) * C + c] = (float)b;
+        partial[dpp_partial_index(0, c, blockIdx.x, C, gridDim.x)] = (float)a;
+        partial[dpp_partial_index(1, c, blockIdx.x, C, gridDim.x)] = (float)b;
     }
 }
 
 template <int U>
-__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int M, int C,
+__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nbs, int nseg, int M, int C,
                                                                       float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                                       float* __restrict__ c1, float* __restrict__ c2) {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
     const int cc = c < C ? c : C - 1;
     double a = 0.0, b = 0.0;
+    const int nb = nbs * nseg;
+    auto addr = [&](int s, int k) {
+        const int seg = k / nbs, ki = k - seg * nbs;
+        return (size_t)seg * 2 * C * nbs + dpp_partial_index(s, cc, ki, C, nbs);
+    };
     for (int k0 = lane; k0 < nb; k0 += DPP_WAVE * U) {
         float pa[U], pb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + u * DPP_WAVE;
             const int kk = k < nb ? k : nb - 1;
-            pa[u] = partial[((size_t)kk * 2 + 0) * C + cc];
-            pb[u] = partial[((size_t)kk * 2 + 1) * C + cc];
+            pa[u] = partial[addr(0, kk)];
+            pb[u] = partial[addr(1, kk)];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -294,15 +306,17 @@ extern "C" int dpp_bn_stats_partial(const float* X, int M, int C, int rows_per_b
     return dpp_launch_status();
 }
 
-extern "C" int dpp_bn_finalize(const float* partial, int nb, int M, int rows_per_block, int C, const float* gamma, float eps,
+extern "C" int dpp_bn_finalize(const float* partial, int nb, int nseg, int M, int rows_per_block, int C, const float* gamma, float eps,
                                float* mean, float* inv_std, float* scale, float* run_mean, float* run_inv_std, float alpha,
                                dpp_stream_t stream) {
-    if (!partial || !gamma || !mean || !inv_std || !scale || nb != dpp_cdiv(M, rows_per_block)) return DPP_E_BADARG;
+    if (!partial || !gamma || !mean || !inv_std || !scale || nseg < 1 || M % nseg || nb != dpp_cdiv(M / nseg, rows_per_block))
+        return DPP_E_BADARG;
     const dim3 grid(dpp_cdiv(C, DPP_THREADS / DPP_WAVE));
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DPP_BNF(U_) hipLaunchKernelGGL(bn_finalize_kernel<U_>, grid, dim3(DPP_THREADS), 0, st, partial, nb, M, rows_per_block, C, gamma, eps, \
+#define DPP_BNF(U_) hipLaunchKernelGGL(bn_finalize_kernel<U_>, grid, dim3(DPP_THREADS), 0, st, partial, nb, nseg, M, rows_per_block, C, gamma, eps, \
                                        mean, inv_std, scale, run_mean, run_inv_std, alpha)
-    if (nb <= 2 * DPP_WAVE) DPP_BNF(2); else if (nb <= 8 * DPP_WAVE) DPP_BNF(8); else DPP_BNF(32);
+    const int tot = nb * nseg;
+    if (tot <= 2 * DPP_WAVE) DPP_BNF(2); else if (tot <= 8 * DPP_WAVE) DPP_BNF(8); else DPP_BNF(32);
 #undef DPP_BNF
     return dpp_launch_status();
 }
@@ -325,13 +339,14 @@ extern "C" int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, 
     return dpp_launch_status();
 }
 
-extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int M, int C, float* dbeta, float* dgamma, float* c1, float* c2,
-                                   dpp_stream_t stream) {
-    if (!partial || !dbeta || !dgamma || !c1 || !c2 || nb < 1) return DPP_E_BADARG;
+extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M, int C, float* dbeta, float* dgamma, float* c1,
+                                   float* c2, dpp_stream_t stream) {
+    if (!partial || !dbeta || !dgamma || !c1 || !c2 || nb < 1 || nseg < 1) return DPP_E_BADARG;
     const dim3 grid(dpp_cdiv(C, DPP_THREADS / DPP_WAVE));
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DPP_BNBF(U_) hipLaunchKernelGGL(bn_bwd_finalize_kernel<U_>, grid, dim3(DPP_THREADS), 0, st, partial, nb, M, C, dbeta, dgamma, c1, c2)
-    if (nb <= 2 * DPP_WAVE) DPP_BNBF(2); else if (nb <= 8 * DPP_WAVE) DPP_BNBF(8); else DPP_BNBF(32);
+#define DPP_BNBF(U_) hipLaunchKernelGGL(bn_bwd_finalize_kernel<U_>, grid, dim3(DPP_THREADS), 0, st, partial, nb, nseg, M, C, dbeta, dgamma, c1, c2)
+    const int tot = nb * nseg;
+    if (tot <= 2 * DPP_WAVE) DPP_BNBF(2); else if (tot <= 8 * DPP_WAVE) DPP_BNBF(8); else DPP_BNBF(32);
 #undef DPP_BNBF
     return dpp_launch_status();
 }

@@ -251,8 +251,8 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
                 for (int ct = 0; ct < CN; ++ct) {
                     int col = cbase + ct * 16;
                     if (col < a.Co) {
-                        ep.bn_partial[((size_t)blockIdx.x * 2 + 0) * a.Co + col] = sx[ct];
-                        ep.bn_partial[((size_t)blockIdx.x * 2 + 1) * a.Co + col] = sy[ct];
+                        ep.bn_partial[dpp_partial_index(0, col, blockIdx.x, a.Co, gridDim.x)] = sx[ct];
+                        ep.bn_partial[dpp_partial_index(1, col, blockIdx.x, a.Co, gridDim.x)] = sy[ct];
                     }
                 }
             }
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
                 for (int ct = 0; ct < CN; ++ct) {
                     int col = cbase + ct * 16;
                     if (col < a.Co) {
-                        ep.stats[((size_t)blockIdx.x * 2 + 0) * a.Co + col] = sm[ct];
-                        ep.stats[((size_t)blockIdx.x * 2 + 1) * a.Co + col] = m2[ct];
+                        ep.stats[dpp_partial_index(0, col, blockIdx.x, a.Co, gridDim.x)] = sm[ct];
+                        ep.stats[dpp_partial_index(1, col, blockIdx.x, a.Co, gridDim.x)] = m2[ct];
                     }
                 }
             }

@@ -59,6 +59,13 @@ __device__ __forceinline__ float dpp_f4_get(const float4& v, int i) {
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
 
+// Layout of the per-workgroup BatchNorm partials (forward statistics (mean, M2) and backward sums (sum G, sum G*xhat)):
+// partial[s][c][b], s in {0, 1}, c the channel, b the row block (= blockIdx.x of the producer, NB = gridDim.x of them).
+// Block-fastest, so that the finalize kernels -- one wave per channel, lanes over blocks -- read 256 contiguous bytes per
+// load; with [b][s][c] every lane of such a load touched its own cache line and a 2048-block finalize took 10-20 us.
+__device__ __forceinline__ size_t dpp_partial_index(int s, int c, int b, int C, int NB) { return ((size_t)s * C + c) * NB + b; }
+
+
 // ---- column reductions of an MFMA output tile in the D layout ----------------------------------------------------------
 // A wave holds RM x CN tiles of 16x16: lane (l15 = column, kq = row quad), register r -> row kq*4 + r.  `s[ct]` enters as
 // this lane's partial sum for column tile ct and leaves as the sum over ALL rows of the workgroup tile (every lane of the
@@ -207,8 +214,8 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
         if (tid < Q && cin) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ep.bn_partial[((size_t)blockIdx.x * 2 + 0) * N + col + j] = sx[j];
-                ep.bn_partial[((size_t)blockIdx.x * 2 + 1) * N + col + j] = sy[j];
+                ep.bn_partial[dpp_partial_index(0, col + j, blockIdx.x, N, gridDim.x)] = sx[j];
+                ep.bn_partial[dpp_partial_index(1, col + j, blockIdx.x, N, gridDim.x)] = sy[j];
             }
         }
     }
@@ -242,8 +249,8 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
         if (tid < Q && cin) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ep.stats[((size_t)blockIdx.x * 2 + 0) * N + col + j] = sm[j];
-                ep.stats[((size_t)blockIdx.x * 2 + 1) * N + col + j] = m2[j];
+                ep.stats[dpp_partial_index(0, col + j, blockIdx.x, N, gridDim.x)] = sm[j];
+                ep.stats[dpp_partial_index(1, col + j, blockIdx.x, N, gridDim.x)] = m2[j];
             }
         }
     }

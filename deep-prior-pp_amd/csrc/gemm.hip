@@ -128,8 +128,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[RM][CN], const dpp_ge
                 for (int ct = 0; ct < CN; ++ct) {
                     int col = cbase + ct * 16;
                     if (col < N) {
-                        ep.bn_partial[((size_t)blockIdx.x * 2 + 0) * N + col] = sx[ct];
-                        ep.bn_partial[((size_t)blockIdx.x * 2 + 1) * N + col] = sy[ct];
+                        ep.bn_partial[dpp_partial_index(0, col, blockIdx.x, N, gridDim.x)] = sx[ct];
+                        ep.bn_partial[dpp_partial_index(1, col, blockIdx.x, N, gridDim.x)] = sy[ct];
                     }
                 }
             }
@@ -169,8 +169,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[RM][CN], const dpp_ge
                 for (int ct = 0; ct < CN; ++ct) {
                     int col = cbase + ct * 16;
                     if (col < N) {
-                        ep.stats[((size_t)blockIdx.x * 2 + 0) * N + col] = sm[ct];
-                        ep.stats[((size_t)blockIdx.x * 2 + 1) * N + col] = m2[ct];
+                        ep.stats[dpp_partial_index(0, col, blockIdx.x, N, gridDim.x)] = sm[ct];
+                        ep.stats[dpp_partial_index(1, col, blockIdx.x, N, gridDim.x)] = m2[ct];
                     }
                 }
             }

@@ -127,8 +127,8 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_fwd_kernel(const float* __re
             for (int ct = 0; ct < CN; ++ct) {
                 int col = ct * 16 + l15;
                 if (col < Co) {
-                    stats[((size_t)blockIdx.x * 2 + 0) * Co + col] = sm[ct];
-                    stats[((size_t)blockIdx.x * 2 + 1) * Co + col] = m2[ct];
+                    stats[dpp_partial_index(0, col, blockIdx.x, Co, gridDim.x)] = sm[ct];
+                    stats[dpp_partial_index(1, col, blockIdx.x, Co, gridDim.x)] = m2[ct];
                 }
             }
         }

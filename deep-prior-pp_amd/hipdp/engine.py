@@ -563,8 +563,8 @@ class CompiledNet(object):
                     allp = self.scratch(b.nb * 2 * C * (W + 1)).view(b.nb * 2 * C, (W * b.nb * 2 * C,))
                     self.fwd.add(self.dp.all_gather_op(part, allp, 'bn_stats_allgather'))
                     part = allp
-                self.fwd.add(ops.bn_finalize(rt, part, b.nb * W, M * W, b.rpb, C, b.gamma_buf, layer.cfgParams.epsilon, b.mean, b.inv_std,
-                                             b.scale, b.run_mean, b.run_inv_std, layer.cfgParams.alpha))
+                self.fwd.add(ops.bn_finalize(rt, part, b.nb, M * W, b.rpb, C, b.gamma_buf, layer.cfgParams.epsilon, b.mean, b.inv_std,
+                                             b.scale, b.run_mean, b.run_inv_std, layer.cfgParams.alpha, nseg=W))
             else:
                 self.fwd.add(ops.bn_eval_coeffs(rt, b.gamma_buf, b.run_mean, b.run_inv_std, C, b.mean, b.inv_std, b.scale))
             v = View(src.base, b, False, shape=src.shape, chan=src.chan)
@@ -782,7 +782,8 @@ class CompiledNet(object):
         # with sync-BN dbeta / dgamma are already global sums on every rank: pre-divide so that the gradient all-reduce
         # (a sum over ranks) leaves them unchanged
         if fused is None:
-            self.bwd.add(ops.bn_bwd_finalize(rt, part, b.nb * W, M * W, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2))
+            self.bwd.add(ops.bn_bwd_finalize(rt, part, b.nb, M * W, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2,
+                                             nseg=W))
         if W > 1:
             for prm in (b.layer.beta, b.layer.gamma):
                 gv = st.view(prm, 'g')

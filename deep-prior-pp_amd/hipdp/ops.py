@@ -199,8 +199,9 @@ def bn_stats_partial(rt, X, M, Cc, rpb, partial, name='bn_stats_partial'):
 
 
 def bn_finalize(rt, partial, nb, M, rpb, Cc, gamma, eps, mean, inv_std, scale, run_mean=None, run_inv_std=None, alpha=0.0,
-                name='bn_finalize'):
-    return Launch(rt.lib.dpp_bn_finalize, (partial.ptr, nb, M, rpb, Cc, gamma.ptr, float(eps), mean.ptr, inv_std.ptr, scale.ptr,
+                nseg=1, name='bn_finalize'):
+    """partial: nseg segments of [2][Cc][nb] (nb blocks per segment), M rows over all segments."""
+    return Launch(rt.lib.dpp_bn_finalize, (partial.ptr, nb, int(nseg), M, rpb, Cc, gamma.ptr, float(eps), mean.ptr, inv_std.ptr, scale.ptr,
                                            _p(run_mean), _p(run_inv_std), float(alpha)),
                   (partial, gamma, mean, inv_std, scale, run_mean, run_inv_std), name,
                   dict(kernel='bn_finalize', flops=0.0, bytes=8.0 * nb * Cc))
@@ -217,8 +218,8 @@ def bn_bwd_reduce(rt, dA, X, M, Cc, mean, inv_std, scale, beta, relu, G, rpb, pa
                   dict(kernel='bn_bwd_reduce', flops=8.0 * M * Cc, bytes=12.0 * M * Cc))
 
 
-def bn_bwd_finalize(rt, partial, nb, M, Cc, dbeta, dgamma, c1, c2, name='bn_bwd_finalize'):
-    return Launch(rt.lib.dpp_bn_bwd_finalize, (partial.ptr, nb, M, Cc, dbeta.ptr, dgamma.ptr, c1.ptr, c2.ptr),
+def bn_bwd_finalize(rt, partial, nb, M, Cc, dbeta, dgamma, c1, c2, nseg=1, name='bn_bwd_finalize'):
+    return Launch(rt.lib.dpp_bn_bwd_finalize, (partial.ptr, nb, int(nseg), M, Cc, dbeta.ptr, dgamma.ptr, c1.ptr, c2.ptr),
                   (partial, dbeta, dgamma, c1, c2), name, dict(kernel='bn_bwd_finalize', flops=0.0, bytes=8.0 * nb * Cc))
 
 

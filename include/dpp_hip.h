@@ -34,7 +34,7 @@ typedef void* dpp_stream_t; /* a hipStream_t */
 #define DPP_E_BADARG 10001
 #define DPP_E_UNSUPPORTED 10002
 
-#define DPP_ABI_VERSION 1
+#define DPP_ABI_VERSION 2
 int dpp_abi_version(void);
 
 /* Pixel row map: row m of a compact (N,Ho,Wo) map -> row of a (N,Hi,Wi) map sampled with stride s.
@@ -56,11 +56,12 @@ typedef struct {
 } dpp_act;
 
 /* Optional fused epilogue work on the output tile (both NULL = plain epilogue).
- *   stats      [row_blocks][2][N]: per-workgroup-row-block (mean, M2) of every output column, i.e. the partial BatchNorm
- *              statistics of the tensor being written (batchnormlayer.py:154-155) -- saves the separate statistics pass;
- *              combine with dpp_bn_finalize(partial = stats, nb = row_blocks, rows_per_block = tile rows).
+ *   stats      [2][N][row_blocks] (block index fastest, see the BatchNorm section): per-workgroup-row-block (mean, M2) of
+ *              every output column, i.e. the partial BatchNorm statistics of the tensor being written
+ *              (batchnormlayer.py:154-155) -- saves the separate statistics pass; combine with
+ *              dpp_bn_finalize(partial = stats, nb = row_blocks, rows_per_block = tile rows).
  *   bn_x ...   BatchNorm-backward fusion for a data-gradient call: the value written is G = acc * [ (x-mean)*scale+beta >= 0 ]
- *              (bn_relu != 0) with x = bn_x at the output's index, and bn_partial [row_blocks][2][N] receives the per-block
+ *              (bn_relu != 0) with x = bn_x at the output's index, and bn_partial [2][N][row_blocks] receives the per-block
  *              (sum G, sum G*xhat), xhat = (x-mean)*inv_std: exactly what dpp_bn_bwd_reduce would produce. */
 typedef struct {
     float* stats;
@@ -139,7 +140,7 @@ int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act
  * 2x2 window (bit j set = window element j, row-major, equals the maximum), kept for the filter gradient: Theano's
  * MaxPoolGrad gives the gradient to every element equal to the maximum, and the constant background of a depth crop
  * makes whole windows tie.
- * stats (may be NULL; needs H % 16 == W % 16 == 0): [N * H/16 * W/16][2][Co] per-tile (mean, M2) of the 64 pooled outputs a
+ * stats (may be NULL; needs H % 16 == W % 16 == 0): [2][Co][N * H/16 * W/16] per-tile (mean, M2) of the 64 pooled outputs a
  * workgroup writes -- the BatchNorm statistics partial of Y, combined by dpp_bn_finalize(rows_per_block = 64). */
 int dpp_stem_fwd(const float* X, int N, int H, int W, const float* Wk, const float* bias, int Co, float* Y, uint8_t* argmax,
                  float* stats, dpp_stream_t stream);
@@ -165,15 +166,17 @@ int dpp_convpool_dgrad(const float* dY, const uint16_t* ties, int N, int H, int 
                        int pad, int Co, int pool, float* dX, dpp_stream_t stream);
 
 /* ---- BatchNormLayer, /root/reference/src/net/batchnormlayer.py:119-194 (tensors pixel-major [M][C], C % 4 == 0) ----
- * stats_partial: per row-chunk (mean_b, M2_b) -> partial[nb][2][C], nb = ceil(M / rows_per_block)
+ * stats_partial: per row-chunk (mean_b, M2_b) -> partial[2][C][nb], nb = ceil(M / rows_per_block); the block index is the
+ *                fastest one so that the finalize (one wave per channel, lanes over blocks) reads contiguous memory
  * finalize:      batch mean, inv_std = 1/sqrt(var_biased + eps), scale = gamma*inv_std; running mean / inv_std EMA
- *                (alpha = 0 or run_mean == NULL: no update)
+ *                (alpha = 0 or run_mean == NULL: no update).  `partial` holds nseg consecutive [2][C][nb] segments (nseg = 1,
+ *                or the ranks of a synchronised-BatchNorm all-gather) covering M rows in total, M / nseg per segment
  * eval_coeffs:   deterministic mode: mean = run_mean, inv_std = run_inv_std, scale = gamma*run_inv_std
- * bwd_reduce:    G = dA * [ (x-mean)*scale+beta >= 0 ] (relu != 0) or dA; partial[nb][2][C] = sum G, sum G*xhat
+ * bwd_reduce:    G = dA * [ (x-mean)*scale+beta >= 0 ] (relu != 0) or dA; partial[2][C][nb] = sum G, sum G*xhat
  * bwd_finalize:  dbeta, dgamma and c1 = dbeta/M, c2 = dgamma/M
  * bwd_apply:     dX = scale * (G - c1 - xhat*c2) + add      (gradient through the batch statistics) */
 int dpp_bn_stats_partial(const float* X, int M, int C, int rows_per_block, float* partial, dpp_stream_t stream);
-int dpp_bn_finalize(const float* partial, int nb, int M, int rows_per_block, int C, const float* gamma, float eps,
+int dpp_bn_finalize(const float* partial, int nb, int nseg, int M, int rows_per_block, int C, const float* gamma, float eps,
                     float* mean, float* inv_std, float* scale, float* run_mean, float* run_inv_std, float alpha,
                     dpp_stream_t stream);
 int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, const float* run_inv_std, int C, float* mean,
@@ -181,7 +184,7 @@ int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, const float* r
 int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, const float* mean, const float* inv_std,
                       const float* scale, const float* beta, int relu, float* G, int rows_per_block, float* partial,
                       dpp_stream_t stream);
-int dpp_bn_bwd_finalize(const float* partial, int nb, int M, int C, float* dbeta, float* dgamma, float* c1, float* c2,
+int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M, int C, float* dbeta, float* dgamma, float* c1, float* c2,
                         dpp_stream_t stream);
 int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
                      const float* scale, const float* c1, const float* c2, const float* add, float* dX,
