@@ -63,14 +63,16 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_stats_partial_kernel(const flo
     }
 }
 
-// One wave per channel: lane l combines partials l, l+64, ... (Chan), then a 6-step shuffle tree combines the lanes --
-// a fixed, data-independent order (deterministic).  4 channels per 256-thread workgroup.
-__device__ __forceinline__ void chan_combine(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
-    if (nb == 0.0) return;
-    double tot = n + nb, delta = mb - mean;
-    mean += delta * nb / tot;
-    m2 += m2b + delta * delta * n * nb / tot;
-    n = tot;
+// One wave per channel, lane l owns partial blocks l, l+64, ... (contiguous in memory, see dpp_partial_index).  The per-block
+// (mean, M2) pairs are combined in two passes over the partials (the second one re-reads them from L2) instead of a chain of
+// pairwise Chan updates:
+//     mean = sum_b n_b mean_b / sum_b n_b ,   M2 = sum_b [ M2_b + n_b (mean_b - mean)^2 ]
+// -- the same quantity, no cancellation (deviations from the final mean), and no dependent f64 division per partial, which is
+// what the finalize of a stage-1 layer (2048 partial blocks, 8192 for the stem) spent its time on once the loads were
+// coalesced.  All sums are f64 in a fixed order; lanes meet in an xor butterfly (every lane ends with the same value).
+__device__ __forceinline__ double wave_allsum(double v) {
+    for (int o = 1; o < DPP_WAVE; o <<= 1) v += __shfl_xor(v, o);
+    return v;
 }
 
 template <int U>
@@ -82,40 +84,52 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
     const int cc = c < C ? c : C - 1;                  // keep every lane in the shuffles
-    double cn = 0.0, mean = 0.0, m2 = 0.0;
-    // partial block b of the whole batch = block b % nbs of segment b / nbs (segments: the ranks of a sync-BN all-gather)
-    const int nb = nbs * nseg, Mseg = M / nseg;
-    auto addr = [&](int s, int b) {
-        const int seg = b / nbs, bi = b - seg * nbs;
-        return (size_t)seg * 2 * C * nbs + dpp_partial_index(s, cc, bi, C, nbs);
-    };
-    // the loads of U partials are issued together (the Chan update is a dependent chain: one L2 round trip per step otherwise);
-    // the launcher picks U so that a lane needs one or two batches
-    for (int b0 = lane; b0 < nb; b0 += DPP_WAVE * U) {
-        float pm[U], pq[U];
+    // `partial` holds nseg segments (the ranks of a sync-BN all-gather) of nbs blocks each; a lane walks blocks lane, lane+64,
+    // ... of every segment (no integer division per partial: this kernel is a few microseconds of pure latency)
+    const int Mseg = M / nseg;
+    auto rows_of = [&](int bi) { return (bi * rpb + rpb <= Mseg) ? rpb : (Mseg - bi * rpb); };
+    double snm = 0.0;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const float* pm_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
+        for (int b0 = lane; b0 < nbs; b0 += DPP_WAVE * U) {
+            float pm[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int b = b0 + u * DPP_WAVE;
-            const int bb = b < nb ? b : nb - 1;
-            pm[u] = partial[addr(0, bb)];
-            pq[u] = partial[addr(1, bb)];
-        }
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + u * DPP_WAVE;
+                pm[u] = pm_row[b < nbs ? b : nbs - 1];
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int b = b0 + u * DPP_WAVE;
-            if (b < nb) {
-                const int bi = b % nbs;
-                int rows = (bi * rpb + rpb <= Mseg) ? rpb : (Mseg - bi * rpb);
-                chan_combine(cn, mean, m2, (double)rows, (double)pm[u], (double)pq[u]);
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + u * DPP_WAVE;
+                if (b < nbs) snm += (double)rows_of(b) * (double)pm[u];
             }
         }
     }
-    for (int o = 1; o < DPP_WAVE; o <<= 1) {
-        double on = __shfl_xor(cn, o), om = __shfl_xor(mean, o), o2 = __shfl_xor(m2, o);
-        // combine in a lane-symmetric order so that both partners compute the same value
-        if (lane & o) { double tn = on, tm = om, t2 = o2; chan_combine(tn, tm, t2, cn, mean, m2); cn = tn; mean = tm; m2 = t2; }
-        else chan_combine(cn, mean, m2, on, om, o2);
+    const double mean = wave_allsum(snm) / (double)M;  // sum_b n_b = M
+    double q = 0.0;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const float* pm_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
+        const float* pq_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(1, cc, 0, C, nbs);
+        for (int b0 = lane; b0 < nbs; b0 += DPP_WAVE * U) {
+            float pm[U], pq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + u * DPP_WAVE;
+                const int bb = b < nbs ? b : nbs - 1;
+                pm[u] = pm_row[bb];
+                pq[u] = pq_row[bb];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int b = b0 + u * DPP_WAVE;
+                if (b < nbs) {
+                    const double d = (double)pm[u] - mean;
+                    q += (double)pq[u] + (double)rows_of(b) * d * d;
+                }
+            }
+        }
     }
+    const double m2 = wave_allsum(q);
     if (lane != 0 || c >= C) return;
     double var = m2 / (double)M;                       // biased, T.var
     float meanf = (float)mean;
@@ -199,23 +213,22 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const floa
     const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
     const int cc = c < C ? c : C - 1;
     double a = 0.0, b = 0.0;
-    const int nb = nbs * nseg;
-    auto addr = [&](int s, int k) {
-        const int seg = k / nbs, ki = k - seg * nbs;
-        return (size_t)seg * 2 * C * nbs + dpp_partial_index(s, cc, ki, C, nbs);
-    };
-    for (int k0 = lane; k0 < nb; k0 += DPP_WAVE * U) {
-        float pa[U], pb[U];
+    for (int seg = 0; seg < nseg; ++seg) {
+        const float* pa_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
+        const float* pb_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(1, cc, 0, C, nbs);
+        for (int k0 = lane; k0 < nbs; k0 += DPP_WAVE * U) {
+            float pa[U], pb[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = k0 + u * DPP_WAVE;
-            const int kk = k < nb ? k : nb - 1;
-            pa[u] = partial[addr(0, kk)];
-            pb[u] = partial[addr(1, kk)];
+            for (int u = 0; u < U; ++u) {
+                const int k = k0 + u * DPP_WAVE;
+                const int kk = k < nbs ? k : nbs - 1;
+                pa[u] = pa_row[kk];
+                pb[u] = pb_row[kk];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + u * DPP_WAVE < nbs) { a += (double)pa[u]; b += (double)pb[u]; }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (k0 + u * DPP_WAVE < nb) { a += (double)pa[u]; b += (double)pb[u]; }
     }
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
     if (lane != 0 || c >= C) return;
@@ -315,7 +328,7 @@ extern "C" int dpp_bn_finalize(const float* partial, int nb, int nseg, int M, in
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define DPP_BNF(U_) hipLaunchKernelGGL(bn_finalize_kernel<U_>, grid, dim3(DPP_THREADS), 0, st, partial, nb, nseg, M, rows_per_block, C, gamma, eps, \
                                        mean, inv_std, scale, run_mean, run_inv_std, alpha)
-    const int tot = nb * nseg;
+    const int tot = nb;      // blocks a lane walks per segment decide the load batch
     if (tot <= 2 * DPP_WAVE) DPP_BNF(2); else if (tot <= 8 * DPP_WAVE) DPP_BNF(8); else DPP_BNF(32);
 #undef DPP_BNF
     return dpp_launch_status();
@@ -345,7 +358,7 @@ extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M
     const dim3 grid(dpp_cdiv(C, DPP_THREADS / DPP_WAVE));
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define DPP_BNBF(U_) hipLaunchKernelGGL(bn_bwd_finalize_kernel<U_>, grid, dim3(DPP_THREADS), 0, st, partial, nb, nseg, M, C, dbeta, dgamma, c1, c2)
-    const int tot = nb * nseg;
+    const int tot = nb;      // blocks a lane walks per segment decide the load batch
     if (tot <= 2 * DPP_WAVE) DPP_BNBF(2); else if (tot <= 8 * DPP_WAVE) DPP_BNBF(8); else DPP_BNBF(32);
 #undef DPP_BNBF
     return dpp_launch_status();
