@@ -75,14 +75,30 @@ __device__ __forceinline__ double wave_allsum(double v) {
     return v;
 }
 
-template <int U>
+// Sum over the WPC waves that share a channel (WPC = 1: the wave; WPC = 4: the whole workgroup, through LDS in wave order).
+// Every thread of the workgroup must call it; `slot` is a distinct LDS array per call site.
+template <int WPC>
+__device__ __forceinline__ double group_allsum(double v, double* slot) {
+    v = wave_allsum(v);
+    if (WPC == 1) return v;
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) slot[wave] = v;
+    __syncthreads();
+    return ((slot[0] + slot[1]) + slot[2]) + slot[3];
+}
+
+template <int U, int WPC>
 __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* __restrict__ partial, int nbs, int nseg, int M, int rpb,
                                                                   int C, const float* __restrict__ gamma, float eps,
                                                                   float* __restrict__ mean_o, float* __restrict__ inv_std_o,
                                                                   float* __restrict__ scale_o, float* __restrict__ run_mean,
                                                                   float* __restrict__ run_inv_std, float alpha) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
+    // WPC waves per channel (4 = the whole workgroup, used when there are many partial blocks); `lane` is the thread's
+    // index among the WPC * 64 threads of its channel
+    __shared__ double slot_a[4], slot_b[4];
+    constexpr int GT = DPP_WAVE * WPC;
+    const int lane = threadIdx.x % GT;
+    const int c = blockIdx.x * (DPP_THREADS / GT) + threadIdx.x / GT;
     const int cc = c < C ? c : C - 1;                  // keep every lane in the shuffles
     // `partial` holds nseg segments (the ranks of a sync-BN all-gather) of nbs blocks each; a lane walks blocks lane, lane+64,
     // ... of every segment (no integer division per partial: this kernel is a few microseconds of pure latency)
@@ -91,37 +107,37 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
     double snm = 0.0;
     for (int seg = 0; seg < nseg; ++seg) {
         const float* pm_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
-        for (int b0 = lane; b0 < nbs; b0 += DPP_WAVE * U) {
+        for (int b0 = lane; b0 < nbs; b0 += GT * U) {
             float pm[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int b = b0 + u * DPP_WAVE;
+                const int b = b0 + u * GT;
                 pm[u] = pm_row[b < nbs ? b : nbs - 1];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int b = b0 + u * DPP_WAVE;
+                const int b = b0 + u * GT;
                 if (b < nbs) snm += (double)rows_of(b) * (double)pm[u];
             }
         }
     }
-    const double mean = wave_allsum(snm) / (double)M;  // sum_b n_b = M
+    const double mean = group_allsum<WPC>(snm, slot_a) / (double)M;  // sum_b n_b = M
     double q = 0.0;
     for (int seg = 0; seg < nseg; ++seg) {
         const float* pm_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
         const float* pq_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(1, cc, 0, C, nbs);
-        for (int b0 = lane; b0 < nbs; b0 += DPP_WAVE * U) {
+        for (int b0 = lane; b0 < nbs; b0 += GT * U) {
             float pm[U], pq[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int b = b0 + u * DPP_WAVE;
+                const int b = b0 + u * GT;
                 const int bb = b < nbs ? b : nbs - 1;
                 pm[u] = pm_row[bb];
                 pq[u] = pq_row[bb];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int b = b0 + u * DPP_WAVE;
+                const int b = b0 + u * GT;
                 if (b < nbs) {
                     const double d = (double)pm[u] - mean;
                     q += (double)pq[u] + (double)rows_of(b) * d * d;
@@ -129,7 +145,7 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
             }
         }
     }
-    const double m2 = wave_allsum(q);
+    const double m2 = group_allsum<WPC>(q, slot_b);
     if (lane != 0 || c >= C) return;
     double var = m2 / (double)M;                       // biased, T.var
     float meanf = (float)mean;
@@ -205,32 +221,35 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float*
     }
 }
 
-template <int U>
+template <int U, int WPC>
 __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nbs, int nseg, int M, int C,
                                                                       float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                                       float* __restrict__ c1, float* __restrict__ c2) {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * (DPP_THREADS / DPP_WAVE) + (threadIdx.x >> 6);
+    __shared__ double slot_a[4], slot_b[4];
+    constexpr int GT = DPP_WAVE * WPC;
+    const int lane = threadIdx.x % GT;
+    const int c = blockIdx.x * (DPP_THREADS / GT) + threadIdx.x / GT;
     const int cc = c < C ? c : C - 1;
     double a = 0.0, b = 0.0;
     for (int seg = 0; seg < nseg; ++seg) {
         const float* pa_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
         const float* pb_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(1, cc, 0, C, nbs);
-        for (int k0 = lane; k0 < nbs; k0 += DPP_WAVE * U) {
+        for (int k0 = lane; k0 < nbs; k0 += GT * U) {
             float pa[U], pb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int k = k0 + u * DPP_WAVE;
+                const int k = k0 + u * GT;
                 const int kk = k < nbs ? k : nbs - 1;
                 pa[u] = pa_row[kk];
                 pb[u] = pb_row[kk];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (k0 + u * DPP_WAVE < nbs) { a += (double)pa[u]; b += (double)pb[u]; }
+                if (k0 + u * GT < nbs) { a += (double)pa[u]; b += (double)pb[u]; }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    a = group_allsum<WPC>(a, slot_a);
+    b = group_allsum<WPC>(b, slot_b);
     if (lane != 0 || c >= C) return;
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
@@ -324,12 +343,12 @@ extern "C" int dpp_bn_finalize(const float* partial, int nb, int nseg, int M, in
                                dpp_stream_t stream) {
     if (!partial || !gamma || !mean || !inv_std || !scale || nseg < 1 || M % nseg || nb != dpp_cdiv(M / nseg, rows_per_block))
         return DPP_E_BADARG;
-    const dim3 grid(dpp_cdiv(C, DPP_THREADS / DPP_WAVE));
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DPP_BNF(U_) hipLaunchKernelGGL(bn_finalize_kernel<U_>, grid, dim3(DPP_THREADS), 0, st, partial, nb, nseg, M, rows_per_block, C, gamma, eps, \
-                                       mean, inv_std, scale, run_mean, run_inv_std, alpha)
-    const int tot = nb;      // blocks a lane walks per segment decide the load batch
-    if (tot <= 2 * DPP_WAVE) DPP_BNF(2); else if (tot <= 8 * DPP_WAVE) DPP_BNF(8); else DPP_BNF(32);
+    // one wave per channel, or the whole workgroup per channel when there are many partial blocks; loads batched so that a
+    // thread needs one or two round trips
+#define DPP_BNF(U_, W_) hipLaunchKernelGGL((bn_finalize_kernel<U_, W_>), dim3(dpp_cdiv(C, 4 / W_)), dim3(DPP_THREADS), 0, st, partial, nb, nseg, \
+                                           M, rows_per_block, C, gamma, eps, mean, inv_std, scale, run_mean, run_inv_std, alpha)
+    if (nb <= 2 * DPP_WAVE) DPP_BNF(2, 1); else if (nb <= 8 * DPP_WAVE) DPP_BNF(8, 1); else if (nb <= 32 * DPP_WAVE) DPP_BNF(8, 4); else DPP_BNF(32, 4);
 #undef DPP_BNF
     return dpp_launch_status();
 }
@@ -355,11 +374,10 @@ extern "C" int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, 
 extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M, int C, float* dbeta, float* dgamma, float* c1,
                                    float* c2, dpp_stream_t stream) {
     if (!partial || !dbeta || !dgamma || !c1 || !c2 || nb < 1 || nseg < 1) return DPP_E_BADARG;
-    const dim3 grid(dpp_cdiv(C, DPP_THREADS / DPP_WAVE));
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DPP_BNBF(U_) hipLaunchKernelGGL(bn_bwd_finalize_kernel<U_>, grid, dim3(DPP_THREADS), 0, st, partial, nb, nseg, M, C, dbeta, dgamma, c1, c2)
-    const int tot = nb;      // blocks a lane walks per segment decide the load batch
-    if (tot <= 2 * DPP_WAVE) DPP_BNBF(2); else if (tot <= 8 * DPP_WAVE) DPP_BNBF(8); else DPP_BNBF(32);
+#define DPP_BNBF(U_, W_) hipLaunchKernelGGL((bn_bwd_finalize_kernel<U_, W_>), dim3(dpp_cdiv(C, 4 / W_)), dim3(DPP_THREADS), 0, st, partial, nb, \
+                                            nseg, M, C, dbeta, dgamma, c1, c2)
+    if (nb <= 2 * DPP_WAVE) DPP_BNBF(2, 1); else if (nb <= 8 * DPP_WAVE) DPP_BNBF(8, 1); else if (nb <= 32 * DPP_WAVE) DPP_BNBF(8, 4); else DPP_BNBF(32, 4);
 #undef DPP_BNBF
     return dpp_launch_status();
 }
