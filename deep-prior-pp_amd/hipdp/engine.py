@@ -917,7 +917,9 @@ class CompiledNet(object):
                 tgt, dst = self._view_grad(src)
                 acc = tgt.grad_written
                 if s != 1 and not acc:
-                    self.bwd.add(ops.fill_zero(rt, dst))
+                    # the strided data gradient leaves the skipped pixels untouched: they are zeroed on the side stream while
+                    # the forward pass runs (the buffer is only written in the backward pass), not in the data-gradient chain
+                    self.early_side.append(ops.fill_zero(rt, dst))
                 tile, _ = gemm_plan(M, Ci, Co, allow_split=False)
                 rs = rowstream_plan(M, Ci, Co, False)
                 if rs is not None:
