@@ -600,7 +600,7 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     const bool red_layout = !d.a_kc && !d.b_kc;
     static const int bk64_min_k = []() { const char* e = getenv("DPP_GEMM_BK64_MINK"); return e ? atoi(e) : 128; }();
     ga.bk = (d.K > 16) ? 32 : 16;
-    if (d.a_kc && d.K >= bk64_min_k && d.splitk == 1) ga.bk = 64;
+    if (d.a_kc && d.K / d.splitk >= bk64_min_k) ga.bk = 64;     // per K slice when split
     const int chunk = red_layout ? 64 : ga.bk;
     int kper = dpp_cdiv(d.K, d.splitk);
     ga.Kper = dpp_cdiv(kper, chunk) * chunk;

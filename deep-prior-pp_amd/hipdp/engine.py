@@ -686,7 +686,8 @@ class CompiledNet(object):
         tile, splitk = gemm_plan(Nb, Nout, K)
         if K >= 4096 and Nb <= 128 and Nout >= 64:
             # weight-streaming shape (FC1: 67 MB of W for 128 rows): wide column tiles read W in 256 B rows, K split 512 deep
-            tile, splitk = (64, 64, 4), max(1, K // 512)
+            # (tools/gemm_micro.py fc: all 128 rows in one tile halve the passes over W through L2, 96 -> 79 us)
+            tile, splitk = ((128, 64, 4) if Nb > 64 and os.environ.get('DPP_FC1_TILE128', '1') != '0' else (64, 64, 4)), max(1, K // 512)
         act = self._act(src)
         if splitk > 1:
             part = self.scratch(splitk * Nb * Nout)
