@@ -224,7 +224,9 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float*
 template <int U, int WPC>
 __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nbs, int nseg, int M, int C,
                                                                       float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                                      float* __restrict__ c1, float* __restrict__ c2) {
+                                                                      float* __restrict__ c1, float* __restrict__ c2,
+                                                                      const float* __restrict__ inv_std, const float* __restrict__ scale,
+                                                                      float* __restrict__ q, float* __restrict__ p) {
     __shared__ double slot_a[4], slot_b[4];
     constexpr int GT = DPP_WAVE * WPC;
     const int lane = threadIdx.x % GT;
@@ -253,8 +255,13 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const floa
     if (lane != 0 || c >= C) return;
     dbeta[c] = (float)a;
     dgamma[c] = (float)b;
-    c1[c] = (float)(a / (double)M);
-    c2[c] = (float)(b / (double)M);
+    const float c1f = (float)(a / (double)M), c2f = (float)(b / (double)M);
+    c1[c] = c1f;
+    c2[c] = c2f;
+    if (q != nullptr) {                                 // constants of the mode-4 operand prologue (dpp_act)
+        q[c] = scale[c] * c1f;
+        p[c] = scale[c] * inv_std[c] * c2f;
+    }
 }
 
 // dX = scale * (G - c1 - xhat * c2) (+ add): gradient through the batch statistics.  Row-chunked like the reductions so
@@ -372,11 +379,12 @@ extern "C" int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, 
 }
 
 extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M, int C, float* dbeta, float* dgamma, float* c1,
-                                   float* c2, dpp_stream_t stream) {
+                                   float* c2, const float* inv_std, const float* scale, float* q, float* p, dpp_stream_t stream) {
     if (!partial || !dbeta || !dgamma || !c1 || !c2 || nb < 1 || nseg < 1) return DPP_E_BADARG;
+    if (q && !(p && inv_std && scale)) return DPP_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define DPP_BNBF(U_, W_) hipLaunchKernelGGL((bn_bwd_finalize_kernel<U_, W_>), dim3(dpp_cdiv(C, 4 / W_)), dim3(DPP_THREADS), 0, st, partial, nb, \
-                                            nseg, M, C, dbeta, dgamma, c1, c2)
+                                            nseg, M, C, dbeta, dgamma, c1, c2, inv_std, scale, q, p)
     if (nb <= 2 * DPP_WAVE) DPP_BNBF(2, 1); else if (nb <= 8 * DPP_WAVE) DPP_BNBF(8, 1); else if (nb <= 32 * DPP_WAVE) DPP_BNBF(8, 4); else DPP_BNBF(32, 4);
 #undef DPP_BNBF
     return dpp_launch_status();

@@ -445,6 +445,7 @@ extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dp
     if (!X || !Wk || !Y || N < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15)) return DPP_E_BADARG;
     Conv3Args a;
     a.X = X; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+    if (act && (act->mode & 4)) return DPP_E_UNSUPPORTED;       // the two-tensor BatchNorm-backward operand is a dpp_gemm feature
     if (act) a.act = *act; else { a.act.mode = 0; a.act.cmod = 1; a.act.mean = a.act.scale = a.act.beta = nullptr; }
     a.Wk = Wk; a.bias = bias; a.residual = residual; a.Y = Y;
     if (epi) a.epi = *epi; else { a.epi.stats = nullptr; a.epi.bn_x = nullptr; a.epi.bn_partial = nullptr; }
@@ -500,6 +501,7 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     if (!X || !dY || !partial || N < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15) || (bm != 64 && bm != 128)) return DPP_E_BADARG;
     Wgrad3Args a;
     a.X = X; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.dY = dY; a.partial = partial;
+    if (act && (act->mode & 4)) return DPP_E_UNSUPPORTED;       // the two-tensor BatchNorm-backward operand is a dpp_gemm feature
     if (act) a.act = *act; else { a.act.mode = 0; a.act.cmod = 1; a.act.mean = a.act.scale = a.act.beta = nullptr; }
     pick_tile(N, H, W, bm, a.lth, a.ltw, a.img);
     int TH = 1 << a.lth, TW = 1 << a.ltw;

@@ -221,6 +221,7 @@ constexpr int CP_WGRAD_MAX_BLOCKS = 512;
 
 extern "C" int dpp_convpool_fwd(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int kh, int kw, int pad,
                                 int Co, int pool, const float* bias, float* Y, uint16_t* ties, dpp_stream_t stream) {
+    if (act && (act->mode & 4)) return DPP_E_UNSUPPORTED;       // the two-tensor BatchNorm-backward operand is a dpp_gemm feature
     cp_geom g;
     if (!X || !Wk || !bias || !Y || !cp_make_geom(g, N, H, W, Ci, kh, kw, pad, Co, pool)) return DPP_E_BADARG;
     size_t lds = (size_t)g.sy * g.sx * Ci * sizeof(float);
@@ -245,6 +246,7 @@ extern "C" int dpp_convpool_wgrad_blocks(int N, int Hp, int Wp) {
 
 extern "C" int dpp_convpool_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, const uint16_t* ties,
                                   int kh, int kw, int pad, int Co, int pool, float* partial, dpp_stream_t stream) {
+    if (act && (act->mode & 4)) return DPP_E_UNSUPPORTED;       // the two-tensor BatchNorm-backward operand is a dpp_gemm feature
     cp_geom g;
     if (!X || !dY || !partial || !cp_make_geom(g, N, H, W, Ci, kh, kw, pad, Co, pool) || (pool > 1 && !ties)) return DPP_E_BADARG;
     size_t lds = ((size_t)g.sy * g.sx * Ci + 2 * 64 * Co) * sizeof(float);

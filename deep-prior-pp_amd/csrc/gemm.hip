@@ -53,6 +53,28 @@ __device__ __forceinline__ float4 act4_masked(float4 v, const dpp_act& a, int c0
     return o;
 }
 
+// Operand A in mode 4: the gradient through a BatchNorm's batch statistics, v = scale*g - aux*(x - mean) - beta, from the masked
+// gradient g and the BatchNorm input x (4 consecutive elements each); elements at or beyond `limit` are zero.
+__device__ __forceinline__ float4 bnbwd4_masked(float4 g, float4 x, const dpp_act& a, int c0, int limit) {
+    if ((a.cmod & 3) == 0 && c0 + 3 < limit) {
+        const int c = c0 % a.cmod;
+        const float4 sc = *reinterpret_cast<const float4*>(a.scale + c), ax = *reinterpret_cast<const float4*>(a.aux + c);
+        const float4 mu = *reinterpret_cast<const float4*>(a.mean + c), be = *reinterpret_cast<const float4*>(a.beta + c);
+        return make_float4(sc.x * g.x - ax.x * (x.x - mu.x) - be.x, sc.y * g.y - ax.y * (x.y - mu.y) - be.y,
+                           sc.z * g.z - ax.z * (x.z - mu.z) - be.z, sc.w * g.w - ax.w * (x.w - mu.w) - be.w);
+    }
+    const float gv[4] = {g.x, g.y, g.z, g.w}, xv[4] = {x.x, x.y, x.z, x.w};
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (c0 + j < limit) {
+            const int c = (c0 + j) % a.cmod;
+            o[j] = a.scale[c] * gv[j] - a.aux[c] * (xv[j] - a.mean[c]) - a.beta[c];
+        }
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // Shared epilogue of the GEMM kernels: bias / residual / fused BatchNorm-backward mask, stores (or split-K partial stores),
 // and the fused column statistics.  acc is in the MFMA D layout; `red` is LDS scratch of >= WM*BN floats.
 template <int RM, int CN, int WM, int WN, int BM, int BN>
@@ -187,7 +209,7 @@ struct Stager {
     static constexpr int LD = KC ? (BKT + 4) : (ROWS + 4);
 };
 
-template <int BM, int BN, int WM, int BKT, bool AKC, bool BKC, int DEPTH>
+template <int BM, int BN, int WM, int BKT, bool AKC, bool BKC, int DEPTH, bool LAZY = false>
 __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     const dpp_gemm_desc& d = ga.d;
     constexpr int WN = 4 / WM;
@@ -244,6 +266,9 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     // DEPTH chunks are kept in flight per workgroup (a ring of register sets): what bounds these skinny GEMMs is the
     // latency of the dependent load -> barrier -> MFMA chain, not bandwidth or the MFMA rate.
     float4 ra[DEPTH][SA::SLOTS], rb[DEPTH][SB::SLOTS];
+    // LAZY: operand A = gradient through a BatchNorm, built from (g, x2) (dpp_act mode 4); its own instantiation, so that the
+    // second load and the extra per-channel vectors cost the ordinary GEMMs nothing
+    const ptrdiff_t a2off = LAZY ? (d.actA.x2 - d.A) : 0;
     auto fetch = [&](float4* ra_, float4* rb_, int kc) {
 #pragma unroll
         for (int s = 0; s < SA::SLOTS; ++s) {
@@ -252,11 +277,20 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
             if (a_base[s] != nullptr) {
                 if (AKC) {
                     int k = kc + (slot % SA::QK) * 4;
-                    if (k < k_end) v = act4_masked(load4(a_base[s] + k, k, k_end, ga.vecA), d.actA, k, k_end);
+                    if (k < k_end) {
+                        const float* pa = a_base[s] + k;
+                        const float4 g = load4(pa, k, k_end, ga.vecA);
+                        if constexpr (LAZY) v = bnbwd4_masked(g, load4(pa + a2off, k, k_end, ga.vecA), d.actA, k, k_end);
+                        else v = act4_masked(g, d.actA, k, k_end);
+                    }
                 } else {
                     int k = kc + slot / (BM / 4), gi = row0 + (slot % (BM / 4)) * 4;
-                    if (k < k_end)
-                        v = act4_masked(load4(a_base[s] + (size_t)dpp_map_row(d.mapA, k) * d.lda, gi, M, ga.vecA), d.actA, gi, M);
+                    if (k < k_end) {
+                        const float* pa = a_base[s] + (size_t)dpp_map_row(d.mapA, k) * d.lda;
+                        const float4 g = load4(pa, gi, M, ga.vecA);
+                        if constexpr (LAZY) v = bnbwd4_masked(g, load4(pa + a2off, gi, M, ga.vecA), d.actA, gi, M);
+                        else v = act4_masked(g, d.actA, gi, M);
+                    }
                 }
             }
             ra_[s] = v;
@@ -554,6 +588,18 @@ int launch_layout(const GemmArgs& ga, hipStream_t st) {
     const dpp_gemm_desc& d = ga.d;
     dim3 grid(dpp_cdiv(d.M, BM), dpp_cdiv(d.N, BN), d.splitk);
     const bool k32 = ga.bk == 32;
+    if (d.actA.mode == 4) {
+        // data gradient (A [pixels][C] with B = W [K][N]) and filter gradient (both operands [k][mn]) of a 1x1 convolution
+        if (d.a_kc && !d.b_kc) {
+            if (ga.bk == 64) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+            else if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+            else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+        } else if (!d.a_kc && !d.b_kc)
+            hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else
+            return DPP_E_UNSUPPORTED;
+        return dpp_launch_status();
+    }
     if (ga.bk == 64 && d.a_kc) {
         // long K-contiguous reductions (stage-2..4 1x1 convolutions and FC layers, K >= 128; measured 4.80 -> 4.74 ms per step): half as many global -> LDS round trips
         if (d.b_kc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
@@ -591,6 +637,12 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     if (d.actA.mode && d.actA.cmod <= 0) return DPP_E_BADARG;
     if (d.actB.mode && d.actB.cmod <= 0) return DPP_E_BADARG;
     ga.vecA = aligned16(d.A) && (d.lda % 4 == 0);
+    if (d.actB.mode & 4) return DPP_E_UNSUPPORTED;
+    if (d.actA.mode & 4) {
+        if (d.actA.mode != 4 || d.variant == 1 || !d.actA.x2 || !d.actA.aux || !d.actA.mean || !d.actA.scale || !d.actA.beta) return DPP_E_BADARG;
+        ga.vecA = ga.vecA && aligned16(d.actA.x2);
+        if (!(aligned16(d.actA.mean) && aligned16(d.actA.scale) && aligned16(d.actA.beta) && aligned16(d.actA.aux))) return DPP_E_BADARG;
+    }
     ga.vecB = aligned16(d.B) && (d.ldb % 4 == 0);
     static const bool wide_ok = []() { const char* e = getenv("DPP_GEMM_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
     ga.wide = wide_ok && d.splitk == 1 && d.N % 4 == 0 && d.ldc % 4 == 0 && aligned16(d.C) && aligned16(d.residual) &&

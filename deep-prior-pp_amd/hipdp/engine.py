@@ -268,6 +268,10 @@ def gemm_plan(M, N, K, allow_split=True):
 
 OVERLAP_ALLREDUCE = os.environ.get('DPP_OVERLAP_ALLREDUCE', '1') != '0'
 EARLY_BUCKET_MIN = int(os.environ.get('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elements; FC1 of the 128x128 ResNet has 16.8 M
+# 1x1 convolutions can read the BatchNorm gradient as (G, x) instead of a materialised dX (see _resolve_view).  Off by default:
+# it takes 20 bn_bwd_apply launches (107 us) off the main chain but makes 40 GEMMs 3.5 us slower each, half of them on the
+# gradient branch, which is what the end of the step waits for (4.87 vs 4.71 ms per step).
+LAZY_BN_BWD = os.environ.get('DPP_LAZY_BN_BWD', '0') == '1'
 ROWSTREAM = os.environ.get('DPP_ROWSTREAM', '0') != '0'      # measured: no gain over the LDS-tiled kernel yet
 
 
@@ -736,6 +740,8 @@ class CompiledNet(object):
     def _grad_of(self, t):
         """Materialised gradient of tensor t (None if nothing flows into it)."""
         rt = self.rt
+        if getattr(t, 'lazy', None) is not None:
+            self._materialise_lazy(t)
         if t.grad_written:
             for p in t.pending:
                 self.bwd.add(ops.axpy(rt, t.grad, p, 1.0, t.grad.size))
@@ -767,11 +773,18 @@ class CompiledNet(object):
         b = view.bn
         M, C, W = b.M, b.C, b.world
         c1, c2 = rt.alloc(_pad4(C)), rt.alloc(_pad4(C))
+        # If t was produced by a 1x1 convolution and nothing else flows into it, the gradient through the batch statistics
+        # dX = scale*(G - c1 - xhat*c2) is never written: that convolution's data- and filter-gradient GEMMs form it from
+        # (G, x) while they stage their operand (dpp_act mode 4), which removes a launch from the dependent chain and a pass
+        # over the tensor.  The finalize then also writes the two per-channel constants that prologue needs.
+        lazy = LAZY_BN_BWD and not t.grad_written and not t.pending and self._produced_by_conv1x1(t)
+        q, p = (rt.alloc(_pad4(C)), rt.alloc(_pad4(C))) if lazy else (None, None)
+        fin = dict(bn=b, q=q, p=p) if lazy else {}
         fused = getattr(vg, 'fused_reduce', None)
         if fused is not None:
             # the data-gradient kernel already masked vg.grad and wrote the per-block sums
             part, nbp = fused
-            self.bwd.add(ops.bn_bwd_finalize(rt, part, nbp, M, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2))
+            self.bwd.add(ops.bn_bwd_finalize(rt, part, nbp, M, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2, **fin))
             W = 0
         else:
             part = self.scratch(b.nb * 2 * C * (W + 1)).view(0, (b.nb * 2 * C,))
@@ -784,11 +797,32 @@ class CompiledNet(object):
         # (a sum over ranks) leaves them unchanged
         if fused is None:
             self.bwd.add(ops.bn_bwd_finalize(rt, part, b.nb, M * W, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2,
-                                             nseg=W))
+                                             nseg=W, **fin))
         if W > 1:
             for prm in (b.layer.beta, b.layer.gamma):
                 gv = st.view(prm, 'g')
                 self.bwd.add(ops.scale(rt, gv, gv, C, a=1.0 / W))
+        if lazy:
+            t.lazy = dict(G=vg.grad, act=ops.act_bn_bwd(b, q, p, t.buf, C), bn=b, c1=c1, c2=c2)
+            return
+        self._emit_bn_bwd_apply(t, vg.grad, b, c1, c2)
+
+    def _produced_by_conv1x1(self, t):
+        for l in self.layers:
+            io = self.layer_io.get(id(l))
+            if io is not None and io.get('out') is t:
+                return (_layer_kind(l) == 'ConvLayer' and tuple(l.cfgParams.filterDim) == (1, 1) and io.get('residual') is None)
+        return False
+
+    def _materialise_lazy(self, t):
+        """Fallback: write the lazily represented gradient of t after all (a consumer that cannot take the two-tensor operand)."""
+        lz = t.lazy
+        t.lazy = None
+        self._emit_bn_bwd_apply(t, lz['G'], lz['bn'], lz['c1'], lz['c2'])
+
+    def _emit_bn_bwd_apply(self, t, G, b, c1, c2):
+        rt = self.rt
+        M, C = b.M, b.C
         addends = ([t.grad] if t.grad_written else []) + t.pending
         t.pending = []
         if t.grad is None:
@@ -800,7 +834,7 @@ class CompiledNet(object):
                 raise NotImplementedError("more than one extra gradient path into a BatchNorm input")
         # t.grad is the dY of the conv(s) that produced t: emit its column sums (their bias gradients) in the same pass
         cs = rt.alloc((b.nb, C), zero=False)
-        self.bwd.add(ops.bn_bwd_apply(rt, vg.grad, t.buf, M, C, b.mean, b.inv_std, b.scale, c1, c2, t.grad, add=add, rpb=b.rpb, colsum=cs))
+        self.bwd.add(ops.bn_bwd_apply(rt, G, t.buf, M, C, b.mean, b.inv_std, b.scale, c1, c2, t.grad, add=add, rpb=b.rpb, colsum=cs))
         self.colsum_of[t.grad.ptr] = (cs, b.nb, C)
         t.grad_written = True
 
@@ -826,6 +860,11 @@ class CompiledNet(object):
             if v is not None and v.key() in self.view_grads:
                 self._resolve_view(self.view_grads.pop(v.key()))
             out = io['out']
+            lz = getattr(out, 'lazy', None)
+            if lz is not None and kind == 'ConvLayer' and tuple(layer.cfgParams.filterDim) == (1, 1):
+                out.lazy = None
+                self._bwd_conv(layer, io, io['in_view'], lz['G'], dY_act=lz['act'])
+                continue
             dY = self._grad_of(out)
             if dY is None:
                 continue
@@ -889,7 +928,8 @@ class CompiledNet(object):
         self.bwd.add(ops.colsum_partial(self.rt, dY, rows, C, rpb, part), side=True)
         self.bwd.add(ops.reduce_partials(self.rt, part, nb, C, gslot), side=True)
 
-    def _bwd_conv(self, layer, io, src, dY):
+    def _bwd_conv(self, layer, io, src, dY, dY_act=None):
+        """dY_act: dY is the masked BatchNorm gradient G and the true dY is formed by this operand prologue (see _resolve_view)."""
         rt, st = self.rt, self.store
         c = layer.cfgParams
         N, Hi, Wi, Ci = src.base.shape
@@ -903,15 +943,21 @@ class CompiledNet(object):
         # parameter gradients only READ dY / the forward activations, so they run as a parallel branch on the side
         # stream while the main stream continues with the data-gradient chain
         self.bwd.fork()
-        self._bias_grad(dY, M, Co, gb)
+        if dY_act is None:
+            self._bias_grad(dY, M, Co, gb)
+        else:
+            # sum over pixels of scale*(G - c1 - xhat*c2) with c1 = mean(G), sum(xhat) = 0: the bias of a convolution that
+            # feeds a BatchNorm has no gradient (the reference adds up rounding noise); a job without slices writes zeros
+            assert k == (1, 1) and io.get('residual') is None
+            self.reduce_jobs.add(dY, 0, Co, gb)
         need_dx = src.base not in self.x_ins
         if k == (1, 1):
             mp = RowMap.strided(s, Ho, Wo, Hi, Wi) if s != 1 else None
             # filter gradient dW[o][c] = sum_m dY[m][o] * act(X)[map(m)][c]
             tile, splitk = wgrad_plan(Co, Ci, M)
             part = rt.alloc(splitk * Co * Ci, zero=False) if splitk > 1 else None     # persistent: reduced at the end of backward
-            self.bwd.add(ops.gemm(rt, dY, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actB=act,
-                                  splitk=splitk, partial=part, tile=tile, name='wgrad1x1_%d' % layer.layerNum), side=True)
+            self.bwd.add(ops.gemm(rt, dY, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actA=dY_act,
+                                  actB=act, splitk=splitk, partial=part, tile=tile, name='wgrad1x1_%d' % layer.layerNum), side=True)
             if splitk > 1:
                 self.reduce_jobs.add(part, splitk, Co * Ci, gW)
             if need_dx:
@@ -934,8 +980,8 @@ class CompiledNet(object):
                     nb2 = -(-M // tile[0])
                     tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
                     epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
-                self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp,
-                                      residual=dst if acc else None, tile=tile, epi=epi, variant=1 if rs is not None else 0,
+                self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
+                                      residual=dst if acc else None, tile=tile, epi=epi, variant=1 if rs is not None and dY_act is None else 0,
                                       name='dgrad1x1_%d' % layer.layerNum))
                 tgt.grad_written = True
         else:
@@ -1025,7 +1071,11 @@ class CompiledNet(object):
         tpb = 8
         nblk = rt.lib.dpp_stem_wgrad_blocks(N, H, W, tpb)
         part = rt.alloc(nblk * Co * 25, zero=False)
-        self.bwd.add(ops.stem_wgrad(rt, self.x_in.buf, N, H, W, dY, io['argmax'], Co, part, tpb), side=True)
+        # The first layer's filter gradient needs the very last data gradient, i.e. it cannot start before the main chain is
+        # done -- and then the main stream has nothing left to do while the gradient branch still works off its backlog
+        # (tools/tail_probe.py): it runs on the main stream.
+        self.bwd.add(ops.stem_wgrad(rt, self.x_in.buf, N, H, W, dY, io['argmax'], Co, part, tpb),
+                     side=os.environ.get('DPP_STEM_WGRAD_SIDE', '0') == '1')
         self.reduce_jobs.add(part, nblk, Co * 25, st.view(layer.W, 'g'))
 
     # ------------------------------------------------------------------------------------------ execution

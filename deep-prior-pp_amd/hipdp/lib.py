@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'lib', 'libdpp_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 c_float_p = C.c_void_p      # device pointers travel as integers
 stream_t = C.c_void_p
 
@@ -29,13 +29,14 @@ class RowMap(C.Structure):
 
 
 class Act(C.Structure):
-    _fields_ = [('mean', C.c_void_p), ('scale', C.c_void_p), ('beta', C.c_void_p), ('mode', C.c_int), ('cmod', C.c_int)]
+    _fields_ = [('mean', C.c_void_p), ('scale', C.c_void_p), ('beta', C.c_void_p), ('mode', C.c_int), ('cmod', C.c_int),
+                ('x2', C.c_void_p), ('aux', C.c_void_p)]
 
-    NONE, RELU, BN, BN_RELU = 0, 1, 2, 3
+    NONE, RELU, BN, BN_RELU, BN_BWD = 0, 1, 2, 3, 4
 
     @staticmethod
     def none():
-        return Act(None, None, None, 0, 1)
+        return Act(None, None, None, 0, 1, None, None)
 
 
 class Epilogue(C.Structure):
@@ -86,7 +87,7 @@ SIGNATURES = {
     'dpp_bn_bwd_reduce': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
     'dpp_bn_bwd_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_void_p, stream_t]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_bn_bwd_apply': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
     'dpp_reduce_job_bytes': (C.c_size_t, []),

@@ -91,8 +91,16 @@ def _p(buf):
     return None if buf is None else buf.ptr
 
 
-def act(mode=0, mean=None, scale=None, beta=None, cmod=1):
-    return Act(_p(mean), _p(scale), _p(beta), int(mode), int(cmod))
+def act(mode=0, mean=None, scale=None, beta=None, cmod=1, x2=None, aux=None):
+    a = Act(_p(mean), _p(scale), _p(beta), int(mode), int(cmod), _p(x2), _p(aux))
+    a._keep = (mean, scale, beta, x2, aux)
+    return a
+
+
+def act_bn_bwd(bn, q, p, x, C):
+    """Operand prologue of dpp_gemm's A in mode 4: the operand is the masked gradient G of BatchNorm `bn`, and the value used
+    is dX = scale*G - p*(x - mean) - q (q = scale*c1, p = scale*inv_std*c2 from bn_bwd_finalize): bn_bwd_apply on the fly."""
+    return act(Act.BN_BWD, mean=bn.mean, scale=bn.scale, beta=q, cmod=C, x2=x, aux=p)
 
 
 def epilogue(stats=None, bn=None, bn_x=None, bn_relu=True, bn_partial=None):
@@ -218,9 +226,12 @@ def bn_bwd_reduce(rt, dA, X, M, Cc, mean, inv_std, scale, beta, relu, G, rpb, pa
                   dict(kernel='bn_bwd_reduce', flops=8.0 * M * Cc, bytes=12.0 * M * Cc))
 
 
-def bn_bwd_finalize(rt, partial, nb, M, Cc, dbeta, dgamma, c1, c2, nseg=1, name='bn_bwd_finalize'):
-    return Launch(rt.lib.dpp_bn_bwd_finalize, (partial.ptr, nb, int(nseg), M, Cc, dbeta.ptr, dgamma.ptr, c1.ptr, c2.ptr),
-                  (partial, dbeta, dgamma, c1, c2), name, dict(kernel='bn_bwd_finalize', flops=0.0, bytes=8.0 * nb * Cc))
+def bn_bwd_finalize(rt, partial, nb, M, Cc, dbeta, dgamma, c1, c2, nseg=1, bn=None, q=None, p=None, name='bn_bwd_finalize'):
+    """q, p (with bn): also write the constants of the mode-4 operand prologue (act_bn_bwd)."""
+    return Launch(rt.lib.dpp_bn_bwd_finalize, (partial.ptr, nb, int(nseg), M, Cc, dbeta.ptr, dgamma.ptr, c1.ptr, c2.ptr,
+                                               _p(bn.inv_std) if q is not None else None, _p(bn.scale) if q is not None else None,
+                                               _p(q), _p(p)),
+                  (partial, dbeta, dgamma, c1, c2, bn, q, p), name, dict(kernel='bn_bwd_finalize', flops=0.0, bytes=8.0 * nb * Cc))
 
 
 def bn_bwd_apply(rt, G, X, M, Cc, mean, inv_std, scale, c1, c2, dX, add=None, rpb=None, colsum=None, name='bn_bwd_apply'):

@@ -34,7 +34,7 @@ typedef void* dpp_stream_t; /* a hipStream_t */
 #define DPP_E_BADARG 10001
 #define DPP_E_UNSUPPORTED 10002
 
-#define DPP_ABI_VERSION 2
+#define DPP_ABI_VERSION 3
 int dpp_abi_version(void);
 
 /* Pixel row map: row m of a compact (N,Ho,Wo) map -> row of a (N,Hi,Wi) map sampled with stride s.
@@ -46,13 +46,21 @@ typedef struct {
 /* Operand prologue applied while a tile is staged: the BatchNorm + ReLU that precede a conv / FC in the
  * pre-activation blocks (batchnormlayer.py:192, theano_helpers.py:61-69), evaluated as
  *   v = (x - mean[c]) * scale[c] + beta[c]   (mode & 2),   v = max(v, 0)   (mode & 1)
- * with c = (index along the operand's contiguous dimension) % cmod. */
+ * with c = (index along the operand's contiguous dimension) % cmod.
+ * mode == 4 (operand A of dpp_gemm only): the operand is the gradient through a BatchNorm's batch statistics,
+ *   v = scale[c] * g - aux[c] * (x2 - mean[c]) - beta[c]
+ * evaluated from the masked gradient g (the operand itself) and the BatchNorm input x2 (same shape and leading dimension
+ * as the operand) instead of being materialised by dpp_bn_bwd_apply: with scale = gamma*inv_std, aux = scale*inv_std*c2 and
+ * beta = scale*c1 (written by dpp_bn_bwd_finalize) this is dX = scale * (G - c1 - xhat*c2), batchnormlayer.py:119-194 under
+ * T.grad. */
 typedef struct {
     const float* mean;
     const float* scale;
     const float* beta;
     int mode;
     int cmod;
+    const float* x2;     /* mode 4 only */
+    const float* aux;    /* mode 4 only */
 } dpp_act;
 
 /* Optional fused epilogue work on the output tile (both NULL = plain epilogue).
@@ -173,7 +181,8 @@ int dpp_convpool_dgrad(const float* dY, const uint16_t* ties, int N, int H, int 
  *                or the ranks of a synchronised-BatchNorm all-gather) covering M rows in total, M / nseg per segment
  * eval_coeffs:   deterministic mode: mean = run_mean, inv_std = run_inv_std, scale = gamma*run_inv_std
  * bwd_reduce:    G = dA * [ (x-mean)*scale+beta >= 0 ] (relu != 0) or dA; partial[2][C][nb] = sum G, sum G*xhat
- * bwd_finalize:  dbeta, dgamma and c1 = dbeta/M, c2 = dgamma/M
+ * bwd_finalize:  dbeta, dgamma and c1 = dbeta/M, c2 = dgamma/M; if q != NULL also q = scale*c1 and p = scale*inv_std*c2, the
+ *                per-channel constants of the mode-4 operand prologue (dpp_act)
  * bwd_apply:     dX = scale * (G - c1 - xhat*c2) + add      (gradient through the batch statistics) */
 int dpp_bn_stats_partial(const float* X, int M, int C, int rows_per_block, float* partial, dpp_stream_t stream);
 int dpp_bn_finalize(const float* partial, int nb, int nseg, int M, int rows_per_block, int C, const float* gamma, float eps,
@@ -185,7 +194,7 @@ int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, const float
                       const float* scale, const float* beta, int relu, float* G, int rows_per_block, float* partial,
                       dpp_stream_t stream);
 int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M, int C, float* dbeta, float* dgamma, float* c1, float* c2,
-                        dpp_stream_t stream);
+                        const float* inv_std, const float* scale, float* q, float* p, dpp_stream_t stream);
 int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
                      const float* scale, const float* c1, const float* c2, const float* add, float* dX,
                      int rows_per_block, float* colsum_partial /* [nb][C] column sums of dX, or NULL */, dpp_stream_t stream);

@@ -95,12 +95,19 @@ def test_resnet_forward_eval_matches_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('type_', [0, 1])
-def test_resnet_train_forward_backward_matches_oracle(backend, type_):
+@pytest.mark.parametrize('type_', [0, 1, 'lazy'])
+def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatch):
+    """'lazy': type 0 with the opt-in plan in which the 1x1 convolutions form the gradient through a BatchNorm from (G, x) in
+    their operand prologue (engine.LAZY_BN_BWD) instead of reading a tensor written by bn_bwd_apply."""
+    if type_ == 'lazy':
+        monkeypatch.setattr(engine, 'LAZY_BN_BWD', True)
+        type_ = 0
     rt = get_runtime(backend)
     nJ, nD = (1, 30) if type_ == 0 else (14, 3)
     net, onet, P = make_net(rt, type_, 4, 32, nJ, nD)
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    if engine.LAZY_BN_BWD:
+        assert any(l.name.startswith('dgrad1x1') and l.keep[0].actA.mode == 4 for l in eng.bwd.launches())
     P64 = nets.cast_params(P, np.float64)
 
     def run(seed):

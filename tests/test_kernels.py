@@ -410,3 +410,38 @@ def test_reduce_multi_ragged_jobs(backend):
     assert np.all(got[:3] == 0)
     for off, n, ref in refs:
         np.testing.assert_allclose(got[off:off + n], ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('a_kc', [1, 0])
+def test_gemm_operand_through_batchnorm_backward(backend, a_kc):
+    """dpp_gemm's mode-4 A operand: the gradient through a BatchNorm's batch statistics is formed from (G, x) while the tile is
+    staged -- same product as materialising it with dpp_bn_bwd_apply first.  a_kc=1: data gradient (operand [pixels][C],
+    reduction over channels); a_kc=0: filter gradient (reduction over pixels), ragged sizes."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(77)
+    Mp, Cc, Co = 203, 24, 20                      # pixels, BatchNorm channels, the other GEMM dimension
+    G = rng.normal(size=(Mp, Cc)).astype(np.float32)
+    X = (rng.normal(size=(Mp, Cc)) * 2 + 5).astype(np.float32)
+    mean = X.mean(0).astype(np.float32)
+    istd = (1 / np.sqrt(X.var(0) + 1e-4)).astype(np.float32)
+    scale = (rng.uniform(0.5, 1.5, Cc) * istd).astype(np.float32)
+    c1, c2 = rng.normal(size=Cc).astype(np.float32) * 0.1, rng.normal(size=Cc).astype(np.float32) * 0.1
+    bn = _BN()
+    bn.mean, bn.inv_std, bn.scale = rt.upload(mean), rt.upload(istd), rt.upload(scale)
+    q, p = rt.upload(scale * c1), rt.upload(scale * istd * c2)
+    Gb, Xb = rt.upload(G), rt.upload(X)
+    dX = scale.astype('f8') * (G.astype('f8') - c1 - (X.astype('f8') - mean) * istd * c2)
+    act = ops.act_bn_bwd(bn, q, p, Xb, Cc)
+    if a_kc:
+        Wm = rng.normal(size=(Cc, Co)).astype(np.float32)            # C[m][o] = sum_c dX[m][c] W[c][o]
+        out = rt.alloc((Mp, Co), zero=False)
+        ops.gemm(rt, Gb, rt.upload(Wm), out, Mp, Co, Cc, 1, 0, Cc, Co, Co, actA=act)(rt.stream)
+        ref = dX @ Wm.astype('f8')
+    else:
+        Y = rng.normal(size=(Mp, Co)).astype(np.float32)             # C[c][o] = sum_m dX[m][c] Y[m][o]
+        out = rt.alloc((Cc, Co), zero=False)
+        ops.gemm(rt, Gb, rt.upload(Y), out, Cc, Co, Mp, 0, 0, Cc, Co, Co, actA=act)(rt.stream)
+        ref = dX.T @ Y.astype('f8')
+    rt.synchronize()
+    np.testing.assert_allclose(out.get(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
