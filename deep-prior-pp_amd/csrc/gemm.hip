@@ -209,7 +209,7 @@ struct Stager {
     static constexpr int LD = KC ? (BKT + 4) : (ROWS + 4);
 };
 
-template <int BM, int BN, int WM, int BKT, bool AKC, bool BKC, int DEPTH, bool LAZY = false>
+template <int BM, int BN, int WM, int BKT, bool AKC, bool BKC, int DEPTH, bool LAZY = false, bool WIDE = true>
 __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     const dpp_gemm_desc& d = ga.d;
     constexpr int WN = 4 / WM;
@@ -387,7 +387,8 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         }
     }
 
-    if (ga.wide) {
+    // WIDE = false: instantiations that never take the LDS-image epilogue (split-K filter gradients) do not carry its registers
+    if (WIDE && ga.wide) {
         const int nvalid = (M - row0 < BM) ? (M - row0) : BM;
         dpp_epilogue_wide<RM, CN, WM, WN, BM, BN>(acc, smem, col0, N, wco, d.residual, d.C, d.epi, nvalid, wm, wn, l15, kq, [&](int rl) {
             const int row = row0 + rl;
@@ -595,7 +596,7 @@ int launch_layout(const GemmArgs& ga, hipStream_t st) {
             else if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
             else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
         } else if (!d.a_kc && !d.b_kc)
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+            hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false, 1, true, false>), grid, dim3(DPP_THREADS), 0, st, ga);
         else
             return DPP_E_UNSUPPORTED;
         return dpp_launch_status();
@@ -612,7 +613,8 @@ int launch_layout(const GemmArgs& ga, hipStream_t st) {
         else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else if (!d.a_kc && !d.b_kc) {
         // reduction over pixels / samples: long K, both operands [k][mn] -> 64-deep chunks keep 20+ KB per workgroup in flight
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (ga.wide) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false, 1, false, false>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else
         return DPP_E_UNSUPPORTED;
     return dpp_launch_status();
