@@ -135,81 +135,139 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_fwd_kernel(const float* __re
     }
 }
 
-// thread = (o = tid % Co', pixel group); accumulates the 25 taps in registers.  The kernel is bound by instruction issue (one
-// LDS read per FMA when every tap is fetched separately, and the constant background of a depth crop ties all four window
-// pixels, i.e. four passes over the taps), so the 6x6 input patch under a pooling window is read ONCE into registers with
-// 8-byte LDS reads (18 instead of up to 100) and the tied window pixels take their taps from there.
-constexpr int LXW = LX + 2;        // 22: even row pitch, so a window's patch rows start 8-byte aligned
+// Filter gradient on the matrix cores.  With the max-pool routing folded into the A operand,
+//     dW[o][tap] = sum over conv pixels pix of  dYc[pix][o] * x[pix + tap],   dYc[pix][o] = dY[pool(pix)][o] * tie(pix, o),
+// is a GEMM with M = o (<= 32), N = tap (25, padded to 32) and K = pixels.  One MFMA k-step (4 k-values) is one pooling
+// window, k = the window pixel a.  A workgroup walks 16x16-pixel tiles (8x8 windows): per tile it stages the input halo and
+// the MASKED gradients gm[a][window][o] = dY[window][o] if tie bit a of ties[window][o] else 0 in LDS (16-byte global loads,
+// the next tile's loads in flight under this tile's MFMAs); its four waves take 16 windows each, lane (o, a) reads gm as A,
+// lane (tap, a) reads x[window pixel a + tap] from the halo as B, and the whole 32x32 product stays in 4 accumulators per
+// wave until the waves meet in LDS at the end.  (A VALU version spent 93 us issuing one FMA per tap, window pixel and
+// channel -- the constant background of a depth crop ties all four pixels -- alone at the end of the step.)
+constexpr int LXW = LX + 2;              // 22: row pitch of the halo image in this kernel
+constexpr int GM_A = 64 * 32 + 16;       // floats between the four window-pixel planes of gm (the +16 spreads them over the banks)
 
 __global__ __launch_bounds__(DPP_THREADS) void stem_wgrad_kernel(const float* __restrict__ X, int N, int H, int W, const float* __restrict__ dY,
                                                                  const uint8_t* __restrict__ arg, int Co, float* __restrict__ partial,
                                                                  int tiles_x, int tiles_y, int tiles_per_block, int total_tiles) {
-    __shared__ __attribute__((aligned(16))) float xs[LX * LXW];
-    __shared__ float red[DPP_THREADS * NTAP];     // 25.6 KB
-    const int tid = threadIdx.x;
-    const int o = tid % Co, pg = tid / Co, npg = DPP_THREADS / Co;
+    __shared__ __attribute__((aligned(16))) float gm[4 * GM_A];     // 33 KB; re-used for the final reduction (4 x 32 x 32 floats)
+    __shared__ float xs[LX * LXW];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int Hp = H >> 1, Wp = W >> 1;
-    float acc[NTAP];
+    const bool vec = (Co & 3) == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0 && (reinterpret_cast<uintptr_t>(arg) & 3) == 0;
+    // B operand: this lane's tap(s) and window pixel give a constant offset into the halo image
+    int offB[2];
+    bool okB[2];
 #pragma unroll
-    for (int k = 0; k < NTAP; ++k) acc[k] = 0.0f;
-    for (int ti = 0; ti < tiles_per_block; ++ti) {
-        int tile = blockIdx.x * tiles_per_block + ti;
-        if (tile >= total_tiles) break;
+    for (int ct = 0; ct < 2; ++ct) {
+        const int tap = ct * 16 + l15;
+        okB[ct] = tap < NTAP;
+        const int tt = okB[ct] ? tap : 0;
+        offB[ct] = ((kq >> 1) + tt / KS) * LXW + (kq & 1) + tt % KS;
+    }
+    // staging registers of one tile: two (window, channel quad) items and two halo pixels per thread
+    float4 rg[2];
+    unsigned rt_[2];
+    float rh[2];
+    auto load_tile = [&](int tile) {
         const int bx = tile % tiles_x, by = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
         const int cy0 = by * TC, cx0 = bx * TC;
-        const float* img = X + (size_t)n * H * W;
-        // pooled gradient and tie mask of pooled output p (0 when p is outside the tile / the map)
-        auto fetch = [&](int p, float& g, int& ties) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = tid + i * DPP_THREADS, p = item >> 3, oq = item & 7;
             const int py = (cy0 >> 1) + (p >> 3), px = (cx0 >> 1) + (p & 7);
-            const bool ok = p < 64 && py < Hp && px < Wp;
-            const size_t idx = ok ? (((size_t)n * Hp + py) * Wp + px) * Co + o : 0;
-            g = ok ? dY[idx] : 0.0f;
-            ties = ok ? (int)arg[idx] : 0;
-        };
-        float g_next = 0.0f;
-        int t_next = 0;
-        if (pg < npg) fetch(pg, g_next, t_next);
-        __syncthreads();
-        for (int s = tid; s < LX * LX; s += DPP_THREADS) {
-            int hy = s / LX, hx = s - hy * LX;
-            int y = cy0 + hy - PAD, x = cx0 + hx - PAD;
-            xs[hy * LXW + hx] = (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : 0.0f;
-        }
-        __syncthreads();
-        if (pg < npg) {
-#pragma unroll 1
-            for (int p = pg; p < 64; p += npg) {          // 8x8 pooled outputs of the tile
-                const float g = g_next;
-                const int ties = t_next;
-                fetch(p + npg, g_next, t_next);           // the next output's loads fly under this one's FMAs
-                if (ties == 0) continue;
-                const int ply = p >> 3, plx = p & 7;
-                float patch[6][6];
-#pragma unroll
-                for (int r = 0; r < 6; ++r)
-#pragma unroll
-                    for (int c2 = 0; c2 < 3; ++c2) {
-                        const float2 v = *reinterpret_cast<const float2*>(&xs[(2 * ply + r) * LXW + 2 * plx + 2 * c2]);
-                        patch[r][2 * c2] = v.x;
-                        patch[r][2 * c2 + 1] = v.y;
-                    }
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    if (!((ties >> a) & 1)) continue;
-#pragma unroll
-                    for (int k = 0; k < NTAP; ++k) acc[k] += g * patch[(a >> 1) + k / KS][(a & 1) + k % KS];
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned t = 0;
+            if (py < Hp && px < Wp && oq * 4 < Co) {
+                const size_t idx = (((size_t)n * Hp + py) * Wp + px) * Co + oq * 4;
+                if (vec) {
+                    g = *reinterpret_cast<const float4*>(dY + idx);
+                    t = *reinterpret_cast<const unsigned*>(arg + idx);
+                } else {
+                    float gv[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 4; ++j)
+                        if (oq * 4 + j < Co) { gv[j] = dY[idx + j]; t |= (unsigned)arg[idx + j] << (8 * j); }
+                    g = make_float4(gv[0], gv[1], gv[2], gv[3]);
                 }
             }
+            rg[i] = g;
+            rt_[i] = t;
         }
-    }
+        const float* img = X + (size_t)n * H * W;
 #pragma unroll
-    for (int k = 0; k < NTAP; ++k) red[tid * NTAP + k] = acc[k];
+        for (int i = 0; i < 2; ++i) {
+            const int s2 = tid + i * DPP_THREADS;
+            float v = 0.0f;
+            if (s2 < LX * LX) {
+                const int hy = s2 / LX, hx = s2 - hy * LX;
+                const int y = cy0 + hy - PAD, x = cx0 + hx - PAD;
+                if (y >= 0 && y < H && x >= 0 && x < W) v = img[(size_t)y * W + x];
+            }
+            rh[i] = v;
+        }
+    };
+    auto commit_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int item = tid + i * DPP_THREADS, p = item >> 3, oq = item & 7;
+            const float4 g = rg[i];
+            const unsigned t = rt_[i];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float4 m;
+                m.x = ((t >> a) & 1u) ? g.x : 0.0f;
+                m.y = ((t >> (8 + a)) & 1u) ? g.y : 0.0f;
+                m.z = ((t >> (16 + a)) & 1u) ? g.z : 0.0f;
+                m.w = ((t >> (24 + a)) & 1u) ? g.w : 0.0f;
+                *reinterpret_cast<float4*>(&gm[a * GM_A + p * 32 + oq * 4]) = m;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s2 = tid + i * DPP_THREADS;
+            if (s2 < LX * LX) xs[(s2 / LX) * LXW + s2 % LX] = rh[i];
+        }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tile0 = blockIdx.x * tiles_per_block;
+    int ntiles = total_tiles - tile0;
+    if (ntiles > tiles_per_block) ntiles = tiles_per_block;
+    if (ntiles > 0) load_tile(tile0);
+    for (int ti = 0; ti < ntiles; ++ti) {
+        commit_tile();
+        __syncthreads();
+        if (ti + 1 < ntiles) load_tile(tile0 + ti + 1);          // in flight under the MFMAs below
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            const int p = wave * 16 + sidx;
+            const int base = (2 * (p >> 3)) * LXW + 2 * (p & 7);
+            const float a0 = gm[kq * GM_A + p * 32 + l15], a1 = gm[kq * GM_A + p * 32 + 16 + l15];
+            const float b0 = okB[0] ? xs[base + offB[0]] : 0.0f;
+            const float b1 = okB[1] ? xs[base + offB[1]] : 0.0f;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D layout: col (tap) = lane & 15, row (o) = (lane >> 4) * 4 + r
+    float* red = gm;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave * 1024 + (rt * 16 + kq * 4 + r) * 32 + ct * 16 + l15] = acc[rt][ct][r];
     __syncthreads();
-    for (int s = tid; s < Co * NTAP; s += DPP_THREADS) {
-        int oo = s / NTAP, k = s - oo * NTAP;
-        float sum = 0.0f;
-        for (int j = 0; j < npg; ++j) sum += red[(j * Co + oo) * NTAP + k];
-        partial[(size_t)blockIdx.x * Co * NTAP + s] = sum;
+    for (int s2 = tid; s2 < Co * NTAP; s2 += DPP_THREADS) {
+        const int oo = s2 / NTAP, k = s2 - oo * NTAP;
+        const int at = oo * 32 + k;
+        partial[(size_t)blockIdx.x * Co * NTAP + s2] = ((red[at] + red[1024 + at]) + red[2048 + at]) + red[3072 + at];
     }
 }
 
