@@ -2,7 +2,9 @@
 """Two-stream timeline of one train step from a rocprofv3 --kernel-trace database (rocpd SQLite):
    python tools/timeline.py <results.db> [step_index_from_end]
 Prints, for the step that ends with the chosen adam_kernel dispatch, when each queue (HIP stream) is busy and what the end of
-the step waits for -- i.e. whether the main chain or the parameter-gradient branch is the critical path."""
+the step waits for.  Caveat: on this ROCm rocprofv3's kernel trace serialises the dispatches of both streams onto one queue
+(the traced step takes 9 ms instead of 4.7), so the trace shows kernel durations and order but NOT the overlap; the overlap is
+measured with HIP events by tools/tail_probe.py."""
 import re
 import sqlite3
 import sys
