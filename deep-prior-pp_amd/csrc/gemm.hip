@@ -280,8 +280,19 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
                     if (k < k_end) {
                         const float* pa = a_base[s] + k;
                         const float4 g = load4(pa, k, k_end, ga.vecA);
-                        if constexpr (LAZY) v = bnbwd4_masked(g, load4(pa + a2off, k, k_end, ga.vecA), d.actA, k, k_end);
-                        else v = act4_masked(g, d.actA, k, k_end);
+                        if constexpr (LAZY) {
+                            v = bnbwd4_masked(g, load4(pa + a2off, k, k_end, ga.vecA), d.actA, k, k_end);
+                            if (d.actA.out != nullptr && blockIdx.y == 0) {
+                                // every operand element is staged exactly once by the first column block: it leaves a copy
+                                float* po = d.actA.out + (pa - d.A);
+                                if (ga.vecA && k + 3 < k_end) *reinterpret_cast<float4*>(po) = v;
+                                else {
+                                    const float vv[4] = {v.x, v.y, v.z, v.w};
+                                    for (int j = 0; j < 4; ++j)
+                                        if (k + j < k_end) po[j] = vv[j];
+                                }
+                            }
+                        } else v = act4_masked(g, d.actA, k, k_end);
                     }
                 } else {
                     int k = kc + slot / (BM / 4), gi = row0 + (slot % (BM / 4)) * 4;
@@ -642,7 +653,8 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     if (d.actB.mode & 4) return DPP_E_UNSUPPORTED;
     if (d.actA.mode & 4) {
         if (d.actA.mode != 4 || d.variant == 1 || !d.actA.x2 || !d.actA.aux || !d.actA.mean || !d.actA.scale || !d.actA.beta) return DPP_E_BADARG;
-        ga.vecA = ga.vecA && aligned16(d.actA.x2);
+        ga.vecA = ga.vecA && aligned16(d.actA.x2) && aligned16(d.actA.out);
+        if (d.actA.out && (!d.a_kc || d.splitk != 1 || d.mapA.s != 1)) return DPP_E_UNSUPPORTED;
         if (!(aligned16(d.actA.mean) && aligned16(d.actA.scale) && aligned16(d.actA.beta) && aligned16(d.actA.aux))) return DPP_E_BADARG;
     }
     ga.vecB = aligned16(d.B) && (d.ldb % 4 == 0);

@@ -268,10 +268,13 @@ def gemm_plan(M, N, K, allow_split=True):
 
 OVERLAP_ALLREDUCE = os.environ.get('DPP_OVERLAP_ALLREDUCE', '1') != '0'
 EARLY_BUCKET_MIN = int(os.environ.get('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elements; FC1 of the 128x128 ResNet has 16.8 M
-# 1x1 convolutions can read the BatchNorm gradient as (G, x) instead of a materialised dX (see _resolve_view).  Off by default:
-# it takes 20 bn_bwd_apply launches (107 us) off the main chain but makes 40 GEMMs 3.5 us slower each, half of them on the
-# gradient branch, which is what the end of the step waits for (4.87 vs 4.71 ms per step).
-LAZY_BN_BWD = os.environ.get('DPP_LAZY_BN_BWD', '0') == '1'
+# 1x1 convolutions can read the BatchNorm gradient as (G, x) instead of a materialised dX (see _resolve_view).
+#   1: data AND filter gradient take the two-tensor operand.  Takes 20 bn_bwd_apply launches (107 us) off the main chain but
+#      makes 40 GEMMs 3.5 us slower each, half of them on the gradient branch, which the end of the step waits for
+#      (4.87 vs 4.71 ms per step).
+#   2: only the data gradient does, and it leaves the dX it forms in memory for the filter gradient (dpp_act.out), which
+#      then starts after it instead of beside it.
+LAZY_BN_BWD = int(os.environ.get('DPP_LAZY_BN_BWD', '0'))
 ROWSTREAM = os.environ.get('DPP_ROWSTREAM', '0') != '0'      # measured: no gain over the LDS-tiled kernel yet
 
 
@@ -803,7 +806,7 @@ class CompiledNet(object):
                 gv = st.view(prm, 'g')
                 self.bwd.add(ops.scale(rt, gv, gv, C, a=1.0 / W))
         if lazy:
-            t.lazy = dict(G=vg.grad, act=ops.act_bn_bwd(b, q, p, t.buf, C), bn=b, c1=c1, c2=c2)
+            t.lazy = dict(G=vg.grad, bn=b, c1=c1, c2=c2, q=q, p=p)
             return
         self._emit_bn_bwd_apply(t, vg.grad, b, c1, c2)
 
@@ -861,9 +864,17 @@ class CompiledNet(object):
                 self._resolve_view(self.view_grads.pop(v.key()))
             out = io['out']
             lz = getattr(out, 'lazy', None)
-            if lz is not None and kind == 'ConvLayer' and tuple(layer.cfgParams.filterDim) == (1, 1):
+            if lz is not None and kind == 'ConvLayer' and tuple(layer.cfgParams.filterDim) == (1, 1) and \
+                    (LAZY_BN_BWD == 1 or io['in_view'].base not in self.x_ins):
                 out.lazy = None
-                self._bwd_conv(layer, io, io['in_view'], lz['G'], dY_act=lz['act'])
+                b = lz['bn']
+                keep = None
+                if LAZY_BN_BWD == 2:
+                    if out.grad is None:
+                        out.grad = rt.alloc(out.shape, zero=False)
+                    keep = out.grad
+                self._bwd_conv(layer, io, io['in_view'], lz['G'], dY_act=ops.act_bn_bwd(b, lz['q'], lz['p'], out.buf, b.C, out=keep),
+                               dY_keep=keep)
                 continue
             dY = self._grad_of(out)
             if dY is None:
@@ -928,8 +939,9 @@ class CompiledNet(object):
         self.bwd.add(ops.colsum_partial(self.rt, dY, rows, C, rpb, part), side=True)
         self.bwd.add(ops.reduce_partials(self.rt, part, nb, C, gslot), side=True)
 
-    def _bwd_conv(self, layer, io, src, dY, dY_act=None):
-        """dY_act: dY is the masked BatchNorm gradient G and the true dY is formed by this operand prologue (see _resolve_view)."""
+    def _bwd_conv(self, layer, io, src, dY, dY_act=None, dY_keep=None):
+        """dY_act: dY is the masked BatchNorm gradient G and the true dY is formed by this operand prologue (see _resolve_view);
+        dY_keep: the data gradient leaves the dY it forms there, and the filter gradient reads that plain tensor."""
         rt, st = self.rt, self.store
         c = layer.cfgParams
         N, Hi, Wi, Ci = src.base.shape
@@ -940,26 +952,34 @@ class CompiledNet(object):
         gW, gb = st.view(layer.W, 'g'), st.view(layer.b, 'g')
         if io.get('residual') is not None:
             io['residual'].pending.append(dY)                 # identity path of the fused residual add
-        # parameter gradients only READ dY / the forward activations, so they run as a parallel branch on the side
-        # stream while the main stream continues with the data-gradient chain
-        self.bwd.fork()
-        if dY_act is None:
-            self._bias_grad(dY, M, Co, gb)
-        else:
-            # sum over pixels of scale*(G - c1 - xhat*c2) with c1 = mean(G), sum(xhat) = 0: the bias of a convolution that
-            # feeds a BatchNorm has no gradient (the reference adds up rounding noise); a job without slices writes zeros
-            assert k == (1, 1) and io.get('residual') is None
-            self.reduce_jobs.add(dY, 0, Co, gb)
         need_dx = src.base not in self.x_ins
-        if k == (1, 1):
+
+        def emit_param_grads(dy, dy_act):
+            # parameter gradients only READ dY / the forward activations, so they run as a parallel branch on the side
+            # stream while the main stream continues with the data-gradient chain
+            self.bwd.fork()
+            if dY_act is None:
+                self._bias_grad(dy, M, Co, gb)
+            else:
+                # sum over pixels of scale*(G - c1 - xhat*c2) with c1 = mean(G), sum(xhat) = 0: the bias of a convolution that
+                # feeds a BatchNorm has no gradient (the reference adds up rounding noise); a job without slices writes zeros
+                assert k == (1, 1) and io.get('residual') is None
+                self.reduce_jobs.add(dy, 0, Co, gb)
+            if k != (1, 1):
+                return
             mp = RowMap.strided(s, Ho, Wo, Hi, Wi) if s != 1 else None
             # filter gradient dW[o][c] = sum_m dY[m][o] * act(X)[map(m)][c]
             tile, splitk = wgrad_plan(Co, Ci, M)
             part = rt.alloc(splitk * Co * Ci, zero=False) if splitk > 1 else None     # persistent: reduced at the end of backward
-            self.bwd.add(ops.gemm(rt, dY, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actA=dY_act,
+            self.bwd.add(ops.gemm(rt, dy, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actA=dy_act,
                                   actB=act, splitk=splitk, partial=part, tile=tile, name='wgrad1x1_%d' % layer.layerNum), side=True)
             if splitk > 1:
                 self.reduce_jobs.add(part, splitk, Co * Ci, gW)
+
+        if dY_keep is None:
+            emit_param_grads(dY, dY_act)
+        if k == (1, 1):
+            mp = RowMap.strided(s, Ho, Wo, Hi, Wi) if s != 1 else None
             if need_dx:
                 tgt, dst = self._view_grad(src)
                 acc = tgt.grad_written
@@ -984,6 +1004,9 @@ class CompiledNet(object):
                                       residual=dst if acc else None, tile=tile, epi=epi, variant=1 if rs is not None and dY_act is None else 0,
                                       name='dgrad1x1_%d' % layer.layerNum))
                 tgt.grad_written = True
+            if dY_keep is not None:
+                assert need_dx
+                emit_param_grads(dY_keep, None)               # after the data gradient, which wrote dY_keep
         else:
             bm = 64
             nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, Hi, Wi, bm)

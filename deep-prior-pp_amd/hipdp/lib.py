@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'lib', 'libdpp_hip.so')
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 c_float_p = C.c_void_p      # device pointers travel as integers
 stream_t = C.c_void_p
 
@@ -30,13 +30,13 @@ class RowMap(C.Structure):
 
 class Act(C.Structure):
     _fields_ = [('mean', C.c_void_p), ('scale', C.c_void_p), ('beta', C.c_void_p), ('mode', C.c_int), ('cmod', C.c_int),
-                ('x2', C.c_void_p), ('aux', C.c_void_p)]
+                ('x2', C.c_void_p), ('aux', C.c_void_p), ('out', C.c_void_p)]
 
     NONE, RELU, BN, BN_RELU, BN_BWD = 0, 1, 2, 3, 4
 
     @staticmethod
     def none():
-        return Act(None, None, None, 0, 1, None, None)
+        return Act(None, None, None, 0, 1, None, None, None)
 
 
 class Epilogue(C.Structure):

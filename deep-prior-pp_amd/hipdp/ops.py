@@ -91,16 +91,16 @@ def _p(buf):
     return None if buf is None else buf.ptr
 
 
-def act(mode=0, mean=None, scale=None, beta=None, cmod=1, x2=None, aux=None):
-    a = Act(_p(mean), _p(scale), _p(beta), int(mode), int(cmod), _p(x2), _p(aux))
-    a._keep = (mean, scale, beta, x2, aux)
+def act(mode=0, mean=None, scale=None, beta=None, cmod=1, x2=None, aux=None, out=None):
+    a = Act(_p(mean), _p(scale), _p(beta), int(mode), int(cmod), _p(x2), _p(aux), _p(out))
+    a._keep = (mean, scale, beta, x2, aux, out)
     return a
 
 
-def act_bn_bwd(bn, q, p, x, C):
+def act_bn_bwd(bn, q, p, x, C, out=None):
     """Operand prologue of dpp_gemm's A in mode 4: the operand is the masked gradient G of BatchNorm `bn`, and the value used
     is dX = scale*G - p*(x - mean) - q (q = scale*c1, p = scale*inv_std*c2 from bn_bwd_finalize): bn_bwd_apply on the fly."""
-    return act(Act.BN_BWD, mean=bn.mean, scale=bn.scale, beta=q, cmod=C, x2=x, aux=p)
+    return act(Act.BN_BWD, mean=bn.mean, scale=bn.scale, beta=q, cmod=C, x2=x, aux=p, out=out)
 
 
 def epilogue(stats=None, bn=None, bn_x=None, bn_relu=True, bn_partial=None):

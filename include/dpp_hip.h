@@ -34,7 +34,7 @@ typedef void* dpp_stream_t; /* a hipStream_t */
 #define DPP_E_BADARG 10001
 #define DPP_E_UNSUPPORTED 10002
 
-#define DPP_ABI_VERSION 3
+#define DPP_ABI_VERSION 4
 int dpp_abi_version(void);
 
 /* Pixel row map: row m of a compact (N,Ho,Wo) map -> row of a (N,Hi,Wi) map sampled with stride s.
@@ -52,7 +52,9 @@ typedef struct {
  * evaluated from the masked gradient g (the operand itself) and the BatchNorm input x2 (same shape and leading dimension
  * as the operand) instead of being materialised by dpp_bn_bwd_apply: with scale = gamma*inv_std, aux = scale*inv_std*c2 and
  * beta = scale*c1 (written by dpp_bn_bwd_finalize) this is dX = scale * (G - c1 - xhat*c2), batchnormlayer.py:119-194 under
- * T.grad. */
+ * T.grad.  If `out` is set (K-contiguous operand only) the values formed are also written there, in the operand's layout,
+ * by the workgroups of the first column block: the data-gradient GEMM materialises dX on the way for the kernels that
+ * want it as a plain tensor (the filter gradient on the other stream). */
 typedef struct {
     const float* mean;
     const float* scale;
@@ -61,6 +63,7 @@ typedef struct {
     int cmod;
     const float* x2;     /* mode 4 only */
     const float* aux;    /* mode 4 only */
+    float* out;          /* mode 4 only, may be NULL */
 } dpp_act;
 
 /* Optional fused epilogue work on the output tile (both NULL = plain epilogue).

@@ -95,12 +95,12 @@ def test_resnet_forward_eval_matches_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('type_', [0, 1, 'lazy'])
+@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2'])
 def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatch):
     """'lazy': type 0 with the opt-in plan in which the 1x1 convolutions form the gradient through a BatchNorm from (G, x) in
     their operand prologue (engine.LAZY_BN_BWD) instead of reading a tensor written by bn_bwd_apply."""
-    if type_ == 'lazy':
-        monkeypatch.setattr(engine, 'LAZY_BN_BWD', True)
+    if type_ in ('lazy', 'lazy2'):       # lazy2: only the data gradient does, and leaves the tensor it forms for the filter gradient
+        monkeypatch.setattr(engine, 'LAZY_BN_BWD', 1 if type_ == 'lazy' else 2)
         type_ = 0
     rt = get_runtime(backend)
     nJ, nD = (1, 30) if type_ == 0 else (14, 3)

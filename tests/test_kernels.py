@@ -434,10 +434,15 @@ def test_gemm_operand_through_batchnorm_backward(backend, a_kc):
     dX = scale.astype('f8') * (G.astype('f8') - c1 - (X.astype('f8') - mean) * istd * c2)
     act = ops.act_bn_bwd(bn, q, p, Xb, Cc)
     if a_kc:
+        Co = 100                                                     # two column blocks: the operand copy is written once
         Wm = rng.normal(size=(Cc, Co)).astype(np.float32)            # C[m][o] = sum_c dX[m][c] W[c][o]
         out = rt.alloc((Mp, Co), zero=False)
+        copy = rt.alloc((Mp, Cc), zero=True)
+        act = ops.act_bn_bwd(bn, q, p, Xb, Cc, out=copy)             # ... and leaves the operand it formed in `copy`
         ops.gemm(rt, Gb, rt.upload(Wm), out, Mp, Co, Cc, 1, 0, Cc, Co, Co, actA=act)(rt.stream)
         ref = dX @ Wm.astype('f8')
+        rt.synchronize()
+        np.testing.assert_allclose(copy.get(), dX, rtol=0, atol=2e-6 * np.abs(dX).max())
     else:
         Y = rng.normal(size=(Mp, Co)).astype(np.float32)             # C[c][o] = sum_m dX[m][c] Y[m][o]
         out = rt.alloc((Cc, Co), zero=False)
