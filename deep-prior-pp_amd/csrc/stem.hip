@@ -295,7 +295,7 @@ extern "C" int dpp_stem_wgrad_blocks(int N, int H, int W, int tiles_per_block) {
 
 extern "C" int dpp_stem_wgrad(const float* X, int N, int H, int W, const float* dY, const uint8_t* argmax, int Co, float* partial,
                               int tiles_per_block, dpp_stream_t stream) {
-    if (!X || !dY || !argmax || !partial || N < 1 || (H & 1) || (W & 1) || Co < 1 || Co > 32 || (DPP_THREADS % Co) || tiles_per_block < 1)
+    if (!X || !dY || !argmax || !partial || N < 1 || (H & 1) || (W & 1) || Co < 1 || Co > 32 || tiles_per_block < 1)
         return DPP_E_BADARG;
     int tiles_x = dpp_cdiv(W, TC), tiles_y = dpp_cdiv(H, TC);
     int total = tiles_x * tiles_y * N;

@@ -58,7 +58,7 @@ def test_conv3x3_fwd_dgrad_wgrad(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('cfg', [(2, 32, 32, 32), (3, 16, 48, 32), (1, 36, 20, 16)])
+@pytest.mark.parametrize('cfg', [(2, 32, 32, 32), (3, 16, 48, 32), (1, 36, 20, 16), (1, 32, 16, 30), (2, 16, 16, 24)])
 def test_stem_fwd_and_wgrad(backend, cfg):
     rt = get_runtime(backend)
     N, H, W, Co = cfg
