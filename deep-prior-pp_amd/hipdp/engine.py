@@ -1039,6 +1039,8 @@ class CompiledNet(object):
         self.bwd.fork()
         self._bias_grad(dY, Nb, Nout, gb)
         tile, _ = gemm_plan(K, Nout, Nb, allow_split=False)
+        if K >= 4096 and Nout >= 64 and os.environ.get('DPP_FC1_TILE128', '1') != '0':
+            tile = (128, 64, 4)          # FC1: 67 MB of output, MFMA-bound (tools/gemm_micro.py fc: 107 -> 84 us)
         self.bwd.add(ops.gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, tile=tile,
                               name='fc_wgrad_%d' % layer.layerNum), side=True)
         if self.dp is not None and self._early_slice is None and K * Nout >= EARLY_BUCKET_MIN and OVERLAP_ALLREDUCE:
