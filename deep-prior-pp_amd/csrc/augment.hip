@@ -541,7 +541,7 @@ extern "C" int dpp_augment_prepare(const float* img, const float* com3d, const f
     a.cam.fx = fx; a.cam.fy = fy; a.cam.ux = ux; a.cam.uy = uy; a.cam.flip_y = flip_y;
     a.B = B; a.J = J; a.dsz = dsz; a.norm01 = norm_zero_one; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
     a.rec = static_cast<AugRec*>(records); a.out_y = out_y; a.out_mode = out_mode;
-    hipLaunchKernelGGL(augment_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    DPP_LAUNCH(augment_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return dpp_launch_status();
 }
 
@@ -553,14 +553,14 @@ __global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc
 
 extern "C" int dpp_counter_add(unsigned long long* counter, unsigned long long inc, dpp_stream_t stream) {
     if (!counter) return DPP_E_BADARG;
-    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, inc);
+    DPP_LAUNCH(counter_add_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), counter, inc);
     return dpp_launch_status();
 }
 
 extern "C" int dpp_augment_warp(const float* img, const void* records, int B, int dsz, float* out, dpp_stream_t stream) {
     if (!img || !records || !out || B < 1 || dsz < 1 || img == out) return DPP_E_BADARG;
     dim3 grid(dpp_cdiv(dsz * dsz, DPP_THREADS), B);
-    hipLaunchKernelGGL(augment_warp_kernel, grid, dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), img,
+    DPP_LAUNCH(augment_warp_kernel, grid, dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), img,
                        static_cast<const AugRec*>(records), dsz, out);
     return dpp_launch_status();
 }
@@ -570,7 +570,7 @@ extern "C" size_t dpp_crop_record_bytes(void) { return sizeof(CropRec); }
 extern "C" int dpp_crop_prepare(const float* frames, int B, int H, int W, const float* com, const float* cube, double fx, double fy,
                                 int dsz, void* records, float* M_out, dpp_stream_t stream) {
     if (!frames || !com || !cube || !records || B < 1 || H < 1 || W < 1 || dsz < 1 || fx == 0.0 || fy == 0.0) return DPP_E_BADARG;
-    hipLaunchKernelGGL(crop_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W, com, cube,
+    DPP_LAUNCH(crop_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W, com, cube,
                        fabs(fx), fabs(fy), dsz, static_cast<CropRec*>(records), M_out);
     return dpp_launch_status();
 }
@@ -579,14 +579,14 @@ extern "C" int dpp_crop_warp(const float* frames, const void* records, int B, in
                              float* out, dpp_stream_t stream) {
     if (!frames || !records || !out || B < 1 || H < 1 || W < 1 || dsz < 1) return DPP_E_BADARG;
     dim3 grid(dpp_cdiv(dsz * dsz, DPP_THREADS), B);
-    hipLaunchKernelGGL(crop_warp_kernel, grid, dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W,
+    DPP_LAUNCH(crop_warp_kernel, grid, dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W,
                        static_cast<const CropRec*>(records), dsz, normalize, nd_value, out);
     return dpp_launch_status();
 }
 
 extern "C" int dpp_crop_com(const float* frames, const void* records, int B, int H, int W, float* com_out, dpp_stream_t stream) {
     if (!frames || !records || !com_out || B < 1 || H < 1 || W < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(crop_com_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W,
+    DPP_LAUNCH(crop_com_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W,
                        static_cast<const CropRec*>(records), com_out);
     return dpp_launch_status();
 }

@@ -340,7 +340,7 @@ bool ok_c(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= MAXQ && (DPP_THR
 extern "C" int dpp_bn_stats_partial(const float* X, int M, int C, int rows_per_block, float* partial, dpp_stream_t stream) {
     if (!X || !partial || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS) return DPP_E_BADARG;
     int nb = dpp_cdiv(M, rows_per_block);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), X, M, C,
+    DPP_LAUNCH(bn_stats_partial_kernel, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), X, M, C,
                        rows_per_block, partial);
     return dpp_launch_status();
 }
@@ -353,7 +353,7 @@ extern "C" int dpp_bn_finalize(const float* partial, int nb, int nseg, int M, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     // one wave per channel, or the whole workgroup per channel when there are many partial blocks; loads batched so that a
     // thread needs one or two round trips
-#define DPP_BNF(U_, W_) hipLaunchKernelGGL((bn_finalize_kernel<U_, W_>), dim3(dpp_cdiv(C, 4 / W_)), dim3(DPP_THREADS), 0, st, partial, nb, nseg, \
+#define DPP_BNF(U_, W_) DPP_LAUNCH((bn_finalize_kernel<U_, W_>), dim3(dpp_cdiv(C, 4 / W_)), dim3(DPP_THREADS), 0, st, partial, nb, nseg, \
                                            M, rows_per_block, C, gamma, eps, mean, inv_std, scale, run_mean, run_inv_std, alpha)
     if (nb <= 2 * DPP_WAVE) DPP_BNF(2, 1); else if (nb <= 8 * DPP_WAVE) DPP_BNF(8, 1); else if (nb <= 32 * DPP_WAVE) DPP_BNF(8, 4); else DPP_BNF(32, 4);
 #undef DPP_BNF
@@ -363,7 +363,7 @@ extern "C" int dpp_bn_finalize(const float* partial, int nb, int nseg, int M, in
 extern "C" int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, const float* run_inv_std, int C, float* mean,
                                   float* inv_std, float* scale, dpp_stream_t stream) {
     if (!gamma || !run_mean || !run_inv_std || !mean || !inv_std || !scale || C < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(dpp_cdiv(C, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+    DPP_LAUNCH(bn_eval_coeffs_kernel, dim3(dpp_cdiv(C, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
                        gamma, run_mean, run_inv_std, C, mean, inv_std, scale);
     return dpp_launch_status();
 }
@@ -373,7 +373,7 @@ extern "C" int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, 
                                  dpp_stream_t stream) {
     if (!dA || !X || !G || !partial || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS) return DPP_E_BADARG;
     int nb = dpp_cdiv(M, rows_per_block);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dA, X, M, C, mean,
+    DPP_LAUNCH(bn_bwd_reduce_kernel, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dA, X, M, C, mean,
                        inv_std, scale, beta, relu, G, rows_per_block, partial);
     return dpp_launch_status();
 }
@@ -383,7 +383,7 @@ extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M
     if (!partial || !dbeta || !dgamma || !c1 || !c2 || nb < 1 || nseg < 1) return DPP_E_BADARG;
     if (q && !(p && inv_std && scale)) return DPP_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DPP_BNBF(U_, W_) hipLaunchKernelGGL((bn_bwd_finalize_kernel<U_, W_>), dim3(dpp_cdiv(C, 4 / W_)), dim3(DPP_THREADS), 0, st, partial, nb, \
+#define DPP_BNBF(U_, W_) DPP_LAUNCH((bn_bwd_finalize_kernel<U_, W_>), dim3(dpp_cdiv(C, 4 / W_)), dim3(DPP_THREADS), 0, st, partial, nb, \
                                             nseg, M, C, dbeta, dgamma, c1, c2, inv_std, scale, q, p)
     if (nb <= 2 * DPP_WAVE) DPP_BNBF(2, 1); else if (nb <= 8 * DPP_WAVE) DPP_BNBF(8, 1); else if (nb <= 32 * DPP_WAVE) DPP_BNBF(8, 4); else DPP_BNBF(32, 4);
 #undef DPP_BNBF
@@ -394,7 +394,7 @@ extern "C" int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, co
                                 const float* scale, const float* c1, const float* c2, const float* add, float* dX,
                                 int rows_per_block, float* colsum_partial, dpp_stream_t stream) {
     if (!G || !X || !dX || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS) return DPP_E_BADARG;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), G, X,
+    DPP_LAUNCH(bn_bwd_apply_kernel, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), G, X,
                        M, C, mean, inv_std, scale, c1, c2, add, dX, rows_per_block, colsum_partial);
     return dpp_launch_status();
 }

@@ -475,7 +475,7 @@ extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dp
     // gfx950 has 160 KiB of LDS per CU; requests above the default 64 KiB window need the opt-in attribute
 #define DPP_C3(BM_, BN_) if (bm == BM_ && bn == BN_) { \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((conv3x3_kernel<BM_, BN_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
+        DPP_LAUNCH((conv3x3_kernel<BM_, BN_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
     DPP_C3(128, 64) DPP_C3(128, 32) DPP_C3(128, 16) DPP_C3(64, 64) DPP_C3(64, 32) DPP_C3(64, 16)
 #undef DPP_C3
     return DPP_E_UNSUPPORTED;
@@ -484,7 +484,7 @@ extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dp
 extern "C" int dpp_conv3x3_wtrans(const float* Wk, int Co, int Ci, float* Wd, dpp_stream_t stream) {
     if (!Wk || !Wd || Co < 1 || Ci < 1) return DPP_E_BADARG;
     int n = Co * 9 * Ci;
-    hipLaunchKernelGGL(conv3x3_wtrans_kernel, dim3(dpp_cdiv(n, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), Wk, Co, Ci, Wd);
+    DPP_LAUNCH(conv3x3_wtrans_kernel, dim3(dpp_cdiv(n, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), Wk, Co, Ci, Wd);
     return dpp_launch_status();
 }
 
@@ -520,7 +520,7 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<BM_, MA_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((conv3x3_wgrad_kernel<BM_, MA_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
+        DPP_LAUNCH((conv3x3_wgrad_kernel<BM_, MA_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
     DPP_W3(128, 3) DPP_W3(128, 9) DPP_W3(128, 12) DPP_W3(128, 16)
     DPP_W3(64, 3) DPP_W3(64, 9) DPP_W3(64, 12) DPP_W3(64, 16)
 #undef DPP_W3

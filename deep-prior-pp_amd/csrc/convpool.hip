@@ -230,11 +230,11 @@ extern "C" int dpp_convpool_fwd(const float* X, int N, int H, int W, int Ci, con
     hipStream_t st = static_cast<hipStream_t>(stream);
     int cpt = dpp_cdiv(Co, WG_WAVES);
     if (cpt <= 2)
-        hipLaunchKernelGGL((convpool_fwd_kernel<2>), grid, block, lds, st, X, cp_act(act), Wk, bias, Y, ties, g);
+        DPP_LAUNCH((convpool_fwd_kernel<2>), grid, block, lds, st, X, cp_act(act), Wk, bias, Y, ties, g);
     else if (cpt <= 4)
-        hipLaunchKernelGGL((convpool_fwd_kernel<4>), grid, block, lds, st, X, cp_act(act), Wk, bias, Y, ties, g);
+        DPP_LAUNCH((convpool_fwd_kernel<4>), grid, block, lds, st, X, cp_act(act), Wk, bias, Y, ties, g);
     else
-        hipLaunchKernelGGL((convpool_fwd_kernel<8>), grid, block, lds, st, X, cp_act(act), Wk, bias, Y, ties, g);
+        DPP_LAUNCH((convpool_fwd_kernel<8>), grid, block, lds, st, X, cp_act(act), Wk, bias, Y, ties, g);
     return dpp_launch_status();
 }
 
@@ -253,7 +253,7 @@ extern "C" int dpp_convpool_wgrad(const float* X, int N, int H, int W, int Ci, c
     if (lds > 64 * 1024) return DPP_E_UNSUPPORTED;
     int total = N * g.tiles_x * g.tiles_y;
     int blocks = dpp_convpool_wgrad_blocks(N, g.Hp, g.Wp);
-    hipLaunchKernelGGL(convpool_wgrad_kernel, dim3(blocks), dim3(DPP_THREADS), lds, static_cast<hipStream_t>(stream), X, cp_act(act), dY,
+    DPP_LAUNCH(convpool_wgrad_kernel, dim3(blocks), dim3(DPP_THREADS), lds, static_cast<hipStream_t>(stream), X, cp_act(act), dY,
                        ties, partial, g, total);
     return dpp_launch_status();
 }
@@ -264,6 +264,6 @@ extern "C" int dpp_convpool_dgrad(const float* dY, const uint16_t* ties, int N, 
     if (!dY || !Wk || !dX || !cp_make_geom(g, N, H, W, Ci, kh, kw, pad, Co, pool) || (pool > 1 && !ties)) return DPP_E_BADARG;
     size_t npix = (size_t)N * H * W;
     dim3 grid((unsigned)((npix + DPP_THREADS - 1) / DPP_THREADS), dpp_cdiv(Ci, 8));
-    hipLaunchKernelGGL(convpool_dgrad_kernel, grid, dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dY, ties, Wk, dX, g);
+    DPP_LAUNCH(convpool_dgrad_kernel, grid, dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dY, ties, Wk, dX, g);
     return dpp_launch_status();
 }

@@ -9,7 +9,64 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DPP_WAVE 64
 #define DPP_THREADS 256
 
+// ---- launch recording (dpp_plan_*, include/dpp_hip.h) ------------------------------------------------------------------
+// Every kernel launch of the library goes through DPP_LAUNCH.  Normally that is a plain launch on `stream`; while the calling
+// thread records a plan (plan.hip) the fully resolved launch -- kernel, grid, block, LDS bytes and a private copy of the
+// arguments -- is appended to the plan instead, to be re-issued later from C++ (or as a hipGraph kernel node).
+#include <functional>
+#include <memory>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+struct dpp_plan_node {
+    int kind = 0;                                          // 0 kernel, 1 memset, 2 fork, 3 join
+    int lane = 0;                                          // 0 main, 1 side
+    std::function<hipError_t(hipStream_t)> issue;          // re-issues the launch on a stream
+    const void* func = nullptr;                            // raw form for hipGraphAddKernelNode
+    dim3 grid, block;
+    size_t shmem = 0;
+    std::shared_ptr<void> argstore;
+    std::vector<void*> argptrs;
+    void* ptr = nullptr;                                   // memset target
+    size_t nbytes = 0;
+};
+struct dpp_plan;
+extern thread_local dpp_plan* dpp_tls_plan;                // the plan this thread is recording into (plan.hip)
+void dpp_plan_append(dpp_plan* plan, dpp_plan_node&& node);
+
+template <class Tuple, size_t... I>
+static inline void dpp_arg_pointers(Tuple& t, std::vector<void*>& out, std::index_sequence<I...>) {
+    (out.push_back(const_cast<void*>(static_cast<const void*>(&std::get<I>(t)))), ...);
+}
+
+template <class... KA, class... A>
+static inline void dpp_launch(void (*kernel)(KA...), dim3 grid, dim3 block, size_t shmem, hipStream_t stream, A&&... args) {
+    static_assert(sizeof...(KA) == sizeof...(A), "kernel / argument count mismatch");
+    if (dpp_tls_plan == nullptr) {
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, static_cast<KA>(args)...);
+        return;
+    }
+    using Tup = std::tuple<std::remove_cv_t<KA>...>;
+    auto tup = std::make_shared<Tup>(static_cast<KA>(args)...);
+    dpp_plan_node n;
+    n.func = reinterpret_cast<const void*>(kernel);
+    n.grid = grid;
+    n.block = block;
+    n.shmem = shmem;
+    dpp_arg_pointers(*tup, n.argptrs, std::index_sequence_for<KA...>{});
+    n.issue = [kernel, grid, block, shmem, tup](hipStream_t s) -> hipError_t {
+        std::apply([&](auto&... a) { hipLaunchKernelGGL(kernel, grid, block, shmem, s, a...); }, *tup);
+        return hipGetLastError();
+    };
+    n.argstore = tup;
+    dpp_plan_append(dpp_tls_plan, std::move(n));
+}
+#define DPP_LAUNCH(kernel, grid, block, shmem, stream, ...) dpp_launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), stream, __VA_ARGS__)
+
 static inline int dpp_launch_status() {
+    if (dpp_tls_plan != nullptr) return DPP_OK;            // recorded, not launched
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DPP_OK : (int)e;
 }

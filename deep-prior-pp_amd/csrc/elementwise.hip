@@ -205,7 +205,7 @@ int grid_for(size_t n) {
 
 extern "C" int dpp_colsum_partial(const float* X, int M, int C, int rows_per_block, float* partial, dpp_stream_t stream) {
     if (!X || !partial || M < 1 || C < 1 || rows_per_block < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+    DPP_LAUNCH(colsum_partial_kernel, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
                        X, M, C, rows_per_block, partial);
     return dpp_launch_status();
 }
@@ -213,20 +213,20 @@ extern "C" int dpp_colsum_partial(const float* X, int M, int C, int rows_per_blo
 extern "C" int dpp_loss_sse(const float* out, const float* y, int rows, int d, int denom, float* cost, float* dout,
                             dpp_stream_t stream) {
     if (!out || !y || !cost || rows < 1 || d < 1 || denom < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(loss_sse_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), out, y, rows * d,
+    DPP_LAUNCH(loss_sse_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), out, y, rows * d,
                        1.0f / (float)denom, cost, dout);
     return dpp_launch_status();
 }
 
 extern "C" int dpp_error_l2(const float* out, const float* y, int rows, int d, float* err, dpp_stream_t stream) {
     if (!out || !y || !err || rows < 1 || d < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(error_l2_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), out, y, rows, d, err);
+    DPP_LAUNCH(error_l2_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), out, y, rows, d, err);
     return dpp_launch_status();
 }
 
 extern "C" int dpp_adam_tick(float* state, dpp_stream_t stream) {
     if (!state) return DPP_E_BADARG;
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), state);
+    DPP_LAUNCH(adam_tick_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), state);
     return dpp_launch_status();
 }
 
@@ -234,36 +234,44 @@ extern "C" int dpp_adam(float* w, const float* g, float* m, float* v, size_t n, 
     if (!w || !g || !m || !v || !hyper || n < 1) return DPP_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
         return DPP_E_BADARG;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n >> 2)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), w, g, m, v, n, hyper);
+    DPP_LAUNCH(adam_kernel, dim3(grid_for(n >> 2)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), w, g, m, v, n, hyper);
     return dpp_launch_status();
 }
 
 extern "C" int dpp_axpy(float* y, const float* x, float alpha, size_t n, dpp_stream_t stream) {
     if (!y || !x || n < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), y, x, alpha, n);
+    DPP_LAUNCH(axpy_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), y, x, alpha, n);
     return dpp_launch_status();
 }
 
 extern "C" int dpp_sumsq(const float* x, size_t n, float alpha, float* out, int accumulate, dpp_stream_t stream) {
     if (!x || !out || n < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), x, n, alpha, out, accumulate);
+    DPP_LAUNCH(sumsq_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), x, n, alpha, out, accumulate);
     return dpp_launch_status();
 }
 
 extern "C" int dpp_scale(const float* x, const float* mask, float a, int relu, float* y, size_t n, dpp_stream_t stream) {
     if (!x || !y || n < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), x, mask, a, relu, y, n);
+    DPP_LAUNCH(scale_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), x, mask, a, relu, y, n);
     return dpp_launch_status();
 }
 
 extern "C" int dpp_relu_bwd(const float* dy, const float* pre, const float* mask, float a, float* g, size_t n, dpp_stream_t stream) {
     if (!dy || !pre || !g || n < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dy, pre, mask, a, g, n);
+    DPP_LAUNCH(relu_bwd_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dy, pre, mask, a, g, n);
     return dpp_launch_status();
 }
 
 extern "C" int dpp_fill_zero(void* p, size_t nbytes, dpp_stream_t stream) {
     if (!p) return DPP_E_BADARG;
+    if (dpp_tls_plan != nullptr) {
+        dpp_plan_node n;
+        n.kind = 1;
+        n.ptr = p;
+        n.nbytes = nbytes;
+        dpp_plan_append(dpp_tls_plan, std::move(n));
+        return DPP_OK;
+    }
     hipError_t e = hipMemsetAsync(p, 0, nbytes, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? DPP_OK : (int)e;
 }
@@ -271,14 +279,14 @@ extern "C" int dpp_fill_zero(void* p, size_t nbytes, dpp_stream_t stream) {
 extern "C" int dpp_bernoulli_mask(float* mask, size_t n, float keep, unsigned long long seed, unsigned long long counter,
                                   const unsigned long long* counter_dev, dpp_stream_t stream) {
     if (!mask || n < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(bernoulli_mask_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), mask, n, keep, seed,
+    DPP_LAUNCH(bernoulli_mask_kernel, dim3(grid_for(n)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), mask, n, keep, seed,
                        counter, counter_dev);
     return dpp_launch_status();
 }
 
 extern "C" int dpp_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, int relu, dpp_stream_t stream) {
     if (!src || !dst || rows < 1 || cols < 1 || lds < cols || ldd < cols) return DPP_E_BADARG;
-    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((size_t)rows * cols)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), src, lds,
+    DPP_LAUNCH(copy2d_kernel, dim3(grid_for((size_t)rows * cols)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), src, lds,
                        dst, ldd, rows, cols, relu);
     return dpp_launch_status();
 }
@@ -287,7 +295,7 @@ extern "C" int dpp_crop_center(const float* src, int B, int H, int W, float* dst
     if (!src || !dst || B < 1 || h < 1 || w < 1 || h > H || w > W) return DPP_E_BADARG;
     // the reference's index arithmetic: start = int(size / 2 - dsize / 2) along each axis
     int y0 = (int)(H / 2.0 - h / 2.0), x0 = (int)(W / 2.0 - w / 2.0);
-    hipLaunchKernelGGL(crop_center_kernel, dim3(grid_for((size_t)B * h * w)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), src, B,
+    DPP_LAUNCH(crop_center_kernel, dim3(grid_for((size_t)B * h * w)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), src, B,
                        H, W, dst, h, w, y0, x0);
     return dpp_launch_status();
 }

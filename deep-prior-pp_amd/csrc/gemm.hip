@@ -603,29 +603,29 @@ int launch_layout(const GemmArgs& ga, hipStream_t st) {
     if (d.actA.mode == 4) {
         // data gradient (A [pixels][C] with B = W [K][N]) and filter gradient (both operands [k][mn]) of a 1x1 convolution
         if (d.a_kc && !d.b_kc) {
-            if (ga.bk == 64) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
-            else if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
-            else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+            if (ga.bk == 64) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+            else if (k32) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 32, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
+            else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 16, true, false, 1, true>), grid, dim3(DPP_THREADS), 0, st, ga);
         } else if (!d.a_kc && !d.b_kc)
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false, 1, true, false>), grid, dim3(DPP_THREADS), 0, st, ga);
+            DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, false, false, 1, true, false>), grid, dim3(DPP_THREADS), 0, st, ga);
         else
             return DPP_E_UNSUPPORTED;
         return dpp_launch_status();
     }
     if (ga.bk == 64 && d.a_kc) {
         // long K-contiguous reductions (stage-2..4 1x1 convolutions and FC layers, K >= 128; measured 4.80 -> 4.74 ms per step): half as many global -> LDS round trips
-        if (d.b_kc) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
-        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, true, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (d.b_kc) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else if (d.a_kc && d.b_kc) {
-        if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
-        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (k32) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 32, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 16, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else if (d.a_kc && !d.b_kc) {
-        if (k32) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 32, true, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
-        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 16, true, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (k32) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 32, true, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 16, true, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else if (!d.a_kc && !d.b_kc) {
         // reduction over pixels / samples: long K, both operands [k][mn] -> 64-deep chunks keep 20+ KB per workgroup in flight
-        if (ga.wide) hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
-        else hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, 64, false, false, 1, false, false>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (ga.wide) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, false, false, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, false, false, 1, false, false>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else
         return DPP_E_UNSUPPORTED;
     return dpp_launch_status();
@@ -694,8 +694,8 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
         if (lds > 64 * 1024) return DPP_E_UNSUPPORTED;
         dim3 grid(dpp_cdiv(d.M, bm), dpp_cdiv(d.N, bn), 1);
 #define DPP_RS(RM_, CN_) if (bm == 64 * RM_ && bn == 16 * CN_) { \
-            if (d.b_kc) hipLaunchKernelGGL((gemm_rowstream_kernel<RM_, CN_, true>), grid, dim3(DPP_THREADS), lds, st, ga); \
-            else hipLaunchKernelGGL((gemm_rowstream_kernel<RM_, CN_, false>), grid, dim3(DPP_THREADS), lds, st, ga); \
+            if (d.b_kc) DPP_LAUNCH((gemm_rowstream_kernel<RM_, CN_, true>), grid, dim3(DPP_THREADS), lds, st, ga); \
+            else DPP_LAUNCH((gemm_rowstream_kernel<RM_, CN_, false>), grid, dim3(DPP_THREADS), lds, st, ga); \
             return dpp_launch_status(); }
         DPP_RS(1, 1) DPP_RS(1, 2) DPP_RS(1, 4) DPP_RS(2, 1) DPP_RS(2, 2) DPP_RS(2, 4)
 #undef DPP_RS
@@ -721,7 +721,7 @@ extern "C" int dpp_reduce_multi_block_cols(void) { return RM_COLS; }
 
 extern "C" int dpp_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, dpp_stream_t stream) {
     if (!jobs_dev || njobs < 1 || total_blocks < 1) return DPP_E_BADARG;
-    hipLaunchKernelGGL(reduce_multi_kernel, dim3(total_blocks), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+    DPP_LAUNCH(reduce_multi_kernel, dim3(total_blocks), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
                        static_cast<const ReduceJob*>(jobs_dev), njobs);
     return dpp_launch_status();
 }
@@ -733,7 +733,7 @@ extern "C" int dpp_reduce_partials(const float* partial, int nz, int n, const fl
     while (ZL < 16 && ZL * 2 <= nz && dpp_cdiv(n, DPP_THREADS / ZL) < 512) ZL *= 2;
     int blocks = dpp_cdiv(n, DPP_THREADS / ZL);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(blocks), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+    DPP_LAUNCH(reduce_partials_kernel, dim3(blocks), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
                        partial, nz, n, bias, nbias > 0 ? nbias : 1, out, ZL);
     return dpp_launch_status();
 }

@@ -1,0 +1,187 @@
+// plan.hip -- launch plans: a whole step (hundreds of dependent kernel launches on two lanes) as ONE call over the C ABI.
+//
+// What the reference gets from `theano.function` -- train_model(index, lr) is a single compiled device function,
+// /root/reference/src/trainer/poseregnettrainer.py:146-170, invoked once per minibatch at
+// /root/reference/src/trainer/nettrainer.py:840 -- is a recorded list of launches here.  The bs128 ResNet step is 400+
+// launches of 5-25 us kernels: issued one by one from Python (ctypes call + descriptor marshalling per launch) the host is
+// slower than the GPU and every dependent kernel waits ~5 us for its successor to arrive.  A plan re-issues the same
+// launches from a tight C++ loop (one hipLaunchKernel each, arguments already packed), or replays them as an explicit
+// hipGraph whose two lanes are parallel branches.
+#include "dpp_common.h"
+// (host code only; the CPU test emulator spells these two built-ins as macros, which would clash with hipKernelNodeParams)
+#undef gridDim
+#undef blockDim
+
+thread_local dpp_plan* dpp_tls_plan = nullptr;
+
+struct dpp_plan {
+    std::vector<dpp_plan_node> nodes;
+    int lane = 0;
+    bool recording = false;
+    int launches = 0, forks = 0, joins = 0;
+    std::vector<hipEvent_t> events;          // one per fork / join, created lazily by the first run
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+void dpp_plan_append(dpp_plan* plan, dpp_plan_node&& node) {
+    node.lane = plan->lane;
+    if (node.kind == 0 || node.kind == 1) plan->launches++;
+    plan->nodes.push_back(std::move(node));
+}
+
+static void plan_drop_graph(dpp_plan* p) {
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    p->exec = nullptr;
+    p->graph = nullptr;
+}
+
+extern "C" int dpp_plan_create(dpp_plan** out) {
+    if (!out) return DPP_E_BADARG;
+    *out = new dpp_plan();
+    return DPP_OK;
+}
+
+extern "C" int dpp_plan_destroy(dpp_plan* plan) {
+    if (!plan) return DPP_E_BADARG;
+    if (dpp_tls_plan == plan) dpp_tls_plan = nullptr;
+    plan_drop_graph(plan);
+    for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
+    delete plan;
+    return DPP_OK;
+}
+
+extern "C" int dpp_plan_record_begin(dpp_plan* plan) {
+    if (!plan || dpp_tls_plan != nullptr) return DPP_E_BADARG;      // one recording per thread
+    plan->recording = true;
+    plan->lane = 0;
+    dpp_tls_plan = plan;
+    return DPP_OK;
+}
+
+extern "C" int dpp_plan_record_lane(dpp_plan* plan, int lane) {
+    if (!plan || dpp_tls_plan != plan || lane < 0 || lane > 1) return DPP_E_BADARG;
+    plan->lane = lane;
+    return DPP_OK;
+}
+
+extern "C" int dpp_plan_record_end(dpp_plan* plan) {
+    if (!plan || dpp_tls_plan != plan) return DPP_E_BADARG;
+    dpp_tls_plan = nullptr;
+    plan->recording = false;
+    plan->lane = 0;
+    return DPP_OK;
+}
+
+static int plan_marker(dpp_plan* plan, int kind) {
+    if (!plan || dpp_tls_plan != plan) return DPP_E_BADARG;
+    dpp_plan_node n;
+    n.kind = kind;
+    const int lane = plan->lane;
+    plan->lane = 0;
+    dpp_plan_append(plan, std::move(n));
+    plan->lane = lane;
+    (kind == 2 ? plan->forks : plan->joins)++;
+    return DPP_OK;
+}
+
+extern "C" int dpp_plan_fork(dpp_plan* plan) { return plan_marker(plan, 2); }
+extern "C" int dpp_plan_join(dpp_plan* plan) { return plan_marker(plan, 3); }
+
+extern "C" int dpp_plan_count(const dpp_plan* plan, int* launches, int* forks, int* joins) {
+    if (!plan) return DPP_E_BADARG;
+    if (launches) *launches = plan->launches;
+    if (forks) *forks = plan->forks;
+    if (joins) *joins = plan->joins;
+    return DPP_OK;
+}
+
+// Eager issue.  A fork is (record event on main, side waits for it), a join the mirror image; markers whose waiting lane has
+// nothing to wait for (no launch on the other lane since the previous marker of that kind) are skipped.
+extern "C" int dpp_plan_run(dpp_plan* plan, dpp_stream_t main_stream, dpp_stream_t side_stream) {
+    if (!plan || plan->recording) return DPP_E_BADARG;
+    hipStream_t ms = static_cast<hipStream_t>(main_stream);
+    hipStream_t ss = static_cast<hipStream_t>(side_stream);
+    const bool two = side_stream != nullptr && ss != ms;
+    if (two && plan->events.size() < (size_t)(plan->forks + plan->joins)) {
+        while (plan->events.size() < (size_t)(plan->forks + plan->joins)) {
+            hipEvent_t e;
+            hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (err != hipSuccess) return (int)err;
+            plan->events.push_back(e);
+        }
+    }
+    size_t ev = 0;
+    bool main_dirty = true, side_dirty = false;     // work issued on the lane since the other lane last synchronised with it
+    for (dpp_plan_node& n : plan->nodes) {
+        if (n.kind == 2 || n.kind == 3) {
+            if (!two) continue;
+            hipEvent_t e = plan->events[ev++];
+            const bool fork = n.kind == 2;
+            if (fork ? !main_dirty : !side_dirty) continue;
+            hipError_t err = hipEventRecord(e, fork ? ms : ss);
+            if (err == hipSuccess) err = hipStreamWaitEvent(fork ? ss : ms, e, 0);
+            if (err != hipSuccess) return (int)err;
+            (fork ? main_dirty : side_dirty) = false;
+            continue;
+        }
+        hipStream_t s = (two && n.lane == 1) ? ss : ms;
+        hipError_t err = n.kind == 0 ? n.issue(s) : hipMemsetAsync(n.ptr, 0, n.nbytes, s);
+        if (err != hipSuccess) return (int)err;
+        (n.lane == 1 && two ? side_dirty : main_dirty) = true;
+    }
+    return DPP_OK;
+}
+
+// Explicit graph: node i depends on the previous node of its lane, a side node additionally on the main node that was last
+// when the most recent fork was recorded, a main node on the side node that was last at the most recent join.
+extern "C" int dpp_plan_graph_build(dpp_plan* plan, int two_lanes) {
+    if (!plan || plan->recording) return DPP_E_BADARG;
+    plan_drop_graph(plan);
+    hipError_t err = hipGraphCreate(&plan->graph, 0);
+    if (err != hipSuccess) return (int)err;
+    hipGraphNode_t last[2] = {nullptr, nullptr};
+    hipGraphNode_t fork_dep = nullptr, join_dep = nullptr;      // pending cross-lane edges
+    for (dpp_plan_node& n : plan->nodes) {
+        if (n.kind == 2) { if (two_lanes) fork_dep = last[0]; continue; }
+        if (n.kind == 3) { if (two_lanes) join_dep = last[1]; continue; }
+        const int lane = two_lanes ? n.lane : 0;
+        hipGraphNode_t deps[2];
+        size_t nd = 0;
+        if (last[lane]) deps[nd++] = last[lane];
+        if (lane == 1 && fork_dep) { if (fork_dep != last[1]) deps[nd++] = fork_dep; fork_dep = nullptr; }
+        if (lane == 0 && join_dep) { if (join_dep != last[0]) deps[nd++] = join_dep; join_dep = nullptr; }
+        hipGraphNode_t node = nullptr;
+        if (n.kind == 0) {
+            hipKernelNodeParams kp = {};
+            kp.func = const_cast<void*>(n.func);
+            kp.gridDim = n.grid;
+            kp.blockDim = n.block;
+            kp.sharedMemBytes = (unsigned)n.shmem;
+            kp.kernelParams = n.argptrs.data();
+            kp.extra = nullptr;
+            err = hipGraphAddKernelNode(&node, plan->graph, deps, nd, &kp);
+        } else {
+            hipMemsetParams mp = {};
+            mp.dst = n.ptr;
+            mp.value = 0;
+            mp.elementSize = 1;
+            mp.width = n.nbytes;
+            mp.height = 1;
+            mp.pitch = n.nbytes;
+            err = hipGraphAddMemsetNode(&node, plan->graph, deps, nd, &mp);
+        }
+        if (err != hipSuccess) { plan_drop_graph(plan); return (int)err; }
+        last[lane] = node;
+    }
+    err = hipGraphInstantiate(&plan->exec, plan->graph, nullptr, nullptr, 0);
+    if (err != hipSuccess) { plan_drop_graph(plan); return (int)err; }
+    return DPP_OK;
+}
+
+extern "C" int dpp_plan_graph_launch(dpp_plan* plan, dpp_stream_t stream) {
+    if (!plan || !plan->exec) return DPP_E_BADARG;
+    hipError_t err = hipGraphLaunch(plan->exec, static_cast<hipStream_t>(stream));
+    return err == hipSuccess ? DPP_OK : (int)err;
+}

@@ -282,9 +282,9 @@ extern "C" int dpp_stem_fwd(const float* X, int N, int H, int W, const float* Wk
     dim3 grid(tiles_x * tiles_y * N);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (Co <= 16)
-        hipLaunchKernelGGL((stem_fwd_kernel<1>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y, stats);
+        DPP_LAUNCH((stem_fwd_kernel<1>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y, stats);
     else
-        hipLaunchKernelGGL((stem_fwd_kernel<2>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y, stats);
+        DPP_LAUNCH((stem_fwd_kernel<2>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y, stats);
     return dpp_launch_status();
 }
 
@@ -299,7 +299,7 @@ extern "C" int dpp_stem_wgrad(const float* X, int N, int H, int W, const float* 
         return DPP_E_BADARG;
     int tiles_x = dpp_cdiv(W, TC), tiles_y = dpp_cdiv(H, TC);
     int total = tiles_x * tiles_y * N;
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(dpp_cdiv(total, tiles_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), X, N,
+    DPP_LAUNCH(stem_wgrad_kernel, dim3(dpp_cdiv(total, tiles_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), X, N,
                        H, W, dY, argmax, Co, partial, tiles_x, tiles_y, tiles_per_block, total);
     return dpp_launch_status();
 }

@@ -1140,12 +1140,23 @@ class CompiledNet(object):
         """forward + loss + backward (+ gradient all-reduce) + ADAM on x_in / y_in; no host<->device traffic, so the
         whole sequence can be captured into a hipGraph (runtime.capture) and replayed."""
         st = self.rt
+        if allreduce is None:
+            self.step_plan().run(st)
+            return
         self.fwd.run(st)
         self.lossplan.run(st)
         self.bwd.run(st)
-        if allreduce is not None:
-            allreduce(self.store.g)
+        allreduce(self.store.g)
         self.upd.run(st)
+
+    def step_plan(self, before=None):
+        """forward + loss + backward + update as ONE plan (one native call per step); `before`: a Plan issued ahead of the
+        forward pass inside the same call (the augmentation kernels)."""
+        key = id(before) if before is not None else 0
+        cache = self.__dict__.setdefault('_step_plans', {})
+        if key not in cache:
+            cache[key] = (before, Plan.concat('step', ([before] if before is not None else []) + [self.fwd, self.lossplan, self.bwd, self.upd]))
+        return cache[key][1]
 
     def train_step_device(self, lr, allreduce=None):
         self.set_lr(lr)

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'lib', 'libdpp_hip.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 c_float_p = C.c_void_p      # device pointers travel as integers
 stream_t = C.c_void_p
 
@@ -118,6 +118,17 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, stream_t]),
     'dpp_crop_com': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_crop_warp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, stream_t]),
+    'dpp_plan_create': (C.c_int, [C.POINTER(C.c_void_p)]),
+    'dpp_plan_destroy': (C.c_int, [C.c_void_p]),
+    'dpp_plan_record_begin': (C.c_int, [C.c_void_p]),
+    'dpp_plan_record_lane': (C.c_int, [C.c_void_p, C.c_int]),
+    'dpp_plan_record_end': (C.c_int, [C.c_void_p]),
+    'dpp_plan_fork': (C.c_int, [C.c_void_p]),
+    'dpp_plan_join': (C.c_int, [C.c_void_p]),
+    'dpp_plan_count': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'dpp_plan_run': (C.c_int, [C.c_void_p, stream_t, stream_t]),
+    'dpp_plan_graph_build': (C.c_int, [C.c_void_p, C.c_int]),
+    'dpp_plan_graph_launch': (C.c_int, [C.c_void_p, stream_t]),
 }
 
 

@@ -4,10 +4,11 @@ pointers resolved) and then replayed every step with `op(stream)`; a `Plan` is a
 Building is host logic only; nothing here computes on the CPU.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
-from .lib import Act, Epilogue, GemmDesc, RowMap, check
+from .lib import Act, DppError, Epilogue, GemmDesc, RowMap, check
 
 
 class Launch(object):
@@ -37,15 +38,86 @@ class Join(object):
     meta = None
 
 
+# How a Plan issues its launches when it runs on a runtime:
+#   native (default)  recorded once into a dpp_plan (include/dpp_hip.h) and re-issued from C++ on the two HIP streams;
+#   graph             the same recording replayed as an explicit hipGraph (lanes = parallel branches);
+#   graph1            one-lane hipGraph (everything chained in recorded order);
+#   python            every launch is a ctypes call from the interpreter (what round 1 measured: host-bound).
+LAUNCH_MODE = os.environ.get('DPP_LAUNCH_MODE', 'native')
+
+
+class NativePlan(object):
+    """A run of launches / fork / join markers recorded into a dpp_plan.  Recording calls every prepared op once with the
+    library in recording mode: the C side keeps the resolved kernel, grid and a private copy of the arguments."""
+
+    def __init__(self, rt, items, mode='native'):
+        self.rt, self.lib, self.items, self.mode = rt, rt.lib, items, mode       # items keep the device buffers alive
+        h = C.c_void_p()
+        check(self.lib.dpp_plan_create(C.byref(h)), 'dpp_plan_create')
+        self.handle = h
+        lib = self.lib
+        check(lib.dpp_plan_record_begin(h), 'dpp_plan_record_begin')
+        try:
+            lane = 0
+            for op, side in items:
+                if isinstance(op, Fork):
+                    check(lib.dpp_plan_fork(h), 'dpp_plan_fork')
+                elif isinstance(op, Join):
+                    check(lib.dpp_plan_join(h), 'dpp_plan_join')
+                else:
+                    if int(bool(side)) != lane:
+                        lane = int(bool(side))
+                        check(lib.dpp_plan_record_lane(h, lane), 'dpp_plan_record_lane')
+                    op(None)
+        finally:
+            check(lib.dpp_plan_record_end(h), 'dpp_plan_record_end')
+        n = C.c_int()
+        check(lib.dpp_plan_count(h, C.byref(n), None, None), 'dpp_plan_count')
+        want = sum(1 for op, _ in items if isinstance(op, Launch))
+        if n.value != want:
+            raise DppError("plan recording captured %d launches, expected %d" % (n.value, want))
+        self.graph_ready = False
+
+    def run(self, rt):
+        two = getattr(rt, 'has_side_stream', False)
+        if self.mode in ('graph', 'graph1') and not getattr(rt, 'is_emulator', False):
+            if not self.graph_ready:
+                check(self.lib.dpp_plan_graph_build(self.handle, 1 if (self.mode == 'graph' and two) else 0), 'dpp_plan_graph_build')
+                self.graph_ready = True
+            check(self.lib.dpp_plan_graph_launch(self.handle, rt.stream), 'dpp_plan_graph_launch')
+            return
+        st = self.lib.dpp_plan_run(self.handle, rt.stream, rt.side_stream if two else None)
+        if st != 0:
+            check(st, 'dpp_plan_run')
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.dpp_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:          # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
 class Plan(object):
     """An ordered list of launches.  Every launch belongs to the main stream or (side=True) to an auxiliary stream that
-    the runtime provides; Fork / Join markers order the two (event wait), which is also what a hipGraph capture records
-    as parallel branches."""
+    the runtime provides; Fork / Join markers order the two (event wait).  Run on a runtime, consecutive launches are
+    compiled into NativePlans (one C call each); steps that are not kernel launches (collectives) stay Python calls
+    between them."""
 
     def __init__(self, name=''):
         self.name = name
         self.ops = []          # (op, side)
         self.uses_side = False
+        self._compiled = None
+
+    @staticmethod
+    def concat(name, plans):
+        out = Plan(name)
+        for p in plans:
+            out.ops.extend(p.ops)
+            out.uses_side = out.uses_side or p.uses_side
+        return out
 
     def add(self, op, side=False):
         if op is not None:
@@ -65,9 +137,34 @@ class Plan(object):
     def steps(self):
         return [o for (o, _) in self.ops if not isinstance(o, (Fork, Join))]
 
+    def _compile(self, rt):
+        key = (id(rt), len(self.ops), LAUNCH_MODE)
+        if self._compiled is not None and self._compiled[0] == key:
+            return self._compiled[1]
+        segs, cur = [], []
+        for op, side in self.ops:
+            if isinstance(op, (Launch, Fork, Join)):
+                cur.append((op, side))
+            else:
+                if cur:
+                    segs.append(NativePlan(rt, cur, LAUNCH_MODE))
+                    cur = []
+                segs.append(op)
+        if cur:
+            segs.append(NativePlan(rt, cur, LAUNCH_MODE))
+        self._compiled = (key, segs)
+        return segs
+
     def run(self, rt_or_stream):
         """rt_or_stream: a runtime (multi-stream aware) or a raw stream handle (single stream, side ops inline)."""
         rt = rt_or_stream if hasattr(rt_or_stream, 'stream') else None
+        if rt is not None and LAUNCH_MODE != 'python':
+            for seg in self._compile(rt):
+                if isinstance(seg, NativePlan):
+                    seg.run(rt)
+                else:
+                    seg(rt.stream)
+            return
         if rt is None or not self.uses_side or not getattr(rt, 'has_side_stream', False):
             st = rt.stream if rt is not None else rt_or_stream
             for op, _ in self.ops:

@@ -34,7 +34,7 @@ typedef void* dpp_stream_t; /* a hipStream_t */
 #define DPP_E_BADARG 10001
 #define DPP_E_UNSUPPORTED 10002
 
-#define DPP_ABI_VERSION 4
+#define DPP_ABI_VERSION 5
 int dpp_abi_version(void);
 
 /* Pixel row map: row m of a compact (N,Ho,Wo) map -> row of a (N,Hi,Wi) map sampled with stride s.
@@ -271,6 +271,33 @@ int dpp_crop_warp(const float* frames, const void* records, int B, int H, int W,
 /* docom = True (handdetector.py:413-427): the centre of mass (calculateCoM, :91-108) of the crop window described by
  * `records`, in image coordinates -> com_out [B][3]; re-run dpp_crop_prepare with it, then dpp_crop_warp. */
 int dpp_crop_com(const float* frames, const void* records, int B, int H, int W, float* com_out, dpp_stream_t stream);
+
+/* ---- launch plans: a whole train / inference step as ONE call --------------------------------------------------------
+ * The reference runs `train_model(index, lr)` as one compiled device function (theano.function,
+ * /root/reference/src/trainer/poseregnettrainer.py:146-170, called at /root/reference/src/trainer/nettrainer.py:840).
+ * A plan is the equivalent here: the ordered kernel launches of a step, recorded once and re-issued from C++ without any
+ * host-language work per launch.  While a plan is recording on the calling thread (dpp_plan_record_begin ..
+ * dpp_plan_record_end) every dpp_* launch call of that thread appends its fully resolved launch (kernel, grid, arguments)
+ * to the plan instead of launching, its `stream` argument being ignored.  A plan has two lanes: lane 0 (main) and lane 1 (side,
+ * the parameter-gradient branch).  dpp_plan_fork makes the side lane wait for everything recorded so far on the main lane,
+ * dpp_plan_join makes the main lane wait for everything recorded so far on the side lane.
+ *   dpp_plan_run          issues the launches on two HIP streams (events for fork / join); side == NULL or == main: one stream
+ *   dpp_plan_graph_build  builds an explicit hipGraph (hipGraphAddKernelNode + dependency edges: lanes stay parallel
+ *                         branches); two_lanes == 0 chains everything in recorded order
+ *   dpp_plan_graph_launch replays it on `stream`
+ * Device pointers recorded in a plan must stay valid for its lifetime (the caller owns them, as everywhere in this ABI). */
+typedef struct dpp_plan dpp_plan;
+int dpp_plan_create(dpp_plan** out);
+int dpp_plan_destroy(dpp_plan* plan);
+int dpp_plan_record_begin(dpp_plan* plan);
+int dpp_plan_record_lane(dpp_plan* plan, int lane);
+int dpp_plan_record_end(dpp_plan* plan);
+int dpp_plan_fork(dpp_plan* plan);
+int dpp_plan_join(dpp_plan* plan);
+int dpp_plan_count(const dpp_plan* plan, int* launches, int* forks, int* joins);
+int dpp_plan_run(dpp_plan* plan, dpp_stream_t main_stream, dpp_stream_t side_stream);
+int dpp_plan_graph_build(dpp_plan* plan, int two_lanes);
+int dpp_plan_graph_launch(dpp_plan* plan, dpp_stream_t stream);
 
 #ifdef __cplusplus
 }

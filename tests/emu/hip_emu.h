@@ -180,6 +180,26 @@ inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem
 }
 }  // namespace emu
 
+// events / graphs: the emulator executes every launch synchronously, so events are no-ops; there is no graph executor
+typedef void* hipEvent_t;
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+typedef void* hipGraphNode_t;
+enum { hipEventDisableTiming = 2, hipErrorNotSupported = 801 };
+struct hipKernelNodeParams { void* func; dim3 gridDim, blockDim; unsigned sharedMemBytes; void** kernelParams; void** extra; };
+struct hipMemsetParams { void* dst; unsigned value, elementSize; size_t width, height, pitch; };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipGraphCreate(hipGraph_t*, unsigned) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+static inline hipError_t hipGraphAddKernelNode(hipGraphNode_t*, hipGraph_t, const hipGraphNode_t*, size_t, const hipKernelNodeParams*) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphAddMemsetNode(hipGraphNode_t*, hipGraph_t, const hipGraphNode_t*, size_t, const hipMemsetParams*) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, char*, size_t) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+
 #define threadIdx (emu::g_cur->tid)
 #define blockIdx (emu::g_bid)
 #define blockDim (emu::g_bdim)
