@@ -7,8 +7,12 @@ the mains' aug_modes) of 128 device-resident synthetic depth crops + PCA-prior l
 = forward + sum-squared-error loss + backward + the reference's ADAM of the ResNet pose regressor
 (`ResNet(type=0, numJoints=1, nDims=30)`, 18.7 M parameters, fp32), i.e. BASELINE.json configs[1]
 "NYU posereg_embedding ResNet-50, 30-dim PCA prior, bs128 fp32, 1xMI355X".  Inputs are resident in HBM before the
-timed region.  With --gpus N the driver launches one rank per GPU (torch.distributed, RCCL): every rank processes its
-own 128-crop shard (weak scaling) and the flat fp32 gradient buffer is all-reduced (mean) between backward and ADAM.
+timed region.  The whole step is ONE call into libdpp_hip.so (a recorded launch plan, include/dpp_hip.h dpp_plan_*).
+
+`--gpus N` (N > 1): one rank per GPU over RCCL.  Started by the driver under torch.distributed.run the script finds
+RANK / WORLD_SIZE in the environment; started plainly (`python bench.py --gpus 4`) it launches the N ranks itself.  Every
+rank processes its own 128-crop shard of the global minibatch (weak scaling), the flat fp32 gradient buffer is all-reduced
+(sum of per-shard partial gradients of the global-batch cost) between backward and the replicated ADAM.
 
 Prints ONE JSON line (rank 0).  `roofline` describes the kernel family with the largest share of the step time,
 timed live with HIP events on the launch stream; `cpu_baseline` times the oracle's PyTorch-CPU restatement of the same
@@ -17,6 +21,8 @@ train step on the host cores (reported only).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,31 +33,32 @@ for p in (ROOT, os.path.join(ROOT, 'deep-prior-pp_amd')):
 
 import numpy as np  # noqa: E402
 
-FLOP_PER_CROP = 722.6e6        # fwd + dgrad + wgrad, SURVEY.md section 8(d)
+FLOP_PER_CROP = {128: 722.6e6, 256: 2.9e9}     # fwd + dgrad + wgrad, SURVEY.md section 8(d)
 PEAK_MFMA_F32 = 157.3e12       # MI355X_MICROARCH.md: f32-in MFMA = f32 vector peak
+PEAK_MFMA_BF16 = 2.5e15        # dense
 PEAK_HBM = 8.0e12
 
 
-def synthetic_db(n, J=14, seed=23455):
+def synthetic_db(n, size, J=14, seed=23455):
     """Device-resident training set: normalised crops + the per-sample geometry augmentCrop needs (NYU camera)."""
     from oracle import augment as A
     rng = np.random.RandomState(seed)
     cam = A.Camera.nyu()
-    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, n, cam, cube=(300., 300., 300.), joints=J)
+    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, n, cam, cube=(300., 300., 300.), joints=J, dsize=size)
     pca_mean = rng.normal(0, 0.05, J * 3).astype(np.float32)
     q, _ = np.linalg.qr(rng.normal(size=(J * 3, 30)))
     return cam, imgs, coms, cubes, Ms, gts, pca_mean, q.T.astype(np.float32)
 
 
-def cpu_baseline(batch, budget_s=12.0):
+def cpu_baseline(batch, size, budget_s=12.0):
     """The oracle's PyTorch-CPU restatement of the identical fp32 train step, bounded sample."""
     import torch
     from oracle import nets, torch_ref
-    onet = nets.build_resnet(type=0, batchSize=batch, numJoints=1, nDims=30)
+    onet = nets.build_resnet(type=0, wIn=size, hIn=size, batchSize=batch, numJoints=1, nDims=30)
     P = nets.init_params(onet, np.random.RandomState(23455), np.float32)
     tr = torch_ref.TorchTrainer(onet, P)
     rng = np.random.RandomState(3)
-    x = torch.tensor(nets.synthetic_crops(rng, batch, 128, 128, np.float32))
+    x = torch.tensor(nets.synthetic_crops(rng, batch, size, size, np.float32))
     y = torch.tensor(rng.normal(0, 0.3, (batch, 30)).astype(np.float32))
     tr.step(x, y, 1e-3)                      # warm-up (thread pools, allocator)
     t0, n = time.time(), 0
@@ -63,158 +70,145 @@ def cpu_baseline(batch, budget_s=12.0):
                 sample='%d train steps of batch %d (PyTorch-CPU fp32 restatement, not Theano), %.2f s/step' % (n, batch, dt))
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks with torch.distributed.run (one per GPU, RCCL)."""
+    import torch
+    emu = os.environ.get('DPP_BENCH_EMU') == '1'
+    shared = os.environ.get('DPP_DIST_BACKEND') == 'gloo'          # control-flow runs: several ranks may share one GPU
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not emu and have < (1 if shared else n):
+        sys.stderr.write('bench.py: --gpus %d needs %d visible MI355X GPUs, PyTorch-ROCm sees %d\n' % (n, n, have))
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=128, help='crops per GPU')
+    ap.add_argument('--size', type=int, default=128, help='crop side: 128 (configs 2-4) or 256 (config 5 stress)')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help='bf16: bf16 MFMA operands / fp32 accumulation in FC1 and the 3x3 convolutions (config 5)')
     ap.add_argument('--no-augment', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sync-bn', action='store_true', help='all-gather BatchNorm partial statistics across ranks (parity mode)')
-    ap.add_argument('--launch', choices=['auto', 'eager', 'graph'], default='eager',
-                    help='eager = every kernel launched from Python (two concurrent HIP streams); graph = replay captured hipGraphs; auto = probe both')
-    ap.add_argument('--eager', action='store_true', help='same as --launch eager')
+    ap.add_argument('--launch', choices=['native', 'python', 'graph', 'graph1'], default=None,
+                    help='native = the step is one C call that issues every launch on two HIP streams (default); python = one '
+                         'ctypes call per launch; graph / graph1 = explicit hipGraph with two lanes / one chain')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-kernel-family time table to stderr')
     args = ap.parse_args()
-    if args.eager:
-        args.launch = 'eager'
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(args.gpus)
+    if args.launch is not None:
+        os.environ['DPP_LAUNCH_MODE'] = args.launch
+    if args.dtype == 'bf16':
+        os.environ['DPP_BF16'] = '1'
 
     import torch
     from hipdp import engine, ops, parallel
-    from hipdp.runtime import TorchHipRuntime
     from net.resnet import ResNet, ResNetParams
 
-    rank, world = parallel.init_from_env('nccl')          # "nccl" is RCCL on ROCm; one rank per GPU
+    emu = os.environ.get('DPP_BENCH_EMU') == '1'      # CPU-tier control-flow test of the multi-rank path (tests/test_bench_cli.py)
+    rank, world = parallel.init_from_env('gloo' if emu else 'nccl')          # "nccl" is RCCL on ROCm; one rank per GPU
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world))
+    dist = None
     if world > 1:
         import torch.distributed as dist
-    else:
-        dist = None
+        backend = dist.get_backend()
+        if backend != 'nccl' and os.environ.get('DPP_DIST_BACKEND') != backend and not emu:
+            raise SystemExit('bench.py: multi-GPU runs use RCCL (backend nccl), got %s' % backend)
+    elif not emu:
         torch.cuda.set_device(0)
 
-    rt = TorchHipRuntime()
-    B = args.batch
-    net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, nChan=1, wIn=128, hIn=128, batchSize=B,
+    if emu:
+        from tests.emu.emu_runtime import EmuRuntime
+        rt = EmuRuntime()
+        sync_dev = lambda: None          # noqa: E731
+    else:
+        from hipdp.runtime import TorchHipRuntime
+        rt = TorchHipRuntime()
+        sync_dev = torch.cuda.synchronize
+    B, S = args.batch, args.size
+    net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, nChan=1, wIn=S, hIn=S, batchSize=B,
                                                                       numJoints=1, nDims=30))
     dp = parallel.DataParallel(rt, sync_bn=args.sync_bn) if world > 1 else None
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), dp=dp)
 
-    # ---- device-resident data (different per rank: each rank owns its shard of the global minibatch) ----
-    NDB, J = 8 * B, 14
-    cam, imgs, coms, cubes, Ms, gts, pca_mean, pca_comp = synthetic_db(NDB, J, seed=23455 + rank)
+    # ---- device-resident data: rank r owns samples [r*NDB, (r+1)*NDB) of the global set ----
+    NDB, J = (8 if not emu else 2) * B, 14
+    cam, imgs, coms, cubes, Ms, gts, pca_mean, pca_comp = synthetic_db(NDB, S, J, seed=23455 + rank)
     f32 = lambda a: rt.upload(np.ascontiguousarray(a, np.float32))       # noqa: E731
     db = dict(img=f32(imgs), com=f32(coms), cube=f32(cubes), M=f32(Ms.reshape(NDB, 9)), gt=f32(gts))
     pm, pc = f32(pca_mean), f32(pca_comp)
-    rec = rt.alloc(B * rt.lib.dpp_augment_record_bytes(), np.uint8)
     table = rt.upload(np.array([1, 2, 0], np.int32))                     # aug_modes = ['com', 'rot', 'none']
     camt = (cam.fx, cam.fy, cam.ux, cam.uy, cam.flip_y)
-    x_out = eng.x_in.buf.reshape(B, 128, 128)
+    x_out = eng.x_in.buf.reshape(B, S, S)
+    nsl = NDB // B
 
-    def slice_views(i):
-        o = (i % (NDB // B)) * B
-        return (db['img'].view(o * 128 * 128, (B, 128, 128)), db['com'].view(o * 3, (B, 3)), db['cube'].view(o * 3, (B, 3)),
+    def slice_views(sl):
+        o = sl * B
+        return (db['img'].view(o * S * S, (B, S, S)), db['com'].view(o * 3, (B, 3)), db['cube'].view(o * 3, (B, 3)),
                 db['M'].view(o * 9, (B, 9)), db['gt'].view(o * J * 3, (B, J, 3)))
 
-    step_no = [0]
-    ctr_dev = rt.alloc(1, np.int64)              # device-resident draw counter of the augmentation RNG
-    aug_cache = {}
-
-    def augment_ops(i):
-        sl = i % (NDB // B)
-        if sl not in aug_cache:
-            im, co, cu, mm, gt = slice_views(sl)
-            if args.no_augment:
-                aug_cache[sl] = None
-            else:
-                aug_cache[sl] = [ops.augment_prepare(rt, im, co, cu, mm, gt, B, J, 128, camt, rec, eng.y_in, mode_table=table, n_modes=3,
-                                                     seed=1234 + rank, counter=0, pca_mean=pm, pca_comp=pc, E=30, counter_dev=ctr_dev),
-                                 ops.augment_warp(rt, im, rec, B, 128, x_out), ops.counter_add(rt, ctr_dev, 1)]
-        return aug_cache[sl]
-
-    def augment(i):
-        lst = augment_ops(i)
-        if lst is None:
-            rt.copy(x_out, slice_views(i % (NDB // B))[0])
-            return []
-        for o in lst:
-            o(rt.stream)
-        return lst
-
+    # device-resident draw counter of the augmentation RNG: draws are keyed by (seed, step, GLOBAL sample index), so what a
+    # sample gets does not depend on how many GPUs the global minibatch is spread over (SURVEY.md section 8(e))
+    aug = ops.AugmentState(rt, B, seed=1234, sample0=rank * B, global_batch=world * B)
+    step_plans = {}
+    for sl in range(nsl):
+        im, co, cu, mm, gt = slice_views(sl)
+        before = ops.Plan('augment')
+        if args.no_augment:
+            before.add(ops.copy2d(rt, im.reshape(B * S * S), S * S, x_out.reshape(B * S * S), S * S, B, S * S, name='load_crops'))
+        else:
+            for o in aug.ops(im, co, cu, mm, gt, J, S, camt, x_out, eng.y_in, mode_table=table, n_modes=3, pca_mean=pm, pca_comp=pc, E=30):
+                before.add(o)
+        step_plans[sl] = (before, eng.step_plan(before=before))
     if args.no_augment:
         eng.y_in.set(np.random.RandomState(5).normal(0, 0.3, (B, 30)).astype(np.float32))
-
     eng.set_lr(1e-3)
 
-    def step_body(i):
-        augment(i)
-        eng.run_step_plans()          # with --gpus N the flat-gradient all-reduce (RCCL) is a step of the update plan
-
-    # One hipGraph per resident data slice (pointers are baked into a graph; draw counter and ADAM step count live on the
-    # device, so every replay sees fresh augmentation draws and the right bias correction).  Multi-GPU runs stay eager:
-    # the RCCL all-reduce sits between backward and ADAM.
-    graphs = {}
-    mode = 'eager'
-    if world == 1 and args.launch != 'eager':
-        try:
-            for sl in range(NDB // B):
-                graphs[sl] = rt.capture(lambda sl=sl: step_body(sl))
-            mode = 'hipgraph'
-        except Exception as e:          # noqa: BLE001
-            print('graph capture failed, running eager: %r' % (e,), file=sys.stderr)
-            graphs = {}
-    if graphs and args.launch == 'auto':
-        # eager launches keep the two HIP streams genuinely concurrent; a replayed graph removes the host cost per launch.
-        # Which wins depends on the driver: time a few untimed steps of each and keep the faster mode.
-        def _probe(use_graph, n=6):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for k in range(n):
-                if use_graph:
-                    graphs[k % (NDB // B)].replay()
-                else:
-                    step_body(k)
-            torch.cuda.synchronize()
-            return time.perf_counter() - t
-        _probe(True, 2), _probe(False, 2)
-        if _probe(False) < _probe(True):
-            graphs, mode = {}, 'eager'
+    step_no = [0]
 
     def step():
-        i = step_no[0]
+        step_plans[step_no[0] % nsl][1].run(rt)
         step_no[0] += 1
-        if graphs:
-            graphs[i % (NDB // B)].replay()
-        else:
-            step_body(i)
 
     for _ in range(args.warmup):
         step()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync_dev()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync_dev()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        te = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        te = torch.tensor([elapsed], device='cpu' if emu or dist.get_backend() == 'gloo' else 'cuda', dtype=torch.float64)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     cost = float(eng.cost.get()[0])
     ms = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
-    # ---- per-kernel-family timing with HIP events on the launch stream (after the timed region) ----
+    # ---- per-kernel-family timing with HIP events on the launch stream (after the timed region, rank 0) ----
     fam = {}
-    if rank == 0:
+    if rank == 0 and not emu:
         stream = torch.cuda.current_stream()
-        allops = eng.all_launches()
-        aug_ops = augment(step_no[0])
-        allops = [('aug', o) for o in aug_ops] + allops
-        eng.set_lr(1e-3)
+        allops = [('aug', o) for o in step_plans[0][0].launches()] + eng.all_launches()
         reps = 3
         for r in range(reps):
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(allops) + 1)]
@@ -233,8 +227,7 @@ def main():
                     f['bytes'] += m['bytes']
         tot = sum(f['ms'] for f in fam.values())
         if args.profile_ops:
-            # per-launch detail of the last repetition
-            for k, (ph, o) in enumerate(allops):
+            for k, (ph, o) in enumerate(allops):          # per-launch detail of the last repetition
                 m = o.meta or dict(kernel=o.name, flops=0.0, bytes=0.0)
                 t = evs[k].elapsed_time(evs[k + 1])
                 print('OP %-4s %-22s %-22s %8.2f us %8.2f TF/s %8.1f GB/s' % (ph, o.name, m['kernel'], t * 1e3,
@@ -246,47 +239,57 @@ def main():
             print('sum of per-launch event intervals: %.3f ms (step %.3f ms)' % (tot, ms), file=sys.stderr)
 
     if rank == 0:
-        dom_name, dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
-        mfma = 'mfma' in dom_name
-        per_launch_t = dom['ms'] * 1e-3 / dom['n']
-        if mfma:
-            ach = dom['flops'] / dom['n'] / per_launch_t / 1e12
-            roof = dict(bound='mfma', kernel=dom_name, achieved=round(ach, 3), peak=PEAK_MFMA_F32 / 1e12, unit='TFLOP/s',
-                        frac=round(ach * 1e12 / PEAK_MFMA_F32, 4), traffic=None)
-        else:
-            ach = dom['bytes'] / dom['n'] / per_launch_t / 1e9
-            roof = dict(bound='hbm', kernel=dom_name, achieved=round(ach, 1), peak=PEAK_HBM / 1e9, unit='GB/s',
-                        frac=round(ach * 1e9 / PEAK_HBM, 4), traffic=None)
-        # HBM bytes per launch of that kernel family from the PMC counters: they cannot be read inside this process, so the
-        # number is the one measured with rocprofv3 --pmc on this same build and workload (separate FETCH_SIZE / WRITE_SIZE
-        # passes, calibrated on adam_kernel; tools/pmc_summary.py -> profiles/r01_hbm_traffic.json)
-        pmc_family = {'gemm_mfma_f32': 'gemm_kernel', 'conv3x3_mfma_f32': 'conv3x3_kernel', 'bn_bwd_apply': 'bn_bwd_apply_kernel',
-                      'adam': 'adam_kernel'}.get(dom_name)
-        try:
-            with open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')) as fh:
-                pj = json.load(fh)
-            if B == 128 and pmc_family in pj:
-                roof['traffic'] = round(pj[pmc_family]['bytes_per_launch'])
-                roof['traffic_source'] = 'profiles/r01_hbm_traffic.txt'
-        except (OSError, ValueError):
-            pass
-        roof['algorithmic_bytes'] = round(dom['bytes'] / dom['n'])
-        roof['hbm_frac'] = round(dom['bytes'] / dom['n'] / per_launch_t / PEAK_HBM, 4)
-        roof['launches_per_step'] = dom['n']
-        roof['avg_launch_us'] = round(per_launch_t * 1e6, 2)
-        roof['share_of_step'] = round(dom['ms'] / sum(f['ms'] for f in fam.values()), 3)
+        roof = None
+        if fam:
+            dom_name, dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
+            mfma = 'mfma' in dom_name
+            peak_mfma = PEAK_MFMA_BF16 if 'bf16' in dom_name else PEAK_MFMA_F32
+            per_launch_t = dom['ms'] * 1e-3 / dom['n']
+            if mfma:
+                ach = dom['flops'] / dom['n'] / per_launch_t / 1e12
+                roof = dict(bound='mfma', kernel=dom_name, achieved=round(ach, 3), peak=peak_mfma / 1e12, unit='TFLOP/s',
+                            frac=round(ach * 1e12 / peak_mfma, 4), traffic=None)
+            else:
+                ach = dom['bytes'] / dom['n'] / per_launch_t / 1e9
+                roof = dict(bound='hbm', kernel=dom_name, achieved=round(ach, 1), peak=PEAK_HBM / 1e9, unit='GB/s',
+                            frac=round(ach * 1e9 / PEAK_HBM, 4), traffic=None)
+            # HBM bytes per launch of that kernel family from the PMC counters: they cannot be read inside this process, so
+            # the number is the one measured with rocprofv3 --pmc on this workload (separate FETCH_SIZE / WRITE_SIZE passes,
+            # tools/pmc_summary.py); the file records the commit it was measured at
+            pmc_family = {'gemm_mfma_f32': 'gemm_kernel', 'conv3x3_mfma_f32': 'conv3x3_kernel', 'bn_bwd_apply': 'bn_bwd_apply_kernel',
+                          'adam': 'adam_kernel'}.get(dom_name)
+            for fn in ('r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+                try:
+                    with open(os.path.join(ROOT, 'profiles', fn)) as fh:
+                        pj = json.load(fh)
+                    if B == 128 and S == 128 and args.dtype == 'f32' and pmc_family in pj:
+                        roof['traffic'] = round(pj[pmc_family]['bytes_per_launch'])
+                        roof['traffic_source'] = 'profiles/' + fn.replace('.json', '.txt')
+                        break
+                except (OSError, ValueError):
+                    pass
+            roof['algorithmic_bytes'] = round(dom['bytes'] / dom['n'])
+            roof['hbm_frac'] = round(dom['bytes'] / dom['n'] / per_launch_t / PEAK_HBM, 4)
+            roof['launches_per_step'] = dom['n']
+            roof['avg_launch_us'] = round(per_launch_t * 1e6, 2)
+            roof['share_of_step'] = round(dom['ms'] / sum(f['ms'] for f in fam.values()), 3)
+        flop = FLOP_PER_CROP.get(S, FLOP_PER_CROP[128] * (S / 128.0) ** 2)
         res = dict(metric='depth-crops/sec (NYU ResNet50 bs128) 1/2/4/8 GPU; mean 3D joint err (mm)', value=round(value, 1),
                    unit='depth-crops/sec', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3),
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
                    config=dict(workload='NYU posereg_embedding ResNet (type 0, 30-D PCA prior) train step: fused augment + fwd + bwd + ADAM, '
-                                        'bs%d/GPU fp32, 128x128x1 crops' % B,
+                                        'bs%d/GPU %s, %dx%dx1 crops' % (B, 'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands (FC1, 3x3) / fp32 accumulate', S, S),
                                global_batch=world * B, parallelism='dp%d' % world, augment=not args.no_augment,
-                               bn='sync (global batch statistics)' if (world > 1 and args.sync_bn) else 'local per-GPU batch statistics', launches=eng.num_launches(), launch_mode=mode,
-                               step_mfma_frac=round(value / world * FLOP_PER_CROP / PEAK_MFMA_F32, 4), final_cost=round(cost, 5)),
+                               bn='sync (global batch statistics)' if (world > 1 and args.sync_bn) else 'local per-GPU batch statistics',
+                               launches=eng.num_launches(), launch_mode=ops.LAUNCH_MODE,
+                               step_mfma_frac=round(value / world * flop / PEAK_MFMA_F32, 4), final_cost=round(cost, 5)),
                    roofline=roof)
-        if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(B)
+        if args.dtype == 'bf16' and hasattr(eng, 'bf16_forward_error_mm'):
+            res['config']['bf16_forward_error_mm_vs_fp32'] = eng.bf16_forward_error_mm()
+        if world == 1 and not args.no_cpu_baseline and not emu:
+            res['cpu_baseline'] = cpu_baseline(B, S)
         print(json.dumps(res))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -11,7 +11,8 @@
 // imgwarp.cpp exactly as oracle/augment.py documents (10-bit fixed point for the affine warp, cvRound of the
 // double coordinate on 64-wide blocks for the perspective warp).
 //
-// Two launches per batch:
+// One launch per batch (augment_fused_kernel, dpp_augment); the two stages also exist as separate launches
+// (dpp_augment_prepare + dpp_augment_warp, used by the parity tests to look at the per-sample records):
 //   augment_prepare_kernel  one workgroup per crop: wave-shuffle max of the crop (the reference's `premax`),
 //                           then lane 0 does the per-sample geometry in f64 (new CoM, crop transform, inverse
 //                           warp matrix, z-thresholds, joint labels) and the workgroup projects the label onto
@@ -152,6 +153,7 @@ struct PrepArgs {
     int n_modes;
     unsigned long long seed, counter;
     const unsigned long long* counter_dev;
+    unsigned long long sample0, gbatch;   // draws are keyed by (seed, step, sample0 + b) with step * gbatch + ... as the counter
     double sigma_com, sigma_sc, rot_range;
     AugCam cam;
     int B, J, dsz;
@@ -164,20 +166,10 @@ struct PrepArgs {
     int* out_mode;           // [B] (optional: the mode actually used)
 };
 
-__global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a) {
-    __shared__ float s_red[DPP_THREADS / DPP_WAVE];
-    __shared__ float s_label[MAXJ3];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int npix = a.dsz * a.dsz;
-    // premax: max of the crop (monotone under the f32 de-normalisation, so max first, de-normalise after)
-    float mx = -3.4e38f;
-    const float* im = a.img + (size_t)b * npix;
-    for (int i = tid; i < npix; i += DPP_THREADS) mx = fmaxf(mx, im[i]);
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((tid & 63) == 0) s_red[tid >> 6] = mx;
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < DPP_THREADS / DPP_WAVE; ++w) mx = fmaxf(mx, s_red[w]);
+// The per-sample geometry of augmentCrop, run by ONE thread: the four draws, the new CoM / cube, the inverse warp matrix and
+// z-thresholds (-> r) and the augmented, normalised joint labels (-> s_label).  `mx` is the maximum of the stored crop.
+__device__ void aug_prepare_sample(const PrepArgs& a, int b, float mx, AugRec& r, float* s_label) {
+    {
         const AugCam cam = a.cam;
         const double fx = fabs(cam.fx), fy = fabs(cam.fy);      // HandDetector(..., abs(di.fx), abs(di.fy))
         // ---- the four draws of augmentCrop (nettrainer.py:954-957) ----
@@ -186,7 +178,7 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a
             mode = a.mode[b]; off[0] = a.off[b * 3]; off[1] = a.off[b * 3 + 1]; off[2] = a.off[b * 3 + 2]; rot = a.rot[b]; sc = a.sc[b];
         } else {
             unsigned r0[4], r1[4], r2[4];
-            unsigned long long ctr = (a.counter + (a.counter_dev ? *a.counter_dev : 0ull)) * (unsigned long long)a.B + b;
+            unsigned long long ctr = (a.counter + (a.counter_dev ? *a.counter_dev : 0ull)) * a.gbatch + a.sample0 + b;
             philox4(a.seed, ctr, 0, r0); philox4(a.seed, ctr, 1, r1); philox4(a.seed, ctr, 2, r2);
             mode = a.mode_table[r0[0] % (unsigned)a.n_modes];
             double u1 = u01(r0[1], r0[2]), u2 = u01(r0[3], r1[0]), u3 = u01(r1[1], r1[2]), u4 = u01(r1[3], r2[0]);
@@ -206,7 +198,6 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a
         double Mold[9];
         for (int i = 0; i < 9; ++i) Mold[i] = (double)a.Mcrop[b * 9 + i];
 
-        AugRec r;
         r.warp = WARP_NONE; r.thresh = 0; r.zlo = 0.f; r.zhi = 0.f;
         for (int i = 0; i < 9; ++i) r.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
         // de-normalisation of the stored crop (nettrainer.py:948-951): [-1, 1] about the CoM, or [0, 1] from the cube's front face
@@ -301,10 +292,12 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a
         r.far_v = (float)far_d; r.near_v = (float)near_d;
         r.norm_off = a.norm01 ? r.near_v : ncom[2];              // nettrainer.py:982-995
         r.norm_div = a.norm01 ? (float)ncube[2] : (float)(ncube[2] / 2.);
-        a.rec[b] = r;
     }
-    __syncthreads();
-    // label -> PCA prior (poseregnettrainer.py:262) or the raw normalised joints
+}
+
+// label -> PCA prior (poseregnettrainer.py:262) or the raw normalised joints; all threads of the workgroup
+__device__ __forceinline__ void aug_project_label(const PrepArgs& a, int b, const float* s_label) {
+    const int tid = threadIdx.x;
     const int D = a.J * 3;
     if (a.pca_comp) {
         for (int e = tid; e < a.E; e += DPP_THREADS) {
@@ -317,20 +310,50 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a
     }
 }
 
+// maximum of a stored crop over the workgroup (the reference's `premax`): monotone under the f32 de-normalisation, so max
+// first, de-normalise after.  Every thread returns the maximum.
+__device__ __forceinline__ float aug_crop_max(const float* __restrict__ im, int npix, float* s_red) {
+    const int tid = threadIdx.x;
+    float mx = -3.4e38f;
+    int i0 = 0;
+    if ((npix & 3) == 0 && (reinterpret_cast<uintptr_t>(im) & 15) == 0) {
+        const float4* im4 = reinterpret_cast<const float4*>(im);
+        for (int i = tid; i < (npix >> 2); i += DPP_THREADS) {
+            const float4 v = im4[i];
+            mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+        i0 = npix;
+    }
+    for (int i = i0 + tid; i < npix; i += DPP_THREADS) mx = fmaxf(mx, im[i]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) s_red[tid >> 6] = mx;
+    __syncthreads();
+    mx = s_red[0];
+    for (int w = 1; w < DPP_THREADS / DPP_WAVE; ++w) mx = fmaxf(mx, s_red[w]);
+    return mx;
+}
+
+__global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a) {
+    __shared__ float s_red[DPP_THREADS / DPP_WAVE];
+    __shared__ float s_label[MAXJ3];
+    const int b = blockIdx.x;
+    const float mx = aug_crop_max(a.img + (size_t)b * a.dsz * a.dsz, a.dsz * a.dsz, s_red);
+    if (threadIdx.x == 0) {
+        AugRec r;
+        aug_prepare_sample(a, b, mx, r, s_label);
+        a.rec[b] = r;
+    }
+    __syncthreads();
+    aug_project_label(a, b, s_label);
+}
+
 __device__ __forceinline__ long long cv_round(double v) { return (long long)rint(v); }
 
-__global__ __launch_bounds__(DPP_THREADS) void augment_warp_kernel(const float* __restrict__ img, const AugRec* __restrict__ rec, int dsz,
-                                                                   float* __restrict__ out) {
-    const int b = blockIdx.y;
-    const int p = blockIdx.x * DPP_THREADS + threadIdx.x;
-    const int npix = dsz * dsz;
-    if (p >= npix) return;
-    const AugRec r = rec[b];
-    const float* im = img + (size_t)b * npix;
-    const int y = p / dsz, x = p - y * dsz;
+// One output pixel (x, y) of the augmented crop: gather through the inverse map, z-rules, far-plane fill, re-normalise.
+__device__ __forceinline__ float aug_warp_pixel(const AugRec& r, const float* __restrict__ im, int dsz, int x, int y) {
     float v;
     if (r.warp == WARP_NONE) {
-        v = im[p] * r.den_scale + r.den_off;
+        v = im[y * dsz + x] * r.den_scale + r.den_off;
     } else {
         long long X, Y;
         if (r.warp == WARP_AFFINE) {
@@ -364,7 +387,71 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_warp_kernel(const float* 
     if (v == 0.0f) v = r.far_v;
     if (v >= r.far_v) v = r.far_v;
     if (v <= r.near_v) v = r.near_v;
-    out[(size_t)b * npix + p] = (v - r.norm_off) / r.norm_div;
+    return (v - r.norm_off) / r.norm_div;
+}
+
+__global__ __launch_bounds__(DPP_THREADS) void augment_warp_kernel(const float* __restrict__ img, const AugRec* __restrict__ rec, int dsz,
+                                                                   float* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int p = blockIdx.x * DPP_THREADS + threadIdx.x;
+    const int npix = dsz * dsz;
+    if (p >= npix) return;
+    const AugRec r = rec[b];
+    const int y = p / dsz, x = p - y * dsz;
+    out[(size_t)b * npix + p] = aug_warp_pixel(r, img + (size_t)b * npix, dsz, x, y);
+}
+
+// The whole augmentation of a (macro-)batch as ONE launch.  Crop b is handled by S workgroups (S = a power of two chosen by the
+// host so that the grid fills the chip at training batch sizes); each of them finds the crop maximum (the crop is 64 KB: after the
+// first touch it is served by the XCD's L2, and the block -> (crop, split) map keeps the S workgroups of a crop on ONE XCD:
+// workgroup w runs on XCD w % 8), lets its thread 0 do the per-sample geometry (identical, deterministic results in every
+// split) and warps its share of the pixels, four consecutive x per thread and one 16-byte store.  Split 0 also writes the
+// labels (and the optional records).  The draw counter lives on the device: after reading it every workgroup takes a ticket,
+// and the one that draws the last ticket advances the counter for the next launch and resets the ticket -- so a recorded
+// launch plan draws fresh parameters every step without a separate launch.
+__global__ __launch_bounds__(DPP_THREADS) void augment_fused_kernel(PrepArgs a, float* __restrict__ out_x, int S,
+                                                                    unsigned long long* counter_rw, unsigned* ticket) {
+    __shared__ float s_red[DPP_THREADS / DPP_WAVE];
+    __shared__ float s_label[MAXJ3];
+    __shared__ AugRec s_rec;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int xcd = w & 7, q = w >> 3;                 // q-th workgroup of this XCD
+    const int split = q % S, b = (q / S) * 8 + xcd;    // crops b with b % 8 == xcd live on this XCD
+    const int npix = a.dsz * a.dsz;
+    const bool live = b < a.B;
+    const float* im = a.img + (size_t)(live ? b : 0) * npix;
+    const float mx = aug_crop_max(im, npix, s_red);
+    if (tid == 0) {
+        if (live) aug_prepare_sample(a, b, mx, s_rec, s_label);
+        if (ticket != nullptr) {
+            // the ticket is taken only after this workgroup's read of the counter has returned (data dependence)
+            unsigned long long c = *counter_rw;
+            unsigned one = 1u + (unsigned)(c >> 63);
+            unsigned t = atomicAdd(ticket, one);
+            if (t == gridDim.x - 1) {
+                *counter_rw = c + 1ull;
+                *ticket = 0u;
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    if (split == 0) {
+        aug_project_label(a, b, s_label);
+        if (a.rec != nullptr && tid == 0) a.rec[b] = s_rec;
+    }
+    const AugRec r = s_rec;
+    const int chunk = npix / S;                          // host guarantees npix % (4 * S) == 0 and dsz % 4 == 0
+    float* o = out_x + (size_t)b * npix;
+    for (int p = split * chunk + tid * 4; p < (split + 1) * chunk; p += DPP_THREADS * 4) {
+        const int y = p / a.dsz, x = p - y * a.dsz;
+        float4 v;
+        v.x = aug_warp_pixel(r, im, a.dsz, x, y);
+        v.y = aug_warp_pixel(r, im, a.dsz, x + 1, y);
+        v.z = aug_warp_pixel(r, im, a.dsz, x + 2, y);
+        v.w = aug_warp_pixel(r, im, a.dsz, x + 3, y);
+        *reinterpret_cast<float4*>(o + p) = v;
+    }
 }
 
 
@@ -541,7 +628,42 @@ extern "C" int dpp_augment_prepare(const float* img, const float* com3d, const f
     a.cam.fx = fx; a.cam.fy = fy; a.cam.ux = ux; a.cam.uy = uy; a.cam.flip_y = flip_y;
     a.B = B; a.J = J; a.dsz = dsz; a.norm01 = norm_zero_one; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
     a.rec = static_cast<AugRec*>(records); a.out_y = out_y; a.out_mode = out_mode;
+    a.sample0 = 0; a.gbatch = (unsigned long long)B;
     DPP_LAUNCH(augment_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_augment(const float* img, const float* com3d, const float* cube, const float* Mcrop, const float* gt3d,
+                           int B, int J, int dsz, const int* mode, const double* off, const double* rot, const double* sc,
+                           const int* mode_table, int n_modes, unsigned long long seed, unsigned long long counter,
+                           double sigma_com, double sigma_sc, double rot_range, double fx, double fy, double ux, double uy,
+                           int flip_y, int norm_zero_one, const float* pca_mean, const float* pca_comp, int E, void* records,
+                           float* out_x, float* out_y, int* out_mode, unsigned long long* counter_dev, unsigned* ticket,
+                           unsigned long long sample0, unsigned long long global_batch, int splits, dpp_stream_t stream) {
+    if (!img || !com3d || !cube || !Mcrop || !gt3d || !out_x || !out_y || B < 1 || J < 1 || J * 3 > MAXJ3 || dsz < 4 || (dsz & 3) || img == out_x)
+        return DPP_E_BADARG;
+    if (!mode && (!mode_table || n_modes < 1)) return DPP_E_BADARG;
+    if (mode && (!off || !rot || !sc)) return DPP_E_BADARG;
+    if (pca_comp && (!pca_mean || E < 1)) return DPP_E_BADARG;
+    if (ticket && !counter_dev) return DPP_E_BADARG;
+    if (global_batch < 1) global_batch = (unsigned long long)B;
+    int S = splits;
+    if (S <= 0) {                                   // enough workgroups for the chip: ~1024 at training batch sizes
+        S = 1;
+        while (S < 16 && B * S < 1024 && (dsz * dsz) % (8 * S) == 0 && dsz * dsz / (2 * S) >= DPP_THREADS * 4) S *= 2;
+    }
+    if (S < 1 || (S & (S - 1)) || (dsz * dsz) % (4 * S)) return DPP_E_BADARG;
+    PrepArgs a;
+    a.img = img; a.com3d = com3d; a.cube = cube; a.Mcrop = Mcrop; a.gt3d = gt3d;
+    a.mode = mode; a.off = off; a.rot = rot; a.sc = sc; a.mode_table = mode_table; a.n_modes = n_modes;
+    a.seed = seed; a.counter = counter; a.counter_dev = counter_dev; a.sigma_com = sigma_com; a.sigma_sc = sigma_sc; a.rot_range = rot_range;
+    a.cam.fx = fx; a.cam.fy = fy; a.cam.ux = ux; a.cam.uy = uy; a.cam.flip_y = flip_y;
+    a.B = B; a.J = J; a.dsz = dsz; a.norm01 = norm_zero_one; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
+    a.rec = static_cast<AugRec*>(records); a.out_y = out_y; a.out_mode = out_mode;
+    a.sample0 = sample0; a.gbatch = global_batch;
+    const int groups = dpp_cdiv(B, 8);             // crops are dealt to XCDs round-robin: 8 per group
+    DPP_LAUNCH(augment_fused_kernel, dim3(groups * S * 8), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a, out_x, S,
+               counter_dev, ticket);
     return dpp_launch_status();
 }
 

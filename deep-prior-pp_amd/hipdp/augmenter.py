@@ -1,5 +1,5 @@
 """
-Device-side crop augmentation for a whole (macro-)batch: the two fused kernels of csrc/augment.hip behind one object.
+Device-side crop augmentation for a whole (macro-)batch: the fused kernel of csrc/augment.hip (dpp_augment) behind one object.
 This is what replaces the 8 worker processes + shared-memory macro-batch protocol of the reference
 (/root/reference/src/trainer/nettrainer.py:601-628, 666-689) and the per-sample loop of
 PoseRegNetTrainer.augment_poses (/root/reference/src/trainer/poseregnettrainer.py:221-264).
@@ -32,8 +32,9 @@ class DeviceAugmenter(object):
         self.rot_range = 180. if rot_range is None else rot_range
         self.seed = int(seed)
         self.normZeroOne = bool(normZeroOne)
-        self.rec = rt.alloc(self.n * rt.lib.dpp_augment_record_bytes(), np.uint8)
         self.counter = rt.alloc(1, np.int64)
+        self.ticket = rt.alloc(1, np.int32)
+        self.sample0, self.global_batch = 0, self.n            # set_shard(): data-parallel ranks key draws by the global sample index
         self.pm = self.pc = None
         self.E = 0
         if proj is not None:                                             # sklearn PCA: (x - mean_) . components_^T
@@ -42,18 +43,20 @@ class DeviceAugmenter(object):
             self.E = int(proj.components_.shape[0])
         self.out_dim = self.E if proj is not None else self.J * 3
 
+    def set_shard(self, sample0, global_batch):
+        """Data parallelism: this augmenter handles samples [sample0, sample0 + n) of a global (macro-)batch of `global_batch`
+        samples; device draws are keyed by the global index, so they do not depend on the number of ranks."""
+        self.sample0, self.global_batch = int(sample0), int(global_batch)
+
     def build(self, img, com3d, cube, Mcrop, gt3d, out_x, out_y, explicit=None):
-        """The launch list augmenting `n` crops from the *DB buffers into out_x / out_y.  explicit = dict(mode, off, rot, sc)
-        of device buffers pins the draws (parity tests); otherwise they come from the device generator."""
+        """The launch list (ONE fused launch) augmenting `n` crops from the *DB buffers into out_x / out_y.  explicit =
+        dict(mode, off, rot, sc) of device buffers pins the draws (parity tests); otherwise they come from the device generator,
+        whose counter the launch itself advances."""
         rt = self.rt
-        kw = dict(mode_table=self.table, n_modes=self.n_modes, seed=self.seed, counter=0, counter_dev=self.counter)
+        kw = dict(mode_table=self.table, n_modes=self.n_modes, seed=self.seed, counter=0, counter_dev=self.counter, ticket=self.ticket,
+                  sample0=self.sample0, global_batch=self.global_batch)
         if explicit is not None:
             kw = dict(mode=explicit['mode'], off=explicit['off'], rot=explicit['rot'], sc=explicit['sc'])
-        a = ops.augment_prepare(rt, img, com3d, cube, Mcrop, gt3d, self.n, self.J, self.dsz, self.cam, self.rec, out_y,
-                                sigma_com=self.sigma_com, sigma_sc=self.sigma_sc, rot_range=self.rot_range, pca_mean=self.pm,
-                                pca_comp=self.pc, E=self.E, norm_zero_one=self.normZeroOne, **kw)
-        w = ops.augment_warp(rt, img, self.rec, self.n, self.dsz, out_x)
-        lst = [a, w]
-        if explicit is None:
-            lst.append(ops.counter_add(rt, self.counter, 1))
-        return lst
+        return [ops.augment(rt, img, com3d, cube, Mcrop, gt3d, self.n, self.J, self.dsz, self.cam, out_x, out_y,
+                            sigma_com=self.sigma_com, sigma_sc=self.sigma_sc, rot_range=self.rot_range, pca_mean=self.pm,
+                            pca_comp=self.pc, E=self.E, norm_zero_one=self.normZeroOne, **kw)]

@@ -113,6 +113,11 @@ SIGNATURES = {
                                       C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_augment_warp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_augment': (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p] * 5 + [C.c_int, C.c_ulonglong,
+                              C.c_ulonglong, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                              C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int,
+                              stream_t]),
     'dpp_crop_record_bytes': (C.c_size_t, []),
     'dpp_crop_prepare': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                    C.c_void_p, C.c_void_p, stream_t]),

@@ -391,6 +391,34 @@ def augment_warp(rt, img, records, B, dsz, out, name='augment_warp'):
                   dict(kernel='augment_warp', flops=40.0 * B * dsz * dsz, bytes=8.0 * B * dsz * dsz))
 
 
+def augment(rt, img, com3d, cube, Mcrop, gt3d, B, J, dsz, cam, out_x, out_y, records=None, mode=None, off=None, rot=None, sc=None,
+            mode_table=None, n_modes=0, seed=0, counter=0, sigma_com=5., sigma_sc=0.02, rot_range=180., pca_mean=None, pca_comp=None,
+            E=0, out_mode=None, counter_dev=None, ticket=None, sample0=0, global_batch=0, splits=0, norm_zero_one=False, name='augment'):
+    """prepare + warp as one launch (dpp_augment); with `ticket` it also advances the device draw counter."""
+    fx, fy, ux, uy, flip = cam
+    return Launch(rt.lib.dpp_augment,
+                  (img.ptr, com3d.ptr, cube.ptr, Mcrop.ptr, gt3d.ptr, B, J, dsz, _p(mode), _p(off), _p(rot), _p(sc), _p(mode_table),
+                   n_modes, seed, counter, float(sigma_com), float(sigma_sc), float(rot_range), float(fx), float(fy), float(ux),
+                   float(uy), int(flip), int(bool(norm_zero_one)), _p(pca_mean), _p(pca_comp), E, _p(records), out_x.ptr, out_y.ptr,
+                   _p(out_mode), _p(counter_dev), _p(ticket), int(sample0), int(global_batch), int(splits)),
+                  (img, com3d, cube, Mcrop, gt3d, mode, off, rot, sc, mode_table, pca_mean, pca_comp, records, out_x, out_y, out_mode,
+                   counter_dev, ticket), name, dict(kernel='augment', flops=40.0 * B * dsz * dsz, bytes=8.0 * B * dsz * dsz))
+
+
+class AugmentState(object):
+    """The device-resident draw counter (+ the ticket word that advances it) of one augmentation stream, shared by the
+    launches over all data slices; sample0 / global_batch key the draws by the GLOBAL sample index (data parallelism)."""
+
+    def __init__(self, rt, B, seed=0, sample0=0, global_batch=0):
+        self.rt, self.B, self.seed, self.sample0, self.global_batch = rt, int(B), int(seed), int(sample0), int(global_batch or B)
+        self.counter = rt.alloc(1, np.int64)
+        self.ticket = rt.alloc(1, np.int32)
+
+    def ops(self, img, com3d, cube, Mcrop, gt3d, J, dsz, cam, out_x, out_y, **kw):
+        return [augment(self.rt, img, com3d, cube, Mcrop, gt3d, self.B, J, dsz, cam, out_x, out_y, seed=self.seed, counter=0,
+                        counter_dev=self.counter, ticket=self.ticket, sample0=self.sample0, global_batch=self.global_batch, **kw)]
+
+
 def crop_prepare(rt, frames, B, H, W, com, cube, fx, fy, dsz, records, M_out=None, name='crop_prepare'):
     return Launch(rt.lib.dpp_crop_prepare, (frames.ptr, B, H, W, com.ptr, cube.ptr, float(fx), float(fy), dsz, records.ptr, _p(M_out)),
                   (frames, com, cube, records, M_out), name, dict(kernel='crop_prepare', flops=2.0 * B * H * W, bytes=4.0 * B * H * W))

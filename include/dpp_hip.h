@@ -254,6 +254,21 @@ int dpp_augment_prepare(const float* img, const float* com3d, const float* cube,
  * augmentation parameters every step) */
 int dpp_counter_add(unsigned long long* counter, unsigned long long inc, dpp_stream_t stream);
 int dpp_augment_warp(const float* img, const void* records, int B, int dsz, float* out, dpp_stream_t stream);
+/* Both stages as ONE launch (what the trainer and bench.py use): prepare + warp of B crops into out_x [B][dsz][dsz] and
+ * out_y, `records` optional (NULL: not written).  Device draws (mode == NULL) are keyed by
+ *   (seed, (counter + *counter_dev) * global_batch + sample0 + b)
+ * i.e. by (seed, step, GLOBAL sample index): a data-parallel rank passes sample0 = rank * B and the global minibatch size, so
+ * what a sample draws does not depend on the number of GPUs (global_batch = 0 means B).  With ticket != NULL (a device
+ * word, zero before the first call) the launch also advances *counter_dev by one after every workgroup has read it, so a
+ * recorded plan / replayed graph draws fresh parameters each step without a dpp_counter_add launch.
+ * splits: workgroups per crop (a power of two dividing dsz*dsz/4; 0 = choose so that the grid fills the chip). */
+int dpp_augment(const float* img, const float* com3d, const float* cube, const float* Mcrop, const float* gt3d,
+                int B, int J, int dsz, const int* mode, const double* off, const double* rot, const double* sc,
+                const int* mode_table, int n_modes, unsigned long long seed, unsigned long long counter,
+                double sigma_com, double sigma_sc, double rot_range, double fx, double fy, double ux, double uy,
+                int flip_y, int norm_zero_one, const float* pca_mean, const float* pca_comp, int E, void* records,
+                float* out_x, float* out_y, int* out_mode, unsigned long long* counter_dev, unsigned* ticket,
+                unsigned long long sample0, unsigned long long global_batch, int splits, dpp_stream_t stream);
 
 /* ---- initial crop: HandDetector.cropArea3D (docom = False) fused with Dataset.imgStackDepthOnly -------------------------
  * /root/reference/src/util/handdetector.py:53-68, 204-226, 260-296, 382-490; /root/reference/src/data/dataset.py:97-103.

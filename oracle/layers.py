@@ -9,7 +9,9 @@ Third-party semantics assumed (Theano 0.9, un-vendored, parity unpinned):
   * conv2d is a TRUE convolution (filter_flip=True), border_mode 'half' pads k//2,
     `subsample` keeps every s-th output of the stride-1 result;
   * pool_2d(ignore_border=True, mode='max') uses non-overlapping windows, floor(H/ds);
-    its gradient goes to the first maximum in scan order of the window;
+    its gradient goes to EVERY window element equal to the maximum (Theano's CPU MaxPoolGrad: `if (a == maximum) gx += gz`;
+    the reference itself trained through cuDNN 5 pooling, whose tie rule is not Theano-CPU's -- the oracle and the kernels
+    follow the Theano-CPU graph, which is the one north_star times and compares against);
   * T.var is the biased variance; T.maximum(x, 0) passes the gradient where x >= 0
     (Theano's Maximum.grad uses eq(out, x)).
 """

@@ -239,9 +239,12 @@ def trained_param_list(net, P):
 
 
 # --------------------------------------------------------------------------- forward / backward
-def forward(net, P, x, train, dropout_masks=None):
-    """Returns (output, cache).  train=True <=> unsetDeterministic (BN batch statistics, dropout masks)."""
+def forward(net, P, x, train, dropout_masks=None, masks=None):
+    """Returns (output, cache).  train=True <=> unsetDeterministic (BN batch statistics, dropout masks).
+    masks (optional): {layer index: bool array} pins the pass / block decision of a 'relu' layer or of an 'fc' layer's ReLU
+    to the given pattern (the device's own, when comparing gradients: see oracle/torch_ref.forward)."""
     vals, cache, memo = {}, {}, {}
+    masks = masks or {}
 
     def get(ref):
         if ref[0] == 'input':
@@ -277,12 +280,15 @@ def forward(net, P, x, train, dropout_masks=None):
             else:
                 vals[i] = L.bn_fwd_eval(a, gamma, beta, rm, ris)
         elif k == 'relu':
-            vals[i] = L.relu_fwd(a)
-            cache[i] = (a,)
+            vals[i] = L.relu_fwd(a) if i not in masks else a * masks[i]
+            cache[i] = (a,) if i not in masks else (a, masks[i])
         elif k == 'fc':
             pre = L.fc_fwd(a, P[i][0], P[i][1])
-            vals[i] = L.relu_fwd(pre) if l['act'] == 'relu' else pre
-            cache[i] = (a, pre)
+            if l['act'] == 'relu':
+                vals[i] = L.relu_fwd(pre) if i not in masks else pre * masks[i]
+            else:
+                vals[i] = pre
+            cache[i] = (a, pre) if i not in masks else (a, pre, masks[i])
         elif k == 'dropout':
             if train:
                 m = dropout_masks[i]
@@ -355,10 +361,13 @@ def backward(net, P, cache, dout, weight_decay=0.0):
             dx, dgamma, dbeta = L.bn_bwd_train(a, P[i][1], mean, inv_std, dy)
             G[i] = [dbeta, dgamma]
         elif k == 'relu':
-            dx = L.relu_bwd(cache[i][0], dy)
+            dx = L.relu_bwd(cache[i][0], dy) if len(cache[i]) == 1 else dy * cache[i][1]
         elif k == 'fc':
-            a, pre = cache[i]
-            g = L.relu_bwd(pre, dy) if l['act'] == 'relu' else dy
+            a, pre = cache[i][:2]
+            if l['act'] == 'relu':
+                g = L.relu_bwd(pre, dy) if len(cache[i]) == 2 else dy * cache[i][2]
+            else:
+                g = dy
             dx, dW, db = L.fc_bwd(a, P[i][0], g)
             G[i] = [dW + 2 * weight_decay * P[i][0] if weight_decay else dW, db]
         elif k == 'dropout':
@@ -370,9 +379,9 @@ def backward(net, P, cache, dout, weight_decay=0.0):
     return G
 
 
-def cost_and_grads(net, P, x, y, train=True, dropout_masks=None, weight_decay=0.0, joints=None):
-    """The training cost (poseregnettrainer.py:92-107) and its gradients."""
-    out, cache = forward(net, P, x, train, dropout_masks)
+def cost_and_grads(net, P, x, y, train=True, dropout_masks=None, weight_decay=0.0, joints=None, masks=None):
+    """The training cost (poseregnettrainer.py:92-107) and its gradients; `masks`: see forward()."""
+    out, cache = forward(net, P, x, train, dropout_masks, masks)
     if joints is None:
         cost, dout = L.loss_embedding(out, y)
     else:

@@ -37,15 +37,16 @@ def _conv(a, W, stride, border):
 
 class _MaxPoolTies(torch.autograd.Function):
     """Non-overlapping max-pool whose gradient goes to EVERY window element equal to the maximum (Theano's MaxPoolGrad;
-    torch's own max_pool2d picks one index, which differs on the constant background of a depth crop)."""
+    torch's own max_pool2d picks one index, which differs on the constant background of a depth crop).  `ties` (optional,
+    bool [N][C][oh][ph][ow][pw]) pins the tie pattern to one decided elsewhere (the device's, see `masks` in forward)."""
 
     @staticmethod
-    def forward(ctx, c, ph, pw):
+    def forward(ctx, c, ph, pw, ties=None):
         N, C, H, W = c.shape
         oh, ow = H // ph, W // pw
         v = c[:, :, :oh * ph, :ow * pw].reshape(N, C, oh, ph, ow, pw)
         y = v.amax(dim=(3, 5))
-        ctx.save_for_backward(v == y[:, :, :, None, :, None])
+        ctx.save_for_backward(v == y[:, :, :, None, :, None] if ties is None else ties)
         ctx.dims = (N, C, H, W, oh, ph, ow, pw)
         return y
 
@@ -55,11 +56,28 @@ class _MaxPoolTies(torch.autograd.Function):
         N, C, H, W, oh, ph, ow, pw = ctx.dims
         g = torch.zeros((N, C, H, W), dtype=gy.dtype)
         g[:, :, :oh * ph, :ow * pw] = (ties * gy[:, :, :, None, :, None]).reshape(N, C, oh * ph, ow * pw)
-        return g, None, None
+        return g, None, None, None
 
 
-def forward(net, T, x, train):
+def _relu(a, mask=None):
+    """T.maximum(a, 0); with `mask` the pass / block decision of every element is the given one (value a where it passes,
+    gradient 1 there): pins the ReLU pattern of a float32 evaluation when comparing gradients, see forward()."""
+    return torch.clamp_min(a, 0) if mask is None else a * mask.to(a.dtype)
+
+
+def forward(net, T, x, train, masks=None):
+    """masks (optional): {layer index: bool array} -- for a 'relu' layer or an 'fc' layer with ReLU the elements that pass,
+    for a 'convpool' layer with pooling the tie pattern [N][C][oh][ow][ph*pw] of the windows.  The gradient of a deep ReLU net
+    is discontinuous in its inputs: two float32 evaluations (or one float32 and one float64) disagree on the sign of the
+    handful of activations that sit within rounding of zero, and every such flip moves all upstream gradients by a fraction
+    of a percent.  Handing the device's own decisions to the oracle removes that (legitimate) difference, so that what is
+    left is the arithmetic of the kernels, comparable at float32 round-off."""
     vals, stats = {}, {}
+    masks = masks or {}
+
+    def mk(i):
+        m = masks.get(i)
+        return None if m is None else torch.as_tensor(np.asarray(m))
 
     def get(ref):
         if ref[0] == 'input':
@@ -80,7 +98,12 @@ def forward(net, T, x, train):
         if k == 'convpool':
             c = _conv(a, T[i][0], l['stride'], l['border'])
             if tuple(l['pool']) != (1, 1):
-                c = _MaxPoolTies.apply(c, int(l['pool'][0]), int(l['pool'][1]))
+                ph, pw = int(l['pool'][0]), int(l['pool'][1])
+                ties = mk(i)
+                if ties is not None:
+                    N_, C_, oh, ow = ties.shape[:4]
+                    ties = ties.reshape(N_, C_, oh, ow, ph, pw).permute(0, 1, 2, 4, 3, 5)
+                c = _MaxPoolTies.apply(c, ph, pw, ties)
             c = c + T[i][1][None, :, None, None]
             vals[i] = torch.clamp_min(c, 0) if l['act'] == 'relu' else c
         elif k == 'conv':
@@ -97,10 +120,10 @@ def forward(net, T, x, train):
             vals[i] = (a - mean[None, :, None, None]) * (gamma * inv_std)[None, :, None, None] \
                 + beta[None, :, None, None]
         elif k == 'relu':
-            vals[i] = torch.clamp_min(a, 0)
+            vals[i] = _relu(a, mk(i))
         elif k == 'fc':
             pre = a @ T[i][0] + T[i][1]
-            vals[i] = torch.clamp_min(pre, 0) if l['act'] == 'relu' else pre
+            vals[i] = _relu(pre, mk(i)) if l['act'] == 'relu' else pre
         elif k == 'dropout':
             vals[i] = a * float(np.float32(1.0 - l['p'])) if not train else a   # masks not modelled here
         else:
@@ -108,16 +131,16 @@ def forward(net, T, x, train):
     return get(net['out']), stats
 
 
-def cost_and_grads(net, P, x, y, dtype=torch.float64):
-    """Returns (cost, {layer: [g0, g1]}, out) with autograd gradients (numpy arrays)."""
+def cost_and_grads(net, P, x, y, dtype=torch.float64, masks=None):
+    """Returns (cost, {layer: [g0, g1]}, out) with autograd gradients (numpy arrays); `masks`: see forward()."""
     T = to_torch(P, dtype)
     xt = [torch.as_tensor(a, dtype=dtype) for a in x] if isinstance(x, (list, tuple)) else torch.tensor(x, dtype=dtype)
     yt = torch.tensor(y, dtype=dtype)
-    out, _ = forward(net, T, xt, True)
+    out, _ = forward(net, T, xt, True, masks)
     cost = ((out - yt) ** 2).sum(dim=1).mean()
     cost.backward()
     G = {i: [T[i][0].grad.numpy(), T[i][1].grad.numpy()] for i in T}
-    return float(cost), G, out.detach().numpy()
+    return float(cost.detach()), G, out.detach().numpy()
 
 
 class TorchTrainer(object):

@@ -207,3 +207,60 @@ def test_augment_norm_zero_one(backend):
         assert nbad <= (6 if names[i] == 'rot' else 0), (i, names[i], nbad)
         assert out[i].min() >= 0.0 and out[i].max() <= 1.0 + 1e-6
         np.testing.assert_allclose(out_y[i].reshape(J, 3), lab, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_fused_augment_equals_two_stage_and_advances_counter(backend):
+    """dpp_augment (ONE launch: prepare + warp + counter advance) against dpp_augment_prepare + dpp_augment_warp, bit for bit,
+    for every split count; the device counter moves by one per launch (fresh draws per step for a recorded plan) and draws are
+    keyed by the GLOBAL sample index, so two shards of a global batch reproduce the single-batch result."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(31)
+    cam = A.Camera.nyu()
+    B, J = 16, 14
+    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, B, cam, cube=(300.,) * 3, joints=J)
+    f32 = lambda a: rt.upload(np.asarray(a, np.float32))
+    camt = (cam.fx, cam.fy, cam.ux, cam.uy, cam.flip_y)
+    mean = rng.normal(0, 0.1, J * 3).astype(np.float32)
+    comp = rng.normal(0, 0.2, (30, J * 3)).astype(np.float32)
+    pm, pc = f32(mean), f32(comp)
+    table = rt.upload(np.array([1, 2, 3, 0], np.int32))
+    img, com, cube, M, gt = f32(imgs), f32(coms), f32(cubes), f32(Ms.reshape(B, 9)), f32(gts)
+
+    def two_stage(counter):
+        rec = rt.alloc(B * rt.lib.dpp_augment_record_bytes(), np.uint8)
+        y, x = rt.alloc((B, 30), zero=False), rt.alloc((B, 128, 128), zero=False)
+        ops.augment_prepare(rt, img, com, cube, M, gt, B, J, 128, camt, rec, y, mode_table=table, n_modes=4, seed=77, counter=counter,
+                            pca_mean=pm, pca_comp=pc, E=30)(rt.stream)
+        ops.augment_warp(rt, img, rec, B, 128, x)(rt.stream)
+        rt.synchronize()
+        return x.get(), y.get()
+
+    x0, y0 = two_stage(0)
+    x1, y1 = two_stage(1)
+    assert (x0 != x1).mean() > 0.01
+    for splits in (0, 1, 4, 16):
+        st = ops.AugmentState(rt, B, seed=77)
+        xo, yo = rt.alloc((B, 128, 128), zero=False), rt.alloc((B, 30), zero=False)
+        (launch,) = st.ops(img, com, cube, M, gt, J, 128, camt, xo, yo, mode_table=table, n_modes=4, pca_mean=pm, pca_comp=pc, E=30, splits=splits)
+        launch(rt.stream)
+        rt.synchronize()
+        np.testing.assert_array_equal(xo.get(), x0)
+        np.testing.assert_array_equal(yo.get(), y0)
+        assert int(st.counter.get()[0]) == 1 and int(st.ticket.get()[0]) == 0
+        launch(rt.stream)                                   # the same prepared launch again: the next step's draws
+        rt.synchronize()
+        np.testing.assert_array_equal(xo.get(), x1)
+        np.testing.assert_array_equal(yo.get(), y1)
+        assert int(st.counter.get()[0]) == 2
+    # two ranks of 8 samples each == one batch of 16 (ragged B = 8 + an odd shard size 5 exercise the dead workgroups)
+    for lo, n in ((0, 8), (8, 8), (3, 5)):
+        st = ops.AugmentState(rt, n, seed=77, sample0=lo, global_batch=B)
+        xo, yo = rt.alloc((n, 128, 128), zero=False), rt.alloc((n, 30), zero=False)
+        v = lambda b, k: b.view(lo * k, (n * k,))          # noqa: E731
+        (launch,) = st.ops(v(img, 128 * 128), v(com, 3), v(cube, 3), v(M, 9), v(gt, J * 3), J, 128, camt, xo, yo, mode_table=table,
+                           n_modes=4, pca_mean=pm, pca_comp=pc, E=30)
+        launch(rt.stream)
+        rt.synchronize()
+        np.testing.assert_array_equal(xo.get(), x0[lo:lo + n])
+        np.testing.assert_array_equal(yo.get(), y0[lo:lo + n])

@@ -1,0 +1,49 @@
+"""bench.py's command line: `--gpus N` without a launcher starts the N ranks itself (torch.distributed.run) and rank 0 prints
+ONE JSON line carrying n_gpus = N.  The CPU tier drives the real control flow (spawn, rendezvous on 127.0.0.1, data-parallel
+engine, gradient all-reduce, max-over-ranks timing) with two gloo ranks on the SIMT emulator at a toy size (DPP_BENCH_EMU=1);
+on the one-GPU box `--gpus 2` has to fail loudly instead of quietly timing one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env=None, timeout=1500):
+    e = dict(os.environ)
+    e.pop('WORLD_SIZE', None)
+    e.pop('RANK', None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return r.returncode, r.stdout.decode(), r.stderr.decode()
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_them():
+    rc, out, err = _bench(['--gpus', '2', '--batch', '4', '--size', '32', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'],
+                          env=dict(DPP_BENCH_EMU='1'))
+    assert rc == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['parallelism'] == 'dp2' and res['config']['global_batch'] == 8
+    assert res['scaling'] == 'weak' and res['unit'] == 'depth-crops/sec' and res['value'] > 0
+    assert res['config']['final_cost'] == res['config']['final_cost'] and res['config']['final_cost'] > 0      # finite
+
+
+def test_world_size_mismatch_is_an_error():
+    """Started under a launcher with another rank count than --gpus says: refuse, do not silently time something else."""
+    rc, out, err = _bench(['--gpus', '2', '--batch', '4', '--size', '32', '--steps', '1', '--warmup', '0', '--no-cpu-baseline'],
+                          env=dict(DPP_BENCH_EMU='1', WORLD_SIZE='1', RANK='0'))
+    assert rc != 0 and '--gpus 2' in (out + err)
+
+
+@pytest.mark.gpu
+def test_gpus_2_on_a_one_gpu_box_fails_loudly():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('this box has %d GPUs' % torch.cuda.device_count())
+    rc, out, err = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline'])
+    assert rc != 0 and 'needs 2 visible' in err and not [l for l in out.splitlines() if l.startswith('{')]

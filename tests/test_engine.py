@@ -10,13 +10,14 @@ import pytest
 from hipdp import engine
 from net.resnet import ResNet, ResNetParams
 from oracle import layers as L
-from oracle import nets
+from oracle import nets, torch_ref
 from tests.backends import BACKENDS, get_runtime
+from tests.pinning import device_masks
 
 MM = 150.0          # normalised unit -> mm for a 300 mm NYU cube
 
 
-def make_net(rt, type_, batch, size, numJoints, nDims, seed=23455):
+def make_net(rt, type_, batch, size, numJoints, nDims, seed=23455, calib_batch=None):
     rng = np.random.RandomState(seed)
     cfg = ResNetParams(type=type_, nChan=1, wIn=size, hIn=size, batchSize=batch, numJoints=numJoints, nDims=nDims)
     net = ResNet(rng, cfgParams=cfg)
@@ -25,7 +26,7 @@ def make_net(rt, type_, batch, size, numJoints, nDims, seed=23455):
     P = nets.perturb_bn(P, onet, np.random.RandomState(seed + 1))
     # running statistics of a "trained" net: the batch statistics of a calibration batch (random running stats would not
     # normalise anything and the deterministic forward would blow up to 1e6)
-    xc = nets.synthetic_crops(np.random.RandomState(seed + 2), batch, size, size, np.float64)
+    xc = nets.synthetic_crops(np.random.RandomState(seed + 2), calib_batch or batch, size, size, np.float64)   # (a small one keeps full-batch tests quick)
     ones = {i: np.ones(l['out_dim']) for i, l in enumerate(onet['layers']) if l['kind'] == 'dropout'}     # calibration only
     _, cache = nets.forward(onet, nets.cast_params(P, np.float64), xc, True, ones)
     for i, l in enumerate(onet['layers']):
@@ -50,18 +51,13 @@ def bad_gradients(G, G_ref, slots=(0, 1)):
             if np.abs(G[i][s] - G_ref[i][s]).max() > 2e-4 * max(np.abs(G_ref[i][s]).max(), 5e-3 * gmax)]
 
 
-def gradients_match_on_some_input(run, seeds=(6, 7, 8)):
-    """`run(seed)` -> list of bad tensors.  On these deliberately tiny nets (16-64 values per BatchNorm channel) one activation
-    within float32 rounding of the ReLU kink flips its mask in one of the two evaluations and moves a whole channel's gradient
-    by percents; such an input says nothing about the kernels.  The tight comparison has to hold on the first of a few
-    inputs that has no such activation (a kernel bug fails on all of them)."""
-    failures = []
-    for seed in seeds:
-        bad = run(seed)
-        if not bad:
-            return
-        failures.append((seed, bad[:4]))
-    raise AssertionError("gradients off on every input: %r" % (failures,))
+def gradients_match_on_every_input(run, seeds=(6, 7, 8)):
+    """`run(seed)` -> list of bad tensors, evaluated with the oracle's ReLU / max-pool decisions pinned to the device's own
+    (tests/pinning.py): on these deliberately tiny nets (16-64 values per BatchNorm channel) one activation within float32
+    rounding of the ReLU kink would otherwise flip its mask in one of the two evaluations and move a whole channel's gradient
+    by percents.  Pinned, the tight comparison has to hold on EVERY input."""
+    failures = [(seed, bad[:4]) for seed, bad in ((seed, run(seed)) for seed in seeds) if bad]
+    assert not failures, "gradients off: %r" % (failures,)
 
 
 def grads_from_store(eng, net):
@@ -115,12 +111,12 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
         x = nets.synthetic_crops(rng, 4, 32, 32, np.float32)
         y = rng.normal(0, 0.3, (4, nJ * nD)).astype(np.float32)
         cost, out = eng.cost_and_grads(x, y)          # train mode: batch statistics, so the moving running stats do not matter
-        c_ref, G_ref, _, out_ref = nets.cost_and_grads(onet, P64, x.astype(np.float64), y.astype(np.float64))
+        c_ref, G_ref, out_ref = torch_ref.cost_and_grads(onet, P64, x.astype(np.float64), y.astype(np.float64), masks=device_masks(eng, net))
         assert np.abs(out - out_ref).max() * MM < 1e-3
         assert abs(cost - c_ref) < 1e-5 * abs(c_ref)
         return bad_gradients(grads_from_store(eng, net), G_ref)
 
-    gradients_match_on_some_input(run)
+    gradients_match_on_every_input(run)
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
@@ -180,9 +176,8 @@ def test_resnet_train_steps_match_oracle(backend):
 def test_resnet_type3_dropout_narrow_stages(backend):
     """ResNet type 3 (resnet.py:243-288): stages 3-4 narrowed to 128 filters -- stage 3 becomes identity blocks without
     down-sampling -- and a DropoutLayer behind each 1024-wide layer; gradients against the oracle with the device's masks.
-    On this tiny net (64 values per BatchNorm channel) a single activation within float32 rounding of the ReLU kink flips its
-    mask and moves a whole channel's gradient by percents, on either side of the comparison; such an input says nothing
-    about the kernels, so the (tight) comparison is made on the first of three inputs that has no such activation."""
+    The oracle evaluates with the device's dropout masks AND the device's ReLU decisions (tests/pinning.py), so the tight
+    comparison holds on every input."""
     rt = get_runtime(backend)
     net, onet, P = make_net(rt, 3, 4, 32, 1, 30)
     assert [l.__class__.__name__ for l in net.layers].count('DropoutLayer') == 2
@@ -197,7 +192,6 @@ def test_resnet_type3_dropout_narrow_stages(backend):
     assert np.abs(net.computeOutput(x0) - ref).max() * MM < max(1e-3, 3 * noise)
     net.unsetDeterministic()
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
-    failures = []
     for seed in (7, 8, 9):
         rng = np.random.RandomState(seed)
         x = nets.synthetic_crops(rng, 4, 32, 32, np.float32)
@@ -205,19 +199,14 @@ def test_resnet_type3_dropout_narrow_stages(backend):
         cost, out = eng.cost_and_grads(x, y)
         masks = {i: eng.dropout_masks[id(l)][0].get().astype(np.float64) for i, l in enumerate(net.layers) if id(l) in eng.dropout_masks}
         assert len(masks) == 2
+        pin = {k: v for k, v in device_masks(eng, net).items() if onet['layers'][k]['kind'] != 'convpool'}
         Pn = {i: [p.get_value() for p in l.params + l.params_nontrained] for i, l in enumerate(net.layers) if l.params}   # running stats moved
-        c_ref, G_ref, _, out_ref = nets.cost_and_grads(onet, nets.cast_params(Pn, np.float64), x.astype(np.float64), y.astype(np.float64), True, masks)
-        noise_mm = np.abs(nets.cost_and_grads(onet, Pn, x, y, True, {k: v.astype(np.float32) for k, v in masks.items()})[3] - out_ref).max() * MM
-        assert np.abs(out - out_ref).max() * MM < max(1e-3, 3 * noise_mm)
+        c_ref, G_ref, _, out_ref = nets.cost_and_grads(onet, nets.cast_params(Pn, np.float64), x.astype(np.float64), y.astype(np.float64), True, masks,
+                                                       masks=pin)
+        assert np.abs(out - out_ref).max() * MM < 1e-3
         assert abs(cost - c_ref) < 1e-5 * abs(c_ref)
-        G = grads_from_store(eng, net)
-        gmax = max(np.abs(G_ref[i][s]).max() for i in G_ref for s in range(2))
-        bad = [(i, s) for i in G_ref for s in range(2)
-               if np.abs(G[i][s] - G_ref[i][s]).max() > 2e-4 * max(np.abs(G_ref[i][s]).max(), 5e-3 * gmax)]
-        if not bad:
-            return
-        failures.append((seed, bad[:4]))
-    raise AssertionError("gradients off on every input: %r" % (failures,))
+        bad = bad_gradients(grads_from_store(eng, net), G_ref)
+        assert not bad, (seed, bad[:4])
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
@@ -244,13 +233,14 @@ def test_weight_decay_cost_and_gradients(backend):
         xs = nets.synthetic_crops(r, 4, 32, 32, np.float32)
         ys = r.normal(0, 0.3, (4, 30)).astype(np.float32)
         cost, _ = eng.cost_and_grads(xs, ys)
-        c_ref, G_ref, _, _ = nets.cost_and_grads(onet, P64, xs.astype(np.float64), ys.astype(np.float64), weight_decay=wd)
-        c_plain, _, _, _ = nets.cost_and_grads(onet, P64, xs.astype(np.float64), ys.astype(np.float64))
+        pin = {k: v for k, v in device_masks(eng, net).items() if onet['layers'][k]['kind'] != 'convpool'}      # (no exact pool ties on random inputs)
+        c_ref, G_ref, _, _ = nets.cost_and_grads(onet, P64, xs.astype(np.float64), ys.astype(np.float64), weight_decay=wd, masks=pin)
+        c_plain, _, _, _ = nets.cost_and_grads(onet, P64, xs.astype(np.float64), ys.astype(np.float64), masks=pin)
         assert c_ref - c_plain > 1e-3 * c_plain                    # the regulariser is visible in the cost
         assert abs(cost - c_ref) < 1e-5 * abs(c_ref)
         return bad_gradients(grads_from_store(eng, net), G_ref, slots=(0,))
 
-    gradients_match_on_some_input(run, seeds=(12, 13, 14))
+    gradients_match_on_every_input(run, seeds=(12, 13, 14))
     # dropout nets ignore the factor
     net3, onet3, P3 = make_net(rt, 3, 4, 32, 1, 30)
     e3 = engine.CompiledNet(net3, train=False, runtime=rt, loss=dict(kind='embedding'), weight_decay=wd)

@@ -191,3 +191,18 @@ def test_rowstream_variant_fwd_and_dgrad(backend, cfg):
     refd = np.zeros((Nb, Hi, Wi, K))
     refd[:, ::s, ::s, :] = (dY.astype('f8') @ Wk.astype('f8')).reshape(Nb, Ho, Wo, K)
     _check(dH.get().reshape(Nb, Hi, Wi, K), refd, N, 8)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_every_gemm_instantiation_of_a_small_resnet(backend):
+    """Every distinct dpp_gemm problem the train plans of a small ResNet launch (tile / split-K heuristics, strided row maps,
+    BN+ReLU prologues, bias / residual / statistics epilogues), stand-alone against float64 (tests/gemm_cases.py); the
+    benchmarked batch of 128 runs the same check on the GPU (tests/test_full_size.py)."""
+    from hipdp import engine
+    from net.resnet import ResNet, ResNetParams
+    from tests import gemm_cases
+    rt = get_runtime(backend)
+    net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, nChan=1, wIn=32, hIn=32, batchSize=4, numJoints=1, nDims=30))
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    checked, skipped = gemm_cases.check_all(rt, eng)
+    assert len(checked) >= 15, (len(checked), len(skipped))
