@@ -37,6 +37,23 @@ struct Conv3Args {
     int tiles_x, tiles_y;
 };
 
+typedef __bf16 c3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 c3_bf16x4 __attribute__((ext_vector_type(4)));
+
+// LDS element type of the operand images: f32 (exact path) or bf16 (BASELINE config 5: operands rounded RNE after the
+// prologue, f32 accumulation).  KP = channels per tap in the image: Ci, or at least 32 for bf16 (one 16x16x32 step; the
+// 16-channel layers zero-fill the upper half).
+template <int PREC> struct C3Prec;
+template <> struct C3Prec<0> { typedef float elem; static constexpr int PAD = 4; __device__ static int kp(int Ci) { return Ci; } };
+template <> struct C3Prec<1> { typedef __bf16 elem; static constexpr int PAD = 8; __device__ static int kp(int Ci) { return Ci < 32 ? 32 : Ci; } };
+
+__device__ __forceinline__ void c3_store4(float* dst, float4 v) { *reinterpret_cast<float4*>(dst) = v; }
+__device__ __forceinline__ void c3_store4(__bf16* dst, float4 v) {
+    c3_bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    *reinterpret_cast<c3_bf16x4*>(dst) = o;
+}
+
 __device__ __forceinline__ void tile_origin(const Conv3Args& a, int bid, int& n0, int& y0, int& x0) {
     int bx = bid % a.tiles_x;
     int t = bid / a.tiles_x;
@@ -47,10 +64,12 @@ __device__ __forceinline__ void tile_origin(const Conv3Args& a, int bid, int& n0
     x0 = bx << a.ltw;
 }
 
-// Stage the activated input halo of the tile into LDS: Ah[(img*(TH+2)+hy)*(TW+2)+hx][Ci+4].
+// Stage the activated input halo of the tile into LDS: Ah[(img*(TH+2)+hy)*(TW+2)+hx][KP+pad] (KP >= Ci: channels Ci..KP-1 zero).
+template <class E>
 __device__ __forceinline__ void stage_halo(const float* __restrict__ X, int N, int H, int W, int Ci, const dpp_act& act, int n0,
-                                           int y0, int x0, int TH, int TW, int IMG, float* Ah, int LDA) {
-    const int q = Ci >> 2;
+                                           int y0, int x0, int TH, int TW, int IMG, E* Ah, int LDA, int KP = 0) {
+    if (KP < Ci) KP = Ci;
+    const int q = KP >> 2;
     const int HW2 = (TH + 2) * (TW + 2);
     const int total = IMG * HW2 * q;
     for (int s = threadIdx.x; s < total; s += DPP_THREADS) {
@@ -59,25 +78,27 @@ __device__ __forceinline__ void stage_halo(const float* __restrict__ X, int N, i
         int hy = rem / (TW + 2), hx = rem - hy * (TW + 2);
         int n = n0 + im, y = y0 + hy - 1, x = x0 + hx - 1;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < N && y >= 0 && y < H && x >= 0 && x < W) {
+        if (c4 * 4 < Ci && n < N && y >= 0 && y < H && x >= 0 && x < W) {
             v = *reinterpret_cast<const float4*>(X + (((size_t)n * H + y) * W + x) * Ci + c4 * 4);
             if (act.mode) v = dpp_act4(v, act, c4 * 4);
         }
-        *reinterpret_cast<float4*>(&Ah[hp * LDA + c4 * 4]) = v;
+        c3_store4(&Ah[hp * LDA + c4 * 4], v);
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PREC = 0>
 __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);
+    typedef typename C3Prec<PREC>::elem elem;
     constexpr int RM = BM / 64;
     constexpr int CN = BN / 16;
+    constexpr int KSTEP = PREC ? 32 : 16;       // channels consumed per fragment read (one b128 per operand)
     const int TH = 1 << a.lth, TW = 1 << a.ltw;
-    const int Ci = a.Ci, LDA = Ci + 4;
+    const int Ci = a.Ci, KP = C3Prec<PREC>::kp(Ci), LDA = KP + C3Prec<PREC>::PAD;
     const int HP = a.img * (TH + 2) * (TW + 2);
-    float* Ah = smem;
-    float* Bs = smem + HP * LDA;                 // [BN][Ci+4]
+    elem* Ah = reinterpret_cast<elem*>(smem);
+    elem* Bs = Ah + HP * LDA;                    // [BN][KP+pad] per slice
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     int n0, y0, x0;
     tile_origin(a, blockIdx.x, n0, y0, x0);
@@ -85,7 +106,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
 
     dpp_wide_coef wco;
     if (a.wide) wco.load<BN>(col0, a.Co, a.bias, a.epi);
-    stage_halo(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA);
+    stage_halo(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP);
 
     // halo index of this lane's A rows (centre tap)
     int hbase[RM];
@@ -106,28 +127,30 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
 
     // weight slices are double-buffered in LDS: the slice of tap t+1 is fetched into registers before the MFMAs of tap t
     // and written to the other buffer after them, so one barrier per tap suffices and the fetch latency is hidden.
-    const int q = Ci >> 2;
-    constexpr int WSLOTS = (BN * 16 + DPP_THREADS - 1) / DPP_THREADS;      // Ci <= 64 -> at most BN*16 float4 per slice
+    const int q = KP >> 2;
+    constexpr int WSLOTS = (BN * 16 + DPP_THREADS - 1) / DPP_THREADS;      // KP <= 64 -> at most BN*16 float4 per slice
     float4 wreg[WSLOTS];
+    auto wload = [&](int j, int tap, int c4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col0 + j < a.Co && c4 * 4 < Ci) v = *reinterpret_cast<const float4*>(a.Wk + ((size_t)(col0 + j) * 9 + tap) * Ci + c4 * 4);
+        return v;
+    };
     auto wfetch = [&](int tap) {
 #pragma unroll
         for (int s = 0; s < WSLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (slot < BN * q) {
-                int j = slot / q, c4 = slot - j * q;
-                if (col0 + j < a.Co) v = *reinterpret_cast<const float4*>(a.Wk + ((size_t)(col0 + j) * 9 + tap) * Ci + c4 * 4);
-            }
+            if (slot < BN * q) v = wload(slot / q, tap, slot % q);
             wreg[s] = v;
         }
     };
-    auto wcommit = [&](float* dst) {
+    auto wcommit = [&](elem* dst) {
 #pragma unroll
         for (int s = 0; s < WSLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
             if (slot < BN * q) {
                 int j = slot / q, c4 = slot - j * q;
-                *reinterpret_cast<float4*>(&dst[j * LDA + c4 * 4]) = wreg[s];
+                c3_store4(&dst[j * LDA + c4 * 4], wreg[s]);
             }
         }
     };
@@ -139,9 +162,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
         for (int sidx = tid; sidx < 9 * per_tap; sidx += DPP_THREADS) {
             const int tap = sidx / per_tap, slot = sidx - tap * per_tap;
             const int j = slot / q, c4 = slot - j * q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col0 + j < a.Co) v = *reinterpret_cast<const float4*>(a.Wk + ((size_t)(col0 + j) * 9 + tap) * Ci + c4 * 4);
-            *reinterpret_cast<float4*>(&Bs[(tap * BN + j) * LDA + c4 * 4]) = v;
+            c3_store4(&Bs[(tap * BN + j) * LDA + c4 * 4], wload(j, tap, c4));
         }
     } else {
         wfetch(0);
@@ -149,32 +170,47 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     }
     __syncthreads();                // halo + first slice (or all slices) visible
     for (int tap = 0; tap < 9; ++tap) {
-        const float* Bcur = allw ? Bs + tap * BN * LDA : Bs + (tap & 1) * BN * LDA;
+        const elem* Bcur = allw ? Bs + tap * BN * LDA : Bs + (tap & 1) * BN * LDA;
         if (!allw && tap + 1 < 9) wfetch(tap + 1);
         const int toff = (tap / 3 - 1) * (TW + 2) + (tap % 3 - 1);
-        for (int kc = 0; kc < Ci; kc += 16) {
-            float4 av[RM], bv[CN];
+        for (int kc = 0; kc < KP; kc += KSTEP) {
+            if constexpr (PREC == 0) {
+                float4 av[RM], bv[CN];
 #pragma unroll
-            for (int rt = 0; rt < RM; ++rt)
-                av[rt] = *reinterpret_cast<const float4*>(&Ah[(hbase[rt] + toff) * LDA + kc + kq * 4]);
+                for (int rt = 0; rt < RM; ++rt)
+                    av[rt] = *reinterpret_cast<const float4*>(&Ah[(hbase[rt] + toff) * LDA + kc + kq * 4]);
 #pragma unroll
-            for (int ct = 0; ct < CN; ++ct)
-                bv[ct] = *reinterpret_cast<const float4*>(&Bcur[(ct * 16 + l15) * LDA + kc + kq * 4]);
+                for (int ct = 0; ct < CN; ++ct)
+                    bv[ct] = *reinterpret_cast<const float4*>(&Bcur[(ct * 16 + l15) * LDA + kc + kq * 4]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < CN; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t),
+                                                                               acc[rt][ct], 0, 0, 0);
+            } else {
+                c3_bf16x8 av[RM], bv[CN];
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt)
+                    av[rt] = *reinterpret_cast<const c3_bf16x8*>(&Ah[(hbase[rt] + toff) * LDA + kc + kq * 8]);
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct)
+                    bv[ct] = *reinterpret_cast<const c3_bf16x8*>(&Bcur[(ct * 16 + l15) * LDA + kc + kq * 8]);
 #pragma unroll
                 for (int rt = 0; rt < RM; ++rt)
 #pragma unroll
                     for (int ct = 0; ct < CN; ++ct)
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t),
-                                                                           acc[rt][ct], 0, 0, 0);
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rt], bv[ct], acc[rt][ct], 0, 0, 0);
+            }
         }
         if (!allw) {
             if (tap + 1 < 9) wcommit(Bs + ((tap + 1) & 1) * BN * LDA);
             __syncthreads();
         }
     }
-    if (allw) __syncthreads();      // the epilogue reuses Bs as scratch
+    if (allw) __syncthreads();      // the epilogue reuses the operand images as scratch
 
     if (a.wide) {
         const int vi = (a.N - n0 < a.img) ? (a.N - n0) : a.img;
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
         }
     }
     if (fused) {
-        float* red = Bs;                               // weight slices are dead after the last tap's barrier
+        float* red = smem;                             // the operand images are dead after the last tap's barrier
         const int cbase = col0 + l15;
         if (ep.bn_x != nullptr && ep.bn_partial != nullptr) {
             dpp_tile_colsum<CN, 4, 1, BN>(sx, red, wave, 0, l15, kq);
@@ -440,8 +476,9 @@ extern "C" int dpp_conv3x3_tiling(int N, int H, int W, int bm, int* th, int* tw,
     return dpp_cdiv(W, 1 << ltw) * dpp_cdiv(H, 1 << lth) * dpp_cdiv(N, im);
 }
 
-extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
-                           const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream) {
+static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
+                          const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, int precision,
+                          dpp_stream_t stream) {
     if (!X || !Wk || !Y || N < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15)) return DPP_E_BADARG;
     Conv3Args a;
     a.X = X; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
@@ -460,25 +497,38 @@ extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dp
     int bn = Co >= 64 ? 64 : (Co >= 32 ? 32 : 16);
     while (bn > 16 && (long)nblk * dpp_cdiv(Co, bn) < 1024) bn >>= 1;     // ~4 workgroups per CU (measured: 256 -> 1024 is ~0.5 % of the step)
     size_t halo = (size_t)a.img * (TH + 2) * (TW + 2);
-    a.allw = (halo + 9 * bn) * (Ci + 4) * sizeof(float) <= 48 * 1024;
-    size_t lds = (halo + (a.allw ? 9 : 2) * bn) * (Ci + 4) * sizeof(float);
+    // bytes of one image row: f32 [Ci + 4], bf16 [max(Ci, 32) + 8]
+    const size_t rowb = precision ? (size_t)((Ci < 32 ? 32 : Ci) + 8) * 2 : (size_t)(Ci + 4) * sizeof(float);
+    a.allw = (halo + 9 * bn) * rowb <= 48 * 1024;
+    size_t lds = (halo + (a.allw ? 9 : 2) * bn) * rowb;
     static const bool wide_ok = []() { const char* e = getenv("DPP_GEMM_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     a.wide = wide_ok && al16(Y) && al16(residual) && al16(a.epi.bn_x);
-    if (a.wide) {
-        size_t need = ((size_t)bm * (bn + 4) + 16 * bn) * sizeof(float);
-        if (lds < need) lds = need;
-    }
+    size_t need = a.wide ? ((size_t)bm * (bn + 4) + 16 * bn) * sizeof(float) : (size_t)4 * bn * sizeof(float);
+    if (lds < need) lds = need;
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, dpp_cdiv(Co, bn));
     hipStream_t st = static_cast<hipStream_t>(stream);
     // gfx950 has 160 KiB of LDS per CU; requests above the default 64 KiB window need the opt-in attribute
 #define DPP_C3(BM_, BN_) if (bm == BM_ && bn == BN_) { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        DPP_LAUNCH((conv3x3_kernel<BM_, BN_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
+        if (precision) { \
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            DPP_LAUNCH((conv3x3_kernel<BM_, BN_, 1>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        DPP_LAUNCH((conv3x3_kernel<BM_, BN_, 0>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
     DPP_C3(128, 64) DPP_C3(128, 32) DPP_C3(128, 16) DPP_C3(64, 64) DPP_C3(64, 32) DPP_C3(64, 16)
 #undef DPP_C3
     return DPP_E_UNSUPPORTED;
+}
+
+extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
+                           const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream) {
+    return conv3x3_launch(X, N, H, W, Ci, act, Wk, Co, bias, residual, Y, bm, epi, 0, stream);
+}
+
+extern "C" int dpp_conv3x3_bf16(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
+                                const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream) {
+    return conv3x3_launch(X, N, H, W, Ci, act, Wk, Co, bias, residual, Y, bm, epi, 1, stream);
 }
 
 extern "C" int dpp_conv3x3_wtrans(const float* Wk, int Co, int Ci, float* Wd, dpp_stream_t stream) {

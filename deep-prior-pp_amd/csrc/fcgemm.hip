@@ -1,0 +1,300 @@
+// fcgemm.hip -- the weight-streaming GEMMs of the HiddenLayer that follows the last convolution map (FC1: 16 384 x 1 024 at
+// 128x128 input, 65 536 x 1 024 at 256x256), in two precisions: exact f32 (v_mfma_f32_16x16x4_f32) and bf16 operands with
+// f32 accumulation (v_mfma_f32_16x16x32_bf16, BASELINE config 5).
+//
+// Reference arithmetic: HiddenLayer x.W + b, /root/reference/src/net/hiddenlayer.py:136-139, and its T.grad
+// (/root/reference/src/trainer/poseregnettrainer.py:110-111): forward C = X.W, data gradient dX = dY.W^T, weight gradient
+// dW = X^T.dY -- 4.3 GFLOP each at batch 128 over a 67 MB weight matrix.
+//
+// Same contract as dpp_gemm (same descriptor, layouts, prologue, bias, split-K partials); what differs is the machinery:
+//   * BOTH operands sit in LDS K-contiguous ([row][chunk]): an operand that is MN-contiguous in memory (W in the forward pass,
+//     both operands of the weight gradient) is transposed on its way into LDS -- a thread loads 4 (f32) or 8 (bf16) k-rows of
+//     a 4-wide column quad and writes four 16-byte k-runs -- so every fragment read is ONE ds_read_b128 (dpp_gemm reads such
+//     operands 4 bytes at a time);
+//   * the LDS image is double-buffered: chunk c+1 is written while other waves still multiply chunk c, one barrier per chunk;
+//   * bf16: operands are rounded (RNE) after the prologue when they are written to LDS, halving LDS bytes per flop twice over
+//     (half the bytes, 8 k per read); the matrix pipe is 16x faster, so these GEMMs become pure HBM streams.
+// Tile: 128 x 64 per workgroup (4 waves stacked along M, each 32 x 64 = 2 x 4 MFMA tiles), K chunks of 64.
+#include "dpp_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int PREC> struct Prec;
+template <> struct Prec<0> {                     // f32
+    typedef float elem;
+    static constexpr int EPT = 4;                // elements per 16-byte LDS run
+    static constexpr int PAD = 4;                // row padding (elements): 16 rows x 16 B land on distinct bank quads
+};
+template <> struct Prec<1> {                     // bf16
+    typedef __bf16 elem;
+    static constexpr int EPT = 8;
+    static constexpr int PAD = 8;
+};
+
+struct FcArgs {
+    dpp_gemm_desc d;
+    int vecA, vecB;
+    int Kper;
+};
+
+__device__ __forceinline__ float4 fc_load4(const float* p, int idx0, int limit, bool vec) {
+    if (vec && idx0 + 3 < limit) return *reinterpret_cast<const float4*>(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx0 + 0 < limit) v.x = p[0];
+    if (idx0 + 1 < limit) v.y = p[1];
+    if (idx0 + 2 < limit) v.z = p[2];
+    if (idx0 + 3 < limit) v.w = p[3];
+    return v;
+}
+
+__device__ __forceinline__ float4 fc_act4(float4 v, const dpp_act& a, int c0, int limit) {
+    if (a.mode == 0) return v;
+    if ((a.cmod & 3) == 0 && c0 + 3 < limit) return dpp_act4(v, a, c0 % a.cmod);
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 + 0 < limit) o.x = dpp_act1(v.x, a, (c0 + 0) % a.cmod);
+    if (c0 + 1 < limit) o.y = dpp_act1(v.y, a, (c0 + 1) % a.cmod);
+    if (c0 + 2 < limit) o.z = dpp_act1(v.z, a, (c0 + 2) % a.cmod);
+    if (c0 + 3 < limit) o.w = dpp_act1(v.w, a, (c0 + 3) % a.cmod);
+    return o;
+}
+
+// 16-byte k-run stores into the LDS image
+__device__ __forceinline__ void fc_store_run(float* dst, const float (&v)[4]) { *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void fc_store_run(__bf16* dst, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x8*>(dst) = o;
+}
+
+// Staging of one operand tile of ROWS (m or n) x KC (k) into its K-contiguous LDS image.
+//   KCONT = true : memory is [row][k]   -> slot = (row, k-run): EPT/4 float4 loads, one 16-byte store
+//   KCONT = false: memory is [k][row]   -> slot = (k-run, row quad): EPT float4 loads (one per k), four 16-byte stores
+template <int PREC, int ROWS, int KC, bool KCONT>
+struct Stage {
+    typedef typename Prec<PREC>::elem elem;
+    static constexpr int EPT = Prec<PREC>::EPT;
+    static constexpr int LD = KC + Prec<PREC>::PAD;
+    static constexpr int NSLOT = KCONT ? ROWS * (KC / EPT) : (KC / EPT) * (ROWS / 4);
+    static constexpr int SLOTS = (NSLOT + DPP_THREADS - 1) / DPP_THREADS;
+    static constexpr int NLD = KCONT ? EPT / 4 : EPT;            // float4 loads per slot
+    float4 r[SLOTS][NLD];
+
+    // base: operand pointer; ld: leading dimension; map: row map of the NON-contiguous index; r0: first row (m / n) of the tile;
+    // rlim: number of rows of the problem; kc .. k_end: the chunk; act: prologue (channel = contiguous index % cmod)
+    __device__ __forceinline__ void fetch(const float* base, int ld, const dpp_rowmap& map, int r0, int rlim, int kc, int k_end,
+                                          const dpp_act& act, bool vec) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int slot = tid + s * DPP_THREADS;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) r[s][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (slot >= NSLOT) continue;
+            if (KCONT) {
+                const int row = r0 + slot / (KC / EPT), k = kc + (slot % (KC / EPT)) * EPT;
+                if (row < rlim) {
+                    const float* p = base + (size_t)dpp_map_row(map, row) * ld + k;
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j)
+                        if (k + 4 * j < k_end) r[s][j] = fc_act4(fc_load4(p + 4 * j, k + 4 * j, k_end, vec), act, k + 4 * j, k_end);
+                }
+            } else {
+                const int q = slot % (ROWS / 4), kr = slot / (ROWS / 4);
+                const int row = r0 + q * 4, k = kc + kr * EPT;
+                if (row < rlim) {
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j)
+                        if (k + j < k_end)
+                            r[s][j] = fc_act4(fc_load4(base + (size_t)dpp_map_row(map, k + j) * ld + row, row, rlim, vec), act, row, rlim);
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void commit(elem* img) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int slot = tid + s * DPP_THREADS;
+            if (slot >= NSLOT) continue;
+            if (KCONT) {
+                const int row = slot / (KC / EPT), k = (slot % (KC / EPT)) * EPT;
+                float v[EPT];
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) { v[4 * j] = r[s][j].x; v[4 * j + 1] = r[s][j].y; v[4 * j + 2] = r[s][j].z; v[4 * j + 3] = r[s][j].w; }
+                fc_store_run(img + row * LD + k, v);
+            } else {
+                const int q = slot % (ROWS / 4), kr = slot / (ROWS / 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v[EPT];
+#pragma unroll
+                    for (int j = 0; j < EPT; ++j) v[j] = dpp_f4_get(r[s][j], e);
+                    fc_store_run(img + (q * 4 + e) * LD + kr * EPT, v);
+                }
+            }
+        }
+    }
+};
+
+template <int PREC, int RM, int CN, int KC, bool AKC, bool BKC>
+__global__ __launch_bounds__(DPP_THREADS) void fc_gemm_kernel(FcArgs ga) {
+    const dpp_gemm_desc& d = ga.d;
+    typedef typename Prec<PREC>::elem elem;
+    constexpr int EPT = Prec<PREC>::EPT;
+    constexpr int BM = 64 * RM, BN = 16 * CN;
+    typedef Stage<PREC, BM, KC, AKC> SA;
+    typedef Stage<PREC, BN, KC, BKC> SB;
+    constexpr int LD = KC + Prec<PREC>::PAD;
+    constexpr int SZA = BM * LD, SZB = BN * LD;                                  // elements per buffer
+    constexpr int OPB = 2 * (SZA + SZB) * (int)sizeof(elem);                     // both buffers, bytes
+    constexpr int EPB = (BM * (BN + 4) + 16 * BN) * 4;                           // wide epilogue image, bytes
+    HIP_DYNAMIC_SHARED(float4, smem4)
+    static_assert(OPB % 16 == 0, "buffer alignment");
+    elem* const img = reinterpret_cast<elem*>(smem4);
+    (void)EPB;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+    const int M = d.M, N = d.N;
+    const int k_begin = blockIdx.z * ga.Kper;
+    const int k_end = (k_begin + ga.Kper < d.K) ? (k_begin + ga.Kper) : d.K;
+    const int nchunks = (k_end > k_begin) ? (k_end - k_begin + KC - 1) / KC : 0;
+
+    f32x4 acc[RM][CN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dpp_wide_coef wco;
+    wco.load<BN>(col0, N, d.splitk == 1 ? d.bias : nullptr, d.epi);
+
+    SA sa;
+    SB sb;
+    const dpp_rowmap ident = {1, 0, 0, 0, 0};
+    auto fetch = [&](int c) {
+        const int kc = k_begin + c * KC;
+        sa.fetch(d.A, d.lda, d.mapA, row0, M, kc, k_end, d.actA, ga.vecA);
+        sb.fetch(d.B, d.ldb, BKC ? ident : d.mapB, col0, N, kc, k_end, d.actB, ga.vecB);
+    };
+    if (nchunks > 0) fetch(0);
+    for (int c = 0; c < nchunks; ++c) {
+        elem* As = img + (c & 1) * (SZA + SZB);
+        elem* Bs = As + SZA;
+        sa.commit(As);
+        sb.commit(Bs);
+        if (c + 1 < nchunks) fetch(c + 1);            // in flight under this chunk's MFMAs
+        __syncthreads();
+#pragma unroll
+        for (int k0 = 0; k0 < KC; k0 += 4 * EPT) {    // one 16-byte run per lane covers k0 + kq*EPT .. + EPT-1
+            if constexpr (PREC == 0) {
+                float af[RM][4], bf[CN][4];
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt) {
+                    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(As) + (wave * (BM / 4) + rt * 16 + l15) * LD + k0 + kq * 4);
+                    af[rt][0] = v.x; af[rt][1] = v.y; af[rt][2] = v.z; af[rt][3] = v.w;
+                }
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Bs) + (ct * 16 + l15) * LD + k0 + kq * 4);
+                    bf[ct][0] = v.x; bf[ct][1] = v.y; bf[ct][2] = v.z; bf[ct][3] = v.w;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < CN; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][t], bf[ct][t], acc[rt][ct], 0, 0, 0);
+            } else {
+                bf16x8 af[RM], bf[CN];
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt)
+                    af[rt] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(As) + (wave * (BM / 4) + rt * 16 + l15) * LD + k0 + kq * 8);
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct)
+                    bf[ct] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(Bs) + (ct * 16 + l15) * LD + k0 + kq * 8);
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CN; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // the operand images are dead: the epilogue reuses the memory
+
+    const int nvalid = (M - row0 < BM) ? (M - row0) : BM;
+    float* smem = reinterpret_cast<float*>(smem4);
+    if (d.splitk > 1) {
+        dpp_epilogue ep0 = {};
+        float* P = d.partial + (size_t)blockIdx.z * M * N;
+        dpp_epilogue_wide<RM, CN, 4, 1, BM, BN>(acc, smem, col0, N, wco, nullptr, P, ep0, nvalid, wave, 0, l15, kq, [&](int rl) {
+            const int row = row0 + rl;
+            return row < M ? (long)row * N : -1L;
+        });
+    } else {
+        dpp_epilogue_wide<RM, CN, 4, 1, BM, BN>(acc, smem, col0, N, wco, d.residual, d.C, d.epi, nvalid, wave, 0, l15, kq, [&](int rl) {
+            const int row = row0 + rl;
+            return row < M ? (long)dpp_map_row(d.mapC, row) * d.ldc : -1L;
+        });
+    }
+}
+
+template <int PREC, int RM, int CN, int KC, bool AKC, bool BKC>
+int fc_launch(const FcArgs& ga, dim3 grid, hipStream_t st) {
+    typedef typename Prec<PREC>::elem elem;
+    constexpr int BM = 64 * RM, BN = 16 * CN, LD = KC + Prec<PREC>::PAD;
+    constexpr size_t opb = 2 * (size_t)(BM + BN) * LD * sizeof(elem);
+    constexpr size_t epb = ((size_t)BM * (BN + 4) + 16 * BN) * 4;
+    const size_t lds = opb > epb ? opb : epb;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_gemm_kernel<PREC, RM, CN, KC, AKC, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DPP_LAUNCH((fc_gemm_kernel<PREC, RM, CN, KC, AKC, BKC>), grid, dim3(DPP_THREADS), lds, st, ga);
+    return dpp_launch_status();
+}
+
+template <int PREC, int KC>
+int fc_dispatch(const FcArgs& ga, dim3 grid, hipStream_t st) {
+    const dpp_gemm_desc& d = ga.d;
+    if (d.a_kc && d.b_kc) return fc_launch<PREC, 2, 4, KC, true, true>(ga, grid, st);
+    if (d.a_kc && !d.b_kc) return fc_launch<PREC, 2, 4, KC, true, false>(ga, grid, st);
+    if (!d.a_kc && !d.b_kc) return fc_launch<PREC, 2, 4, KC, false, false>(ga, grid, st);
+    return fc_launch<PREC, 2, 4, KC, false, true>(ga, grid, st);
+}
+
+}  // namespace
+
+// dpp_fc_gemm: dpp_gemm's contract (same descriptor) on the weight-streaming kernel above.  precision: 0 = f32 (exact, the
+// result equals dpp_gemm's up to summation order), 1 = bf16 operands / f32 accumulation.  Tile 128 x 64, d.bm / d.bn / d.wm /
+// d.variant are ignored; kchunk = 32 or 64 (0 = 64).  Supported: actA / actB modes 0-3, bias, residual, mapA / mapB / mapC,
+// split-K partials; the fused statistics / BatchNorm-backward epilogues of dpp_gemm are not (the FC layers have no BatchNorm).
+extern "C" int dpp_fc_gemm(const dpp_gemm_desc* dp, int precision, int kchunk, dpp_stream_t stream) {
+    if (!dp) return DPP_E_BADARG;
+    const dpp_gemm_desc& d = *dp;
+    if (!d.A || !d.B || d.M < 1 || d.N < 1 || d.K < 1 || d.splitk < 1) return DPP_E_BADARG;
+    if (d.splitk > 1 ? !d.partial : !d.C) return DPP_E_BADARG;
+    if (precision != 0 && precision != 1) return DPP_E_BADARG;
+    if (d.actA.mode > 3 || d.actB.mode > 3 || d.epi.stats || d.epi.bn_x) return DPP_E_UNSUPPORTED;
+    if (d.N % 4) return DPP_E_UNSUPPORTED;                                  // the 16-byte epilogue
+    const int ldc = d.splitk > 1 ? d.N : d.ldc;
+    if (ldc % 4 || (reinterpret_cast<uintptr_t>(d.splitk > 1 ? d.partial : d.C) & 15)) return DPP_E_UNSUPPORTED;
+    if (d.residual && (reinterpret_cast<uintptr_t>(d.residual) & 15)) return DPP_E_UNSUPPORTED;
+    const int KC = kchunk == 0 ? 64 : kchunk;
+    if (KC != 32 && KC != 64) return DPP_E_BADARG;
+    FcArgs ga;
+    ga.d = d;
+    auto aligned = [](const float* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; };
+    ga.vecA = aligned(d.A, d.lda);
+    ga.vecB = aligned(d.B, d.ldb);
+    int per = (d.K + d.splitk - 1) / d.splitk;
+    per = (per + KC - 1) / KC * KC;
+    ga.Kper = per;
+    dim3 grid(dpp_cdiv(d.M, 128), dpp_cdiv(d.N, 64), d.splitk);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (precision == 0) return KC == 64 ? fc_dispatch<0, 64>(ga, grid, st) : fc_dispatch<0, 32>(ga, grid, st);
+    return KC == 64 ? fc_dispatch<1, 64>(ga, grid, st) : fc_dispatch<1, 32>(ga, grid, st);
+}

@@ -275,6 +275,18 @@ EARLY_BUCKET_MIN = int(os.environ.get('DPP_EARLY_BUCKET_MIN', str(1 << 22)))    
 #   2: only the data gradient does, and it leaves the dX it forms in memory for the filter gradient (dpp_act.out), which
 #      then starts after it instead of beside it.
 LAZY_BN_BWD = int(os.environ.get('DPP_LAZY_BN_BWD', '0'))
+BF16_DEFAULT = os.environ.get('DPP_BF16', '0') == '1'
+# FC1 (the HiddenLayer behind the last conv map) on the weight-streaming kernel dpp_fc_gemm (K-contiguous double-buffered LDS
+# images, f32 or bf16) instead of the generic dpp_gemm
+FC1_STREAM = os.environ.get('DPP_FC1_STREAM', '1') != '0'
+FC1_KCHUNK = int(os.environ.get('DPP_FC1_KCHUNK', '0'))
+FC1_SLICES = int(os.environ.get('DPP_FC1_SLICES', '32'))
+FC1_MIN_K = int(os.environ.get('DPP_FC1_MIN_K', '4096'))
+
+
+def is_fc1_shape(Nb, K, Nout):
+    """The weight-streaming shape: tens of MB of weights for at most a few hundred rows."""
+    return K >= FC1_MIN_K and Nout >= 64 and Nout % 4 == 0 and K % 4 == 0
 ROWSTREAM = os.environ.get('DPP_ROWSTREAM', '0') != '0'      # measured: no gain over the LDS-tiled kernel yet
 
 
@@ -320,14 +332,19 @@ def wgrad_plan(Co, Ci, K):
 
 
 class CompiledNet(object):
-    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None, fuse_bn=True):
+    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None, fuse_bn=True, bf16=None):
         """
+        :param bf16:  True -> the 3x3 convolutions (forward, data gradient) and the HiddenLayer behind the last conv map (FC1:
+                      forward, data and weight gradient) round their operands to bf16 and accumulate in f32 on the bf16 matrix
+                      pipe (BASELINE config 5).  Opt-in (default: DPP_BF16=1 in the environment): the f32 path is the one that
+                      meets the 1e-3 mm bar.
         :param train: True -> BatchNorm uses batch statistics (and updates the running ones), dropout uses masks,
                       and the loss / backward / ADAM plans are built; False -> deterministic forward only.
         :param loss:  None, or dict(kind='embedding'|'joints', numJoints=, nDims=) -- the cost of
                       poseregnettrainer.py:92-99; also available in eval mode (validation cost / error).
         """
         self.rt = rt = runtime or default_runtime()
+        self.prec = int(bool(BF16_DEFAULT if bf16 is None else bf16))
         self.dp = dp                                  # hipdp.parallel.DataParallel or None
         # BatchNorm statistics / backward sums produced by the conv epilogues (off with sync-BN, whose partials are
         # all-gathered by row block, and for tests that want the stand-alone BatchNorm kernels)
@@ -677,7 +694,7 @@ class CompiledNet(object):
                     out.stats = (rt.alloc((nblk, 2, Co), zero=False), nblk, bm)
                     epi = ops.epilogue(stats=out.stats[0])
             self.fwd.add(ops.conv3x3(rt, src.base.buf, N, Hi, Wi, Ci, st.view(layer.W), Co, out.buf, actX=act, bias=st.view(layer.b),
-                                     residual=res, bm=bm, epi=epi, name='conv3x3_%d' % layer.layerNum))
+                                     residual=res, bm=bm, epi=epi, name='conv3x3_%d' % layer.layerNum, precision=self.prec))
         self.layer_io[id(layer)] = dict(in_view=src, out=out, residual=residual)
         return View(out)
 
@@ -690,6 +707,15 @@ class CompiledNet(object):
         assert K == c.inputDim[1], (K, c.inputDim)
         out = self._new_tensor((Nb, Nout), 'fc%d' % layer.layerNum)
         rt, st = self.rt, self.store
+        act = self._act(src)
+        if FC1_STREAM and is_fc1_shape(Nb, K, Nout):
+            splitk = max(1, min(FC1_SLICES, K // 512))
+            part = self.scratch(splitk * Nb * Nout)
+            self.fwd.add(ops.fc_gemm(rt, src.base.buf, st.view(layer.W), None, Nb, Nout, K, 1, 0, K, Nout, Nout, actA=act, splitk=splitk,
+                                     partial=part, precision=self.prec, kchunk=FC1_KCHUNK, name='fc_%d' % layer.layerNum))
+            self.fwd.add(ops.reduce_partials(rt, part, splitk, Nb * Nout, out.buf, bias=st.view(layer.b), nbias=Nout))
+            self.layer_io[id(layer)] = dict(in_view=src, out=out)
+            return View(out)
         tile, splitk = gemm_plan(Nb, Nout, K)
         if K >= 4096 and Nb <= 128 and Nout >= 64:
             # weight-streaming shape (FC1: 67 MB of W for 128 rows): wide column tiles read W in 256 B rows, K split 512 deep
@@ -1027,7 +1053,7 @@ class CompiledNet(object):
                     tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
                     epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
                 self.bwd.add(ops.conv3x3(rt, dY, N, Hi, Wi, Co, Wd, Ci, dst, residual=dst if acc else None, bm=bmd, epi=epi,
-                                         name='dgrad3x3_%d' % layer.layerNum))
+                                         name='dgrad3x3_%d' % layer.layerNum, precision=self.prec))
                 tgt.grad_written = True
 
     def _bwd_fc(self, layer, io, src, dY):
@@ -1038,11 +1064,16 @@ class CompiledNet(object):
         act = self._act(src)
         self.bwd.fork()
         self._bias_grad(dY, Nb, Nout, gb)
-        tile, _ = gemm_plan(K, Nout, Nb, allow_split=False)
-        if K >= 4096 and Nout >= 64 and os.environ.get('DPP_FC1_TILE128', '1') != '0':
-            tile = (128, 64, 4)          # FC1: 67 MB of output, MFMA-bound (tools/gemm_micro.py fc: 107 -> 84 us)
-        self.bwd.add(ops.gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, tile=tile,
-                              name='fc_wgrad_%d' % layer.layerNum), side=True)
+        stream_kernel = FC1_STREAM and is_fc1_shape(Nb, K, Nout)
+        if stream_kernel:
+            self.bwd.add(ops.fc_gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, precision=self.prec,
+                                     kchunk=FC1_KCHUNK, name='fc_wgrad_%d' % layer.layerNum), side=True)
+        else:
+            tile, _ = gemm_plan(K, Nout, Nb, allow_split=False)
+            if K >= 4096 and Nout >= 64 and os.environ.get('DPP_FC1_TILE128', '1') != '0':
+                tile = (128, 64, 4)          # FC1: 67 MB of output, MFMA-bound (tools/gemm_micro.py fc: 107 -> 84 us)
+            self.bwd.add(ops.gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, tile=tile,
+                                  name='fc_wgrad_%d' % layer.layerNum), side=True)
         if self.dp is not None and self._early_slice is None and K * Nout >= EARLY_BUCKET_MIN and OVERLAP_ALLREDUCE:
             # data parallel: this gradient (FC1: 90 % of all parameter bytes) is final now -- start its all-reduce from the
             # side stream so that it overlaps the rest of the backward pass
@@ -1053,7 +1084,10 @@ class CompiledNet(object):
             tgt, dst = self._view_grad(src)
             acc = tgt.grad_written
             tile, splitk = gemm_plan(Nb, K, Nout, allow_split=not acc)
-            if splitk > 1:
+            if stream_kernel:
+                self.bwd.add(ops.fc_gemm(rt, dY, st.view(layer.W), dst, Nb, K, Nout, 1, 1, Nout, Nout, K, residual=dst if acc else None,
+                                         precision=self.prec, kchunk=FC1_KCHUNK, name='fc_dgrad_%d' % layer.layerNum))
+            elif splitk > 1:
                 part = self.scratch(splitk * Nb * K)
                 self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), None, Nb, K, Nout, 1, 1, Nout, Nout, K, splitk=splitk, partial=part,
                                       tile=tile, name='fc_dgrad_%d' % layer.layerNum))

@@ -59,9 +59,12 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     'dpp_abi_version': (C.c_int, []),
     'dpp_gemm': (C.c_int, [C.POINTER(GemmDesc), stream_t]),
+    'dpp_fc_gemm': (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_int, stream_t]),
     'dpp_reduce_partials': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
     'dpp_conv3x3': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Epilogue), stream_t]),
+    'dpp_conv3x3_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Epilogue), stream_t]),
     'dpp_conv3x3_tiling': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'dpp_conv3x3_wtrans': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_conv3x3_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

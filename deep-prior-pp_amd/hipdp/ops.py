@@ -236,6 +236,24 @@ def gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, mapA=None, mapB=N
     return Launch(rt.lib.dpp_gemm, (C.byref(d),), (d, A, B, Cbuf, bias, residual, partial, actA, actB, epi), name, meta)
 
 
+def fc_gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, actA=None, actB=None, bias=None, residual=None, splitk=1, partial=None,
+            precision=0, kchunk=0, name='fc_gemm'):
+    """dpp_fc_gemm: dpp_gemm's contract on the weight-streaming kernel (f32 or bf16 operands), see include/dpp_hip.h."""
+    d = GemmDesc()
+    d.A, d.lda, d.a_kc = A.ptr, lda, int(a_kc)
+    d.mapA, d.mapB, d.mapC = RowMap.identity(), RowMap.identity(), RowMap.identity()
+    d.actA = actA or Act.none()
+    d.B, d.ldb, d.b_kc = B.ptr, ldb, int(b_kc)
+    d.actB = actB or Act.none()
+    d.C, d.ldc = _p(Cbuf), ldc
+    d.bias, d.residual = _p(bias), _p(residual)
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.splitk, d.partial = int(splitk), _p(partial)
+    meta = dict(kernel='fc_gemm_mfma_bf16' if precision else 'gemm_mfma_f32', flops=2.0 * M * N * K,
+                bytes=4.0 * (M * K + K * N + M * N * (max(1, splitk) if splitk > 1 else 1) + (M * N if residual is not None else 0)))
+    return Launch(rt.lib.dpp_fc_gemm, (C.byref(d), int(precision), int(kchunk)), (d, A, B, Cbuf, bias, residual, partial, actA, actB), name, meta)
+
+
 def reduce_partials(rt, partial, nz, n, out, bias=None, nbias=1, name='reduce_partials'):
     return Launch(rt.lib.dpp_reduce_partials, (partial.ptr, int(nz), int(n), _p(bias), int(nbias), out.ptr),
                   (partial, out, bias), name, dict(kernel='reduce_partials', flops=float(nz) * n, bytes=4.0 * (nz + 1) * n))
@@ -245,11 +263,11 @@ def _actp(a):
     return C.byref(a) if a is not None else None
 
 
-def conv3x3(rt, X, N, H, W, Ci, Wk, Co, Y, actX=None, bias=None, residual=None, bm=0, epi=None, name='conv3x3'):
+def conv3x3(rt, X, N, H, W, Ci, Wk, Co, Y, actX=None, bias=None, residual=None, bm=0, epi=None, name='conv3x3', precision=0):
     px = float(N) * H * W
-    meta = dict(kernel='conv3x3_mfma_f32', flops=2.0 * px * 9 * Ci * Co,
+    meta = dict(kernel='conv3x3_mfma_bf16' if precision else 'conv3x3_mfma_f32', flops=2.0 * px * 9 * Ci * Co,
                 bytes=4.0 * (px * (Ci + Co + (Co if residual is not None else 0)) + 9 * Ci * Co))
-    return Launch(rt.lib.dpp_conv3x3, (X.ptr, N, H, W, Ci, _actp(actX), Wk.ptr, Co, _p(bias), _p(residual), Y.ptr, bm,
+    return Launch(rt.lib.dpp_conv3x3_bf16 if precision else rt.lib.dpp_conv3x3, (X.ptr, N, H, W, Ci, _actp(actX), Wk.ptr, Co, _p(bias), _p(residual), Y.ptr, bm,
                                        C.byref(epi) if epi is not None else None),
                   (X, Wk, Y, actX, bias, residual, epi), name, meta)
 

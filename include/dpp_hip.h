@@ -116,6 +116,15 @@ typedef struct {
 } dpp_gemm_desc;
 int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);
 
+/* The same contract on the weight-streaming kernel for the HiddenLayer behind the last convolution map (FC1: 16 384 x 1 024
+ * weights at 128x128 input, 65 536 x 1 024 at 256x256; hiddenlayer.py:136-139 and its T.grad): tile 128 x 64, both operands
+ * K-contiguous in LDS (memory-MN-contiguous operands are transposed while staged), double-buffered LDS.
+ * precision 0: exact f32 (v_mfma_f32_16x16x4_f32; equals dpp_gemm up to summation order).
+ * precision 1: operands rounded to bf16 (RNE, after the prologue), f32 accumulation (v_mfma_f32_16x16x32_bf16) -- BASELINE
+ *              config 5; not for the 1e-3 mm parity path.
+ * kchunk: 32 | 64 (0 = 64).  d->bm / bn / wm / variant are ignored; no fused statistics / BatchNorm-backward epilogue. */
+int dpp_fc_gemm(const dpp_gemm_desc* d, int precision, int kchunk, dpp_stream_t stream);
+
 /* out[i] = sum_z partial[z*n + i] (+ bias[i % nbias] if bias) -- fixed summation order (deterministic). */
 int dpp_reduce_partials(const float* partial, int nz, int n, const float* bias, int nbias, float* out,
                         dpp_stream_t stream);
@@ -135,6 +144,10 @@ int dpp_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, dpp_stre
  * dpp_conv3x3_wtrans.  bm = 64 | 128 rows per workgroup (0 = choose).  Ci, Co multiples of 16. */
 int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
                 const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream);
+/* The same with the activated input and the weights rounded to bf16 (RNE) as they are staged in LDS, f32 accumulation
+ * (v_mfma_f32_16x16x32_bf16): BASELINE config 5, not for the 1e-3 mm parity path.  Same tiling, epilogues and results layout. */
+int dpp_conv3x3_bf16(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
+                     const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream);
 /* tile geometry chosen for (N,H,W,bm): returns the number of workgroup row blocks, writes tile height / width / images */
 int dpp_conv3x3_tiling(int N, int H, int W, int bm, int* th, int* tw, int* img);
 /* Wd[c][8-tap][o] = Wk[o][tap][c] (mirrored taps, channels swapped): weights of the data-gradient correlation. */

@@ -276,6 +276,32 @@ static inline emu_f32x16 emu_mfma_32x32x2(float a, float b, emu_f32x16 c, int, i
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_16x16x4
+// 16x16x32 bf16: lane l holds A[i = l & 15][k = 8 * (l >> 4) + j] and B[k = 8 * (l >> 4) + j][col = l & 15], j = 0..7; the
+// products are exact in f32 and the hardware accumulates them in f32 (summation order inside one instruction is not
+// architecturally defined; k-ordered here)
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+static inline emu_f32x4 emu_mfma_16x16x32_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x4 c, int, int, int) {
+    struct { float a[8], b[8]; } in;
+    for (int j = 0; j < 8; ++j) { in.a[j] = (float)a[j]; in.b[j] = (float)b[j]; }
+    emu_f32x4 d = c;
+    emu::wave_exchange(&in, sizeof(in), [&](emu::Wave& w, int lane) {
+        int col = lane & 15;
+        for (int r = 0; r < 4; ++r) {
+            int row = (lane >> 4) * 4 + r;
+            float acc = c[r];
+            for (int g = 0; g < 4; ++g)
+                for (int j = 0; j < 8; ++j) {
+                    float av, bv;
+                    memcpy(&av, w.buf[row + 16 * g] + 4 * j, 4);
+                    memcpy(&bv, w.buf[col + 16 * g] + 32 + 4 * j, 4);
+                    acc = fmaf(av, bv, acc);
+                }
+            d[r] = acc;
+        }
+    });
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 emu_mfma_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_32x32x2
 
 // ---- atomics / misc device functions ------------------------------------------------------------

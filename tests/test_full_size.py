@@ -17,7 +17,7 @@ from oracle import nets, torch_ref
 from tests import gemm_cases
 from tests.backends import get_runtime
 from tests.pinning import device_masks
-from tests.test_engine import MM, bad_gradients, grads_from_store, make_net
+from tests.test_engine import MM, bad_gradients, grads_from_store, make_net, zero_gradient_bounds
 
 pytestmark = pytest.mark.gpu
 
@@ -49,7 +49,7 @@ def _gradients_vs_pinned_oracle(B, seed):
     assert np.abs(out - out_ref).max() * MM < 1e-3
     assert abs(cost - c_ref) < 1e-5 * abs(c_ref)
     G = grads_from_store(eng, net)
-    bad = bad_gradients(G, G_ref)                              # 2e-4 of each tensor's scale
+    bad = bad_gradients(G, G_ref, zero_tol=zero_gradient_bounds(eng, net, onet, G_ref))       # 2e-4 of each tensor's scale
     assert not bad, [(i, s, float(np.abs(G[i][s] - G_ref[i][s]).max() / np.abs(G_ref[i][s]).max())) for i, s in bad[:6]]
     return eng
 

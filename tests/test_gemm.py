@@ -206,3 +206,55 @@ def test_every_gemm_instantiation_of_a_small_resnet(backend):
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
     checked, skipped = gemm_cases.check_all(rt, eng)
     assert len(checked) >= 15, (len(checked), len(skipped))
+
+
+def _bf16_round(a):
+    """Round-to-nearest-even to bfloat16, returned as float32 (what the kernel does when it writes an operand to LDS)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('precision', [0, 1])
+@pytest.mark.parametrize('layout', ['fwd', 'dgrad', 'wgrad', 'tn'])
+def test_fc_gemm_layouts_and_precisions(backend, precision, layout):
+    """dpp_fc_gemm (the FC1 weight-streaming kernel): the three layouts FC1 runs in (forward: A K-contiguous, W [K][N];
+    data gradient: both K-contiguous; weight gradient: both MN-contiguous, transposed on the way into LDS) plus the fourth
+    combination, ragged M / N / K, split-K partials, BN+ReLU prologue on A, bias and residual -- f32 against float64, bf16
+    against float64 on bf16-rounded operands (f32 accumulation: the same tolerance)."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(17 + precision)
+    a_kc, b_kc = {'fwd': (1, 0), 'dgrad': (1, 1), 'wgrad': (0, 0), 'tn': (0, 1)}[layout]
+    for (M, N, K, splitk, kchunk, feats) in ((40, 72, 200, 1, 0, 'act+bias+res'), (128, 64, 192, 3, 32, ''), (200, 132, 96, 1, 32, 'relu'),
+                                             (16, 8, 64, 2, 0, 'act')):
+        A = rng.normal(0, 1, (M, K) if a_kc else (K, M)).astype(np.float32)
+        Bm = rng.normal(0, 1, (N, K) if b_kc else (K, N)).astype(np.float32)
+        cmod = (K if a_kc else M)
+        actA, Aact = None, A.astype(np.float64)
+        if 'act' in feats and cmod % 4 == 0:
+            mean, scale, beta = (rng.normal(0, 0.3, cmod).astype(np.float32), rng.uniform(0.5, 1.5, cmod).astype(np.float32),
+                                 rng.normal(0, 0.3, cmod).astype(np.float32))
+            actA = ops.act(Act.BN_RELU, rt.upload(mean), rt.upload(scale), rt.upload(beta), cmod)
+            Aact = np.maximum(((A - mean) * scale + beta).astype(np.float32), 0).astype(np.float64)
+        elif 'relu' in feats:
+            actA = ops.act(Act.RELU, None, None, None, cmod)
+            Aact = np.maximum(A, 0).astype(np.float64)
+        Bq = Bm.astype(np.float64)
+        if precision == 1:
+            Aact, Bq = _bf16_round(Aact.astype(np.float32)).astype(np.float64), _bf16_round(Bm).astype(np.float64)
+        ref = (Aact if a_kc else Aact.T) @ (Bq.T if b_kc else Bq)
+        bias = rng.normal(0, 1, N).astype(np.float32) if 'bias' in feats and splitk == 1 else None
+        res = rng.normal(0, 1, (M, N)).astype(np.float32) if 'res' in feats and splitk == 1 else None
+        Cb = rt.alloc((M, N), zero=False)
+        if res is not None:
+            Cb.set(res)
+        part = rt.alloc(splitk * M * N, zero=False) if splitk > 1 else None
+        ops.fc_gemm(rt, rt.upload(A), rt.upload(Bm), Cb if splitk == 1 else None, M, N, K, a_kc, b_kc, K if a_kc else M, K if b_kc else N, N,
+                    actA=actA, bias=rt.upload(bias) if bias is not None else None, residual=Cb if res is not None else None, splitk=splitk,
+                    partial=part, precision=precision, kchunk=kchunk)(rt.stream)
+        rt.synchronize()
+        got = part.get().reshape(splitk, M, N).astype(np.float64).sum(axis=0) if splitk > 1 else Cb.get().astype(np.float64)
+        want = ref + (bias if bias is not None else 0) + (res if res is not None else 0)
+        tol = 6e-7 * (np.sqrt(K) + 4) * max(1.0, float(np.abs(Aact).max()) * float(np.abs(Bq).max()))
+        assert np.abs(got - want).max() < tol, (layout, precision, (M, N, K, splitk), np.abs(got - want).max(), tol)

@@ -450,3 +450,49 @@ def test_gemm_operand_through_batchnorm_backward(backend, a_kc):
         ref = dX.T @ Y.astype('f8')
     rt.synchronize()
     np.testing.assert_allclose(out.get(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+
+
+def _bf16(a):
+    """Round-to-nearest-even to bfloat16 (returned as float64): what the bf16 kernels do to an operand when they stage it."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 64, 64, 64), (3, 16, 16, 16, 16, 64), (2, 12, 20, 32, 32, 128), (1, 8, 8, 64, 32, 64)])
+def test_conv3x3_bf16_operands(backend, cfg):
+    """dpp_conv3x3_bf16 (BASELINE config 5): forward with the BN+ReLU prologue, bias and residual, and the data gradient, against
+    the float64 convolution of the bf16-ROUNDED activated input and weights -- the rounding is the whole difference to the f32
+    kernel, accumulation stays f32, so the f32 tolerance applies; the 16-channel case zero-fills half of each 32-deep MFMA step."""
+    rt = get_runtime(backend)
+    N, H, W, Ci, Co, bm = cfg
+    rng = np.random.RandomState(13)
+    x = rng.normal(size=(N, Ci, H, W))
+    Wr = rng.normal(size=(Co, Ci, 3, 3)) * 0.2
+    b = rng.normal(size=Co)
+    mean, scale, beta = rng.normal(size=Ci) * 0.3, rng.uniform(0.5, 1.5, Ci), rng.normal(size=Ci) * 0.3
+    res = rng.normal(size=(N, Co, H, W))
+    d = up(rt, X=layout.nchw_to_nhwc(x), Wk=layout.conv_w_to_kernel(Wr), b=b, mean=mean, scale=scale, beta=beta, res=layout.nchw_to_nhwc(res))
+    f = np.float32
+    a32 = np.maximum((x.astype(f) - mean.astype(f)[None, :, None, None]) * scale.astype(f)[None, :, None, None] + beta.astype(f)[None, :, None, None], 0)
+    y_ref = L.conv2d_fwd(_bf16(a32), _bf16(Wr), b.astype(f).astype('f8'), (1, 1), 'half') + res.astype(f)
+    act = ops.act(Act.BN_RELU, d['mean'], d['scale'], d['beta'], Ci)
+    Y = rt.alloc((N, H, W, Co), zero=False)
+    ops.conv3x3(rt, d['X'], N, H, W, Ci, d['Wk'], Co, Y, actX=act, bias=d['b'], residual=d['res'], bm=bm, precision=1)(rt.stream)
+    rt.synchronize()
+    got = layout.nhwc_to_nchw(Y.get())
+    np.testing.assert_allclose(got, y_ref, rtol=0, atol=3e-6 * np.sqrt(9 * Ci) * np.abs(y_ref).max())
+    # and it IS a different result from the exact f32 kernel (the rounding is visible, ~2^-9 relative)
+    y32 = L.conv2d_fwd(a32.astype('f8'), Wr.astype(f).astype('f8'), b.astype(f).astype('f8'), (1, 1), 'half') + res.astype(f)
+    rel = np.abs(got - y32).max() / np.abs(y32).max()
+    assert 1e-5 < rel < 2e-2, rel
+    dy = rng.normal(size=(N, Co, H, W))
+    da_ref, _, _ = L.conv2d_bwd(np.zeros((N, Ci, H, W)), _bf16(Wr), _bf16(dy), (1, 1), 'half')
+    dYb = rt.upload(layout.nchw_to_nhwc(dy).astype(np.float32))
+    Wd = rt.alloc((Ci, 9, Co), zero=False)
+    dA = rt.alloc((N, H, W, Ci), zero=False)
+    ops.conv3x3_wtrans(rt, d['Wk'], Co, Ci, Wd)(rt.stream)
+    ops.conv3x3(rt, dYb, N, H, W, Co, Wd, Ci, dA, bm=bm, precision=1)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_allclose(layout.nhwc_to_nchw(dA.get()), da_ref, rtol=0, atol=3e-6 * np.sqrt(9 * Co) * np.abs(da_ref).max())

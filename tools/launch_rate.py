@@ -35,15 +35,25 @@ def worker(mode, steps, batch):
     for _ in range(5):
         eng.run_step_plans()
     torch.cuda.synchronize()
+    # (a) one step issued into an EMPTY queue (synchronised before): the host's own cost per launch, nothing throttles it
+    t_one = []
+    for _ in range(10):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.run_step_plans()
+        t_one.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    t_one = sorted(t_one)[len(t_one) // 2]
+    # (b) many steps back to back: once the queue is full the issuing loop runs at the GPU's pace
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.run_step_plans()
     t_issue = time.perf_counter() - t0
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
-    print('%-8s side_stream=%d  launches/step %d  host %.2f us/launch (issue loop %.3f ms/step)  GPU %.3f ms/step  -> %s' % (
-        mode, int(rt.has_side_stream), n, t_issue / steps / n * 1e6, t_issue / steps * 1e3, t_all / steps * 1e3,
-        'host-bound' if t_issue > 0.9 * t_all else 'GPU-bound'))
+    print('%-8s side_stream=%d  launches/step %d  host %.2f us/launch into an empty queue (%.3f ms/step), %.2f us/launch saturated  '
+          'GPU %.3f ms/step  -> %s' % (mode, int(rt.has_side_stream), n, t_one / n * 1e6, t_one * 1e3, t_issue / steps / n * 1e6,
+                                        t_all / steps * 1e3, 'host-bound' if t_one > 0.9 * t_all / steps else 'GPU-bound'))
     sys.stdout.flush()
 
 
