@@ -126,6 +126,12 @@ class DepthImporter(object):
                                        side, {}))
         return data
 
+    def _crop_stream(self, config, docom, side, chunk=256):
+        """Incremental form of _crop_records: frames are cropped (on the device) as soon as `chunk` of them have been read and
+        only the 128x128 crops are kept, like the reference, which crops frame by frame (importers.py:382-396) -- the raw
+        640x480 frames of NYU's 72 757-frame training sequence would need 89 GB of host memory."""
+        return _CropStream(self, config, docom, side, chunk)
+
     @staticmethod
     def _has_content(dpt, tol=1.):
         """HandDetector.checkImage on the detector-preprocessed frame (handdetector.py:53-68, 110-120)."""
@@ -140,6 +146,30 @@ class DepthImporter(object):
             print("Shuffling")
             rng.shuffle(data)
         return NamedImgSequence(seqName, data, config)
+
+
+class _CropStream(object):
+    def __init__(self, importer, config, docom, side, chunk):
+        self.imp, self.config, self.docom, self.side, self.chunk = importer, config, docom, side, int(chunk)
+        self.pending, self.data, self.count = [], [], 0
+
+    def __len__(self):
+        return self.count
+
+    def append(self, record):
+        self.pending.append(record)
+        self.count += 1
+        if len(self.pending) >= self.chunk:
+            self._flush()
+
+    def _flush(self):
+        if self.pending:
+            self.data.extend(self.imp._crop_records(self.pending, self.config, self.docom, self.side, chunk=self.chunk))
+            self.pending = []
+
+    def finish(self):
+        self._flush()
+        return self.data
 
 
 class ICVLImporter(DepthImporter):
@@ -176,7 +206,7 @@ class ICVLImporter(DepthImporter):
         if self.hand is not None and self.hand != self.sides[seqName]:
             raise NotImplementedError()
         objdir = '{}/Depth/'.format(self.basepath)
-        records = []
+        records = self._crop_stream(config, docom, self.sides[seqName])
         with open('{}/{}.txt'.format(self.basepath, seqName)) as inputfile:
             for line in inputfile:
                 if len(records) >= Nmax:
@@ -204,7 +234,7 @@ class ICVLImporter(DepthImporter):
                     continue
                 records.append((dpt, gtorig, gt3Dorig, dptFileName, subSeqName))
         print("Loaded {} samples.".format(len(records)))
-        data = self._crop_records(records, config, docom, self.sides[seqName])
+        data = records.finish()
         return self._finish(seqName, data, config, cache, shuffle, rng)
 
 
@@ -248,7 +278,7 @@ class MSRA15Importer(DepthImporter):
             return cached
         objdir = '{}/{}/'.format(self.basepath, seqName)
         subdirs = sorted([name for name in os.listdir(objdir) if os.path.isdir(os.path.join(objdir, name))])
-        records = []
+        records = self._crop_stream(config, docom, self.sides[seqName])
         for subdir in subdirs:
             subSeqName = ''
             if subSeq is not None:
@@ -283,7 +313,7 @@ class MSRA15Importer(DepthImporter):
                         continue
                     records.append((dpt, gtorig, gt3Dorig, dptFileName, subSeqName))
         print("Loaded {} samples.".format(len(records)))
-        data = self._crop_records(records, config, docom, self.sides[seqName])
+        data = records.finish()
         return self._finish(seqName, data, config, cache, shuffle, rng)
 
 
@@ -335,7 +365,7 @@ class NYUImporter(DepthImporter):
         joints2D = mat['joint_uvd'][0]
         eval_idxs = np.arange(36) if self.allJoints else np.asarray(self.restrictedJointsEval)
         self.numJoints = len(eval_idxs)
-        records = []
+        records = self._crop_stream(config, docom, self.sides[seqName])
         for line in range(joints3D.shape[0]):
             if len(records) >= Nmax:
                 break
@@ -351,5 +381,5 @@ class NYUImporter(DepthImporter):
                 continue
             records.append((dpt, gtorig, gt3Dorig, dptFileName, ''))
         print("Loaded {} samples.".format(len(records)))
-        data = self._crop_records(records, config, docom, self.sides[seqName])
+        data = records.finish()
         return self._finish(seqName, data, config, cache, shuffle, rng)

@@ -278,7 +278,10 @@ LAZY_BN_BWD = int(os.environ.get('DPP_LAZY_BN_BWD', '0'))
 BF16_DEFAULT = os.environ.get('DPP_BF16', '0') == '1'
 # FC1 (the HiddenLayer behind the last conv map) on the weight-streaming kernel dpp_fc_gemm (K-contiguous double-buffered LDS
 # images, f32 or bf16) instead of the generic dpp_gemm
-FC1_STREAM = os.environ.get('DPP_FC1_STREAM', '1') != '0'
+# Measured (profiles/r02_fc1_kernels.txt): in f32 the streaming kernel only ties with dpp_gemm (both are bound by the f32 MFMA
+# issue pattern, not by operand traffic), so it is the default for bf16 only -- where dpp_gemm has no counterpart.
+#   DPP_FC1_STREAM=1: also in f32, =0: never (bf16 FC1 then falls back to f32 dpp_gemm)
+FC1_STREAM = os.environ.get('DPP_FC1_STREAM', 'bf16')
 FC1_KCHUNK = int(os.environ.get('DPP_FC1_KCHUNK', '0'))
 FC1_SLICES = int(os.environ.get('DPP_FC1_SLICES', '32'))
 FC1_MIN_K = int(os.environ.get('DPP_FC1_MIN_K', '4096'))
@@ -398,9 +401,11 @@ class CompiledNet(object):
             if self.weight_decay and not net.hasDropout():
                 # cost += weightreg_factor * sum(W^2) over the conv / FC weights, only for nets without dropout
                 # (poseregnettrainer.py:101-107); the kernel-layout W holds the same values in another order
+                # (data parallel: every rank's cost is its share of the global cost, so each adds 1/world of the regulariser)
+                share = self.weight_decay / (dp.world if (dp is not None and train) else 1)
                 for l in self.layers:
                     if hasattr(l, 'W'):
-                        self.lossplan.add(ops.sumsq(rt, self.store.view(l.W), int(np.prod(l.W.shape)), self.weight_decay, self.cost, 1))
+                        self.lossplan.add(ops.sumsq(rt, self.store.view(l.W), int(np.prod(l.W.shape)), share, self.cost, 1))
             if not train:
                 d = loss['nDims'] if loss.get('kind', 'embedding') != 'embedding' else self.out_dim
                 rows = self.N * (loss['numJoints'] if loss.get('kind', 'embedding') != 'embedding' else 1)
@@ -428,6 +433,7 @@ class CompiledNet(object):
                 for a, b in ((0, lo), (hi, n)) if self._early_slice is not None else ((0, n),):
                     if b > a:
                         self._grad_allreduce.append(dp.allreduce_sum_op(self.store.g.view(a, (b - a,)), 'grad_allreduce'))
+                self._grad_allreduce += self._wd_ops       # once, on the all-reduced gradient (see _emit_backward)
                 for op in self._grad_allreduce:
                     self.upd.add(op)
             self.upd.add(ops.adam(rt, self.store.w, self.store.g, self.store.m, self.store.v, self.store.n_w, self.hyper))
@@ -462,6 +468,9 @@ class CompiledNet(object):
             b = view.bn
             return ops.act(mode, b.mean, b.scale, b.beta_buf, view.chan)
         return ops.act(mode, None, None, None, view.chan)
+
+    def _fc1_stream(self):
+        return FC1_STREAM == '1' or (FC1_STREAM == 'bf16' and self.prec == 1)
 
     def _single_consumer(self, var):
         return len(self.consumers.get(id(var), [])) == 1
@@ -708,7 +717,7 @@ class CompiledNet(object):
         out = self._new_tensor((Nb, Nout), 'fc%d' % layer.layerNum)
         rt, st = self.rt, self.store
         act = self._act(src)
-        if FC1_STREAM and is_fc1_shape(Nb, K, Nout):
+        if self._fc1_stream() and is_fc1_shape(Nb, K, Nout):
             splitk = max(1, min(FC1_SLICES, K // 512))
             part = self.scratch(splitk * Nb * Nout)
             self.fwd.add(ops.fc_gemm(rt, src.base.buf, st.view(layer.W), None, Nb, Nout, K, 1, 0, K, Nout, Nout, actA=act, splitk=splitk,
@@ -744,7 +753,9 @@ class CompiledNet(object):
             mask = self.rt.alloc(src.shape)
             self.dropout_masks[id(layer)] = (mask, float(keep), layer.mask_seed)
             # a fresh Bernoulli(1-p) mask per step (dropoutlayer.py:98-103): stream keyed by (layer seed, layer, device step counter)
-            self.fwd.add(ops.bernoulli_mask(self.rt, mask, n, float(keep), layer.mask_seed, layer.layerNum << 40, self.step_ctr))
+            # (data parallel: ranks build the net from the same seed, so the rank enters the stream key -- shards get independent masks)
+            rank = self.dp.rank if self.dp is not None else 0
+            self.fwd.add(ops.bernoulli_mask(self.rt, mask, n, float(keep), layer.mask_seed, (layer.layerNum << 40) + (rank << 32), self.step_ctr))
         self.fwd.add(ops.scale(self.rt, src.base.buf, out.buf, n, a=keep, relu=src.relu, mask=mask))
         self.layer_io[id(layer)] = dict(in_view=src, out=out, mask=mask)
         return View(out)
@@ -923,10 +934,18 @@ class CompiledNet(object):
                 raise NotImplementedError(kind)
         self.bwd.join()
         self.bwd.add(self.reduce_jobs.launch())       # every filter / bias gradient partial of the pass, one launch
+        # cost += wd * sum(W^2): gradient 2*wd*W.  Single process: the last step of the backward plan.  Data parallel: the
+        # regulariser is NOT a per-shard partial sum, so it is added once, AFTER the gradient all-reduce (added before, the
+        # sum over ranks would scale it by the world size -- and the axpy would write the slice whose all-reduce the early bucket
+        # still has in flight)
+        self._wd_ops = []
         if self.weight_decay and not self.net.hasDropout():
-            for l in self.layers:                             # cost += wd * sum(W^2): gradient 2*wd*W
+            for l in self.layers:
                 if hasattr(l, 'W'):
-                    self.bwd.add(ops.axpy(rt, st.view(l.W, 'g'), st.view(l.W), 2.0 * self.weight_decay, int(np.prod(l.W.shape))))
+                    self._wd_ops.append(ops.axpy(rt, st.view(l.W, 'g'), st.view(l.W), 2.0 * self.weight_decay, int(np.prod(l.W.shape))))
+        if self.dp is None:
+            for o in self._wd_ops:
+                self.bwd.add(o)
 
     def _sole_consumer_bn_view(self, view):
         """A BatchNorm(+ReLU) view read by exactly one conv: that conv's data-gradient epilogue may finish the BatchNorm
@@ -1064,7 +1083,7 @@ class CompiledNet(object):
         act = self._act(src)
         self.bwd.fork()
         self._bias_grad(dY, Nb, Nout, gb)
-        stream_kernel = FC1_STREAM and is_fc1_shape(Nb, K, Nout)
+        stream_kernel = self._fc1_stream() and is_fc1_shape(Nb, K, Nout)
         if stream_kernel:
             self.bwd.add(ops.fc_gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, precision=self.prec,
                                      kchunk=FC1_KCHUNK, name='fc_wgrad_%d' % layer.layerNum), side=True)
@@ -1211,6 +1230,19 @@ class CompiledNet(object):
         self.lossplan.run(st)
         self.bwd.run(st)
         return float(self.cost.get()[0]), self.out.buf.get()
+
+    def global_cost(self):
+        """The cost of the GLOBAL minibatch: eng.cost holds this rank's share (its shard's sum over the global batch size), the
+        sum over ranks is the reference's cost.  A collective: every rank must call it."""
+        c = float(self.cost.get()[0])
+        if self.dp is None:
+            return c
+        import torch
+        t = torch.tensor([c], dtype=torch.float64)
+        if self.dp.dist.get_backend() == 'nccl':
+            t = t.cuda()
+        self.dp.dist.all_reduce(t, op=self.dp.dist.ReduceOp.SUM)
+        return float(t.item())
 
     def allreduce_grads(self):
         """Finish summing the flat gradient buffer over the data-parallel ranks after a backward pass (no-op without dp):

@@ -49,15 +49,26 @@ class NetTrainerParams(object):
 class DeviceData(object):
     """Stand-in for a Theano shared variable holding a data array on the device."""
 
+    @staticmethod
+    def _floatX(value):
+        """Floating-point data becomes float32 like every Theano shared variable of the reference (floatX): the kernels read
+        and write raw float32 pointers, so a float64 array (sklearn's pca.mean_ / components_ / transform output, which the
+        mains pass on uncast) must not reach the device as it is."""
+        value = numpy.asarray(value)
+        if value.dtype.kind == 'f' and value.dtype != numpy.float32:
+            value = value.astype(numpy.float32)
+        return numpy.ascontiguousarray(value)
+
     def __init__(self, rt, value, name):
         self.name = name
         self.rt = rt
-        self.buf = rt.upload(numpy.ascontiguousarray(value))
+        value = self._floatX(value)
+        self.buf = rt.upload(value)
         self.shape = tuple(value.shape)
         self.dtype = value.dtype
 
     def set_value(self, value, borrow=False):
-        value = numpy.ascontiguousarray(value)
+        value = self._floatX(value)
         if tuple(value.shape) != self.shape or value.dtype != self.dtype:
             self.buf = self.rt.upload(value)
             self.shape, self.dtype = tuple(value.shape), value.dtype

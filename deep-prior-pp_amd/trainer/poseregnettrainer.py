@@ -153,9 +153,19 @@ class PoseRegNetTrainer(NetTrainer):
             # the un-augmented crops stay resident next to the augmented macro-batch (the reference's train_data_xDB)
             from trainer.nettrainer import DeviceData
             self._aug_src = DeviceData(self.rt, self.train_data_xDB, 'train_data_x_orig')
-        gt = self.train_gt3Dcrop
-        J = gt.shape[1]
         proj = args.get('proj')
+        if proj is not None or hasattr(self, 'train_gt3Dcrop'):
+            gt = self.train_gt3Dcrop
+        else:
+            # no PCA prior: the labels ARE the normalised joints, so the mm-space joints the augmentation needs come from
+            # train_data_y * cube_z / 2 (poseregnettrainer.py:228-240)
+            if not hasattr(self, '_aug_gt'):
+                from trainer.nettrainer import DeviceData
+                ydb = numpy.asarray(self.train_data_yDB, numpy.float32)
+                gt_mm = ydb.reshape(ydb.shape[0], -1, 3) * (numpy.asarray(self.train_data_cubeDB, numpy.float32)[:, 2] / 2.)[:, None, None]
+                self._aug_gt = DeviceData(self.rt, gt_mm, 'train_gt3Dcrop_from_labels')
+            gt = self._aug_gt
+        J = gt.shape[1]
         key = (idxs[0], tidxs[0], n)
         if self._augmenter is None or self._augmenter[0] != key:
             aug = DeviceAugmenter(self.rt, args['di'], args['aug_modes'], n, J, dsz=self.train_data_xDB.shape[-1], proj=proj,

@@ -1,5 +1,5 @@
 """Worker of tests/test_data_parallel.py: one data-parallel rank (gloo, emulator runtime) computing the gradients of its
-shard of a global batch with sync-BN, then one full train step.  Usage: dp_worker.py <out.npz> <sync_bn 0|1>"""
+shard of a global batch with sync-BN, then one full train step.  Usage: dp_worker.py <out.npz> <sync_bn 0|1> [weight_decay]"""
 import os
 import sys
 
@@ -20,12 +20,13 @@ from tests.emu.emu_runtime import EmuRuntime  # noqa: E402
 
 def main():
     out, sync = sys.argv[1], bool(int(sys.argv[2]))
+    wd = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
     rank, world = parallel.init_from_env('gloo')
     rt = EmuRuntime()
     B = 4
     net = ResNet(np.random.RandomState(23455 + rank), cfgParams=ResNetParams(type=0, wIn=32, hIn=32, batchSize=B, numJoints=1, nDims=30))
     dp = parallel.DataParallel(rt, sync_bn=sync)
-    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), dp=dp)   # broadcasts rank 0's parameters
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), dp=dp, weight_decay=wd)   # broadcasts rank 0's parameters
     rng = np.random.RandomState(99)
     x = nets.synthetic_crops(rng, B * world, 32, 32, np.float32)
     y = rng.normal(0, 0.3, (B * world, 30)).astype(np.float32)
@@ -39,6 +40,7 @@ def main():
         for s, p in enumerate(l.params):
             G['g_%d_%d' % (i, s)] = eng.store.read_grad(p)
     G['cost'] = np.array([cost])
+    G['global_cost'] = np.array([eng.global_cost()])            # collective: the reference's cost of the global minibatch
     eng.train_step(xs, ys, 1e-3)
     last = net.layers[-1]
     G['w_last'] = last.W.get_value()

@@ -25,14 +25,14 @@ def _free_port():
     return p
 
 
-def _run_ranks(tmp_path, sync, world=2):
+def _run_ranks(tmp_path, sync, world=2, wd=0.0):
     port = _free_port()
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         out = os.path.join(str(tmp_path), 'rank%d_%d.npz' % (r, int(sync)))
         outs.append(out)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), out, str(int(sync))], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), out, str(int(sync)), repr(wd)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         log = p.communicate(timeout=900)[0].decode()
@@ -40,19 +40,22 @@ def _run_ranks(tmp_path, sync, world=2):
     return [np.load(o) for o in outs]
 
 
-def test_sync_bn_gradients_equal_single_process(tmp_path):
-    r0, r1 = _run_ranks(tmp_path, sync=True)
+@pytest.mark.parametrize('wd', [0.0, 1e-3])
+def test_sync_bn_gradients_equal_single_process(tmp_path, wd):
+    """wd > 0: the weight-decay gradient 2*wd*W is not a per-shard partial sum -- it has to enter ONCE, after the all-reduce."""
+    r0, r1 = _run_ranks(tmp_path, sync=True, wd=wd)
     rt = get_runtime('emu')
     net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, wIn=32, hIn=32, batchSize=8, numJoints=1, nDims=30))
     # the single-process reference runs the same stand-alone BatchNorm kernels as the sync-BN ranks: in this deep, tiny-batch
     # net f32 rounding differences between kernel variants are amplified enough to flip ReLU masks of near-zero elements
-    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), fuse_bn=False)
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), fuse_bn=False, weight_decay=wd)
     rng = np.random.RandomState(99)
     x = nets.synthetic_crops(rng, 8, 32, 32, np.float32)
     y = rng.normal(0, 0.3, (8, 30)).astype(np.float32)
     cost, _ = eng.cost_and_grads(x, y)
     # the per-rank cost is the rank's share of the global mean
     assert abs(float(r0['cost'][0] + r1['cost'][0]) - cost) < 1e-5 * abs(cost)
+    assert abs(float(r0['global_cost'][0]) - cost) < 1e-5 * abs(cost) and r0['global_cost'][0] == r1['global_cost'][0]
     gmax = 0.0
     ref = {}
     for i, l in enumerate(net.layers):

@@ -77,6 +77,30 @@ def test_icvl_reader(backend, tmp_path):
     assert [f.subSeqName for f in imp2.loadSequence('train', subSeq=['45', '22-5']).data] == ['45', '45', '22-5']
     with pytest.raises(TypeError):
         imp2.loadSequence('train', subSeq='45')
+    # frames are cropped while the file list is being read (chunks of 2 here): only crops are kept, never the whole sequence of
+    # raw frames -- and the result does not depend on the chunking, nor does Nmax
+    import data.importers as I
+    real = I.DepthImporter._crop_stream
+    calls = []
+
+    def small_chunks(self, config, docom, side, chunk=256):
+        st = real(self, config, docom, side, chunk=2)
+        inner = st._flush
+
+        def spy():
+            calls.append(len(st.pending))
+            inner()
+        st._flush = spy
+        return st
+    I.DepthImporter._crop_stream = small_chunks
+    try:
+        seq3 = imp2.loadSequence('train')
+        seq4 = imp2.loadSequence('train', Nmax=3)
+    finally:
+        I.DepthImporter._crop_stream = real
+    assert max(calls) <= 2 and len(calls) >= 3
+    assert len(seq3.data) == 5 and all(np.array_equal(a.dpt, b.dpt) and np.array_equal(a.T, b.T) for a, b in zip(seq3.data, seq.data))
+    assert len(seq4.data) == 3
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
