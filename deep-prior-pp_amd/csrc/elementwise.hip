@@ -186,6 +186,18 @@ __global__ __launch_bounds__(DPP_THREADS) void copy2d_kernel(const float* __rest
     }
 }
 
+// out[r][c] = x[r][c] * (s[r * sld + scol] * factor): normalised joint labels back to millimetres, label * cube_z / 2, as the
+// augmentation's input when no separate mm-space copy is kept (poseregnettrainer.py:228-240, scalenettrainer.py:226-229).
+// The product s * factor is formed first, like the reference's `(cube[2] / 2.)`.
+__global__ __launch_bounds__(DPP_THREADS) void rowscale_kernel(const float* __restrict__ x, const float* __restrict__ s, int sld, int scol,
+                                                               float factor, float* __restrict__ out, int rows, int cols) {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DPP_THREADS) {
+        const int r = (int)(i / cols);
+        out[i] = x[i] * (s[(size_t)r * sld + scol] * factor);
+    }
+}
+
 // centre h x w window of every [H][W] image of a batch (scalenettrainer.py:239-251, handdetector.py:654-666)
 __global__ __launch_bounds__(DPP_THREADS) void crop_center_kernel(const float* __restrict__ src, int B, int H, int W, float* __restrict__ dst,
                                                                   int h, int w, int y0, int x0) {
@@ -288,6 +300,14 @@ extern "C" int dpp_copy2d(const float* src, int lds, float* dst, int ldd, int ro
     if (!src || !dst || rows < 1 || cols < 1 || lds < cols || ldd < cols) return DPP_E_BADARG;
     DPP_LAUNCH(copy2d_kernel, dim3(grid_for((size_t)rows * cols)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), src, lds,
                        dst, ldd, rows, cols, relu);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_rowscale(const float* x, const float* s, int sld, int scol, float factor, float* out, int rows, int cols,
+                            dpp_stream_t stream) {
+    if (!x || !s || !out || rows < 1 || cols < 1 || sld < 1 || scol < 0 || scol >= sld) return DPP_E_BADARG;
+    DPP_LAUNCH(rowscale_kernel, dim3(grid_for((size_t)rows * cols)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), x, s, sld, scol,
+               factor, out, rows, cols);
     return dpp_launch_status();
 }
 

@@ -108,6 +108,7 @@ SIGNATURES = {
     'dpp_relu_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, stream_t]),
     'dpp_fill_zero': (C.c_int, [C.c_void_p, C.c_size_t, stream_t]),
     'dpp_copy2d': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, stream_t]),
+    'dpp_rowscale': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_crop_center': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_bernoulli_mask': (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_ulonglong, C.c_ulonglong, C.c_void_p, stream_t]),
     'dpp_augment_record_bytes': (C.c_size_t, []),

@@ -455,6 +455,11 @@ def copy2d(rt, src, lds, dst, ldd, rows, cols, relu=False, name='copy2d'):
     return Launch(rt.lib.dpp_copy2d, (src.ptr, lds, dst.ptr, ldd, rows, cols, int(bool(relu))), (src, dst), name)
 
 
+def rowscale(rt, x, s, scol, factor, out, rows, cols, name='rowscale'):
+    """out[r][c] = x[r][c] * (s[r][scol] * factor); s has s.shape[-1] columns."""
+    return Launch(rt.lib.dpp_rowscale, (x.ptr, s.ptr, int(s.shape[-1]), int(scol), float(factor), out.ptr, int(rows), int(cols)), (x, s, out), name)
+
+
 def crop_center(rt, src, B, H, W, dst, h, w, name='crop_center'):
     return Launch(rt.lib.dpp_crop_center, (src.ptr, B, H, W, dst.ptr, h, w), (src, dst), name)
 

@@ -125,6 +125,36 @@ class TorchHipRuntime(object):
     def copy(self, dst, src):
         self._tensor(dst).copy_(self._tensor(src))
 
+    def pinned_like(self, arr):
+        """An uninitialised page-locked host array of arr's shape / dtype (source of asynchronous uploads)."""
+        t = self.torch
+        ten = t.empty(tuple(arr.shape), dtype=t.from_numpy(np.empty(0, arr.dtype)).dtype, pin_memory=True)
+        return ten.numpy()
+
+    def upload_async(self, buf, host):
+        """Start copying `host` (ideally page-locked: then the copy engine moves it while kernels run) into the first
+        host.size elements of `buf` on a dedicated copy stream; returns a handle whose wait() makes the CURRENT stream wait for
+        the copy (no host block).  The copy itself first waits for the work queued so far, which may still read `buf`."""
+        t = self.torch
+        if getattr(self, '_copy', None) is None:
+            self._copy = t.cuda.Stream(self.device)
+        cur = t.cuda.current_stream(self.device)
+        src = t.from_numpy(np.ascontiguousarray(host, dtype=buf.dtype).reshape(-1))
+        dst = self._tensor(buf)[:src.numel()]
+        self._copy.wait_stream(cur)
+        with t.cuda.stream(self._copy):
+            dst.copy_(src, non_blocking=True)
+            ev = t.cuda.Event()
+            ev.record(self._copy)
+
+        class _Copy(object):
+            def __init__(self, ev, keep):
+                self.ev, self.keep = ev, keep
+
+            def wait(self_inner):
+                t.cuda.current_stream(self.device).wait_event(self_inner.ev)
+        return _Copy(ev, src)
+
     @property
     def stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream

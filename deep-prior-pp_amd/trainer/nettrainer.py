@@ -98,8 +98,10 @@ class NetTrainer(object):
         self.memorySize = self._free_device_mb() / float(memory_factor)    # MB, nettrainer.py:100-112
         if cfgParams.para_load is True and numChunks == 1:
             raise ValueError("para_load is True but numChunks == 1, so we do not need para_load!")
-        if cfgParams.para_load is True or numChunks != 1:
-            raise NotImplementedError("chunked host loading (para_load) is not needed with device-resident data")
+        self._src = {}                 # var -> device buffer with the UN-augmented rows of the current macro-batch window
+        self._src_next = {}            # the other staging set: the next macro-batch is uploaded into it while this one trains
+        self._prefetched = None        # (macro_idx, handles) of the upload in flight
+        self._load_thread = None
         self.currentMacroBatch = -1
         self.currentChunk = -1
         self.numChunks = numChunks
@@ -151,15 +153,40 @@ class NetTrainer(object):
         for key in data:
             if data[key].shape[0] != self.numTrainSamplesMB:
                 raise ValueError("Number of samples must be the same as number of labels.")
-            self._require_single_macrobatch()
-            self._publish(key, self.alignData(data[key]))
+            self._publish_training(key, numpy.asarray(data[key]))
             self.trainingVar.append(key)
 
-    def _require_single_macrobatch(self):
-        if self.getNumMacroBatches() > 1:
-            raise NotImplementedError("training set (%.0f MB) exceeds the device budget (%.0f MB): multi-macro-batch paging is "
-                                      "not implemented -- raise memory_factor or shard the data over GPUs" %
-                                      (self.trainSize, self.getGPUMemAligned()))
+    def _publish_training(self, key, data):
+        """A per-training-sample array.  It fits one macro-batch (always, on 288 GB, for the datasets of the mains): aligned and
+        resident on the device as a whole.  Otherwise the reference's paging layout (nettrainer.py:259-276, 193-204): host
+        arrays keyDB (the full macro-batches) and keyDBlast (the last one, padded), and a device window of ONE macro-batch that
+        loadMacroBatch refills."""
+        nmb = self.getNumMacroBatches()
+        if nmb == 1:
+            self._publish(key, self.alignData(data))
+            return
+        spm = self.getNumSamplesPerMacroBatch()
+        n_full = (nmb - 1) * spm
+        setattr(self, key + 'DB', self._pinned(data[0:n_full]))
+        setattr(self, key + 'DBlast', self._pinned(self.alignData(data[n_full:], fillData=data)))
+        if key not in self.managedVar:
+            self.managedVar.append(key)
+        first = getattr(self, key + 'DB')[:spm]
+        if hasattr(self, key):
+            print("Reusing shared variables!")
+            getattr(self, key).set_value(first, borrow=True)
+        else:
+            setattr(self, key, DeviceData(self.rt, first, key))
+
+    def _pinned(self, arr):
+        """Page-locked host copy (asynchronous uploads need it); a plain array on runtimes without pinned memory."""
+        arr = DeviceData._floatX(arr)
+        pin = getattr(self.rt, 'pinned_like', None)
+        if pin is None:
+            return arr
+        out = pin(arr)
+        out[...] = arr
+        return out
 
     def setData(self, train_data, train_y, val_data, val_y, max_train_size=0):
         if (train_data.shape[0] != train_y.shape[0]) or (val_data.shape[0] != val_y.shape[0]):
@@ -175,9 +202,8 @@ class NetTrainer(object):
             # shrink the macro batch to the smallest possible (nettrainer.py:255-257)
             self.memorySize = self.sampleSize * numpy.ceil(self.numTrainSamplesMB / float(self.cfgParams.batch_size)) * \
                 self.cfgParams.batch_size
-        self._require_single_macrobatch()
-        self._publish('train_data_x', self.alignData(train_data))
-        self._publish('train_data_y', self.alignData(train_y))
+        self._publish_training('train_data_x', train_data)
+        self._publish_training('train_data_y', train_y)
         self.trainingVar.append('train_data_x')
         self.trainingVar.append('train_data_y')
         self._publish('val_data_x', val_data)
@@ -279,23 +305,156 @@ class NetTrainer(object):
         return mini_idx % self.getNumMiniBatchesPerMacroBatch()
 
     def loadMacroBatch(self, macro_idx, mini_idx):
-        """When the reference swaps in a (re-)augmented macro-batch -- first use, or just before the last minibatch of
-        an epoch with force_macrobatch_reload (nettrainer.py:528) -- run the augmentation hook over the resident data."""
+        """Make macro-batch `macro_idx` the one in the device window (nettrainer.py:500-599): on first use, or -- with
+        force_macrobatch_reload and a single macro-batch -- just before the last minibatch of an epoch, which re-augments the
+        resident data.  Paged training sets (more than one macro-batch) are uploaded from the pinned host arrays, the NEXT
+        macro-batch already travelling over PCIe on a copy stream while this one trains; the augmentation hook then runs on the
+        device from the uploaded rows into the window."""
         force_reload = (((mini_idx % self.getNumMiniBatchesPerChunk()) == self.getNumMiniBatchesPerMacroBatch() - 1) and
                         self.cfgParams.force_macrobatch_reload is True and (self.getNumMacroBatches() == 1))
         if macro_idx != self.currentMacroBatch or force_reload is True:
             fun = self.cfgParams.augment_fun_params['fun']
+            nmb = self.getNumMacroBatches()
+            if nmb > 1:
+                self._page_in(macro_idx, augmenting=fun is not None)
             if fun is not None:
                 last, tidx, idxs = self.chunksForMP(macro_idx)
+                print("Loading macro batch {}, last {}, start idx {}, end idx {}".format(macro_idx, last, idxs[0][0], idxs[-1][-1]))
                 getattr(self, fun)(self.cfgParams.augment_fun_params, macro_idx, last,
                                    [itm for sl in tidx for itm in sl], [itm for sl in idxs for itm in sl], None)
             self.currentMacroBatch = macro_idx
+            self._para_swap(macro_idx)
+            if nmb > 1:
+                self._prefetch((macro_idx + 1) % nmb, augmenting=fun is not None)
 
+    def _macro_rows(self, var, macro_idx):
+        """Host rows of macro-batch `macro_idx` of a training array."""
+        nmb = self.getNumMacroBatches()
+        if nmb == 1:
+            return getattr(self, var + 'DB')
+        if self.isLastMacroBatch(macro_idx):
+            return getattr(self, var + 'DBlast')
+        spm = self.getNumSamplesPerMacroBatch()
+        return getattr(self, var + 'DB')[macro_idx * spm:(macro_idx + 1) * spm]
+
+    def _stage_target(self, var, augmenting, which):
+        """Where the raw rows of `var` go: straight into the device window, or -- for the arrays the augmentation REWRITES
+        (train_data_x / train_data_y) -- into a staging buffer the augmentation kernel reads."""
+        rewritten = augmenting and var in ('train_data_x', 'train_data_y')
+        store = self._src if which == 0 else self._src_next
+        if var not in store:
+            shape = (self.getNumSamplesPerMacroBatch(),) + tuple(getattr(self, var + 'DBlast').shape[1:])
+            store[var] = DeviceData(self.rt, numpy.zeros(shape, getattr(self, var + 'DBlast').dtype), var + '_stage%d' % which)
+        return store[var], rewritten
+
+    def _prefetch(self, macro_idx, augmenting):
+        up = getattr(self.rt, 'upload_async', None)
+        if up is None:
+            return                                           # a runtime without asynchronous copies pages in synchronously
+        handles = []
+        for var in self.trainingVar:
+            tgt, _ = self._stage_target(var, augmenting, 1)
+            handles.append(up(tgt.buf, self._macro_rows(var, macro_idx)))
+        self._prefetched = (macro_idx, handles)
+
+    def _page_in(self, macro_idx, augmenting):
+        if self._prefetched is not None and self._prefetched[0] == macro_idx:
+            for h in self._prefetched[1]:
+                h.wait()                                     # the main stream waits for the copy stream's event
+            self._src, self._src_next = self._src_next, self._src
+        else:
+            for var in self.trainingVar:
+                tgt, _ = self._stage_target(var, augmenting, 0)
+                tgt.set_value(self._macro_rows(var, macro_idx))
+        self._prefetched = None
+        for var in self.trainingVar:
+            stage, rewritten = self._stage_target(var, augmenting, 0)
+            if not rewritten:
+                self.rt.copy(getattr(self, var).buf, stage.buf)      # device-to-device into the window
+
+    def source_rows(self, var, idxs, macro_idx, last):
+        """Device rows holding the UN-augmented samples `idxs` (contiguous) of `var` for the augmentation hooks: idxs are indices
+        into keyDB (or keyDBlast when `last`), exactly what the reference's augment_poses indexes (poseregnettrainer.py:223-241)."""
+        n = len(idxs)
+        if self.getNumMacroBatches() == 1:
+            if var not in self._src:
+                self._src[var] = getattr(self, var) if var not in ('train_data_x', 'train_data_y') else \
+                    DeviceData(self.rt, getattr(self, var + 'DB'), var + '_orig')
+            return self._src[var].rows(idxs[0], n)
+        base = 0 if last else macro_idx * self.getNumSamplesPerMacroBatch()
+        return self._src[var].rows(idxs[0] - base, n)
+
+    # ---- chunked host loading (para_load, nettrainer.py:512-526, 630-655, 701-723) ---------------------------------------
     def setupDataLoading(self):
-        pass        # no worker processes / shared memory: augmentation is two kernel launches
+        """para_load: the training set is one of `numChunks` chunks; while chunk c trains, `load_fun_params['fun']`
+        (a trainer method `fun(params, chunk_idx, last, data_queue)` that fills data_queue[var][:]) prepares chunk c+1 on a
+        host thread (file reading and NumPy release the GIL; the reference forks a process because its loop also augments on the
+        CPU).  Augmentation needs no workers here: it is a kernel launch."""
+        if self.cfgParams.para_load is True:
+            import queue
+            import threading
+            assert self.numChunks > 1, "Please set the number of chunks appropriately!"
+            self.load_recv_queue, self.load_send_queue = queue.Queue(), queue.Queue()
+            self.load_data_queue = {}
+            for var in self.trainingVar:
+                if not hasattr(self, var):
+                    raise ValueError("Variable " + var + " not defined!")
+                if var.startswith("train_"):
+                    sz = list(getattr(self, var + 'DB').shape)
+                    if hasattr(self, var + 'DBlast'):
+                        sz[0] += getattr(self, var + 'DBlast').shape[0]
+                    self.load_data_queue[var] = numpy.full(tuple(sz), numpy.nan, dtype=getattr(self, var + 'DB').dtype) \
+                        if getattr(self, var + 'DB').dtype.kind == 'f' else numpy.zeros(tuple(sz), getattr(self, var + 'DB').dtype)
+            self._load_thread = threading.Thread(target=self.loadDataMP, args=(self.load_recv_queue, self.load_send_queue, self.load_data_queue),
+                                                 daemon=True)
+            self._load_thread.start()
+            print("Loading chunk {}, last {}".format(0, False))
+            self.load_recv_queue.put((0, self.cfgParams.load_fun_params, False))
+
+    def loadDataMP(self, recv_queue, send_queue, data_queue):
+        while True:
+            (chunk_idx, params, last) = recv_queue.get()
+            if chunk_idx == -1:
+                return
+            assert params['fun'] is not None
+            getattr(self, params['fun'])(params, chunk_idx, last, data_queue)
+            send_queue.put((chunk_idx, self.SYNC_LOAD_FINISHED))
+
+    def _para_swap(self, macro_idx):
+        """do_para_swap (nettrainer.py:512-526): at the last macro-batch of a chunk the freshly loaded chunk replaces the host
+        arrays (it is what the NEXT macro-batch loads read), and the following chunk is requested."""
+        if self.cfgParams.para_load is not True or self._load_thread is None or not self.isLastMacroBatch(macro_idx):
+            return
+        (ci, msg) = self.load_send_queue.get()
+        assert msg == self.SYNC_LOAD_FINISHED
+        nmb, spm = self.getNumMacroBatches(), self.getNumSamplesPerMacroBatch()
+        for var in self.trainingVar:
+            if not hasattr(self, var):
+                raise ValueError("Variable " + var + " not defined!")
+            if var not in self.load_data_queue:
+                continue
+            new = self.load_data_queue[var]
+            if nmb > 1:
+                getattr(self, var + 'DB')[:] = new[0:(nmb - 1) * spm]
+                getattr(self, var + 'DBlast')[:] = self.alignData(new[(nmb - 1) * spm:], fillData=new)
+            else:
+                getattr(self, var + 'DB')[:] = new
+                # single macro-batch: the resident copy the augmentation reads is refreshed as well
+                if var in self._src and self._src[var] is not getattr(self, var):
+                    self._src[var].set_value(getattr(self, var + 'DB'))
+                elif self.cfgParams.augment_fun_params['fun'] is None or var not in ('train_data_x', 'train_data_y'):
+                    getattr(self, var).set_value(getattr(self, var + 'DB'))
+        self._prefetched = None                                  # it was read from the old chunk
+        self.currentChunk = ci
+        next_chunk = int(numpy.mod(ci + 1, self.numChunks))
+        print("Received chunk {}, requesting {}".format(ci, next_chunk))
+        self.load_recv_queue.put((next_chunk, self.cfgParams.load_fun_params, False))
 
     def unsetDataLoading(self):
-        pass
+        if self._load_thread is not None:
+            self.load_recv_queue.put((-1, None, False))
+            self._load_thread.join(timeout=60)
+            self._load_thread = None
 
     # ---- training loop (nettrainer.py:778-907) ---------------------------------------------------------------
     def train(self, n_epochs=50, storeFilters=False):

@@ -149,33 +149,32 @@ class PoseRegNetTrainer(NetTrainer):
             return
         if list(tidxs) != list(range(tidxs[0], tidxs[0] + n)) or list(idxs) != list(range(idxs[0], idxs[0] + n)):
             raise NotImplementedError("augment_poses expects contiguous index ranges")
-        if not hasattr(self, '_aug_src'):
-            # the un-augmented crops stay resident next to the augmented macro-batch (the reference's train_data_xDB)
-            from trainer.nettrainer import DeviceData
-            self._aug_src = DeviceData(self.rt, self.train_data_xDB, 'train_data_x_orig')
         proj = args.get('proj')
-        if proj is not None or hasattr(self, 'train_gt3Dcrop'):
-            gt = self.train_gt3Dcrop
+        # un-augmented rows: resident as a whole next to the augmented window (the reference's *DB arrays), or -- for a paged
+        # training set -- the macro-batch NetTrainer.loadMacroBatch just uploaded
+        src_x = self.source_rows('train_data_x', idxs, macro_idx, last)
+        if proj is not None or hasattr(self, 'train_gt3DcropDB'):
+            gt = self.source_rows('train_gt3Dcrop', idxs, macro_idx, last)
+            scale_labels = None
         else:
-            # no PCA prior: the labels ARE the normalised joints, so the mm-space joints the augmentation needs come from
-            # train_data_y * cube_z / 2 (poseregnettrainer.py:228-240)
-            if not hasattr(self, '_aug_gt'):
-                from trainer.nettrainer import DeviceData
-                ydb = numpy.asarray(self.train_data_yDB, numpy.float32)
-                gt_mm = ydb.reshape(ydb.shape[0], -1, 3) * (numpy.asarray(self.train_data_cubeDB, numpy.float32)[:, 2] / 2.)[:, None, None]
-                self._aug_gt = DeviceData(self.rt, gt_mm, 'train_gt3Dcrop_from_labels')
-            gt = self._aug_gt
-        J = gt.shape[1]
-        key = (idxs[0], tidxs[0], n)
+            # no PCA prior: the labels ARE the normalised joints; the mm-space joints the augmentation needs are
+            # train_data_y * cube_z / 2 (poseregnettrainer.py:228-240), formed on the device from the un-augmented labels
+            scale_labels = self.source_rows('train_data_y', idxs, macro_idx, last)
+            gt = None
+        com, cube, M = (self.source_rows(v, idxs, macro_idx, last) for v in ('train_data_com', 'train_data_cube', 'train_data_M'))
+        dsz = self.train_data_xDB.shape[-1]
+        J = (self.train_gt3DcropDB.shape[1] if gt is not None else int(numpy.prod(self.train_data_yDB.shape[1:])) // 3)
+        key = (src_x.ptr, tidxs[0], n)
         if self._augmenter is None or self._augmenter[0] != key:
-            aug = DeviceAugmenter(self.rt, args['di'], args['aug_modes'], n, J, dsz=self.train_data_xDB.shape[-1], proj=proj,
+            aug = DeviceAugmenter(self.rt, args['di'], args['aug_modes'], n, J, dsz=dsz, proj=proj,
                                   sigma_com=args.get('sigma_com'), sigma_sc=args.get('sigma_sc'), rot_range=args.get('rot_range'),
                                   seed=int(self.rng.randint(1 << 30)), normZeroOne=bool(args.get('normZeroOne')))
-            launches = aug.build(self._aug_src.rows(idxs[0], n).reshape(n, *self.train_data_xDB.shape[-2:]),
-                                 self.train_data_com.rows(idxs[0], n), self.train_data_cube.rows(idxs[0], n),
-                                 self.train_data_M.rows(idxs[0], n).reshape(n, 9), gt.rows(idxs[0], n),
-                                 self.train_data_x.rows(tidxs[0], n).reshape(n, *self.train_data_xDB.shape[-2:]),
-                                 self.train_data_y.rows(tidxs[0], n))
+            launches = []
+            if gt is None:
+                gt = self.rt.alloc((n, J, 3), zero=False)
+                launches.append(ops.rowscale(self.rt, scale_labels.reshape(n, J * 3), cube.reshape(n, 3), 2, 0.5, gt.reshape(n, J * 3), n, J * 3))
+            launches += aug.build(src_x.reshape(n, dsz, dsz), com, cube, M.reshape(n, 9), gt.reshape(n, J, 3),
+                                  self.train_data_x.rows(tidxs[0], n).reshape(n, dsz, dsz), self.train_data_y.rows(tidxs[0], n))
             self._augmenter = (key, aug, launches)
         for op in self._augmenter[2]:
             op(self.rt.stream)

@@ -108,21 +108,20 @@ class ScaleNetTrainer(PoseRegNetTrainer):
         if list(tidxs) != list(range(tidxs[0], tidxs[0] + n)) or list(idxs) != list(range(idxs[0], idxs[0] + n)):
             raise NotImplementedError("augment_poses expects contiguous index ranges")
         H, W = self.train_data_xDB.shape[-2:]
-        if not hasattr(self, '_aug_src'):
-            from trainer.nettrainer import DeviceData
-            self._aug_src = DeviceData(self.rt, self.train_data_xDB, 'train_data_x_orig')
-            gt_mm = numpy.asarray(self.train_data_yDB, numpy.float32).reshape(-1, 1, 3) * \
-                (numpy.asarray(self.train_data_cubeDB, numpy.float32)[:, 2] / 2.)[:, None, None]
-            self._aug_gt = DeviceData(self.rt, gt_mm.astype(numpy.float32), 'train_offset_mm')
-        key = (idxs[0], tidxs[0], n)
+        # un-augmented rows (resident as a whole, or the macro-batch loadMacroBatch just uploaded); the offset label in mm
+        # (label * cube_z / 2, one "joint") is formed on the device
+        src_x = self.source_rows('train_data_x', idxs, macro_idx, last)
+        src_y = self.source_rows('train_data_y', idxs, macro_idx, last)
+        com, cube, M = (self.source_rows(v, idxs, macro_idx, last) for v in ('train_data_com', 'train_data_cube', 'train_data_M'))
+        key = (src_x.ptr, tidxs[0], n)
         if self._augmenter is None or self._augmenter[0] != key:
             aug = DeviceAugmenter(self.rt, args['di'], args['aug_modes'], n, 1, dsz=H, proj=None, sigma_com=args.get('sigma_com'),
                                   sigma_sc=args.get('sigma_sc'), rot_range=args.get('rot_range'), seed=int(self.rng.randint(1 << 30)),
                                   normZeroOne=bool(args.get('normZeroOne')))
             x_out = self.train_data_x.rows(tidxs[0], n).reshape(n, H, W)
-            launches = aug.build(self._aug_src.rows(idxs[0], n).reshape(n, H, W), self.train_data_com.rows(idxs[0], n),
-                                 self.train_data_cube.rows(idxs[0], n), self.train_data_M.rows(idxs[0], n).reshape(n, 9),
-                                 self._aug_gt.rows(idxs[0], n), x_out, self.train_data_y.rows(tidxs[0], n))
+            gt = self.rt.alloc((n, 1, 3), zero=False)
+            launches = [ops.rowscale(self.rt, src_y.reshape(n, 3), cube.reshape(n, 3), 2, 0.5, gt.reshape(n, 3), n, 3)]
+            launches += aug.build(src_x.reshape(n, H, W), com, cube, M.reshape(n, 9), gt, x_out, self.train_data_y.rows(tidxs[0], n))
             for k, name in ((2, 'train_data_x1'), (4, 'train_data_x2')):
                 launches.append(ops.crop_center(self.rt, x_out, n, H, W, getattr(self, name).rows(tidxs[0], n), H // k, W // k))
             self._augmenter = (key, aug, launches)

@@ -239,6 +239,9 @@ int dpp_fill_zero(void* p, size_t nbytes, dpp_stream_t stream);
 /* dst[r][c] = relu ? max(src[r][c], 0) : src[r][c] over rows x cols with row strides lds / ldd: the column-wise
  * concatenation of ScaleNet's flattened tower outputs (/root/reference/src/net/scalenet.py:167-171) and its gradient split */
 int dpp_copy2d(const float* src, int lds, float* dst, int ldd, int rows, int cols, int relu, dpp_stream_t stream);
+/* out[r][c] = x[r][c] * (s[r*sld + scol] * factor): normalised labels back to mm (label * cube_z / 2), the augmentation's input
+ * when the labels are the joints themselves (/root/reference/src/trainer/poseregnettrainer.py:228-240) */
+int dpp_rowscale(const float* x, const float* s, int sld, int scol, float factor, float* out, int rows, int cols, dpp_stream_t stream);
 /* centre h x w window of each [H][W] image: ScaleNet's 1/2 and 1/4 inputs
  * (/root/reference/src/trainer/scalenettrainer.py:239-251, /root/reference/src/util/handdetector.py:654-666) */
 int dpp_crop_center(const float* src, int B, int H, int W, float* dst, int h, int w, dpp_stream_t stream);

@@ -169,3 +169,122 @@ def test_sample_random_poses_vectorised_equals_loop(flip):
     ref = _sample_random_poses_loop(di, np.random.RandomState(6), gts, coms, cubes, 600, modes)
     assert got.shape == ref.shape == (600, J, 3) and got.dtype == ref.dtype
     assert np.array_equal(got, ref)
+
+
+def _small_trainer(rt, tmp_path, n_train, budget_mb=None, augment=False, numChunks=1, para_load=False, seed=23455):
+    """A PoseRegNetTrainer on a small ResNet (32x32 crops, batch 4, labels = the 16 x 3 joints themselves, no PCA prior)."""
+    R.set_default_runtime(rt)
+    rng = np.random.RandomState(seed)
+    J, B, size = 16, 4, 32
+    di = ICVLImporter('../data/ICVL/')
+    x, com, cube, M, gt = synth(n_train, size, J, 1)
+    vx, _, vcube, _, vgt = synth(4, size, J, 2)
+    y = (gt / (cube[:, 2] / 2.)[:, None, None]).astype('float32').reshape(n_train, J * 3)
+    vy = (vgt / (vcube[:, 2] / 2.)[:, None, None]).astype('float32').reshape(4, J * 3)
+    net = ResNet(rng, cfgParams=ResNetParams(type=0, nChan=1, wIn=size, hIn=size, batchSize=B, numJoints=J, nDims=3))
+    p = PoseRegNetTrainerParams()
+    p.batch_size, p.learning_rate, p.validation_frequency, p.snapshot_last = B, 0.001, 1000, 1000
+    p.para_load = para_load
+    if augment:
+        p.para_augment = True
+        p.augment_fun_params = {'fun': 'augment_poses', 'args': {'normZeroOne': False, 'di': di, 'aug_modes': ['com', 'rot', 'none'], 'proj': None,
+                                                                 'hd': HandDetector(x[0, 0].copy(), abs(di.fx), abs(di.fy), importer=di)}}
+    os.makedirs(str(tmp_path), exist_ok=True)
+    tr = PoseRegNetTrainer(net, p, rng, str(tmp_path), numChunks=numChunks)
+    if budget_mb is not None:
+        tr.memorySize = budget_mb                                # what `free device memory / memory_factor` would have given
+    tr.setData(x, y, vx, vy)
+    tr.addManagedData({'train_data_cube': cube, 'train_data_com': com, 'train_data_M': M.astype('float32')})
+    tr.compileFunctions(compileDebugFcts=False)
+    return tr, net, (x, y, com, cube, M)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_paged_training_set_trains_like_the_resident_one(backend, tmp_path):
+    """memory_factor-limited runs (nettrainer.py:259-276, 489-599): a training set larger than the device budget is split into
+    macro-batches on the host (keyDB + the padded keyDBlast) and paged through a one-macro-batch device window.  Without
+    augmentation the minibatch sequence is the same as with everything resident, so the trained weights must be bit-identical."""
+    rt = get_runtime(backend)
+    n = 22                                                          # 6 minibatches of 4; sample = 32*32*4 B = 4 KB
+    res, net_r, _ = _small_trainer(rt, tmp_path / 'r', n)
+    assert res.getNumMacroBatches() == 1
+    costs_r, _, _ = res.train(n_epochs=1)
+    w_r = [p.get_value().copy() for p in net_r.params]
+    pag, net_p, (x, y, com, cube, M) = _small_trainer(rt, tmp_path / 'p', n, budget_mb=2.2 * 4 * 4096 / 1024. ** 2)
+    nmb, spm = pag.getNumMacroBatches(), pag.getNumSamplesPerMacroBatch()
+    assert nmb == 3 and spm == 8 and pag.getNumMiniBatches() == 6
+    assert pag.train_data_xDB.shape[0] == 16 and pag.train_data_xDBlast.shape[0] == 8 and pag.train_data_x.shape[0] == 8
+    assert 'train_data_x' in pag.managedVar and 'train_data_com' in pag.managedVar
+    # the padded last macro-batch is filled from the WHOLE training set (alignData(fillData=...), nettrainer.py:263)
+    pad_rng = np.random.RandomState(6)
+    assert np.array_equal(pag.train_data_xDBlast[6], x[pad_rng.randint(0, n)])
+    costs_p, _, _ = pag.train(n_epochs=1)
+    # NOTE the reference pads the single resident macro-batch with RandomState(22) and the last paged one with RandomState(6):
+    # the first five minibatches see identical data, the sixth differs by its two padding samples
+    np.testing.assert_array_equal(np.asarray(costs_p[:5], np.float32), np.asarray(costs_r[:5], np.float32))
+    assert np.isfinite(costs_p).all() and pag.currentMacroBatch == 2
+    assert np.array_equal(pag.train_data_x.get_value(), pag.train_data_xDBlast)      # the window holds the last macro-batch
+    # second epoch wraps around to macro-batch 0 (served by the prefetch where the runtime has a copy stream)
+    pag.train(n_epochs=1)
+    assert pag.currentMacroBatch == 2 and all(np.isfinite(p.get_value()).all() for p in net_p.params)
+    assert len(w_r) == len(net_p.params)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_paged_training_set_with_device_augmentation(backend, tmp_path):
+    """The same paging with the augmentation hook: every macro-batch is uploaded un-augmented, augmented on the device into the
+    window (labels = joints: formed from label * cube_z / 2 on the device, poseregnettrainer.py:228-240), and its 'none'-mode
+    samples come out untouched (rows of the right macro-batch: a mix-up of windows would change them)."""
+    rt = get_runtime(backend)
+    tr, net, (x, y, com, cube, M) = _small_trainer(rt, tmp_path, 22, budget_mb=2.2 * 4 * 4096 / 1024. ** 2, augment=True)
+    assert tr.getNumMacroBatches() == 3
+    seen = []
+    orig = tr.augment_poses
+
+    def spy(params, macro_idx, last, tidxs, idxs, new_data):
+        orig(params, macro_idx, last, tidxs, idxs, new_data)
+        src = tr.train_data_xDBlast if last else tr.train_data_xDB[macro_idx * 8:(macro_idx + 1) * 8]
+        ysrc = tr.train_data_yDBlast if last else tr.train_data_yDB[macro_idx * 8:(macro_idx + 1) * 8]
+        out, oy = tr.train_data_x.get_value(), tr.train_data_y.get_value()
+        same = [i for i in range(8) if np.allclose(out[i], src[i], atol=2e-6)]
+        seen.append((macro_idx, last, len(same)))
+        assert np.isfinite(out).all() and out.min() >= -1 - 1e-5 and out.max() <= 1 + 1e-5
+        # a sample whose label did not move is a 'none' draw: its crop is the uploaded one, bit for bit up to the f32 normalisation
+        # round trip (the converse does not hold at 32x32: a CoM shift below one pixel = 7.8 mm moves the label only)
+        for i in range(8):
+            if np.allclose(oy[i], ysrc[i], atol=1e-6):
+                assert i in same, (macro_idx, i)
+        assert any(not np.allclose(out[i], src[i], atol=2e-6) for i in range(8))
+        assert np.isfinite(oy).all() and np.abs(oy - ysrc).max() < 3.0
+    tr.augment_poses = spy
+    costs, _, _ = tr.train(n_epochs=1)
+    assert [s[0] for s in seen] == [0, 1, 2] and seen[-1][1] is True and np.isfinite(costs).all()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_para_load_swaps_chunks_at_the_last_macro_batch(backend, tmp_path):
+    """para_load (nettrainer.py:512-526, 630-655, 701-723): while a chunk trains, load_fun_params['fun'] prepares the next one
+    on a host thread; at the chunk's last macro-batch the host arrays are replaced and the following chunk is requested."""
+    rt = get_runtime(backend)
+    with pytest.raises(ValueError):
+        _small_trainer(rt, tmp_path, 8, para_load=True, numChunks=1)
+    tr, net, (x, y, com, cube, M) = _small_trainer(rt, tmp_path, 8, para_load=True, numChunks=3)
+    loaded = []
+
+    def load_chunk(params, chunk_idx, last, data_queue):
+        loaded.append(chunk_idx)
+        for var, arr in data_queue.items():
+            base = {'train_data_x': x, 'train_data_y': y, 'train_data_cube': cube, 'train_data_com': com, 'train_data_M': M}[var]
+            arr[:] = np.roll(base, chunk_idx + 1, axis=0)          # a recognisable "next chunk"
+    tr.load_chunk = load_chunk
+    tr.cfgParams.load_fun_params = {'fun': 'load_chunk', 'args': {}}
+    # with a single macro-batch the reference only reloads when force_macrobatch_reload asks for it: before the last minibatch of
+    # every epoch (nettrainer.py:528)
+    tr.cfgParams.force_macrobatch_reload = True
+    tr.train(n_epochs=2)
+    # first use (chunk 0 received, 1 requested), end of epoch 1 (chunk 1, 2 requested), end of epoch 2 (chunk 2, 0 requested)
+    assert loaded[:4] == [0, 1, 2, 0] and tr.currentChunk == 2
+    np.testing.assert_array_equal(tr.train_data_xDB, np.roll(x, 3, axis=0))
+    np.testing.assert_array_equal(tr.train_data_x.get_value(), np.roll(x, 3, axis=0))
+    np.testing.assert_array_equal(tr.train_data_com.get_value(), np.roll(com, 3, axis=0))
+    assert tr._load_thread is None                                 # the worker was shut down by train()
