@@ -127,6 +127,12 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, stream_t]),
     'dpp_crop_com': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_crop_warp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, stream_t]),
+    'dpp_pose_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, stream_t]),
+    'dpp_pca_workspace_bytes': (C.c_size_t, [C.c_long, C.c_int]),
+    'dpp_pca_fit': (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
+    'dpp_pose_eval': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_plan_create': (C.c_int, [C.POINTER(C.c_void_p)]),
     'dpp_plan_destroy': (C.c_int, [C.c_void_p]),
     'dpp_plan_record_begin': (C.c_int, [C.c_void_p]),

@@ -303,6 +303,26 @@ int dpp_crop_warp(const float* frames, const void* records, int B, int H, int W,
  * `records`, in image coordinates -> com_out [B][3]; re-run dpp_crop_prepare with it, then dpp_crop_warp. */
 int dpp_crop_com(const float* frames, const void* records, int B, int H, int W, float* com_out, dpp_stream_t stream);
 
+/* ---- PCA prior set-up and evaluation on the device --------------------------------------------
+ * pose_sample: HandDetector.sampleRandomPoses (/root/reference/src/util/handdetector.py:805-909) for n samples: sample i augments
+ *   base pose ridx[i] in label space with mode[i] (0 none, 1 com, 2 rot, 3 sc, 4 rot+com, 5 rot+com+sc) and the draws off[i][3],
+ *   sc[i], rot[i] (degrees) -- the host draws them from the script's RandomState in the reference's order, the arithmetic (f64
+ *   projections, f32 storage) runs here.  out_poses [n][J][3] normalised by the (new) cube_z / 2; out_com / out_cube may be NULL.
+ * pca_fit: sklearn PCA.fit on X [N][D] f32 (main_nyu_posereg_embedding.py:86-92): mean[D], the eigenvalues of the covariance
+ *   (1 / (N - 1)) in descending order and the eigenvectors as ROWS (components_, largest-magnitude entry of each row positive),
+ *   all f64; D <= 192.  workspace: dpp_pca_workspace_bytes(N, D) bytes of device memory.
+ * pose_eval: HandposeEvaluation's numeric methods (/root/reference/src/util/handpose_evaluation.py:92-228) on gt / pred [N][J][3]:
+ *   err [N][J] Euclidean errors, frame [N][4] = per-frame (nanmean, nanmax, count, nanstd) over joints, and out (4 + 3J + 2T
+ *   doubles): mean error, max error, mean of the frame stds, frames counted; per-joint nanmean / nanstd / nanmax; for each of the T
+ *   thresholds the frames whose max (then: mean) error is <= it. */
+int dpp_pose_sample(const float* base_poses, const float* base_com, const float* base_cube, int n_base, int J, const int* mode,
+                    const int* ridx, const double* off, const double* sc, const double* rot, long n, double fx, double fy,
+                    double ux, double uy, int flip_y, float* out_poses, float* out_com, float* out_cube, dpp_stream_t stream);
+size_t dpp_pca_workspace_bytes(long N, int D);
+int dpp_pca_fit(const float* X, long N, int D, void* workspace, double* mean, double* evals, double* components, dpp_stream_t stream);
+int dpp_pose_eval(const float* gt, const float* pred, int N, int J, const double* thresholds, int T, double* err, double* frame,
+                  double* out, dpp_stream_t stream);
+
 /* ---- launch plans: a whole train / inference step as ONE call --------------------------------------------------------
  * The reference runs `train_model(index, lr)` as one compiled device function (theano.function,
  * /root/reference/src/trainer/poseregnettrainer.py:146-170, called at /root/reference/src/trainer/nettrainer.py:840).
