@@ -29,7 +29,8 @@ Python-2-only modules (netbase.py, handdetector.py, importers.py use print state
 converted IN MEMORY with lib2to3 and exec'd; nothing is written to disk.  `cv2`, `progressbar` and
 `theano` are absent: empty placeholder modules satisfy the import statements and are never called by
 the functions exercised here (pure NumPy arithmetic).  Python-2 integer division is NOT reproduced by
-such an import, so comToTransform (handdetector.py:246,249) is deliberately not taken from it.
+such an import, so comToTransform (handdetector.py:246,249) is not taken from it here: make_golden_r2.py
+runs it with those two int / int sites rewritten to `//` (transform.npz).
 """
 import builtins
 import json

@@ -368,3 +368,70 @@ def test_evaluation_metrics_against_reference_outputs():
     np.testing.assert_allclose([hpe.getJointMaxError(j) for j in range(14)], g['joint_max'], **r)
     assert [[d, int(hpe.getNumFramesWithinMaxDist(d))] for d in (10, 20, 30, 40)] == g['within']
     np.testing.assert_allclose(L.mean_joint_error(gt, jt), g['mean'], **r)
+
+
+def test_com_to_transform_against_the_reference_with_py2_division():
+    """tests/golden/transform.npz: the reference's own HandDetector.comToTransform (util/handdetector.py:228-258) executed here
+    with its two int / int crop-size expressions (lines 246, 249) written as the floor divisions Python 2 performed
+    (tests/golden/make_golden_r2.py) -- pins the oracle's restatement, the product's host helper and, through the oracle, the
+    crop transform the augmentation kernels compute."""
+    from util.handdetector import HandDetector
+    g = _golden('transform.npz')
+    frame = np.full((240, 320), 500., np.float32)
+    n_branch = [0, 0]
+    for com, size, (fx, fy), ds, M, bounds in zip(g['com'], g['size'], g['fx'], g['dsize'], g['M'], g['bounds']):
+        ds = (int(ds[0]), int(ds[1]))
+        size = tuple(float(v) for v in size)
+        np.testing.assert_array_equal(np.asarray(A.com_to_bounds(com, size, fx, fy), np.float64), bounds)
+        np.testing.assert_allclose(A.com_to_transform(com, size, fx, fy, ds), M, rtol=0, atol=1e-12)
+        hd = HandDetector(frame.copy(), fx, fy)
+        np.testing.assert_allclose(hd.comToTransform(com, size, ds), M, rtol=0, atol=1e-12)
+        n_branch[int((bounds[1] - bounds[0]) > (bounds[3] - bounds[2]))] += 1
+        # the floor division is visible: true division gives another paste offset whenever the crop is not square
+        wb, hb = bounds[1] - bounds[0], bounds[3] - bounds[2]
+        if wb != hb and (min(wb, hb) * ds[0]) % max(wb, hb) != 0:
+            assert (min(wb, hb) * ds[0] / max(wb, hb)) != (min(wb, hb) * ds[0] // max(wb, hb))
+    assert min(n_branch) >= 5, n_branch                          # both branches (wb > hb, wb <= hb) are covered
+
+
+def test_netbase_load_reads_a_python2_cpickle_checkpoint(tmp_path):
+    """tests/golden/net_py2.pkl: a checkpoint in the byte layout Python 2's cPickle (protocol 2) gave NetBase.save
+    (net/netbase.py:405-424) -- str keys as SHORT_BINSTRING, arrays as py2 NumPy reconstruct tuples with the raw data in a str --
+    assembled by tests/golden/make_golden_r2.py.  NetBase.load must read it (encoding='latin1'); a plain pickle.load cannot."""
+    import pickle
+    import pickletools
+    from net.batchnormlayer import BatchNormLayer, BatchNormLayerParams
+    from net.convpoollayer import ConvPoolLayer, ConvPoolLayerParams
+    from net.netbase import NetBase
+    path = os.path.join(GOLD, 'net_py2.pkl')
+    want = json.load(open(os.path.join(GOLD, 'net_py2.json')))
+    raw = open(path, 'rb').read()
+    ops_used = set(op.name for op, _, _ in pickletools.genops(raw))
+    assert 'SHORT_BINSTRING' in ops_used and 'BINUNICODE' not in ops_used          # it really is the py2 layout
+    with pytest.raises(Exception):
+        pickle.loads(raw)                                                            # default ASCII decoding of the array bytes fails
+
+    class _P(object):
+        batch_size, inputDim, outputDim, layers = 4, (4, 1, 32, 32), (4, 8, 14, 14), []
+
+    net = NetBase.__new__(NetBase)
+    rng = np.random.RandomState(0)
+    from hipdp.graph import Var
+    x = Var('input', shape=(4, 1, 32, 32))
+    l0 = ConvPoolLayer(rng, x, ConvPoolLayerParams(inputDim=(4, 1, 32, 32), nFilters=8, filterDim=(5, 5), poolsize=(2, 2), activation=None), layerNum=0)
+    l1 = BatchNormLayer(rng, l0.output, BatchNormLayerParams(inputDim=l0.cfgParams.outputDim), layerNum=1)
+    net.layers, net.cfgParams = [l0, l1], _P()
+    net.load(path)
+    for layer, key in ((l0, '0-values'), (l1, '1-values')):
+        got = [p.get_value() for p in layer.params + layer.params_nontrained]
+        assert len(got) == len(want['arrays'][key])
+        for a, w in zip(got, want['arrays'][key]):
+            assert list(a.shape) == w['shape'] and a.dtype == np.float32
+            np.testing.assert_array_equal(a.astype(np.float64).ravel(), np.asarray(w['data']))
+    # and what NetBase.save writes is read back by the same loader (protocol 2, as cPickle wrote it)
+    out = str(tmp_path / 'resaved.pkl')
+    net.save(out)
+    assert pickle.load(open(out, 'rb'), encoding='latin1')['class'] == 'NetBase'
+    l0.W.set_value(np.zeros((8, 1, 5, 5), np.float32))
+    net.load(out)
+    np.testing.assert_array_equal(l0.W.get_value().astype(np.float64).ravel(), np.asarray(want['arrays']['0-values'][0]['data']))
