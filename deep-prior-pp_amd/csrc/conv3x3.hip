@@ -35,6 +35,7 @@ struct Conv3Args {
     int lth, ltw;         // log2 of tile height / width
     int img;              // images per workgroup
     int tiles_x, tiles_y;
+    unsigned long long* prof;   // phase stamps (profiling build only, see dpp_stamp)
 };
 
 typedef __bf16 c3_bf16x8 __attribute__((ext_vector_type(8)));
@@ -104,9 +105,11 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     tile_origin(a, blockIdx.x, n0, y0, x0);
     const int col0 = blockIdx.y * BN;
 
+    dpp_stamp(a.prof, 0);
     dpp_wide_coef wco;
     if (a.wide) wco.load<BN>(col0, a.Co, a.bias, a.epi);
     stage_halo(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP);
+    dpp_stamp(a.prof, 1);
 
     // halo index of this lane's A rows (centre tap)
     int hbase[RM];
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
         wcommit(Bs);
     }
     __syncthreads();                // halo + first slice (or all slices) visible
+    dpp_stamp(a.prof, 2);
     for (int tap = 0; tap < 9; ++tap) {
         const elem* Bcur = allw ? Bs + tap * BN * LDA : Bs + (tap & 1) * BN * LDA;
         if (!allw && tap + 1 < 9) wfetch(tap + 1);
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
         }
     }
     if (allw) __syncthreads();      // the epilogue reuses the operand images as scratch
+    dpp_stamp(a.prof, 3);
 
     if (a.wide) {
         const int vi = (a.N - n0 < a.img) ? (a.N - n0) : a.img;
@@ -225,6 +230,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
             const bool ok = !(im >= a.img || n >= a.N || y >= a.H || x >= a.W);
             return ok ? (long)((((size_t)n * a.H + y) * a.W + x) * a.Co) : -1L;
         });
+        dpp_stamp(a.prof, 4);
         return;
     }
 
@@ -482,6 +488,7 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     if (!X || !Wk || !Y || N < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15)) return DPP_E_BADARG;
     Conv3Args a;
     a.X = X; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+    a.prof = dpp_prof_buffer;
     if (act && (act->mode & 4)) return DPP_E_UNSUPPORTED;       // the two-tensor BatchNorm-backward operand is a dpp_gemm feature
     if (act) a.act = *act; else { a.act.mode = 0; a.act.cmod = 1; a.act.mean = a.act.scale = a.act.beta = nullptr; }
     a.Wk = Wk; a.bias = bias; a.residual = residual; a.Y = Y;
@@ -499,6 +506,9 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     size_t halo = (size_t)a.img * (TH + 2) * (TW + 2);
     // bytes of one image row: f32 [Ci + 4], bf16 [max(Ci, 32) + 8]
     const size_t rowb = precision ? (size_t)((Ci < 32 ? 32 : Ci) + 8) * 2 : (size_t)(Ci + 4) * sizeof(float);
+    // All nine weight slices up front for the narrow layers only.  Measured for the 64-channel layers as well (76 KB limit,
+    // tools/phase_profile.py): the barrier-free tap loop is then at its f32 MFMA floor (3.8 us), but staging 36 KB of weights ahead
+    // of the first MFMA costs more than the nine overlapped per-tap fetches did (13.6 vs 12.2 us per launch).
     a.allw = (halo + 9 * bn) * rowb <= 48 * 1024;
     size_t lds = (halo + (a.allw ? 9 : 2) * bn) * rowb;
     static const bool wide_ok = []() { const char* e = getenv("DPP_GEMM_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();

@@ -73,6 +73,21 @@ static inline int dpp_launch_status() {
 
 static inline int dpp_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Phase stamps for tools/phase_profile.py: compiled in only in the profiling build of the library (-DDPP_KERNEL_PROF, a separate
+// .so that the product never loads); in the product build the call is empty.  slot s of workgroup w lands in buf[w * 16 + s] as a
+// 100 MHz wall-clock tick (s_memrealtime: comparable across CUs).
+#ifdef DPP_KERNEL_PROF
+__device__ __forceinline__ void dpp_stamp(unsigned long long* buf, int slot) {
+    if (buf != nullptr && threadIdx.x == 0) {
+        const size_t w = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        buf[w * 16 + slot] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+#else
+__device__ __forceinline__ void dpp_stamp(unsigned long long*, int) {}
+#endif
+extern unsigned long long* dpp_prof_buffer;                // host-side: where instrumented launches stamp (NULL = nowhere); plan.hip
+
 // Row map of a compact (N,Ho,Wo) pixel index onto a (N,Hi,Wi) map sampled with stride s.
 __device__ __forceinline__ int dpp_map_row(const dpp_rowmap& m, int r) {
     if (m.s == 1) return r;

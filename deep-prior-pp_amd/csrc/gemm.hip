@@ -27,6 +27,7 @@ struct GemmArgs {
     int Kper;         // K-slice length per blockIdx.z (multiple of the chunk depth)
     int bk;           // chunk depth for K-contiguous A: 16 or 32 (both-MN-contiguous layout always uses 64)
     int wide;         // epilogue goes through an LDS image of the tile and touches C / residual / bn_x with 16-B accesses
+    unsigned long long* prof;   // phase stamps (profiling build only, see dpp_stamp)
 };
 
 // Load 4 consecutive floats p[0..3] where element e is valid iff (idx0 + e) < limit.
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     const int M = d.M, N = d.N;
     const int k_begin = blockIdx.z * ga.Kper;
     const int k_end = (k_begin + ga.Kper < d.K) ? (k_begin + ga.Kper) : d.K;
+    dpp_stamp(ga.prof, 0);
 
     // ---- per-thread staging slots: base pointers that do not depend on the chunk -----------------------
     const float* a_base[SA::SLOTS];
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
                                         if (k + j < k_end) po[j] = vv[j];
                                 }
                             }
-                        } else v = act4_masked(g, d.actA, k, k_end);
+                        } else v = g;                  // the BN + ReLU prologue is applied when the chunk is written to LDS (commit)
                     }
                 } else {
                     int k = kc + slot / (BM / 4), gi = row0 + (slot % (BM / 4)) * 4;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
                         const float* pa = a_base[s] + (size_t)dpp_map_row(d.mapA, k) * d.lda;
                         const float4 g = load4(pa, gi, M, ga.vecA);
                         if constexpr (LAZY) v = bnbwd4_masked(g, load4(pa + a2off, gi, M, ga.vecA), d.actA, gi, M);
-                        else v = act4_masked(g, d.actA, gi, M);
+                        else v = g;
                     }
                 }
             }
@@ -313,28 +315,41 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
             if (b_base[s] != nullptr) {
                 if (BKC) {
                     int k = kc + (slot % SB::QK) * 4;
-                    if (k < k_end) v = act4_masked(load4(b_base[s] + k, k, k_end, ga.vecB), d.actB, k, k_end);
+                    if (k < k_end) v = load4(b_base[s] + k, k, k_end, ga.vecB);
                 } else {
                     int k = kc + slot / (BN / 4), gj = col0 + (slot % (BN / 4)) * 4;
-                    if (k < k_end)
-                        v = act4_masked(load4(b_base[s] + (size_t)dpp_map_row(d.mapB, k) * d.ldb, gj, N, ga.vecB), d.actB, gj, N);
+                    if (k < k_end) v = load4(b_base[s] + (size_t)dpp_map_row(d.mapB, k) * d.ldb, gj, N, ga.vecB);
                 }
             }
             rb_[s] = v;
         }
     };
-    auto commit = [&](const float4* ra_, const float4* rb_) {
+    // commit: apply the BN + ReLU prologue to the raw registers of chunk `kc` and write them to LDS.  Doing it HERE, not in
+    // fetch, is what lets the loads of the next chunk stay in flight under this chunk's MFMAs: a prologue in fetch makes the
+    // wave wait for its loads right where they are issued (measured with tools/phase_profile.py: 2-3 us per 64-deep chunk of the
+    // K = 256 layers, all of it exposed latency).
+    auto commit = [&](const float4* ra_, const float4* rb_, int kc) {
 #pragma unroll
         for (int s = 0; s < SA::SLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
-            if (AKC) { if (slot < BM * SA::QK) *reinterpret_cast<float4*>(&As[(slot / SA::QK) * LDA_ + (slot % SA::QK) * 4]) = ra_[s]; }
-            else { if (slot < BKT * (BM / 4)) *reinterpret_cast<float4*>(&As[(slot / (BM / 4)) * LDA_ + (slot % (BM / 4)) * 4]) = ra_[s]; }
+            float4 v = ra_[s];
+            if (!LAZY && d.actA.mode != 0 && a_base[s] != nullptr) {
+                if (AKC) { const int k = kc + (slot % SA::QK) * 4; if (k < k_end) v = act4_masked(v, d.actA, k, k_end); }
+                else { const int k = kc + slot / (BM / 4), gi = row0 + (slot % (BM / 4)) * 4; if (k < k_end) v = act4_masked(v, d.actA, gi, M); }
+            }
+            if (AKC) { if (slot < BM * SA::QK) *reinterpret_cast<float4*>(&As[(slot / SA::QK) * LDA_ + (slot % SA::QK) * 4]) = v; }
+            else { if (slot < BKT * (BM / 4)) *reinterpret_cast<float4*>(&As[(slot / (BM / 4)) * LDA_ + (slot % (BM / 4)) * 4]) = v; }
         }
 #pragma unroll
         for (int s = 0; s < SB::SLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
-            if (BKC) { if (slot < BN * SB::QK) *reinterpret_cast<float4*>(&Bs[(slot / SB::QK) * LDB_ + (slot % SB::QK) * 4]) = rb_[s]; }
-            else { if (slot < BKT * (BN / 4)) *reinterpret_cast<float4*>(&Bs[(slot / (BN / 4)) * LDB_ + (slot % (BN / 4)) * 4]) = rb_[s]; }
+            float4 v = rb_[s];
+            if (d.actB.mode != 0 && b_base[s] != nullptr) {
+                if (BKC) { const int k = kc + (slot % SB::QK) * 4; if (k < k_end) v = act4_masked(v, d.actB, k, k_end); }
+                else { const int k = kc + slot / (BN / 4), gj = col0 + (slot % (BN / 4)) * 4; if (k < k_end) v = act4_masked(v, d.actB, gj, N); }
+            }
+            if (BKC) { if (slot < BN * SB::QK) *reinterpret_cast<float4*>(&Bs[(slot / SB::QK) * LDB_ + (slot % SB::QK) * 4]) = v; }
+            else { if (slot < BKT * (BN / 4)) *reinterpret_cast<float4*>(&Bs[(slot / (BN / 4)) * LDB_ + (slot % (BN / 4)) * 4]) = v; }
         }
     };
 
@@ -352,13 +367,15 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
 #pragma unroll
     for (int dd = 0; dd < DEPTH; ++dd)
         if (dd < nchunks) fetch(ra[dd], rb[dd], k_begin + dd * BKT);
+    dpp_stamp(ga.prof, 1);
     for (int c0 = 0; c0 < nchunks; c0 += DEPTH) {
 #pragma unroll
         for (int dd = 0; dd < DEPTH; ++dd) {
             const int c = c0 + dd;
             if (c < nchunks) {
-                commit(ra[dd], rb[dd]);
+                commit(ra[dd], rb[dd], k_begin + c * BKT);
                 __syncthreads();
+                if (c == 0) dpp_stamp(ga.prof, 2);
                 if (c + DEPTH < nchunks) fetch(ra[dd], rb[dd], k_begin + (c + DEPTH) * BKT);
 #pragma unroll
                 for (int e4 = 0; e4 < KL; e4 += 4) {
@@ -398,6 +415,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         }
     }
 
+    dpp_stamp(ga.prof, 3);
     // WIDE = false: instantiations that never take the LDS-image epilogue (split-K filter gradients) do not carry its registers
     if (WIDE && ga.wide) {
         const int nvalid = (M - row0 < BM) ? (M - row0) : BM;
@@ -407,6 +425,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         });
     }
     else gemm_epilogue<RM, CN, WM, WN, BM, BN>(acc, d, row0, col0, wm, wn, l15, kq, As);
+    dpp_stamp(ga.prof, 4);
 }
 
 // ---- row-streaming variant for the skinny conv GEMMs (M = pixels >> K, N) -------------------------------------------------
@@ -612,6 +631,16 @@ int launch_layout(const GemmArgs& ga, hipStream_t st) {
             return DPP_E_UNSUPPORTED;
         return dpp_launch_status();
     }
+    if constexpr ((BM == 64 && WM == 4 && BN <= 64) || (BM == 32 && BN == 64 && WM == 1)) {
+        if (ga.bk == 64 && d.a_kc && d.variant == 2) {
+            // variant 2: a ring of FOUR 64-deep chunks in flight (the whole K of the K = 256 layers): these GEMMs spend their K loop
+            // waiting for one chunk after the other (tools/phase_profile.py: 2-3 us per chunk, 0.2 us of MFMAs), with all loads
+            // issued up front they wait once
+            if (d.b_kc) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, true, 4>), grid, dim3(DPP_THREADS), 0, st, ga);
+            else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, false, 4>), grid, dim3(DPP_THREADS), 0, st, ga);
+            return dpp_launch_status();
+        }
+    }
     if (ga.bk == 64 && d.a_kc) {
         // long K-contiguous reductions (stage-2..4 1x1 convolutions and FC layers, K >= 128; measured 4.80 -> 4.74 ms per step): half as many global -> LDS round trips
         if (d.b_kc) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);
@@ -641,6 +670,7 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     if (!dp || !dp->A || !dp->B || dp->M <= 0 || dp->N <= 0 || dp->K <= 0) return DPP_E_BADARG;
     GemmArgs ga;
     ga.d = *dp;
+    ga.prof = dpp_prof_buffer;
     dpp_gemm_desc& d = ga.d;
     if (d.splitk < 1) d.splitk = 1;
     if (d.splitk > 1 && !d.partial) return DPP_E_BADARG;

@@ -13,6 +13,13 @@
 #undef blockDim
 
 thread_local dpp_plan* dpp_tls_plan = nullptr;
+unsigned long long* dpp_prof_buffer = nullptr;
+
+// tools/phase_profile.py (profiling build only): device buffer of 16 uint64 per workgroup that instrumented kernels stamp
+extern "C" int dpp_prof_set(void* buf) {
+    dpp_prof_buffer = static_cast<unsigned long long*>(buf);
+    return DPP_OK;
+}
 
 struct dpp_plan {
     std::vector<dpp_plan_node> nodes;

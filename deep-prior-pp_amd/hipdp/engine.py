@@ -222,8 +222,18 @@ def _param_specs(net, layers):
     return specs
 
 
+def _dedupe_specs(specs):
+    """A parameter shared by several layers (copyLayer: ScaleNet's shared_conv, scalenet.py:176-180) owns ONE slot."""
+    seen, out = set(), []
+    for sp in specs:
+        if sp[0].auto_name not in seen:
+            seen.add(sp[0].auto_name)
+            out.append(sp)
+    return out
+
+
 def get_store(net, rt, layers):
-    specs = _param_specs(net, layers)
+    specs = _dedupe_specs(_param_specs(net, layers))
     names = [p.auto_name for (p, _, _, _) in specs]
     store = getattr(net, '_param_store', None)
     if store is not None and store.rt is rt and [s['param'].auto_name for s in store.slots] == names and \
@@ -291,6 +301,9 @@ def is_fc1_shape(Nb, K, Nout):
     """The weight-streaming shape: tens of MB of weights for at most a few hundred rows."""
     return K >= FC1_MIN_K and Nout >= 64 and Nout % 4 == 0 and K % 4 == 0
 ROWSTREAM = os.environ.get('DPP_ROWSTREAM', '0') != '0'      # measured: no gain over the LDS-tiled kernel yet
+# 1x1 convolutions whose reduction is at least this deep run dpp_gemm variant 2 (four 64-deep K chunks in flight instead of one):
+# the K = 256 layers of stages 3-4 otherwise wait for one chunk after the other (tools/phase_profile.py).  0 = never.
+DEEP_MIN_K = int(os.environ.get('DPP_GEMM_DEEP_MIN_K', '256'))
 
 
 def rowstream_plan(M, N, K, b_kc):
@@ -403,9 +416,8 @@ class CompiledNet(object):
                 # (poseregnettrainer.py:101-107); the kernel-layout W holds the same values in another order
                 # (data parallel: every rank's cost is its share of the global cost, so each adds 1/world of the regulariser)
                 share = self.weight_decay / (dp.world if (dp is not None and train) else 1)
-                for l in self.layers:
-                    if hasattr(l, 'W'):
-                        self.lossplan.add(ops.sumsq(rt, self.store.view(l.W), int(np.prod(l.W.shape)), share, self.cost, 1))
+                for W in self._unique_weights():
+                    self.lossplan.add(ops.sumsq(rt, self.store.view(W), int(np.prod(W.shape)), share, self.cost, 1))
             if not train:
                 d = loss['nDims'] if loss.get('kind', 'embedding') != 'embedding' else self.out_dim
                 rows = self.N * (loss['numJoints'] if loss.get('kind', 'embedding') != 'embedding' else 1)
@@ -468,6 +480,28 @@ class CompiledNet(object):
             b = view.bn
             return ops.act(mode, b.mean, b.scale, b.beta_buf, view.chan)
         return ops.act(mode, None, None, None, view.chan)
+
+    def _grad_view(self, param):
+        """Where a layer's backward pass writes the gradient of `param`: its slot of the flat gradient buffer -- or, for the
+        second and later layers that SHARE the parameter, a private buffer that is added to the slot after the pass (the
+        gradient of a shared weight is the sum over its uses)."""
+        uses = self.__dict__.setdefault('_grad_uses', {})
+        n = uses.get(param.auto_name, 0)
+        uses[param.auto_name] = n + 1
+        slot = self.store.view(param, 'g')
+        if n == 0:
+            return slot
+        priv = self.rt.alloc(slot.size, zero=False)
+        self.__dict__.setdefault('_shared_grad_adds', []).append((slot, priv))
+        return priv
+
+    def _unique_weights(self):
+        seen, out = set(), []
+        for l in self.layers:
+            if hasattr(l, 'W') and l.W.auto_name not in seen:
+                seen.add(l.W.auto_name)
+                out.append(l.W)
+        return out
 
     def _fc1_stream(self):
         return FC1_STREAM == '1' or (FC1_STREAM == 'bf16' and self.prec == 1)
@@ -691,8 +725,9 @@ class CompiledNet(object):
                 out.stats = (rt.alloc((nblk, 2, Co), zero=False), nblk, tile[0])
                 epi = ops.epilogue(stats=out.stats[0])
             mp = RowMap.strided(s[0], Ho, Wo, Hi, Wi) if s[0] != 1 else None
+            variant = 1 if rs is not None else (2 if (DEEP_MIN_K and Ci >= DEEP_MIN_K) else 0)
             self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
-                                  bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=1 if rs is not None else 0,
+                                  bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=variant,
                                   name='conv1x1_%d' % layer.layerNum))
         else:
             bm = conv3x3_bm(M, Co)
@@ -934,15 +969,16 @@ class CompiledNet(object):
                 raise NotImplementedError(kind)
         self.bwd.join()
         self.bwd.add(self.reduce_jobs.launch())       # every filter / bias gradient partial of the pass, one launch
+        for slot, priv in self.__dict__.get('_shared_grad_adds', []):
+            self.bwd.add(ops.axpy(rt, slot, priv, 1.0, slot.size))     # shared parameters: sum of the per-use gradients
         # cost += wd * sum(W^2): gradient 2*wd*W.  Single process: the last step of the backward plan.  Data parallel: the
         # regulariser is NOT a per-shard partial sum, so it is added once, AFTER the gradient all-reduce (added before, the
         # sum over ranks would scale it by the world size -- and the axpy would write the slice whose all-reduce the early bucket
         # still has in flight)
         self._wd_ops = []
         if self.weight_decay and not self.net.hasDropout():
-            for l in self.layers:
-                if hasattr(l, 'W'):
-                    self._wd_ops.append(ops.axpy(rt, st.view(l.W, 'g'), st.view(l.W), 2.0 * self.weight_decay, int(np.prod(l.W.shape))))
+            for W in self._unique_weights():
+                self._wd_ops.append(ops.axpy(rt, st.view(W, 'g'), st.view(W), 2.0 * self.weight_decay, int(np.prod(W.shape))))
         if self.dp is None:
             for o in self._wd_ops:
                 self.bwd.add(o)
@@ -994,7 +1030,7 @@ class CompiledNet(object):
         k, s = tuple(c.filterDim), c.stride[0]
         M = N * Ho * Wo
         act = self._act(src)
-        gW, gb = st.view(layer.W, 'g'), st.view(layer.b, 'g')
+        gW, gb = self._grad_view(layer.W), self._grad_view(layer.b)
         if io.get('residual') is not None:
             io['residual'].pending.append(dY)                 # identity path of the fused residual add
         need_dx = src.base not in self.x_ins
@@ -1045,8 +1081,9 @@ class CompiledNet(object):
                     nb2 = -(-M // tile[0])
                     tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
                     epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
+                variant = 1 if (rs is not None and dY_act is None) else (2 if (DEEP_MIN_K and Co >= DEEP_MIN_K and dY_act is None) else 0)
                 self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
-                                      residual=dst if acc else None, tile=tile, epi=epi, variant=1 if rs is not None and dY_act is None else 0,
+                                      residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
                                       name='dgrad1x1_%d' % layer.layerNum))
                 tgt.grad_written = True
             if dY_keep is not None:
@@ -1079,7 +1116,7 @@ class CompiledNet(object):
         rt, st = self.rt, self.store
         Nb, K = src.shape
         Nout = layer.cfgParams.outputDim[1]
-        gW, gb = st.view(layer.W, 'g'), st.view(layer.b, 'g')
+        gW, gb = self._grad_view(layer.W), self._grad_view(layer.b)
         act = self._act(src)
         self.bwd.fork()
         self._bias_grad(dY, Nb, Nout, gb)
@@ -1123,12 +1160,12 @@ class CompiledNet(object):
         g, src = io['geom'], io['in_view']
         nW = g['Co'] * g['kh'] * g['kw'] * g['Ci']
         self.bwd.fork()
-        self._bias_grad(dY, io['out'].rows, g['Co'], st.view(layer.b, 'g'))
+        self._bias_grad(dY, io['out'].rows, g['Co'], self._grad_view(layer.b))
         nblk = rt.lib.dpp_convpool_wgrad_blocks(g['N'], g['Hp'], g['Wp'])
         part = rt.alloc(nblk * nW, zero=False)
         self.bwd.add(ops.convpool_wgrad(rt, src.base.buf, g['N'], g['H'], g['W'], g['Ci'], dY, io['ties'], g['kh'], g['kw'], g['pad'],
                                         g['Co'], g['pool'], part, actX=self._act(src), name='convpool_wgrad_%d' % layer.layerNum), side=True)
-        self.reduce_jobs.add(part, nblk, nW, st.view(layer.W, 'g'))
+        self.reduce_jobs.add(part, nblk, nW, self._grad_view(layer.W))
         if src.base not in self.x_ins:
             tgt, dst = self._view_grad(src)
             if tgt.grad_written:
@@ -1145,7 +1182,7 @@ class CompiledNet(object):
         Co = layer.cfgParams.nFilters
         out = io['out']
         self.bwd.fork()
-        self._bias_grad(dY, out.rows, Co, st.view(layer.b, 'g'))
+        self._bias_grad(dY, out.rows, Co, self._grad_view(layer.b))
         tpb = 8
         nblk = rt.lib.dpp_stem_wgrad_blocks(N, H, W, tpb)
         part = rt.alloc(nblk * Co * 25, zero=False)
@@ -1154,7 +1191,7 @@ class CompiledNet(object):
         # (tools/tail_probe.py): it runs on the main stream.
         self.bwd.add(ops.stem_wgrad(rt, self.x_in.buf, N, H, W, dY, io['argmax'], Co, part, tpb),
                      side=os.environ.get('DPP_STEM_WGRAD_SIDE', '0') == '1')
-        self.reduce_jobs.add(part, nblk, Co * 25, st.view(layer.W, 'g'))
+        self.reduce_jobs.add(part, nblk, Co * 25, self._grad_view(layer.W))
 
     # ------------------------------------------------------------------------------------------ execution
     def set_input(self, x):

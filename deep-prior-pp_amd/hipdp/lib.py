@@ -133,6 +133,7 @@ SIGNATURES = {
     'dpp_pca_workspace_bytes': (C.c_size_t, [C.c_long, C.c_int]),
     'dpp_pca_fit': (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_pose_eval': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
+    'dpp_prof_set': (C.c_int, [C.c_void_p]),
     'dpp_plan_create': (C.c_int, [C.POINTER(C.c_void_p)]),
     'dpp_plan_destroy': (C.c_int, [C.c_void_p]),
     'dpp_plan_record_begin': (C.c_int, [C.c_void_p]),

@@ -52,8 +52,10 @@ class ScaleNet(NetBase):
             raise Exception("Cannot create a Net without config parameters (ie. cfgParams==None)")
         if inputVar is not None:
             raise Exception("Do not give inputVar, created inline")
-        if twin is not None or cfgParams.shared_conv:
-            raise NotImplementedError("weight sharing between towers / twin nets (scalenet.py:176-178) is not provided")
+        if twin is not None:
+            # a second net instance on the first one's parameters (siamese training; no shipped main uses it): the parameter store
+            # is per net here
+            raise NotImplementedError("twin nets (scalenet.py:176) are not provided; weight sharing between the towers is (shared_conv)")
         self._params_filter = []
         self._weights_filter = []
         self.inputVar = [tensor4('x{}'.format(i)) for i in range(cfgParams.numInputs)]
@@ -70,6 +72,9 @@ class ScaleNet(NetBase):
             else:
                 inp = self.layers[-1].output
             ctor = _LAYER_CLASSES[layerParam.__class__.__name__[:-11]]           # '<X>LayerParams' -> '<X>'
-            self.layers.append(ctor(rng, inputVar=inp, cfgParams=layerParam, copyLayer=None, layerNum=len(self.layers)))
+            # shared_conv: towers 2 and 3 run on the FIRST tower's filters and biases (scalenet.py:177-178) -- same shapes, the
+            # towers differ in pooling only
+            cl = self.layers[i % cfgParams.inpConv] if (cfgParams.shared_conv is True and cfgParams.inpConv - 1 < i < nConv) else None
+            self.layers.append(ctor(rng, inputVar=inp, cfgParams=layerParam, copyLayer=cl, layerNum=len(self.layers)))
         self.output = self.layers[-1].output
         self.load(self.cfgParams.loadFile)

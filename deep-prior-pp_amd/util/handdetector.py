@@ -244,7 +244,7 @@ class HandDetector(object):
         if len(size) != 3 or len(dsize) != 2:
             raise ValueError("Size must be 3D and dsize 2D bounding box")
         if com is None:
-            raise NotImplementedError("whole-frame CoM detection (calculateCoM(self.dpt), detect) is not provided yet")
+            com = self.calculateCoM(self.dpt)            # handdetector.py:401-402: centre of mass of the whole (range-limited) frame
         if dsize[0] != dsize[1]:
             raise NotImplementedError("square destination sizes only")
         frame = numpy.asarray(self.dpt, numpy.float32)[None]
@@ -327,7 +327,8 @@ class HandDetector(object):
         return com
 
     def detect(self, *args, **kwargs):
-        raise NotImplementedError("hand detection / tracking (OpenCV contour analysis) is not provided (DESIGN.md section 8)")
+        raise NotImplementedError("hand detection / tracking (cv2.findContours slab analysis, handdetector.py:504-631) belongs to the realtime demo "
+                                  "(util/realtimehandposepipeline.py is its only caller), which is out of scope (SURVEY.md section 2)")
 
     track = detect
 

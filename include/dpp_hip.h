@@ -111,7 +111,8 @@ typedef struct {
     int bm, bn, wm; /* tile: rows, cols, waves along M (4 or 1); 0 = choose */
     int variant;    /* 0: LDS-tiled kernel (any layout, split-K); 1: row-streaming kernel for skinny conv GEMMs (a_kc = 1,
                        splitk = 1, bm in {64,128}, bn in {16,32,64}): A fragments straight from global memory, no barrier
-                       in the K loop */
+                       in the K loop; 2: the LDS-tiled kernel with four 64-deep K chunks in flight (a_kc = 1, K >= 128, tiles
+                       64 x {16,32,64} and 32 x 64; other shapes fall back to variant 0) */
     dpp_epilogue epi; /* fused statistics / BatchNorm-backward epilogue (requires splitk == 1) */
 } dpp_gemm_desc;
 int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);
@@ -337,6 +338,9 @@ int dpp_pose_eval(const float* gt, const float* pred, int N, int J, const double
  *                         branches); two_lanes == 0 chains everything in recorded order
  *   dpp_plan_graph_launch replays it on `stream`
  * Device pointers recorded in a plan must stay valid for its lifetime (the caller owns them, as everywhere in this ABI). */
+/* Profiling build only (make -C csrc prof): kernels compiled with phase stamps write 16 x uint64 of 100 MHz ticks per workgroup
+ * to `buf` (tools/phase_profile.py); in the product build the stamps are compiled out and this only stores the pointer. */
+int dpp_prof_set(void* buf);
 typedef struct dpp_plan dpp_plan;
 int dpp_plan_create(dpp_plan** out);
 int dpp_plan_destroy(dpp_plan* plan);

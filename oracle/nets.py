@@ -126,7 +126,7 @@ def build_poseregnet(type=0, nChan=1, wIn=128, hIn=128, batchSize=128, numJoints
                 in_dim=(batchSize, nChan, hIn, wIn), out_dim=(batchSize, numJoints * nDims), name='PoseRegNet')
 
 
-def build_scalenet(type=1, nChan=1, wIn=128, hIn=128, batchSize=128, numJoints=1, nDims=3, resizeFactor=2):
+def build_scalenet(type=1, nChan=1, wIn=128, hIn=128, batchSize=128, numJoints=1, nDims=3, resizeFactor=2, shared_conv=False):
     """ScaleNet type 1, /root/reference/src/net/scalenet.py:49-127, 150-180: three conv-pool towers on the crop and its
     1/2 and 1/4 centre crops, flattened and concatenated, then FC 1024 - dropout - FC 1024 - dropout - FC out."""
     if type != 1:
@@ -144,6 +144,9 @@ def build_scalenet(type=1, nChan=1, wIn=128, hIn=128, batchSize=128, numJoints=1
             od = (cd[0], cd[1], cd[2] // pool[0], cd[3] // pool[1])
             layers.append(dict(kind='convpool', src=src, in_dim=d, out_dim=od, nf=8, k=k, stride=(1, 1), border='valid', pool=pool,
                                act='relu'))
+            if shared_conv and t > 0:
+                # scalenet.py:176-180: towers 2 and 3 are built with copyLayer = the first tower's layer: the SAME W and b
+                layers[-1]['share'] = (len(layers) - 1) % len(tower)
             src, d = ('layer', len(layers) - 1), od
         tails.append((src, d[1] * d[2] * d[3]))
     src = ('concat',) + tuple(('flatten', r) for r, _ in tails)
@@ -189,6 +192,9 @@ def init_params(net, rng, dtype=np.float32):
     P = {}
     for i, l in enumerate(net['layers']):
         k = l['kind']
+        if 'share' in l:
+            P[i] = P[l['share']]                     # copyLayer: no initialiser call, the rng is not consumed
+            continue
         if k in ('conv', 'convpool'):
             shape = (l['nf'], l['in_dim'][1], l['k'][0], l['k'][1])
             bound = np.sqrt(2. / np.prod(shape[1:]))
@@ -226,14 +232,19 @@ def perturb_bn(P, net, rng, dtype=None):
 
 
 def cast_params(P, dtype):
-    return {i: [np.asarray(a, dtype) for a in v] for i, v in P.items()}
+    out, seen = {}, {}
+    for i, v in P.items():
+        if id(v) not in seen:
+            seen[id(v)] = [np.asarray(a, dtype) for a in v]
+        out[i] = seen[id(v)]                         # layers that share parameters keep sharing them
+    return out
 
 
 def trained_param_list(net, P):
     """The (layer, slot) pairs of net.params: conv/fc [W, b], bn [beta, gamma] (batchnormlayer.py:146-151)."""
     out = []
     for i, l in enumerate(net['layers']):
-        if l['kind'] in ('conv', 'convpool', 'fc', 'bn'):
+        if l['kind'] in ('conv', 'convpool', 'fc', 'bn') and 'share' not in l:      # a shared parameter is trained once
             out += [(i, 0), (i, 1)]
     return out
 
@@ -376,6 +387,10 @@ def backward(net, P, cache, dout, weight_decay=0.0):
             raise NotImplementedError(k)
         if need_dx:
             push(l['src'], dx)
+    for i, l in enumerate(net['layers']):            # shared parameters: the gradient is the sum over the layers that use them
+        if 'share' in l and i in G:
+            src = l['share']
+            G[src] = [a + b for a, b in zip(G[src], G.pop(i))]
     return G
 
 

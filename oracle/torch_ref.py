@@ -20,11 +20,15 @@ BN_EPS = float(np.float32(1e-4))
 
 
 def to_torch(P, dtype=torch.float64, requires_grad=True):
-    T = {}
+    T, seen = {}, {}
     for i, v in P.items():
+        if id(v) in seen:                            # layers that share parameters (copyLayer) share the leaf tensors
+            T[i] = seen[id(v)]
+            continue
         T[i] = [torch.tensor(np.asarray(a), dtype=dtype) for a in v]
         for t in T[i][:2]:
             t.requires_grad_(requires_grad)
+        seen[id(v)] = T[i]
     return T
 
 
@@ -67,7 +71,8 @@ def _relu(a, mask=None):
 
 def forward(net, T, x, train, masks=None):
     """masks (optional): {layer index: bool array} -- for a 'relu' layer or an 'fc' layer with ReLU the elements that pass,
-    for a 'convpool' layer with pooling the tie pattern [N][C][oh][ow][ph*pw] of the windows.  The gradient of a deep ReLU net
+    for a 'convpool' layer with pooling the tie pattern [N][C][oh][ow][ph*pw] of the windows (and, under the key
+    ('relu', layer index), the pass pattern of its own ReLU).  The gradient of a deep ReLU net
     is discontinuous in its inputs: two float32 evaluations (or one float32 and one float64) disagree on the sign of the
     handful of activations that sit within rounding of zero, and every such flip moves all upstream gradients by a fraction
     of a percent.  Handing the device's own decisions to the oracle removes that (legitimate) difference, so that what is
@@ -105,7 +110,7 @@ def forward(net, T, x, train, masks=None):
                     ties = ties.reshape(N_, C_, oh, ow, ph, pw).permute(0, 1, 2, 4, 3, 5)
                 c = _MaxPoolTies.apply(c, ph, pw, ties)
             c = c + T[i][1][None, :, None, None]
-            vals[i] = torch.clamp_min(c, 0) if l['act'] == 'relu' else c
+            vals[i] = _relu(c, mk(('relu', i))) if l['act'] == 'relu' else c
         elif k == 'conv':
             vals[i] = _conv(a, T[i][0], l['stride'], l['border']) + T[i][1][None, :, None, None]
         elif k == 'bn':

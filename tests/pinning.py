@@ -36,10 +36,19 @@ def device_masks(eng, net):
             m = pre >= 0
             if lay.__class__.__name__ == 'HiddenLayer':
                 masks[idx[id(lay)]] = m
+            elif lay.__class__.__name__ == 'ConvPoolLayer':
+                # conv -> pool -> bias -> ReLU: the ReLU decision on the pooled, biased map (key ('relu', layer))
+                masks[('relu', idx[id(lay)])] = np.ascontiguousarray(np.moveaxis(m, -1, 1))
     for lay in net.layers:
         io = eng.layer_io.get(id(lay))
         if io is not None and io.get('stem') and io.get('argmax') is not None:
             bits = io['argmax'].get()                              # [N][Hp][Wp][Co] uint8, bit j = window element j (row-major)
             t = np.stack([(bits >> j) & 1 for j in range(4)], axis=-1).astype(bool)      # [N][Hp][Wp][Co][4]
             masks[idx[id(lay)]] = np.ascontiguousarray(np.moveaxis(t, 3, 1))              # [N][Co][Hp][Wp][4]
+        elif io is not None and io.get('ties') is not None:
+            g = io['geom']
+            pp = g['pool'] * g['pool']
+            bits = io['ties'].get().astype(np.uint32)              # [N][Hp][Wp][Co] uint16, bit j = window element j (row-major)
+            t = np.stack([(bits >> j) & 1 for j in range(pp)], axis=-1).astype(bool)
+            masks[idx[id(lay)]] = np.ascontiguousarray(np.moveaxis(t, 3, 1))
     return masks

@@ -132,8 +132,13 @@ def test_crop_area_3d_matches_oracle(backend):
         d, _, _ = A.detector_preprocess(frames[2])
         ref, Mref, _ = A.crop_area_3d(d, coms[2], cubes[2], fx, fy)
         assert np.array_equal(crop, ref) and np.allclose(M, Mref, rtol=1e-6) and hd.getNDValue() == 0.
+        # com=None: the crop is centred on the centre of mass of the whole range-limited frame (handdetector.py:401-402)
+        com0 = hd.calculateCoM(hd.dpt)
+        crop0, M0, c0 = hd.cropArea3D(com=None, size=tuple(cubes[2]), dsize=(128, 128))
+        ref0, Mref0, _ = A.crop_area_3d(d, com0.astype(np.float32), cubes[2], fx, fy)
+        assert np.array_equal(crop0, ref0) and np.allclose(M0, Mref0, rtol=1e-6) and np.allclose(c0, com0, rtol=1e-6)
         with pytest.raises(NotImplementedError):
-            hd.cropArea3D(com=None)
+            hd.detect()
 
 
 @pytest.mark.parametrize('backend', BACKENDS)

@@ -127,6 +127,8 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
     'fc1stream': the HiddenLayer behind the last conv map on the weight-streaming kernel (dpp_fc_gemm: forward with split-K,
     data gradient, weight gradient with the BN+ReLU prologue) -- the full-size nets take that path for FC1, this 32x32 net
     (K = 1 024) only with the threshold lowered."""
+    if type_ == 'lazy2' and backend == 'emu':
+        pytest.skip("the opt-in lazy2 plan (measured slower, off by default) is exercised on the GPU tier only; 'lazy' covers the mode-4 operand here")
     if type_ in ('lazy', 'lazy2'):       # lazy2: only the data gradient does, and leaves the tensor it forms for the filter gradient
         monkeypatch.setattr(engine, 'LAZY_BN_BWD', 1 if type_ == 'lazy' else 2)
         type_ = 0

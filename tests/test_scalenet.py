@@ -134,3 +134,80 @@ def test_com_refine_script_flow(backend, tmp_path):
     off = hd.refineCoM(crop0, (250., 250., 250.), com0)
     expect = di.joint3DToImg(off + di.jointImgTo3D(com0))
     np.testing.assert_allclose(com, expect, rtol=0, atol=1e-3)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_scalenet_shared_conv_towers(backend):
+    """ScaleNetParams(shared_conv=True) (scalenet.py:176-180): towers 2 and 3 run on the first tower's filters and biases.  One
+    parameter slot per shared weight, forward on all three towers from it, and a gradient that is the SUM over the towers --
+    against the oracle; one ADAM step then moves the single copy."""
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    B = 4
+    net = ScaleNet(np.random.RandomState(23455), cfgParams=ScaleNetParams(type=1, batchSize=B, numJoints=1, nDims=3, shared_conv=True))
+    assert net.layers[3].W is net.layers[0].W and net.layers[7].b is net.layers[1].b and net.layers[8].W is net.layers[2].W
+    assert len(net.params) == 2 * 3 + 2 * 3                       # three shared conv layers + three FC layers, each (W, b)
+    onet = nets.build_scalenet(batchSize=B, numJoints=1, nDims=3, shared_conv=True)
+    P = nets.init_params(onet, np.random.RandomState(23455), np.float32)
+    assert P[3] is P[0] and P[8] is P[2]
+    for i in (0, 1, 2, 9, 11, 13):
+        P[i][1] = np.random.RandomState(100 + i).normal(0, 0.05, P[i][1].shape).astype(np.float32)
+    for i, l in enumerate(net.layers):
+        if i in P and 'share' not in onet['layers'][i]:
+            for p, v in zip(l.params, P[i]):
+                p.set_value(v)
+    # the same RandomState draws as the reference: copyLayer layers consume nothing, so the FC weights follow the first tower's
+    np.testing.assert_array_equal(net.layers[9].W.get_value(), P[9][0])
+    rng = np.random.RandomState(9)
+    xs = nets.scalenet_inputs(nets.synthetic_crops(rng, B, 128, 128, np.float32))
+    y = rng.normal(0, 0.3, (B, 3)).astype(np.float32)
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    assert len(eng.store.slots) == 12
+    cost, out = eng.cost_and_grads(xs, y)
+    masks = {i: eng.dropout_masks[id(l)][0].get().astype(np.float64) for i, l in enumerate(net.layers) if id(l) in eng.dropout_masks}
+    # the float64 oracle with the device's own ReLU / pool-tie decisions (tests/pinning.py): a float32 near-tie in one pooling
+    # window would otherwise route one gradient differently and move 200 of a filter bank's 1 600 elements by half a percent
+    from oracle import torch_ref
+    from tests.pinning import device_masks
+    c_ref, G_all, out_ref = _torch_with_dropout(torch_ref, onet, nets.cast_params(P, np.float64), xs, y, masks, device_masks(eng, net))
+    G_ref = {i: g for i, g in G_all.items() if 'share' not in onet['layers'][i] and onet['layers'][i]['kind'] != 'dropout'}
+    assert np.abs(out - out_ref).max() * MM < 1e-3 and abs(cost - c_ref) < 1e-5 * abs(c_ref)
+    assert sorted(G_ref) == [0, 1, 2, 9, 11, 13]
+    gmax = max(np.abs(G_ref[i][s]).max() for i in G_ref for s in range(2))
+    for i in G_ref:
+        for s in range(2):
+            got = eng.store.read_grad(net.layers[i].params[s])
+            np.testing.assert_allclose(got, G_ref[i][s], rtol=0, atol=2e-4 * max(np.abs(G_ref[i][s]).max(), 5e-3 * gmax),
+                                       err_msg='layer %d slot %d' % (i, s))
+    # the shared gradient really is a sum: the first tower alone gives something else
+    _, G_solo, _, _ = nets.cost_and_grads(nets.build_scalenet(batchSize=B, numJoints=1, nDims=3), {i: [a.astype(np.float64) for a in P[i]] for i in P},
+                                          [a.astype(np.float64) for a in xs], y.astype(np.float64), True, masks)
+    assert np.abs(G_solo[0][0] - G_ref[0][0]).max() > 1e-3 * np.abs(G_ref[0][0]).max()
+    # ... and the numpy oracle's sum over the towers agrees with autograd's accumulation into the shared leaves
+    _, G_np, _, _ = nets.cost_and_grads(onet, nets.cast_params(P, np.float64), [a.astype(np.float64) for a in xs], y.astype(np.float64), True, masks)
+    assert sorted(G_np) == sorted(G_ref)
+    w0 = net.layers[0].W.get_value().copy()
+    assert np.isfinite(eng.train_step(xs, y, 1e-3))
+    w1 = net.layers[0].W.get_value()
+    assert np.abs(w1 - w0).max() > 1e-4 and np.array_equal(net.layers[6].W.get_value(), w1)
+
+
+def _torch_with_dropout(torch_ref, onet, P64, xs, y, dropout_masks, pin):
+    """torch_ref.forward models dropout in training mode as the identity: apply the device's masks by folding them into the
+    ReLU decision of the HiddenLayer in front of each DropoutLayer (mask * relu(pre) == pre * (mask & pass) for 0/1 masks)."""
+    import torch
+    pin = dict(pin)
+    for i, l in enumerate(onet['layers']):
+        if l['kind'] == 'dropout':
+            src = l['src'][1]
+            pin[src] = np.asarray(pin[src], bool) & (np.asarray(dropout_masks[i]) > 0)
+    T = torch_ref.to_torch(P64, torch.float64)
+    xt = [torch.as_tensor(a, dtype=torch.float64) for a in xs]
+    out, _ = torch_ref.forward(onet, T, xt, True, pin)
+    cost = ((out - torch.tensor(y, dtype=torch.float64)) ** 2).sum(dim=1).mean()
+    cost.backward()
+    G = {}
+    for i in T:
+        if T[i][0].grad is not None:
+            G[i] = [T[i][0].grad.numpy(), T[i][1].grad.numpy()]
+    return float(cost.detach()), G, out.detach().numpy()

@@ -172,16 +172,17 @@ def test_sample_random_poses_vectorised_equals_loop(flip):
 
 
 def _small_trainer(rt, tmp_path, n_train, budget_mb=None, augment=False, numChunks=1, para_load=False, seed=23455):
-    """A PoseRegNetTrainer on a small ResNet (32x32 crops, batch 4, labels = the 16 x 3 joints themselves, no PCA prior)."""
+    """A PoseRegNetTrainer on the small conv-pool PoseRegNet (48x48 crops, batch 4, labels = the 16 x 3 joints themselves, no PCA
+    prior): the paging logic under test is the trainer's, the cheapest net keeps the emulator tier quick."""
     R.set_default_runtime(rt)
     rng = np.random.RandomState(seed)
-    J, B, size = 16, 4, 32
+    J, B, size = 16, 4, 48
     di = ICVLImporter('../data/ICVL/')
     x, com, cube, M, gt = synth(n_train, size, J, 1)
     vx, _, vcube, _, vgt = synth(4, size, J, 2)
     y = (gt / (cube[:, 2] / 2.)[:, None, None]).astype('float32').reshape(n_train, J * 3)
     vy = (vgt / (vcube[:, 2] / 2.)[:, None, None]).astype('float32').reshape(4, J * 3)
-    net = ResNet(rng, cfgParams=ResNetParams(type=0, nChan=1, wIn=size, hIn=size, batchSize=B, numJoints=J, nDims=3))
+    net = PoseRegNet(rng, cfgParams=PoseRegNetParams(type=0, nChan=1, wIn=size, hIn=size, batchSize=B, numJoints=J, nDims=3))
     p = PoseRegNetTrainerParams()
     p.batch_size, p.learning_rate, p.validation_frequency, p.snapshot_last = B, 0.001, 1000, 1000
     p.para_load = para_load
@@ -205,12 +206,12 @@ def test_paged_training_set_trains_like_the_resident_one(backend, tmp_path):
     macro-batches on the host (keyDB + the padded keyDBlast) and paged through a one-macro-batch device window.  Without
     augmentation the minibatch sequence is the same as with everything resident, so the trained weights must be bit-identical."""
     rt = get_runtime(backend)
-    n = 22                                                          # 6 minibatches of 4; sample = 32*32*4 B = 4 KB
+    n = 22                                                          # 6 minibatches of 4; sample = 48*48*4 B = 9 KB
     res, net_r, _ = _small_trainer(rt, tmp_path / 'r', n)
     assert res.getNumMacroBatches() == 1
     costs_r, _, _ = res.train(n_epochs=1)
     w_r = [p.get_value().copy() for p in net_r.params]
-    pag, net_p, (x, y, com, cube, M) = _small_trainer(rt, tmp_path / 'p', n, budget_mb=2.2 * 4 * 4096 / 1024. ** 2)
+    pag, net_p, (x, y, com, cube, M) = _small_trainer(rt, tmp_path / 'p', n, budget_mb=2.2 * 4 * 9216 / 1024. ** 2)
     nmb, spm = pag.getNumMacroBatches(), pag.getNumSamplesPerMacroBatch()
     assert nmb == 3 and spm == 8 and pag.getNumMiniBatches() == 6
     assert pag.train_data_xDB.shape[0] == 16 and pag.train_data_xDBlast.shape[0] == 8 and pag.train_data_x.shape[0] == 8
@@ -236,7 +237,7 @@ def test_paged_training_set_with_device_augmentation(backend, tmp_path):
     window (labels = joints: formed from label * cube_z / 2 on the device, poseregnettrainer.py:228-240), and its 'none'-mode
     samples come out untouched (rows of the right macro-batch: a mix-up of windows would change them)."""
     rt = get_runtime(backend)
-    tr, net, (x, y, com, cube, M) = _small_trainer(rt, tmp_path, 22, budget_mb=2.2 * 4 * 4096 / 1024. ** 2, augment=True)
+    tr, net, (x, y, com, cube, M) = _small_trainer(rt, tmp_path, 22, budget_mb=2.2 * 4 * 9216 / 1024. ** 2, augment=True)
     assert tr.getNumMacroBatches() == 3
     seen = []
     orig = tr.augment_poses

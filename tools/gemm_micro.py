@@ -18,16 +18,19 @@ REP = 200
 
 
 def timeit(launch, rep=REP):
-    for _ in range(10):
-        launch(rt.stream)
+    """us per launch, GPU side: `rep` copies of the launch replayed as ONE explicit hipGraph chain (0.3 us of host work per
+    launch), so that kernels shorter than the host's 3-5 us per eager launch are not measured at the host's pace.  The figure
+    includes the dependent-kernel boundary (~1.5 us)."""
+    plan = ops.NativePlan(rt, [(launch, False)] * rep, mode='graph1')
+    plan.run(rt)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(rep):
-        launch(rt.stream)
+    for _ in range(3):
+        plan.run(rt)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / rep
+    return e0.elapsed_time(e1) * 1e3 / (3 * rep)
 
 
 class BN(object):
@@ -152,7 +155,26 @@ def main_conv3():
                   (label, bm, us, 2.0 * px * 9 * C * C / us * 1e-6, 8.0 * px * C / us * 1e-3, nblk))
 
 
+def main_floor():
+    """What the small kernels of the critical chain cost on the GPU (kernel + boundary), measured inside a graph chain."""
+    ctr = rt.alloc(1, np.int64)
+    print('empty kernel (counter_add)                         %6.2f us' % timeit(ops.counter_add(rt, ctr, 1)))
+    for C, nb, M in ((64, 128, 8192), (256, 128, 8192), (32, 512, 32768), (128, 512, 32768), (16, 2048, 131072), (64, 2048, 131072)):
+        part = rt.alloc((2, C, nb), zero=False)
+        rt.tensor(part).normal_()
+        v = [rt.alloc(C) for _ in range(6)]
+        print('bn_finalize      C=%3d nb=%4d                      %6.2f us' % (
+            C, nb, timeit(ops.bn_finalize(rt, part, nb, M, M // nb, C, v[0], 1e-4, v[1], v[2], v[3], v[4], v[5], 0.1))))
+        print('bn_bwd_finalize  C=%3d nb=%4d                      %6.2f us' % (
+            C, nb, timeit(ops.bn_bwd_finalize(rt, part, nb, M, C, v[0], v[1], v[2], v[3]))))
+        G, X, dX = rt.alloc((M, C), zero=False), rt.alloc((M, C), zero=False), rt.alloc((M, C), zero=False)
+        us = timeit(ops.bn_bwd_apply(rt, G, X, M, C, v[0], v[1], v[2], v[3], v[4], dX))
+        print('bn_bwd_apply     M=%6d C=%3d                     %6.2f us  %6.0f GB/s' % (M, C, us, 12.0 * M * C / us * 1e-3))
+
+
 def main():
+    if 'floor' in sys.argv[1:]:
+        return main_floor()
     if 'conv3' in sys.argv[1:]:
         return main_conv3()
     if 'feats' in sys.argv[1:]:

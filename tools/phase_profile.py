@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Where the time goes INSIDE the small kernels of the critical chain: phase stamps (s_memrealtime, 100 MHz) written by the
+profiling build of the library (make -C deep-prior-pp_amd/csrc prof -> deep-prior-pp_amd/lib_prof/libdpp_hip.so).
+   python tools/phase_profile.py > profiles/r02_phase_profile.txt
+
+For each case the kernel is launched alone (after warm-up launches), every workgroup stamps its phases, and the table gives, over
+the workgroups: when they START relative to the first one (dispatch skew), the median / max duration of each phase, and the
+kernel's span (first start -> last end).  gemm phases: 0 entry -> 1 loads of the first K chunk issued -> 2 first chunk in LDS
+(load latency + commit + barrier) -> 3 K loop done -> 4 epilogue done.  conv3x3: 0 entry -> 1 halo staged (loads + LDS writes
+issued) -> 2 halo + weights visible (barrier) -> 3 nine taps done -> 4 epilogue done."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'deep-prior-pp_amd'))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from hipdp import ops  # noqa: E402
+from hipdp.lib import Act  # noqa: E402
+from hipdp.runtime import TorchHipRuntime  # noqa: E402
+
+rt = TorchHipRuntime(lib_path=os.path.join(ROOT, 'deep-prior-pp_amd', 'lib_prof', 'libdpp_hip.so'))
+TICK_US = 0.01
+
+
+def profile(label, launch, nwg, nphase=5):
+    buf = rt.alloc((nwg + 8, 16), np.int64)
+    for _ in range(5):
+        launch(rt.stream)
+    torch.cuda.synchronize()
+    rt.lib.dpp_prof_set(buf.ptr)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch(rt.stream)
+    e1.record()
+    torch.cuda.synchronize()
+    rt.lib.dpp_prof_set(None)
+    t = buf.get()[:nwg, :nphase].astype(np.float64) * TICK_US
+    t0 = t[:, 0].min()
+    start = t[:, 0] - t0
+    span = t[:, nphase - 1].max() - t0
+    ph = np.diff(t, axis=1)
+    print('%-44s %4d WGs  span %6.2f us (events incl. launch: %6.2f)  start skew med %5.2f max %5.2f | phases med/max: %s' % (
+        label, nwg, span, e0.elapsed_time(e1) * 1e3, np.median(start), start.max(),
+        '  '.join('%5.2f/%5.2f' % (np.median(ph[:, k]), ph[:, k].max()) for k in range(nphase - 1))))
+    sys.stdout.flush()
+
+
+class BN(object):
+    pass
+
+
+def gemm_case(label, M, N, K, tile, feats):
+    A = rt.alloc((M, K), zero=False)
+    rt.tensor(A).normal_()
+    B = rt.alloc((N, K), zero=False)
+    rt.tensor(B).normal_()
+    Cb = rt.alloc((M, N), zero=False)
+    kw = {}
+    if 'act' in feats:
+        mean, scale, beta = rt.alloc(K), rt.alloc(K), rt.alloc(K)
+        a = Act(mean.ptr, scale.ptr, beta.ptr, 3, K)
+        a._keep = (mean, scale, beta)
+        kw['actA'] = a
+    if 'bias' in feats:
+        kw['bias'] = rt.alloc(N)
+    if 'res' in feats:
+        kw['residual'] = rt.alloc((M, N))
+    if 'stats' in feats:
+        kw['epi'] = ops.epilogue(stats=rt.alloc((-(-M // tile[0]), 2, N), zero=False))
+    L = ops.gemm(rt, A, B, Cb, M, N, K, 1, 1, K, K, N, tile=tile, **kw)
+    profile('%s %s' % (label, '+'.join(feats) or 'plain'), L, -(-M // tile[0]) * -(-N // tile[1]))
+
+
+def conv_case(label, N, H, C, bm, feats):
+    X = rt.alloc((N, H, H, C), zero=False)
+    rt.tensor(X).normal_()
+    Wk = rt.alloc((C, 9, C), zero=False)
+    rt.tensor(Wk).normal_()
+    Y = rt.alloc((N, H, H, C), zero=False)
+    kw = {}
+    if 'act' in feats:
+        mean, scale, beta = rt.alloc(C), rt.alloc(C), rt.alloc(C)
+        a = Act(mean.ptr, scale.ptr, beta.ptr, 3, C)
+        a._keep = (mean, scale, beta)
+        kw['actX'] = a
+    if 'bias' in feats:
+        kw['bias'] = rt.alloc(C)
+    nblk = rt.lib.dpp_conv3x3_tiling(N, H, H, bm, None, None, None)
+    if 'stats' in feats:
+        kw['epi'] = ops.epilogue(stats=rt.alloc((nblk, 2, C), zero=False))
+    L = ops.conv3x3(rt, X, N, H, H, C, Wk, C, Y, bm=bm, **kw)
+    bn = 64 if C >= 64 else (32 if C >= 32 else 16)
+    while bn > 16 and nblk * -(-C // bn) < 1024:
+        bn >>= 1
+    profile('%s bm=%d %s' % (label, bm, '+'.join(feats) or 'plain'), L, nblk * -(-C // bn))
+
+
+if __name__ == '__main__':
+    full = ('act', 'bias', 'res', 'stats')
+    for feats in ((), full):
+        gemm_case('1x1 stage3/4 a 256->64  tile 64x16', 8192, 64, 256, (64, 16, 4), feats)
+        gemm_case('1x1 stage3/4 c 64->256  tile 64x64', 8192, 256, 64, (64, 64, 4), feats)
+        gemm_case('1x1 stage2  a 128->32   tile 64x32', 32768, 32, 128, (64, 32, 4), feats)
+        gemm_case('1x1 stage2  c 32->128   tile 64x64', 32768, 128, 32, (64, 64, 4), feats)
+        gemm_case('1x1 stage1  a 64->16    tile 128x16', 131072, 16, 64, (128, 16, 4), feats)
+        gemm_case('1x1 stage1  c 16->64    tile 64x64', 131072, 64, 16, (64, 64, 4), feats)
+    for feats in ((), ('act', 'bias', 'stats')):
+        conv_case('3x3 stage3/4 64->64', 128, 8, 64, 64, feats)
+        conv_case('3x3 stage2 32->32', 128, 16, 32, 64, feats)
+        conv_case('3x3 stage1 16->16', 128, 32, 16, 128, feats)
