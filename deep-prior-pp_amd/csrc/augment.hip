@@ -166,132 +166,146 @@ struct PrepArgs {
     int* out_mode;           // [B] (optional: the mode actually used)
 };
 
+// What the per-joint label transforms need from the per-sample geometry (written by thread 0, read by the joint threads).
+struct AugLabelCtx {
+    int mode, zero;            // augmentation mode actually applied; the reference's early-out (zero offset / angle)
+    float c3[3], n3[3];        // old / new CoM in 3-D
+    float com[3];              // old CoM in image coordinates
+    double ca, sa;             // cos / sin of the label rotation
+    float half_old, half_new;  // cube_z / 2 before / after scaling
+};
+
 // The per-sample geometry of augmentCrop, run by ONE thread: the four draws, the new CoM / cube, the inverse warp matrix and
-// z-thresholds (-> r) and the augmented, normalised joint labels (-> s_label).  `mx` is the maximum of the stored crop.
-__device__ void aug_prepare_sample(const PrepArgs& a, int b, float mx, AugRec& r, float* s_label) {
-    {
-        const AugCam cam = a.cam;
-        const double fx = fabs(cam.fx), fy = fabs(cam.fy);      // HandDetector(..., abs(di.fx), abs(di.fy))
-        // ---- the four draws of augmentCrop (nettrainer.py:954-957) ----
-        int mode; double off[3], rot, sc;
-        if (a.mode) {
-            mode = a.mode[b]; off[0] = a.off[b * 3]; off[1] = a.off[b * 3 + 1]; off[2] = a.off[b * 3 + 2]; rot = a.rot[b]; sc = a.sc[b];
-        } else {
-            unsigned r0[4], r1[4], r2[4];
-            unsigned long long ctr = (a.counter + (a.counter_dev ? *a.counter_dev : 0ull)) * a.gbatch + a.sample0 + b;
-            philox4(a.seed, ctr, 0, r0); philox4(a.seed, ctr, 1, r1); philox4(a.seed, ctr, 2, r2);
-            mode = a.mode_table[r0[0] % (unsigned)a.n_modes];
-            double u1 = u01(r0[1], r0[2]), u2 = u01(r0[3], r1[0]), u3 = u01(r1[1], r1[2]), u4 = u01(r1[3], r2[0]);
-            double ra = sqrt(-2.0 * log(u1)), rb = sqrt(-2.0 * log(u3));
-            const double TWO_PI = 6.283185307179586;
-            off[0] = ra * cos(TWO_PI * u2) * a.sigma_com;
-            off[1] = ra * sin(TWO_PI * u2) * a.sigma_com;
-            off[2] = rb * cos(TWO_PI * u4) * a.sigma_com;
-            rot = (2.0 * u01(r2[1], r2[2]) - 1.0) * a.rot_range;
-            sc = fabs(1.0 + rb * sin(TWO_PI * u4) * a.sigma_sc);
+// z-thresholds (-> r) and what the label transforms need (-> lc).  `mx` is the maximum of the stored crop.
+__device__ void aug_prepare_geometry(const PrepArgs& a, int b, float mx, AugRec& r, AugLabelCtx& lc) {
+    const AugCam cam = a.cam;
+    const double fx = fabs(cam.fx), fy = fabs(cam.fy);      // HandDetector(..., abs(di.fx), abs(di.fy))
+    // ---- the four draws of augmentCrop (nettrainer.py:954-957) ----
+    int mode; double off[3], rot, sc;
+    if (a.mode) {
+        mode = a.mode[b]; off[0] = a.off[b * 3]; off[1] = a.off[b * 3 + 1]; off[2] = a.off[b * 3 + 2]; rot = a.rot[b]; sc = a.sc[b];
+    } else {
+        unsigned r0[4], r1[4], r2[4];
+        unsigned long long ctr = (a.counter + (a.counter_dev ? *a.counter_dev : 0ull)) * a.gbatch + a.sample0 + b;
+        philox4(a.seed, ctr, 0, r0); philox4(a.seed, ctr, 1, r1); philox4(a.seed, ctr, 2, r2);
+        mode = a.mode_table[r0[0] % (unsigned)a.n_modes];
+        double u1 = u01(r0[1], r0[2]), u2 = u01(r0[3], r1[0]), u3 = u01(r1[1], r1[2]), u4 = u01(r1[3], r2[0]);
+        double ra = sqrt(-2.0 * log(u1)), rb = sqrt(-2.0 * log(u3));
+        const double TWO_PI = 6.283185307179586;
+        off[0] = ra * cos(TWO_PI * u2) * a.sigma_com;
+        off[1] = ra * sin(TWO_PI * u2) * a.sigma_com;
+        off[2] = rb * cos(TWO_PI * u4) * a.sigma_com;
+        rot = (2.0 * u01(r2[1], r2[2]) - 1.0) * a.rot_range;
+        sc = fabs(1.0 + rb * sin(TWO_PI * u4) * a.sigma_sc);
+    }
+    if (a.out_mode) a.out_mode[b] = mode;
+
+    double cube[3] = {(double)a.cube[b * 3], (double)a.cube[b * 3 + 1], (double)a.cube[b * 3 + 2]};
+    float com[3];           // CoM in image coordinates (float32 array in the reference)
+    toimg(cam, a.com3d[b * 3], a.com3d[b * 3 + 1], a.com3d[b * 3 + 2], true, com);
+    double Mold[9];
+    for (int i = 0; i < 9; ++i) Mold[i] = (double)a.Mcrop[b * 9 + i];
+
+    r.warp = WARP_NONE; r.thresh = 0; r.zlo = 0.f; r.zhi = 0.f;
+    for (int i = 0; i < 9; ++i) r.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    // de-normalisation of the stored crop (nettrainer.py:948-951): [-1, 1] about the CoM, or [0, 1] from the cube's front face
+    r.den_scale = a.norm01 ? (float)cube[2] : (float)(cube[2] / 2.);
+    r.den_off = a.norm01 ? (float)((double)com[2] - cube[2] / 2.) : com[2];
+    r.premax = mx * r.den_scale + r.den_off;      // two roundings (contraction is off)
+    float ncom[3] = {com[0], com[1], com[2]};
+    double ncube[3] = {cube[0], cube[1], cube[2]};
+    lc.mode = mode; lc.zero = 0; lc.ca = 1.0; lc.sa = 0.0;
+    lc.com[0] = com[0]; lc.com[1] = com[1]; lc.com[2] = com[2];
+    lc.half_old = (float)(cube[2] / 2.);
+    to3d(cam, com[0], com[1], com[2], lc.c3);
+    lc.n3[0] = lc.c3[0]; lc.n3[1] = lc.c3[1]; lc.n3[2] = lc.c3[2];
+
+    if (mode == AUG_COM) {
+        const bool zero = fabs(off[0]) <= 1e-8 && fabs(off[1]) <= 1e-8 && fabs(off[2]) <= 1e-8;
+        lc.zero = zero;
+        if (!zero) {
+            toimg(cam, (double)lc.c3[0] + off[0], (double)lc.c3[1] + off[1], (double)lc.c3[2] + off[2], false, ncom);
+            if (!(fabs((double)com[2]) <= 1e-8 || fabs((double)ncom[2]) <= 1e-8)) {
+                double Mn[9], Mi[9], Mt[9];
+                com_to_transform(ncom, cube, fx, fy, a.dsz, Mn);
+                mat3_inv(Mold, Mi);                 // numpy.linalg.inv(M) restated as cofactor inverse (f64)
+                mat3_mul(Mn, Mi, Mt);
+                mat3_inv(Mt, r.m);                  // warpPerspective inverts the forward matrix
+                r.warp = WARP_PERSP; r.thresh = 1;
+                r.zlo = (float)((double)ncom[2] - cube[2] / 2.);
+                r.zhi = (float)((double)ncom[2] + cube[2] / 2.);
+            }
         }
-        if (a.out_mode) a.out_mode[b] = mode;
-
-        double cube[3] = {(double)a.cube[b * 3], (double)a.cube[b * 3 + 1], (double)a.cube[b * 3 + 2]};
-        float com[3];           // CoM in image coordinates (float32 array in the reference)
-        toimg(cam, a.com3d[b * 3], a.com3d[b * 3 + 1], a.com3d[b * 3 + 2], true, com);
-        double Mold[9];
-        for (int i = 0; i < 9; ++i) Mold[i] = (double)a.Mcrop[b * 9 + i];
-
-        r.warp = WARP_NONE; r.thresh = 0; r.zlo = 0.f; r.zhi = 0.f;
-        for (int i = 0; i < 9; ++i) r.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
-        // de-normalisation of the stored crop (nettrainer.py:948-951): [-1, 1] about the CoM, or [0, 1] from the cube's front face
-        r.den_scale = a.norm01 ? (float)cube[2] : (float)(cube[2] / 2.);
-        r.den_off = a.norm01 ? (float)((double)com[2] - cube[2] / 2.) : com[2];
-        r.premax = mx * r.den_scale + r.den_off;      // two roundings (contraction is off)
-        float ncom[3] = {com[0], com[1], com[2]};
-        double ncube[3] = {cube[0], cube[1], cube[2]};
-        const int J = a.J;
-        const float half_old = (float)(cube[2] / 2.);
-
-        if (mode == AUG_COM) {
-            bool zero = fabs(off[0]) <= 1e-8 && fabs(off[1]) <= 1e-8 && fabs(off[2]) <= 1e-8;
-            float c3[3];
-            to3d(cam, com[0], com[1], com[2], c3);
-            if (!zero) {
-                toimg(cam, (double)c3[0] + off[0], (double)c3[1] + off[1], (double)c3[2] + off[2], false, ncom);
-                if (!(fabs((double)com[2]) <= 1e-8 || fabs((double)ncom[2]) <= 1e-8)) {
-                    double Mn[9], Mi[9], Mt[9];
-                    com_to_transform(ncom, cube, fx, fy, a.dsz, Mn);
-                    mat3_inv(Mold, Mi);                 // numpy.linalg.inv(M) restated as cofactor inverse (f64)
-                    mat3_mul(Mn, Mi, Mt);
-                    mat3_inv(Mt, r.m);                  // warpPerspective inverts the forward matrix
-                    r.warp = WARP_PERSP; r.thresh = 1;
-                    r.zlo = (float)((double)ncom[2] - cube[2] / 2.);
-                    r.zhi = (float)((double)ncom[2] + cube[2] / 2.);
-                }
-            }
-            float n3[3];
-            to3d(cam, ncom[0], ncom[1], ncom[2], n3);
-            for (int j = 0; j < J; ++j)
-                for (int d = 0; d < 3; ++d) {
-                    float g = a.gt3d[((size_t)b * J + j) * 3 + d];
-                    float nj = zero ? g : ((g + c3[d]) - n3[d]);
-                    s_label[j * 3 + d] = nj / half_old;
-                }
-        } else if (mode == AUG_ROT) {
-            bool zero = fabs(rot) <= 1e-8;
-            if (!zero) {
-                rot = rot - floor(rot / 360.0) * 360.0;                 // numpy.mod(rot, 360)
-                // cv2.getRotationMatrix2D((W//2, H//2), -rot, 1) then the inversion at the top of cv::warpAffine
-                double ang = -rot * 3.141592653589793 / 180.;
-                double al = cos(ang), be = sin(ang);
-                double cx = (double)(a.dsz / 2), cy = (double)(a.dsz / 2);
-                double F[6] = {al, be, (1 - al) * cx - be * cy, -be, al, be * cx + (1 - al) * cy};
-                double D = F[0] * F[4] - F[1] * F[3];
-                D = D != 0 ? 1. / D : 0.;
-                double A11 = F[4] * D, A22 = F[0] * D;
-                r.m[0] = A11; r.m[1] = F[1] * (-D); r.m[3] = F[3] * (-D); r.m[4] = A22;
-                r.m[2] = -r.m[0] * F[2] - r.m[1] * F[5];
-                r.m[5] = -r.m[3] * F[2] - r.m[4] * F[5];
-                r.warp = WARP_AFFINE;
-            }
-            float c3[3];
-            to3d(cam, com[0], com[1], com[2], c3);
-            double alpha = rot * 3.141592653589793 / 180.;
-            double ca = cos(alpha), sa = sin(alpha);
-            for (int j = 0; j < J; ++j) {
-                float g[3], p3[3], p2[3], pr[3], q3[3];
-                for (int d = 0; d < 3; ++d) g[d] = a.gt3d[((size_t)b * J + j) * 3 + d];
-                if (zero) { for (int d = 0; d < 3; ++d) s_label[j * 3 + d] = g[d] / half_old; continue; }
-                for (int d = 0; d < 3; ++d) p3[d] = g[d] + c3[d];
-                toimg(cam, p3[0], p3[1], p3[2], true, p2);
-                float px = p2[0] - com[0], py = p2[1] - com[1];          // rotatePoint2D on float32 arrays
-                pr[0] = (float)((double)px * ca - (double)py * sa);
-                pr[1] = (float)((double)px * sa + (double)py * ca);
-                pr[0] = pr[0] + com[0]; pr[1] = pr[1] + com[1]; pr[2] = p2[2];
-                to3d(cam, pr[0], pr[1], pr[2], q3);
-                for (int d = 0; d < 3; ++d) s_label[j * 3 + d] = (q3[d] - c3[d]) / half_old;
-            }
-        } else if (mode == AUG_SC) {
-            bool one = fabs(sc - 1.0) <= (1e-8 + 1e-5);                  // numpy.allclose(sc, 1.)
-            if (!one) {
-                for (int d = 0; d < 3; ++d) ncube[d] = cube[d] * sc;
-                if (!(fabs((double)com[2]) <= 1e-8)) {
-                    double Mn[9], Mi[9], Mt[9];
-                    com_to_transform(com, ncube, fx, fy, a.dsz, Mn);
-                    mat3_inv(Mold, Mi);
-                    mat3_mul(Mn, Mi, Mt);
-                    mat3_inv(Mt, r.m);
-                    r.warp = WARP_PERSP; r.thresh = 1;
-                    r.zlo = (float)((double)com[2] - cube[2] / 2.);      // thresholds use the OLD cube
-                    r.zhi = (float)((double)com[2] + cube[2] / 2.);
-                }
-            }
-            const float half_new = (float)(ncube[2] / 2.);
-            for (int i = 0; i < J * 3; ++i) s_label[i] = a.gt3d[(size_t)b * J * 3 + i] / half_new;
-        } else {
-            for (int i = 0; i < J * 3; ++i) s_label[i] = a.gt3d[(size_t)b * J * 3 + i] / half_old;
+        to3d(cam, ncom[0], ncom[1], ncom[2], lc.n3);
+    } else if (mode == AUG_ROT) {
+        const bool zero = fabs(rot) <= 1e-8;
+        lc.zero = zero;
+        if (!zero) {
+            rot = rot - floor(rot / 360.0) * 360.0;                 // numpy.mod(rot, 360)
+            // cv2.getRotationMatrix2D((W//2, H//2), -rot, 1) then the inversion at the top of cv::warpAffine
+            double ang = -rot * 3.141592653589793 / 180.;
+            double al = cos(ang), be = sin(ang);
+            double cx = (double)(a.dsz / 2), cy = (double)(a.dsz / 2);
+            double F[6] = {al, be, (1 - al) * cx - be * cy, -be, al, be * cx + (1 - al) * cy};
+            double D = F[0] * F[4] - F[1] * F[3];
+            D = D != 0 ? 1. / D : 0.;
+            double A11 = F[4] * D, A22 = F[0] * D;
+            r.m[0] = A11; r.m[1] = F[1] * (-D); r.m[3] = F[3] * (-D); r.m[4] = A22;
+            r.m[2] = -r.m[0] * F[2] - r.m[1] * F[5];
+            r.m[5] = -r.m[3] * F[2] - r.m[4] * F[5];
+            r.warp = WARP_AFFINE;
         }
-        double far_d = (double)ncom[2] + ncube[2] / 2., near_d = (double)ncom[2] - ncube[2] / 2.;
-        r.far_v = (float)far_d; r.near_v = (float)near_d;
-        r.norm_off = a.norm01 ? r.near_v : ncom[2];              // nettrainer.py:982-995
-        r.norm_div = a.norm01 ? (float)ncube[2] : (float)(ncube[2] / 2.);
+        const double alpha = rot * 3.141592653589793 / 180.;
+        lc.ca = cos(alpha); lc.sa = sin(alpha);
+    } else if (mode == AUG_SC) {
+        const bool one = fabs(sc - 1.0) <= (1e-8 + 1e-5);                  // numpy.allclose(sc, 1.)
+        if (!one) {
+            for (int d = 0; d < 3; ++d) ncube[d] = cube[d] * sc;
+            if (!(fabs((double)com[2]) <= 1e-8)) {
+                double Mn[9], Mi[9], Mt[9];
+                com_to_transform(com, ncube, fx, fy, a.dsz, Mn);
+                mat3_inv(Mold, Mi);
+                mat3_mul(Mn, Mi, Mt);
+                mat3_inv(Mt, r.m);
+                r.warp = WARP_PERSP; r.thresh = 1;
+                r.zlo = (float)((double)com[2] - cube[2] / 2.);      // thresholds use the OLD cube
+                r.zhi = (float)((double)com[2] + cube[2] / 2.);
+            }
+        }
+    }
+    lc.half_new = (float)(ncube[2] / 2.);
+    double far_d = (double)ncom[2] + ncube[2] / 2., near_d = (double)ncom[2] - ncube[2] / 2.;
+    r.far_v = (float)far_d; r.near_v = (float)near_d;
+    r.norm_off = a.norm01 ? r.near_v : ncom[2];              // nettrainer.py:982-995
+    r.norm_div = a.norm01 ? (float)ncube[2] : (float)(ncube[2] / 2.);
+}
+
+// The label of ONE joint j under the augmentation described by lc (the per-joint bodies of moveCoM / rotateHand / scaleHand's
+// label handling, nettrainer.py:958-981): one thread per joint.
+__device__ __forceinline__ void aug_label_joint(const PrepArgs& a, int b, const AugLabelCtx& lc, int j, float* s_label) {
+    const AugCam cam = a.cam;
+    float g[3];
+    for (int d = 0; d < 3; ++d) g[d] = a.gt3d[((size_t)b * a.J + j) * 3 + d];
+    if (lc.mode == AUG_COM) {
+        for (int d = 0; d < 3; ++d) {
+            const float nj = lc.zero ? g[d] : ((g[d] + lc.c3[d]) - lc.n3[d]);
+            s_label[j * 3 + d] = nj / lc.half_old;
+        }
+    } else if (lc.mode == AUG_ROT) {
+        if (lc.zero) { for (int d = 0; d < 3; ++d) s_label[j * 3 + d] = g[d] / lc.half_old; return; }
+        float p3[3], p2[3], pr[3], q3[3];
+        for (int d = 0; d < 3; ++d) p3[d] = g[d] + lc.c3[d];
+        toimg(cam, p3[0], p3[1], p3[2], true, p2);
+        const float px = p2[0] - lc.com[0], py = p2[1] - lc.com[1];          // rotatePoint2D on float32 arrays
+        pr[0] = (float)((double)px * lc.ca - (double)py * lc.sa);
+        pr[1] = (float)((double)px * lc.sa + (double)py * lc.ca);
+        pr[0] = pr[0] + lc.com[0]; pr[1] = pr[1] + lc.com[1]; pr[2] = p2[2];
+        to3d(cam, pr[0], pr[1], pr[2], q3);
+        for (int d = 0; d < 3; ++d) s_label[j * 3 + d] = (q3[d] - lc.c3[d]) / lc.half_old;
+    } else if (lc.mode == AUG_SC) {
+        for (int d = 0; d < 3; ++d) s_label[j * 3 + d] = g[d] / lc.half_new;
+    } else {
+        for (int d = 0; d < 3; ++d) s_label[j * 3 + d] = g[d] / lc.half_old;
     }
 }
 
@@ -338,11 +352,14 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a
     __shared__ float s_label[MAXJ3];
     const int b = blockIdx.x;
     const float mx = aug_crop_max(a.img + (size_t)b * a.dsz * a.dsz, a.dsz * a.dsz, s_red);
+    __shared__ AugLabelCtx s_lc;
     if (threadIdx.x == 0) {
         AugRec r;
-        aug_prepare_sample(a, b, mx, r, s_label);
+        aug_prepare_geometry(a, b, mx, r, s_lc);
         a.rec[b] = r;
     }
+    __syncthreads();
+    if ((int)threadIdx.x < a.J) aug_label_joint(a, b, s_lc, threadIdx.x, s_label);
     __syncthreads();
     aug_project_label(a, b, s_label);
 }
@@ -420,9 +437,10 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_fused_kernel(PrepArgs a, 
     const int npix = a.dsz * a.dsz;
     const bool live = b < a.B;
     const float* im = a.img + (size_t)(live ? b : 0) * npix;
+    __shared__ AugLabelCtx s_lc;
     const float mx = aug_crop_max(im, npix, s_red);
     if (tid == 0) {
-        if (live) aug_prepare_sample(a, b, mx, s_rec, s_label);
+        if (live) aug_prepare_geometry(a, b, mx, s_rec, s_lc);
         if (ticket != nullptr) {
             // the ticket is taken only after this workgroup's read of the counter has returned (data dependence)
             unsigned long long c = *counter_rw;
@@ -436,7 +454,9 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_fused_kernel(PrepArgs a, 
     }
     __syncthreads();
     if (!live) return;
-    if (split == 0) {
+    if (split == 0) {                                    // (uniform per workgroup: the barrier below is safe)
+        if (tid < a.J) aug_label_joint(a, b, s_lc, tid, s_label);      // one thread per joint
+        __syncthreads();
         aug_project_label(a, b, s_label);
         if (a.rec != nullptr && tid == 0) a.rec[b] = s_rec;
     }

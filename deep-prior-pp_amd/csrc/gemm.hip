@@ -631,16 +631,6 @@ int launch_layout(const GemmArgs& ga, hipStream_t st) {
             return DPP_E_UNSUPPORTED;
         return dpp_launch_status();
     }
-    if constexpr ((BM == 64 && WM == 4 && BN <= 64) || (BM == 32 && BN == 64 && WM == 1)) {
-        if (ga.bk == 64 && d.a_kc && d.variant == 2) {
-            // variant 2: a ring of FOUR 64-deep chunks in flight (the whole K of the K = 256 layers): these GEMMs spend their K loop
-            // waiting for one chunk after the other (tools/phase_profile.py: 2-3 us per chunk, 0.2 us of MFMAs), with all loads
-            // issued up front they wait once
-            if (d.b_kc) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, true, 4>), grid, dim3(DPP_THREADS), 0, st, ga);
-            else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, false, 4>), grid, dim3(DPP_THREADS), 0, st, ga);
-            return dpp_launch_status();
-        }
-    }
     if (ga.bk == 64 && d.a_kc) {
         // long K-contiguous reductions (stage-2..4 1x1 convolutions and FC layers, K >= 128; measured 4.80 -> 4.74 ms per step): half as many global -> LDS round trips
         if (d.b_kc) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, true, 1>), grid, dim3(DPP_THREADS), 0, st, ga);

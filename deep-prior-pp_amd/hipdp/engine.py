@@ -301,10 +301,6 @@ def is_fc1_shape(Nb, K, Nout):
     """The weight-streaming shape: tens of MB of weights for at most a few hundred rows."""
     return K >= FC1_MIN_K and Nout >= 64 and Nout % 4 == 0 and K % 4 == 0
 ROWSTREAM = os.environ.get('DPP_ROWSTREAM', '0') != '0'      # measured: no gain over the LDS-tiled kernel yet
-# 1x1 convolutions whose reduction is at least this deep run dpp_gemm variant 2 (four 64-deep K chunks in flight instead of one):
-# the K = 256 layers of stages 3-4 otherwise wait for one chunk after the other (tools/phase_profile.py).  0 = never.
-DEEP_MIN_K = int(os.environ.get('DPP_GEMM_DEEP_MIN_K', '256'))
-
 
 def rowstream_plan(M, N, K, b_kc):
     """Tile of the barrier-free row-streaming GEMM variant for conv-shaped problems (M = pixels >> K, N), or None when it
@@ -725,7 +721,7 @@ class CompiledNet(object):
                 out.stats = (rt.alloc((nblk, 2, Co), zero=False), nblk, tile[0])
                 epi = ops.epilogue(stats=out.stats[0])
             mp = RowMap.strided(s[0], Ho, Wo, Hi, Wi) if s[0] != 1 else None
-            variant = 1 if rs is not None else (2 if (DEEP_MIN_K and Ci >= DEEP_MIN_K) else 0)
+            variant = 1 if rs is not None else 0
             self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
                                   bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=variant,
                                   name='conv1x1_%d' % layer.layerNum))
@@ -1081,7 +1077,7 @@ class CompiledNet(object):
                     nb2 = -(-M // tile[0])
                     tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
                     epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
-                variant = 1 if (rs is not None and dY_act is None) else (2 if (DEEP_MIN_K and Co >= DEEP_MIN_K and dY_act is None) else 0)
+                variant = 1 if (rs is not None and dY_act is None) else 0
                 self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
                                       residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
                                       name='dgrad1x1_%d' % layer.layerNum))

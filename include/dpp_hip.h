@@ -111,8 +111,7 @@ typedef struct {
     int bm, bn, wm; /* tile: rows, cols, waves along M (4 or 1); 0 = choose */
     int variant;    /* 0: LDS-tiled kernel (any layout, split-K); 1: row-streaming kernel for skinny conv GEMMs (a_kc = 1,
                        splitk = 1, bm in {64,128}, bn in {16,32,64}): A fragments straight from global memory, no barrier
-                       in the K loop; 2: the LDS-tiled kernel with four 64-deep K chunks in flight (a_kc = 1, K >= 128, tiles
-                       64 x {16,32,64} and 32 x 64; other shapes fall back to variant 0) */
+                       in the K loop */
     dpp_epilogue epi; /* fused statistics / BatchNorm-backward epilogue (requires splitk == 1) */
 } dpp_gemm_desc;
 int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);

@@ -259,30 +259,3 @@ def test_fc_gemm_layouts_and_precisions(backend, precision, layout):
         tol = 6e-7 * (np.sqrt(K) + 4) * max(1.0, float(np.abs(Aact).max()) * float(np.abs(Bq).max()))
         assert np.abs(got - want).max() < tol, (layout, precision, (M, N, K, splitk), np.abs(got - want).max(), tol)
 
-
-@pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('b_kc', [1, 0])
-def test_gemm_deep_ring_variant(backend, b_kc):
-    """dpp_gemm variant 2 (four 64-deep K chunks in flight): K = 256 / 320 (one ring, ring + one refill) / 192 (a short ring) with
-    the BN+ReLU prologue, bias, residual and the statistics epilogue, on the tiles it is instantiated for -- the result is the
-    one-chunk-at-a-time kernel's bit for bit (same accumulation order)."""
-    rt = get_runtime(backend)
-    rng = np.random.RandomState(23)
-    for (M, N, K, tile) in ((128, 64, 256, (64, 16, 4)), (96, 64, 320, (32, 64, 1)), (64, 32, 192, (64, 32, 4)), (128, 128, 256, (64, 64, 4))):
-        A = rng.normal(0, 1, (M, K)).astype(np.float32)
-        Bm = rng.normal(0, 1, (N, K) if b_kc else (K, N)).astype(np.float32)
-        mean, scale, beta = rng.normal(0, 0.3, K).astype(np.float32), rng.uniform(0.5, 1.5, K).astype(np.float32), rng.normal(0, 0.3, K).astype(np.float32)
-        bias, res = rng.normal(0, 1, N).astype(np.float32), rng.normal(0, 1, (M, N)).astype(np.float32)
-        outs = []
-        for variant in (0, 2):
-            act = ops.act(Act.BN_RELU, rt.upload(mean), rt.upload(scale), rt.upload(beta), K)
-            Cb = rt.upload(res.copy())
-            stats = rt.alloc((2, N, -(-M // tile[0])), zero=False)
-            ops.gemm(rt, rt.upload(A), rt.upload(Bm), Cb, M, N, K, 1, b_kc, K, K if b_kc else N, N, actA=act, bias=rt.upload(bias), residual=Cb,
-                     tile=tile, epi=ops.epilogue(stats=stats), variant=variant)(rt.stream)
-            rt.synchronize()
-            outs.append((Cb.get(), stats.get()))
-        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
-        a = np.maximum(((A - mean) * scale + beta).astype(np.float32), 0).astype(np.float64)
-        ref = a @ (Bm.T if b_kc else Bm).astype(np.float64) + bias + res
-        assert np.abs(outs[1][0] - ref).max() < 6e-7 * (np.sqrt(K) + 4) * max(1.0, np.abs(a).max() * np.abs(Bm).max())

@@ -51,7 +51,7 @@ class BN(object):
     pass
 
 
-def gemm_case(label, M, N, K, tile, feats):
+def gemm_case(label, M, N, K, tile, feats, variant=0):
     A = rt.alloc((M, K), zero=False)
     rt.tensor(A).normal_()
     B = rt.alloc((N, K), zero=False)
@@ -69,7 +69,7 @@ def gemm_case(label, M, N, K, tile, feats):
         kw['residual'] = rt.alloc((M, N))
     if 'stats' in feats:
         kw['epi'] = ops.epilogue(stats=rt.alloc((-(-M // tile[0]), 2, N), zero=False))
-    L = ops.gemm(rt, A, B, Cb, M, N, K, 1, 1, K, K, N, tile=tile, **kw)
+    L = ops.gemm(rt, A, B, Cb, M, N, K, 1, 1, K, K, N, tile=tile, variant=variant, **kw)
     profile('%s %s' % (label, '+'.join(feats) or 'plain'), L, -(-M // tile[0]) * -(-N // tile[1]))
 
 
@@ -97,7 +97,26 @@ def conv_case(label, N, H, C, bm, feats):
     profile('%s bm=%d %s' % (label, bm, '+'.join(feats) or 'plain'), L, nblk * -(-C // bn))
 
 
+def fc_case(label, M, N, K, a_kc, b_kc, tile, splitk):
+    A = rt.alloc((M, K) if a_kc else (K, M), zero=False)
+    rt.tensor(A).normal_()
+    B = rt.alloc((N, K) if b_kc else (K, N), zero=False)
+    rt.tensor(B).normal_()
+    Cb = rt.alloc((M, N), zero=False)
+    part = rt.alloc((splitk, M, N), zero=False) if splitk > 1 else None
+    L = ops.gemm(rt, A, B, None if splitk > 1 else Cb, M, N, K, a_kc, b_kc, K if a_kc else M, K if b_kc else N, N, splitk=splitk, partial=part, tile=tile)
+    profile('%s tile %dx%d splitk %d' % (label, tile[0], tile[1], splitk), L, -(-M // tile[0]) * -(-N // tile[1]) * splitk)
+
+
 if __name__ == '__main__':
+    if 'fc' in sys.argv[1:]:
+        fc_case('FC1 fwd   128 x 1024 x 16384', 128, 1024, 16384, 1, 0, (128, 64, 4), 32)
+        fc_case('FC1 fwd   128 x 1024 x 16384', 128, 1024, 16384, 1, 0, (64, 64, 4), 32)
+        fc_case('FC1 dgrad 128 x 16384 x 1024', 128, 16384, 1024, 1, 1, (128, 64, 4), 1)
+        fc_case('FC1 dgrad 128 x 16384 x 1024', 128, 16384, 1024, 1, 1, (64, 64, 4), 1)
+        fc_case('FC1 wgrad 16384 x 1024 x 128', 16384, 1024, 128, 0, 0, (128, 64, 4), 1)
+        fc_case('FC1 wgrad 16384 x 1024 x 128', 16384, 1024, 128, 0, 0, (64, 64, 4), 1)
+        sys.exit(0)
     full = ('act', 'bias', 'res', 'stats')
     for feats in ((), full):
         gemm_case('1x1 stage3/4 a 256->64  tile 64x16', 8192, 64, 256, (64, 16, 4), feats)

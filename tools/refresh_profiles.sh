@@ -1,14 +1,27 @@
+# Regenerate the rocprofv3 evidence of the current round on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
+# Outputs land in gpurun_out/<round>/ and are then copied to profiles/<round>_*.
 set -x
+ROUND=${1:-r02}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r01
+O=$R/gpurun_out/$ROUND
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace -d /tmp/p1 -o run -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --launch eager > /dev/null 2>&1
+# kernel trace of the measured configuration (bench defaults: native plan, two streams) -- kernel-trace only, no counters
+rocprofv3 --kernel-trace -d /tmp/p1 -o run -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/prof_summary.py $(find /tmp/p1 -name '*_results.db' | head -1) 28 > $O/kernel_stats_bench.txt 2>&1
+# un-overlapped kernel durations, one line per (kernel, grid)
 DPP_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace -d /tmp/p2 -o run -- python $R/tools/step_profile.py 8 > /dev/null 2>&1
 python $R/tools/prof_summary.py $(find /tmp/p2 -name '*_results.db' | head -1) 8 --by-grid > $O/kernel_stats_single_stream_by_grid.txt 2>&1
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md, rocprofv3 PMC slots), no other trace domains
 DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p3 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
 DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p4 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/p3 -name '*_results.db' | head -1) $(find /tmp/p4 -name '*_results.db' | head -1) 3 --json $O/hbm_traffic.json > $O/hbm_traffic.txt 2>&1
+# the other bench modes of BASELINE.json
+python $R/bench.py --no-cpu-baseline --dtype bf16 > $O/bench_bf16_128.json 2>/dev/null
+python $R/bench.py --no-cpu-baseline --size 256 --steps 20 --warmup 5 > $O/bench_f32_256.json 2>/dev/null
+python $R/bench.py --no-cpu-baseline --size 256 --steps 20 --warmup 5 --dtype bf16 > $O/bench_bf16_256.json 2>/dev/null
+python $R/bench.py --no-cpu-baseline --batch 256 > $O/bench_bs256.json 2>/dev/null
+python $R/tools/augment_bench.py > $O/augment_bench.json 2> $O/augment_bench.err
+python $R/tools/augment_bench.py --batch 4096 --iters 50 >> $O/augment_bench.json 2>> $O/augment_bench.err
 ls -la $O
