@@ -104,43 +104,63 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
     // ... of every segment (no integer division per partial: this kernel is a few microseconds of pure latency)
     const int Mseg = M / nseg;
     auto rows_of = [&](int bi) { return (bi * rpb + rpb <= Mseg) ? rpb : (Mseg - bi * rpb); };
+    // One sweep covers all blocks in every single-rank case (nbs <= GT * U by the host's choice of U / WPC): (mean_b, M2_b) are then
+    // loaded ONCE, both in the first round trip, and the second pass runs from registers -- this kernel is nothing but dependent
+    // memory latency, so a saved round trip is a fifth of its run time (tools/gemm_micro.py floor).
+    const bool one_sweep = nseg == 1 && nbs <= GT * U;
+    float pm0[U], pq0[U];
     double snm = 0.0;
     for (int seg = 0; seg < nseg; ++seg) {
         const float* pm_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
+        const float* pq_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(1, cc, 0, C, nbs);
         for (int b0 = lane; b0 < nbs; b0 += GT * U) {
             float pm[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int b = b0 + u * GT;
-                pm[u] = pm_row[b < nbs ? b : nbs - 1];
+                const int bb = b < nbs ? b : nbs - 1;
+                pm[u] = pm_row[bb];
+                if (one_sweep) pq0[u] = pq_row[bb];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int b = b0 + u * GT;
                 if (b < nbs) snm += (double)rows_of(b) * (double)pm[u];
+                pm0[u] = pm[u];
             }
         }
     }
     const double mean = group_allsum<WPC>(snm, slot_a) / (double)M;  // sum_b n_b = M
     double q = 0.0;
-    for (int seg = 0; seg < nseg; ++seg) {
-        const float* pm_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
-        const float* pq_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(1, cc, 0, C, nbs);
-        for (int b0 = lane; b0 < nbs; b0 += GT * U) {
-            float pm[U], pq[U];
+    if (one_sweep) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int b = b0 + u * GT;
-                const int bb = b < nbs ? b : nbs - 1;
-                pm[u] = pm_row[bb];
-                pq[u] = pq_row[bb];
+        for (int u = 0; u < U; ++u) {
+            const int b = lane + u * GT;
+            if (b < nbs) {
+                const double d = (double)pm0[u] - mean;
+                q += (double)pq0[u] + (double)rows_of(b) * d * d;
             }
+        }
+    } else {
+        for (int seg = 0; seg < nseg; ++seg) {
+            const float* pm_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
+            const float* pq_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(1, cc, 0, C, nbs);
+            for (int b0 = lane; b0 < nbs; b0 += GT * U) {
+                float pm[U], pq[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int b = b0 + u * GT;
-                if (b < nbs) {
-                    const double d = (double)pm[u] - mean;
-                    q += (double)pq[u] + (double)rows_of(b) * d * d;
+                for (int u = 0; u < U; ++u) {
+                    const int b = b0 + u * GT;
+                    const int bb = b < nbs ? b : nbs - 1;
+                    pm[u] = pm_row[bb];
+                    pq[u] = pq_row[bb];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int b = b0 + u * GT;
+                    if (b < nbs) {
+                        const double d = (double)pm[u] - mean;
+                        q += (double)pq[u] + (double)rows_of(b) * d * d;
+                    }
                 }
             }
         }

@@ -120,7 +120,9 @@ extern "C" int dpp_plan_run(dpp_plan* plan, dpp_stream_t main_stream, dpp_stream
         }
     }
     size_t ev = 0;
-    bool main_dirty = true, side_dirty = false;     // work issued on the lane since the other lane last synchronised with it
+    // work issued on a lane since the other lane last synchronised with it.  Both start TRUE: a plan may be one segment of a
+    // longer sequence (collectives run between segments), so the lane may carry work from before this call
+    bool main_dirty = true, side_dirty = true;
     for (dpp_plan_node& n : plan->nodes) {
         if (n.kind == 2 || n.kind == 3) {
             if (!two) continue;
