@@ -265,13 +265,73 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         }
     }
 
+    // ---- fast path (block-uniform): the whole tile inside the problem, whole K chunks, 16-byte loads, prologue channels in quads.
+    // The checked path below spends 3-4 instructions per bounds test and a runtime modulo per prologue quad; one wave of a
+    // 64x16 K=256 forward tile issued 2360 instructions for its 64 MFMAs, and two such waves per SIMD at ~4 cycles per
+    // instruction are 8 of the kernel's 14 us (tools/inst_summary.py, profiles/r02_instruction_mix.txt).  On the fast path a
+    // staging slot is one load and, at commit, 12 VALU + one ds_write; the BatchNorm coefficients of a thread's quad are loaded
+    // once per chunk (K-contiguous operand: all slots of a thread share the k-quad) or once per kernel (MN-contiguous operand:
+    // the quad is the thread's column) together with the operand loads, not after them.
+    constexpr int QA = AKC ? SA::QK : BM / 4, QB = BKC ? SB::QK : BN / 4;      // quads per staged row
+    constexpr bool A_EXACT = ((AKC ? BM * SA::QK : BKT * (BM / 4)) % DPP_THREADS) == 0 && DPP_THREADS % QA == 0;
+    constexpr bool B_EXACT = ((BKC ? BN * SB::QK : BKT * (BN / 4)) % DPP_THREADS) == 0 && DPP_THREADS % QB == 0;
+    const int klen = k_end - k_begin;
+    const bool kfull = klen > 0 && (klen % BKT) == 0;
+    const int modeA = d.actA.mode, modeB = d.actB.mode;
+    const bool fastA = !LAZY && A_EXACT && ga.vecA && kfull && row0 + BM <= M && (modeA == 0 || (d.actA.cmod & 3) == 0);
+    const bool fastB = B_EXACT && ga.vecB && kfull && col0 + BN <= N && (modeB == 0 || (d.actB.cmod & 3) == 0);
+    const int qa = (tid % QA) * 4, qb = (tid % QB) * 4;                          // this thread's quad along the contiguous dimension
+    const int ldsA0 = (tid / QA) * LDA_ + qa, ldsB0 = (tid / QB) * LDB_ + qb;    // its first LDS slot; slot s is s*(THREADS/Q) rows below
+    struct Co4 { float4 mu, sc, be; };
+    auto load_co = [](const dpp_act& a, int c0) {
+        const int c = c0 < a.cmod ? c0 : c0 % a.cmod;
+        Co4 o;
+        o.mu = *reinterpret_cast<const float4*>(a.mean + c);
+        o.sc = *reinterpret_cast<const float4*>(a.scale + c);
+        o.be = *reinterpret_cast<const float4*>(a.beta + c);
+        return o;
+    };
+    auto apply_co = [](float4 v, const Co4& co, int mode) {
+        if (mode & 2) {
+            v.x = (v.x - co.mu.x) * co.sc.x + co.be.x;
+            v.y = (v.y - co.mu.y) * co.sc.y + co.be.y;
+            v.z = (v.z - co.mu.z) * co.sc.z + co.be.z;
+            v.w = (v.w - co.mu.w) * co.sc.w + co.be.w;
+        }
+        if (mode & 1) {
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        }
+        return v;
+    };
+    Co4 coA[DEPTH], coB[DEPTH];
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) {
+        coA[dd].mu = coA[dd].sc = coA[dd].be = make_float4(0.f, 0.f, 0.f, 0.f);
+        coB[dd] = coA[dd];
+    }
+    if (!AKC && fastA && (modeA & 2)) coA[0] = load_co(d.actA, row0 + qa);
+    if (!BKC && fastB && (modeB & 2)) coB[0] = load_co(d.actB, col0 + qb);
+
     // DEPTH chunks are kept in flight per workgroup (a ring of register sets): what bounds these skinny GEMMs is the
     // latency of the dependent load -> barrier -> MFMA chain, not bandwidth or the MFMA rate.
     float4 ra[DEPTH][SA::SLOTS], rb[DEPTH][SB::SLOTS];
     // LAZY: operand A = gradient through a BatchNorm, built from (g, x2) (dpp_act mode 4); its own instantiation, so that the
     // second load and the extra per-channel vectors cost the ordinary GEMMs nothing
     const ptrdiff_t a2off = LAZY ? (d.actA.x2 - d.A) : 0;
-    auto fetch = [&](float4* ra_, float4* rb_, int kc) {
+    auto fetch = [&](int dd, int kc) {
+        float4* const ra_ = ra[dd];
+        float4* const rb_ = rb[dd];
+        if (fastA) {
+            if (AKC) {
+                if (modeA & 2) coA[dd] = load_co(d.actA, kc + qa);
+#pragma unroll
+                for (int s = 0; s < SA::SLOTS; ++s) ra_[s] = *reinterpret_cast<const float4*>(a_base[s] + kc + qa);
+            } else {
+#pragma unroll
+                for (int s = 0; s < SA::SLOTS; ++s)
+                    ra_[s] = *reinterpret_cast<const float4*>(a_base[s] + (size_t)dpp_map_row(d.mapA, kc + tid / QA + s * (DPP_THREADS / QA)) * d.lda);
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < SA::SLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
@@ -308,6 +368,17 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
             }
             ra_[s] = v;
         }
+        if (fastB) {
+            if (BKC) {
+                if (modeB & 2) coB[dd] = load_co(d.actB, kc + qb);
+#pragma unroll
+                for (int s = 0; s < SB::SLOTS; ++s) rb_[s] = *reinterpret_cast<const float4*>(b_base[s] + kc + qb);
+            } else {
+#pragma unroll
+                for (int s = 0; s < SB::SLOTS; ++s)
+                    rb_[s] = *reinterpret_cast<const float4*>(b_base[s] + (size_t)dpp_map_row(d.mapB, kc + tid / QB + s * (DPP_THREADS / QB)) * d.ldb);
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < SB::SLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
@@ -328,7 +399,17 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     // fetch, is what lets the loads of the next chunk stay in flight under this chunk's MFMAs: a prologue in fetch makes the
     // wave wait for its loads right where they are issued (measured with tools/phase_profile.py: 2-3 us per 64-deep chunk of the
     // K = 256 layers, all of it exposed latency).
-    auto commit = [&](const float4* ra_, const float4* rb_, int kc) {
+    auto commit = [&](int dd, int kc) {
+        const float4* const ra_ = ra[dd];
+        const float4* const rb_ = rb[dd];
+        if (fastA) {
+#pragma unroll
+            for (int s = 0; s < SA::SLOTS; ++s) {
+                float4 v = ra_[s];
+                if (modeA != 0) v = apply_co(v, coA[AKC ? dd : 0], modeA);
+                *reinterpret_cast<float4*>(&As[ldsA0 + s * (DPP_THREADS / QA) * LDA_]) = v;
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < SA::SLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
@@ -340,6 +421,14 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
             if (AKC) { if (slot < BM * SA::QK) *reinterpret_cast<float4*>(&As[(slot / SA::QK) * LDA_ + (slot % SA::QK) * 4]) = v; }
             else { if (slot < BKT * (BM / 4)) *reinterpret_cast<float4*>(&As[(slot / (BM / 4)) * LDA_ + (slot % (BM / 4)) * 4]) = v; }
         }
+        if (fastB) {
+#pragma unroll
+            for (int s = 0; s < SB::SLOTS; ++s) {
+                float4 v = rb_[s];
+                if (modeB != 0) v = apply_co(v, coB[BKC ? dd : 0], modeB);
+                *reinterpret_cast<float4*>(&Bs[ldsB0 + s * (DPP_THREADS / QB) * LDB_]) = v;
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < SB::SLOTS; ++s) {
             int slot = tid + s * DPP_THREADS;
@@ -366,17 +455,17 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     const int nchunks = (k_end > k_begin) ? (k_end - k_begin + BKT - 1) / BKT : 0;
 #pragma unroll
     for (int dd = 0; dd < DEPTH; ++dd)
-        if (dd < nchunks) fetch(ra[dd], rb[dd], k_begin + dd * BKT);
+        if (dd < nchunks) fetch(dd, k_begin + dd * BKT);
     dpp_stamp(ga.prof, 1);
     for (int c0 = 0; c0 < nchunks; c0 += DEPTH) {
 #pragma unroll
         for (int dd = 0; dd < DEPTH; ++dd) {
             const int c = c0 + dd;
             if (c < nchunks) {
-                commit(ra[dd], rb[dd], k_begin + c * BKT);
+                commit(dd, k_begin + c * BKT);
                 __syncthreads();
                 if (c == 0) dpp_stamp(ga.prof, 2);
-                if (c + DEPTH < nchunks) fetch(ra[dd], rb[dd], k_begin + (c + DEPTH) * BKT);
+                if (c + DEPTH < nchunks) fetch(dd, k_begin + (c + DEPTH) * BKT);
 #pragma unroll
                 for (int e4 = 0; e4 < KL; e4 += 4) {
                     float af[RM][4], bf[CN][4];
