@@ -21,6 +21,17 @@
 
 namespace {
 
+// Division constants of the staging loops.  A runtime integer division is ~25 instructions on this hardware and the staging
+// loops had three per 16-byte slot; a wave issues about one instruction per 4 cycles, so they cost more than the loads they
+// index (tools/inst_summary.py).  Halo positions are split with n / d = umulhi(n, floor(2^32 / d) + 1), exact for n * d < 2^32;
+// channel quads are dealt to threads in power-of-two groups (QP >= quads per position; the lanes beyond the image idle).
+struct C3Stage {
+    unsigned m_hw2, m_tw2;   // magic of (TH+2)*(TW+2) and of TW+2
+    int lqp;                 // log2(QP)
+};
+
+__host__ __device__ inline unsigned c3_magic(int d) { return (unsigned)(0x100000000ull / (unsigned)d) + 1u; }      // d >= 2
+
 struct Conv3Args {
     const float* X;       // [N][H][W][Ci]
     int N, H, W, Ci, Co;
@@ -35,6 +46,7 @@ struct Conv3Args {
     int lth, ltw;         // log2 of tile height / width
     int img;              // images per workgroup
     int tiles_x, tiles_y;
+    C3Stage sg;           // staging geometry (host-computed division constants)
     unsigned long long* prof;   // phase stamps (profiling build only, see dpp_stamp)
 };
 
@@ -66,24 +78,52 @@ __device__ __forceinline__ void tile_origin(const Conv3Args& a, int bid, int& n0
 }
 
 // Stage the activated input halo of the tile into LDS: Ah[(img*(TH+2)+hy)*(TW+2)+hx][KP+pad] (KP >= Ci: channels Ci..KP-1 zero).
-template <class E>
+// A thread owns ONE channel quad (its BatchNorm coefficients are loaded once) and walks halo positions; the loads of up to 8
+// positions are issued before the first is used, so the usual tile (<= 8 slots per thread) costs one memory round trip.
+template <int UB, class E>
 __device__ __forceinline__ void stage_halo(const float* __restrict__ X, int N, int H, int W, int Ci, const dpp_act& act, int n0,
-                                           int y0, int x0, int TH, int TW, int IMG, E* Ah, int LDA, int KP = 0) {
+                                           int y0, int x0, int TH, int TW, int IMG, E* Ah, int LDA, int KP, const C3Stage& sg) {
     if (KP < Ci) KP = Ci;
-    const int q = KP >> 2;
-    const int HW2 = (TH + 2) * (TW + 2);
-    const int total = IMG * HW2 * q;
-    for (int s = threadIdx.x; s < total; s += DPP_THREADS) {
-        int hp = s / q, c4 = s - hp * q;
-        int im = hp / HW2, rem = hp - im * HW2;
-        int hy = rem / (TW + 2), hx = rem - hy * (TW + 2);
-        int n = n0 + im, y = y0 + hy - 1, x = x0 + hx - 1;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c4 * 4 < Ci && n < N && y >= 0 && y < H && x >= 0 && x < W) {
-            v = *reinterpret_cast<const float4*>(X + (((size_t)n * H + y) * W + x) * Ci + c4 * 4);
-            if (act.mode) v = dpp_act4(v, act, c4 * 4);
+    const int HW2 = (TH + 2) * (TW + 2), TW2 = TW + 2;
+    const int HP = IMG * HW2;
+    const int c0 = ((int)threadIdx.x & ((1 << sg.lqp) - 1)) * 4;
+    const int hstep = DPP_THREADS >> sg.lqp;
+    if (c0 >= KP) return;                            // idle lanes of the power-of-two quad group
+    const bool cld = c0 < Ci;                        // bf16 images pad narrow layers to 32 channels with zeros
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
+    if (cld && (act.mode & 2)) {
+        mu = *reinterpret_cast<const float4*>(act.mean + c0);
+        sc = *reinterpret_cast<const float4*>(act.scale + c0);
+        be = *reinterpret_cast<const float4*>(act.beta + c0);
+    }
+    for (int hb = (int)threadIdx.x >> sg.lqp; hb < HP; hb += UB * hstep) {
+        float4 v[UB];
+        bool in[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int hp = hb + u * hstep;
+            const int im = (int)__umulhi((unsigned)hp, sg.m_hw2), rem = hp - im * HW2;
+            const int hy = (int)__umulhi((unsigned)rem, sg.m_tw2), hx = rem - hy * TW2;
+            const int n = n0 + im, y = y0 + hy - 1, x = x0 + hx - 1;
+            in[u] = hp < HP && cld && n < N && y >= 0 && y < H && x >= 0 && x < W;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in[u]) v[u] = *reinterpret_cast<const float4*>(X + (((size_t)n * H + y) * W + x) * Ci + c0);
         }
-        c3_store4(&Ah[hp * LDA + c4 * 4], v);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int hp = hb + u * hstep;
+            if (hp < HP) {
+                float4 t = v[u];
+                if (in[u]) {                         // zero padding is applied AFTER the activation
+                    if (act.mode & 2) {
+                        t.x = (t.x - mu.x) * sc.x + be.x; t.y = (t.y - mu.y) * sc.y + be.y;
+                        t.z = (t.z - mu.z) * sc.z + be.z; t.w = (t.w - mu.w) * sc.w + be.w;
+                    }
+                    if (act.mode & 1) { t.x = fmaxf(t.x, 0.0f); t.y = fmaxf(t.y, 0.0f); t.z = fmaxf(t.z, 0.0f); t.w = fmaxf(t.w, 0.0f); }
+                }
+                c3_store4(&Ah[hp * LDA + c0], t);
+            }
+        }
     }
 }
 
@@ -108,7 +148,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     dpp_stamp(a.prof, 0);
     dpp_wide_coef wco;
     if (a.wide) wco.load<BN>(col0, a.Co, a.bias, a.epi);
-    stage_halo(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP);
+    stage_halo<8>(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP, a.sg);
     dpp_stamp(a.prof, 1);
 
     // halo index of this lane's A rows (centre tap)
@@ -130,42 +170,50 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
 
     // weight slices are double-buffered in LDS: the slice of tap t+1 is fetched into registers before the MFMAs of tap t
     // and written to the other buffer after them, so one barrier per tap suffices and the fetch latency is hidden.
-    const int q = KP >> 2;
-    constexpr int WSLOTS = (BN * 16 + DPP_THREADS - 1) / DPP_THREADS;      // KP <= 64 -> at most BN*16 float4 per slice
+    // Slot s of a thread is (output column j, channel quad c4) of the weight slice, dealt in the same power-of-two quad groups
+    // as the halo: the pointer and the LDS offset are formed once, a tap is one load (+ tap*Ci) and one store per slot.
+    constexpr int WSLOTS = (BN * 16 + DPP_THREADS - 1) / DPP_THREADS;      // KP <= 64 -> at most 16 quads per column
     float4 wreg[WSLOTS];
-    auto wload = [&](int j, int tap, int c4) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (col0 + j < a.Co && c4 * 4 < Ci) v = *reinterpret_cast<const float4*>(a.Wk + ((size_t)(col0 + j) * 9 + tap) * Ci + c4 * 4);
-        return v;
-    };
+    const float* wp[WSLOTS];
+    int wo[WSLOTS];
+#pragma unroll
+    for (int s = 0; s < WSLOTS; ++s) {
+        const int slot = tid + s * DPP_THREADS;
+        const int j = slot >> a.sg.lqp, c0 = (slot & ((1 << a.sg.lqp) - 1)) * 4;
+        wo[s] = (j < BN && c0 < KP) ? j * LDA + c0 : -1;
+        wp[s] = (j < BN && c0 < Ci && col0 + j < a.Co) ? a.Wk + (size_t)(col0 + j) * 9 * Ci + c0 : nullptr;
+    }
     auto wfetch = [&](int tap) {
 #pragma unroll
         for (int s = 0; s < WSLOTS; ++s) {
-            int slot = tid + s * DPP_THREADS;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (slot < BN * q) v = wload(slot / q, tap, slot % q);
-            wreg[s] = v;
+            wreg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wp[s] != nullptr) wreg[s] = *reinterpret_cast<const float4*>(wp[s] + tap * Ci);
         }
     };
     auto wcommit = [&](elem* dst) {
 #pragma unroll
-        for (int s = 0; s < WSLOTS; ++s) {
-            int slot = tid + s * DPP_THREADS;
-            if (slot < BN * q) {
-                int j = slot / q, c4 = slot - j * q;
-                c3_store4(&dst[j * LDA + c4 * 4], wreg[s]);
-            }
-        }
+        for (int s = 0; s < WSLOTS; ++s)
+            if (wo[s] >= 0) c3_store4(&dst[wo[s]], wreg[s]);
     };
     // Narrow layers (stages 1-2: Ci = 16 / 32) have all nine weight slices staged up front (11-21 KB): one barrier for the
     // whole workgroup instead of one per tap, which is what bounds these short K loops.
     const bool allw = a.allw != 0;
     if (allw) {
-        const int per_tap = BN * q;
-        for (int sidx = tid; sidx < 9 * per_tap; sidx += DPP_THREADS) {
-            const int tap = sidx / per_tap, slot = sidx - tap * per_tap;
-            const int j = slot / q, c4 = slot - j * q;
-            c3_store4(&Bs[(tap * BN + j) * LDA + c4 * 4], wload(j, tap, c4));
+#pragma unroll
+        for (int t3 = 0; t3 < 9; t3 += 3) {          // three taps' loads in flight at a time
+            float4 w3[3][WSLOTS];
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int s = 0; s < WSLOTS; ++s) {
+                    w3[u][s] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (wp[s] != nullptr) w3[u][s] = *reinterpret_cast<const float4*>(wp[s] + (t3 + u) * Ci);
+                }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int s = 0; s < WSLOTS; ++s)
+                    if (wo[s] >= 0) c3_store4(&Bs[(t3 + u) * BN * LDA + wo[s]], w3[u][s]);
         }
     } else {
         wfetch(0);
@@ -368,6 +416,8 @@ struct Wgrad3Args {
     int lth, ltw, img, tiles_x, tiles_y;
     int ntiles;           // spatial tiles in total (a workgroup walks several)
     int taps_pb;          // taps per blockIdx.y
+    C3Stage sg;           // staging geometry of the halo (host-computed division constants)
+    int lqy;              // log2 of the power-of-two quad group of the dY rows (>= Co/4 quads per row)
 };
 
 template <int BM, int MAXACC>
@@ -389,29 +439,46 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a
 #pragma unroll
     for (int i = 0; i < MAXACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // (tap, 16x16 tile) of accumulator i and this lane's operand offsets, formed ONCE: inside the reduction loop the divisions
+    // that split the pair index cost 20x the MFMAs they fed (4 100-4 900 VALU instructions per wave, tools/inst_summary.py)
+    int yoff[MAXACC], xoff[MAXACC];
+#pragma unroll
+    for (int i = 0; i < MAXACC; ++i) {
+        const int p = wave + 4 * i;
+        yoff[i] = -1; xoff[i] = 0;
+        if (p < pairs) {
+            const int tap = tap0 + p / NT, tile = p % NT;
+            const int to = tile / ntc, tc = tile - to * ntc;
+            yoff[i] = to * 16 + l15;
+            xoff[i] = ((tap / 3 - 1) * (TW + 2) + (tap % 3 - 1)) * LDA + tc * 16 + l15;
+        }
+    }
+
     // a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... keeping its accumulators in registers, so the
     // number of partial slices (and the traffic of the reduce) is bounded by the grid size, not by the tile count
     for (int tile_id = blockIdx.x; tile_id < a.ntiles; tile_id += gridDim.x) {
         int n0, y0, x0;
         tile_origin(ta, tile_id, n0, y0, x0);
         __syncthreads();               // previous tile's fragments are consumed before LDS is overwritten
-        stage_halo(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA);
-        {   // stage dY rows of the tile (zeros for out-of-range rows)
-            const int q = Co >> 2;
-            for (int s = tid; s < BM * q; s += DPP_THREADS) {
-                int row = s / q, c4 = s - row * q;
-                int im = row >> (a.lth + a.ltw);
-                int ty = (row >> a.ltw) & (TH - 1);
-                int tx = row & (TW - 1);
-                int n = n0 + im, y = y0 + ty, x = x0 + tx;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (im < a.img && n < a.N && y < a.H && x < a.W)
-                    v = *reinterpret_cast<const float4*>(a.dY + (((size_t)n * a.H + y) * a.W + x) * Co + c4 * 4);
-                *reinterpret_cast<float4*>(&Ys[row * LDY + c4 * 4]) = v;
+        stage_halo<4>(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, Ci, a.sg);
+        {   // stage dY rows of the tile (zeros for out-of-range rows): a thread owns one channel quad and walks rows
+            const int c0 = (tid & ((1 << a.lqy) - 1)) * 4, rstep = DPP_THREADS >> a.lqy;
+            if (c0 < Co) {
+                for (int row = tid >> a.lqy; row < BM; row += rstep) {
+                    int im = row >> (a.lth + a.ltw);
+                    int ty = (row >> a.ltw) & (TH - 1);
+                    int tx = row & (TW - 1);
+                    int n = n0 + im, y = y0 + ty, x = x0 + tx;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (im < a.img && n < a.N && y < a.H && x < a.W)
+                        v = *reinterpret_cast<const float4*>(a.dY + (((size_t)n * a.H + y) * a.W + x) * Co + c0);
+                    *reinterpret_cast<float4*>(&Ys[row * LDY + c0]) = v;
+                }
             }
         }
         __syncthreads();
 
+#pragma unroll 1
         for (int rc = 0; rc < BM; rc += 16) {
             // halo index of the 4 reduction rows this lane feeds: r = rc + 4*kq + t
             int hb[4];
@@ -421,19 +488,16 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a
                 int im = row >> (a.lth + a.ltw);
                 int ty = (row >> a.ltw) & (TH - 1);
                 int tx = row & (TW - 1);
-                hb[t] = (im * (TH + 2) + ty + 1) * (TW + 2) + tx + 1;
+                hb[t] = ((im * (TH + 2) + ty + 1) * (TW + 2) + tx + 1) * LDA;
             }
+            const float* yrow = Ys + (rc + kq * 4) * LDY;
 #pragma unroll
             for (int i = 0; i < MAXACC; ++i) {
-                int p = wave + 4 * i;
-                if (p < pairs) {
-                    int tap = tap0 + p / NT, tile = p % NT;
-                    int to = tile / ntc, tc = tile - to * ntc;
-                    int toff = (tap / 3 - 1) * (TW + 2) + (tap % 3 - 1);
+                if (yoff[i] >= 0) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        float av = Ys[(rc + kq * 4 + t) * LDY + to * 16 + l15];
-                        float bv = Ah[(hb[t] + toff) * LDA + tc * 16 + l15];
+                        float av = yrow[t * LDY + yoff[i]];
+                        float bv = Ah[hb[t] + xoff[i]];
                         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i], 0, 0, 0);
                     }
                 }
@@ -501,6 +565,9 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     a.tiles_x = dpp_cdiv(W, TW); a.tiles_y = dpp_cdiv(H, TH);
     int nblk = a.tiles_x * a.tiles_y * dpp_cdiv(N, a.img);
     if (Ci > 64) return DPP_E_UNSUPPORTED;          // weight-slice register staging is sized for Ci <= 64
+    a.sg.m_hw2 = c3_magic((TH + 2) * (TW + 2));
+    a.sg.m_tw2 = c3_magic(TW + 2);
+    a.sg.lqp = ilog2(((precision && Ci < 32) ? 32 : Ci) / 4);
     int bn = Co >= 64 ? 64 : (Co >= 32 ? 32 : 16);
     while (bn > 16 && (long)nblk * dpp_cdiv(Co, bn) < 1024) bn >>= 1;     // ~4 workgroups per CU (measured: 256 -> 1024 is ~0.5 % of the step)
     size_t halo = (size_t)a.img * (TH + 2) * (TW + 2);
@@ -574,6 +641,10 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     int pairs = taps_pb * NT;
     int maxacc = dpp_cdiv(pairs, 4);
     a.taps_pb = taps_pb;
+    a.sg.m_hw2 = c3_magic((TH + 2) * (TW + 2));
+    a.sg.m_tw2 = c3_magic(TW + 2);
+    a.sg.lqp = ilog2(Ci / 4);
+    a.lqy = ilog2(Co / 4);
     size_t lds = ((size_t)a.img * (TH + 2) * (TW + 2) * (Ci + 4) + (size_t)bm * (Co + 4)) * sizeof(float);
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, 9 / taps_pb);
