@@ -148,7 +148,11 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     dpp_stamp(a.prof, 0);
     dpp_wide_coef wco;
     if (a.wide) wco.load<BN>(col0, a.Co, a.bias, a.epi);
-    stage_halo<8>(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP, a.sg);
+    // halo slots per thread: 3 for the 16- and 32-channel layers, 7 for the 64-channel ones; unrolling 8 for 3 wastes 5 slots of index arithmetic
+    if (((HP + (DPP_THREADS >> a.sg.lqp) - 1) >> (8 - a.sg.lqp)) <= 4)
+        stage_halo<4>(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP, a.sg);
+    else
+        stage_halo<8>(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP, a.sg);
     dpp_stamp(a.prof, 1);
 
     // halo index of this lane's A rows (centre tap)
@@ -615,12 +619,28 @@ extern "C" int dpp_conv3x3_wtrans(const float* Wk, int Co, int Ci, float* Wd, dp
     return dpp_launch_status();
 }
 
-extern "C" int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int bm) {
+// Geometry of the filter-gradient launch: `nblk` partial slices [Co][9][Ci] (one per blockIdx.x, each workgroup walks tiles
+// blockIdx.x, +nblk, ...) and `taps_pb` taps per blockIdx.y.  The slice count is bounded by the BYTES the slices cost: the
+// 64-channel layers of a batch-128 step wrote 128 slices of 147 KB each (189 MB per step for ten layers, re-read by
+// dpp_reduce_multi at the end of the data-gradient chain); 6 MB of slices per layer is 32 of them, and the taps are dealt to
+// more workgroups instead so that >= 256 workgroups stay in flight.
+static void wgrad_geometry(int N, int H, int W, int Ci, int Co, int bm, int& nblk, int& taps_pb) {
     int lth, ltw, img;
-    if (bm != 64 && bm != 128) return -1;
     pick_tile(N, H, W, bm, lth, ltw, img);
-    int tiles = dpp_cdiv(W, 1 << ltw) * dpp_cdiv(H, 1 << lth) * dpp_cdiv(N, img);
-    return tiles < WGRAD_MAX_BLOCKS ? tiles : WGRAD_MAX_BLOCKS;
+    const int ntiles = dpp_cdiv(W, 1 << ltw) * dpp_cdiv(H, 1 << lth) * dpp_cdiv(N, img);
+    const int NT = (Co >> 4) * (Ci >> 4);
+    taps_pb = NT <= 4 ? 9 : (NT <= 16 ? 3 : 1);        // (tap, tile) pairs per workgroup <= 4 waves * MAXACC accumulators
+    int cap = WGRAD_MAX_BLOCKS;
+    while (cap > 32 && (long)cap * Co * 9 * Ci * 4 > 6L * 1024 * 1024) cap >>= 1;
+    nblk = ntiles < cap ? ntiles : cap;
+    while (taps_pb > 1 && nblk * (9 / taps_pb) < 256) taps_pb = taps_pb == 9 ? 3 : 1;
+}
+
+extern "C" int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int Ci, int Co, int bm) {
+    if ((bm != 64 && bm != 128) || Ci < 16 || Co < 16) return -1;
+    int nblk, taps_pb;
+    wgrad_geometry(N, H, W, Ci, Co, bm, nblk, taps_pb);
+    return nblk;
 }
 
 extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
@@ -634,10 +654,9 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     int TH = 1 << a.lth, TW = 1 << a.ltw;
     a.tiles_x = dpp_cdiv(W, TW); a.tiles_y = dpp_cdiv(H, TH);
     a.ntiles = a.tiles_x * a.tiles_y * dpp_cdiv(N, a.img);
-    int nblk = a.ntiles < WGRAD_MAX_BLOCKS ? a.ntiles : WGRAD_MAX_BLOCKS;
+    int nblk, taps_pb;
+    wgrad_geometry(N, H, W, Ci, Co, bm, nblk, taps_pb);
     int NT = (Co >> 4) * (Ci >> 4);
-    // (tap, tile) pairs per workgroup <= 4 waves * MAXACC accumulators
-    int taps_pb = NT <= 4 ? 9 : (NT <= 16 ? 3 : 1);
     int pairs = taps_pb * NT;
     int maxacc = dpp_cdiv(pairs, 4);
     a.taps_pb = taps_pb;
@@ -652,8 +671,8 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
 #define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<BM_, MA_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         DPP_LAUNCH((conv3x3_wgrad_kernel<BM_, MA_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
-    DPP_W3(128, 3) DPP_W3(128, 9) DPP_W3(128, 12) DPP_W3(128, 16)
-    DPP_W3(64, 3) DPP_W3(64, 9) DPP_W3(64, 12) DPP_W3(64, 16)
+    DPP_W3(128, 3) DPP_W3(128, 4) DPP_W3(128, 9) DPP_W3(128, 12) DPP_W3(128, 16)
+    DPP_W3(64, 3) DPP_W3(64, 4) DPP_W3(64, 9) DPP_W3(64, 12) DPP_W3(64, 16)
 #undef DPP_W3
     return DPP_E_UNSUPPORTED;
 }

@@ -1087,7 +1087,7 @@ class CompiledNet(object):
                 emit_param_grads(dY_keep, None)               # after the data gradient, which wrote dY_keep
         else:
             bm = 64
-            nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, Hi, Wi, bm)
+            nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, Hi, Wi, Ci, Co, bm)
             part = rt.alloc(nblk * Co * 9 * Ci, zero=False)
             self.bwd.add(ops.conv3x3_wgrad(rt, src.base.buf, N, Hi, Wi, Ci, dY, Co, part, actX=act, bm=bm), side=True)
             self.reduce_jobs.add(part, nblk, Co * 9 * Ci, gW)

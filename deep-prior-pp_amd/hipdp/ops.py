@@ -278,7 +278,7 @@ def conv3x3_wtrans(rt, Wk, Co, Ci, Wd, name='conv3x3_wtrans'):
 
 def conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, partial, actX=None, bm=64, name='conv3x3_wgrad'):
     px = float(N) * H * W
-    nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, bm)
+    nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, Ci, Co, bm)
     meta = dict(kernel='conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co, bytes=4.0 * (px * (Ci + Co) + nblk * 9.0 * Ci * Co))
     return Launch(rt.lib.dpp_conv3x3_wgrad, (X.ptr, N, H, W, Ci, _actp(actX), dY.ptr, Co, partial.ptr, bm),
                   (X, dY, partial, actX), name, meta)

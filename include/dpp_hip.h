@@ -34,7 +34,7 @@ typedef void* dpp_stream_t; /* a hipStream_t */
 #define DPP_E_BADARG 10001
 #define DPP_E_UNSUPPORTED 10002
 
-#define DPP_ABI_VERSION 5
+#define DPP_ABI_VERSION 6
 int dpp_abi_version(void);
 
 /* Pixel row map: row m of a compact (N,Ho,Wo) map -> row of a (N,Hi,Wi) map sampled with stride s.
@@ -153,8 +153,8 @@ int dpp_conv3x3_tiling(int N, int H, int W, int bm, int* th, int* tw, int* img);
 /* Wd[c][8-tap][o] = Wk[o][tap][c] (mirrored taps, channels swapped): weights of the data-gradient correlation. */
 int dpp_conv3x3_wtrans(const float* Wk, int Co, int Ci, float* Wd, dpp_stream_t stream);
 /* Filter gradient partials: partial[blk][o][tap][c] = sum over the workgroup's pixels of dY[.,o] * act(X)[.+tap, c];
- * blk < dpp_conv3x3_wgrad_blocks(N,H,W,bm); sum over blk with dpp_reduce_partials.  (T.grad, poseregnettrainer.py:110-111) */
-int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int bm);
+ * blk < dpp_conv3x3_wgrad_blocks(N,H,W,Ci,Co,bm); sum over blk with dpp_reduce_partials.  (T.grad, poseregnettrainer.py:110-111) */
+int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int Ci, int Co, int bm);
 int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
                       float* partial, int bm, dpp_stream_t stream);
 

@@ -47,7 +47,7 @@ def test_conv3x3_fwd_dgrad_wgrad(backend, cfg):
     rt.synchronize()
     np.testing.assert_allclose(layout.nhwc_to_nchw(dA.get()), da_ref, rtol=0, atol=3e-6 * np.sqrt(9 * Co) * np.abs(da_ref).max())
     # filter gradient: per-workgroup partials + fixed-order reduce
-    nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, bm)
+    nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, Ci, Co, bm)
     part = rt.alloc((nblk, Co, 9, Ci), zero=False)
     dWk = rt.alloc((Co, 9, Ci), zero=False)
     ops.conv3x3_wgrad(rt, d['X'], N, H, W, Ci, dYb, Co, part, actX=act, bm=bm)(rt.stream)

@@ -148,7 +148,7 @@ def main_conv3():
             print('%-22s bm=%3d plain  %7.2f us  %6.1f TFLOP/s  %6.0f GB/s' % (label, bm, us, 2.0 * px * 9 * C * C / us * 1e-6, 8.0 * px * C / us * 1e-3))
             dY = rt.alloc((N, H, H, C), zero=False)
             rt.tensor(dY).normal_()
-            nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, H, bm)
+            nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, H, C, C, bm)
             part = rt.alloc((nblk, C * 9 * C), zero=False)
             us = timeit(ops.conv3x3_wgrad(rt, X, N, H, H, C, dY, C, part, bm=bm))
             print('%-22s bm=%3d wgrad  %7.2f us  %6.1f TFLOP/s  %6.0f GB/s (%d partial blocks)' %
