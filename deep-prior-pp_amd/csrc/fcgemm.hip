@@ -15,6 +15,7 @@
 //   * bf16: operands are rounded (RNE) after the prologue when they are written to LDS, halving LDS bytes per flop twice over
 //     (half the bytes, 8 k per read); the matrix pipe is 16x faster, so these GEMMs become pure HBM streams.
 // Tile: 128 x 64 per workgroup (4 waves stacked along M, each 32 x 64 = 2 x 4 MFMA tiles), K chunks of 64.
+#include <stdlib.h>
 #include "dpp_common.h"
 
 namespace {
@@ -244,6 +245,218 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_gemm_kernel(FcArgs ga) {
     }
 }
 
+
+// ---- f32, three LDS stages (fc_stream_kernel) ----------------------------------------------------------------------------
+// The same GEMMs when the whole tile is inside the problem (M % 128 == 0, N % BN == 0, K slices of whole 32-deep chunks,
+// 16-byte aligned operands): tile 128 x BN (BN = 128 or 64), 2 x 2 waves of 64 x BN/2 (4 x BN/32 MFMA tiles each), and a
+// three-deep pipeline -- while the waves multiply chunk c out of LDS buffer c % 3, chunk c+1 has just been written to the next
+// buffer and the global loads of chunk c+2 are in flight, with ONE barrier per chunk.  At batch 128 the three FC1 GEMMs are 4.3
+// GFLOP each on a 67 MB weight matrix: 27 us at the f32 matrix-core peak, 10 us of HBM.  dpp_gemm's 64 x 32 / 128 x 64 tiles move
+// 390 / 200 MB through the CUs for them and wait on every chunk (102 / 104 us); here a workgroup of the forward pass owns
+// 128 x 128 outputs of one 512-deep K slice (131 MB through the CUs in total, 256 workgroups = one per CU), staging is one
+// unchecked 16-byte load per slot, and a chunk's 128..256 MFMAs per wave cover the next chunk's loads and LDS writes.
+struct FsArgs {
+    dpp_gemm_desc d;
+    int Kper;
+};
+
+template <int BN, bool AKC, bool BKC>
+__global__ __launch_bounds__(DPP_THREADS) void fc_stream_kernel(FsArgs ga) {
+    const dpp_gemm_desc& d = ga.d;
+    constexpr int BM = 128, KC = 32, LD = KC + 4, NST = 3, WM = 2, WN = 2;
+    constexpr int RM = BM / (16 * WM), CN = BN / (16 * WN);
+    constexpr int SZA = BM * LD, SZB = BN * LD, SZ = SZA + SZB;
+    HIP_DYNAMIC_SHARED(float4, smem4)
+    float* const img = reinterpret_cast<float*>(smem4);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+    const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+    const int M = d.M, N = d.N;
+    const int k_begin = blockIdx.z * ga.Kper;
+    const int nchunks = ga.Kper / KC;
+
+    // ---- staging slots -------------------------------------------------------------------------------------------------
+    // K-contiguous operand of R rows: thread (r = tid / 8, quad = tid % 8) owns rows r, r + 32, ...: one 16-byte load and one
+    // 16-byte LDS store per slot.  MN-contiguous operand [k][R]: thread (kg = tid / (R/4), cq = tid % (R/4)) loads the four k-rows
+    // 4kg .. 4kg+3 of column quad cq and stores four k-runs (one per column): the transposition happens in registers.
+    constexpr int SA = AKC ? BM / 32 : 4, SB = BKC ? BN / 32 : 4;
+    const float* pa[SA];
+    const float* pb[SB];
+    int la, lb;                                   // LDS offset of slot 0 (floats)
+    bool bvalid = true;
+    if (AKC) {
+        const int r = tid >> 3, quad = (tid & 7) * 4;
+#pragma unroll
+        for (int s = 0; s < SA; ++s) pa[s] = d.A + (size_t)(row0 + r + 32 * s) * d.lda + k_begin + quad;
+        la = r * LD + quad;
+    } else {
+        const int cq = tid % (BM / 4), kg = tid / (BM / 4);
+#pragma unroll
+        for (int s = 0; s < SA; ++s) pa[s] = d.A + (size_t)(k_begin + 4 * kg + s) * d.lda + row0 + 4 * cq;
+        la = (4 * cq) * LD + 4 * kg;
+    }
+    if (BKC) {
+        const int r = tid >> 3, quad = (tid & 7) * 4;
+#pragma unroll
+        for (int s = 0; s < SB; ++s) pb[s] = d.B + (size_t)(col0 + r + 32 * s) * d.ldb + k_begin + quad;
+        lb = r * LD + quad;
+    } else {
+        const int cq = tid % (BN / 4), kg = tid / (BN / 4);
+        bvalid = kg < KC / 4;                     // BN = 64: the chunk has 128 slots, half the threads idle
+#pragma unroll
+        for (int s = 0; s < SB; ++s) pb[s] = d.B + (size_t)(k_begin + 4 * (bvalid ? kg : 0) + s) * d.ldb + col0 + 4 * cq;
+        lb = (4 * cq) * LD + 4 * kg;
+    }
+    // operand-A prologue (BatchNorm + ReLU of the map that was flattened): channel = contiguous index % cmod
+    const int modeA = d.actA.mode;
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
+    int cidx = 0;
+    if (modeA & 2) {
+        cidx = AKC ? (k_begin + (tid & 7) * 4) % d.actA.cmod : (row0 + 4 * (tid % (BM / 4))) % d.actA.cmod;
+        if (!AKC) {
+            mu = *reinterpret_cast<const float4*>(d.actA.mean + cidx);
+            sc = *reinterpret_cast<const float4*>(d.actA.scale + cidx);
+            be = *reinterpret_cast<const float4*>(d.actA.beta + cidx);
+        }
+    }
+    float4 ra[SA], rb[SB];
+    const size_t stepA = AKC ? (size_t)KC : (size_t)KC * d.lda, stepB = BKC ? (size_t)KC : (size_t)KC * d.ldb;
+    auto fetch = [&](int c) {
+        if (AKC && (modeA & 2)) {
+            mu = *reinterpret_cast<const float4*>(d.actA.mean + cidx);
+            sc = *reinterpret_cast<const float4*>(d.actA.scale + cidx);
+            be = *reinterpret_cast<const float4*>(d.actA.beta + cidx);
+            cidx += KC;
+            if (cidx >= d.actA.cmod) cidx -= d.actA.cmod;
+        }
+#pragma unroll
+        for (int s = 0; s < SA; ++s) ra[s] = *reinterpret_cast<const float4*>(pa[s] + c * stepA);
+        if (bvalid) {
+#pragma unroll
+            for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb[s] + c * stepB);
+        }
+    };
+    auto act = [&](float4 v) {
+        if (modeA & 2) {
+            v.x = (v.x - mu.x) * sc.x + be.x; v.y = (v.y - mu.y) * sc.y + be.y;
+            v.z = (v.z - mu.z) * sc.z + be.z; v.w = (v.w - mu.w) * sc.w + be.w;
+        }
+        if (modeA & 1) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        return v;
+    };
+    auto commit = [&](int buf) {
+        float* As = img + buf * SZ;
+        float* Bs = As + SZA;
+        if (AKC) {
+#pragma unroll
+            for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(&As[la + 32 * s * LD]) = modeA ? act(ra[s]) : ra[s];
+        } else {
+            float4 v[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = modeA ? act(ra[s]) : ra[s];
+            *reinterpret_cast<float4*>(&As[la + 0 * LD]) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+            *reinterpret_cast<float4*>(&As[la + 1 * LD]) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+            *reinterpret_cast<float4*>(&As[la + 2 * LD]) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
+            *reinterpret_cast<float4*>(&As[la + 3 * LD]) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+        }
+        if (BKC) {
+#pragma unroll
+            for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(&Bs[lb + 32 * s * LD]) = rb[s];
+        } else if (bvalid) {
+            *reinterpret_cast<float4*>(&Bs[lb + 0 * LD]) = make_float4(rb[0].x, rb[1].x, rb[2].x, rb[3].x);
+            *reinterpret_cast<float4*>(&Bs[lb + 1 * LD]) = make_float4(rb[0].y, rb[1].y, rb[2].y, rb[3].y);
+            *reinterpret_cast<float4*>(&Bs[lb + 2 * LD]) = make_float4(rb[0].z, rb[1].z, rb[2].z, rb[3].z);
+            *reinterpret_cast<float4*>(&Bs[lb + 3 * LD]) = make_float4(rb[0].w, rb[1].w, rb[2].w, rb[3].w);
+        }
+    };
+
+    f32x4 acc[RM][CN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dpp_wide_coef wco;
+    wco.load<BN>(col0, N, d.splitk == 1 ? d.bias : nullptr, d.epi);
+
+    fetch(0);
+    commit(0);
+    if (nchunks > 1) fetch(1);
+    __syncthreads();
+    int cur = 0;
+    const int aoff = (wm * (BM / WM) + l15) * LD + kq * 4, boff = (wn * (BN / WN) + l15) * LD + kq * 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const int nxt = cur == NST - 1 ? 0 : cur + 1;
+        if (c + 1 < nchunks) commit(nxt);                 // its loads were issued one whole MFMA block ago
+        if (c + 2 < nchunks) fetch(c + 2);                // in flight under this chunk's MFMAs
+        const float* As = img + cur * SZ;
+        const float* Bs = As + SZA;
+#pragma unroll
+        for (int k0 = 0; k0 < KC; k0 += 16) {
+            float4 af[RM], bf[CN];
+#pragma unroll
+            for (int rt = 0; rt < RM; ++rt) af[rt] = *reinterpret_cast<const float4*>(&As[aoff + rt * 16 * LD + k0]);
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) bf[ct] = *reinterpret_cast<const float4*>(&Bs[boff + ct * 16 * LD + k0]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < CN; ++ct)
+                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(af[rt], t), dpp_f4_get(bf[ct], t), acc[rt][ct], 0, 0, 0);
+        }
+        __syncthreads();
+        cur = nxt;
+    }
+
+    float* smem = reinterpret_cast<float*>(smem4);
+    if (d.splitk > 1) {
+        dpp_epilogue ep0 = {};
+        float* P = d.partial + (size_t)blockIdx.z * M * N;
+        dpp_epilogue_wide<RM, CN, WM, WN, BM, BN>(acc, smem, col0, N, wco, nullptr, P, ep0, BM, wm, wn, l15, kq,
+                                                  [&](int rl) { return (long)(row0 + rl) * N; });
+    } else {
+        dpp_epilogue_wide<RM, CN, WM, WN, BM, BN>(acc, smem, col0, N, wco, d.residual, d.C, d.epi, BM, wm, wn, l15, kq,
+                                                  [&](int rl) { return (long)dpp_map_row(d.mapC, row0 + rl) * d.ldc; });
+    }
+}
+
+template <int BN, bool AKC, bool BKC>
+int fs_launch(const FsArgs& ga, dim3 grid, hipStream_t st) {
+    constexpr size_t opb = 3 * (size_t)(128 + BN) * 36 * sizeof(float);
+    constexpr size_t epb = ((size_t)128 * (BN + 4) + 16 * BN) * 4;
+    const size_t lds = opb > epb ? opb : epb;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_stream_kernel<BN, AKC, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DPP_LAUNCH((fc_stream_kernel<BN, AKC, BKC>), grid, dim3(DPP_THREADS), lds, st, ga);
+    return dpp_launch_status();
+}
+
+template <int BN>
+int fs_dispatch(const FsArgs& ga, dim3 grid, hipStream_t st) {
+    const dpp_gemm_desc& d = ga.d;
+    if (d.a_kc && d.b_kc) return fs_launch<BN, true, true>(ga, grid, st);
+    if (d.a_kc && !d.b_kc) return fs_launch<BN, true, false>(ga, grid, st);
+    if (!d.a_kc && !d.b_kc) return fs_launch<BN, false, false>(ga, grid, st);
+    return fs_launch<BN, false, true>(ga, grid, st);
+}
+
+// whether fc_stream_kernel takes the call; bn receives its column tile
+bool fs_accepts(const dpp_gemm_desc& d, int& bn) {
+    static const bool on = []() { const char* e = getenv("DPP_FC_STREAM3"); return !(e && e[0] == '0'); }();
+    if (!on) return false;
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (d.M % 128 || d.K % d.splitk || (d.K / d.splitk) % 32) return false;
+    if (!al(d.A) || !al(d.B) || (d.lda & 3) || (d.ldb & 3)) return false;
+    if (d.mapA.s != 1 || d.mapB.s != 1 || d.actB.mode != 0) return false;
+    if (d.actA.mode & 2) {
+        if ((d.actA.cmod & 3) || d.actA.cmod < 32) return false;
+        if (!al(d.actA.mean) || !al(d.actA.scale) || !al(d.actA.beta)) return false;
+    }
+    // 128-wide column tiles when they still give every CU a workgroup
+    bn = (d.N % 128 == 0 && (long)(d.M / 128) * (d.N / 128) * d.splitk >= 256) ? 128 : 64;
+    return d.N % bn == 0;
+}
+
 template <int PREC, int RM, int CN, int KC, bool AKC, bool BKC>
 int fc_launch(const FcArgs& ga, dim3 grid, hipStream_t st) {
     typedef typename Prec<PREC>::elem elem;
@@ -285,6 +498,15 @@ extern "C" int dpp_fc_gemm(const dpp_gemm_desc* dp, int precision, int kchunk, d
     if (d.residual && (reinterpret_cast<uintptr_t>(d.residual) & 15)) return DPP_E_UNSUPPORTED;
     const int KC = kchunk == 0 ? 64 : kchunk;
     if (KC != 32 && KC != 64) return DPP_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int bn3 = 0;
+    if (precision == 0 && fs_accepts(d, bn3)) {
+        FsArgs fa;
+        fa.d = d;
+        fa.Kper = d.K / d.splitk;
+        dim3 g3(d.M / 128, d.N / bn3, d.splitk);
+        return bn3 == 128 ? fs_dispatch<128>(fa, g3, st) : fs_dispatch<64>(fa, g3, st);
+    }
     FcArgs ga;
     ga.d = d;
     auto aligned = [](const float* p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; };
@@ -294,7 +516,6 @@ extern "C" int dpp_fc_gemm(const dpp_gemm_desc* dp, int precision, int kchunk, d
     per = (per + KC - 1) / KC * KC;
     ga.Kper = per;
     dim3 grid(dpp_cdiv(d.M, 128), dpp_cdiv(d.N, 64), d.splitk);
-    hipStream_t st = static_cast<hipStream_t>(stream);
     if (precision == 0) return KC == 64 ? fc_dispatch<0, 64>(ga, grid, st) : fc_dispatch<0, 32>(ga, grid, st);
     return KC == 64 ? fc_dispatch<1, 64>(ga, grid, st) : fc_dispatch<1, 32>(ga, grid, st);
 }

@@ -286,12 +286,13 @@ EARLY_BUCKET_MIN = int(os.environ.get('DPP_EARLY_BUCKET_MIN', str(1 << 22)))    
 #      then starts after it instead of beside it.
 LAZY_BN_BWD = int(os.environ.get('DPP_LAZY_BN_BWD', '0'))
 BF16_DEFAULT = os.environ.get('DPP_BF16', '0') == '1'
-# FC1 (the HiddenLayer behind the last conv map) on the weight-streaming kernel dpp_fc_gemm (K-contiguous double-buffered LDS
-# images, f32 or bf16) instead of the generic dpp_gemm
-# Measured (profiles/r02_fc1_kernels.txt): in f32 the streaming kernel only ties with dpp_gemm (both are bound by the f32 MFMA
-# issue pattern, not by operand traffic), so it is the default for bf16 only -- where dpp_gemm has no counterpart.
-#   DPP_FC1_STREAM=1: also in f32, =0: never (bf16 FC1 then falls back to f32 dpp_gemm)
-FC1_STREAM = os.environ.get('DPP_FC1_STREAM', 'bf16')
+# FC1 (the HiddenLayer behind the last conv map) on the weight-streaming kernels of dpp_fc_gemm instead of the generic dpp_gemm.
+# f32: the three-stage kernel (fc_stream_kernel: 128 x 128 / 128 x 64 tiles, whole tiles only) runs the batch-128 FC1 forward /
+# data gradient in 53 / 70 us against dpp_gemm's 102 / 104 us; the older double-buffered kernel, which takes ragged shapes, only
+# ties with dpp_gemm in f32 (profiles/r02_fc1_kernels.txt), so f32 goes there only when the shape fits the three-stage kernel.
+# bf16 (config 5) always uses dpp_fc_gemm: dpp_gemm has no bf16 counterpart.
+#   DPP_FC1_STREAM=auto (default) | bf16: bf16 only | 1: always | 0: never (bf16 FC1 then falls back to f32 dpp_gemm)
+FC1_STREAM = os.environ.get('DPP_FC1_STREAM', 'auto')
 FC1_KCHUNK = int(os.environ.get('DPP_FC1_KCHUNK', '0'))
 FC1_SLICES = int(os.environ.get('DPP_FC1_SLICES', '32'))
 FC1_MIN_K = int(os.environ.get('DPP_FC1_MIN_K', '4096'))
@@ -499,8 +500,17 @@ class CompiledNet(object):
                 out.append(l.W)
         return out
 
-    def _fc1_stream(self):
-        return FC1_STREAM == '1' or (FC1_STREAM == 'bf16' and self.prec == 1)
+    def _fc1_stream(self, Nb, K, Nout):
+        if not is_fc1_shape(Nb, K, Nout) or FC1_STREAM == '0':
+            return False
+        if FC1_STREAM == '1' or self.prec == 1:
+            return True
+        if FC1_STREAM != 'auto':
+            return False
+        # f32: whole 128-row tiles in all three GEMMs (forward / data gradient rows = samples, filter gradient reduces over them),
+        # whole 32-deep chunks per K slice
+        splitk = max(1, min(FC1_SLICES, K // 512))
+        return Nb % 128 == 0 and K % 128 == 0 and Nout % 64 == 0 and K % splitk == 0 and (K // splitk) % 32 == 0
 
     def _single_consumer(self, var):
         return len(self.consumers.get(id(var), [])) == 1
@@ -748,7 +758,7 @@ class CompiledNet(object):
         out = self._new_tensor((Nb, Nout), 'fc%d' % layer.layerNum)
         rt, st = self.rt, self.store
         act = self._act(src)
-        if self._fc1_stream() and is_fc1_shape(Nb, K, Nout):
+        if self._fc1_stream(Nb, K, Nout):
             splitk = max(1, min(FC1_SLICES, K // 512))
             part = self.scratch(splitk * Nb * Nout)
             self.fwd.add(ops.fc_gemm(rt, src.base.buf, st.view(layer.W), None, Nb, Nout, K, 1, 0, K, Nout, Nout, actA=act, splitk=splitk,
@@ -1116,7 +1126,7 @@ class CompiledNet(object):
         act = self._act(src)
         self.bwd.fork()
         self._bias_grad(dY, Nb, Nout, gb)
-        stream_kernel = self._fc1_stream() and is_fc1_shape(Nb, K, Nout)
+        stream_kernel = self._fc1_stream(Nb, K, Nout)
         if stream_kernel:
             self.bwd.add(ops.fc_gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, precision=self.prec,
                                      kchunk=FC1_KCHUNK, name='fc_wgrad_%d' % layer.layerNum), side=True)

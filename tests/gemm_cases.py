@@ -9,11 +9,14 @@ from hipdp.lib import RowMap
 
 def gemm_problems(eng):
     seen = {}
+    lib = eng.rt.lib
     for _, l in eng.all_launches():
-        if l.fn is not eng.rt.lib.dpp_gemm:
+        if l.fn is not lib.dpp_gemm and l.fn is not lib.dpp_fc_gemm:
             continue
         d = l.keep[0]
-        key = (d.M, d.N, d.K, d.a_kc, d.b_kc, d.lda, d.ldb, d.ldc, d.mapA.s, d.mapB.s, d.mapC.s, d.bm, d.bn, d.wm, d.splitk, d.variant,
+        # the weight-streaming kernels (dpp_fc_gemm: same descriptor) are keyed with tile (-1, precision, kchunk)
+        tile = (d.bm, d.bn, d.wm) if l.fn is lib.dpp_gemm else (-1, l.args[1], l.args[2])
+        key = (d.M, d.N, d.K, d.a_kc, d.b_kc, d.lda, d.ldb, d.ldc, d.mapA.s, d.mapB.s, d.mapC.s) + tile + (d.splitk, d.variant,
                d.actA.mode, d.actB.mode, bool(d.bias), bool(d.residual), bool(d.epi.stats), bool(d.epi.bn_x))
         seen.setdefault(key, (l.name, d))
     return seen
@@ -55,8 +58,11 @@ def _apply_act(X, c):
     return v
 
 
-def check_gemm_problem(rt, rng, name, d0):
-    """Returns None if the problem was checked, or a reason string if it is covered elsewhere."""
+def check_gemm_problem(rt, rng, name, d0, fc=None):
+    """Returns None if the problem was checked, or a reason string if it is covered elsewhere.  fc = (precision, kchunk) when the
+    launch was a dpp_fc_gemm."""
+    if fc is not None and fc[0] != 0:
+        return 'bf16 operands: tests/test_gemm.py, tests/test_configs.py'
     if d0.actA.mode == 4:
         return 'mode-4 prologue (lazy BatchNorm backward): tests/test_engine.py'
     if d0.epi.bn_x:
@@ -89,13 +95,18 @@ def check_gemm_problem(rt, rng, name, d0):
         up = lambda v: rt.upload(v) if v is not None else None          # noqa: E731
         return ops.act(c['mode'], up(c['mean']), up(c['scale']), up(c['beta']), c['cmod'])
 
-    nblk = -(-M // d0.bm)
+    nblk = -(-M // d0.bm) if fc is None else 1
     stats = rt.alloc((2, N, nblk), zero=False) if d0.epi.stats else None
-    op = ops.gemm(rt, dA, dB, Cb if d0.splitk == 1 else None, M, N, K, d0.a_kc, d0.b_kc, d0.lda, d0.ldb, ldc,
+    if fc is not None:
+        op = ops.fc_gemm(rt, dA, dB, Cb if d0.splitk == 1 else None, M, N, K, d0.a_kc, d0.b_kc, d0.lda, d0.ldb, ldc, actA=mkact(ca),
+                         actB=mkact(cb), bias=rt.upload(bias) if bias is not None else None, residual=Cb if res is not None else None,
+                         splitk=d0.splitk, partial=part, precision=fc[0], kchunk=fc[1], name=name)
+    else:
+        op = ops.gemm(rt, dA, dB, Cb if d0.splitk == 1 else None, M, N, K, d0.a_kc, d0.b_kc, d0.lda, d0.ldb, ldc,
                   mapA=_copy_map(d0.mapA), mapB=_copy_map(d0.mapB), mapC=_copy_map(d0.mapC), actA=mkact(ca), actB=mkact(cb),
                   bias=rt.upload(bias) if bias is not None else None, residual=Cb if res is not None else None, splitk=d0.splitk,
-                  partial=part, tile=(d0.bm, d0.bn, d0.wm), epi=ops.epilogue(stats=stats) if stats is not None else None,
-                  variant=d0.variant, name=name)
+                      partial=part, tile=(d0.bm, d0.bn, d0.wm), epi=ops.epilogue(stats=stats) if stats is not None else None,
+                      variant=d0.variant, name=name)
     op(rt.stream)
     rt.synchronize()
     if d0.splitk > 1:
@@ -122,6 +133,6 @@ def check_all(rt, eng, seed=3):
     probs = gemm_problems(eng)
     checked, skipped = [], []
     for key, (name, d0) in sorted(probs.items(), key=lambda kv: kv[1][0]):
-        why = check_gemm_problem(rt, rng, name, d0)
+        why = check_gemm_problem(rt, rng, name, d0, fc=(key[12], key[13]) if key[11] == -1 else None)
         (checked if why is None else skipped).append((name, key))
     return checked, skipped

@@ -226,8 +226,12 @@ def test_fc_gemm_layouts_and_precisions(backend, precision, layout):
     rt = get_runtime(backend)
     rng = np.random.RandomState(17 + precision)
     a_kc, b_kc = {'fwd': (1, 0), 'dgrad': (1, 1), 'wgrad': (0, 0), 'tn': (0, 1)}[layout]
-    for (M, N, K, splitk, kchunk, feats) in ((40, 72, 200, 1, 0, 'act+bias+res'), (128, 64, 192, 3, 32, ''), (200, 132, 96, 1, 32, 'relu'),
-                                             (16, 8, 64, 2, 0, 'act')):
+    shapes = [(40, 72, 200, 1, 0, 'act+bias+res'), (128, 64, 192, 3, 32, ''), (200, 132, 96, 1, 32, 'relu'), (16, 8, 64, 2, 0, 'act')]
+    if precision == 0:
+        # whole 128-row tiles, K slices of whole 32-deep chunks: the three-stage f32 kernel (fc_stream_kernel), 64- and 128-wide
+        # column tiles (the latter needs >= 256 workgroups), one and several chunks per slice, every epilogue / prologue feature
+        shapes += [(128, 192, 96, 1, 0, 'act+bias+res'), (256, 64, 256, 2, 0, 'relu'), (256, 512, 1024, 32, 0, 'act'), (128, 128, 64, 1, 0, 'bias')]
+    for (M, N, K, splitk, kchunk, feats) in shapes:
         A = rng.normal(0, 1, (M, K) if a_kc else (K, M)).astype(np.float32)
         Bm = rng.normal(0, 1, (N, K) if b_kc else (K, N)).astype(np.float32)
         cmod = (K if a_kc else M)
