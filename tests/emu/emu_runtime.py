@@ -14,7 +14,15 @@ EMU_LIB = os.path.join(ROOT, 'tests', 'emu', '_build', 'libdpp_emu.so')
 
 
 def build_emulator():
-    subprocess.check_call(['make', '-s', '-j8', '-C', os.path.join(ROOT, 'deep-prior-pp_amd', 'csrc'), 'emu'])
+    """make emu (a no-op when the library is newer than the kernel sources), under a file lock: several test processes may ask."""
+    import fcntl
+    os.makedirs(os.path.dirname(EMU_LIB), exist_ok=True)
+    with open(os.path.join(os.path.dirname(EMU_LIB), '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            subprocess.check_call(['make', '-s', '-j8', '-C', os.path.join(ROOT, 'deep-prior-pp_amd', 'csrc'), 'emu'])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return EMU_LIB
 
 
