@@ -106,39 +106,103 @@ extern "C" int dpp_plan_count(const dpp_plan* plan, int* launches, int* forks, i
 
 // Eager issue.  A fork is (record event on main, side waits for it), a join the mirror image; markers whose waiting lane has
 // nothing to wait for (no launch on the other lane since the previous marker of that kind) are skipped.
+//
+// Lane 1 can be spread over SEVERAL side streams (DPP_SIDE_STREAMS = S > 1): the launches between two forks are one group
+// (a layer's bias / filter gradient: they only read what the main chain has produced and write buffers of their own), groups
+// are dealt round-robin to the S streams, so filter gradients of different layers overlap each other as well as the main
+// chain.  Seen from outside nothing changes: a join makes main wait for every side stream, and before the call returns the
+// extra streams are folded into `side_stream`, so whatever the caller issues there next (a collective) is behind all of lane 1.
+static int plan_side_streams() {
+    static const int n = []() {
+        const char* e = getenv("DPP_SIDE_STREAMS");
+        int v = e ? atoi(e) : 1;
+        return v < 1 ? 1 : (v > 8 ? 8 : v);
+    }();
+    return n;
+}
+
+static hipStream_t plan_extra_stream(int i) {      // i >= 1; created on first use, live for the process
+    static hipStream_t pool[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (!pool[i]) {
+        if (hipStreamCreateWithFlags(&pool[i], hipStreamNonBlocking) != hipSuccess) pool[i] = nullptr;
+    }
+    return pool[i];
+}
+
 extern "C" int dpp_plan_run(dpp_plan* plan, dpp_stream_t main_stream, dpp_stream_t side_stream) {
     if (!plan || plan->recording) return DPP_E_BADARG;
     hipStream_t ms = static_cast<hipStream_t>(main_stream);
     hipStream_t ss = static_cast<hipStream_t>(side_stream);
     const bool two = side_stream != nullptr && ss != ms;
-    if (two && plan->events.size() < (size_t)(plan->forks + plan->joins)) {
-        while (plan->events.size() < (size_t)(plan->forks + plan->joins)) {
-            hipEvent_t e;
-            hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
-            if (err != hipSuccess) return (int)err;
-            plan->events.push_back(e);
-        }
+    int S = two ? plan_side_streams() : 1;
+    hipStream_t sides[8] = {ss, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 1; i < S; ++i) {
+        sides[i] = plan_extra_stream(i);
+        if (!sides[i]) { S = i; break; }
     }
     size_t ev = 0;
-    // work issued on a lane since the other lane last synchronised with it.  Both start TRUE: a plan may be one segment of a
-    // longer sequence (collectives run between segments), so the lane may carry work from before this call
-    bool main_dirty = true, side_dirty = true;
+    auto next_event = [&](hipEvent_t* e) -> hipError_t {
+        if (ev == plan->events.size()) {
+            hipEvent_t n;
+            hipError_t err = hipEventCreateWithFlags(&n, hipEventDisableTiming);
+            if (err != hipSuccess) return err;
+            plan->events.push_back(n);
+        }
+        *e = plan->events[ev++];
+        return hipSuccess;
+    };
+    // work issued on a lane since the other lane last synchronised with it.  Main and the caller's side stream start TRUE: a plan
+    // may be one segment of a longer sequence (collectives run between segments), so the lane may carry work from before this
+    // call; the extra streams were folded into the side stream at the end of the previous call.
+    bool main_dirty = true;
+    bool side_dirty[8] = {true, false, false, false, false, false, false, false};
+    hipEvent_t fork_event = nullptr;         // latest event recorded on main; covers all main work iff !main_dirty
+    bool waited[8] = {false, false, false, false, false, false, false, false};      // side stream i already waits for fork_event
+    int cur = 0, groups = 0;
     for (dpp_plan_node& n : plan->nodes) {
-        if (n.kind == 2 || n.kind == 3) {
+        if (n.kind == 2) {                   // fork: the next lane-1 group starts here
             if (!two) continue;
-            hipEvent_t e = plan->events[ev++];
-            const bool fork = n.kind == 2;
-            if (fork ? !main_dirty : !side_dirty) continue;
-            hipError_t err = hipEventRecord(e, fork ? ms : ss);
-            if (err == hipSuccess) err = hipStreamWaitEvent(fork ? ss : ms, e, 0);
-            if (err != hipSuccess) return (int)err;
-            (fork ? main_dirty : side_dirty) = false;
+            if (S > 1) cur = groups++ % S;
+            if (main_dirty) {
+                hipError_t err = next_event(&fork_event);
+                if (err == hipSuccess) err = hipEventRecord(fork_event, ms);
+                if (err != hipSuccess) return (int)err;
+                main_dirty = false;
+                for (int i = 0; i < S; ++i) waited[i] = false;
+            }
+            if (fork_event && !waited[cur]) {
+                hipError_t err = hipStreamWaitEvent(sides[cur], fork_event, 0);
+                if (err != hipSuccess) return (int)err;
+                waited[cur] = true;
+            }
             continue;
         }
-        hipStream_t s = (two && n.lane == 1) ? ss : ms;
+        if (n.kind == 3) {                   // join: main waits for every side stream that has issued work
+            if (!two) continue;
+            for (int i = 0; i < S; ++i) {
+                if (!side_dirty[i]) continue;
+                hipEvent_t e;
+                hipError_t err = next_event(&e);
+                if (err == hipSuccess) err = hipEventRecord(e, sides[i]);
+                if (err == hipSuccess) err = hipStreamWaitEvent(ms, e, 0);
+                if (err != hipSuccess) return (int)err;
+                side_dirty[i] = false;
+            }
+            continue;
+        }
+        const bool on_side = two && n.lane == 1;
+        hipStream_t s = on_side ? sides[cur] : ms;
         hipError_t err = n.kind == 0 ? n.issue(s) : hipMemsetAsync(n.ptr, 0, n.nbytes, s);
         if (err != hipSuccess) return (int)err;
-        (n.lane == 1 && two ? side_dirty : main_dirty) = true;
+        if (on_side) side_dirty[cur] = true; else main_dirty = true;
+    }
+    for (int i = 1; i < S; ++i) {            // fold the extra streams into the caller's side stream
+        if (!side_dirty[i]) continue;
+        hipEvent_t e;
+        hipError_t err = next_event(&e);
+        if (err == hipSuccess) err = hipEventRecord(e, sides[i]);
+        if (err == hipSuccess) err = hipStreamWaitEvent(ss, e, 0);
+        if (err != hipSuccess) return (int)err;
     }
     return DPP_OK;
 }

@@ -286,6 +286,18 @@ EARLY_BUCKET_MIN = int(os.environ.get('DPP_EARLY_BUCKET_MIN', str(1 << 22)))    
 #      then starts after it instead of beside it.
 LAZY_BN_BWD = int(os.environ.get('DPP_LAZY_BN_BWD', '0'))
 BF16_DEFAULT = os.environ.get('DPP_BF16', '0') == '1'
+# ADAM of the FC1 weight (90 % of the parameters, 470 MB of optimizer traffic) inside the backward pass: its gradient is final a few
+# kernels into the pass, so the update runs on the gradient branch under the latency-bound data-gradient chain instead of in the
+# serial tail of the step (step_plan only: cost_and_grads / allreduce paths keep backward and update apart).
+# Measured on the MI355X (tools/exp_tail.sh, profiles/r02_tail_experiments.txt): 4.19-4.20 vs 4.18 ms per step -- the gradient branch
+# finishes together with the data-gradient chain (tools/tail_probe.py: 2.51 vs 2.53 ms), so work moved onto it comes back as a longer
+# wait at the join.  Off by default; the plan surgery stays tested (tests/test_engine.py).
+EARLY_ADAM = os.environ.get('DPP_EARLY_ADAM', '0') != '0'
+# Filter / bias gradient partials are summed by dpp_reduce_multi.  One launch at the end of the pass reads all of them (224 MB) in the
+# serial tail of the step; with a threshold the jobs collected so far are reduced on the gradient branch as soon as they amount to
+# this many bytes (their producers are on that branch or already issued on the main stream), and the tail launch keeps the rest.
+# Measured: 4.21 (16 MB) / 4.19 (64 MB) vs 4.18 ms with the single launch, for the same reason as EARLY_ADAM.  0 = one launch (default).
+EARLY_REDUCE_BYTES = int(os.environ.get('DPP_EARLY_REDUCE_MB', '0')) << 20
 # FC1 (the HiddenLayer behind the last conv map) on the weight-streaming kernels of dpp_fc_gemm instead of the generic dpp_gemm.
 # f32: the three-stage kernel (fc_stream_kernel: 128 x 128 / 128 x 64 tiles, whole tiles only) runs the batch-128 FC1 forward /
 # data gradient in 53 / 70 us against dpp_gemm's 102 / 104 us; the older double-buffered kernel, which takes ragged shapes, only
@@ -426,6 +438,7 @@ class CompiledNet(object):
             self.hyper = rt.alloc(8)
             self.early_side = []
             self._early_slice, self._early_work = None, [None]
+            self._early_adam = None
             self._emit_backward()
             if self.early_side:
                 self.fwd.ops[0:0] = [(ops.Fork(), False)] + [(o, True) for o in self.early_side]
@@ -973,18 +986,22 @@ class CompiledNet(object):
                 tgt.grad_written = True
             else:
                 raise NotImplementedError(kind)
+            if EARLY_REDUCE_BYTES > 0 and self.reduce_jobs.pending_bytes() >= EARLY_REDUCE_BYTES:
+                self.bwd.fork()
+                self.bwd.add(self.reduce_jobs.flush('reduce_multi_early'), side=True)
         self.bwd.join()
-        self.bwd.add(self.reduce_jobs.launch())       # every filter / bias gradient partial of the pass, one launch
+        self.bwd.add(self.reduce_jobs.flush())        # the remaining filter / bias gradient partials of the pass, one launch
         for slot, priv in self.__dict__.get('_shared_grad_adds', []):
             self.bwd.add(ops.axpy(rt, slot, priv, 1.0, slot.size))     # shared parameters: sum of the per-use gradients
         # cost += wd * sum(W^2): gradient 2*wd*W.  Single process: the last step of the backward plan.  Data parallel: the
         # regulariser is NOT a per-shard partial sum, so it is added once, AFTER the gradient all-reduce (added before, the
         # sum over ranks would scale it by the world size -- and the axpy would write the slice whose all-reduce the early bucket
         # still has in flight)
-        self._wd_ops = []
+        self._wd_ops, self._wd_of = [], {}
         if self.weight_decay and not self.net.hasDropout():
             for W in self._unique_weights():
                 self._wd_ops.append(ops.axpy(rt, st.view(W, 'g'), st.view(W), 2.0 * self.weight_decay, int(np.prod(W.shape))))
+                self._wd_of[id(self._wd_ops[-1])] = W.auto_name
         if self.dp is None:
             for o in self._wd_ops:
                 self.bwd.add(o)
@@ -1022,7 +1039,7 @@ class CompiledNet(object):
             return
         rpb = max(32, -(-rows // 256))
         nb = -(-rows // rpb)
-        part = self.scratch_side(nb * C)
+        part = self.rt.alloc(nb * C, zero=False)     # private: groups of the gradient branch may run on different side streams
         self.bwd.add(ops.colsum_partial(self.rt, dY, rows, C, rpb, part), side=True)
         self.bwd.add(ops.reduce_partials(self.rt, part, nb, C, gslot), side=True)
 
@@ -1160,6 +1177,12 @@ class CompiledNet(object):
             tgt.grad_written = True
             if getattr(src.base, 'concat_parts', None) is not None:
                 self._split_concat_grad(src.base)
+        if self._early_adam is None and K * Nout >= EARLY_BUCKET_MIN and gW.ptr >= st.g.ptr and \
+                gW.ptr + 4 * K * Nout <= st.g.ptr + 4 * st.n_w:
+            # from here on nothing reads this weight or writes its gradient any more (filter gradient on the branch, data gradient
+            # on the main stream, both issued above): the position where step_plan may put its ADAM update
+            off = (gW.ptr - st.g.ptr) // 4
+            self._early_adam = dict(after=self.bwd.ops[-1][0], lo=off, hi=off + K * Nout, W=layer.W)
 
     def _bwd_convpool(self, layer, io, dY):
         rt, st = self.rt, self.store
@@ -1251,8 +1274,45 @@ class CompiledNet(object):
         key = id(before) if before is not None else 0
         cache = self.__dict__.setdefault('_step_plans', {})
         if key not in cache:
-            cache[key] = (before, Plan.concat('step', ([before] if before is not None else []) + [self.fwd, self.lossplan, self.bwd, self.upd]))
+            bwd, upd = self._early_adam_plans()
+            plan = Plan.concat('step', ([before] if before is not None else []) + [self.fwd, self.lossplan, bwd, upd])
+            skip = tuple(x for x in os.environ.get('DPP_WHATIF_SKIP', '').split(',') if x)
+            if skip:
+                # ablation for tools/whatif.sh ONLY (results are wrong): the step without the launches whose name starts with one of
+                # the prefixes -- what the step would cost if those kernels were free
+                plan.ops = [(op, side) for (op, side) in plan.ops if not str(getattr(op, 'name', '')).startswith(skip)]
+            cache[key] = (before, plan)
         return cache[key][1]
+
+    def _early_adam_plans(self):
+        """(backward, update) plans of a whole step.  With EARLY_ADAM the FC1 weight is updated inside the backward pass, on the
+        gradient branch, right after the two kernels that use it (its weight-decay term first), and the update plan covers the rest of
+        the flat buffer.  Single process only: with data parallelism the gradient is not final before its all-reduce."""
+        ea = self._early_adam
+        if not EARLY_ADAM or ea is None or self.dp is not None:
+            return self.bwd, self.upd
+        if '_early_adam_cache' in self.__dict__:
+            return self._early_adam_cache
+        rt, st = self.rt, self.store
+        lo, hi, n = ea['lo'], ea['hi'], st.n_w
+        sl = lambda b, a, z: b.view(a, (z - a,))          # noqa: E731
+        bwd = Plan('backward')
+        early = [o for o in self._wd_ops if self._wd_of.get(id(o)) == ea['W'].auto_name]
+        early.append(ops.adam(rt, sl(st.w, lo, hi), sl(st.g, lo, hi), sl(st.m, lo, hi), sl(st.v, lo, hi), hi - lo, self.hyper, name='adam_fc1'))
+        pos = 1 + [i for i, (op, _) in enumerate(self.bwd.ops) if op is ea['after']][0]      # (an index would go stale: plans are edited)
+        head = list(self.bwd.ops[:pos])
+        tail = [(op, side) for (op, side) in self.bwd.ops[pos:] if not any(op is e for e in early)]
+        bwd.ops = head + [(ops.Fork(), False)] + [(o, True) for o in early] + tail
+        bwd.uses_side = True
+        upd = Plan('update')
+        for a, z in ((0, lo), (hi, n)):
+            if z > a:
+                upd.add(ops.adam(rt, sl(st.w, a, z), sl(st.g, a, z), sl(st.m, a, z), sl(st.v, a, z), z - a, self.hyper))
+        for (op, side) in self.upd.ops:
+            if getattr(op, 'name', '') != 'adam':
+                upd.add(op, side)
+        self._early_adam_cache = (bwd, upd)
+        return self._early_adam_cache
 
     def train_step_device(self, lr, allreduce=None):
         self.set_lr(lr)

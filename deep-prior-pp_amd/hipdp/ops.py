@@ -490,6 +490,15 @@ class ReduceJobs(object):
     def add(self, partial, nz, n, out):
         self.jobs.append((partial, int(nz), int(n), out))
 
+    def pending_bytes(self):
+        return 4 * sum(nz * n for (_, nz, n, _) in self.jobs)
+
+    def flush(self, name='reduce_multi'):
+        """The launch for the jobs collected so far; the list starts over (several launches per pass, see engine._emit_backward)."""
+        op = self.launch(name)
+        self.jobs = []
+        return op
+
     def launch(self, name='reduce_multi'):
         if not self.jobs:
             return None

@@ -1,5 +1,8 @@
 """Worker of tests/test_data_parallel.py: one data-parallel rank (gloo, emulator runtime) computing the gradients of its
-shard of a global batch with sync-BN, then one full train step.  Usage: dp_worker.py <out.npz> <sync_bn 0|1> [weight_decay]"""
+shard of a global batch with sync-BN, then one full train step.  Usage: dp_worker.py <out.npz> <sync_bn 0|1> [weight_decay]
+DPP_WORKER_BACKEND=nccl: the same on the MI355X through RCCL (the GPU tier runs it with a world of ONE rank: every collective of
+the step -- early FC1 bucket from the side stream, its wait, the second bucket, the sync-BN all-gathers, the cost reduction and
+the parameter broadcast -- goes through RCCL and its stream ordering, and must leave the single-process result untouched)."""
 import os
 import sys
 
@@ -15,15 +18,25 @@ import numpy as np  # noqa: E402
 from hipdp import engine, parallel  # noqa: E402
 from net.resnet import ResNet, ResNetParams  # noqa: E402
 from oracle import nets  # noqa: E402
-from tests.emu.emu_runtime import EmuRuntime  # noqa: E402
 
 
 def main():
     out, sync = sys.argv[1], bool(int(sys.argv[2]))
     wd = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
-    rank, world = parallel.init_from_env('gloo')
-    rt = EmuRuntime()
-    B = 4
+    if os.environ.get('DPP_WORKER_BACKEND') == 'nccl':
+        import torch
+        import torch.distributed as dist
+        from hipdp.runtime import TorchHipRuntime
+        torch.cuda.set_device(0)
+        rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world)     # also for a world of one
+        assert dist.get_backend() == 'nccl'
+        rt = TorchHipRuntime()
+    else:
+        from tests.emu.emu_runtime import EmuRuntime
+        rank, world = parallel.init_from_env('gloo')
+        rt = EmuRuntime()
+    B = int(os.environ.get('DPP_WORKER_BATCH', '4'))
     net = ResNet(np.random.RandomState(23455 + rank), cfgParams=ResNetParams(type=0, wIn=32, hIn=32, batchSize=B, numJoints=1, nDims=30))
     dp = parallel.DataParallel(rt, sync_bn=sync)
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), dp=dp, weight_decay=wd)   # broadcasts rank 0's parameters

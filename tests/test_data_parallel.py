@@ -25,11 +25,12 @@ def _free_port():
     return p
 
 
-def _run_ranks(tmp_path, sync, world=2, wd=0.0):
+def _run_ranks(tmp_path, sync, world=2, wd=0.0, **extra_env):
     port = _free_port()
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.update(extra_env)
         out = os.path.join(str(tmp_path), 'rank%d_%d.npz' % (r, int(sync)))
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), out, str(int(sync)), repr(wd)], env=env,
@@ -77,3 +78,26 @@ def test_local_bn_replicas_stay_identical(tmp_path):
         if k.startswith('g_') or k == 'w_last':
             assert np.array_equal(r0[k], r1[k]), k
     assert not np.array_equal(r0['bn_mean'], r1['bn_mean'])            # per-GPU running statistics differ by design
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sync', [False, True])
+def test_rccl_world_of_one_equals_single_process(tmp_path, sync):
+    """The data-parallel step through RCCL on the MI355X, one rank: the all-reduces / all-gathers are identities, so gradients,
+    cost and the updated weights must be BIT-identical to the engine without `dp` -- what is tested is that the collectives are
+    ordered correctly against the engine's two HIP streams (a race shows up as a stale or half-reduced FC1 gradient)."""
+    B = 8
+    (r0,) = _run_ranks(tmp_path, sync=sync, world=1, wd=1e-3, DPP_WORKER_BACKEND='nccl', DPP_WORKER_BATCH=str(B))
+    rt = get_runtime('hip')
+    net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, wIn=32, hIn=32, batchSize=B, numJoints=1, nDims=30))
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), fuse_bn=not sync, weight_decay=1e-3)
+    rng = np.random.RandomState(99)
+    x = nets.synthetic_crops(rng, B, 32, 32, np.float32)
+    y = rng.normal(0, 0.3, (B, 30)).astype(np.float32)
+    cost, _ = eng.cost_and_grads(x, y)
+    assert float(r0['cost'][0]) == cost and float(r0['global_cost'][0]) == cost
+    for i, l in enumerate(net.layers):
+        for s, p in enumerate(l.params):
+            assert np.array_equal(r0['g_%d_%d' % (i, s)], eng.store.read_grad(p)), (i, s)
+    eng.train_step(x, y, 1e-3)
+    assert np.array_equal(r0['w_last'], net.layers[-1].W.get_value())

@@ -120,17 +120,22 @@ def test_resnet_forward_eval_matches_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'fc1stream'])
+@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'fc1stream', 'early_reduce'])
 def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatch):
     """'lazy': type 0 with the opt-in plan in which the 1x1 convolutions form the gradient through a BatchNorm from (G, x) in
     their operand prologue (engine.LAZY_BN_BWD) instead of reading a tensor written by bn_bwd_apply.
     'fc1stream': the HiddenLayer behind the last conv map on the weight-streaming kernel (dpp_fc_gemm: forward with split-K,
     data gradient, weight gradient with the BN+ReLU prologue) -- the full-size nets take that path for FC1, this 32x32 net
-    (K = 1 024) only with the threshold lowered."""
+    (K = 1 024) only with the threshold lowered.
+    'early_reduce': the filter / bias gradient partials reduced in several dpp_reduce_multi launches on the gradient branch while the
+    pass runs (engine.EARLY_REDUCE_BYTES; the bs128 net flushes every 16 MB) instead of one launch at its end."""
     if type_ == 'lazy2' and backend == 'emu':
         pytest.skip("the opt-in lazy2 plan (measured slower, off by default) is exercised on the GPU tier only; 'lazy' covers the mode-4 operand here")
     if type_ in ('lazy', 'lazy2'):       # lazy2: only the data gradient does, and leaves the tensor it forms for the filter gradient
         monkeypatch.setattr(engine, 'LAZY_BN_BWD', 1 if type_ == 'lazy' else 2)
+        type_ = 0
+    if type_ == 'early_reduce':
+        monkeypatch.setattr(engine, 'EARLY_REDUCE_BYTES', 1 << 14)
         type_ = 0
     if type_ == 'fc1stream':
         monkeypatch.setattr(engine, 'FC1_MIN_K', 512)
@@ -144,6 +149,8 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
         assert any(l.name.startswith('dgrad1x1') and l.keep[0].actA.mode == 4 for l in eng.bwd.launches())
     if engine.FC1_MIN_K == 512:
         assert sum(l.fn is rt.lib.dpp_fc_gemm for _, l in eng.all_launches()) >= 5
+    if engine.EARLY_REDUCE_BYTES == 1 << 14:
+        assert sum(l.name == 'reduce_multi_early' for l in eng.bwd.launches()) >= 3
     P64 = nets.cast_params(P, np.float64)
 
     def run(seed):
@@ -318,3 +325,32 @@ def test_bf16_option_is_close_to_f32_and_not_equal(backend, monkeypatch):
     for i in sorted(G32)[-3:]:
         a, b = G32[i][0].ravel().astype('f8'), G16[i][0].ravel().astype('f8')
         assert a @ b / (np.linalg.norm(a) * np.linalg.norm(b)) > 0.9, i
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_early_fc1_adam_step_equals_plain_step(backend, monkeypatch):
+    """step_plan updates the FC1 weight inside the backward pass (gradient branch, after the two kernels that use it, weight decay
+    first) and the rest of the flat buffer at the end: two whole steps must leave EVERY parameter, both ADAM moments and the cost
+    bit-identical to backward-then-one-ADAM."""
+    rt = get_runtime(backend)
+    monkeypatch.setattr(engine, 'EARLY_BUCKET_MIN', 1 << 18)           # the 32x32 test net's FC1 (1 M weights) qualifies
+    wd = 1e-3
+    state = {}
+    for early in (True, False):
+        monkeypatch.setattr(engine, 'EARLY_ADAM', early)
+        net, _, _ = make_net(rt, 0, 4, 32, 1, 30)
+        eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), weight_decay=wd)
+        assert eng._early_adam is not None
+        bwd, upd = eng._early_adam_plans()
+        assert (bwd is not eng.bwd) == early
+        if early:
+            assert len(bwd) == len(eng.bwd) + 1 and [o.name for o in upd.launches()].count('adam') == 2
+            names = [o.name for o in bwd.launches()]
+            assert names.index('adam_fc1') < len(names) // 4                      # early in the pass, not in its tail
+        costs = []
+        for seed in (5, 6):
+            r = np.random.RandomState(seed)
+            costs.append(eng.train_step(nets.synthetic_crops(r, 4, 32, 32, np.float32), r.normal(0, 0.3, (4, 30)).astype(np.float32), 1e-3))
+        state[early] = (costs, eng.store.w.get(), eng.store.m.get(), eng.store.v.get(), eng.hyper.get())
+    for a, b in zip(state[True], state[False]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
