@@ -99,6 +99,9 @@ def main():
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help='bf16: bf16 MFMA operands / fp32 accumulation in FC1 and the 3x3 convolutions (config 5)')
     ap.add_argument('--no-augment', action='store_true')
+    ap.add_argument('--augment-inline', action='store_true',
+                    help='augment the minibatch at the start of its own step on the main stream (default: the previous step does it '
+                         'on the gradient-branch stream while ADAM runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sync-bn', action='store_true', help='all-gather BatchNorm partial statistics across ranks (parity mode)')
     ap.add_argument('--launch', choices=['native', 'python', 'graph', 'graph1'], default=None,
@@ -165,15 +168,28 @@ def main():
     # sample gets does not depend on how many GPUs the global minibatch is spread over
     aug = ops.AugmentState(rt, B, seed=1234, sample0=rank * B, global_batch=world * B)
     step_plans = {}
+    aug_plans = {}
     for sl in range(nsl):
         im, co, cu, mm, gt = slice_views(sl)
-        before = ops.Plan('augment')
+        p = ops.Plan('augment')
         if args.no_augment:
-            before.add(ops.copy2d(rt, im.reshape(B * S * S), S * S, x_out.reshape(B * S * S), S * S, B, S * S, name='load_crops'))
+            p.add(ops.copy2d(rt, im.reshape(B * S * S), S * S, x_out.reshape(B * S * S), S * S, B, S * S, name='load_crops'))
         else:
             for o in aug.ops(im, co, cu, mm, gt, J, S, camt, x_out, eng.y_in, mode_table=table, n_modes=3, pca_mean=pm, pca_comp=pc, E=30):
-                before.add(o)
-        step_plans[sl] = (before, eng.step_plan(before=before))
+                p.add(o)
+        aug_plans[sl] = p
+    # Step i trains on slice i % nsl.  Pipelined (default): its minibatch was augmented into x_in / y_in by step i - 1, on the gradient
+    # branch under that step's ADAM update (engine.step_plan(prefetch=)), and step i does the same for slice i + 1 -- the reference's
+    # background augmentation workers (nettrainer.py:601-628) as one kernel on an idle stream; every step still launches exactly one
+    # augmentation.  --augment-inline: the augmentation of slice i is the first launch of step i, on the main stream.
+    pipelined = not args.augment_inline
+    for sl in range(nsl):
+        if pipelined:
+            step_plans[sl] = (aug_plans[sl], eng.step_plan(prefetch=aug_plans[(sl + 1) % nsl]))
+        else:
+            step_plans[sl] = (aug_plans[sl], eng.step_plan(before=aug_plans[sl]))
+    if pipelined:
+        aug_plans[0].run(rt)              # the minibatch of the first step
     if args.no_augment:
         eng.y_in.set(np.random.RandomState(5).normal(0, 0.3, (B, 30)).astype(np.float32))
     eng.set_lr(1e-3)
@@ -279,7 +295,7 @@ def main():
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
                    config=dict(workload='NYU posereg_embedding ResNet (type 0, 30-D PCA prior) train step: fused augment + fwd + bwd + ADAM, '
                                         'bs%d/GPU %s, %dx%dx1 crops' % (B, 'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands (FC1, 3x3) / fp32 accumulate', S, S),
-                               global_batch=world * B, parallelism='dp%d' % world, augment=not args.no_augment,
+                               global_batch=world * B, parallelism='dp%d' % world, augment=not args.no_augment, augment_pipelined=pipelined,
                                bn='sync (global batch statistics)' if (world > 1 and args.sync_bn) else 'local per-GPU batch statistics',
                                launches=eng.num_launches(), launch_mode=ops.LAUNCH_MODE,
                                step_mfma_frac=round(value / world * flop / PEAK_MFMA_F32, 4), final_cost=round(cost, 5)),

@@ -8,6 +8,9 @@
 // launches from a tight C++ loop (one hipLaunchKernel each, arguments already packed), or replays them as an explicit
 // hipGraph whose two lanes are parallel branches.
 #include "dpp_common.h"
+#ifndef DPP_HIP_EMU
+#include <hip/hip_ext.h>
+#endif
 // (host code only; the CPU test emulator spells these two built-ins as macros, which would clash with hipKernelNodeParams)
 #undef gridDim
 #undef blockDim
@@ -144,7 +147,13 @@ extern "C" int dpp_plan_run(dpp_plan* plan, dpp_stream_t main_stream, dpp_stream
     auto next_event = [&](hipEvent_t* e) -> hipError_t {
         if (ev == plan->events.size()) {
             hipEvent_t n;
-            hipError_t err = hipEventCreateWithFlags(&n, hipEventDisableTiming);
+            // device-scope release: the events only order streams of this GPU against each other (a default event releases to
+            // system scope, i.e. to the host as well, when it is recorded)
+            static const unsigned flags = []() {
+                const char* e = getenv("DPP_EVENT_RELEASE");
+                return (unsigned)hipEventDisableTiming | ((e && e[0] == 's') ? 0u : (unsigned)hipEventReleaseToDevice);
+            }();
+            hipError_t err = hipEventCreateWithFlags(&n, flags);
             if (err != hipSuccess) return err;
             plan->events.push_back(n);
         }
@@ -157,9 +166,15 @@ extern "C" int dpp_plan_run(dpp_plan* plan, dpp_stream_t main_stream, dpp_stream
     bool main_dirty = true;
     bool side_dirty[8] = {true, false, false, false, false, false, false, false};
     hipEvent_t fork_event = nullptr;         // latest event recorded on main; covers all main work iff !main_dirty
+    // A fork that directly follows a main-lane kernel takes that kernel's own completion signal as its event (hipExtLaunchKernel's
+    // stop event) instead of a hipEventRecord: a recorded event is a marker packet of its own in the main queue, and the next
+    // kernel of the chain waits for it -- measured 4.5-5.3 us per fork on the critical path (tools/join_probe.py), 60 forks per step.
+    static const bool stop_events = []() { const char* e = getenv("DPP_FORK_STOP_EVENT"); return !(e && e[0] == '0'); }();
+    const size_t nn = plan->nodes.size();
     bool waited[8] = {false, false, false, false, false, false, false, false};      // side stream i already waits for fork_event
     int cur = 0, groups = 0;
-    for (dpp_plan_node& n : plan->nodes) {
+    for (size_t ni = 0; ni < nn; ++ni) {
+        dpp_plan_node& n = plan->nodes[ni];
         if (n.kind == 2) {                   // fork: the next lane-1 group starts here
             if (!two) continue;
             if (S > 1) cur = groups++ % S;
@@ -192,6 +207,15 @@ extern "C" int dpp_plan_run(dpp_plan* plan, dpp_stream_t main_stream, dpp_stream
         }
         const bool on_side = two && n.lane == 1;
         hipStream_t s = on_side ? sides[cur] : ms;
+        if (!on_side && two && stop_events && n.kind == 0 && n.func != nullptr && ni + 1 < nn && plan->nodes[ni + 1].kind == 2) {
+            hipError_t err = next_event(&fork_event);
+            if (err == hipSuccess)
+                err = hipExtLaunchKernel(n.func, n.grid, n.block, n.argptrs.data(), n.shmem, ms, nullptr, fork_event, 0);
+            if (err != hipSuccess) return (int)err;
+            main_dirty = false;              // the event covers everything issued on main so far
+            for (int i = 0; i < S; ++i) waited[i] = false;
+            continue;
+        }
         hipError_t err = n.kind == 0 ? n.issue(s) : hipMemsetAsync(n.ptr, 0, n.nbytes, s);
         if (err != hipSuccess) return (int)err;
         if (on_side) side_dirty[cur] = true; else main_dirty = true;

@@ -1268,21 +1268,33 @@ class CompiledNet(object):
         allreduce(self.store.g)
         self.upd.run(st)
 
-    def step_plan(self, before=None):
+    def step_plan(self, before=None, prefetch=None):
         """forward + loss + backward + update as ONE plan (one native call per step); `before`: a Plan issued ahead of the
-        forward pass inside the same call (the augmentation kernels)."""
-        key = id(before) if before is not None else 0
+        forward pass inside the same call (the augmentation kernels).  `prefetch`: a Plan whose launches run on the gradient
+        branch between the backward pass and the update -- the augmentation of the NEXT step's minibatch, written straight into
+        x_in / y_in (their last readers, the first layer's filter gradient and the loss, are done by then) while the main stream is
+        busy with the ADAM update; the plan then opens with a join, so that the forward pass waits for the prefetch of the previous
+        call.  What the reference does with its background augmentation processes (nettrainer.py:601-628)."""
+        key = (id(before) if before is not None else 0, id(prefetch) if prefetch is not None else 0)
         cache = self.__dict__.setdefault('_step_plans', {})
         if key not in cache:
             bwd, upd = self._early_adam_plans()
-            plan = Plan.concat('step', ([before] if before is not None else []) + [self.fwd, self.lossplan, bwd, upd])
+            parts = ([before] if before is not None else []) + [self.fwd, self.lossplan, bwd]
+            if prefetch is not None:
+                pre, post = Plan('prefetch_join'), Plan('prefetch')
+                pre.join()
+                post.fork()
+                for op in prefetch.steps():
+                    post.add(op, side=True)
+                parts = [pre] + parts + [post]
+            plan = Plan.concat('step', parts + [upd])
             skip = tuple(x for x in os.environ.get('DPP_WHATIF_SKIP', '').split(',') if x)
             if skip:
                 # ablation for tools/whatif.sh ONLY (results are wrong): the step without the launches whose name starts with one of
                 # the prefixes -- what the step would cost if those kernels were free
                 plan.ops = [(op, side) for (op, side) in plan.ops if not str(getattr(op, 'name', '')).startswith(skip)]
-            cache[key] = (before, plan)
-        return cache[key][1]
+            cache[key] = (before, prefetch, plan)
+        return cache[key][-1]
 
     def _early_adam_plans(self):
         """(backward, update) plans of a whole step.  With EARLY_ADAM the FC1 weight is updated inside the backward pass, on the

@@ -185,7 +185,7 @@ typedef void* hipEvent_t;
 typedef void* hipGraph_t;
 typedef void* hipGraphExec_t;
 typedef void* hipGraphNode_t;
-enum { hipEventDisableTiming = 2, hipErrorNotSupported = 801 };
+enum { hipEventDisableTiming = 2, hipEventReleaseToDevice = 0x40000000, hipErrorNotSupported = 801 };
 struct hipKernelNodeParams { void* func; dim3 gridDim, blockDim; unsigned sharedMemBytes; void** kernelParams; void** extra; };
 struct hipMemsetParams { void* dst; unsigned value, elementSize; size_t width, height, pitch; };
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
@@ -199,6 +199,8 @@ static inline hipError_t hipGraphAddKernelNode(hipGraphNode_t*, hipGraph_t, cons
 static inline hipError_t hipGraphAddMemsetNode(hipGraphNode_t*, hipGraph_t, const hipGraphNode_t*, size_t, const hipMemsetParams*) { return hipErrorNotSupported; }
 static inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, char*, size_t) { return hipErrorNotSupported; }
 static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+static inline hipError_t hipExtLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t, hipEvent_t, hipEvent_t, int) { return hipErrorNotSupported; }
+#define DPP_HIP_EMU 1
 
 #define threadIdx (emu::g_cur->tid)
 #define blockIdx (emu::g_bid)

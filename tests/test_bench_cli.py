@@ -47,3 +47,17 @@ def test_gpus_2_on_a_one_gpu_box_fails_loudly():
         pytest.skip('this box has %d GPUs' % torch.cuda.device_count())
     rc, out, err = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline'])
     assert rc != 0 and 'needs 2 visible' in err and not [l for l in out.splitlines() if l.startswith('{')]
+
+
+def test_pipelined_augmentation_trains_on_the_same_minibatches():
+    """Default: step i's minibatch is augmented by step i - 1 on the gradient-branch stream (engine.step_plan(prefetch=));
+    --augment-inline does it at the start of step i.  Same slices, same draw counters: the cost after the run is identical."""
+    costs = {}
+    for flag in ([], ['--augment-inline']):
+        rc, out, err = _bench(['--batch', '4', '--size', '32', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'] + flag,
+                              env=dict(DPP_BENCH_EMU='1'))
+        assert rc == 0, err[-3000:]
+        res = json.loads([l for l in out.splitlines() if l.startswith('{')][0])
+        assert res['config']['augment_pipelined'] == (not flag)
+        costs[bool(flag)] = res['config']['final_cost']
+    assert costs[True] == costs[False] and costs[True] > 0
