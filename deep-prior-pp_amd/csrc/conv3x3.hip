@@ -129,6 +129,7 @@ __device__ __forceinline__ void stage_halo(const float* __restrict__ X, int N, i
 
 template <int BM, int BN, int PREC = 0>
 __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
+    dpp_kernarg_warm<sizeof(Conv3Args)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);
     typedef typename C3Prec<PREC>::elem elem;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
 
     dpp_stamp(a.prof, 0);
     dpp_wide_coef wco;
-    if (a.wide) wco.load<BN>(col0, a.Co, a.bias, a.epi);
+    if (a.wide) wco.load<BN>(col0, a.Co, a.bias, a.epi, a.Y);
     // halo slots per thread: 3 for the 16- and 32-channel layers, 7 for the 64-channel ones; unrolling 8 for 3 wastes 5 slots of index arithmetic
     if (((HP + (DPP_THREADS >> a.sg.lqp) - 1) >> (8 - a.sg.lqp)) <= 4)
         stage_halo<4>(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP, a.sg);
@@ -426,6 +427,7 @@ struct Wgrad3Args {
 
 template <int BM, int MAXACC>
 __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a) {
+    dpp_kernarg_warm<sizeof(Wgrad3Args)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);
     const int TH = 1 << a.lth, TW = 1 << a.ltw;
@@ -584,7 +586,8 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     size_t lds = (halo + (a.allw ? 9 : 2) * bn) * rowb;
     static const bool wide_ok = []() { const char* e = getenv("DPP_GEMM_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    a.wide = wide_ok && al16(Y) && al16(residual) && al16(a.epi.bn_x);
+    a.wide = wide_ok && al16(Y) && al16(residual) && al16(a.epi.bn_x) && al16(bias) && al16(a.epi.bn_mean) && al16(a.epi.bn_scale) &&
+             al16(a.epi.bn_beta) && al16(a.epi.bn_inv_std);
     size_t need = a.wide ? ((size_t)bm * (bn + 4) + 16 * bn) * sizeof(float) : (size_t)4 * bn * sizeof(float);
     if (lds < need) lds = need;
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;

@@ -88,6 +88,25 @@ __device__ __forceinline__ void dpp_stamp(unsigned long long*, int) {}
 #endif
 extern unsigned long long* dpp_prof_buffer;                // host-side: where instrumented launches stamp (NULL = nowhere); plan.hip
 
+// Kernel arguments are passed by value (descriptors of 300-450 bytes = 5-8 cache lines of the kernarg segment).  The compiler
+// fetches the fields where they are first used -- dozens of s_load / s_waitcnt pairs spread over the entry code -- and the first
+// wave of a workgroup on a CU finds none of the lines in the scalar cache: a dispatch's kernarg segment is fresh memory, every line
+// is a miss to HBM taken one after the other.  This touches one dword per 64-byte line with back-to-back scalar loads, so the misses
+// overlap (one latency instead of one per line) and the field loads that follow hit the scalar cache.
+template <int NBYTES>
+__device__ __forceinline__ void dpp_kernarg_warm() {
+#ifndef DPP_HIP_EMU
+    typedef __attribute__((address_space(4))) const int kint;
+    kint* ka = (kint*)__builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int L = (NBYTES + 63) / 64;
+    int t[L];
+#pragma unroll
+    for (int i = 0; i < L; ++i) t[i] = ka[i * 16];
+#pragma unroll
+    for (int i = 0; i < L; ++i) asm volatile("" ::"s"(t[i]));
+#endif
+}
+
 // Row map of a compact (N,Ho,Wo) pixel index onto a (N,Hi,Wi) map sampled with stride s.
 __device__ __forceinline__ int dpp_map_row(const dpp_rowmap& m, int r) {
     if (m.s == 1) return r;
@@ -181,47 +200,64 @@ __device__ __forceinline__ void dpp_tile_colsum(float (&s)[CN], float* red, int 
 // else, and issued late they put one more memory latency on the critical path of a short workgroup.
 struct dpp_wide_coef {
     float cbias[4], cmean[4], cscale[4], cbeta[4], cistd[4];
+    float4 raw[5];
+    bool on_bias, on_bn;
+    // `safe`: any valid 16-byte aligned device address (the kernel's output pointer).  Every vector is fetched with ONE unconditional
+    // 16-byte load -- from `safe` when the vector is absent or the quad lies outside the problem -- and masked by finish(), which
+    // the epilogue calls: nothing between the loads and the K loop touches the loaded registers, so the wave does not wait for
+    // them in its entry code.  The earlier form (aligned 16-byte load OR four scalar loads, chosen at run time, values used on the
+    // spot) made the compiler drain all outstanding loads in front of each vector (both paths write the same registers): up to five
+    // serialized memory round trips at the start of every kernel with the BatchNorm-backward epilogue, one in the others.  The host
+    // only takes the wide path with 16-byte aligned vectors.
     template <int BN>
-    __device__ __forceinline__ void load(int col0, int N, const float* bias, const dpp_epilogue& ep) {
+    __device__ __forceinline__ void load(int col0, int N, const float* bias, const dpp_epilogue& ep, const float* safe) {
         const int col = col0 + ((int)threadIdx.x % (BN / 4)) * 4;
-        const bool cin = col < N;
-        const bool bn = ep.bn_x != nullptr;
-        auto quad = [&](const float* p, bool on, float (&dst)[4]) {
-            // N % 4 == 0 on this path, so a quad is inside or outside as a whole: one 16-byte load when the vector is aligned
-            if (on && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-                const float4 v = *reinterpret_cast<const float4*>(p + col);
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dst[j] = on ? p[col + j] : 0.0f;
-            }
+        const bool cin = col < N;                            // N % 4 == 0 on this path: a quad is inside or outside as a whole
+        on_bias = cin && bias != nullptr;
+        on_bn = cin && ep.bn_x != nullptr;
+        raw[0] = *reinterpret_cast<const float4*>(on_bias ? bias + col : safe);
+        raw[1] = *reinterpret_cast<const float4*>(on_bn ? ep.bn_mean + col : safe);
+        raw[2] = *reinterpret_cast<const float4*>(on_bn ? ep.bn_scale + col : safe);
+        raw[3] = *reinterpret_cast<const float4*>(on_bn ? ep.bn_beta + col : safe);
+        raw[4] = *reinterpret_cast<const float4*>(on_bn ? ep.bn_inv_std + col : safe);
+    }
+    __device__ __forceinline__ void finish() {
+        auto quad = [](const float4& v, bool on, float (&dst)[4]) {
+            dst[0] = on ? v.x : 0.0f; dst[1] = on ? v.y : 0.0f; dst[2] = on ? v.z : 0.0f; dst[3] = on ? v.w : 0.0f;
         };
-        quad(bias, cin && bias != nullptr, cbias);
-        quad(ep.bn_mean, cin && bn, cmean);
-        quad(ep.bn_scale, cin && bn, cscale);
-        quad(ep.bn_beta, cin && bn, cbeta);
-        quad(ep.bn_inv_std, cin && bn, cistd);
+        quad(raw[0], on_bias, cbias);
+        quad(raw[1], on_bn, cmean);
+        quad(raw[2], on_bn, cscale);
+        quad(raw[3], on_bn, cbeta);
+        quad(raw[4], on_bn, cistd);
     }
 };
 
-template <int RM, int CN, int WM, int WN, int BM, int BN, class RowOff>
-__device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* smem, int col0, int N, const dpp_wide_coef& co,
+// NIMG > 1 (the K-split kernel): the tile is the sum of NIMG images -- every wave holds a partial sum of the WHOLE tile over its K
+// slice (WM = WN = 1) and drops it into image `img`; the images are added in a fixed order when the tile is read back.  `smem` must
+// then hold NIMG*BM*(BN+4) + 16*BN floats.
+template <int RM, int CN, int WM, int WN, int BM, int BN, int NIMG = 1, class RowOff>
+__device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* smem, int col0, int N, dpp_wide_coef& co,
                                                   const float* residual, float* C, const dpp_epilogue& ep, int nvalid, int wm,
-                                                  int wn, int l15, int kq, RowOff rowoff) {
+                                                  int wn, int l15, int kq, RowOff rowoff, int img = 0) {
+    co.finish();
     constexpr int LDT = BN + 4;
     constexpr int Q = BN / 4;                                // column quads per tile row
     constexpr int RSTEP = DPP_THREADS / Q;                   // rows covered by one sweep of the workgroup
     constexpr int ITERS = (BM + RSTEP - 1) / RSTEP;
     float* Ts = smem;
-    float* red = smem + BM * LDT;                            // 4 regions of 4*BN floats
+    float* red = smem + NIMG * BM * LDT;                     // 4 regions of 4*BN floats
     // (the K loop ended on a barrier, so nobody reads the operand tiles any more)
+    {
+        float* Ti = Ts + (NIMG > 1 ? img * BM * LDT : 0);
 #pragma unroll
-    for (int rt = 0; rt < RM; ++rt)
+        for (int rt = 0; rt < RM; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < CN; ++ct)
+            for (int ct = 0; ct < CN; ++ct)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Ts[(wm * (BM / WM) + rt * 16 + kq * 4 + r) * LDT + wn * (BN / WN) + ct * 16 + l15] = acc[rt][ct][r];
+                for (int r = 0; r < 4; ++r)
+                    Ti[(wm * (BM / WM) + rt * 16 + kq * 4 + r) * LDT + wn * (BN / WN) + ct * 16 + l15] = acc[rt][ct][r];
+    }
     __syncthreads();
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,7 +274,12 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
         const long ro = (rl < BM && cin) ? rowoff(rl) : -1L;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (ro >= 0) {
-            const float4 t = *reinterpret_cast<const float4*>(&Ts[rl * LDT + cq * 4]);
+            float4 t = *reinterpret_cast<const float4*>(&Ts[rl * LDT + cq * 4]);
+#pragma unroll
+            for (int im = 1; im < NIMG; ++im) {
+                const float4 u = *reinterpret_cast<const float4*>(&Ts[(im * BM + rl) * LDT + cq * 4]);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
             v[0] = t.x + co.cbias[0]; v[1] = t.y + co.cbias[1]; v[2] = t.z + co.cbias[2]; v[3] = t.w + co.cbias[3];
             const size_t o = (size_t)ro + col;
             if (residual) {

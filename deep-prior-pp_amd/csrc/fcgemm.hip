@@ -171,7 +171,7 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_gemm_kernel(FcArgs ga) {
 #pragma unroll
         for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dpp_wide_coef wco;
-    wco.load<BN>(col0, N, d.splitk == 1 ? d.bias : nullptr, d.epi);
+    wco.load<BN>(col0, N, d.splitk == 1 ? d.bias : nullptr, d.epi, d.splitk > 1 ? d.partial : d.C);
 
     SA sa;
     SB sb;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_stream_kernel(FsArgs ga) {
 #pragma unroll
         for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dpp_wide_coef wco;
-    wco.load<BN>(col0, N, d.splitk == 1 ? d.bias : nullptr, d.epi);
+    wco.load<BN>(col0, N, d.splitk == 1 ? d.bias : nullptr, d.epi, d.splitk > 1 ? d.partial : d.C);
 
     fetch(0);
     commit(0);
@@ -496,6 +496,7 @@ extern "C" int dpp_fc_gemm(const dpp_gemm_desc* dp, int precision, int kchunk, d
     const int ldc = d.splitk > 1 ? d.N : d.ldc;
     if (ldc % 4 || (reinterpret_cast<uintptr_t>(d.splitk > 1 ? d.partial : d.C) & 15)) return DPP_E_UNSUPPORTED;
     if (d.residual && (reinterpret_cast<uintptr_t>(d.residual) & 15)) return DPP_E_UNSUPPORTED;
+    if (d.splitk == 1 && d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15)) return DPP_E_UNSUPPORTED;     // one 16-byte load per column quad
     const int KC = kchunk == 0 ? 64 : kchunk;
     if (KC != 32 && KC != 64) return DPP_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -212,6 +212,7 @@ struct Stager {
 
 template <int BM, int BN, int WM, int BKT, bool AKC, bool BKC, int DEPTH, bool LAZY = false, bool WIDE = true>
 __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
+    dpp_kernarg_warm<sizeof(GemmArgs)>();
     const dpp_gemm_desc& d = ga.d;
     constexpr int WN = 4 / WM;
     constexpr int RM = BM / (16 * WM);
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
 #pragma unroll
         for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     dpp_wide_coef wco;
-    if (ga.wide) wco.load<BN>(col0, N, d.bias, d.epi);
+    if (ga.wide) wco.load<BN>(col0, N, d.bias, d.epi, d.C);
 
     // Software pipeline: DEPTH chunks are fetched ahead; chunk c is written to LDS from ring slot c % DEPTH, and as soon
     // as the barrier publishes it the slot is refilled with chunk c + DEPTH, whose loads stay in flight under the MFMAs.
@@ -592,6 +593,152 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_rowstream_kernel(GemmArgs ga
     }
     __syncthreads();                        // the B slice is dead: the epilogue reuses LDS for its column reductions
     gemm_epilogue<RM, CN, 4, 1, BM, BN>(acc, d, row0, col0, wave, 0, l15, kq, Bs);
+}
+
+// ---- K-split variant for the long-K / narrow-N 1x1 convolutions (variant 2) ------------------------------------------------
+// The stage-3/4 bottleneck entries (256 -> 64 channels over 8 192 pixels) and the data gradients of the bottleneck exits (same
+// shape) are four dependent 64-deep global -> LDS -> MFMA round trips in gemm_kernel, on 64 x 16 tiles that pull every A row
+// through the CUs four times (tools/phase_profile.py: 6.2 of the kernel's 12.8 us are the K loop, 2.4 us its entry code).  Here a
+// workgroup owns 32 rows x ALL BN columns and the WHOLE K: every load of the kernel is issued up front (one memory round trip),
+// one barrier publishes the operands, then wave w multiplies its quarter of K (KT/4 deep, no barrier, 8 accumulator tiles) and
+// the four partial tiles meet in the LDS images of the wide epilogue.  Compile-time K and BN, whole tiles only: the entry code
+// is a few dozen instructions.  A is K-contiguous [M][KT] with the BatchNorm + ReLU prologue, B either K-contiguous [BN][KT]
+// (forward: the filters) or [KT][BN] (data gradient).
+template <int KT, int BN, bool BKC>
+__global__ __launch_bounds__(DPP_THREADS) void gemm_ksplit_kernel(GemmArgs ga) {
+    dpp_kernarg_warm<sizeof(GemmArgs)>();
+    const dpp_gemm_desc& d = ga.d;
+    HIP_DYNAMIC_SHARED(float4, smem4)
+    float* smem = reinterpret_cast<float*>(smem4);
+    constexpr int BM = 32, RM = 2, CN = BN / 16;
+    constexpr int LDA_ = KT + 4, LDB_ = BKC ? KT + 4 : BN + 4;
+    constexpr int QK = KT / 4;                               // float4 per K-contiguous row
+    constexpr int SA = BM * QK / DPP_THREADS;                // staging slots per thread
+    constexpr int SB = BN * QK / DPP_THREADS;
+    constexpr int KS = KT / 4;                               // K slice of a wave
+    static_assert(DPP_THREADS % QK == 0 && (BM * QK) % DPP_THREADS == 0 && (BN * QK) % DPP_THREADS == 0 && KS % 16 == 0, "tile");
+    float* const As = smem;
+    float* const Bs = smem + BM * LDA_;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+    dpp_stamp(ga.prof, 0);
+
+    // ---- every load of the kernel, back to back ----
+    const int modeA = d.actA.mode;
+    const int ka = (tid % QK) * 4;                           // this thread's k-quad (the same for all its A slots)
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
+    if (modeA & 2) {
+        mu = *reinterpret_cast<const float4*>(d.actA.mean + ka);
+        sc = *reinterpret_cast<const float4*>(d.actA.scale + ka);
+        be = *reinterpret_cast<const float4*>(d.actA.beta + ka);
+    }
+    float4 ra[SA], rb[SB];
+    {
+        const float* pa = d.A + (size_t)(row0 + tid / QK) * d.lda + ka;
+#pragma unroll
+        for (int s = 0; s < SA; ++s) ra[s] = *reinterpret_cast<const float4*>(pa + (size_t)s * (DPP_THREADS / QK) * d.lda);
+        if (BKC) {
+            const float* pb = d.B + (size_t)(col0 + tid / QK) * d.ldb + ka;
+#pragma unroll
+            for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb + (size_t)s * (DPP_THREADS / QK) * d.ldb);
+        } else {
+            constexpr int QN = BN / 4;
+            const float* pb = d.B + (size_t)(tid / QN) * d.ldb + col0 + (tid % QN) * 4;
+#pragma unroll
+            for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb + (size_t)s * (DPP_THREADS / QN) * d.ldb);
+        }
+    }
+    dpp_wide_coef wco;
+    wco.load<BN>(col0, d.N, d.bias, d.epi, d.C);
+    dpp_stamp(ga.prof, 1);
+
+    // ---- commit: prologue on A, both operands into LDS ----
+    {
+        float* la = As + (tid / QK) * LDA_ + ka;
+#pragma unroll
+        for (int s = 0; s < SA; ++s) {
+            float4 v = ra[s];
+            if (modeA & 2) {
+                v.x = (v.x - mu.x) * sc.x + be.x; v.y = (v.y - mu.y) * sc.y + be.y;
+                v.z = (v.z - mu.z) * sc.z + be.z; v.w = (v.w - mu.w) * sc.w + be.w;
+            }
+            if (modeA & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(la + s * (DPP_THREADS / QK) * LDA_) = v;
+        }
+        if (BKC) {
+            float* lb = Bs + (tid / QK) * LDB_ + ka;
+#pragma unroll
+            for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(lb + s * (DPP_THREADS / QK) * LDB_) = rb[s];
+        } else {
+            constexpr int QN = BN / 4;
+            float* lb = Bs + (tid / QN) * LDB_ + (tid % QN) * 4;
+#pragma unroll
+            for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(lb + s * (DPP_THREADS / QN) * LDB_) = rb[s];
+        }
+    }
+    __syncthreads();
+    dpp_stamp(ga.prof, 2);
+
+    // ---- wave `wave` multiplies k in [wave*KS, wave*KS + KS): lane (i, kq) owns k = base + 16 g + 4 kq + t ----
+    f32x4 acc[RM][CN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* arow = As + l15 * LDA_ + wave * KS + kq * 4;
+    const float* brow = BKC ? Bs + l15 * LDB_ + wave * KS + kq * 4 : Bs + (wave * KS + kq * 4) * LDB_ + l15;
+#pragma unroll
+    for (int g = 0; g < KS / 16; ++g) {
+        float af[RM][4], bf[CN][4];
+#pragma unroll
+        for (int rt = 0; rt < RM; ++rt) {
+            const float4 v = *reinterpret_cast<const float4*>(arow + rt * 16 * LDA_ + g * 16);
+            af[rt][0] = v.x; af[rt][1] = v.y; af[rt][2] = v.z; af[rt][3] = v.w;
+        }
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            if (BKC) {
+                const float4 v = *reinterpret_cast<const float4*>(brow + ct * 16 * LDB_ + g * 16);
+                bf[ct][0] = v.x; bf[ct][1] = v.y; bf[ct][2] = v.z; bf[ct][3] = v.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bf[ct][t] = brow[(g * 16 + t) * LDB_ + ct * 16];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][t], bf[ct][t], acc[rt][ct], 0, 0, 0);
+    }
+    __syncthreads();                         // the operand images are dead: the epilogue's tile images take their place
+    dpp_stamp(ga.prof, 3);
+    dpp_epilogue_wide<RM, CN, 1, 1, BM, BN, 4>(acc, smem, col0, d.N, wco, d.residual, d.C, d.epi, BM, 0, 0, l15, kq,
+                                               [&](int rl) { return (long)(row0 + rl) * d.ldc; }, wave);
+    dpp_stamp(ga.prof, 4);
+}
+
+// dpp_gemm variant 2: can this problem run on gemm_ksplit_kernel, and with which tile?
+static int ksplit_bn(const dpp_gemm_desc& d, const GemmArgs& ga) {
+    if (!d.a_kc || d.splitk != 1 || !ga.wide || !ga.vecA || !ga.vecB || d.M % 32 || (d.K != 256 && d.K != 128)) return 0;
+    if (d.mapA.s != 1 || d.mapB.s != 1 || d.mapC.s != 1 || d.actB.mode != 0 || (d.actA.mode & ~3)) return 0;
+    if ((d.actA.mode & 2) && d.actA.cmod < d.K) return 0;
+    const int bn = d.K == 256 ? 64 : 32;
+    return d.N % bn == 0 ? bn : 0;
+}
+
+template <int KT, int BN, bool BKC>
+static int launch_ksplit(const GemmArgs& ga, hipStream_t st) {
+    const dpp_gemm_desc& d = ga.d;
+    constexpr int opnd = 32 * (KT + 4) + (BKC ? BN * (KT + 4) : KT * (BN + 4));
+    constexpr int epil = 4 * 32 * (BN + 4) + 16 * BN;
+    constexpr size_t lds = sizeof(float) * (opnd > epil ? opnd : epil);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ksplit_kernel<KT, BN, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DPP_LAUNCH((gemm_ksplit_kernel<KT, BN, BKC>), dim3(d.M / 32, d.N / BN), dim3(DPP_THREADS), lds, st, ga);
+    return dpp_launch_status();
 }
 
 // out[i] = sum_z partial[z][i] (+ bias).  Threads are laid out as CB columns x ZL z-lanes: lane zl sums z = zl, zl+ZL, ...
@@ -769,7 +916,8 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     ga.vecB = aligned16(d.B) && (d.ldb % 4 == 0);
     static const bool wide_ok = []() { const char* e = getenv("DPP_GEMM_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
     ga.wide = wide_ok && d.splitk == 1 && d.N % 4 == 0 && d.ldc % 4 == 0 && aligned16(d.C) && aligned16(d.residual) &&
-              aligned16(d.epi.bn_x);
+              aligned16(d.epi.bn_x) && aligned16(d.bias) && aligned16(d.epi.bn_mean) && aligned16(d.epi.bn_scale) &&
+              aligned16(d.epi.bn_beta) && aligned16(d.epi.bn_inv_std);
     if ((d.actA.mode & 2) && !(aligned16(d.actA.mean) && aligned16(d.actA.scale) && aligned16(d.actA.beta))) return DPP_E_BADARG;
     if ((d.actB.mode & 2) && !(aligned16(d.actB.mean) && aligned16(d.actB.scale) && aligned16(d.actB.beta))) return DPP_E_BADARG;
     const bool red_layout = !d.a_kc && !d.b_kc;
@@ -792,6 +940,12 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
         }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d.variant == 2) {
+        const int kbn = ksplit_bn(d, ga);
+        if (!kbn) return DPP_E_UNSUPPORTED;
+        if (d.K == 256) return d.b_kc ? launch_ksplit<256, 64, true>(ga, st) : launch_ksplit<256, 64, false>(ga, st);
+        return d.b_kc ? launch_ksplit<128, 32, true>(ga, st) : launch_ksplit<128, 32, false>(ga, st);
+    }
     if (d.variant == 1) {
         // row-streaming kernel: bm in {64, 128} rows per workgroup, bn in {16, 32, 64} columns, whole K staged for B
         if (!d.a_kc || d.splitk != 1) return DPP_E_UNSUPPORTED;

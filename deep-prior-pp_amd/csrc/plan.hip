@@ -30,6 +30,7 @@ struct dpp_plan {
     bool recording = false;
     int launches = 0, forks = 0, joins = 0;
     std::vector<hipEvent_t> events;          // one per fork / join, created lazily by the first run
+    std::vector<char> last_before_join;      // per node: lane-1 kernel with a join (and no other lane-1 node) ahead of it
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
 };
@@ -169,8 +170,25 @@ extern "C" int dpp_plan_run(dpp_plan* plan, dpp_stream_t main_stream, dpp_stream
     // A fork that directly follows a main-lane kernel takes that kernel's own completion signal as its event (hipExtLaunchKernel's
     // stop event) instead of a hipEventRecord: a recorded event is a marker packet of its own in the main queue, and the next
     // kernel of the chain waits for it -- measured 4.5-5.3 us per fork on the critical path (tools/join_probe.py), 60 forks per step.
+    // (A kernel that carries a signal still costs the chain ~1.5 us.  Thinning the forks -- only every k-th one real, the groups in
+    // between issued behind the next real fork -- was measured and is worse: 4.09 / 4.10 / 4.14 / 4.19 ms for k = 2 / 3 / 4 / 6 against
+    // 4.07: the gradient branch ends together with the main chain, so every delay of its work shows at the final join.)
     static const bool stop_events = []() { const char* e = getenv("DPP_FORK_STOP_EVENT"); return !(e && e[0] == '0'); }();
     const size_t nn = plan->nodes.size();
+    // the same for a join: the last lane-1 kernel in front of it is launched with a stop event and main waits for that
+    if (plan->last_before_join.size() != nn) {
+        plan->last_before_join.assign(nn, 0);
+        bool join_next = false;              // walking backwards: a join lies ahead and no lane-1 node in between
+        for (size_t i = nn; i-- > 0;) {
+            const dpp_plan_node& q = plan->nodes[i];
+            if (q.kind == 3) join_next = true;
+            else if ((q.kind == 0 || q.kind == 1) && q.lane == 1) {
+                plan->last_before_join[i] = join_next && q.kind == 0 && q.func != nullptr;
+                join_next = false;
+            }
+        }
+    }
+    hipEvent_t side_stop[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // stop event of the stream's LAST launch
     bool waited[8] = {false, false, false, false, false, false, false, false};      // side stream i already waits for fork_event
     int cur = 0, groups = 0;
     for (size_t ni = 0; ni < nn; ++ni) {
@@ -196,9 +214,12 @@ extern "C" int dpp_plan_run(dpp_plan* plan, dpp_stream_t main_stream, dpp_stream
             if (!two) continue;
             for (int i = 0; i < S; ++i) {
                 if (!side_dirty[i]) continue;
-                hipEvent_t e;
-                hipError_t err = next_event(&e);
-                if (err == hipSuccess) err = hipEventRecord(e, sides[i]);
+                hipEvent_t e = side_stop[i];
+                hipError_t err = hipSuccess;
+                if (e == nullptr) {
+                    err = next_event(&e);
+                    if (err == hipSuccess) err = hipEventRecord(e, sides[i]);
+                }
                 if (err == hipSuccess) err = hipStreamWaitEvent(ms, e, 0);
                 if (err != hipSuccess) return (int)err;
                 side_dirty[i] = false;
@@ -216,9 +237,17 @@ extern "C" int dpp_plan_run(dpp_plan* plan, dpp_stream_t main_stream, dpp_stream
             for (int i = 0; i < S; ++i) waited[i] = false;
             continue;
         }
+        if (on_side && stop_events && plan->last_before_join[ni]) {
+            hipError_t err = next_event(&side_stop[cur]);
+            if (err == hipSuccess)
+                err = hipExtLaunchKernel(n.func, n.grid, n.block, n.argptrs.data(), n.shmem, s, nullptr, side_stop[cur], 0);
+            if (err != hipSuccess) return (int)err;
+            side_dirty[cur] = true;
+            continue;
+        }
         hipError_t err = n.kind == 0 ? n.issue(s) : hipMemsetAsync(n.ptr, 0, n.nbytes, s);
         if (err != hipSuccess) return (int)err;
-        if (on_side) side_dirty[cur] = true; else main_dirty = true;
+        if (on_side) { side_dirty[cur] = true; side_stop[cur] = nullptr; } else main_dirty = true;
     }
     for (int i = 1; i < S; ++i) {            // fold the extra streams into the caller's side stream
         if (!side_dirty[i]) continue;
