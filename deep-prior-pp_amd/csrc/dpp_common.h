@@ -93,6 +93,13 @@ extern unsigned long long* dpp_prof_buffer;                // host-side: where i
 // wave of a workgroup on a CU finds none of the lines in the scalar cache: a dispatch's kernarg segment is fresh memory, every line
 // is a miss to HBM taken one after the other.  This touches one dword per 64-byte line with back-to-back scalar loads, so the misses
 // overlap (one latency instead of one per line) and the field loads that follow hit the scalar cache.
+// occupancy goal of a kernel for the register allocator / scheduler (the host build against the SIMT emulator has no such thing)
+#ifdef DPP_HIP_EMU
+#define DPP_WAVES_PER_EU(lo, hi)
+#else
+#define DPP_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
+
 template <int NBYTES>
 __device__ __forceinline__ void dpp_kernarg_warm() {
 #ifndef DPP_HIP_EMU

@@ -604,8 +604,10 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_rowstream_kernel(GemmArgs ga
 // the four partial tiles meet in the LDS images of the wide epilogue.  Compile-time K and BN, whole tiles only: the entry code
 // is a few dozen instructions.  A is K-contiguous [M][KT] with the BatchNorm + ReLU prologue, B either K-contiguous [BN][KT]
 // (forward: the filters) or [KT][BN] (data gradient).
+// (amdgpu_waves_per_eu: with the default occupancy goal the scheduler sinks every load down to its LDS write to save registers --
+// "load, wait, write" twenty-four times over; one workgroup per CU is all the 100 KB LDS footprint allows anyway)
 template <int KT, int BN, bool BKC>
-__global__ __launch_bounds__(DPP_THREADS) void gemm_ksplit_kernel(GemmArgs ga) {
+__global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4) void gemm_ksplit_kernel(GemmArgs ga) {
     dpp_kernarg_warm<sizeof(GemmArgs)>();
     const dpp_gemm_desc& d = ga.d;
     HIP_DYNAMIC_SHARED(float4, smem4)
@@ -633,27 +635,36 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_ksplit_kernel(GemmArgs ga) {
         be = *reinterpret_cast<const float4*>(d.actA.beta + ka);
     }
     float4 ra[SA], rb[SB];
-    {
-        const float* pa = d.A + (size_t)(row0 + tid / QK) * d.lda + ka;
-#pragma unroll
-        for (int s = 0; s < SA; ++s) ra[s] = *reinterpret_cast<const float4*>(pa + (size_t)s * (DPP_THREADS / QK) * d.lda);
+    constexpr int QN = BN / 4;
+    {   // B first (its commit is nothing but LDS writes), then A: loads return in issue order
         if (BKC) {
             const float* pb = d.B + (size_t)(col0 + tid / QK) * d.ldb + ka;
 #pragma unroll
             for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb + (size_t)s * (DPP_THREADS / QK) * d.ldb);
         } else {
-            constexpr int QN = BN / 4;
             const float* pb = d.B + (size_t)(tid / QN) * d.ldb + col0 + (tid % QN) * 4;
 #pragma unroll
             for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb + (size_t)s * (DPP_THREADS / QN) * d.ldb);
         }
+        const float* pa = d.A + (size_t)(row0 + tid / QK) * d.lda + ka;
+#pragma unroll
+        for (int s = 0; s < SA; ++s) ra[s] = *reinterpret_cast<const float4*>(pa + (size_t)s * (DPP_THREADS / QK) * d.lda);
     }
     dpp_wide_coef wco;
     wco.load<BN>(col0, d.N, d.bias, d.epi, d.C);
     dpp_stamp(ga.prof, 1);
 
-    // ---- commit: prologue on A, both operands into LDS ----
+    // ---- commit: both operands into LDS, the prologue on A ----
     {
+        if (BKC) {
+            float* lb = Bs + (tid / QK) * LDB_ + ka;
+#pragma unroll
+            for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(lb + s * (DPP_THREADS / QK) * LDB_) = rb[s];
+        } else {
+            float* lb = Bs + (tid / QN) * LDB_ + (tid % QN) * 4;
+#pragma unroll
+            for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(lb + s * (DPP_THREADS / QN) * LDB_) = rb[s];
+        }
         float* la = As + (tid / QK) * LDA_ + ka;
 #pragma unroll
         for (int s = 0; s < SA; ++s) {
@@ -664,16 +675,6 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_ksplit_kernel(GemmArgs ga) {
             }
             if (modeA & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(la + s * (DPP_THREADS / QK) * LDA_) = v;
-        }
-        if (BKC) {
-            float* lb = Bs + (tid / QK) * LDB_ + ka;
-#pragma unroll
-            for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(lb + s * (DPP_THREADS / QK) * LDB_) = rb[s];
-        } else {
-            constexpr int QN = BN / 4;
-            float* lb = Bs + (tid / QN) * LDB_ + (tid % QN) * 4;
-#pragma unroll
-            for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(lb + s * (DPP_THREADS / QN) * LDB_) = rb[s];
         }
     }
     __syncthreads();

@@ -332,6 +332,23 @@ def rowstream_plan(M, N, K, b_kc):
     return None
 
 
+# dpp_gemm variant 2 (gemm_ksplit_kernel): 32 rows x all columns x the WHOLE K per workgroup, one memory round trip, the four waves
+# split K.  For the long-K / narrow-N 1x1 convolutions of the late stages, K-contiguous A, whole tiles only.
+#   DPP_KSPLIT = 0: off | 1: K = 256 (stage 3 / 4 bottleneck entries and the data gradients of their exits) | 2: K = 128 as well
+KSPLIT = int(os.environ.get('DPP_KSPLIT', '2'))
+KSPLIT_MAX_M = int(os.environ.get('DPP_KSPLIT_MAX_M', '16384'))
+
+
+def ksplit_plan(M, N, K):
+    if KSPLIT <= 0 or M % 32 or M > KSPLIT_MAX_M * (2 if K == 128 else 1):
+        return None
+    if K == 256 and N % 64 == 0:
+        return (32, 64, 4)
+    if K == 128 and N % 32 == 0 and KSPLIT >= 2:
+        return (32, 32, 4)
+    return None
+
+
 def conv3x3_bm(pixels, Co):
     """Rows per workgroup of the 3x3 kernel (the choice dpp_conv3x3 makes for bm = 0, made explicit so that the host knows
     the row-block count of the fused epilogue partials)."""
@@ -739,12 +756,15 @@ class CompiledNet(object):
             rs = rowstream_plan(M, Co, Ci, True)
             if rs is not None:
                 tile = rs
+            ks = ksplit_plan(M, Co, Ci) if (s[0] == 1 and rs is None) else None
+            if ks is not None:
+                tile = ks
             if want_stats:
                 nblk = -(-M // tile[0])
                 out.stats = (rt.alloc((nblk, 2, Co), zero=False), nblk, tile[0])
                 epi = ops.epilogue(stats=out.stats[0])
             mp = RowMap.strided(s[0], Ho, Wo, Hi, Wi) if s[0] != 1 else None
-            variant = 1 if rs is not None else 0
+            variant = 1 if rs is not None else (2 if ks is not None else 0)
             self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
                                   bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=variant,
                                   name='conv1x1_%d' % layer.layerNum))
@@ -1095,6 +1115,9 @@ class CompiledNet(object):
                 rs = rowstream_plan(M, Ci, Co, False)
                 if rs is not None:
                     tile = rs
+                ks = ksplit_plan(M, Ci, Co) if (s == 1 and rs is None and dY_act is None) else None
+                if ks is not None:
+                    tile = ks
                 epi = None
                 if (s == 1 and not acc and self._sole_consumer_bn_view(src)) or (acc and self._two_conv1x1_consumers(src)):
                     # ReLU mask + (sum G, sum G*xhat) of the BatchNorm backward in this kernel's epilogue.  A projection block
@@ -1104,7 +1127,7 @@ class CompiledNet(object):
                     nb2 = -(-M // tile[0])
                     tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
                     epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
-                variant = 1 if (rs is not None and dY_act is None) else 0
+                variant = 1 if (rs is not None and dY_act is None) else (2 if ks is not None else 0)
                 self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
                                       residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
                                       name='dgrad1x1_%d' % layer.layerNum))

@@ -194,6 +194,49 @@ def test_rowstream_variant_fwd_and_dgrad(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(256, 64), (256, 128), (128, 32), (128, 96)])
+def test_ksplit_variant_fwd_and_dgrad(backend, cfg):
+    """The K-split kernel (variant 2: 32 rows x all columns x the whole K per workgroup, the waves split K, partial tiles summed in
+    the epilogue's LDS images): 1x1 conv forward (filters K-contiguous) with BN+ReLU prologue, bias, residual and fused statistics,
+    and the data gradient of a channel-expanding conv (B in [k][n] layout) accumulating onto an earlier share."""
+    rt = get_runtime(backend)
+    K, N = cfg
+    bn = 64 if K == 256 else 32
+    rng = np.random.RandomState(18)
+    M = 96
+    X = rng.normal(size=(M, K)).astype('float32')
+    Wk = (rng.normal(size=(N, K)) * 0.3).astype('float32')
+    mean, scale, beta = (rng.normal(size=K).astype('float32') for _ in range(3))
+    bias = rng.normal(size=N).astype('float32')
+    res = rng.normal(size=(M, N)).astype('float32')
+    b = {k: rt.upload(v) for k, v in dict(X=X, Wk=Wk, mean=mean, scale=scale, beta=beta, bias=bias, res=res).items()}
+    Y = rt.alloc((M, N), zero=False)
+    nblk = M // 32
+    stats = rt.alloc((nblk, 2, N), zero=False)
+    ops.gemm(rt, b['X'], b['Wk'], Y, M, N, K, 1, 1, K, K, N, actA=ops.act(Act.BN_RELU, b['mean'], b['scale'], b['beta'], K),
+             bias=b['bias'], residual=b['res'], tile=(32, bn, 4), variant=2, epi=ops.epilogue(stats=stats))(rt.stream)
+    gamma, mo, io, so = rt.upload(np.ones(N, 'float32')), rt.alloc(N), rt.alloc(N), rt.alloc(N)
+    ops.bn_finalize(rt, stats, nblk, M, 32, N, gamma, 1e-4, mo, io, so)(rt.stream)
+    rt.synchronize()
+    A = np.maximum((X.astype('f8') - mean) * scale + beta, 0)
+    ref = A @ Wk.astype('f8').T + bias + res
+    _check(Y.get(), ref, K, 8)
+    np.testing.assert_allclose(mo.get(), ref.mean(0), rtol=0, atol=3e-6 * np.abs(ref).max())
+    np.testing.assert_allclose(io.get(), 1 / np.sqrt(ref.var(0) + np.float32(1e-4)), rtol=3e-5)
+    # data gradient of a conv with K output channels and N input channels: dA[m][c] = share[m][c] + sum_o dY[m][o] W2[o][c]
+    W2 = (rng.normal(size=(K, N)) * 0.3).astype('float32')
+    dY = rng.normal(size=(M, K)).astype('float32')
+    share = rng.normal(size=(M, N)).astype('float32')
+    dH = rt.upload(share)
+    ops.gemm(rt, rt.upload(dY), rt.upload(W2), dH, M, N, K, 1, 0, K, N, N, residual=dH, tile=(32, bn, 4), variant=2)(rt.stream)
+    rt.synchronize()
+    _check(dH.get(), share + dY.astype('f8') @ W2.astype('f8'), K, 8)
+    # what the kernel does not take is refused, not mis-computed
+    with pytest.raises(Exception):
+        ops.gemm(rt, b['X'], b['Wk'], Y, M - 8, N, K, 1, 1, K, K, N, tile=(32, bn, 4), variant=2)(rt.stream)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_every_gemm_instantiation_of_a_small_resnet(backend):
     """Every distinct dpp_gemm problem the train plans of a small ResNet launch (tile / split-K heuristics, strided row maps,
     BN+ReLU prologues, bias / residual / statistics epilogues), stand-alone against float64 (tests/gemm_cases.py); the

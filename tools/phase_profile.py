@@ -121,7 +121,9 @@ if __name__ == '__main__':
     for feats in ((), full):
         gemm_case('1x1 stage3/4 a 256->64  tile 64x16', 8192, 64, 256, (64, 16, 4), feats)
         gemm_case('1x1 stage3/4 c 64->256  tile 64x64', 8192, 256, 64, (64, 64, 4), feats)
+        gemm_case('1x1 stage3/4 a 256->64  K-split 32x64', 8192, 64, 256, (32, 64, 4), feats, variant=2)
         gemm_case('1x1 stage2  a 128->32   tile 64x32', 32768, 32, 128, (64, 32, 4), feats)
+        gemm_case('1x1 stage2  a 128->32   K-split 32x32', 32768, 32, 128, (32, 32, 4), feats, variant=2)
         gemm_case('1x1 stage2  c 32->128   tile 64x64', 32768, 128, 32, (64, 64, 4), feats)
         gemm_case('1x1 stage1  a 64->16    tile 128x16', 131072, 16, 64, (128, 16, 4), feats)
         gemm_case('1x1 stage1  c 16->64    tile 64x64', 131072, 64, 16, (64, 64, 4), feats)
