@@ -348,6 +348,7 @@ __device__ __forceinline__ float aug_crop_max(const float* __restrict__ im, int 
 }
 
 __global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a) {
+    dpp_kernarg_warm<sizeof(PrepArgs)>();
     __shared__ float s_red[DPP_THREADS / DPP_WAVE];
     __shared__ float s_label[MAXJ3];
     const int b = blockIdx.x;
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_warp_kernel(const float* 
 // launch plan draws fresh parameters every step without a separate launch.
 __global__ __launch_bounds__(DPP_THREADS) void augment_fused_kernel(PrepArgs a, float* __restrict__ out_x, int S,
                                                                     unsigned long long* counter_rw, unsigned* ticket) {
+    dpp_kernarg_warm<sizeof(PrepArgs) + 32>();
     __shared__ float s_red[DPP_THREADS / DPP_WAVE];
     __shared__ float s_label[MAXJ3];
     __shared__ AugRec s_rec;

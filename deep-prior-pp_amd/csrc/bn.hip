@@ -95,11 +95,17 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
                                                                   float* __restrict__ run_inv_std, float alpha) {
     // WPC waves per channel (4 = the whole workgroup, used when there are many partial blocks); `lane` is the thread's
     // index among the WPC * 64 threads of its channel
+    dpp_kernarg_warm<96>();
     __shared__ double slot_a[4], slot_b[4];
     constexpr int GT = DPP_WAVE * WPC;
     const int lane = threadIdx.x % GT;
     const int c = blockIdx.x * (DPP_THREADS / GT) + threadIdx.x / GT;
     const int cc = c < C ? c : C - 1;                  // keep every lane in the shuffles
+    // what the last lines need from memory is fetched NOW, with the partials: loaded where it is used it is one more dependent
+    // round trip at the end of a kernel that consists of nothing else
+    const bool upd = alpha > 0.0f && run_mean != nullptr;
+    const float gam = gamma[cc];
+    const float rm_old = (upd ? run_mean : gamma)[cc], ri_old = (upd ? run_inv_std : gamma)[cc];
     // `partial` holds nseg segments (the ranks of a sync-BN all-gather) of nbs blocks each; a lane walks blocks lane, lane+64,
     // ... of every segment (no integer division per partial: this kernel is a few microseconds of pure latency)
     const int Mseg = M / nseg;
@@ -172,11 +178,11 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
     float inv_std = (float)(1.0 / sqrt(var + (double)eps));
     mean_o[c] = meanf;
     inv_std_o[c] = inv_std;
-    scale_o[c] = gamma[c] * inv_std;
-    if (alpha > 0.0f && run_mean != nullptr) {
+    scale_o[c] = gam * inv_std;
+    if (upd) {
         float oma = 1.0f - alpha;                        // (1. - alpha) in floatX, batchnormlayer.py:165-172
-        run_mean[c] = oma * run_mean[c] + alpha * meanf;
-        run_inv_std[c] = oma * run_inv_std[c] + alpha * inv_std;
+        run_mean[c] = oma * rm_old + alpha * meanf;
+        run_inv_std[c] = oma * ri_old + alpha * inv_std;
     }
 }
 
@@ -197,6 +203,7 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float*
                                                                     const float* __restrict__ mean, const float* __restrict__ inv_std,
                                                                     const float* __restrict__ scale, const float* __restrict__ beta,
                                                                     int relu, float* G, int rpb, float* __restrict__ partial) {
+    dpp_kernarg_warm<128>();
     __shared__ float s_a[DPP_THREADS * 4];
     __shared__ float s_b[DPP_THREADS * 4];
     const int Q = C >> 2, RP = DPP_THREADS / Q;
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const floa
                                                                       float* __restrict__ c1, float* __restrict__ c2,
                                                                       const float* __restrict__ inv_std, const float* __restrict__ scale,
                                                                       float* __restrict__ q, float* __restrict__ p) {
+    dpp_kernarg_warm<96>();
     __shared__ double slot_a[4], slot_b[4];
     constexpr int GT = DPP_WAVE * WPC;
     const int lane = threadIdx.x % GT;
@@ -292,6 +300,7 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const float* 
                                                                    const float* __restrict__ inv_std, const float* __restrict__ scale,
                                                                    const float* __restrict__ c1, const float* __restrict__ c2,
                                                                    const float* add, float* dX, int rpb, float* __restrict__ colsum) {
+    dpp_kernarg_warm<128>();
     __shared__ float s_a[DPP_THREADS * 4];
     const int Q = C >> 2, RP = DPP_THREADS / Q;
     const int tid = threadIdx.x, q = tid % Q, rr = tid / Q;

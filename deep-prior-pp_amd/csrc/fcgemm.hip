@@ -143,6 +143,7 @@ struct Stage {
 
 template <int PREC, int RM, int CN, int KC, bool AKC, bool BKC>
 __global__ __launch_bounds__(DPP_THREADS) void fc_gemm_kernel(FcArgs ga) {
+    dpp_kernarg_warm<sizeof(FcArgs)>();
     const dpp_gemm_desc& d = ga.d;
     typedef typename Prec<PREC>::elem elem;
     constexpr int EPT = Prec<PREC>::EPT;
@@ -262,6 +263,7 @@ struct FsArgs {
 
 template <int BN, bool AKC, bool BKC>
 __global__ __launch_bounds__(DPP_THREADS) void fc_stream_kernel(FsArgs ga) {
+    dpp_kernarg_warm<sizeof(FsArgs)>();
     const dpp_gemm_desc& d = ga.d;
     constexpr int BM = 128, KC = 32, LD = KC + 4, NST = 3, WM = 2, WN = 2;
     constexpr int RM = BM / (16 * WM), CN = BN / (16 * WN);

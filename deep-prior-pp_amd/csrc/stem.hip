@@ -30,6 +30,7 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_fwd_kernel(const float* __re
                                                                const float* __restrict__ bias, int Co, float* __restrict__ Y,
                                                                uint8_t* __restrict__ arg, int tiles_x, int tiles_y,
                                                                float* __restrict__ stats) {
+    dpp_kernarg_warm<128>();
     __shared__ float xs[LX * LXP];
     __shared__ float Ws[KPAD * CN * 16];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
@@ -150,6 +151,7 @@ constexpr int GM_A = 64 * 32 + 16;       // floats between the four window-pixel
 __global__ __launch_bounds__(DPP_THREADS) void stem_wgrad_kernel(const float* __restrict__ X, int N, int H, int W, const float* __restrict__ dY,
                                                                  const uint8_t* __restrict__ arg, int Co, float* __restrict__ partial,
                                                                  int tiles_x, int tiles_y, int tiles_per_block, int total_tiles) {
+    dpp_kernarg_warm<128>();
     __shared__ __attribute__((aligned(16))) float gm[4 * GM_A];     // 33 KB; re-used for the final reduction (4 x 32 x 32 floats)
     __shared__ float xs[LX * LXW];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
