@@ -604,6 +604,10 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_rowstream_kernel(GemmArgs ga
 // the four partial tiles meet in the LDS images of the wide epilogue.  Compile-time K and BN, whole tiles only: the entry code
 // is a few dozen instructions.  A is K-contiguous [M][KT] with the BatchNorm + ReLU prologue, B either K-contiguous [BN][KT]
 // (forward: the filters) or [KT][BN] (data gradient).
+// Measured: alone the kernel is no faster than the 64 x 16 tiles (9.8 vs 9.3 us: a CU takes in ~25 KB/us whatever the access
+// pattern, and 96 KB per workgroup is 3.8 us of that), in the step it is (3.96 -> 3.85 ms: 24 instead of 40 MB through the
+// L2s per launch).  Running row tile t on the XCD that the 64-row producers put rows 64 (t/2).. on (their L2 keeps what it wrote)
+// changed nothing (3.84-3.86 ms either way): not kept.
 // (amdgpu_waves_per_eu: with the default occupancy goal the scheduler sinks every load down to its LDS write to save registers --
 // "load, wait, write" twenty-four times over; one workgroup per CU is all the 100 KB LDS footprint allows anyway)
 template <int KT, int BN, bool BKC>

@@ -194,16 +194,15 @@ def test_rowstream_variant_fwd_and_dgrad(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('cfg', [(256, 64), (256, 128), (128, 32), (128, 96)])
+@pytest.mark.parametrize('cfg', [(256, 64, 96), (256, 128, 96), (128, 32, 96), (128, 96, 96), (256, 64, 512), (128, 32, 1024)])
 def test_ksplit_variant_fwd_and_dgrad(backend, cfg):
     """The K-split kernel (variant 2: 32 rows x all columns x the whole K per workgroup, the waves split K, partial tiles summed in
     the epilogue's LDS images): 1x1 conv forward (filters K-contiguous) with BN+ReLU prologue, bias, residual and fused statistics,
     and the data gradient of a channel-expanding conv (B in [k][n] layout) accumulating onto an earlier share."""
     rt = get_runtime(backend)
-    K, N = cfg
+    K, N, M = cfg
     bn = 64 if K == 256 else 32
     rng = np.random.RandomState(18)
-    M = 96
     X = rng.normal(size=(M, K)).astype('float32')
     Wk = (rng.normal(size=(N, K)) * 0.3).astype('float32')
     mean, scale, beta = (rng.normal(size=K).astype('float32') for _ in range(3))
