@@ -272,14 +272,17 @@ def main():
             # HBM bytes per launch of that kernel family from the PMC counters: they cannot be read inside this process, so
             # the number is the one measured with rocprofv3 --pmc on this workload (separate FETCH_SIZE / WRITE_SIZE passes,
             # tools/pmc_summary.py); the file records the commit it was measured at
-            pmc_family = {'gemm_mfma_f32': 'gemm_kernel', 'conv3x3_mfma_f32': 'conv3x3_kernel', 'bn_bwd_apply': 'bn_bwd_apply_kernel',
-                          'adam': 'adam_kernel'}.get(dom_name)
+            pmc_family = {'gemm_mfma_f32': ('gemm_kernel', 'gemm_ksplit_kernel', 'gemm_rowstream_kernel', 'fc_stream_kernel', 'fc_gemm_kernel'),
+                          'conv3x3_mfma_f32': ('conv3x3_kernel',), 'bn_bwd_apply': ('bn_bwd_apply_kernel',), 'adam': ('adam_kernel',)}.get(dom_name, ())
             for fn in ('r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
                 try:
                     with open(os.path.join(ROOT, 'profiles', fn)) as fh:
                         pj = json.load(fh)
-                    if B == 128 and S == 128 and args.dtype == 'f32' and pmc_family in pj:
-                        roof['traffic'] = round(pj[pmc_family]['bytes_per_launch'])
+                    ks = [k for k in pmc_family if k in pj]
+                    if B == 128 and S == 128 and args.dtype == 'f32' and ks:
+                        # launch-weighted mean over the kernels the family's launches run on
+                        nl = sum(pj[k]['launches_per_step'] for k in ks)
+                        roof['traffic'] = round(sum(pj[k]['bytes_per_launch'] * pj[k]['launches_per_step'] for k in ks) / nl)
                         roof['traffic_source'] = 'profiles/' + fn.replace('.json', '.txt')
                         break
                 except (OSError, ValueError):
