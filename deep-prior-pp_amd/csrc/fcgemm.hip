@@ -177,7 +177,7 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_gemm_kernel(FcArgs ga) {
     SA sa;
     SB sb;
     const dpp_rowmap ident = {1, 0, 0, 0, 0};
-    auto fetch = [&](int c) {
+    auto fetch = [&](int c) __attribute__((always_inline)) {
         const int kc = k_begin + c * KC;
         sa.fetch(d.A, d.lda, d.mapA, row0, M, kc, k_end, d.actA, ga.vecA);
         sb.fetch(d.B, d.ldb, BKC ? ident : d.mapB, col0, N, kc, k_end, d.actB, ga.vecB);
@@ -261,8 +261,10 @@ struct FsArgs {
     int Kper;
 };
 
+// (DPP_WAVES_PER_EU: 83-110 KB of dynamic LDS allow one workgroup per CU, which the compiler cannot see -- aiming at four waves per
+// SIMD it kept the kernel under 128 VGPRs by spilling the chunk in flight (ra[]) to scratch memory and back in every iteration)
 template <int BN, bool AKC, bool BKC>
-__global__ __launch_bounds__(DPP_THREADS) void fc_stream_kernel(FsArgs ga) {
+__global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void fc_stream_kernel(FsArgs ga) {
     dpp_kernarg_warm<sizeof(FsArgs)>();
     const dpp_gemm_desc& d = ga.d;
     constexpr int BM = 128, KC = 32, LD = KC + 4, NST = 3, WM = 2, WN = 2;
@@ -321,9 +323,13 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_stream_kernel(FsArgs ga) {
             be = *reinterpret_cast<const float4*>(d.actA.beta + cidx);
         }
     }
-    float4 ra[SA], rb[SB];
+    // rb as a native vector type: float4 is a struct, and a value that is only copied (global -> register -> LDS, no arithmetic) was
+    // lowered to memcpy intrinsics through a private-memory array -- scratch stores and loads in every K iteration, and a drain of
+    // all outstanding loads right where they were issued
+    float4 ra[SA];
+    f32x4 rb[SB];
     const size_t stepA = AKC ? (size_t)KC : (size_t)KC * d.lda, stepB = BKC ? (size_t)KC : (size_t)KC * d.ldb;
-    auto fetch = [&](int c) {
+    auto fetch = [&](int c) __attribute__((always_inline)) {
         if (AKC && (modeA & 2)) {
             mu = *reinterpret_cast<const float4*>(d.actA.mean + cidx);
             sc = *reinterpret_cast<const float4*>(d.actA.scale + cidx);
@@ -333,12 +339,12 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_stream_kernel(FsArgs ga) {
         }
 #pragma unroll
         for (int s = 0; s < SA; ++s) ra[s] = *reinterpret_cast<const float4*>(pa[s] + c * stepA);
-        if (bvalid) {
+        if (BKC || bvalid) {
 #pragma unroll
-            for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb[s] + c * stepB);
+            for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const f32x4*>(pb[s] + c * stepB);
         }
     };
-    auto act = [&](float4 v) {
+    auto act = [&](float4 v) __attribute__((always_inline)) {
         if (modeA & 2) {
             v.x = (v.x - mu.x) * sc.x + be.x; v.y = (v.y - mu.y) * sc.y + be.y;
             v.z = (v.z - mu.z) * sc.z + be.z; v.w = (v.w - mu.w) * sc.w + be.w;
@@ -346,10 +352,10 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_stream_kernel(FsArgs ga) {
         if (modeA & 1) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
         return v;
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf) __attribute__((always_inline)) {
         float* As = img + buf * SZ;
         float* Bs = As + SZA;
-        if (AKC) {
+        if constexpr (AKC) {
 #pragma unroll
             for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(&As[la + 32 * s * LD]) = modeA ? act(ra[s]) : ra[s];
         } else {
@@ -361,14 +367,14 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_stream_kernel(FsArgs ga) {
             *reinterpret_cast<float4*>(&As[la + 2 * LD]) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
             *reinterpret_cast<float4*>(&As[la + 3 * LD]) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
         }
-        if (BKC) {
+        if constexpr (BKC) {
 #pragma unroll
-            for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(&Bs[lb + 32 * s * LD]) = rb[s];
+            for (int s = 0; s < SB; ++s) *reinterpret_cast<f32x4*>(&Bs[lb + 32 * s * LD]) = rb[s];
         } else if (bvalid) {
-            *reinterpret_cast<float4*>(&Bs[lb + 0 * LD]) = make_float4(rb[0].x, rb[1].x, rb[2].x, rb[3].x);
-            *reinterpret_cast<float4*>(&Bs[lb + 1 * LD]) = make_float4(rb[0].y, rb[1].y, rb[2].y, rb[3].y);
-            *reinterpret_cast<float4*>(&Bs[lb + 2 * LD]) = make_float4(rb[0].z, rb[1].z, rb[2].z, rb[3].z);
-            *reinterpret_cast<float4*>(&Bs[lb + 3 * LD]) = make_float4(rb[0].w, rb[1].w, rb[2].w, rb[3].w);
+            *reinterpret_cast<float4*>(&Bs[lb + 0 * LD]) = make_float4(rb[0][0], rb[1][0], rb[2][0], rb[3][0]);
+            *reinterpret_cast<float4*>(&Bs[lb + 1 * LD]) = make_float4(rb[0][1], rb[1][1], rb[2][1], rb[3][1]);
+            *reinterpret_cast<float4*>(&Bs[lb + 2 * LD]) = make_float4(rb[0][2], rb[1][2], rb[2][2], rb[3][2]);
+            *reinterpret_cast<float4*>(&Bs[lb + 3 * LD]) = make_float4(rb[0][3], rb[1][3], rb[2][3], rb[3][3]);
         }
     };
 
