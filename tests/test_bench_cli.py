@@ -61,3 +61,18 @@ def test_pipelined_augmentation_trains_on_the_same_minibatches():
         assert res['config']['augment_pipelined'] == (not flag)
         costs[bool(flag)] = res['config']['final_cost']
     assert costs[True] == costs[False] and costs[True] > 0
+
+
+@pytest.mark.gpu
+def test_plan_runner_modes_train_the_same_net_on_the_gpu():
+    """The plan runner's issue modes only change HOW the two lanes are ordered against each other -- forks / joins riding on kernel
+    completion signals (default), as recorded events (DPP_FORK_STOP_EVENT=0), the gradient branch dealt to two side streams
+    (DPP_SIDE_STREAMS=2), the augmentation inline instead of prefetched -- so a few steps of the bs128 bench must end on the same cost
+    in every mode (a missing dependency shows up as a different or non-finite cost)."""
+    costs = {}
+    for name, env, flags in (('default', {}, []), ('recorded_events', dict(DPP_FORK_STOP_EVENT='0'), []),
+                             ('two_side_streams', dict(DPP_SIDE_STREAMS='2'), []), ('inline_augment', {}, ['--augment-inline'])):
+        rc, out, err = _bench(['--steps', '6', '--warmup', '2', '--no-cpu-baseline'] + flags, env=env, timeout=600)
+        assert rc == 0, err[-3000:]
+        costs[name] = json.loads([l for l in out.splitlines() if l.startswith('{')][0])['config']['final_cost']
+    assert len(set(costs.values())) == 1 and costs['default'] > 0, costs
