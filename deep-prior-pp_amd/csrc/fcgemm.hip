@@ -21,6 +21,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 template <int PREC> struct Prec;
 template <> struct Prec<0> {                     // f32
@@ -263,15 +264,28 @@ struct FsArgs {
 
 // (DPP_WAVES_PER_EU: 83-110 KB of dynamic LDS allow one workgroup per CU, which the compiler cannot see -- aiming at four waves per
 // SIMD it kept the kernel under 128 VGPRs by spilling the chunk in flight (ra[]) to scratch memory and back in every iteration)
-template <int BN, bool AKC, bool BKC>
+// PREC = 1 (BASELINE config 5): the same pipeline with bf16 LDS images -- operands rounded RNE after the prologue when the chunk is
+// committed, one v_mfma_f32_16x16x32_bf16 per accumulator tile and 32-deep chunk (16 instead of 128 MFMAs per wave and chunk: the
+// kernel is then bound by the weight stream alone).
+template <int PREC, int BN, bool AKC, bool BKC>
 __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void fc_stream_kernel(FsArgs ga) {
     dpp_kernarg_warm<sizeof(FsArgs)>();
     const dpp_gemm_desc& d = ga.d;
-    constexpr int BM = 128, KC = 32, LD = KC + 4, NST = 3, WM = 2, WN = 2;
+    typedef typename Prec<PREC>::elem elem;
+    constexpr int BM = 128, KC = 32, LD = KC + Prec<PREC>::PAD, NST = 3, WM = 2, WN = 2;
     constexpr int RM = BM / (16 * WM), CN = BN / (16 * WN);
     constexpr int SZA = BM * LD, SZB = BN * LD, SZ = SZA + SZB;
     HIP_DYNAMIC_SHARED(float4, smem4)
-    float* const img = reinterpret_cast<float*>(smem4);
+    elem* const img = reinterpret_cast<elem*>(smem4);
+    // one k-run of four values into the image: 16 bytes (f32) or 8 bytes (bf16, rounded to nearest even)
+    auto put4 = [](elem* dst, float x, float y, float z, float w) __attribute__((always_inline)) {
+        if constexpr (PREC == 0) *reinterpret_cast<float4*>(dst) = make_float4(x, y, z, w);
+        else {
+            bf16x4 o;
+            o[0] = (__bf16)x; o[1] = (__bf16)y; o[2] = (__bf16)z; o[3] = (__bf16)w;
+            *reinterpret_cast<bf16x4*>(dst) = o;
+        }
+    };
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
     const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
@@ -353,28 +367,34 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void fc_stream_
         return v;
     };
     auto commit = [&](int buf) __attribute__((always_inline)) {
-        float* As = img + buf * SZ;
-        float* Bs = As + SZA;
+        elem* As = img + buf * SZ;
+        elem* Bs = As + SZA;
         if constexpr (AKC) {
 #pragma unroll
-            for (int s = 0; s < SA; ++s) *reinterpret_cast<float4*>(&As[la + 32 * s * LD]) = modeA ? act(ra[s]) : ra[s];
+            for (int s = 0; s < SA; ++s) {
+                const float4 v = modeA ? act(ra[s]) : ra[s];
+                put4(&As[la + 32 * s * LD], v.x, v.y, v.z, v.w);
+            }
         } else {
             float4 v[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) v[s] = modeA ? act(ra[s]) : ra[s];
-            *reinterpret_cast<float4*>(&As[la + 0 * LD]) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-            *reinterpret_cast<float4*>(&As[la + 1 * LD]) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-            *reinterpret_cast<float4*>(&As[la + 2 * LD]) = make_float4(v[0].z, v[1].z, v[2].z, v[3].z);
-            *reinterpret_cast<float4*>(&As[la + 3 * LD]) = make_float4(v[0].w, v[1].w, v[2].w, v[3].w);
+            put4(&As[la + 0 * LD], v[0].x, v[1].x, v[2].x, v[3].x);
+            put4(&As[la + 1 * LD], v[0].y, v[1].y, v[2].y, v[3].y);
+            put4(&As[la + 2 * LD], v[0].z, v[1].z, v[2].z, v[3].z);
+            put4(&As[la + 3 * LD], v[0].w, v[1].w, v[2].w, v[3].w);
         }
         if constexpr (BKC) {
 #pragma unroll
-            for (int s = 0; s < SB; ++s) *reinterpret_cast<f32x4*>(&Bs[lb + 32 * s * LD]) = rb[s];
+            for (int s = 0; s < SB; ++s) {
+                if constexpr (PREC == 0) *reinterpret_cast<f32x4*>(&Bs[lb + 32 * s * LD]) = rb[s];
+                else put4(&Bs[lb + 32 * s * LD], rb[s][0], rb[s][1], rb[s][2], rb[s][3]);
+            }
         } else if (bvalid) {
-            *reinterpret_cast<float4*>(&Bs[lb + 0 * LD]) = make_float4(rb[0][0], rb[1][0], rb[2][0], rb[3][0]);
-            *reinterpret_cast<float4*>(&Bs[lb + 1 * LD]) = make_float4(rb[0][1], rb[1][1], rb[2][1], rb[3][1]);
-            *reinterpret_cast<float4*>(&Bs[lb + 2 * LD]) = make_float4(rb[0][2], rb[1][2], rb[2][2], rb[3][2]);
-            *reinterpret_cast<float4*>(&Bs[lb + 3 * LD]) = make_float4(rb[0][3], rb[1][3], rb[2][3], rb[3][3]);
+            put4(&Bs[lb + 0 * LD], rb[0][0], rb[1][0], rb[2][0], rb[3][0]);
+            put4(&Bs[lb + 1 * LD], rb[0][1], rb[1][1], rb[2][1], rb[3][1]);
+            put4(&Bs[lb + 2 * LD], rb[0][2], rb[1][2], rb[2][2], rb[3][2]);
+            put4(&Bs[lb + 3 * LD], rb[0][3], rb[1][3], rb[2][3], rb[3][3]);
         }
     };
 
@@ -391,27 +411,41 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void fc_stream_
     if (nchunks > 1) fetch(1);
     __syncthreads();
     int cur = 0;
-    const int aoff = (wm * (BM / WM) + l15) * LD + kq * 4, boff = (wn * (BN / WN) + l15) * LD + kq * 4;
+    constexpr int EPT = Prec<PREC>::EPT;      // k-values of a lane's 16-byte fragment read
+    const int aoff = (wm * (BM / WM) + l15) * LD + kq * EPT, boff = (wn * (BN / WN) + l15) * LD + kq * EPT;
     for (int c = 0; c < nchunks; ++c) {
         const int nxt = cur == NST - 1 ? 0 : cur + 1;
         if (c + 1 < nchunks) commit(nxt);                 // its loads were issued one whole MFMA block ago
         if (c + 2 < nchunks) fetch(c + 2);                // in flight under this chunk's MFMAs
-        const float* As = img + cur * SZ;
-        const float* Bs = As + SZA;
+        const elem* As = img + cur * SZ;
+        const elem* Bs = As + SZA;
+        if constexpr (PREC == 0) {
 #pragma unroll
-        for (int k0 = 0; k0 < KC; k0 += 16) {
-            float4 af[RM], bf[CN];
+            for (int k0 = 0; k0 < KC; k0 += 16) {
+                float4 af[RM], bf[CN];
 #pragma unroll
-            for (int rt = 0; rt < RM; ++rt) af[rt] = *reinterpret_cast<const float4*>(&As[aoff + rt * 16 * LD + k0]);
+                for (int rt = 0; rt < RM; ++rt) af[rt] = *reinterpret_cast<const float4*>(&As[aoff + rt * 16 * LD + k0]);
 #pragma unroll
-            for (int ct = 0; ct < CN; ++ct) bf[ct] = *reinterpret_cast<const float4*>(&Bs[boff + ct * 16 * LD + k0]);
+                for (int ct = 0; ct < CN; ++ct) bf[ct] = *reinterpret_cast<const float4*>(&Bs[boff + ct * 16 * LD + k0]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int rt = 0; rt < RM; ++rt)
+                    for (int rt = 0; rt < RM; ++rt)
 #pragma unroll
-                    for (int ct = 0; ct < CN; ++ct)
-                        acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(af[rt], t), dpp_f4_get(bf[ct], t), acc[rt][ct], 0, 0, 0);
+                        for (int ct = 0; ct < CN; ++ct)
+                            acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(af[rt], t), dpp_f4_get(bf[ct], t), acc[rt][ct], 0, 0, 0);
+            }
+        } else {
+            bf16x8 af[RM], bf[CN];                        // lane (i, kq) holds k = 8 kq .. 8 kq + 7 of row i: the whole chunk in one step
+#pragma unroll
+            for (int rt = 0; rt < RM; ++rt) af[rt] = *reinterpret_cast<const bf16x8*>(&As[aoff + rt * 16 * LD]);
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) bf[ct] = *reinterpret_cast<const bf16x8*>(&Bs[boff + ct * 16 * LD]);
+#pragma unroll
+            for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
         }
         __syncthreads();
         cur = nxt;
@@ -429,23 +463,23 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void fc_stream_
     }
 }
 
-template <int BN, bool AKC, bool BKC>
+template <int PREC, int BN, bool AKC, bool BKC>
 int fs_launch(const FsArgs& ga, dim3 grid, hipStream_t st) {
-    constexpr size_t opb = 3 * (size_t)(128 + BN) * 36 * sizeof(float);
+    constexpr size_t opb = 3 * (size_t)(128 + BN) * (32 + Prec<PREC>::PAD) * sizeof(typename Prec<PREC>::elem);
     constexpr size_t epb = ((size_t)128 * (BN + 4) + 16 * BN) * 4;
     const size_t lds = opb > epb ? opb : epb;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_stream_kernel<BN, AKC, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    DPP_LAUNCH((fc_stream_kernel<BN, AKC, BKC>), grid, dim3(DPP_THREADS), lds, st, ga);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_stream_kernel<PREC, BN, AKC, BKC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DPP_LAUNCH((fc_stream_kernel<PREC, BN, AKC, BKC>), grid, dim3(DPP_THREADS), lds, st, ga);
     return dpp_launch_status();
 }
 
-template <int BN>
+template <int PREC, int BN>
 int fs_dispatch(const FsArgs& ga, dim3 grid, hipStream_t st) {
     const dpp_gemm_desc& d = ga.d;
-    if (d.a_kc && d.b_kc) return fs_launch<BN, true, true>(ga, grid, st);
-    if (d.a_kc && !d.b_kc) return fs_launch<BN, true, false>(ga, grid, st);
-    if (!d.a_kc && !d.b_kc) return fs_launch<BN, false, false>(ga, grid, st);
-    return fs_launch<BN, false, true>(ga, grid, st);
+    if (d.a_kc && d.b_kc) return fs_launch<PREC, BN, true, true>(ga, grid, st);
+    if (d.a_kc && !d.b_kc) return fs_launch<PREC, BN, true, false>(ga, grid, st);
+    if (!d.a_kc && !d.b_kc) return fs_launch<PREC, BN, false, false>(ga, grid, st);
+    return fs_launch<PREC, BN, false, true>(ga, grid, st);
 }
 
 // whether fc_stream_kernel takes the call; bn receives its column tile
@@ -509,12 +543,14 @@ extern "C" int dpp_fc_gemm(const dpp_gemm_desc* dp, int precision, int kchunk, d
     if (KC != 32 && KC != 64) return DPP_E_BADARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int bn3 = 0;
-    if (precision == 0 && fs_accepts(d, bn3)) {
+    static const bool fs_bf16 = []() { const char* e = getenv("DPP_FC_STREAM3_BF16"); return !(e && e[0] == '0'); }();
+    if ((precision == 0 || fs_bf16) && fs_accepts(d, bn3)) {
         FsArgs fa;
         fa.d = d;
         fa.Kper = d.K / d.splitk;
         dim3 g3(d.M / 128, d.N / bn3, d.splitk);
-        return bn3 == 128 ? fs_dispatch<128>(fa, g3, st) : fs_dispatch<64>(fa, g3, st);
+        if (precision == 0) return bn3 == 128 ? fs_dispatch<0, 128>(fa, g3, st) : fs_dispatch<0, 64>(fa, g3, st);
+        return bn3 == 128 ? fs_dispatch<1, 128>(fa, g3, st) : fs_dispatch<1, 64>(fa, g3, st);
     }
     FcArgs ga;
     ga.d = d;
