@@ -725,6 +725,142 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
     dpp_stamp(ga.prof, 4);
 }
 
+// ---- row-streaming variant for the stage-1 shapes with 16 output columns and K = 64 (variant 3) ----------------------------
+// 131 072 pixel rows x (64 -> 16 channels): 41 MB of traffic and 0.27 GFLOP, i.e. an elementwise-like stream with a tiny matrix
+// product inside.  On 128 x 16 LDS tiles every workgroup runs entry code, one load round trip, four barriers and the LDS-image
+// epilogue in lockstep with all the others (tools/phase_profile.py: 2.9 + 5.0 + 2.8 us per workgroup, nothing overlapping).  Here a
+// WAVE owns TPW tiles of 16 rows: its A fragments come straight from memory (lane (i, kq) reads 16 bytes of row i, all tiles'
+// loads issued before the first use), the 64 x 16 filter lives in registers, and the epilogue works in the MFMA D layout --
+// with the 16 rows of a tile fed in 4 x 4-transposed order, so that one store instruction covers four CONSECUTIVE 64-byte rows
+// (256 contiguous bytes); no LDS, no barrier until the column reductions at the very end.
+// ACT: operand prologue present (forward); EPI: residual / BatchNorm-backward epilogue present (data gradient) -- two register diets
+template <bool BKC, int TPW, bool ACT, bool EPI>
+__global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga) {
+    dpp_kernarg_warm<sizeof(GemmArgs)>();
+    const dpp_gemm_desc& d = ga.d;
+    __shared__ float red[4 * 16];
+    constexpr int ROWS = 64 * TPW;                           // rows per workgroup = one BatchNorm partial block
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wrow0 = blockIdx.x * ROWS + wave * 16 * TPW;
+    const int mrow = (l15 & 3) * 4 + (l15 >> 2);             // memory row (within a tile) that MFMA row l15 carries
+    const dpp_epilogue& ep = d.epi;
+    const bool bn = EPI && ep.bn_x != nullptr;
+    const int modeA = ACT ? d.actA.mode : 0;
+
+    // ---- every load up front ----
+    float4 bw[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (BKC) bw[g] = *reinterpret_cast<const float4*>(d.B + (size_t)l15 * d.ldb + g * 16 + kq * 4);
+        else {
+            const float* pb = d.B + (size_t)(g * 16 + kq * 4) * d.ldb + l15;
+            bw[g] = make_float4(pb[0], pb[d.ldb], pb[2 * (size_t)d.ldb], pb[3 * (size_t)d.ldb]);
+        }
+    }
+    float4 ra[TPW][4];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const float* pa = d.A + (size_t)(wrow0 + t * 16 + mrow) * d.lda + kq * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ra[t][g] = *reinterpret_cast<const float4*>(pa + g * 16);
+    }
+    float4 mu[4], sc[4], be[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        mu[g] = sc[g] = be[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (modeA & 2) {
+            mu[g] = *reinterpret_cast<const float4*>(d.actA.mean + g * 16 + kq * 4);
+            sc[g] = *reinterpret_cast<const float4*>(d.actA.scale + g * 16 + kq * 4);
+            be[g] = *reinterpret_cast<const float4*>(d.actA.beta + g * 16 + kq * 4);
+        }
+    }
+    const float cb = d.bias ? d.bias[l15] : 0.0f;
+    const float cmean = bn ? ep.bn_mean[l15] : 0.0f, cscale = bn ? ep.bn_scale[l15] : 0.0f;
+    const float cbeta = bn ? ep.bn_beta[l15] : 0.0f, cistd = bn ? ep.bn_inv_std[l15] : 0.0f;
+    float xr[TPW][4], rr[TPW][4];                            // bn_x / residual at this lane's output elements
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t o = (size_t)(wrow0 + t * 16 + r * 4 + kq) * d.ldc + l15;
+            xr[t][r] = bn ? ep.bn_x[o] : 0.0f;
+            rr[t][r] = (EPI && d.residual) ? d.residual[o] : 0.0f;
+        }
+
+    float vals[TPW][4];
+    float sx = 0.0f, sy = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 v = ra[t][g];
+            if (modeA & 2) {
+                v.x = (v.x - mu[g].x) * sc[g].x + be[g].x; v.y = (v.y - mu[g].y) * sc[g].y + be[g].y;
+                v.z = (v.z - mu[g].z) * sc[g].z + be[g].z; v.w = (v.w - mu[g].w) * sc[g].w + be[g].w;
+            }
+            if (modeA & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, bw[g].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, bw[g].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, bw[g].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, bw[g].w, acc, 0, 0, 0);
+        }
+        // D layout: this lane holds column l15 of MFMA rows 4 kq + r, i.e. memory rows 4 r + kq of the tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const size_t o = (size_t)(wrow0 + t * 16 + r * 4 + kq) * d.ldc + l15;
+            float v = acc[r] + cb + rr[t][r];
+            if (bn) {
+                const float dx = xr[t][r] - cmean;
+                if (ep.bn_relu && dx * cscale + cbeta < 0.0f) v = 0.0f;
+                sx += v;
+                sy += v * (dx * cistd);
+            }
+            d.C[o] = v;
+            vals[t][r] = v;
+        }
+    }
+    // ---- column reductions over the workgroup's rows (the only barriers of the kernel) ----
+    if (bn && ep.bn_partial != nullptr) {
+        float s1[1] = {sx}, s2[1] = {sy};
+        dpp_tile_colsum<1, 4, 1, 16>(s1, red, wave, 0, l15, kq);
+        dpp_tile_colsum<1, 4, 1, 16>(s2, red, wave, 0, l15, kq);
+        if (wave == 0 && kq == 0) {
+            ep.bn_partial[dpp_partial_index(0, l15, blockIdx.x, 16, gridDim.x)] = s1[0];
+            ep.bn_partial[dpp_partial_index(1, l15, blockIdx.x, 16, gridDim.x)] = s2[0];
+        }
+    }
+    if (ep.stats != nullptr) {
+        float sm[1] = {0.0f};
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[0] += vals[t][r];
+        dpp_tile_colsum<1, 4, 1, 16>(sm, red, wave, 0, l15, kq);
+        const float mean = sm[0] * (1.0f / (float)ROWS);
+        float m2[1] = {0.0f};
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float dv = vals[t][r] - mean; m2[0] += dv * dv; }
+        dpp_tile_colsum<1, 4, 1, 16>(m2, red, wave, 0, l15, kq);
+        if (wave == 0 && kq == 0) {
+            ep.stats[dpp_partial_index(0, l15, blockIdx.x, 16, gridDim.x)] = mean;
+            ep.stats[dpp_partial_index(1, l15, blockIdx.x, 16, gridDim.x)] = m2[0];
+        }
+    }
+}
+
+// dpp_gemm variant 3: rows per workgroup of gemm_stream16_kernel for this problem, or 0
+static int stream16_rows(const dpp_gemm_desc& d, const GemmArgs& ga) {
+    if (!d.a_kc || d.splitk != 1 || d.N != 16 || d.K != 64 || !ga.vecA || !d.C || d.M % 128) return 0;
+    if (d.mapA.s != 1 || d.mapB.s != 1 || d.mapC.s != 1 || d.actB.mode != 0 || (d.actA.mode & ~3)) return 0;
+    if ((d.actA.mode & 2) && d.actA.cmod < 64) return 0;        // (dpp_gemm has checked that the prologue vectors are 16-byte aligned)
+    if (d.b_kc && !ga.vecB) return 0;
+    if (d.epi.stats && d.epi.bn_x) return 0;
+    return 128;
+}
+
 // dpp_gemm variant 2: can this problem run on gemm_ksplit_kernel, and with which tile?
 static int ksplit_bn(const dpp_gemm_desc& d, const GemmArgs& ga) {
     if (!d.a_kc || d.splitk != 1 || !ga.wide || !ga.vecA || !ga.vecB || d.M % 32 || (d.K != 256 && d.K != 128)) return 0;
@@ -945,6 +1081,17 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
         }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d.variant == 3) {
+        if (stream16_rows(d, ga) != 128) return DPP_E_UNSUPPORTED;
+        const bool act = d.actA.mode != 0, epi = d.residual != nullptr || d.epi.bn_x != nullptr;
+#define DPP_S16(B_, A_, E_) DPP_LAUNCH((gemm_stream16_kernel<B_, 2, A_, E_>), dim3(d.M / 128), dim3(DPP_THREADS), 0, st, ga)
+        if (d.b_kc) { if (act) { if (epi) DPP_S16(true, true, true); else DPP_S16(true, true, false); }
+                      else { if (epi) DPP_S16(true, false, true); else DPP_S16(true, false, false); } }
+        else { if (act) { if (epi) DPP_S16(false, true, true); else DPP_S16(false, true, false); }
+               else { if (epi) DPP_S16(false, false, true); else DPP_S16(false, false, false); } }
+#undef DPP_S16
+        return dpp_launch_status();
+    }
     if (d.variant == 2) {
         const int kbn = ksplit_bn(d, ga);
         if (!kbn) return DPP_E_UNSUPPORTED;

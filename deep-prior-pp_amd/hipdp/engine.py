@@ -349,6 +349,20 @@ def ksplit_plan(M, N, K):
     return None
 
 
+# dpp_gemm variant 3 (gemm_stream16_kernel): the stage-1 bottleneck entries and the data gradients of their exits (K = 64 -> 16
+# columns) as a barrier-free row stream, see csrc/gemm.hip.   DPP_STREAM16 = 0 | 1.  No lower bound on the row count by default:
+# the kernel sums k in another order than the LDS-tiled one, and a frame's joints must not depend on the batch it is evaluated in
+# (tests/test_full_size.py compares batches of 8 and 128 at 1e-4 mm), so the choice of kernel must not depend on the batch either.
+STREAM16 = int(os.environ.get('DPP_STREAM16', '1'))
+STREAM16_MIN_M = int(os.environ.get('DPP_STREAM16_MIN_M', '128'))
+
+
+def stream16_plan(M, N, K):
+    if STREAM16 <= 0 or N != 16 or K != 64 or M % 128 or M < STREAM16_MIN_M:
+        return None
+    return (128, 16, 4)
+
+
 def conv3x3_bm(pixels, Co):
     """Rows per workgroup of the 3x3 kernel (the choice dpp_conv3x3 makes for bm = 0, made explicit so that the host knows
     the row-block count of the fused epilogue partials)."""
@@ -759,12 +773,15 @@ class CompiledNet(object):
             ks = ksplit_plan(M, Co, Ci) if (s[0] == 1 and rs is None) else None
             if ks is not None:
                 tile = ks
+            s16 = stream16_plan(M, Co, Ci) if (s[0] == 1 and rs is None and ks is None) else None
+            if s16 is not None:
+                tile = s16
             if want_stats:
                 nblk = -(-M // tile[0])
                 out.stats = (rt.alloc((nblk, 2, Co), zero=False), nblk, tile[0])
                 epi = ops.epilogue(stats=out.stats[0])
             mp = RowMap.strided(s[0], Ho, Wo, Hi, Wi) if s[0] != 1 else None
-            variant = 1 if rs is not None else (2 if ks is not None else 0)
+            variant = 1 if rs is not None else (2 if ks is not None else (3 if s16 is not None else 0))
             self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
                                   bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=variant,
                                   name='conv1x1_%d' % layer.layerNum))
@@ -1118,6 +1135,9 @@ class CompiledNet(object):
                 ks = ksplit_plan(M, Ci, Co) if (s == 1 and rs is None and dY_act is None) else None
                 if ks is not None:
                     tile = ks
+                s16 = stream16_plan(M, Ci, Co) if (s == 1 and rs is None and ks is None and dY_act is None) else None
+                if s16 is not None:
+                    tile = s16
                 epi = None
                 if (s == 1 and not acc and self._sole_consumer_bn_view(src)) or (acc and self._two_conv1x1_consumers(src)):
                     # ReLU mask + (sum G, sum G*xhat) of the BatchNorm backward in this kernel's epilogue.  A projection block
@@ -1127,7 +1147,7 @@ class CompiledNet(object):
                     nb2 = -(-M // tile[0])
                     tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
                     epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
-                variant = 1 if (rs is not None and dY_act is None) else (2 if ks is not None else 0)
+                variant = 1 if (rs is not None and dY_act is None) else (2 if ks is not None else (3 if s16 is not None else 0))
                 self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
                                       residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
                                       name='dgrad1x1_%d' % layer.layerNum))

@@ -236,6 +236,63 @@ def test_ksplit_variant_fwd_and_dgrad(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+def test_stream16_variant_against_the_tiled_kernel(backend):
+    """The barrier-free row-streaming kernel for K = 64 -> 16 columns (variant 3) against float64 and against the LDS-tiled kernel on
+    the same inputs: forward with BN+ReLU prologue, bias and fused statistics; data gradient (B in [k][n] layout) with the fused
+    BatchNorm-backward epilogue (ReLU mask, per-block (sum G, sum G*xhat)) accumulating onto an earlier share."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(28)
+    M, K, N = 384, 64, 16
+    X = rng.normal(size=(M, K)).astype('float32')
+    Wk = (rng.normal(size=(N, K)) * 0.3).astype('float32')
+    mean, scale, beta = (rng.normal(size=K).astype('float32') for _ in range(3))
+    bias = rng.normal(size=N).astype('float32')
+    b = {k: rt.upload(v) for k, v in dict(X=X, Wk=Wk, mean=mean, scale=scale, beta=beta, bias=bias).items()}
+    Y = rt.alloc((M, N), zero=False)
+    stats = rt.alloc((M // 128, 2, N), zero=False)
+    ops.gemm(rt, b['X'], b['Wk'], Y, M, N, K, 1, 1, K, K, N, actA=ops.act(Act.BN_RELU, b['mean'], b['scale'], b['beta'], K),
+             bias=b['bias'], tile=(128, 16, 4), variant=3, epi=ops.epilogue(stats=stats))(rt.stream)
+    gamma, mo, io, so = rt.upload(np.ones(N, 'float32')), rt.alloc(N), rt.alloc(N), rt.alloc(N)
+    ops.bn_finalize(rt, stats, M // 128, M, 128, N, gamma, 1e-4, mo, io, so)(rt.stream)
+    rt.synchronize()
+    ref = np.maximum((X.astype('f8') - mean) * scale + beta, 0) @ Wk.astype('f8').T + bias
+    _check(Y.get(), ref, K, 8)
+    np.testing.assert_allclose(mo.get(), ref.mean(0), rtol=0, atol=3e-6 * np.abs(ref).max())
+    np.testing.assert_allclose(io.get(), 1 / np.sqrt(ref.var(0) + np.float32(1e-4)), rtol=3e-5)
+    # data gradient with the fused BatchNorm-backward epilogue, on both kernels
+    W2 = (rng.normal(size=(K, N)) * 0.3).astype('float32')
+    dY = rng.normal(size=(M, K)).astype('float32')
+    bnx = rng.normal(size=(M, N)).astype('float32')
+    share = rng.normal(size=(M, N)).astype('float32')
+
+    class BN(object):
+        pass
+    bnl = BN()
+    bm, bs, bb, bi = (rng.normal(0, 0.3, N).astype('float32'), rng.uniform(0.5, 1.5, N).astype('float32'), rng.normal(0, 0.3, N).astype('float32'),
+                      rng.uniform(0.5, 1.5, N).astype('float32'))
+    bnl.mean, bnl.scale, bnl.beta_buf, bnl.inv_std = rt.upload(bm), rt.upload(bs), rt.upload(bb), rt.upload(bi)
+    out = {}
+    for variant, tile in ((3, (128, 16, 4)), (0, (64, 16, 4))):
+        dH = rt.upload(share)
+        nb = M // tile[0]
+        part = rt.alloc((nb, 2, N), zero=False)
+        ops.gemm(rt, rt.upload(dY), rt.upload(W2), dH, M, N, K, 1, 0, K, N, N, residual=dH, tile=tile, variant=variant,
+                 epi=ops.epilogue(bn=bnl, bn_x=rt.upload(bnx), bn_relu=True, bn_partial=part))(rt.stream)
+        rt.synchronize()
+        p = part.get().reshape(2, N, nb)                      # [s][c][b], block index fastest
+        out[variant] = (dH.get(), p.sum(axis=2))
+    g = share.astype('f8') + dY.astype('f8') @ W2.astype('f8')
+    keep = ((bnx.astype('f8') - bm) * bs + bb) >= 0
+    g = np.where(keep, g, 0.0)
+    _check(out[3][0], g, K, 8)
+    xhat = (bnx.astype('f8') - bm) * bi
+    np.testing.assert_allclose(out[3][1][0], g.sum(0), rtol=0, atol=2e-5 * np.abs(g).sum(0).max())
+    np.testing.assert_allclose(out[3][1][1], (g * xhat).sum(0), rtol=0, atol=2e-5 * np.abs(g * xhat).sum(0).max())
+    np.testing.assert_allclose(out[3][0], out[0][0], rtol=0, atol=1e-5 * np.abs(g).max())
+    np.testing.assert_allclose(out[3][1], out[0][1], rtol=0, atol=2e-5 * np.abs(g).sum(0).max())
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_every_gemm_instantiation_of_a_small_resnet(backend):
     """Every distinct dpp_gemm problem the train plans of a small ResNet launch (tile / split-K heuristics, strided row maps,
     BN+ReLU prologues, bias / residual / statistics epilogues), stand-alone against float64 (tests/gemm_cases.py); the
