@@ -733,13 +733,15 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
 // loads issued before the first use), the 64 x 16 filter lives in registers, and the epilogue works in the MFMA D layout --
 // with the 16 rows of a tile fed in 4 x 4-transposed order, so that one store instruction covers four CONSECUTIVE 64-byte rows
 // (256 contiguous bytes); no LDS, no barrier until the column reductions at the very end.
-// ACT: operand prologue present (forward); EPI: residual / BatchNorm-backward epilogue present (data gradient) -- two register diets
-template <bool BKC, int TPW, bool ACT, bool EPI>
+// ACT: operand prologue present (forward); EPI: residual / BatchNorm-backward epilogue present -- register diets.  KT = K (16 or 64),
+// CN = column tiles of 16 (N = 16 or 64), TPW = 16-row tiles per wave (rows per workgroup = 64 * TPW = one BatchNorm partial block).
+template <int KT, int CN, bool BKC, int TPW, bool ACT, bool EPI>
 __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga) {
     dpp_kernarg_warm<sizeof(GemmArgs)>();
     const dpp_gemm_desc& d = ga.d;
-    __shared__ float red[4 * 16];
-    constexpr int ROWS = 64 * TPW;                           // rows per workgroup = one BatchNorm partial block
+    constexpr int G = KT / 16, N = 16 * CN;
+    __shared__ float red[4 * N];
+    constexpr int ROWS = 64 * TPW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wrow0 = blockIdx.x * ROWS + wave * 16 * TPW;
     const int mrow = (l15 & 3) * 4 + (l15 >> 2);             // memory row (within a tile) that MFMA row l15 carries
@@ -748,25 +750,27 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga)
     const int modeA = ACT ? d.actA.mode : 0;
 
     // ---- every load up front ----
-    float4 bw[4];
+    float4 bw[G][CN];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (BKC) bw[g] = *reinterpret_cast<const float4*>(d.B + (size_t)l15 * d.ldb + g * 16 + kq * 4);
-        else {
-            const float* pb = d.B + (size_t)(g * 16 + kq * 4) * d.ldb + l15;
-            bw[g] = make_float4(pb[0], pb[d.ldb], pb[2 * (size_t)d.ldb], pb[3 * (size_t)d.ldb]);
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            if (BKC) bw[g][ct] = *reinterpret_cast<const float4*>(d.B + (size_t)(ct * 16 + l15) * d.ldb + g * 16 + kq * 4);
+            else {
+                const float* pb = d.B + (size_t)(g * 16 + kq * 4) * d.ldb + ct * 16 + l15;
+                bw[g][ct] = make_float4(pb[0], pb[d.ldb], pb[2 * (size_t)d.ldb], pb[3 * (size_t)d.ldb]);
+            }
         }
-    }
-    float4 ra[TPW][4];
+    float4 ra[TPW][G];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const float* pa = d.A + (size_t)(wrow0 + t * 16 + mrow) * d.lda + kq * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) ra[t][g] = *reinterpret_cast<const float4*>(pa + g * 16);
+        for (int g = 0; g < G; ++g) ra[t][g] = *reinterpret_cast<const float4*>(pa + g * 16);
     }
-    float4 mu[4], sc[4], be[4];
+    float4 mu[G], sc[G], be[G];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < G; ++g) {
         mu[g] = sc[g] = be[g] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (modeA & 2) {
             mu[g] = *reinterpret_cast<const float4*>(d.actA.mean + g * 16 + kq * 4);
@@ -774,91 +778,121 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga)
             be[g] = *reinterpret_cast<const float4*>(d.actA.beta + g * 16 + kq * 4);
         }
     }
-    const float cb = d.bias ? d.bias[l15] : 0.0f;
-    const float cmean = bn ? ep.bn_mean[l15] : 0.0f, cscale = bn ? ep.bn_scale[l15] : 0.0f;
-    const float cbeta = bn ? ep.bn_beta[l15] : 0.0f, cistd = bn ? ep.bn_inv_std[l15] : 0.0f;
-    float xr[TPW][4], rr[TPW][4];                            // bn_x / residual at this lane's output elements
+    float cb[CN], cmean[CN], cscale[CN], cbeta[CN], cistd[CN];
+#pragma unroll
+    for (int ct = 0; ct < CN; ++ct) {
+        const int col = ct * 16 + l15;
+        cb[ct] = d.bias ? d.bias[col] : 0.0f;
+        cmean[ct] = bn ? ep.bn_mean[col] : 0.0f; cscale[ct] = bn ? ep.bn_scale[col] : 0.0f;
+        cbeta[ct] = bn ? ep.bn_beta[col] : 0.0f; cistd[ct] = bn ? ep.bn_inv_std[col] : 0.0f;
+    }
+    float xr[TPW][CN][4], rr[TPW][CN][4];                    // bn_x / residual at this lane's output elements
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const size_t o = (size_t)(wrow0 + t * 16 + r * 4 + kq) * d.ldc + l15;
-            xr[t][r] = bn ? ep.bn_x[o] : 0.0f;
-            rr[t][r] = (EPI && d.residual) ? d.residual[o] : 0.0f;
-        }
+        for (int ct = 0; ct < CN; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t o = (size_t)(wrow0 + t * 16 + r * 4 + kq) * d.ldc + ct * 16 + l15;
+                xr[t][ct][r] = bn ? ep.bn_x[o] : 0.0f;
+                rr[t][ct][r] = (EPI && d.residual) ? d.residual[o] : 0.0f;
+            }
 
-    float vals[TPW][4];
-    float sx = 0.0f, sy = 0.0f;
+    float vals[TPW][CN][4];
+    float sx[CN], sy[CN];
+#pragma unroll
+    for (int ct = 0; ct < CN; ++ct) { sx[ct] = 0.0f; sy[ct] = 0.0f; }
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[CN];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int ct = 0; ct < CN; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
             float4 v = ra[t][g];
             if (modeA & 2) {
                 v.x = (v.x - mu[g].x) * sc[g].x + be[g].x; v.y = (v.y - mu[g].y) * sc[g].y + be[g].y;
                 v.z = (v.z - mu[g].z) * sc[g].z + be[g].z; v.w = (v.w - mu[g].w) * sc[g].w + be[g].w;
             }
             if (modeA & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, bw[g].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, bw[g].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, bw[g].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, bw[g].w, acc, 0, 0, 0);
-        }
-        // D layout: this lane holds column l15 of MFMA rows 4 kq + r, i.e. memory rows 4 r + kq of the tile
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const size_t o = (size_t)(wrow0 + t * 16 + r * 4 + kq) * d.ldc + l15;
-            float v = acc[r] + cb + rr[t][r];
-            if (bn) {
-                const float dx = xr[t][r] - cmean;
-                if (ep.bn_relu && dx * cscale + cbeta < 0.0f) v = 0.0f;
-                sx += v;
-                sy += v * (dx * cistd);
+            for (int ct = 0; ct < CN; ++ct) {
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, bw[g][ct].x, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, bw[g][ct].y, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, bw[g][ct].z, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, bw[g][ct].w, acc[ct], 0, 0, 0);
             }
-            d.C[o] = v;
-            vals[t][r] = v;
         }
+        // D layout: this lane holds column ct*16 + l15 of MFMA rows 4 kq + r, i.e. memory rows 4 r + kq of the tile
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t o = (size_t)(wrow0 + t * 16 + r * 4 + kq) * d.ldc + ct * 16 + l15;
+                float v = acc[ct][r] + cb[ct] + rr[t][ct][r];
+                if (bn) {
+                    const float dx = xr[t][ct][r] - cmean[ct];
+                    if (ep.bn_relu && dx * cscale[ct] + cbeta[ct] < 0.0f) v = 0.0f;
+                    sx[ct] += v;
+                    sy[ct] += v * (dx * cistd[ct]);
+                }
+                d.C[o] = v;
+                vals[t][ct][r] = v;
+            }
     }
     // ---- column reductions over the workgroup's rows (the only barriers of the kernel) ----
     if (bn && ep.bn_partial != nullptr) {
-        float s1[1] = {sx}, s2[1] = {sy};
-        dpp_tile_colsum<1, 4, 1, 16>(s1, red, wave, 0, l15, kq);
-        dpp_tile_colsum<1, 4, 1, 16>(s2, red, wave, 0, l15, kq);
+        dpp_tile_colsum<CN, 4, 1, N>(sx, red, wave, 0, l15, kq);
+        dpp_tile_colsum<CN, 4, 1, N>(sy, red, wave, 0, l15, kq);
         if (wave == 0 && kq == 0) {
-            ep.bn_partial[dpp_partial_index(0, l15, blockIdx.x, 16, gridDim.x)] = s1[0];
-            ep.bn_partial[dpp_partial_index(1, l15, blockIdx.x, 16, gridDim.x)] = s2[0];
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                ep.bn_partial[dpp_partial_index(0, ct * 16 + l15, blockIdx.x, N, gridDim.x)] = sx[ct];
+                ep.bn_partial[dpp_partial_index(1, ct * 16 + l15, blockIdx.x, N, gridDim.x)] = sy[ct];
+            }
         }
     }
     if (ep.stats != nullptr) {
-        float sm[1] = {0.0f};
+        float sm[CN], m2[CN];
 #pragma unroll
-        for (int t = 0; t < TPW; ++t)
+        for (int ct = 0; ct < CN; ++ct) {
+            sm[ct] = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sm[0] += vals[t][r];
-        dpp_tile_colsum<1, 4, 1, 16>(sm, red, wave, 0, l15, kq);
-        const float mean = sm[0] * (1.0f / (float)ROWS);
-        float m2[1] = {0.0f};
+            for (int t = 0; t < TPW; ++t)
 #pragma unroll
-        for (int t = 0; t < TPW; ++t)
+                for (int r = 0; r < 4; ++r) sm[ct] += vals[t][ct][r];
+        }
+        dpp_tile_colsum<CN, 4, 1, N>(sm, red, wave, 0, l15, kq);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float dv = vals[t][r] - mean; m2[0] += dv * dv; }
-        dpp_tile_colsum<1, 4, 1, 16>(m2, red, wave, 0, l15, kq);
+        for (int ct = 0; ct < CN; ++ct) {
+            sm[ct] *= 1.0f / (float)ROWS;
+            m2[ct] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float dv = vals[t][ct][r] - sm[ct]; m2[ct] += dv * dv; }
+        }
+        dpp_tile_colsum<CN, 4, 1, N>(m2, red, wave, 0, l15, kq);
         if (wave == 0 && kq == 0) {
-            ep.stats[dpp_partial_index(0, l15, blockIdx.x, 16, gridDim.x)] = mean;
-            ep.stats[dpp_partial_index(1, l15, blockIdx.x, 16, gridDim.x)] = m2[0];
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                ep.stats[dpp_partial_index(0, ct * 16 + l15, blockIdx.x, N, gridDim.x)] = sm[ct];
+                ep.stats[dpp_partial_index(1, ct * 16 + l15, blockIdx.x, N, gridDim.x)] = m2[ct];
+            }
         }
     }
 }
 
-// dpp_gemm variant 3: rows per workgroup of gemm_stream16_kernel for this problem, or 0
+// dpp_gemm variant 3: rows per workgroup of gemm_stream16_kernel for this problem (K = 64 -> 16 columns: 128; K = 16 -> 64 columns:
+// 64), or 0 when the kernel does not take it
 static int stream16_rows(const dpp_gemm_desc& d, const GemmArgs& ga) {
-    if (!d.a_kc || d.splitk != 1 || d.N != 16 || d.K != 64 || !ga.vecA || !d.C || d.M % 128) return 0;
+    const bool narrow = d.N == 16 && d.K == 64, wide = d.N == 64 && d.K == 16;
+    if (!d.a_kc || d.splitk != 1 || !(narrow || wide) || !ga.vecA || !d.C || d.M % (narrow ? 128 : 64)) return 0;
     if (d.mapA.s != 1 || d.mapB.s != 1 || d.mapC.s != 1 || d.actB.mode != 0 || (d.actA.mode & ~3)) return 0;
-    if ((d.actA.mode & 2) && d.actA.cmod < 64) return 0;        // (dpp_gemm has checked that the prologue vectors are 16-byte aligned)
+    if ((d.actA.mode & 2) && d.actA.cmod < d.K) return 0;        // (dpp_gemm has checked that the prologue vectors are 16-byte aligned)
     if (d.b_kc && !ga.vecB) return 0;
     if (d.epi.stats && d.epi.bn_x) return 0;
-    return 128;
+    return narrow ? 128 : 64;
 }
 
 // dpp_gemm variant 2: can this problem run on gemm_ksplit_kernel, and with which tile?
@@ -1082,13 +1116,17 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (d.variant == 3) {
-        if (stream16_rows(d, ga) != 128) return DPP_E_UNSUPPORTED;
+        const int rows = stream16_rows(d, ga);
+        if (!rows) return DPP_E_UNSUPPORTED;
         const bool act = d.actA.mode != 0, epi = d.residual != nullptr || d.epi.bn_x != nullptr;
-#define DPP_S16(B_, A_, E_) DPP_LAUNCH((gemm_stream16_kernel<B_, 2, A_, E_>), dim3(d.M / 128), dim3(DPP_THREADS), 0, st, ga)
-        if (d.b_kc) { if (act) { if (epi) DPP_S16(true, true, true); else DPP_S16(true, true, false); }
-                      else { if (epi) DPP_S16(true, false, true); else DPP_S16(true, false, false); } }
-        else { if (act) { if (epi) DPP_S16(false, true, true); else DPP_S16(false, true, false); }
-               else { if (epi) DPP_S16(false, false, true); else DPP_S16(false, false, false); } }
+#define DPP_S16(K_, CN_, T_, B_, A_, E_) DPP_LAUNCH((gemm_stream16_kernel<K_, CN_, B_, T_, A_, E_>), dim3(d.M / rows), dim3(DPP_THREADS), 0, st, ga)
+#define DPP_S16_ALL(K_, CN_, T_) \
+        if (d.b_kc) { if (act) { if (epi) DPP_S16(K_, CN_, T_, true, true, true); else DPP_S16(K_, CN_, T_, true, true, false); } \
+                      else { if (epi) DPP_S16(K_, CN_, T_, true, false, true); else DPP_S16(K_, CN_, T_, true, false, false); } } \
+        else { if (act) { if (epi) DPP_S16(K_, CN_, T_, false, true, true); else DPP_S16(K_, CN_, T_, false, true, false); } \
+               else { if (epi) DPP_S16(K_, CN_, T_, false, false, true); else DPP_S16(K_, CN_, T_, false, false, false); } }
+        if (rows == 128) { DPP_S16_ALL(64, 1, 2) } else { DPP_S16_ALL(16, 4, 1) }
+#undef DPP_S16_ALL
 #undef DPP_S16
         return dpp_launch_status();
     }

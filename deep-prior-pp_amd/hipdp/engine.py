@@ -350,17 +350,26 @@ def ksplit_plan(M, N, K):
 
 
 # dpp_gemm variant 3 (gemm_stream16_kernel): the stage-1 bottleneck entries and the data gradients of their exits (K = 64 -> 16
-# columns) as a barrier-free row stream, see csrc/gemm.hip.   DPP_STREAM16 = 0 | 1.  No lower bound on the row count by default:
+# columns; 2 (default): also the K = 16 -> 64 columns data gradients; 3: and those forward convolutions) as a barrier-free row stream,
+# see csrc/gemm.hip.  DPP_STREAM16 = 0 | 1 | 2 | 3.  No lower bound on the row count by default:
 # the kernel sums k in another order than the LDS-tiled one, and a frame's joints must not depend on the batch it is evaluated in
 # (tests/test_full_size.py compares batches of 8 and 128 at 1e-4 mm), so the choice of kernel must not depend on the batch either.
-STREAM16 = int(os.environ.get('DPP_STREAM16', '1'))
+STREAM16 = int(os.environ.get('DPP_STREAM16', '2'))
 STREAM16_MIN_M = int(os.environ.get('DPP_STREAM16_MIN_M', '128'))
 
 
-def stream16_plan(M, N, K):
-    if STREAM16 <= 0 or N != 16 or K != 64 or M % 128 or M < STREAM16_MIN_M:
+def stream16_plan(M, N, K, forward):
+    """K = 64 -> 16 columns: 128 rows per workgroup; K = 16 -> 64 columns: 64 rows, data gradients only (DPP_STREAM16 >= 2; the
+    forward pass gains nothing there -- 22.8 vs 23.5 us: reading the residual and writing 256-byte rows 4 bytes per lane costs what the
+    LDS transposition did -- and its other summation order put the bs256 training-mode forward at 1.02e-5 of the output scale from
+    the float32 oracle, against the 1e-5 bar of tests/test_configs.py)."""
+    if STREAM16 <= 0 or M < STREAM16_MIN_M:
         return None
-    return (128, 16, 4)
+    if N == 16 and K == 64 and M % 128 == 0:
+        return (128, 16, 4)
+    if N == 64 and K == 16 and M % 64 == 0 and (STREAM16 >= 3 or (STREAM16 >= 2 and not forward)):
+        return (64, 64, 4)
+    return None
 
 
 def conv3x3_bm(pixels, Co):
@@ -773,7 +782,7 @@ class CompiledNet(object):
             ks = ksplit_plan(M, Co, Ci) if (s[0] == 1 and rs is None) else None
             if ks is not None:
                 tile = ks
-            s16 = stream16_plan(M, Co, Ci) if (s[0] == 1 and rs is None and ks is None) else None
+            s16 = stream16_plan(M, Co, Ci, True) if (s[0] == 1 and rs is None and ks is None) else None
             if s16 is not None:
                 tile = s16
             if want_stats:
@@ -1135,7 +1144,7 @@ class CompiledNet(object):
                 ks = ksplit_plan(M, Ci, Co) if (s == 1 and rs is None and dY_act is None) else None
                 if ks is not None:
                     tile = ks
-                s16 = stream16_plan(M, Ci, Co) if (s == 1 and rs is None and ks is None and dY_act is None) else None
+                s16 = stream16_plan(M, Ci, Co, False) if (s == 1 and rs is None and ks is None and dY_act is None) else None
                 if s16 is not None:
                     tile = s16
                 epi = None

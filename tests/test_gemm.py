@@ -236,26 +236,31 @@ def test_ksplit_variant_fwd_and_dgrad(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-def test_stream16_variant_against_the_tiled_kernel(backend):
+@pytest.mark.parametrize('shape', [(64, 16, 128), (16, 64, 64)])
+def test_stream16_variant_against_the_tiled_kernel(backend, shape):
     """The barrier-free row-streaming kernel for K = 64 -> 16 columns (variant 3) against float64 and against the LDS-tiled kernel on
-    the same inputs: forward with BN+ReLU prologue, bias and fused statistics; data gradient (B in [k][n] layout) with the fused
-    BatchNorm-backward epilogue (ReLU mask, per-block (sum G, sum G*xhat)) accumulating onto an earlier share."""
+    the same inputs: forward with BN+ReLU prologue, bias, residual and fused statistics; data gradient (B in [k][n] layout) with the fused
+    BatchNorm-backward epilogue (ReLU mask, per-block (sum G, sum G*xhat)) accumulating onto an earlier share; the same for the
+    K = 16 -> 64 columns shape (four column tiles per wave, one 16-row tile)."""
     rt = get_runtime(backend)
     rng = np.random.RandomState(28)
-    M, K, N = 384, 64, 16
+    K, N, rows = shape                     # rows per workgroup = rows per BatchNorm partial block
+    M = 384
     X = rng.normal(size=(M, K)).astype('float32')
     Wk = (rng.normal(size=(N, K)) * 0.3).astype('float32')
     mean, scale, beta = (rng.normal(size=K).astype('float32') for _ in range(3))
     bias = rng.normal(size=N).astype('float32')
     b = {k: rt.upload(v) for k, v in dict(X=X, Wk=Wk, mean=mean, scale=scale, beta=beta, bias=bias).items()}
     Y = rt.alloc((M, N), zero=False)
-    stats = rt.alloc((M // 128, 2, N), zero=False)
+    res = rng.normal(size=(M, N)).astype('float32')
+    Y.set(res)
+    stats = rt.alloc((M // rows, 2, N), zero=False)
     ops.gemm(rt, b['X'], b['Wk'], Y, M, N, K, 1, 1, K, K, N, actA=ops.act(Act.BN_RELU, b['mean'], b['scale'], b['beta'], K),
-             bias=b['bias'], tile=(128, 16, 4), variant=3, epi=ops.epilogue(stats=stats))(rt.stream)
+             bias=b['bias'], residual=Y, tile=(rows, N, 4), variant=3, epi=ops.epilogue(stats=stats))(rt.stream)
     gamma, mo, io, so = rt.upload(np.ones(N, 'float32')), rt.alloc(N), rt.alloc(N), rt.alloc(N)
-    ops.bn_finalize(rt, stats, M // 128, M, 128, N, gamma, 1e-4, mo, io, so)(rt.stream)
+    ops.bn_finalize(rt, stats, M // rows, M, rows, N, gamma, 1e-4, mo, io, so)(rt.stream)
     rt.synchronize()
-    ref = np.maximum((X.astype('f8') - mean) * scale + beta, 0) @ Wk.astype('f8').T + bias
+    ref = np.maximum((X.astype('f8') - mean) * scale + beta, 0) @ Wk.astype('f8').T + bias + res
     _check(Y.get(), ref, K, 8)
     np.testing.assert_allclose(mo.get(), ref.mean(0), rtol=0, atol=3e-6 * np.abs(ref).max())
     np.testing.assert_allclose(io.get(), 1 / np.sqrt(ref.var(0) + np.float32(1e-4)), rtol=3e-5)
@@ -272,7 +277,7 @@ def test_stream16_variant_against_the_tiled_kernel(backend):
                       rng.uniform(0.5, 1.5, N).astype('float32'))
     bnl.mean, bnl.scale, bnl.beta_buf, bnl.inv_std = rt.upload(bm), rt.upload(bs), rt.upload(bb), rt.upload(bi)
     out = {}
-    for variant, tile in ((3, (128, 16, 4)), (0, (64, 16, 4))):
+    for variant, tile in ((3, (rows, N, 4)), (0, (64, 16, 4))):
         dH = rt.upload(share)
         nb = M // tile[0]
         part = rt.alloc((nb, 2, N), zero=False)
