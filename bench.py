@@ -272,7 +272,7 @@ def main():
             # HBM bytes per launch of that kernel family from the PMC counters: they cannot be read inside this process, so
             # the number is the one measured with rocprofv3 --pmc on this workload (separate FETCH_SIZE / WRITE_SIZE passes,
             # tools/pmc_summary.py); the file records the commit it was measured at
-            pmc_family = {'gemm_mfma_f32': ('gemm_kernel', 'gemm_ksplit_kernel', 'gemm_rowstream_kernel', 'fc_stream_kernel', 'fc_gemm_kernel'),
+            pmc_family = {'gemm_mfma_f32': ('gemm_kernel', 'gemm_ksplit_kernel', 'gemm_stream16_kernel', 'gemm_rowstream_kernel', 'fc_stream_kernel', 'fc_gemm_kernel'),
                           'conv3x3_mfma_f32': ('conv3x3_kernel',), 'bn_bwd_apply': ('bn_bwd_apply_kernel',), 'adam': ('adam_kernel',)}.get(dom_name, ())
             for fn in ('r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
                 try:
