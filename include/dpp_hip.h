@@ -111,7 +111,14 @@ typedef struct {
     int bm, bn, wm; /* tile: rows, cols, waves along M (4 or 1); 0 = choose */
     int variant;    /* 0: LDS-tiled kernel (any layout, split-K); 1: row-streaming kernel for skinny conv GEMMs (a_kc = 1,
                        splitk = 1, bm in {64,128}, bn in {16,32,64}): A fragments straight from global memory, no barrier
-                       in the K loop */
+                       in the K loop;
+                       2: K-split kernel (a_kc = 1, splitk = 1, identity row maps, no actB; K = 256 with N % 64 == 0 or
+                       K = 128 with N % 32 == 0, M % 32 == 0): a workgroup owns 32 rows x all columns x the whole K, every
+                       load issued up front, the four waves split K; statistics blocks of 32 rows;
+                       3: barrier-free row stream (a_kc = 1, splitk = 1, identity row maps, no actB; K = 64 -> N = 16
+                       with M % 128 == 0, statistics blocks of 128 rows, or K = 16 -> N = 64 with M % 64 == 0, blocks of
+                       64 rows): a wave owns whole 16-row tiles, epilogue in the MFMA D layout.
+                       Variants 2 and 3 return DPP_E_UNSUPPORTED for anything else (bm / bn / wm are ignored). */
     dpp_epilogue epi; /* fused statistics / BatchNorm-backward epilogue (requires splitk == 1) */
 } dpp_gemm_desc;
 int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);
