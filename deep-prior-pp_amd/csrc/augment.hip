@@ -117,6 +117,65 @@ __device__ void mat3_inv(const double S[9], double t[9]) {     // cv::invert, 3x
     t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
 }
 
+// ---- correctly rounded sin / cos --------------------------------------------------------------------------------------------
+// cv2.getRotationMatrix2D and rotatePoint2D call libm, which on the reference's platform (glibc 2.19, IBM Accurate Mathematical
+// Library) returns the CORRECTLY ROUNDED cosine / sine of the float64 angle; ocml's cos / sin (and today's NumPy) are only
+// "< 1 ulp".  Rotation coefficients that differ in the last bit are a different affine map, and nearest-neighbour gathering is
+// index work, so the coefficients are computed here in plain IEEE arithmetic that oracle/augment.py:sincos_cr repeats operation
+// for operation: Cody-Waite reduction by pi/2 in three 33-bit parts (k * part is exact), Taylor series of sin and cos in
+// double-double (two_prod through one fma: the exact error term, the pair Dekker's splitting gives the oracle), result = the
+// high word.  ~106 bits, so a rounding can only be missed when the true value lies within 2^-100 of a midpoint of two doubles.
+struct dd2 { double hi, lo; };
+__device__ __forceinline__ dd2 dd_two_sum(double a, double b) {
+    const double s = a + b, bb = s - a;
+    return dd2{s, (a - (s - bb)) + (b - bb)};
+}
+__device__ __forceinline__ dd2 dd_fast_two_sum(double a, double b) {
+    const double s = a + b;
+    return dd2{s, b - (s - a)};
+}
+__device__ __forceinline__ dd2 dd_mul(dd2 x, dd2 y) {
+    const double p = x.hi * y.hi;
+    double e = __builtin_fma(x.hi, y.hi, -p);
+    e = e + (x.hi * y.lo + x.lo * y.hi);
+    return dd_fast_two_sum(p, e);
+}
+__device__ __forceinline__ dd2 dd_add(dd2 x, dd2 y) {
+    dd2 s = dd_two_sum(x.hi, y.hi);
+    return dd_fast_two_sum(s.hi, s.lo + (x.lo + y.lo));
+}
+__device__ void dpp_sincos_cr(double a, double* sn, double* cs) {      // |a| < 8
+    static const double SC[12][2] = {
+        {-0x1.5555555555555p-3, -0x1.5555555555555p-57}, {0x1.1111111111111p-7, 0x1.1111111111111p-63},
+        {-0x1.a01a01a01a01ap-13, -0x1.a01a01a01a01ap-73}, {0x1.71de3a556c734p-19, -0x1.c154f8ddc6c00p-73},
+        {-0x1.ae64567f544e4p-26, 0x1.c062e06d1f209p-80}, {0x1.6124613a86d09p-33, 0x1.f28e0cc748ebep-87},
+        {-0x1.ae7f3e733b81fp-41, -0x1.1d8656b0ee8cbp-97}, {0x1.952c77030ad4ap-49, 0x1.ac981465ddc6cp-103},
+        {-0x1.2f49b46814157p-57, -0x1.2650f61dbdcb4p-112}, {0x1.71b8ef6dcf572p-66, -0x1.d043ae40c4647p-120},
+        {-0x1.761b41316381ap-75, 0x1.3423c7d91404fp-130}, {0x1.3f3ccdd165fa9p-84, -0x1.58ddadf344487p-139}};
+    static const double CC[13][2] = {
+        {-0x1.0000000000000p-1, 0x0.0p+0}, {0x1.5555555555555p-5, 0x1.5555555555555p-59},
+        {-0x1.6c16c16c16c17p-10, 0x1.f49f49f49f49fp-65}, {0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-76},
+        {-0x1.27e4fb7789f5cp-22, -0x1.cbbc05b4fa99ap-76}, {0x1.1eed8eff8d898p-29, -0x1.2aec959e14c06p-83},
+        {-0x1.93974a8c07c9dp-37, -0x1.05d6f8a2efd1fp-92}, {0x1.ae7f3e733b81fp-45, 0x1.1d8656b0ee8cbp-101},
+        {-0x1.6827863b97d97p-53, -0x1.eec01221a8b0bp-107}, {0x1.e542ba4020225p-62, 0x1.ea72b4afe3c2fp-120},
+        {-0x1.0ce396db7f853p-70, 0x1.aebcdbd20331cp-124}, {0x1.f2cf01972f578p-80, -0x1.9ada5fcc1ab14p-135},
+        {-0x1.88e85fc6a4e5ap-89, 0x1.71c37ebd16540p-143}};
+    const double P1 = 0x1.921fb54400000p+0, P2 = 0x1.0b4611a600000p-34, P3 = 0x1.3198a2e000000p-69, P3T = 0x1.b839a252049c1p-104;
+    const double k = rint(a * 0x1.45f306dc9c883p-1);
+    dd2 r = dd_two_sum(a - k * P1, -(k * P2));
+    r = dd_add(r, dd2{-(k * P3), -(k * P3T)});
+    const dd2 z = dd_mul(r, r);
+    dd2 ps = dd2{SC[11][0], SC[11][1]};
+    for (int i = 10; i >= 0; --i) ps = dd_add(dd_mul(ps, z), dd2{SC[i][0], SC[i][1]});
+    const dd2 s = dd_add(dd_mul(dd_mul(ps, z), r), r);
+    dd2 pc = dd2{CC[12][0], CC[12][1]};
+    for (int i = 11; i >= 0; --i) pc = dd_add(dd_mul(pc, z), dd2{CC[i][0], CC[i][1]});
+    const dd2 c = dd_add(dd_mul(pc, z), dd2{1.0, 0.0});
+    const int q = (int)k & 3;
+    *sn = q == 0 ? s.hi : (q == 1 ? c.hi : (q == 2 ? -s.hi : -c.hi));
+    *cs = q == 0 ? c.hi : (q == 1 ? -s.hi : (q == 2 ? -c.hi : s.hi));
+}
+
 // ---- counter-based RNG for on-device parameter draws (Philox-4x32-10) -----------------------------------
 __device__ __forceinline__ void philox_round(unsigned& c0, unsigned& c1, unsigned& c2, unsigned& c3, unsigned k0, unsigned k1) {
     const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
@@ -244,7 +303,8 @@ __device__ void aug_prepare_geometry(const PrepArgs& a, int b, float mx, AugRec&
             rot = rot - floor(rot / 360.0) * 360.0;                 // numpy.mod(rot, 360)
             // cv2.getRotationMatrix2D((W//2, H//2), -rot, 1) then the inversion at the top of cv::warpAffine
             double ang = -rot * 3.141592653589793 / 180.;
-            double al = cos(ang), be = sin(ang);
+            double al, be;
+            dpp_sincos_cr(ang, &be, &al);
             double cx = (double)(a.dsz / 2), cy = (double)(a.dsz / 2);
             double F[6] = {al, be, (1 - al) * cx - be * cy, -be, al, be * cx + (1 - al) * cy};
             double D = F[0] * F[4] - F[1] * F[3];
@@ -256,7 +316,7 @@ __device__ void aug_prepare_geometry(const PrepArgs& a, int b, float mx, AugRec&
             r.warp = WARP_AFFINE;
         }
         const double alpha = rot * 3.141592653589793 / 180.;
-        lc.ca = cos(alpha); lc.sa = sin(alpha);
+        dpp_sincos_cr(alpha, &lc.sa, &lc.ca);
     } else if (mode == AUG_SC) {
         const bool one = fabs(sc - 1.0) <= (1e-8 + 1e-5);                  // numpy.allclose(sc, 1.)
         if (!one) {

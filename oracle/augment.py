@@ -90,14 +90,99 @@ class Camera(object):
         return np.stack([self.joint3DToImg(p) for p in pts]).astype(np.float32)
 
 
+# --------------------------------------------------------------------------- correctly rounded cos / sin
+# The reference calls libm: cv2.getRotationMatrix2D -> C cos() / sin(), rotatePoint2D -> numpy.cos / numpy.sin (NumPy 1.x
+# forwards float64 to libm).  On its platform (glibc 2.19: the IBM Accurate Mathematical Library) both are CORRECTLY ROUNDED.
+# Today's numpy.cos (SIMD kernels) and the device's ocml cos are only "< 1 ulp", i.e. each may differ from that value -- and from
+# each other -- in the last bit.  So the oracle computes the correctly rounded value itself, with an algorithm that is plain IEEE
+# arithmetic and therefore reproducible operation for operation on the device (csrc/augment.hip: dpp_sincos_cr): Cody-Waite
+# reduction by pi/2 in three 33-bit parts, Taylor series in double-double (106 bits), result = the high word.  tests/test_oracle.py
+# holds it against mpmath at 400 bits (every tested argument equal; the method can miss a rounding only when the true value lies
+# within 2^-100 of a midpoint between two doubles).
+_SIN_DD = [(float.fromhex(a), float.fromhex(b)) for a, b in (
+    ('-0x1.5555555555555p-3', '-0x1.5555555555555p-57'), ('0x1.1111111111111p-7', '0x1.1111111111111p-63'),
+    ('-0x1.a01a01a01a01ap-13', '-0x1.a01a01a01a01ap-73'), ('0x1.71de3a556c734p-19', '-0x1.c154f8ddc6c00p-73'),
+    ('-0x1.ae64567f544e4p-26', '0x1.c062e06d1f209p-80'), ('0x1.6124613a86d09p-33', '0x1.f28e0cc748ebep-87'),
+    ('-0x1.ae7f3e733b81fp-41', '-0x1.1d8656b0ee8cbp-97'), ('0x1.952c77030ad4ap-49', '0x1.ac981465ddc6cp-103'),
+    ('-0x1.2f49b46814157p-57', '-0x1.2650f61dbdcb4p-112'), ('0x1.71b8ef6dcf572p-66', '-0x1.d043ae40c4647p-120'),
+    ('-0x1.761b41316381ap-75', '0x1.3423c7d91404fp-130'), ('0x1.3f3ccdd165fa9p-84', '-0x1.58ddadf344487p-139'))]
+_COS_DD = [(float.fromhex(a), float.fromhex(b)) for a, b in (
+    ('-0x1.0000000000000p-1', '0x0.0p+0'), ('0x1.5555555555555p-5', '0x1.5555555555555p-59'),
+    ('-0x1.6c16c16c16c17p-10', '0x1.f49f49f49f49fp-65'), ('0x1.a01a01a01a01ap-16', '0x1.a01a01a01a01ap-76'),
+    ('-0x1.27e4fb7789f5cp-22', '-0x1.cbbc05b4fa99ap-76'), ('0x1.1eed8eff8d898p-29', '-0x1.2aec959e14c06p-83'),
+    ('-0x1.93974a8c07c9dp-37', '-0x1.05d6f8a2efd1fp-92'), ('0x1.ae7f3e733b81fp-45', '0x1.1d8656b0ee8cbp-101'),
+    ('-0x1.6827863b97d97p-53', '-0x1.eec01221a8b0bp-107'), ('0x1.e542ba4020225p-62', '0x1.ea72b4afe3c2fp-120'),
+    ('-0x1.0ce396db7f853p-70', '0x1.aebcdbd20331cp-124'), ('0x1.f2cf01972f578p-80', '-0x1.9ada5fcc1ab14p-135'),
+    ('-0x1.88e85fc6a4e5ap-89', '0x1.71c37ebd16540p-143'))]
+_PIO2 = tuple(float.fromhex(h) for h in ('0x1.921fb54400000p+0', '0x1.0b4611a600000p-34', '0x1.3198a2e000000p-69', '0x1.b839a252049c1p-104'))
+_TWO_OVER_PI = float.fromhex('0x1.45f306dc9c883p-1')
+
+
+def _two_sum(a, b):
+    s = a + b
+    bb = s - a
+    return s, (a - (s - bb)) + (b - bb)
+
+
+def _fast_two_sum(a, b):          # |a| >= |b|
+    s = a + b
+    return s, b - (s - a)
+
+
+def _two_prod(a, b):
+    """p + e == a * b exactly (Dekker's splitting; the device gets the same pair from one fma)."""
+    p = a * b
+    t = 134217729.0 * a
+    ah = t - (t - a)
+    al = a - ah
+    t = 134217729.0 * b
+    bh = t - (t - b)
+    bl = b - bh
+    return p, ((ah * bh - p) + ah * bl + al * bh) + al * bl
+
+
+def _dd_mul(x, y):
+    p, e = _two_prod(x[0], y[0])
+    e = e + (x[0] * y[1] + x[1] * y[0])
+    return _fast_two_sum(p, e)
+
+
+def _dd_add(x, y):
+    s, e = _two_sum(x[0], y[0])
+    e = e + (x[1] + y[1])
+    return _fast_two_sum(s, e)
+
+
+def sincos_cr(a):
+    """(sin(a), cos(a)) of the float64 `a`, |a| < 8, correctly rounded (see above)."""
+    a = float(a)
+    k = float(np.rint(a * _TWO_OVER_PI))                  # round half to even, like rint() on the device
+    # r = a - k * pi/2 as a double-double: k * (33-bit part) is exact, and so is the first difference
+    r = _two_sum(a - k * _PIO2[0], -(k * _PIO2[1]))
+    r = _dd_add(r, (-(k * _PIO2[2]), -(k * _PIO2[3])))
+    z = _dd_mul(r, r)
+    ps = _SIN_DD[-1]
+    for c in _SIN_DD[-2::-1]:
+        ps = _dd_add(_dd_mul(ps, z), c)
+    s = _dd_add(_dd_mul(_dd_mul(ps, z), r), r)             # r + r * z * P(z)
+    pc = _COS_DD[-1]
+    for c in _COS_DD[-2::-1]:
+        pc = _dd_add(_dd_mul(pc, z), c)
+    c = _dd_add(_dd_mul(pc, z), (1.0, 0.0))                # 1 + z * Q(z)
+    q = int(k) & 3
+    s, c = s[0], c[0]
+    return ((s, c), (c, -s), (-s, -c), (-c, s))[q]
+
+
 def rotate_point_2d(p1, center, angle):
     """rotatePoint2D, transformations.py:71-88 (angle in degrees, keeps the dtype of p1)."""
     alpha = angle * np.pi / 180.
     pp = p1.copy()
     pp[0:2] -= center[0:2]
     pr = np.zeros_like(pp)
-    pr[0] = pp[0] * np.cos(alpha) - pp[1] * np.sin(alpha)
-    pr[1] = pp[0] * np.sin(alpha) + pp[1] * np.cos(alpha)
+    sa, ca = sincos_cr(alpha)
+    pr[0] = pp[0] * ca - pp[1] * sa
+    pr[1] = pp[0] * sa + pp[1] * ca
     pr[2] = pp[2]
     pr[0:2] += center[0:2]
     return pr
@@ -145,8 +230,9 @@ def com_to_transform(com, size, fx, fy, dsize=(128, 128)):
 def rotation_matrix_2d(center, angle_deg, scale=1.0):
     """cv2.getRotationMatrix2D (center is a Point2f)."""
     a = angle_deg * np.pi / 180.
-    alpha = np.cos(a) * scale
-    beta = np.sin(a) * scale
+    sa, ca = sincos_cr(a)
+    alpha = ca * scale
+    beta = sa * scale
     cx, cy = float(np.float32(center[0])), float(np.float32(center[1]))
     return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy],
                      [-beta, alpha, beta * cx + (1 - alpha) * cy]], dtype=np.float64)

@@ -1,7 +1,7 @@
 """Fused augmentation kernels vs the oracle's restatement of augmentCrop / moveCoM / rotateHand / scaleHand on
 explicit per-sample (mode, off, rot, sc).  Pixels: bit-exact (both sides evaluate the same IEEE-double coordinate
-arithmetic without FMA contraction); 'rot' may differ on a handful of pixels whose coordinate sits on a rounding
-boundary if the device cos/sin differ from libm by an ulp.  Labels: 1e-6 (f32 storage)."""
+arithmetic without FMA contraction), rotations included: the rotation coefficients are the correctly rounded cos / sin on both
+sides (oracle.augment.sincos_cr == csrc/augment.hip dpp_sincos_cr, operation for operation).  Labels: 1e-6 (f32 storage)."""
 import numpy as np
 import pytest
 
@@ -56,7 +56,7 @@ def test_augment_matches_oracle(backend, camname):
         ref, lab, *_ = A.augment_crop(imgs[i].copy(), gts[i].copy(), com2d, cubes[i], Ms[i], names[i], offs[i], rots[i], scs[i],
                                       cam, abs(cam.fx), abs(cam.fy))
         nbad = int((out[i] != ref).sum())
-        assert nbad <= (6 if names[i] == 'rot' else 0), (i, names[i], nbad)
+        assert nbad == 0, (i, names[i], nbad)
         yref = A.pca_transform(lab.astype('f8'), mean.astype('f8'), comp.astype('f8'))[0]
         np.testing.assert_allclose(out_y[i], yref, rtol=0, atol=2e-6 * max(1.0, np.abs(yref).max()))
     # the warps really moved pixels (guards against a degenerate pass)
@@ -209,7 +209,7 @@ def test_augment_norm_zero_one(backend):
         ref, lab, *_ = A.augment_crop(imgs01[i].copy(), gts[i].copy(), cam.joint3DToImg(coms[i]), cubes[i], Ms[i], names[i], offs[i],
                                       rots[i], scs[i], cam, abs(cam.fx), abs(cam.fy), normZeroOne=True)
         nbad = int((out[i] != ref).sum())
-        assert nbad <= (6 if names[i] == 'rot' else 0), (i, names[i], nbad)
+        assert nbad == 0, (i, names[i], nbad)
         assert out[i].min() >= 0.0 and out[i].max() <= 1.0 + 1e-6
         np.testing.assert_allclose(out_y[i].reshape(J, 3), lab, rtol=0, atol=2e-6)
 
@@ -269,3 +269,38 @@ def test_fused_augment_equals_two_stage_and_advances_counter(backend):
         rt.synchronize()
         np.testing.assert_array_equal(xo.get(), x0[lo:lo + n])
         np.testing.assert_array_equal(yo.get(), y0[lo:lo + n])
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_rotation_coefficients_are_the_correctly_rounded_ones(backend):
+    """rot mode over many angles (special ones included): the inverse affine map the device stores in its per-sample record
+    (six float64) equals the oracle's invert_affine(getRotationMatrix2D) BIT FOR BIT -- cos / sin included, which the device
+    evaluates with its own correctly rounded routine, not ocml's -- and so does every pixel of every rotated crop."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(77)
+    cam = A.Camera.nyu()
+    J, B = 14, 48
+    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, B, cam, cube=(300.,) * 3, joints=J)
+    rots = rng.uniform(-180, 180, B)
+    rots[:12] = [90., -90., 180., -180., 45., 135., 1e-3, -1e-3, 30., 60., 179.999999, 0.5]
+    offs, scs = np.zeros((B, 3)), np.ones(B)
+    f32 = lambda a: rt.upload(np.asarray(a, np.float32))          # noqa: E731
+    nrec = rt.lib.dpp_augment_record_bytes()
+    rec = rt.alloc(B * nrec, np.uint8)
+    out_y, out = rt.alloc((B, J * 3), zero=False), rt.alloc((B, 128, 128), zero=False)
+    img = f32(imgs)
+    ops.augment_prepare(rt, img, f32(coms), f32(cubes), f32(Ms.reshape(B, 9)), f32(gts), B, J, 128, (cam.fx, cam.fy, cam.ux, cam.uy, cam.flip_y),
+                        rec, out_y, mode=rt.upload(np.full(B, MODES['rot'], np.int32)), off=rt.upload(offs), rot=rt.upload(rots),
+                        sc=rt.upload(scs))(rt.stream)
+    ops.augment_warp(rt, img, rec, B, 128, out)(rt.stream)
+    rt.synchronize()
+    m = rec.get().reshape(B, nrec)[:, :72].copy().view(np.float64).reshape(B, 9)      # AugRec.m leads the record
+    got, lab = out.get(), out_y.get().reshape(B, J, 3)
+    for i in range(B):
+        r = np.mod(rots[i], 360)
+        want = A.invert_affine(A.rotation_matrix_2d((64, 64), -r, 1))
+        assert np.array_equal(m[i, :6], want), (i, rots[i], m[i, :6], want)
+        ref, rlab, *_ = A.augment_crop(imgs[i].copy(), gts[i].copy(), cam.joint3DToImg(coms[i]), cubes[i], Ms[i], 'rot', offs[i], rots[i], 1.,
+                                       cam, abs(cam.fx), abs(cam.fy))
+        assert np.array_equal(got[i], ref), (i, rots[i], int((got[i] != ref).sum()))
+        np.testing.assert_allclose(lab[i], rlab, rtol=0, atol=2e-6)

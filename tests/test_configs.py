@@ -47,7 +47,7 @@ def _augment_and_step(rt, cam, cube, J, B, names_cycle, seed, sample0=0, global_
         ref, lab, *_ = A.augment_crop(imgs[i].copy(), gts[i].copy(), cam.joint3DToImg(coms[i]), cubes[i], Ms[i], names[i], offs[i], rots[i], scs[i],
                                       cam, abs(cam.fx), abs(cam.fy))
         nbad = int((out[i] != ref).sum())
-        assert nbad <= (6 if names[i] == 'rot' else 0), (i, names[i], nbad)
+        assert nbad == 0, (i, names[i], nbad)
         yref = A.pca_transform(lab.astype('f8'), mean.astype('f8'), comp.astype('f8'))[0]
         np.testing.assert_allclose(out_y[i], yref, rtol=0, atol=2e-6 * max(1.0, np.abs(yref).max()))
         xs[i, 0], ys[i] = out[i], out_y[i]

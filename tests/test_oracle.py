@@ -435,3 +435,21 @@ def test_netbase_load_reads_a_python2_cpickle_checkpoint(tmp_path):
     l0.W.set_value(np.zeros((8, 1, 5, 5), np.float32))
     net.load(out)
     np.testing.assert_array_equal(l0.W.get_value().astype(np.float64).ravel(), np.asarray(want['arrays']['0-values'][0]['data']))
+
+
+def test_sincos_cr_is_correctly_rounded():
+    """oracle.augment.sincos_cr against mpmath at 400 bits: the rotation coefficients of rotateHand / rotatePoint2D are what the
+    reference's libm (glibc 2.19, correctly rounded) returned -- not today's `< 1 ulp` numpy.cos, which differs in the last bit on a
+    fraction of a percent of the arguments."""
+    mpmath = pytest.importorskip('mpmath')
+    from oracle import augment as A
+    mpmath.mp.prec = 400
+    rng = np.random.RandomState(0)
+    vals = list(rng.uniform(-2 * np.pi, 2 * np.pi, 4000)) + [-d * np.pi / 180. for d in range(0, 360)] + \
+        [d * np.pi / 180. for d in np.arange(0, 360, 0.5)] + [0.0, 1e-300, -1e-8, 1e-8, 7.9, -7.9]
+    off_by_ulp = 0
+    for a in vals:
+        s, c = A.sincos_cr(a)
+        assert s == float(mpmath.sin(mpmath.mpf(a))) and c == float(mpmath.cos(mpmath.mpf(a))), a
+        off_by_ulp += int(np.sin(a) != s or np.cos(a) != c)
+    assert off_by_ulp < 0.02 * len(vals)                        # libm / NumPy agree almost everywhere: it is the same function
