@@ -14,6 +14,10 @@ RANK / WORLD_SIZE in the environment; started plainly (`python bench.py --gpus 4
 rank processes its own 128-crop shard of the global minibatch (weak scaling), the flat fp32 gradient buffer is all-reduced
 (sum of per-shard partial gradients of the global-batch cost) between backward and the replicated ADAM.
 
+`--workload cascade` (with `--size 256 [--dtype bf16]`) is BASELINE.json configs[4] on this GPU: every step cuts its minibatch out of
+640x480 depth frames through the CoM-refinement cascade (crop -> centre of mass -> ScaleNet -> crop, hipdp/cascade.py) and trains the
+256x256 ResNet on it -- one plan per step.
+
 Prints ONE JSON line (rank 0).  `roofline` describes the kernel family with the largest share of the step time,
 timed live with HIP events on the launch stream; `cpu_baseline` times the oracle's PyTorch-CPU restatement of the same
 train step on the host cores (reported only).
@@ -39,19 +43,27 @@ PEAK_MFMA_BF16 = 2.5e15        # dense
 PEAK_HBM = 8.0e12
 
 
-def synthetic_db(n, size, J=14, seed=23455):
-    """Device-resident training set: normalised crops + the per-sample geometry augmentCrop needs (NYU camera)."""
-    from oracle import augment as A
-    rng = np.random.RandomState(seed)
-    cam = A.Camera.nyu()
-    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, n, cam, cube=(300., 300., 300.), joints=J, dsize=size)
-    pca_mean = rng.normal(0, 0.05, J * 3).astype(np.float32)
-    q, _ = np.linalg.qr(rng.normal(size=(J * 3, 30)))
-    return cam, imgs, coms, cubes, Ms, gts, pca_mean, q.T.astype(np.float32)
+def csrc_sha16():
+    """Fingerprint of the kernel sources: rocprofv3 counter files under profiles/ record it, and `roofline.traffic` is only taken
+    from a file measured on THESE sources."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'deep-prior-pp_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'deep-prior-pp_amd', 'csrc', '*.h'))):
+        with open(fn, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
-def cpu_baseline(batch, size, budget_s=12.0):
-    """The oracle's PyTorch-CPU restatement of the identical fp32 train step, bounded sample."""
+# environment variables that select a measured configuration through a command-line flag of this script (recorded in `config` by
+# that flag) or plumbing; every other DPP_* variable is an experiment / opt-in knob and is stamped into config.knobs
+PLUMBING_ENV = ('DPP_LAUNCH_MODE', 'DPP_BF16', 'DPP_DIST_BACKEND', 'DPP_BENCH_EMU', 'DPP_TEST_WORKERS')
+ABLATION_ENV = ('DPP_WHATIF_SKIP',)            # drops launches from the timed plan: results are wrong on purpose
+
+
+def cpu_baseline(batch, size, budget_s=45.0):
+    """The oracle's PyTorch-CPU restatement of the identical fp32 train step, bounded sample: one warm-up
+    step, then at least 5 timed steps (more while the budget lasts, 12 at most).  The only place this script touches oracle/."""
     import torch
     from oracle import nets, torch_ref
     onet = nets.build_resnet(type=0, wIn=size, hIn=size, batchSize=batch, numJoints=1, nDims=30)
@@ -62,7 +74,7 @@ def cpu_baseline(batch, size, budget_s=12.0):
     y = torch.tensor(rng.normal(0, 0.3, (batch, 30)).astype(np.float32))
     tr.step(x, y, 1e-3)                      # warm-up (thread pools, allocator)
     t0, n = time.time(), 0
-    while n < 1 or (time.time() - t0 < budget_s and n < 8):
+    while n < 5 or (time.time() - t0 < budget_s and n < 12):
         tr.step(x, y, 1e-3)
         n += 1
     dt = (time.time() - t0) / n
@@ -108,7 +120,19 @@ def main():
                     help='native = the step is one C call that issues every launch on two HIP streams (default); python = one '
                          'ctypes call per launch; graph / graph1 = explicit hipGraph with two lanes / one chain')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-kernel-family time table to stderr')
+    ap.add_argument('--workload', choices=['train', 'cascade'], default='train',
+                    help="train (default): BASELINE configs[1]; cascade: configs[4] on this GPU -- every step crops its minibatch from "
+                         "640x480 frames through the CoM-refinement cascade (crop -> CoM -> ScaleNet -> crop at --size) and trains the "
+                         "ResNet on it (use with --size 256 [--dtype bf16])")
+    ap.add_argument('--allow-ablation', action='store_true',
+                    help='run although an ablation variable (DPP_WHATIF_SKIP) is set: the timed plan then misses launches and its '
+                         'results are wrong; tools/whatif.sh only')
     args = ap.parse_args()
+    ablation = sorted(k for k in ABLATION_ENV if os.environ.get(k))
+    if ablation and not args.allow_ablation:
+        raise SystemExit('bench.py: %s is set -- an ablation that drops launches from the timed plan; refusing to report a number '
+                         '(pass --allow-ablation for tools/whatif.sh)' % ', '.join(ablation))
+    knobs = {k: v for k, v in sorted(os.environ.items()) if k.startswith('DPP_') and k not in PLUMBING_ENV}
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(args.gpus)
@@ -149,35 +173,64 @@ def main():
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), dp=dp)
 
     # ---- device-resident data: rank r owns samples [r*NDB, (r+1)*NDB) of the global set ----
+    from hipdp.augmenter import camera_tuple
+    from tools import synth
     NDB, J = (8 if not emu else 2) * B, 14
-    cam, imgs, coms, cubes, Ms, gts, pca_mean, pca_comp = synthetic_db(NDB, S, J, seed=23455 + rank)
     f32 = lambda a: rt.upload(np.ascontiguousarray(a, np.float32))       # noqa: E731
-    db = dict(img=f32(imgs), com=f32(coms), cube=f32(cubes), M=f32(Ms.reshape(NDB, 9)), gt=f32(gts))
-    pm, pc = f32(pca_mean), f32(pca_comp)
-    table = rt.upload(np.array([1, 2, 0], np.int32))                     # aug_modes = ['com', 'rot', 'none']
-    camt = (cam.fx, cam.fy, cam.ux, cam.uy, cam.flip_y)
     x_out = eng.x_in.buf.reshape(B, S, S)
     nsl = NDB // B
-
-    def slice_views(sl):
-        o = sl * B
-        return (db['img'].view(o * S * S, (B, S, S)), db['com'].view(o * 3, (B, 3)), db['cube'].view(o * 3, (B, 3)),
-                db['M'].view(o * 9, (B, 9)), db['gt'].view(o * J * 3, (B, J, 3)))
-
-    # device-resident draw counter of the augmentation RNG: draws are keyed by (seed, step, GLOBAL sample index), so what a
-    # sample gets does not depend on how many GPUs the global minibatch is spread over
-    aug = ops.AugmentState(rt, B, seed=1234, sample0=rank * B, global_batch=world * B)
     step_plans = {}
     aug_plans = {}
-    for sl in range(nsl):
-        im, co, cu, mm, gt = slice_views(sl)
-        p = ops.Plan('augment')
-        if args.no_augment:
-            p.add(ops.copy2d(rt, im.reshape(B * S * S), S * S, x_out.reshape(B * S * S), S * S, B, S * S, name='load_crops'))
-        else:
-            for o in aug.ops(im, co, cu, mm, gt, J, S, camt, x_out, eng.y_in, mode_table=table, n_modes=3, pca_mean=pm, pca_comp=pc, E=30):
-                p.add(o)
-        aug_plans[sl] = p
+    if args.workload == 'cascade':
+        # config 5: the minibatch of every step comes out of the refinement cascade (hipdp/cascade.py): 128 frames of 640x480 ->
+        # docom crop -> ScaleNet (3 scales, deterministic) -> refined centre -> crop at SxS + 30-D labels, then the train step
+        from hipdp.cascade import CascadeCropper
+        from net.scalenet import ScaleNet, ScaleNetParams
+        di = synth.importer_of('nyu')
+        H, W = (480, 640) if not emu else (120, 160)
+        frames, coms0, gt3d = synth.depth_frames(np.random.RandomState(23455 + rank), NDB, di, H, W, (300., 300., 300.), J)
+        rnet = ScaleNet(np.random.RandomState(23455), cfgParams=ScaleNetParams(type=1, nChan=1, wIn=128, hIn=128, batchSize=B, resizeFactor=2,
+                                                                             numJoints=1, nDims=3))
+        rnet.setDeterministic()
+        rng = np.random.RandomState(99)
+
+        class Proj(object):
+            mean_ = rng.normal(0, 0.05, J * 3)
+            components_ = np.linalg.qr(rng.normal(size=(J * 3, 30)))[0].T
+
+        pca_comp = np.asarray(Proj.components_, np.float32)
+        db = dict(frames=f32(frames), com=f32(coms0), cube=f32(np.tile(np.float32((300., 300., 300.)), (NDB, 1))), gt=f32(gt3d))
+        imgs = None
+        for sl in range(nsl):
+            o = sl * B
+            cc = CascadeCropper(rt, di, rnet, B, H, W, dsize=S, frames=db['frames'].view(o * H * W, (B, H, W)), coms=db['com'].view(o * 3, (B, 3)),
+                                cubes=db['cube'].view(o * 3, (B, 3)), out=x_out, gt3d=db['gt'].view(o * J * 3, (B, J, 3)), J=J, proj=Proj,
+                                out_y=eng.y_in)
+            aug_plans[sl] = cc.plan
+    else:
+        di, imgs, coms, cubes, Ms, gts, pca_mean, pca_comp = synth.crop_db(NDB, S, J, seed=23455 + rank)
+        db = dict(img=f32(imgs), com=f32(coms), cube=f32(cubes), M=f32(Ms.reshape(NDB, 9)), gt=f32(gts))
+        pm, pc = f32(pca_mean), f32(pca_comp)
+        table = rt.upload(np.array([1, 2, 0], np.int32))                     # aug_modes = ['com', 'rot', 'none']
+        camt = camera_tuple(di)
+
+        def slice_views(sl):
+            o = sl * B
+            return (db['img'].view(o * S * S, (B, S, S)), db['com'].view(o * 3, (B, 3)), db['cube'].view(o * 3, (B, 3)),
+                    db['M'].view(o * 9, (B, 9)), db['gt'].view(o * J * 3, (B, J, 3)))
+
+        # device-resident draw counter of the augmentation RNG: draws are keyed by (seed, step, GLOBAL sample index), so what a
+        # sample gets does not depend on how many GPUs the global minibatch is spread over
+        aug = ops.AugmentState(rt, B, seed=1234, sample0=rank * B, global_batch=world * B)
+        for sl in range(nsl):
+            im, co, cu, mm, gt = slice_views(sl)
+            p = ops.Plan('augment')
+            if args.no_augment:
+                p.add(ops.copy2d(rt, im.reshape(B * S * S), S * S, x_out.reshape(B * S * S), S * S, B, S * S, name='load_crops'))
+            else:
+                for o in aug.ops(im, co, cu, mm, gt, J, S, camt, x_out, eng.y_in, mode_table=table, n_modes=3, pca_mean=pm, pca_comp=pc, E=30):
+                    p.add(o)
+            aug_plans[sl] = p
     # Step i trains on slice i % nsl.  Pipelined (default): its minibatch was augmented into x_in / y_in by step i - 1, on the gradient
     # branch under that step's ADAM update (engine.step_plan(prefetch=)), and step i does the same for slice i + 1 -- the reference's
     # background augmentation workers (nettrainer.py:601-628) as one kernel on an idle stream; every step still launches exactly one
@@ -190,7 +243,7 @@ def main():
             step_plans[sl] = (aug_plans[sl], eng.step_plan(before=aug_plans[sl]))
     if pipelined:
         aug_plans[0].run(rt)              # the minibatch of the first step
-    if args.no_augment:
+    if args.no_augment and args.workload == 'train':
         eng.y_in.set(np.random.RandomState(5).normal(0, 0.3, (B, 30)).astype(np.float32))
     eng.set_lr(1e-3)
 
@@ -269,21 +322,25 @@ def main():
                 ach = dom['bytes'] / dom['n'] / per_launch_t / 1e9
                 roof = dict(bound='hbm', kernel=dom_name, achieved=round(ach, 1), peak=PEAK_HBM / 1e9, unit='GB/s',
                             frac=round(ach * 1e9 / PEAK_HBM, 4), traffic=None)
-            # HBM bytes per launch of that kernel family from the PMC counters: they cannot be read inside this process, so
-            # the number is the one measured with rocprofv3 --pmc on this workload (separate FETCH_SIZE / WRITE_SIZE passes,
-            # tools/pmc_summary.py); the file records the commit it was measured at
-            pmc_family = {'gemm_mfma_f32': ('gemm_kernel', 'gemm_ksplit_kernel', 'gemm_stream16_kernel', 'gemm_rowstream_kernel', 'fc_stream_kernel', 'fc_gemm_kernel'),
+            # HBM bytes per launch of that kernel family from the PMC counters: they cannot be read inside this process, so the number
+            # is the one measured with rocprofv3 --pmc on this workload (separate FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py).
+            # The file records the fingerprint of the kernel sources it was measured on (`_csrc_sha16`); it is used only when that is the
+            # fingerprint of the sources this run was built from -- otherwise `traffic` stays null (stale counters are not evidence).
+            pmc_family = {'gemm_mfma_f32': ('gemm_kernel', 'gemm_ksplit_kernel', 'gemm_stream16_kernel', 'gemm_rowstream_kernel', 'fc_stream_kernel',
+                                            'fc_gemm_kernel', 'wgrad_stream_kernel'),
                           'conv3x3_mfma_f32': ('conv3x3_kernel',), 'bn_bwd_apply': ('bn_bwd_apply_kernel',), 'adam': ('adam_kernel',)}.get(dom_name, ())
-            for fn in ('r02_hbm_traffic.json', 'r01_hbm_traffic.json'):
+            sha = csrc_sha16()
+            import glob
+            for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic.json')), reverse=True):
                 try:
-                    with open(os.path.join(ROOT, 'profiles', fn)) as fh:
+                    with open(fn) as fh:
                         pj = json.load(fh)
                     ks = [k for k in pmc_family if k in pj]
-                    if B == 128 and S == 128 and args.dtype == 'f32' and ks:
+                    if pj.get('_csrc_sha16') == sha and B == 128 and S == 128 and args.dtype == 'f32' and args.workload == 'train' and ks:
                         # launch-weighted mean over the kernels the family's launches run on
                         nl = sum(pj[k]['launches_per_step'] for k in ks)
                         roof['traffic'] = round(sum(pj[k]['bytes_per_launch'] * pj[k]['launches_per_step'] for k in ks) / nl)
-                        roof['traffic_source'] = 'profiles/' + fn.replace('.json', '.txt')
+                        roof['traffic_source'] = 'profiles/' + os.path.basename(fn).replace('.json', '.txt') + ' (kernel sources ' + sha + ')'
                         break
                 except (OSError, ValueError):
                     pass
@@ -296,25 +353,29 @@ def main():
         res = dict(metric='depth-crops/sec (NYU ResNet50 bs128) 1/2/4/8 GPU; mean 3D joint err (mm)', value=round(value, 1),
                    unit='depth-crops/sec', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3),
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
-                   config=dict(workload='NYU posereg_embedding ResNet (type 0, 30-D PCA prior) train step: fused augment + fwd + bwd + ADAM, '
-                                        'bs%d/GPU %s, %dx%dx1 crops' % (B, 'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands (FC1, 3x3) / fp32 accumulate', S, S),
+                   config=dict(workload=('NYU posereg_embedding ResNet (type 0, 30-D PCA prior) train step: fused augment + fwd + bwd + ADAM, '
+                                         'bs%d/GPU %s, %dx%dx1 crops' if args.workload == 'train' else
+                                         'NYU com_refine + posereg cascade: per step %d frames of 640x480 -> crop -> CoM -> ScaleNet refinement -> '
+                                         'crop + 30-D labels, then the ResNet (type 0) train step fwd + bwd + ADAM, %s, %dx%dx1 crops')
+                               % (B, 'fp32' if args.dtype == 'f32' else 'bf16 MFMA operands / fp32 accumulate', S, S),
                                global_batch=world * B, parallelism='dp%d' % world, augment=not args.no_augment, augment_pipelined=pipelined,
                                bn='sync (global batch statistics)' if (world > 1 and args.sync_bn) else 'local per-GPU batch statistics',
                                launches=eng.num_launches(), launch_mode=ops.LAUNCH_MODE,
-                               step_mfma_frac=round(value / world * flop / PEAK_MFMA_F32, 4), final_cost=round(cost, 5)),
+                               step_mfma_frac=round(value / world * flop / PEAK_MFMA_F32, 4), final_cost=round(cost, 5),
+                               knobs=knobs or None, ablation=ablation or None, kernel_sources=csrc_sha16()),
                    roofline=roof)
         if args.dtype == 'bf16':
             # forward error of the bf16 path against the fp32 path on the SAME (just trained) weights, deterministic mode:
             # embedding difference pushed through the PCA prior to joints, in mm of the 300 mm cube (SURVEY.md section 8(d) cfg 5:
             # "parity reported vs fp32, not vs the 1e-3 mm bar")
-            xb = np.ascontiguousarray(imgs[:B].reshape(B, 1, S, S), np.float32)
+            xb = np.ascontiguousarray((imgs[:B] if imgs is not None else eng.x_in.buf.get()).reshape(B, 1, S, S), np.float32)
             o32 = engine.CompiledNet(net, train=False, runtime=rt, bf16=False).forward(xb)
             o16 = engine.CompiledNet(net, train=False, runtime=rt, bf16=True).forward(xb)
             dj = (o16.astype(np.float64) - o32.astype(np.float64)) @ pca_comp.astype(np.float64)
             res['config']['bf16_forward_error_mm_vs_fp32'] = dict(max=round(float(np.abs(dj).max() * 150.0), 4),
                                                                    mean=round(float(np.abs(dj).mean() * 150.0), 4),
                                                                    relative_to_output=round(float(np.abs(o16 - o32).max() / max(1e-30, np.abs(o32).max())), 5))
-        if world == 1 and not args.no_cpu_baseline and not emu:
+        if world == 1 and not args.no_cpu_baseline and not emu and args.workload == 'train':
             res['cpu_baseline'] = cpu_baseline(B, S)
         print(json.dumps(res))
         sys.stdout.flush()

@@ -555,8 +555,8 @@ struct CropRec {
 
 __global__ __launch_bounds__(DPP_THREADS) void crop_prepare_kernel(const float* __restrict__ frames, int H, int W,
                                                                    const float* __restrict__ com, const float* __restrict__ cube,
-                                                                   double fx, double fy, int dsz, CropRec* __restrict__ rec,
-                                                                   float* __restrict__ M_out) {
+                                                                   double fx, double fy, int dsz, int stretch,
+                                                                   CropRec* __restrict__ rec, float* __restrict__ M_out) {
     __shared__ float s_mn[DPP_THREADS / DPP_WAVE], s_mx[DPP_THREADS / DPP_WAVE];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* f = frames + (size_t)b * H * W;
@@ -598,6 +598,7 @@ __global__ __launch_bounds__(DPP_THREADS) void crop_prepare_kernel(const float* 
     long long sz0, sz1;                                         // (width, height) of the resized crop
     if (wb > hb) { sz0 = dsz; sz1 = floordiv((long long)hb * dsz, wb); }
     else { sz0 = floordiv((long long)wb * dsz, hb); sz1 = dsz; }
+    if (stretch) { sz0 = dsz; sz1 = dsz; }                      // resizeCrop(cropped, dsize): the refinement net's input, handdetector.py:430
     r.szw = (int)sz0; r.szh = (int)sz1;
     const double sc = (hb > wb) ? (double)sz1 / (double)hb : (double)sz0 / (double)wb;     // cropped.shape = (hb, wb)
     r.ifx = 1. / ((double)sz0 / (double)wb);
@@ -689,6 +690,59 @@ __global__ __launch_bounds__(DPP_THREADS) void crop_warp_kernel(const float* __r
     out[(size_t)b * dsz * dsz + p] = v;
 }
 
+// The CoM-refinement step of cropArea3D(docom=True) with a refineNet (handdetector.py:429-440, refineCoM :634-676), batched:
+//   newCom3D = net_out * (cube_z / 2) + jointImgTo3D(com);  com' = joint3DToImg(newCom3D);
+//   allclose(com', 0) -> com'_z = centre pixel of the (re-centred) crop window
+// one workgroup per frame.  With gt3d_orig it also forms what the importers keep per frame for the NEXT crop (importers.py:388-392,
+// dataset.py:103): gt3Dcrop = gt3Dorig - jointImgTo3D(com') and the training label gt3Dcrop / (cube_z / 2), optionally projected
+// onto the PCA prior (poseregnettrainer.py:262) -- so that a refine -> re-crop -> regress cascade needs no host step.
+__global__ __launch_bounds__(DPP_THREADS) void crop_refine_kernel(const float* __restrict__ frames, int H, int W,
+                                                                  const CropRec* __restrict__ rec, const float* __restrict__ com_in,
+                                                                  const float* __restrict__ cube, const float* __restrict__ net_out,
+                                                                  AugCam cam, const float* __restrict__ gt3d_orig, int J,
+                                                                  const float* __restrict__ pca_mean, const float* __restrict__ pca_comp,
+                                                                  int E, float* __restrict__ com_out, float* __restrict__ com3d_out,
+                                                                  float* __restrict__ gt3d_crop, float* __restrict__ out_y) {
+    __shared__ float s_c3[3];
+    __shared__ float s_label[MAXJ3];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        const float half = (float)((double)cube[b * 3 + 2] / 2.);              // size[2] / 2. as a floatX constant
+        float c3[3], n3[3], c2[3];
+        to3d(cam, com_in[b * 3], com_in[b * 3 + 1], com_in[b * 3 + 2], c3);
+        for (int d = 0; d < 3; ++d) n3[d] = net_out[b * 3 + d] * half + c3[d];   // float32 arrays: two roundings
+        toimg(cam, n3[0], n3[1], n3[2], true, c2);
+        if (fabs((double)c2[0]) <= 1e-8 && fabs((double)c2[1]) <= 1e-8 && fabs((double)c2[2]) <= 1e-8) {
+            const CropRec r = rec[b];
+            c2[2] = crop_window_value(frames + (size_t)b * H * W, H, W, r, r.cw / 2, r.ch / 2);
+        }
+        for (int d = 0; d < 3; ++d) com_out[b * 3 + d] = c2[d];
+        float q3[3];
+        to3d(cam, c2[0], c2[1], c2[2], q3);
+        for (int d = 0; d < 3; ++d) { s_c3[d] = q3[d]; if (com3d_out) com3d_out[b * 3 + d] = q3[d]; }
+    }
+    if (gt3d_orig == nullptr) return;
+    __syncthreads();
+    const float half = (float)((double)cube[b * 3 + 2] / 2.);
+    for (int i = tid; i < J * 3; i += DPP_THREADS) {
+        const float g = gt3d_orig[(size_t)b * J * 3 + i] - s_c3[i % 3];
+        if (gt3d_crop) gt3d_crop[(size_t)b * J * 3 + i] = g;
+        s_label[i] = g / half;
+    }
+    __syncthreads();
+    if (out_y == nullptr) return;
+    const int D = J * 3;
+    if (pca_comp) {
+        for (int e = tid; e < E; e += DPP_THREADS) {
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) s += ((double)s_label[d] - (double)pca_mean[d]) * (double)pca_comp[(size_t)e * D + d];
+            out_y[(size_t)b * E + e] = (float)s;
+        }
+    } else {
+        for (int d = tid; d < D; d += DPP_THREADS) out_y[(size_t)b * D + d] = s_label[d];
+    }
+}
+
 }  // namespace
 
 extern "C" size_t dpp_augment_record_bytes(void) { return sizeof(AugRec); }
@@ -772,10 +826,10 @@ extern "C" int dpp_augment_warp(const float* img, const void* records, int B, in
 extern "C" size_t dpp_crop_record_bytes(void) { return sizeof(CropRec); }
 
 extern "C" int dpp_crop_prepare(const float* frames, int B, int H, int W, const float* com, const float* cube, double fx, double fy,
-                                int dsz, void* records, float* M_out, dpp_stream_t stream) {
+                                int dsz, int stretch, void* records, float* M_out, dpp_stream_t stream) {
     if (!frames || !com || !cube || !records || B < 1 || H < 1 || W < 1 || dsz < 1 || fx == 0.0 || fy == 0.0) return DPP_E_BADARG;
     DPP_LAUNCH(crop_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W, com, cube,
-                       fabs(fx), fabs(fy), dsz, static_cast<CropRec*>(records), M_out);
+                       fabs(fx), fabs(fy), dsz, stretch, static_cast<CropRec*>(records), M_out);
     return dpp_launch_status();
 }
 
@@ -792,5 +846,21 @@ extern "C" int dpp_crop_com(const float* frames, const void* records, int B, int
     if (!frames || !records || !com_out || B < 1 || H < 1 || W < 1) return DPP_E_BADARG;
     DPP_LAUNCH(crop_com_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W,
                        static_cast<const CropRec*>(records), com_out);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_crop_refine(const float* frames, const void* records, int B, int H, int W, const float* com_in, const float* cube,
+                               const float* net_out, double fx, double fy, double ux, double uy, int flip_y, const float* gt3d_orig, int J,
+                               const float* pca_mean, const float* pca_comp, int E, float* com_out, float* com3d_out, float* gt3d_crop,
+                               float* out_y, dpp_stream_t stream) {
+    if (!frames || !records || !com_in || !cube || !net_out || !com_out || B < 1 || H < 1 || W < 1 || fx == 0.0 || fy == 0.0) return DPP_E_BADARG;
+    if (gt3d_orig && (J < 1 || J * 3 > MAXJ3)) return DPP_E_BADARG;
+    if ((gt3d_crop || out_y) && !gt3d_orig) return DPP_E_BADARG;
+    if (pca_comp && (!pca_mean || E < 1)) return DPP_E_BADARG;
+    AugCam cam;
+    cam.fx = fx; cam.fy = fy; cam.ux = ux; cam.uy = uy; cam.flip_y = flip_y;
+    DPP_LAUNCH(crop_refine_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W,
+               static_cast<const CropRec*>(records), com_in, cube, net_out, cam, gt3d_orig, J, pca_mean, pca_comp, E, com_out, com3d_out,
+               gt3d_crop, out_y);
     return dpp_launch_status();
 }

@@ -107,11 +107,8 @@ class DepthImporter(object):
         for i0 in range(0, len(records), chunk):
             part = records[i0:i0 + chunk]
             if docom and self.refineNet is not None:
-                crops, Ms, coms = [], [], []
-                for (dpt, gtorig, _, _, _) in part:
-                    hd = HandDetector(dpt, self.fx, self.fy, refineNet=self.refineNet, importer=self)
-                    c, M, com = hd.cropArea3D(com=gtorig[self.crop_joint_idx], size=config['cube'], docom=True)
-                    crops.append(c), Ms.append(M), coms.append(com)
+                # crop -> CoM -> ScaleNet refinement -> crop (handdetector.py:413-440) for the whole chunk as one device plan
+                crops, Ms, coms = self._crop_refined(part, cube)
             else:
                 frames = np.stack([r[0] for r in part]).astype(np.float32)
                 c0 = np.stack([r[1][self.crop_joint_idx] for r in part]).astype(np.float32)
@@ -125,6 +122,26 @@ class DepthImporter(object):
                 data.append(DepthFrame(np.asarray(c, np.float32), gtorig, gtcrop, M, gt3Dorig, gt3Dcrop, com3D, fileName, subSeqName,
                                        side, {}))
         return data
+
+    def _crop_refined(self, part, cube):
+        from hipdp.cascade import CascadeCropper
+        from hipdp.runtime import default_runtime
+        frames = np.stack([r[0] for r in part]).astype(np.float32)
+        c0 = np.stack([r[1][self.crop_joint_idx] for r in part]).astype(np.float32)
+        n = len(part)
+        nb = int(self.refineNet.cfgParams.batch_size)
+        if n < nb:                                        # a short last chunk: padded by repeating its last frame (netbase.py:285-290)
+            frames = np.concatenate([frames, np.repeat(frames[-1:], nb - n, axis=0)])
+            c0 = np.concatenate([c0, np.repeat(c0[-1:], nb - n, axis=0)])
+        B, H, W = frames.shape
+        key = (B, H, W, id(self.refineNet))
+        cc = getattr(self, '_cascade', None)
+        if cc is None or cc[0] != key:
+            self.refineNet.setDeterministic()
+            cc = (key, CascadeCropper(default_runtime(), self, self.refineNet, B, H, W, dsize=128, normalize=False))
+            self._cascade = cc
+        crops, Ms, coms = cc[1](frames, c0, np.tile(cube, (B, 1)))
+        return crops[:n], Ms[:n].astype(np.float64), coms[:n]
 
     def _crop_stream(self, config, docom, side, chunk=256):
         """Incremental form of _crop_records: frames are cropped (on the device) as soon as `chunk` of them have been read and

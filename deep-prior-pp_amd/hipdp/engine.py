@@ -23,7 +23,18 @@ from .lib import Act, RowMap
 from .ops import Plan
 from .runtime import default_runtime
 
-BN_RPB_TARGET_BLOCKS = int(os.environ.get('DPP_BN_BLOCKS', '1024'))
+
+
+def knob(name, default):
+    """Experiment knobs (tile / kernel-variant choices the measurements of DESIGN.md section 5 were made with, and the ablation
+    DPP_WHATIF_SKIP of tools/whatif.sh).  The product ignores them: they are read only when DPP_EXPERIMENT=1 is set as well, which
+    the tools/ scripts do and bench.py stamps into its output line (config.knobs)."""
+    if os.environ.get('DPP_EXPERIMENT', '0') != '1':
+        return default
+    return os.environ.get(name, default)
+
+
+BN_RPB_TARGET_BLOCKS = int(knob('DPP_BN_BLOCKS', '1024'))
 
 
 def _pad4(n):
@@ -246,7 +257,7 @@ def get_store(net, rt, layers):
     return store
 
 
-GEMM_TARGET_BLOCKS = int(os.environ.get('DPP_GEMM_TARGET_BLOCKS', '1024'))
+GEMM_TARGET_BLOCKS = int(knob('DPP_GEMM_TARGET_BLOCKS', '1024'))
 
 
 def gemm_plan(M, N, K, allow_split=True):
@@ -260,7 +271,7 @@ def gemm_plan(M, N, K, allow_split=True):
     else:
         wm = 4
         cands = [(128, 64), (64, 64), (128, 32), (64, 32), (128, 16), (64, 16)]
-        if os.environ.get('DPP_NO_128x64', '1') != '0':
+        if knob('DPP_NO_128x64', '1') != '0':
             cands = cands[1:]          # measured: 64x64 beats 128x64 on every conv shape of the net (gemm_micro.py)
         cands = [(a, b) for (a, b) in cands if b <= max(16, 16 * (-(-N // 16))) or b == 16]
         bm, bn = cands[-1]
@@ -276,15 +287,15 @@ def gemm_plan(M, N, K, allow_split=True):
     return (bm, bn, wm), splitk
 
 
-OVERLAP_ALLREDUCE = os.environ.get('DPP_OVERLAP_ALLREDUCE', '1') != '0'
-EARLY_BUCKET_MIN = int(os.environ.get('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elements; FC1 of the 128x128 ResNet has 16.8 M
+OVERLAP_ALLREDUCE = knob('DPP_OVERLAP_ALLREDUCE', '1') != '0'
+EARLY_BUCKET_MIN = int(knob('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elements; FC1 of the 128x128 ResNet has 16.8 M
 # 1x1 convolutions can read the BatchNorm gradient as (G, x) instead of a materialised dX (see _resolve_view).
 #   1: data AND filter gradient take the two-tensor operand.  Takes 20 bn_bwd_apply launches (107 us) off the main chain but
 #      makes 40 GEMMs 3.5 us slower each, half of them on the gradient branch, which the end of the step waits for
 #      (4.87 vs 4.71 ms per step).
 #   2: only the data gradient does, and it leaves the dX it forms in memory for the filter gradient (dpp_act.out), which
 #      then starts after it instead of beside it.
-LAZY_BN_BWD = int(os.environ.get('DPP_LAZY_BN_BWD', '0'))
+LAZY_BN_BWD = int(knob('DPP_LAZY_BN_BWD', '0'))
 BF16_DEFAULT = os.environ.get('DPP_BF16', '0') == '1'
 # ADAM of the FC1 weight (90 % of the parameters, 470 MB of optimizer traffic) inside the backward pass: its gradient is final a few
 # kernels into the pass, so the update runs on the gradient branch under the latency-bound data-gradient chain instead of in the
@@ -292,28 +303,28 @@ BF16_DEFAULT = os.environ.get('DPP_BF16', '0') == '1'
 # Measured on the MI355X (tools/exp_tail.sh, profiles/r02_tail_experiments.txt): 4.19-4.20 vs 4.18 ms per step -- the gradient branch
 # finishes together with the data-gradient chain (tools/tail_probe.py: 2.51 vs 2.53 ms), so work moved onto it comes back as a longer
 # wait at the join.  Off by default; the plan surgery stays tested (tests/test_engine.py).
-EARLY_ADAM = os.environ.get('DPP_EARLY_ADAM', '0') != '0'
+EARLY_ADAM = knob('DPP_EARLY_ADAM', '0') != '0'
 # Filter / bias gradient partials are summed by dpp_reduce_multi.  One launch at the end of the pass reads all of them (224 MB) in the
 # serial tail of the step; with a threshold the jobs collected so far are reduced on the gradient branch as soon as they amount to
 # this many bytes (their producers are on that branch or already issued on the main stream), and the tail launch keeps the rest.
 # Measured: 4.21 (16 MB) / 4.19 (64 MB) vs 4.18 ms with the single launch, for the same reason as EARLY_ADAM.  0 = one launch (default).
-EARLY_REDUCE_BYTES = int(os.environ.get('DPP_EARLY_REDUCE_MB', '0')) << 20
+EARLY_REDUCE_BYTES = int(knob('DPP_EARLY_REDUCE_MB', '0')) << 20
 # FC1 (the HiddenLayer behind the last conv map) on the weight-streaming kernels of dpp_fc_gemm instead of the generic dpp_gemm.
 # f32: the three-stage kernel (fc_stream_kernel: 128 x 128 / 128 x 64 tiles, whole tiles only) runs the batch-128 FC1 forward /
 # data gradient in 53 / 70 us against dpp_gemm's 102 / 104 us; the older double-buffered kernel, which takes ragged shapes, only
 # ties with dpp_gemm in f32 (profiles/r02_fc1_kernels.txt), so f32 goes there only when the shape fits the three-stage kernel.
 # bf16 (config 5) always uses dpp_fc_gemm: dpp_gemm has no bf16 counterpart.
 #   DPP_FC1_STREAM=auto (default) | bf16: bf16 only | 1: always | 0: never (bf16 FC1 then falls back to f32 dpp_gemm)
-FC1_STREAM = os.environ.get('DPP_FC1_STREAM', 'auto')
-FC1_KCHUNK = int(os.environ.get('DPP_FC1_KCHUNK', '0'))
-FC1_SLICES = int(os.environ.get('DPP_FC1_SLICES', '32'))
-FC1_MIN_K = int(os.environ.get('DPP_FC1_MIN_K', '4096'))
+FC1_STREAM = knob('DPP_FC1_STREAM', 'auto')
+FC1_KCHUNK = int(knob('DPP_FC1_KCHUNK', '0'))
+FC1_SLICES = int(knob('DPP_FC1_SLICES', '32'))
+FC1_MIN_K = int(knob('DPP_FC1_MIN_K', '4096'))
 
 
 def is_fc1_shape(Nb, K, Nout):
     """The weight-streaming shape: tens of MB of weights for at most a few hundred rows."""
     return K >= FC1_MIN_K and Nout >= 64 and Nout % 4 == 0 and K % 4 == 0
-ROWSTREAM = os.environ.get('DPP_ROWSTREAM', '0') != '0'      # measured: no gain over the LDS-tiled kernel yet
+ROWSTREAM = knob('DPP_ROWSTREAM', '0') != '0'      # measured: no gain over the LDS-tiled kernel yet
 
 def rowstream_plan(M, N, K, b_kc):
     """Tile of the barrier-free row-streaming GEMM variant for conv-shaped problems (M = pixels >> K, N), or None when it
@@ -335,8 +346,8 @@ def rowstream_plan(M, N, K, b_kc):
 # dpp_gemm variant 2 (gemm_ksplit_kernel): 32 rows x all columns x the WHOLE K per workgroup, one memory round trip, the four waves
 # split K.  For the long-K / narrow-N 1x1 convolutions of the late stages, K-contiguous A, whole tiles only.
 #   DPP_KSPLIT = 0: off | 1: K = 256 (stage 3 / 4 bottleneck entries and the data gradients of their exits) | 2: K = 128 as well
-KSPLIT = int(os.environ.get('DPP_KSPLIT', '2'))
-KSPLIT_MAX_M = int(os.environ.get('DPP_KSPLIT_MAX_M', '16384'))
+KSPLIT = int(knob('DPP_KSPLIT', '2'))
+KSPLIT_MAX_M = int(knob('DPP_KSPLIT_MAX_M', '16384'))
 
 
 def ksplit_plan(M, N, K):
@@ -354,8 +365,8 @@ def ksplit_plan(M, N, K):
 # see csrc/gemm.hip.  DPP_STREAM16 = 0 | 1 | 2 | 3.  No lower bound on the row count by default:
 # the kernel sums k in another order than the LDS-tiled one, and a frame's joints must not depend on the batch it is evaluated in
 # (tests/test_full_size.py compares batches of 8 and 128 at 1e-4 mm), so the choice of kernel must not depend on the batch either.
-STREAM16 = int(os.environ.get('DPP_STREAM16', '2'))
-STREAM16_MIN_M = int(os.environ.get('DPP_STREAM16_MIN_M', '128'))
+STREAM16 = int(knob('DPP_STREAM16', '2'))
+STREAM16_MIN_M = int(knob('DPP_STREAM16_MIN_M', '128'))
 
 
 def stream16_plan(M, N, K, forward):
@@ -378,7 +389,7 @@ def conv3x3_bm(pixels, Co):
     return 128 if (pixels // 128) * (-(-Co // 64)) >= 512 else 64
 
 
-WGRAD_TARGET_BLOCKS = int(os.environ.get('DPP_WGRAD_TARGET_BLOCKS', '256'))
+WGRAD_TARGET_BLOCKS = int(knob('DPP_WGRAD_TARGET_BLOCKS', '256'))
 
 
 def wgrad_plan(Co, Ci, K):
@@ -829,7 +840,7 @@ class CompiledNet(object):
         if K >= 4096 and Nb <= 128 and Nout >= 64:
             # weight-streaming shape (FC1: 67 MB of W for 128 rows): wide column tiles read W in 256 B rows, K split 512 deep
             # (tools/gemm_micro.py fc: all 128 rows in one tile halve the passes over W through L2, 96 -> 79 us)
-            tile, splitk = ((128, 64, 4) if Nb > 64 and os.environ.get('DPP_FC1_TILE128', '1') != '0' else (64, 64, 4)), max(1, K // 512)
+            tile, splitk = ((128, 64, 4) if Nb > 64 and knob('DPP_FC1_TILE128', '1') != '0' else (64, 64, 4)), max(1, K // 512)
         act = self._act(src)
         if splitk > 1:
             part = self.scratch(splitk * Nb * Nout)
@@ -1201,7 +1212,7 @@ class CompiledNet(object):
                                      kchunk=FC1_KCHUNK, name='fc_wgrad_%d' % layer.layerNum), side=True)
         else:
             tile, _ = gemm_plan(K, Nout, Nb, allow_split=False)
-            if K >= 4096 and Nout >= 64 and os.environ.get('DPP_FC1_TILE128', '1') != '0':
+            if K >= 4096 and Nout >= 64 and knob('DPP_FC1_TILE128', '1') != '0':
                 tile = (128, 64, 4)          # FC1: 67 MB of output, MFMA-bound (tools/gemm_micro.py fc: 107 -> 84 us)
             self.bwd.add(ops.gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, tile=tile,
                                   name='fc_wgrad_%d' % layer.layerNum), side=True)
@@ -1271,7 +1282,7 @@ class CompiledNet(object):
         # done -- and then the main stream has nothing left to do while the gradient branch still works off its backlog
         # (tools/tail_probe.py): it runs on the main stream.
         self.bwd.add(ops.stem_wgrad(rt, self.x_in.buf, N, H, W, dY, io['argmax'], Co, part, tpb),
-                     side=os.environ.get('DPP_STEM_WGRAD_SIDE', '0') == '1')
+                     side=knob('DPP_STEM_WGRAD_SIDE', '0') == '1')
         self.reduce_jobs.add(part, nblk, Co * 25, self._grad_view(layer.W))
 
     # ------------------------------------------------------------------------------------------ execution
@@ -1340,7 +1351,7 @@ class CompiledNet(object):
                     post.add(op, side=True)
                 parts = [pre] + parts + [post]
             plan = Plan.concat('step', parts + [upd])
-            skip = tuple(x for x in os.environ.get('DPP_WHATIF_SKIP', '').split(',') if x)
+            skip = tuple(x for x in knob('DPP_WHATIF_SKIP', '').split(',') if x)
             if skip:
                 # ablation for tools/whatif.sh ONLY (results are wrong): the step without the launches whose name starts with one of
                 # the prefixes -- what the step would cost if those kernels were free

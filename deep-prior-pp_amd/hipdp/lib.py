@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'lib', 'libdpp_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 c_float_p = C.c_void_p      # device pointers travel as integers
 stream_t = C.c_void_p
 
@@ -123,10 +123,13 @@ SIGNATURES = {
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int,
                               stream_t]),
     'dpp_crop_record_bytes': (C.c_size_t, []),
-    'dpp_crop_prepare': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+    'dpp_crop_prepare': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, stream_t]),
     'dpp_crop_com': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_crop_warp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, stream_t]),
+    'dpp_crop_refine': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                  C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, stream_t]),
     'dpp_pose_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, stream_t]),

@@ -138,7 +138,9 @@ class Plan(object):
         return [o for (o, _) in self.ops if not isinstance(o, (Fork, Join))]
 
     def _compile(self, rt):
-        key = (id(rt), len(self.ops), LAUNCH_MODE)
+        # keyed on the identity of the ops: a plan whose ops are replaced or reordered (the engine splices plans) must be re-recorded,
+        # a recording freezes each launch's grid and arguments
+        key = (id(rt), LAUNCH_MODE, tuple((id(op), bool(side)) for op, side in self.ops))
         if self._compiled is not None and self._compiled[0] == key:
             return self._compiled[1]
         segs, cur = [], []
@@ -437,8 +439,9 @@ class AugmentState(object):
                         counter_dev=self.counter, ticket=self.ticket, sample0=self.sample0, global_batch=self.global_batch, **kw)]
 
 
-def crop_prepare(rt, frames, B, H, W, com, cube, fx, fy, dsz, records, M_out=None, name='crop_prepare'):
-    return Launch(rt.lib.dpp_crop_prepare, (frames.ptr, B, H, W, com.ptr, cube.ptr, float(fx), float(fy), dsz, records.ptr, _p(M_out)),
+def crop_prepare(rt, frames, B, H, W, com, cube, fx, fy, dsz, records, M_out=None, stretch=False, name='crop_prepare'):
+    return Launch(rt.lib.dpp_crop_prepare, (frames.ptr, B, H, W, com.ptr, cube.ptr, float(fx), float(fy), dsz, int(bool(stretch)), records.ptr,
+                                            _p(M_out)),
                   (frames, com, cube, records, M_out), name, dict(kernel='crop_prepare', flops=2.0 * B * H * W, bytes=4.0 * B * H * W))
 
 
@@ -449,6 +452,16 @@ def crop_com(rt, frames, records, B, H, W, com_out, name='crop_com'):
 def crop_warp(rt, frames, records, B, H, W, dsz, out, normalize=True, nd_value=0.0, name='crop_warp'):
     return Launch(rt.lib.dpp_crop_warp, (frames.ptr, records.ptr, B, H, W, dsz, int(bool(normalize)), float(nd_value), out.ptr),
                   (frames, records, out), name, dict(kernel='crop_warp', flops=10.0 * B * dsz * dsz, bytes=8.0 * B * dsz * dsz))
+
+
+def crop_refine(rt, frames, records, B, H, W, com_in, cube, net_out, cam, com_out, gt3d_orig=None, J=0, pca_mean=None, pca_comp=None, E=0,
+                com3d_out=None, gt3d_crop=None, out_y=None, name='crop_refine'):
+    """dpp_crop_refine: the refined crop centre from a refinement net's output (+ optionally the labels of the re-cropped frame)."""
+    fx, fy, ux, uy, flip = cam
+    return Launch(rt.lib.dpp_crop_refine,
+                  (frames.ptr, records.ptr, B, H, W, com_in.ptr, cube.ptr, net_out.ptr, float(fx), float(fy), float(ux), float(uy), int(flip),
+                   _p(gt3d_orig), int(J), _p(pca_mean), _p(pca_comp), int(E), com_out.ptr, _p(com3d_out), _p(gt3d_crop), _p(out_y)),
+                  (frames, records, com_in, cube, net_out, gt3d_orig, pca_mean, pca_comp, com_out, com3d_out, gt3d_crop, out_y), name)
 
 
 def copy2d(rt, src, lds, dst, ldd, rows, cols, relu=False, name='copy2d'):

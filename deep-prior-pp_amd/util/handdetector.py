@@ -253,8 +253,13 @@ class HandDetector(object):
         crops, Ms, coms = crop_frames(frame, numpy.asarray(com, numpy.float32)[None], cube, self.fx, self.fy, dsize[0], normalize=False,
                                       nd_value=nd, docom=docom, return_com=True)
         if docom and self.refineNet is not None and self.importer is not None:
-            # handdetector.py:429-440: a ScaleNet regresses the offset of the true CoM from the crop; crop again around it
-            newCom3D = self.refineCoM(crops[0], size, coms[0]) + self.importer.jointImgTo3D(coms[0])
+            # handdetector.py:429-440: a ScaleNet regresses the offset of the true CoM from the crop; crop again around it.  The net
+            # looks at resizeCrop(cropped, dsize): the window resized to dsize AS IT IS (:430), not the aspect-preserving paste
+            # (at the net's own input size: the reference passes dsize, which has to be that size there)
+            dims = self.refineNet.cfgParams.inputDim
+            rs = int((dims[0] if isinstance(dims[0], (list, tuple)) else dims)[2])
+            rz, _ = crop_frames(frame, coms[0][None], cube, self.fx, self.fy, rs, normalize=False, nd_value=nd, stretch=True)
+            newCom3D = self.refineCoM(rz[0], size, coms[0]) + self.importer.jointImgTo3D(coms[0])
             com2 = numpy.asarray(self.importer.joint3DToImg(newCom3D), numpy.float64)
             if numpy.allclose(com2, 0.):
                 com2[2] = crops[0][crops[0].shape[0] // 2, crops[0].shape[1] // 2]
@@ -333,11 +338,13 @@ class HandDetector(object):
     track = detect
 
 
-def crop_frames(frames, coms, cubes, fx, fy, dsize=128, normalize=True, nd_value=0., runtime=None, docom=False, return_com=False):
+def crop_frames(frames, coms, cubes, fx, fy, dsize=128, normalize=True, nd_value=0., runtime=None, docom=False, return_com=False,
+                stretch=False):
     """Batched cropArea3D (+ Dataset.imgStackDepthOnly when normalize): frames (B, H, W) raw depth in mm, coms (B, 3) crop
     centres in image coordinates, cubes (B, 3) in mm -> (crops (B, dsize, dsize) float32, M (B, 3, 3) float32[, coms]).
     Two kernel launches for the whole batch (csrc/augment.hip: crop_prepare / crop_warp); docom=True re-centres every crop
-    on the centre of mass of its first window (two more launches), as handdetector.py:413-427 does."""
+    on the centre of mass of its first window (two more launches), as handdetector.py:413-427 does; stretch=True resizes the
+    window to dsize x dsize as it is (resizeCrop(cropped, dsize), the refinement net's input, :430)."""
     from hipdp import ops
     from hipdp.runtime import default_runtime
     rt = runtime or default_runtime()
@@ -348,11 +355,11 @@ def crop_frames(frames, coms, cubes, fx, fy, dsize=128, normalize=True, nd_value
     cu = rt.upload(numpy.ascontiguousarray(cubes, numpy.float32).reshape(B, 3))
     rec = rt.alloc(B * rt.lib.dpp_crop_record_bytes(), numpy.uint8)
     out, M = rt.alloc((B, dsize, dsize), zero=False), rt.alloc((B, 9), zero=False)
-    ops.crop_prepare(rt, fr, B, H, W, co, cu, fx, fy, dsize, rec, M)(rt.stream)
+    ops.crop_prepare(rt, fr, B, H, W, co, cu, fx, fy, dsize, rec, M, stretch=stretch)(rt.stream)
     if docom:
         co2 = rt.alloc((B, 3), zero=False)
         ops.crop_com(rt, fr, rec, B, H, W, co2)(rt.stream)
-        ops.crop_prepare(rt, fr, B, H, W, co2, cu, fx, fy, dsize, rec, M)(rt.stream)
+        ops.crop_prepare(rt, fr, B, H, W, co2, cu, fx, fy, dsize, rec, M, stretch=stretch)(rt.stream)
         co = co2
     ops.crop_warp(rt, fr, rec, B, H, W, dsize, out, normalize=normalize, nd_value=nd_value)(rt.stream)
     rt.synchronize()

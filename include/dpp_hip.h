@@ -34,7 +34,7 @@ typedef void* dpp_stream_t; /* a hipStream_t */
 #define DPP_E_BADARG 10001
 #define DPP_E_UNSUPPORTED 10002
 
-#define DPP_ABI_VERSION 6
+#define DPP_ABI_VERSION 7
 int dpp_abi_version(void);
 
 /* Pixel row map: row m of a compact (N,Ho,Wo) map -> row of a (N,Hi,Wi) map sampled with stride s.
@@ -300,15 +300,29 @@ int dpp_augment(const float* img, const float* com3d, const float* cube, const f
  * the crop window (comToBounds), the aspect-preserving nearest-neighbour resize geometry (cv2.resize INTER_NEAREST) and the
  * crop transform M_out [B][9] (= comToTransform; may be NULL).  warp: out [B][dsz][dsz]: the crop in mm with background
  * nd_value (normalize == 0, what cropArea3D returns) or normalised like the training stacks: 0 -> com_z + cube_z/2, then
- * (d - com_z) / (cube_z / 2) (normalize != 0). */
+ * (d - com_z) / (cube_z / 2) (normalize != 0).  stretch != 0: the window is resized to dsz x dsz as it is (no aspect-preserving
+ * size, no centred paste): `resizeCrop(cropped, dsize)`, the image cropArea3D shows its refinement net (handdetector.py:430). */
 size_t dpp_crop_record_bytes(void);
 int dpp_crop_prepare(const float* frames, int B, int H, int W, const float* com, const float* cube, double fx, double fy,
-                     int dsz, void* records, float* M_out, dpp_stream_t stream);
+                     int dsz, int stretch, void* records, float* M_out, dpp_stream_t stream);
 int dpp_crop_warp(const float* frames, const void* records, int B, int H, int W, int dsz, int normalize, float nd_value,
                   float* out, dpp_stream_t stream);
 /* docom = True (handdetector.py:413-427): the centre of mass (calculateCoM, :91-108) of the crop window described by
  * `records`, in image coordinates -> com_out [B][3]; re-run dpp_crop_prepare with it, then dpp_crop_warp. */
 int dpp_crop_com(const float* frames, const void* records, int B, int H, int W, float* com_out, dpp_stream_t stream);
+/* docom = True WITH a refinement net (handdetector.py:429-440 and refineCoM, :634-676), batched: net_out [B][3] is the net's
+ * output for the re-centred crops (normalised offset of the hand centre), com_in [B][3] the centre those crops were cut around
+ * (dpp_crop_com's output), records the crop records of that second dpp_crop_prepare.
+ *   com_out [B][3]  = joint3DToImg(net_out * cube_z / 2 + jointImgTo3D(com_in)); an all-zero result takes the depth of the crop
+ *                     window's centre pixel.  Re-run dpp_crop_prepare / dpp_crop_warp with it (any dsz) for the final crop.
+ * Optional, for a refine -> re-crop -> regress cascade that never leaves the device (importers.py:388-392, dataset.py:103,
+ * poseregnettrainer.py:262): gt3d_orig [B][J][3] -> gt3d_crop = gt3d_orig - jointImgTo3D(com_out) (may be NULL), com3d_out
+ * [B][3] (may be NULL) and out_y = gt3d_crop / (cube_z / 2), projected onto the PCA prior when pca_comp [E][J*3] / pca_mean are
+ * given ([B][E]) and raw otherwise ([B][J*3]).  (fx, fy, ux, uy, flip_y): the importer's camera, signs included. */
+int dpp_crop_refine(const float* frames, const void* records, int B, int H, int W, const float* com_in, const float* cube,
+                    const float* net_out, double fx, double fy, double ux, double uy, int flip_y, const float* gt3d_orig, int J,
+                    const float* pca_mean, const float* pca_comp, int E, float* com_out, float* com3d_out, float* gt3d_crop,
+                    float* out_y, dpp_stream_t stream);
 
 /* ---- PCA prior set-up and evaluation on the device --------------------------------------------
  * pose_sample: HandDetector.sampleRandomPoses (/root/reference/src/util/handdetector.py:805-909) for n samples: sample i augments

@@ -613,3 +613,53 @@ def synthetic_frames(rng, n, cam, H=240, W=320, cube=(250., 250., 250.)):
         frames[i] = f
         coms[i] = (u, v, d)
     return frames, coms
+
+
+def refine_com(crop_mm, size, com, net_forward):
+    """refineCoM, handdetector.py:634-676: normalise and clamp the crop to the cube, feed it with its 1/2 and 1/4 centre crops to the
+    refinement net (`net_forward(list of (1,1,h,w) arrays) -> (1, 3)`), return the offset in mm (float32)."""
+    imgD = np.asarray(crop_mm, np.float32).copy()
+    imgD[imgD == 0] = com[2] + (size[2] / 2.)
+    imgD[imgD >= com[2] + (size[2] / 2.)] = com[2] + (size[2] / 2.)
+    imgD[imgD <= com[2] - (size[2] / 2.)] = com[2] - (size[2] / 2.)
+    imgD -= com[2]
+    imgD /= (size[2] / 2.)
+    test_data = np.zeros((1, 1) + imgD.shape, np.float32)
+    test_data[0, 0] = imgD
+    ins = [test_data]
+    for k in (2, 4):
+        dsize = (int(test_data.shape[2] // k), int(test_data.shape[3] // k))
+        xstart = int(test_data.shape[2] / 2 - dsize[0] / 2)
+        ystart = int(test_data.shape[3] / 2 - dsize[1] / 2)
+        ins.append(test_data[:, :, ystart:ystart + dsize[1], xstart:xstart + dsize[0]])
+    jts = np.asarray(net_forward(ins), np.float32)
+    return jts[0] * np.float32(size[2] / 2.)
+
+
+def crop_area_3d_refined(dpt, com, size, cam, fx, fy, min_depth, max_depth, net_forward, dsize=(128, 128), nd_value=0., rsize=(128, 128),
+                         com2_override=None):
+    """cropArea3D with docom=True AND a refinement net, handdetector.py:413-440: re-centre on the CoM of the first window, show the
+    net that window resized to `rsize` as it is (resizeCrop(cropped, dsize), :430 -- no aspect-preserving paste), move the centre by
+    the regressed offset, crop again (the aspect-preserving crop of :446-490).  Returns (crop, M, com2, com1, net input crop).
+    com2_override: crop around this centre instead of the one computed here (tests hand in the device's own float32 centre so
+    that the final crops can be compared bit for bit although the net outputs differ in the last bits)."""
+    xstart, xend, ystart, yend, zstart, zend = com_to_bounds(com, size, fx, fy)
+    cropped = get_crop(dpt, xstart, xend, ystart, yend, zstart, zend)
+    com1 = calculate_com(cropped, min_depth, max_depth)
+    if np.allclose(com1, 0.):
+        com1[2] = cropped[cropped.shape[0] // 2, cropped.shape[1] // 2]
+        if np.isclose(com1[2], 0):
+            com1[2] = 300
+    com1[0] += xstart
+    com1[1] += ystart
+    com1 = com1.astype(np.float32)
+    xstart, xend, ystart, yend, zstart, zend = com_to_bounds(com1, size, fx, fy)
+    cropped = get_crop(dpt, xstart, xend, ystart, yend, zstart, zend)
+    rz = resize_nn(cropped, rsize)
+    newCom3D = refine_com(rz, size, com1, net_forward) + cam.jointImgTo3D(com1)
+    com2 = cam.joint3DToImg(newCom3D)
+    if np.allclose(com2, 0.):
+        com2[2] = cropped[cropped.shape[0] // 2, cropped.shape[1] // 2]
+    use = com2 if com2_override is None else np.asarray(com2_override, np.float32)
+    ret, M, _ = crop_area_3d(dpt, use, size, fx, fy, dsize, nd_value)
+    return ret, M, com2, com1, rz

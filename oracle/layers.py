@@ -18,6 +18,19 @@ Third-party semantics assumed (Theano 0.9, un-vendored, parity unpinned):
 import numpy as np
 
 
+# --------------------------------------------------------------------------- bf16 operands (BASELINE config 5)
+def bf16_round(x):
+    """Round to bfloat16 (8 bits of significand, round to nearest even) and return the value in x's dtype: what the bf16 kernels
+    do to an MFMA operand when they stage it (csrc: dpp_bf16_rne).  float64 input is first rounded to float32, the type the device
+    holds the operand in."""
+    x = np.asarray(x)
+    f = np.ascontiguousarray(x, np.float32)
+    u = f.view(np.uint32)
+    r = ((u + (np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)))) & np.uint32(0xFFFF0000)).view(np.float32)
+    r = np.where(np.isfinite(f), r, f)
+    return r.astype(x.dtype).reshape(x.shape)
+
+
 # --------------------------------------------------------------------------- conv
 def _out_hw(H, W, kh, kw, stride, border_mode):
     """Shape rule of ConvLayerParams.update, /root/reference/src/net/convlayer.py:131-163."""

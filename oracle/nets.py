@@ -250,12 +250,17 @@ def trained_param_list(net, P):
 
 
 # --------------------------------------------------------------------------- forward / backward
-def forward(net, P, x, train, dropout_masks=None, masks=None):
+def forward(net, P, x, train, dropout_masks=None, masks=None, bf16=None):
     """Returns (output, cache).  train=True <=> unsetDeterministic (BN batch statistics, dropout masks).
     masks (optional): {layer index: bool array} pins the pass / block decision of a 'relu' layer or of an 'fc' layer's ReLU
-    to the given pattern (the device's own, when comparing gradients: see oracle/torch_ref.forward)."""
+    to the given pattern (the device's own, when comparing gradients: see oracle/torch_ref.forward).
+    bf16 (optional): the set of 'conv' / 'fc' layer indices whose two MFMA operands (activated input, weight) are rounded to
+    bfloat16 before the product, accumulation and everything else staying in the array dtype -- the arithmetic of the bf16 kernels
+    (BASELINE config 5).  Forward only: backward() differentiates the unrounded graph; the gradient-parity tests use
+    oracle/torch_ref.py, which models the rounded backward operands as well."""
     vals, cache, memo = {}, {}, {}
     masks = masks or {}
+    bf16 = bf16 or ()
 
     def get(ref):
         if ref[0] == 'input':
@@ -281,7 +286,10 @@ def forward(net, P, x, train, dropout_masks=None, masks=None):
                                                l['act'] == 'relu')
             cache[i] = (a,) + cache[i]
         elif k == 'conv':
-            vals[i] = L.conv2d_fwd(a, P[i][0], P[i][1], l['stride'], l['border'])
+            if i in bf16:
+                vals[i] = L.conv2d_fwd(L.bf16_round(a), L.bf16_round(P[i][0]), P[i][1], l['stride'], l['border'])
+            else:
+                vals[i] = L.conv2d_fwd(a, P[i][0], P[i][1], l['stride'], l['border'])
             cache[i] = (a,)
         elif k == 'bn':
             beta, gamma, rm, ris = P[i]
@@ -294,7 +302,7 @@ def forward(net, P, x, train, dropout_masks=None, masks=None):
             vals[i] = L.relu_fwd(a) if i not in masks else a * masks[i]
             cache[i] = (a,) if i not in masks else (a, masks[i])
         elif k == 'fc':
-            pre = L.fc_fwd(a, P[i][0], P[i][1])
+            pre = L.fc_fwd(L.bf16_round(a), L.bf16_round(P[i][0]), P[i][1]) if i in bf16 else L.fc_fwd(a, P[i][0], P[i][1])
             if l['act'] == 'relu':
                 vals[i] = L.relu_fwd(pre) if i not in masks else pre * masks[i]
             else:
@@ -435,9 +443,9 @@ def train_step(net, P, state, x, y, lr, dropout_masks=None, weight_decay=0.0):
     return cost, G
 
 
-def compute_output(net, P, inputs):
+def compute_output(net, P, inputs, bf16=None):
     """NetBase.computeOutput, /root/reference/src/net/netbase.py:217-316: deterministic forward in
-    batches of batch_size, the last batch padded by repeating the last sample, result trimmed."""
+    batches of batch_size, the last batch padded by repeating the last sample, result trimmed.  bf16: see forward()."""
     bs = net['batch_size']
     multi = isinstance(inputs, (list, tuple))
     ins = list(inputs) if multi else [inputs]
@@ -451,7 +459,7 @@ def compute_output(net, P, inputs):
             if chunk.shape[0] < bs:
                 chunk = np.concatenate([chunk, np.repeat(a[-1:], bs - chunk.shape[0], axis=0)], axis=0)
             chunks.append(chunk)
-        o, _ = forward(net, P, chunks if multi else chunks[0], train=False)
+        o, _ = forward(net, P, chunks if multi else chunks[0], train=False, bf16=bf16)
         out[i * bs:(i + 1) * bs] = o.reshape((bs,) + tuple(net['out_dim'][1:]))
     return out[:n]
 

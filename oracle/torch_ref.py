@@ -63,14 +63,55 @@ class _MaxPoolTies(torch.autograd.Function):
         return g, None, None, None
 
 
+def bf16r(t):
+    """Round to bfloat16 (nearest even) and come back in t's dtype: what the bf16 kernels do to an MFMA operand when they stage it."""
+    return t.detach().to(torch.float32).to(torch.bfloat16).to(t.dtype)
+
+
+class _QBilinear(torch.autograd.Function):
+    """y = fn(a, W) for a bilinear fn (a convolution without bias, a matrix product) evaluated the way the bf16 kernels of BASELINE
+    config 5 do it -- operands rounded to bfloat16, accumulation in the working precision -- in EACH of the three passes, per
+    layer as the device's launches are configured (tests/pinning.py:device_quant reads that off the compiled net):
+        forward        fn(q(a), q(W))                        q = bf16r if 'fwd' else identity
+        data gradient  fn^T_a(q(dY), q(W))                   if 'dgrad', else the unrounded fn^T_a(dY, W)
+        filter grad.   fn^T_W(q(a), q(dY))                   if 'wgrad', else fn^T_W(a, dY)
+    (rounding is NOT differentiated: the data gradient goes straight to `a`, as on the device).  `pin`: the device's own rounded
+    forward operand -- a float32 and a float64 evaluation of the same activation round to different bfloat16 neighbours for a few
+    elements in 1e5, and one such flip is 100x a float32 rounding error; with the device's operand handed in, what is compared is
+    the arithmetic of the kernels (the same idea as the ReLU / pooling masks of forward()).  `pin_dy`: likewise the device's rounded
+    output gradient, the operand of the two backward products."""
+
+    @staticmethod
+    def forward(ctx, a, W, fn, q):
+        aq = q['pin'].to(a.dtype) if q.get('pin') is not None else (bf16r(a) if q.get('fwd') else a.detach())
+        Wq = bf16r(W) if q.get('fwd') else W.detach()
+        ctx.fn, ctx.q = fn, q
+        ctx.save_for_backward(a.detach(), W.detach(), aq)
+        return fn(aq, Wq)
+
+    @staticmethod
+    def backward(ctx, gy):
+        a, W, aq = ctx.saved_tensors
+        fn, q = ctx.fn, ctx.q
+        with torch.enable_grad():
+            gq = q['pin_dy'].to(gy.dtype) if q.get('pin_dy') is not None else bf16r(gy)
+            av = a.clone().requires_grad_(True)
+            (da,) = torch.autograd.grad(fn(av, bf16r(W) if q.get('dgrad') else W), av, gq if q.get('dgrad') else gy)
+            Wv = W.clone().requires_grad_(True)
+            (dW,) = torch.autograd.grad(fn(aq if q.get('wgrad') else a, Wv), Wv, gq if q.get('wgrad') else gy)
+        return da, dW, None, None
+
+
 def _relu(a, mask=None):
     """T.maximum(a, 0); with `mask` the pass / block decision of every element is the given one (value a where it passes,
     gradient 1 there): pins the ReLU pattern of a float32 evaluation when comparing gradients, see forward()."""
     return torch.clamp_min(a, 0) if mask is None else a * mask.to(a.dtype)
 
 
-def forward(net, T, x, train, masks=None):
-    """masks (optional): {layer index: bool array} -- for a 'relu' layer or an 'fc' layer with ReLU the elements that pass,
+def forward(net, T, x, train, masks=None, quant=None):
+    """quant (optional): {layer index of a 'conv' / 'fc' layer: dict(fwd=, dgrad=, wgrad=, pin=)} -- the layers whose products run
+    on bf16 operands, see _QBilinear.
+    masks (optional): {layer index: bool array} -- for a 'relu' layer or an 'fc' layer with ReLU the elements that pass,
     for a 'convpool' layer with pooling the tie pattern [N][C][oh][ow][ph*pw] of the windows (and, under the key
     ('relu', layer index), the pass pattern of its own ReLU).  The gradient of a deep ReLU net
     is discontinuous in its inputs: two float32 evaluations (or one float32 and one float64) disagree on the sign of the
@@ -79,6 +120,17 @@ def forward(net, T, x, train, masks=None):
     left is the arithmetic of the kernels, comparable at float32 round-off."""
     vals, stats = {}, {}
     masks = masks or {}
+    quant = quant or {}
+
+    def qd(i):
+        q = quant.get(i)
+        if q is None:
+            return None
+        q = dict(q)
+        for key in ('pin', 'pin_dy'):
+            if q.get(key) is not None:
+                q[key] = torch.as_tensor(np.asarray(q[key]))
+        return q
 
     def mk(i):
         m = masks.get(i)
@@ -112,7 +164,12 @@ def forward(net, T, x, train, masks=None):
             c = c + T[i][1][None, :, None, None]
             vals[i] = _relu(c, mk(('relu', i))) if l['act'] == 'relu' else c
         elif k == 'conv':
-            vals[i] = _conv(a, T[i][0], l['stride'], l['border']) + T[i][1][None, :, None, None]
+            q = qd(i)
+            if q is None:
+                c = _conv(a, T[i][0], l['stride'], l['border'])
+            else:
+                c = _QBilinear.apply(a, T[i][0], (lambda u, w, l=l: _conv(u, w, l['stride'], l['border'])), q)
+            vals[i] = c + T[i][1][None, :, None, None]
         elif k == 'bn':
             beta, gamma, rm, ris = T[i]
             if train:
@@ -127,7 +184,8 @@ def forward(net, T, x, train, masks=None):
         elif k == 'relu':
             vals[i] = _relu(a, mk(i))
         elif k == 'fc':
-            pre = a @ T[i][0] + T[i][1]
+            q = qd(i)
+            pre = (a @ T[i][0] if q is None else _QBilinear.apply(a, T[i][0], (lambda u, w: u @ w), q)) + T[i][1]
             vals[i] = _relu(pre, mk(i)) if l['act'] == 'relu' else pre
         elif k == 'dropout':
             vals[i] = a * float(np.float32(1.0 - l['p'])) if not train else a   # masks not modelled here
@@ -136,12 +194,12 @@ def forward(net, T, x, train, masks=None):
     return get(net['out']), stats
 
 
-def cost_and_grads(net, P, x, y, dtype=torch.float64, masks=None):
-    """Returns (cost, {layer: [g0, g1]}, out) with autograd gradients (numpy arrays); `masks`: see forward()."""
+def cost_and_grads(net, P, x, y, dtype=torch.float64, masks=None, quant=None):
+    """Returns (cost, {layer: [g0, g1]}, out) with autograd gradients (numpy arrays); `masks`, `quant`: see forward()."""
     T = to_torch(P, dtype)
     xt = [torch.as_tensor(a, dtype=dtype) for a in x] if isinstance(x, (list, tuple)) else torch.tensor(x, dtype=dtype)
     yt = torch.tensor(y, dtype=dtype)
-    out, _ = forward(net, T, xt, True, masks)
+    out, _ = forward(net, T, xt, True, masks, quant)
     cost = ((out - yt) ** 2).sum(dim=1).mean()
     cost.backward()
     G = {i: [T[i][0].grad.numpy(), T[i][1].grad.numpy()] for i in T}

@@ -11,11 +11,12 @@ for p in (ROOT, os.path.join(ROOT, 'deep-prior-pp_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-os.environ['DPP_EARLY_BUCKET_MIN'] = str(1 << 18)      # the test net's FC layers (1 M weights) take the overlapped early-bucket path
 
 import numpy as np  # noqa: E402
 
 from hipdp import engine, parallel  # noqa: E402
+
+engine.EARLY_BUCKET_MIN = 1 << 18      # the test net's FC layers (1 M weights) take the overlapped early-bucket path
 from net.resnet import ResNet, ResNetParams  # noqa: E402
 from oracle import nets  # noqa: E402
 

@@ -52,3 +52,54 @@ def device_masks(eng, net):
             t = np.stack([(bits >> j) & 1 for j in range(pp)], axis=-1).astype(bool)
             masks[idx[id(lay)]] = np.ascontiguousarray(np.moveaxis(t, 3, 1))
     return masks
+
+
+# ---- bf16 operands (BASELINE config 5) ------------------------------------------------------------------------------------------
+def _activated_operand(view):
+    """The float32 value the kernels form from a (base tensor, pending BatchNorm, pending ReLU) view while they stage it, NCHW (or
+    [N][D] for a flattened view): (x - mean) in float32, then ONE fused multiply-add with scale / beta, then the ReLU -- the
+    arithmetic of dpp_act4 (csrc/dpp_common.h), reproduced with exact float64 products rounded once."""
+    x = view.base.buf.get().astype(np.float32)
+    if view.bn is not None:
+        C = view.bn.C
+        mean, scale, beta = (b.get()[:C].astype(np.float32) for b in (view.bn.mean, view.bn.scale, view.bn.beta_buf))
+        dx = (x - mean).astype(np.float32)
+        x = (dx.astype(np.float64) * scale.astype(np.float64) + beta.astype(np.float64)).astype(np.float32)
+    if view.relu:
+        x = np.maximum(x, np.float32(0))
+    if x.ndim == 4:
+        x = np.moveaxis(x, -1, 1)                          # NHWC -> NCHW
+        if len(view.shape) == 2:
+            x = x.reshape(x.shape[0], -1)                  # the oracle flattens NCHW (its FC rows are in that order)
+    return np.ascontiguousarray(x)
+
+
+def device_quant(eng, net):
+    """Which conv / FC layers of the compiled net run on bf16 MFMA operands, read off its launches, in the form
+    oracle.torch_ref.forward takes as `quant`: {layer index: dict(fwd=, dgrad=, wgrad=, pin=)}.  `pin` is the device's own rounded
+    forward operand of the layer (bf16 values as float32), rebuilt from the tensors the engine holds; `pin_dy` the rounded gradient
+    w.r.t. its output, the operand of its backward products."""
+    from oracle import layers as L
+    by_num = {l.layerNum: (i, l) for i, l in enumerate(net.layers)}
+    roles = {'conv3x3_': 'fwd', 'conv1x1_': 'fwd', 'fc_': 'fwd', 'dgrad3x3_': 'dgrad', 'dgrad1x1_': 'dgrad', 'fc_dgrad_': 'dgrad',
+             'wgrad1x1_': 'wgrad', 'wgrad3x3_': 'wgrad', 'fc_wgrad_': 'wgrad'}
+    quant = {}
+    for _, l in eng.all_launches():
+        if 'bf16' not in (l.meta or {}).get('kernel', ''):
+            continue
+        for prefix in sorted(roles, key=len, reverse=True):
+            if l.name.startswith(prefix) and l.name[len(prefix):].isdigit():
+                i, layer = by_num[int(l.name[len(prefix):])]
+                quant.setdefault(i, dict(fwd=False, dgrad=False, wgrad=False, pin=None, pin_dy=None))[roles[prefix]] = True
+                break
+        else:
+            raise AssertionError("a bf16 launch the oracle cannot place: %r" % (l.name,))
+    for i, q in quant.items():
+        io = eng.layer_io[id(net.layers[i])]
+        if q['fwd']:
+            q['pin'] = L.bf16_round(_activated_operand(io['in_view']))
+        if (q['dgrad'] or q['wgrad']) and io['out'].grad is not None:
+            # the gradient w.r.t. the layer's output as the backward kernels read it (call after the backward pass has run)
+            g = io['out'].grad.get().astype(np.float32)
+            q['pin_dy'] = L.bf16_round(np.ascontiguousarray(np.moveaxis(g, -1, 1)) if g.ndim == 4 else g)
+    return quant

@@ -76,3 +76,40 @@ def test_plan_runner_modes_train_the_same_net_on_the_gpu():
         assert rc == 0, err[-3000:]
         costs[name] = json.loads([l for l in out.splitlines() if l.startswith('{')][0])['config']['final_cost']
     assert len(set(costs.values())) == 1 and costs['default'] > 0, costs
+
+
+def test_ablation_variable_is_refused_and_knobs_are_stamped():
+    """DPP_WHATIF_SKIP drops launches from the timed plan (tools/whatif.sh): bench.py must not report a number with it set unless told
+    so, and any other DPP_* experiment variable present in the environment is recorded in the output line."""
+    args = ['--batch', '4', '--size', '32', '--steps', '1', '--warmup', '0', '--no-cpu-baseline']
+    rc, out, err = _bench(args, env=dict(DPP_BENCH_EMU='1', DPP_WHATIF_SKIP='bn_finalize'))
+    assert rc != 0 and 'DPP_WHATIF_SKIP' in (out + err) and not [l for l in out.splitlines() if l.startswith('{')]
+    rc, out, err = _bench(args, env=dict(DPP_BENCH_EMU='1', DPP_EXPERIMENT='1', DPP_KSPLIT='0'))
+    assert rc == 0, err[-3000:]
+    res = json.loads([l for l in out.splitlines() if l.startswith('{')][0])
+    assert res['config']['knobs'] == {'DPP_EXPERIMENT': '1', 'DPP_KSPLIT': '0'} and res['config']['ablation'] is None
+    rc, out, err = _bench(args, env=dict(DPP_BENCH_EMU='1'))
+    assert rc == 0 and json.loads([l for l in out.splitlines() if l.startswith('{')][0])['config']['knobs'] is None
+
+
+def test_cascade_workload_control_flow():
+    """`--workload cascade` (BASELINE configs[4]) at a toy size on the emulator: frames -> refinement cascade -> crops + labels ->
+    train step, pipelined and inline, end on the same cost."""
+    costs = {}
+    for flag in ([], ['--augment-inline']):
+        rc, out, err = _bench(['--workload', 'cascade', '--batch', '2', '--size', '32', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'] + flag,
+                              env=dict(DPP_BENCH_EMU='1'))
+        assert rc == 0, err[-3000:]
+        res = json.loads([l for l in out.splitlines() if l.startswith('{')][0])
+        assert 'cascade' in res['config']['workload'] and 'cpu_baseline' not in res
+        costs[bool(flag)] = res['config']['final_cost']
+    assert costs[True] == costs[False] and costs[True] > 0
+
+
+@pytest.mark.gpu
+def test_cascade_workload_on_the_gpu_full_size():
+    """configs[4] on one GPU as bench.py times it: 128 frames of 640x480 per step, 256x256 crops, bf16."""
+    rc, out, err = _bench(['--workload', 'cascade', '--size', '256', '--dtype', 'bf16', '--steps', '4', '--warmup', '2', '--no-cpu-baseline'], timeout=900)
+    assert rc == 0, err[-3000:]
+    res = json.loads([l for l in out.splitlines() if l.startswith('{')][0])
+    assert res['value'] > 1000 and res['dtype'] == 'bf16' and res['config']['final_cost'] > 0

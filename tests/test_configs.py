@@ -119,11 +119,12 @@ def test_config5_forward_256x256_within_1e3_mm():
     assert np.abs(out - ref).max() * MM < 1e-3
 
 
-def test_config5_bf16_forward_error_against_fp32_is_bounded():
-    """configs[4]'s arithmetic: bf16 MFMA operands in the 3x3 convolutions and FC1, f32 accumulation, on a calibrated net at
-    256x256 (FC1 65 536 x 1 024).  SURVEY.md section 8(d): parity is REPORTED against the fp32 path, not held to the 1e-3 mm bar;
-    the bound here is what keeps the option honest (millimetres on a 300 mm cube: three decimal digits per rounded operand), and the bf16 kernels must
-    have run (the result differs from fp32)."""
+def test_config5_bf16_forward_matches_the_bf16_oracle_and_reports_its_error():
+    """configs[4]'s arithmetic at 256x256 (FC1 65 536 x 1 024), deterministic forward on a calibrated net: the device against the
+    float64 oracle that rounds the SAME operands (the 3x3 convolutions' and FC1's) to bfloat16 -- the kernels' arithmetic, held to
+    0.05 mm (unpinned: a few operands in 1e5 round to the other bf16 neighbour in float32 and float64) -- and the distance of the
+    bf16 result from the fp32 path, which SURVEY.md section 8(d) asks to REPORT: measured 2-4 mm max on this net, bounded at 1.5x."""
+    from tests.pinning import device_quant
     rt = get_runtime('hip')
     R.set_default_runtime(rt)
     net, onet, P = make_net(rt, 1, 2, 256, 14, 3)
@@ -134,27 +135,32 @@ def test_config5_bf16_forward_error_against_fp32_is_bounded():
     assert any(l.fn is rt.lib.dpp_conv3x3_bf16 for _, l in [('fwd', o) for o in e16.fwd.launches()])
     assert any(l.fn is rt.lib.dpp_fc_gemm and l.args[1] == 1 for l in e16.fwd.launches())
     o32, o16 = e32.forward(x), e16.forward(x)
-    ref = nets.compute_output(onet, nets.cast_params(P, np.float64), x.astype(np.float64))
+    P64 = nets.cast_params(P, np.float64)
+    ref = nets.compute_output(onet, P64, x.astype(np.float64))
     assert np.abs(o32 - ref).max() * MM < 1e-3                 # the fp32 path keeps the bar
+    rounded = set(i for i, q in device_quant(e16, net).items() if q['fwd'])
+    ref16 = nets.compute_output(onet, P64, x.astype(np.float64), bf16=rounded)
+    err_oracle = np.abs(o16 - ref16).max() * MM
     err_mm = np.abs(o16 - o32).max() * MM
-    print('bf16 vs fp32 forward error at 256x256: %.4f mm (max), %.4f mm (mean)' % (err_mm, np.abs(o16 - o32).mean() * MM))
-    assert 1e-4 < err_mm < 10.0, err_mm                        # measured: 4.1 mm max on this net (bf16 keeps 8 bits of mantissa)
+    print('bf16 forward at 256x256: %.4f mm from the bf16 oracle; %.4f mm (max), %.4f mm (mean) from the fp32 path' % (
+        err_oracle, err_mm, np.abs(o16 - o32).mean() * MM))
+    assert err_oracle < 0.05, err_oracle
+    assert 1e-4 < err_mm < 6.2, err_mm                         # 1.5 x the 4.1 mm measured on this net (bf16 keeps 8 bits of mantissa)
 
 
-def test_config5_bf16_train_step_runs_and_tracks_fp32():
-    """One bs32 train step at 256x256 in both precisions from the same weights: costs agree to a few percent, the bf16 update
-    is finite and of ADAM's size."""
+def test_config5_bf16_train_step_gradients_match_the_bf16_oracle_at_256():
+    """bs32 at 256x256, bf16: forward at 1e-3 mm, cost at 1e-5 and EVERY parameter gradient at 2e-4 of its tensor's scale against the
+    oracle that rounds the same operands in each pass (tests/test_engine.py:bf16_gradients_vs_pinned_oracle), then one ADAM step."""
+    from tests.test_engine import bf16_gradients_vs_pinned_oracle
     rt = get_runtime('hip')
     B = 32
+    net, onet, P = make_net(rt, 0, B, 256, 1, 30, calib_batch=4)
     rng = np.random.RandomState(8)
     x = nets.synthetic_crops(rng, B, 256, 256, np.float32)
     y = rng.normal(0, 0.3, (B, 30)).astype(np.float32)
-    costs = {}
-    for bf in (False, True):
-        net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, nChan=1, wIn=256, hIn=256, batchSize=B, numJoints=1, nDims=30))
-        eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), bf16=bf)
-        w0 = eng.store.w.get().copy()
-        costs[bf] = eng.train_step(x, y, 1e-3)
-        step = eng.store.w.get() - w0
-        assert np.isfinite(step).all() and np.abs(step).max() <= 1e-3 * (1 + 1e-3) + 1e-6
-    assert abs(costs[True] - costs[False]) < 0.05 * abs(costs[False]), costs
+    eng, quant, _, _ = bf16_gradients_vs_pinned_oracle(rt, net, onet, P, x, y)
+    assert len(quant) == 21                                    # twenty 3x3 convolutions and FC1
+    w0 = eng.store.w.get().copy()
+    cost = eng.train_step(x, y, 1e-3)
+    step = eng.store.w.get() - w0
+    assert np.isfinite(cost) and np.isfinite(step).all() and np.abs(step).max() <= 1e-3 * (1 + 1e-3) + 1e-6

@@ -69,6 +69,19 @@ def test_train_gradients_match_oracle_at_benchmarked_batch_128():
     assert n_fc == 3 or (128, 64) in tiles          # FC1 on the three-stage weight-streaming kernel (default) or on dpp_gemm's 128 x 64 tile
 
 
+def test_bf16_train_gradients_match_the_bf16_oracle_at_benchmarked_batch_128():
+    """`bench.py --dtype bf16` at its own size (bs128, 128x128): every gradient of the bf16 step at the 2e-4 bar against the oracle
+    that rounds the same operands to bfloat16 in each pass, on the device's own decisions and rounded operands."""
+    from tests.test_engine import bf16_gradients_vs_pinned_oracle
+    rt = get_runtime('hip')
+    B = 128
+    net, onet, P = make_net(rt, 0, B, 128, 1, 30, calib_batch=8)
+    rng = np.random.RandomState(17)
+    x = nets.synthetic_crops(rng, B, 128, 128, np.float32)
+    y = rng.normal(0, 0.3, (B, 30)).astype(np.float32)
+    bf16_gradients_vs_pinned_oracle(rt, net, onet, P, x, y)
+
+
 def test_every_bs128_gemm_instantiation_against_float64():
     """(M, N, K, layouts, tile, split-K, prologue / epilogue flags) exactly as the bs128 forward / backward plans emit them,
     each re-run stand-alone on random operands (tests/gemm_cases.py)."""

@@ -104,6 +104,46 @@ def test_icvl_reader(backend, tmp_path):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+def test_icvl_reader_with_refinement_net(backend, tmp_path):
+    """loadSequence(docom=True) with `di.refineNet` set (the 'comref' data of main_nyu_posereg_embedding.py, importers.py:382-396):
+    every frame goes crop -> CoM -> ScaleNet -> crop.  The chunked device cascade equals the per-frame HandDetector.cropArea3D."""
+    from net.scalenet import ScaleNet, ScaleNetParams
+    from util.handdetector import HandDetector
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    cam, cube = A.Camera.icvl(), (250, 250, 250)
+    frames, gt3D, gtuvd = _frames_and_joints(cam, 3, 16, 240, 320, (250., 250., 250.), 0, 2)
+    base = str(tmp_path / 'ICVL')
+    os.makedirs(os.path.join(base, 'Depth', 'a'), exist_ok=True)
+    lines = []
+    for i in range(3):
+        rel = 'a/image_{:04d}.png'.format(i)
+        Image.fromarray(frames[i].astype(np.uint16)).save(os.path.join(base, 'Depth', rel))
+        lines.append(rel + ' ' + ' '.join('%.4f' % v for v in gtuvd[i].reshape(-1)) + ' \n')
+    with open(os.path.join(base, 'train.txt'), 'w') as f:
+        f.writelines(lines)
+    net = ScaleNet(np.random.RandomState(23455), cfgParams=ScaleNetParams(type=1, batchSize=2, numJoints=1, nDims=3))
+    for i, l in enumerate(net.layers):
+        if hasattr(l, 'b'):
+            l.b.set_value(np.random.RandomState(i).normal(0, 0.05, l.b.get_value().shape).astype(np.float32))
+    net.setDeterministic()
+    imp = ICVLImporter(base, useCache=False)
+    imp.refineNet = net
+    seq = imp.loadSequence('train', docom=True)
+    assert len(seq.data) == 3
+    for i, fr in enumerate(seq.data):
+        hd = HandDetector(frames[i].copy(), abs(imp.fx), abs(imp.fy), importer=imp, refineNet=net)
+        c, M, com = hd.cropArea3D(com=fr.gtorig[imp.crop_joint_idx], size=cube, docom=True)
+        np.testing.assert_allclose(fr.com, imp.jointImgTo3D(com), rtol=0, atol=1e-3)
+        assert (fr.dpt != c).mean() < 1e-3 and fr.dpt.shape == (128, 128)
+        np.testing.assert_allclose(fr.gt3Dcrop, fr.gt3Dorig - fr.com, rtol=0, atol=1e-5)
+        # the refinement moved the centre away from plain docom
+        _, _, com_plain = HandDetector(frames[i].copy(), abs(imp.fx), abs(imp.fy), importer=imp).cropArea3D(
+            com=fr.gtorig[imp.crop_joint_idx], size=cube, docom=True)
+        assert np.abs(np.asarray(com) - np.asarray(com_plain)).max() > 1e-3
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_nyu_reader(backend, tmp_path):
     R.set_default_runtime(get_runtime(backend))
     cam, cube = A.Camera.nyu(), (300, 300, 300)

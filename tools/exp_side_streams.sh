@@ -1,3 +1,4 @@
+export DPP_EXPERIMENT=1      # the engine reads its experiment knobs only with this set (hipdp/engine.py: knob)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02s; mkdir -p $O
 python -m pytest tests/test_data_parallel.py -m gpu -x -q > $O/pytest_dp.txt 2>&1; tail -3 $O/pytest_dp.txt

@@ -1,4 +1,5 @@
 # Tail-shortening knobs against the bench step time:  gpurun -- 'bash tools/exp_tail.sh'
+export DPP_EXPERIMENT=1      # the engine reads its experiment knobs only with this set (hipdp/engine.py: knob)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02t; mkdir -p $O
 python -m pytest tests/test_engine.py -m gpu -x -q -k "early" > $O/pytest_early.txt 2>&1; tail -3 $O/pytest_early.txt

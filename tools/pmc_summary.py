@@ -66,6 +66,12 @@ def main():
         js = {key: dict(launches_per_step=calls / steps, bytes_per_launch=t / calls * 1e6) for key, (calls, t) in fam.items()}
         js['_total_bytes_per_step'] = tot / steps * 1e6
         js['_source'] = 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), calibrated on adam_kernel'
+        # fingerprint of the kernel sources of the tree this ran in (= the tree that was profiled): bench.py only quotes the file for
+        # a build of the same sources
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        js['_csrc_sha16'] = bench.csrc_sha16()
         with open(sys.argv[sys.argv.index('--json') + 1], 'w') as fh:
             json.dump(js, fh, indent=1, sort_keys=True)
 
