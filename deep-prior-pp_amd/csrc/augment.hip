@@ -39,6 +39,7 @@ struct AugRec {                // per-sample record written by prepare, read by 
     float premax;
     float far_v, near_v;       // com_z' +- cz'/2
     float norm_off, norm_div;  // (v - com_z') / (cz'/2)
+    int binarize;              // then < 0.5 -> 0, >= 0.5 -> 1 (augment_poses' binarizeImage, poseregnettrainer.py:255-257)
 };
 
 struct AugCam {
@@ -217,6 +218,7 @@ struct PrepArgs {
     AugCam cam;
     int B, J, dsz;
     int norm01;              // crops normalised to [0, 1] (normZeroOne) instead of [-1, 1]
+    int binarize;            // binarizeImage: the augmented crop is thresholded at 0.5 (bit 1 of the ABI's norm_zero_one argument)
     const float* pca_mean;   // [J*3] or null
     const float* pca_comp;   // [E][J*3]
     int E;
@@ -338,6 +340,7 @@ __device__ void aug_prepare_geometry(const PrepArgs& a, int b, float mx, AugRec&
     r.far_v = (float)far_d; r.near_v = (float)near_d;
     r.norm_off = a.norm01 ? r.near_v : ncom[2];              // nettrainer.py:982-995
     r.norm_div = a.norm01 ? (float)ncube[2] : (float)(ncube[2] / 2.);
+    r.binarize = a.binarize;
 }
 
 // The label of ONE joint j under the augmentation described by lc (the per-joint bodies of moveCoM / rotateHand / scaleHand's
@@ -465,7 +468,9 @@ __device__ __forceinline__ float aug_warp_pixel(const AugRec& r, const float* __
     if (v == 0.0f) v = r.far_v;
     if (v >= r.far_v) v = r.far_v;
     if (v <= r.near_v) v = r.near_v;
-    return (v - r.norm_off) / r.norm_div;
+    v = (v - r.norm_off) / r.norm_div;
+    if (r.binarize) v = v < 0.5f ? 0.0f : 1.0f;
+    return v;
 }
 
 __global__ __launch_bounds__(DPP_THREADS) void augment_warp_kernel(const float* __restrict__ img, const AugRec* __restrict__ rec, int dsz,
@@ -762,7 +767,7 @@ extern "C" int dpp_augment_prepare(const float* img, const float* com3d, const f
     a.mode = mode; a.off = off; a.rot = rot; a.sc = sc; a.mode_table = mode_table; a.n_modes = n_modes;
     a.seed = seed; a.counter = counter; a.counter_dev = counter_dev; a.sigma_com = sigma_com; a.sigma_sc = sigma_sc; a.rot_range = rot_range;
     a.cam.fx = fx; a.cam.fy = fy; a.cam.ux = ux; a.cam.uy = uy; a.cam.flip_y = flip_y;
-    a.B = B; a.J = J; a.dsz = dsz; a.norm01 = norm_zero_one; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
+    a.B = B; a.J = J; a.dsz = dsz; a.norm01 = norm_zero_one & 1; a.binarize = (norm_zero_one >> 1) & 1; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
     a.rec = static_cast<AugRec*>(records); a.out_y = out_y; a.out_mode = out_mode;
     a.sample0 = 0; a.gbatch = (unsigned long long)B;
     DPP_LAUNCH(augment_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
@@ -794,7 +799,7 @@ extern "C" int dpp_augment(const float* img, const float* com3d, const float* cu
     a.mode = mode; a.off = off; a.rot = rot; a.sc = sc; a.mode_table = mode_table; a.n_modes = n_modes;
     a.seed = seed; a.counter = counter; a.counter_dev = counter_dev; a.sigma_com = sigma_com; a.sigma_sc = sigma_sc; a.rot_range = rot_range;
     a.cam.fx = fx; a.cam.fy = fy; a.cam.ux = ux; a.cam.uy = uy; a.cam.flip_y = flip_y;
-    a.B = B; a.J = J; a.dsz = dsz; a.norm01 = norm_zero_one; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
+    a.B = B; a.J = J; a.dsz = dsz; a.norm01 = norm_zero_one & 1; a.binarize = (norm_zero_one >> 1) & 1; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
     a.rec = static_cast<AugRec*>(records); a.out_y = out_y; a.out_mode = out_mode;
     a.sample0 = sample0; a.gbatch = global_batch;
     const int groups = dpp_cdiv(B, 8);             // crops are dealt to XCDs round-robin: 8 per group

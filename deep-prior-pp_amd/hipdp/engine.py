@@ -244,15 +244,24 @@ def _dedupe_specs(specs):
 
 
 def get_store(net, rt, layers):
+    """The device parameter store of `net` (created on first use, rebuilt when the parameter list changed).  A net built as the
+    `twin` of another one (copyLayer = twin.layers[i] for every layer: the same SharedParam objects) lives in THAT net's store --
+    one copy of the weights, whichever instance trains or evaluates.  (Each compiled engine owns the gradient buffer during its
+    backward pass: gradients of two twins trained in one step are not summed.)"""
     specs = _dedupe_specs(_param_specs(net, layers))
     names = [p.auto_name for (p, _, _, _) in specs]
-    store = getattr(net, '_param_store', None)
+    owner = net
+    while getattr(owner, '_twin', None) is not None:
+        owner = owner._twin
+    store = getattr(owner, '_param_store', None)
     if store is not None and store.rt is rt and [s['param'].auto_name for s in store.slots] == names and \
             [s['info'] for s in store.slots] == [i for (_, _, i, _) in specs]:
+        net._param_store = store
         return store
     if store is not None:
         store.release()
     store = ParamStore(rt, specs)
+    owner._param_store = store
     net._param_store = store
     return store
 

@@ -413,13 +413,14 @@ def augment_warp(rt, img, records, B, dsz, out, name='augment_warp'):
 
 def augment(rt, img, com3d, cube, Mcrop, gt3d, B, J, dsz, cam, out_x, out_y, records=None, mode=None, off=None, rot=None, sc=None,
             mode_table=None, n_modes=0, seed=0, counter=0, sigma_com=5., sigma_sc=0.02, rot_range=180., pca_mean=None, pca_comp=None,
-            E=0, out_mode=None, counter_dev=None, ticket=None, sample0=0, global_batch=0, splits=0, norm_zero_one=False, name='augment'):
+            E=0, out_mode=None, counter_dev=None, ticket=None, sample0=0, global_batch=0, splits=0, norm_zero_one=False, binarize=False,
+            name='augment'):
     """prepare + warp as one launch (dpp_augment); with `ticket` it also advances the device draw counter."""
     fx, fy, ux, uy, flip = cam
     return Launch(rt.lib.dpp_augment,
                   (img.ptr, com3d.ptr, cube.ptr, Mcrop.ptr, gt3d.ptr, B, J, dsz, _p(mode), _p(off), _p(rot), _p(sc), _p(mode_table),
                    n_modes, seed, counter, float(sigma_com), float(sigma_sc), float(rot_range), float(fx), float(fy), float(ux),
-                   float(uy), int(flip), int(bool(norm_zero_one)), _p(pca_mean), _p(pca_comp), E, _p(records), out_x.ptr, out_y.ptr,
+                   float(uy), int(flip), int(bool(norm_zero_one)) | (2 if binarize else 0), _p(pca_mean), _p(pca_comp), E, _p(records), out_x.ptr, out_y.ptr,
                    _p(out_mode), _p(counter_dev), _p(ticket), int(sample0), int(global_batch), int(splits)),
                   (img, com3d, cube, Mcrop, gt3d, mode, off, rot, sc, mode_table, pca_mean, pca_comp, records, out_x, out_y, out_mode,
                    counter_dev, ticket), name, dict(kernel='augment', flops=40.0 * B * dsz * dsz, bytes=8.0 * B * dsz * dsz))

@@ -26,6 +26,17 @@ class CollectiveOp(object):
         self.fn()
 
 
+class _SideJoin(object):
+    """Stand-in for the work object of an asynchronous collective whose result was written on the side stream: wait() makes the
+    current (main) stream wait for that stream."""
+
+    def __init__(self, rt):
+        self.rt = rt
+
+    def wait(self):
+        self.rt.main_wait_side()
+
+
 class DataParallel(object):
     def __init__(self, rt, sync_bn=False):
         import torch.distributed as dist
@@ -36,10 +47,25 @@ class DataParallel(object):
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.sync_bn = bool(sync_bn)
+        # gloo with device tensors (several ranks sharing ONE MI355X: the control-flow / parity tests of the GPU tier,
+        # DPP_DIST_BACKEND=gloo): the collectives run on host copies.  Blocking, correct against the HIP streams (the device -> host
+        # copy waits for the stream it is issued on), and nothing a measured run ever takes: bench.py insists on RCCL.
+        self.host_staged = dist.get_backend() == 'gloo' and not getattr(rt, 'is_emulator', False)
+
+    def _collective(self, fn, *bufs):
+        """fn(*tensors) on the buffers -- directly (RCCL on device memory; gloo on the emulator's host memory) or on host copies that
+        are written back (gloo, device memory)."""
+        ts = [self.rt.tensor(b) for b in bufs]
+        if not self.host_staged:
+            return fn(*ts)
+        hs = [t.cpu() for t in ts]
+        out = fn(*hs)
+        for t, h in zip(ts, hs):
+            t.copy_(h)
+        return out
 
     def allreduce_sum_op(self, buf, name='allreduce_sum'):
-        t = self.rt.tensor(buf)
-        return CollectiveOp(lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM), name)
+        return CollectiveOp(lambda: self._collective(lambda t: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM), buf), name)
 
     def allreduce_sum_async_op(self, buf, handle, name='allreduce_sum_async'):
         """Start summing `buf` over the ranks WITHOUT blocking the stream the step continues on: issued from the side
@@ -49,7 +75,16 @@ class DataParallel(object):
 
         def start():
             side = getattr(self.rt, '_side', None)
-            if side is not None and getattr(self.rt, 'has_side_stream', False):
+            two = side is not None and getattr(self.rt, 'has_side_stream', False)
+            if self.host_staged:
+                if two:
+                    with self.rt.torch.cuda.stream(side):
+                        self._collective(lambda h: self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM), buf)
+                    handle[0] = _SideJoin(self.rt)
+                else:
+                    self._collective(lambda h: self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM), buf)
+                    handle[0] = None
+            elif two:
                 with self.rt.torch.cuda.stream(side):
                     handle[0] = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
             else:
@@ -68,10 +103,36 @@ class DataParallel(object):
         """dst (world * src.size floats) <- concatenation over ranks of src."""
         ts, td = self.rt.tensor(src), self.rt.tensor(dst)
         assert td.numel() == self.world * ts.numel()
-        return CollectiveOp(lambda: self.dist.all_gather_into_tensor(td, ts), name)
+        return CollectiveOp(lambda: self._collective(lambda d, s_: self.dist.all_gather_into_tensor(d, s_), dst, src), name)
 
     def broadcast(self, buf, src=0):
-        self.dist.broadcast(self.rt.tensor(buf), src=src)
+        self._collective(lambda t: self.dist.broadcast(t, src=src), buf)
+
+    def mean_scalars(self, values):
+        """Mean over the ranks of a few host floats (validation costs / errors of equally sized shards); a collective."""
+        import torch
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+        if self.dist.get_backend() == 'nccl':
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) / self.world for v in t.cpu()]
+
+    def shard(self, data, batch, pad_rng_seed=None):
+        """This rank's rows of a per-sample array under the minibatch layout of SURVEY.md section 8(e): the global minibatch k is rows
+        [k*G*B, (k+1)*G*B) and rank r owns its contiguous slice [r*B, (r+1)*B).  pad_rng_seed None: the array is cut to whole
+        global minibatches (validation data: the reference drops the remainder too, nettrainer.py:793); otherwise it is first padded
+        to whole global minibatches with rows drawn by RandomState(seed) (alignData's rule, nettrainer.py:365-413)."""
+        import numpy as np
+        data = np.asarray(data)
+        G, B = self.world, int(batch)
+        n, gb = data.shape[0], G * B
+        if pad_rng_seed is None:
+            data = data[:(n // gb) * gb]
+        elif n % gb:
+            rng = np.random.RandomState(pad_rng_seed)
+            fill = np.stack([data[rng.randint(0, n)] for _ in range(gb - n % gb)])
+            data = np.concatenate([data, fill], axis=0)
+        return np.ascontiguousarray(data.reshape((-1, G, B) + data.shape[1:])[:, self.rank].reshape((-1,) + data.shape[1:]))
 
     def broadcast_store(self, store):
         """Replicas start from rank 0's parameters and running statistics."""

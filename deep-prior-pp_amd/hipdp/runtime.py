@@ -153,6 +153,10 @@ class TorchHipRuntime(object):
 
             def wait(self_inner):
                 t.cuda.current_stream(self.device).wait_event(self_inner.ev)
+
+            def synchronize(self_inner):
+                """Block the HOST until the copy has read its source (before the host buffer is rewritten)."""
+                self_inner.ev.synchronize()
         return _Copy(ev, src)
 
     @property

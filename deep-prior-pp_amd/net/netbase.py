@@ -55,6 +55,7 @@ class NetBase(object):
         self.inputVar = inputVar
         self.cfgParams = cfgParams
         self.rng = rng
+        self._twin = twin                 # layers built with copyLayer = twin.layers[i] (netbase.py:117): one parameter store for both
         self.layers = []
         for i, layerParam in enumerate(cfgParams.layers):
             if i == 0:

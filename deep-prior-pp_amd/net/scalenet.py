@@ -52,10 +52,10 @@ class ScaleNet(NetBase):
             raise Exception("Cannot create a Net without config parameters (ie. cfgParams==None)")
         if inputVar is not None:
             raise Exception("Do not give inputVar, created inline")
-        if twin is not None:
-            # a second net instance on the first one's parameters (siamese training; no shipped main uses it): the parameter store
-            # is per net here
-            raise NotImplementedError("twin nets (scalenet.py:176) are not provided; weight sharing between the towers is (shared_conv)")
+        # twin: a second net instance on ANOTHER net's parameters (scalenet.py:178: every layer is built with copyLayer =
+        # twin.layers[i]) -- e.g. the same regressor at another batch size.  Both instances then run on one device parameter store
+        # (hipdp.engine.get_store follows `_twin`).
+        self._twin = twin
         self._params_filter = []
         self._weights_filter = []
         self.inputVar = [tensor4('x{}'.format(i)) for i in range(cfgParams.numInputs)]
@@ -74,7 +74,9 @@ class ScaleNet(NetBase):
             ctor = _LAYER_CLASSES[layerParam.__class__.__name__[:-11]]           # '<X>LayerParams' -> '<X>'
             # shared_conv: towers 2 and 3 run on the FIRST tower's filters and biases (scalenet.py:177-178) -- same shapes, the
             # towers differ in pooling only
-            cl = self.layers[i % cfgParams.inpConv] if (cfgParams.shared_conv is True and cfgParams.inpConv - 1 < i < nConv) else None
+            cl = None if twin is None else twin.layers[i]
+            if cl is None and cfgParams.shared_conv is True and cfgParams.inpConv - 1 < i < nConv:
+                cl = self.layers[i % cfgParams.inpConv]
             self.layers.append(ctor(rng, inputVar=inp, cfgParams=layerParam, copyLayer=cl, layerNum=len(self.layers)))
         self.output = self.layers[-1].output
         self.load(self.cfgParams.loadFile)

@@ -88,13 +88,24 @@ class NetTrainer(object):
     SYNC_BATCH_FINISHED = 'batch_finished'
     SYNC_LOAD_FINISHED = 'load_finished'
 
-    def __init__(self, cfgParams, memory_factor, subfolder='./eval/', numChunks=1, runtime=None):
+    def __init__(self, cfgParams, memory_factor, subfolder='./eval/', numChunks=1, runtime=None, dp=None):
+        """dp: None, a hipdp.parallel.DataParallel, or 'env' (torch.distributed from RANK / WORLD_SIZE / MASTER_*; one process per
+        GPU, RCCL).  With G ranks `cfgParams.batch_size` is the PER-GPU batch and the global minibatch has G x that many samples:
+        every rank keeps its contiguous slice of every global minibatch of the arrays handed to setData / addManagedData /
+        addStaticData('val_*'), augments it on its own GPU with draws keyed by the global sample index,
+        the gradients are all-reduced inside `train_model`, validation values are averaged over the ranks and rank 0 writes the
+        snapshots.  The reference is single-device (nettrainer.py:778-907 is the loop this wraps)."""
         self.subfolder = subfolder
         self.cfgParams = cfgParams
         self.rng = numpy.random.RandomState(23455)
         if not isinstance(cfgParams, NetTrainerParams):
             raise ValueError("cfgParams must be an instance of NetTrainerParams")
         self.rt = runtime or default_runtime()
+        if dp == 'env':
+            from hipdp import parallel
+            _, world = parallel.init_from_env()
+            dp = parallel.DataParallel(self.rt) if world > 1 else None
+        self.dp = dp
         self.memorySize = self._free_device_mb() / float(memory_factor)    # MB, nettrainer.py:100-112
         if cfgParams.para_load is True and numChunks == 1:
             raise ValueError("para_load is True but numChunks == 1, so we do not need para_load!")
@@ -145,15 +156,18 @@ class NetTrainer(object):
         if not isinstance(data, dict):
             raise ValueError("Error: expected dictionary for data!")
         for key in data:
-            self._publish(key, numpy.asarray(data[key]))
+            val = numpy.asarray(data[key])
+            if self.dp is not None and key.startswith('val_') and val.ndim >= 1 and val.shape[0] == getattr(self, '_global_val_n', -1):
+                val = self.dp.shard(val, self.cfgParams.batch_size)        # per-sample validation arrays follow val_data_x
+            self._publish(key, val)
 
     def addManagedData(self, data):
         if not isinstance(data, dict):
             raise ValueError("Error: expected dictionary for data!")
         for key in data:
-            if data[key].shape[0] != self.numTrainSamplesMB:
+            if data[key].shape[0] != (self.numTrainSamplesMB if self.dp is None else self._global_train_n):
                 raise ValueError("Number of samples must be the same as number of labels.")
-            self._publish_training(key, numpy.asarray(data[key]))
+            self._publish_training(key, self._shard_train(numpy.asarray(data[key])))
             self.trainingVar.append(key)
 
     def _publish_training(self, key, data):
@@ -188,9 +202,25 @@ class NetTrainer(object):
         out[...] = arr
         return out
 
+    def _shard_train(self, data):
+        """Data parallel: this rank's slice of every global minibatch, the global array first padded to whole global minibatches by
+        alignData's rule (rows drawn by RandomState(n)); single process: the array as it is."""
+        if self.dp is None:
+            return data
+        return self.dp.shard(data, self.cfgParams.batch_size, pad_rng_seed=data.shape[0] if self.cfgParams.pad_random else None)
+
+    def _dp_layout(self):
+        """(G, rank, B) for the augmenter: how this rank's samples sit in the global macro-batch (None: single process)."""
+        return None if self.dp is None else (self.dp.world, self.dp.rank, self.cfgParams.batch_size)
+
     def setData(self, train_data, train_y, val_data, val_y, max_train_size=0):
         if (train_data.shape[0] != train_y.shape[0]) or (val_data.shape[0] != val_y.shape[0]):
             raise ValueError("Number of samples must be the same as number of labels.")
+        if self.dp is not None:
+            self._global_train_n, self._global_val_n = train_data.shape[0], val_data.shape[0]
+            max_train_size = max_train_size / float(self.dp.world)
+            train_data, train_y = self._shard_train(train_data), self._shard_train(train_y)
+            val_data, val_y = self.dp.shard(val_data, self.cfgParams.batch_size), self.dp.shard(val_y, self.cfgParams.batch_size)
         self.trainSize = max(train_data.nbytes, train_y.nbytes, max_train_size) / 1024. / 1024.
         self.numTrainSamplesMB = train_data.shape[0]
         self.numTrainSamples = self.numTrainSamplesMB
@@ -361,6 +391,7 @@ class NetTrainer(object):
         if self._prefetched is not None and self._prefetched[0] == macro_idx:
             for h in self._prefetched[1]:
                 h.wait()                                     # the main stream waits for the copy stream's event
+            self._last_paged_in = self._prefetched[1]        # (_para_swap makes the HOST wait for them before it rewrites their source)
             self._src, self._src_next = self._src_next, self._src
         else:
             for var in self.trainingVar:
@@ -427,6 +458,17 @@ class NetTrainer(object):
             return
         (ci, msg) = self.load_send_queue.get()
         assert msg == self.SYNC_LOAD_FINISHED
+        # the asynchronous upload of a prefetched macro-batch may still be READING the pinned host arrays that are rewritten below:
+        # the host waits for those copies (stream-side waits do not protect host memory)
+        if self._prefetched is not None:
+            for h in self._prefetched[1]:
+                sync = getattr(h, 'synchronize', None)
+                if sync is not None:
+                    sync()
+        for h in getattr(self, '_last_paged_in', ()):
+            sync = getattr(h, 'synchronize', None)
+            if sync is not None:
+                sync()
         nmb, spm = self.getNumMacroBatches(), self.getNumSamplesPerMacroBatch()
         for var in self.trainingVar:
             if not hasattr(self, var):
@@ -497,10 +539,11 @@ class NetTrainer(object):
             train_costs.append(minibatch_avg_cost)
 
         while self.epoch < n_epochs:
-            if self.epoch % self.cfgParams.snapshot_last == 0:
+            writer = self.dp is None or self.dp.rank == 0          # replicas hold the same weights: rank 0 writes the snapshots
+            if self.epoch % self.cfgParams.snapshot_last == 0 and writer:
                 self.poseNet.save(self.subfolder + '/net_last.pkl')
             if self.cfgParams.snapshot_freq is not None:
-                if self.epoch % self.cfgParams.snapshot_freq == 0:
+                if self.epoch % self.cfgParams.snapshot_freq == 0 and writer:
                     self.poseNet.save(self.subfolder + '/net_{}.pkl'.format(self.epoch))
             if self.cfgParams.pre_epoch_fn is not None:
                 getattr(self, self.cfgParams.pre_epoch_fn)()

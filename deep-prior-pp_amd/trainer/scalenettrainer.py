@@ -21,9 +21,9 @@ class ScaleNetTrainerParams(NetTrainerParams):
 
 
 class ScaleNetTrainer(PoseRegNetTrainer):
-    def __init__(self, poseNet=None, cfgParams=None, rng=None, subfolder='./eval/', numChunks=1, runtime=None):
+    def __init__(self, poseNet=None, cfgParams=None, rng=None, subfolder='./eval/', numChunks=1, runtime=None, dp=None):
         from trainer.nettrainer import NetTrainer
-        NetTrainer.__init__(self, cfgParams, 8, subfolder, numChunks, runtime=runtime)         # memory factor 8, :61
+        NetTrainer.__init__(self, cfgParams, 8, subfolder, numChunks, runtime=runtime, dp=dp)         # memory factor 8, :61
         self.poseNet = poseNet
         self.rng = rng if rng is not None else self.rng
         if not isinstance(cfgParams, ScaleNetTrainerParams):
@@ -41,18 +41,16 @@ class ScaleNetTrainer(PoseRegNetTrainer):
         self.updates = opt.ADAM(self.cfgParams.learning_rate)
         print("compiling train_model() ... ")
         wd = self.cfgParams.weightreg_factor if not self.poseNet.hasDropout() else 0.0
-        self.train_engine = engine.CompiledNet(self.poseNet, train=True, runtime=self.rt, loss=self.loss_cfg, weight_decay=wd)
-        self.eval_engine = engine.CompiledNet(self.poseNet, train=False, runtime=self.rt, loss=self.loss_cfg, weight_decay=wd)
+        self._compile_engines(wd)
         print("done.")
         B = self.cfgParams.batch_size
         te = self.train_engine
-        self._allreduce = None
 
         def launch(index, learning_rate):
             for t, src in zip(te.x_ins, self._inputs('train', index)):       # givens_train of scalenettrainer.py:148-151
                 self.rt.copy(t.buf, src)
             self.rt.copy(te.y_in, self.train_data_y.rows(index * B, B))
-            te.train_step_device(learning_rate, allreduce=self._allreduce)
+            self._train_step(learning_rate)
 
         def train_model(index, learning_rate):
             launch(index, learning_rate)
@@ -74,7 +72,7 @@ class ScaleNetTrainer(PoseRegNetTrainer):
         self.rt.copy(ee.y_in, ys.rows(index * B, B))
         ee.fwd.run(self.rt)
         ee.lossplan.run(self.rt)
-        return float(ee.cost.get()[0]), float(ee.err.get()[0])
+        return self._reduce_eval(float(ee.cost.get()[0]), float(ee.err.get()[0]))
 
     # ---- validate ---------------------------------------------------------------------------------------
     def setupValidate(self):
@@ -113,17 +111,22 @@ class ScaleNetTrainer(PoseRegNetTrainer):
         src_x = self.source_rows('train_data_x', idxs, macro_idx, last)
         src_y = self.source_rows('train_data_y', idxs, macro_idx, last)
         com, cube, M = (self.source_rows(v, idxs, macro_idx, last) for v in ('train_data_com', 'train_data_cube', 'train_data_M'))
-        key = (src_x.ptr, tidxs[0], n)
-        if self._augmenter is None or self._augmenter[0] != key:
+        akey = (n, H, tuple(args['aug_modes']))          # one augmenter for the run, launch lists per source buffer (see PoseRegNetTrainer)
+        if self._augmenter is None or self._augmenter[0] != akey:
             aug = DeviceAugmenter(self.rt, args['di'], args['aug_modes'], n, 1, dsz=H, proj=None, sigma_com=args.get('sigma_com'),
                                   sigma_sc=args.get('sigma_sc'), rot_range=args.get('rot_range'), seed=int(self.rng.randint(1 << 30)),
                                   normZeroOne=bool(args.get('normZeroOne')))
+            self._augmenter = (akey, aug, {})
+        aug, cache = self._augmenter[1], self._augmenter[2]
+        key = (src_x.ptr, tidxs[0], n)
+        if key not in cache:
             x_out = self.train_data_x.rows(tidxs[0], n).reshape(n, H, W)
             gt = self.rt.alloc((n, 1, 3), zero=False)
             launches = [ops.rowscale(self.rt, src_y.reshape(n, 3), cube.reshape(n, 3), 2, 0.5, gt.reshape(n, 3), n, 3)]
-            launches += aug.build(src_x.reshape(n, H, W), com, cube, M.reshape(n, 9), gt, x_out, self.train_data_y.rows(tidxs[0], n))
+            launches += aug.build(src_x.reshape(n, H, W), com, cube, M.reshape(n, 9), gt, x_out, self.train_data_y.rows(tidxs[0], n),
+                                  dp_layout=self._dp_layout())
             for k, name in ((2, 'train_data_x1'), (4, 'train_data_x2')):
                 launches.append(ops.crop_center(self.rt, x_out, n, H, W, getattr(self, name).rows(tidxs[0], n), H // k, W // k))
-            self._augmenter = (key, aug, launches)
-        for op in self._augmenter[2]:
+            cache[key] = launches
+        for op in cache[key]:
             op(self.rt.stream)

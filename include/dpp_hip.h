@@ -261,7 +261,8 @@ int dpp_bernoulli_mask(float* mask, size_t n, float keep, unsigned long long see
  * prepare: per crop, the geometry of HandDetector.moveCoM / rotateHand / scaleHand
  *          (/root/reference/src/util/handdetector.py:678-780): new CoM, crop transform, inverse warp matrix,
  *          z-thresholds, augmented joint labels, PCA-prior projection (poseregnettrainer.py:262) -> records, out_y.
- *          norm_zero_one: the crops are normalised to [0, 1] (normZeroOne, nettrainer.py:948, 982-988) instead of [-1, 1].
+ *          norm_zero_one: bit 0: the crops are normalised to [0, 1] (normZeroOne, nettrainer.py:948, 982-988) instead of [-1, 1];
+ *          bit 1: binarizeImage (poseregnettrainer.py:255-257): the augmented crop is thresholded, < 0.5 -> 0, >= 0.5 -> 1.
  *          mode codes: 0 none, 1 com, 2 rot, 3 sc.  mode == NULL: (mode, off, rot, sc) are drawn on the device from
  *          Philox(seed, counter, sample) with mode = mode_table[u % n_modes].
  * warp:    per pixel, cv2.warpAffine / warpPerspective (NEAREST, constant 0) + recropHand's z-clamp

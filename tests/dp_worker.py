@@ -33,6 +33,12 @@ def main():
         dist.init_process_group(backend='nccl', rank=rank, world_size=world)     # also for a world of one
         assert dist.get_backend() == 'nccl'
         rt = TorchHipRuntime()
+    elif os.environ.get('DPP_WORKER_BACKEND') == 'hip-gloo':      # several gloo ranks sharing the one MI355X (host-staged collectives)
+        import torch
+        from hipdp.runtime import TorchHipRuntime
+        torch.cuda.set_device(0)
+        rank, world = parallel.init_from_env('gloo')
+        rt = TorchHipRuntime()
     else:
         from tests.emu.emu_runtime import EmuRuntime
         rank, world = parallel.init_from_env('gloo')

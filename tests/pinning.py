@@ -84,7 +84,8 @@ def device_quant(eng, net):
     roles = {'conv3x3_': 'fwd', 'conv1x1_': 'fwd', 'fc_': 'fwd', 'dgrad3x3_': 'dgrad', 'dgrad1x1_': 'dgrad', 'fc_dgrad_': 'dgrad',
              'wgrad1x1_': 'wgrad', 'wgrad3x3_': 'wgrad', 'fc_wgrad_': 'wgrad'}
     quant = {}
-    for _, l in eng.all_launches():
+    launches = eng.all_launches() if getattr(eng, 'train', False) else [('fwd', o) for o in eng.fwd.launches()]
+    for _, l in launches:
         if 'bf16' not in (l.meta or {}).get('kernel', ''):
             continue
         for prefix in sorted(roles, key=len, reverse=True):
@@ -98,7 +99,7 @@ def device_quant(eng, net):
         io = eng.layer_io[id(net.layers[i])]
         if q['fwd']:
             q['pin'] = L.bf16_round(_activated_operand(io['in_view']))
-        if (q['dgrad'] or q['wgrad']) and io['out'].grad is not None:
+        if (q['dgrad'] or q['wgrad']) and io['out'].grad is not None and getattr(eng, 'train', False):
             # the gradient w.r.t. the layer's output as the backward kernels read it (call after the backward pass has run)
             g = io['out'].grad.get().astype(np.float32)
             q['pin_dy'] = L.bf16_round(np.ascontiguousarray(np.moveaxis(g, -1, 1)) if g.ndim == 4 else g)

@@ -122,8 +122,7 @@ def test_config5_forward_256x256_within_1e3_mm():
 def test_config5_bf16_forward_matches_the_bf16_oracle_and_reports_its_error():
     """configs[4]'s arithmetic at 256x256 (FC1 65 536 x 1 024), deterministic forward on a calibrated net: the device against the
     float64 oracle that rounds the SAME operands (the 3x3 convolutions' and FC1's) to bfloat16 -- the kernels' arithmetic, held to
-    0.05 mm (unpinned: a few operands in 1e5 round to the other bf16 neighbour in float32 and float64) -- and the distance of the
-    bf16 result from the fp32 path, which SURVEY.md section 8(d) asks to REPORT: measured 2-4 mm max on this net, bounded at 1.5x."""
+    the 1e-3 mm bar on the device's own rounded operands -- and the distance of the bf16 result from the fp32 path, which SURVEY.md section 8(d) asks to REPORT: measured 2-4 mm max on this net, bounded at 1.5x."""
     from tests.pinning import device_quant
     rt = get_runtime('hip')
     R.set_default_runtime(rt)
@@ -138,13 +137,21 @@ def test_config5_bf16_forward_matches_the_bf16_oracle_and_reports_its_error():
     P64 = nets.cast_params(P, np.float64)
     ref = nets.compute_output(onet, P64, x.astype(np.float64))
     assert np.abs(o32 - ref).max() * MM < 1e-3                 # the fp32 path keeps the bar
-    rounded = set(i for i, q in device_quant(e16, net).items() if q['fwd'])
-    ref16 = nets.compute_output(onet, P64, x.astype(np.float64), bf16=rounded)
-    err_oracle = np.abs(o16 - ref16).max() * MM
+    # the oracle that rounds the SAME operands, handed the device's own rounded operands (a few activations in 1e5 round to the other
+    # bf16 neighbour in a float64 evaluation, and one such flip is worth 100 float32 rounding errors: unpinned the two sit 0.6 mm apart)
+    import torch
+    quant = device_quant(e16, net)
+    assert len(quant) == 21 and all(q['pin'] is not None for q in quant.values())
+    with torch.no_grad():
+        T = torch_ref.to_torch(P64, requires_grad=False)
+        ref16, _ = torch_ref.forward(onet, T, torch.tensor(x, dtype=torch.float64), False, quant=quant)
+    err_oracle = np.abs(o16 - ref16.numpy()).max() * MM
+    unpinned = nets.compute_output(onet, P64, x.astype(np.float64), bf16=set(quant))
     err_mm = np.abs(o16 - o32).max() * MM
-    print('bf16 forward at 256x256: %.4f mm from the bf16 oracle; %.4f mm (max), %.4f mm (mean) from the fp32 path' % (
-        err_oracle, err_mm, np.abs(o16 - o32).mean() * MM))
-    assert err_oracle < 0.05, err_oracle
+    print('bf16 forward at 256x256: %.5f mm from the bf16 oracle on the device operands (%.3f mm unpinned); %.4f mm (max), %.4f mm (mean) from '
+          'the fp32 path' % (err_oracle, np.abs(o16 - unpinned).max() * MM, err_mm, np.abs(o16 - o32).mean() * MM))
+    assert err_oracle < 1e-3, err_oracle                        # the bar of the fp32 path
+    assert np.abs(o16 - unpinned).max() * MM < 2.0
     assert 1e-4 < err_mm < 6.2, err_mm                         # 1.5 x the 4.1 mm measured on this net (bf16 keeps 8 bits of mantissa)
 
 

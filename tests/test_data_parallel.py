@@ -101,3 +101,95 @@ def test_rccl_world_of_one_equals_single_process(tmp_path, sync):
             assert np.array_equal(r0['g_%d_%d' % (i, s)], eng.store.read_grad(p)), (i, s)
     eng.train_step(x, y, 1e-3)
     assert np.array_equal(r0['w_last'], net.layers[-1].W.get_value())
+
+
+# ---- data parallelism behind the drop-in API: PoseRegNetTrainer(..., dp=) ---------------------------------------------------------
+def _run_trainer(tmp_path, world, sync, GB, epochs, backend='emu', **extra_env):
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        env = dict(os.environ, DPP_WORKER_BACKEND=backend)
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        if world > 1:
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.update(extra_env)
+        out = os.path.join(str(tmp_path), 'trainer_w%d_r%d_%d.npz' % (world, r, int(sync)))
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_trainer_worker.py'), out, str(int(sync)), str(GB), str(epochs)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        log = p.communicate(timeout=1500)[0].decode()
+        assert p.returncode == 0, log[-4000:]
+    return [np.load(o) for o in outs]
+
+
+def _check_trainer_ranks_against_single_process(ranks, single, G, B, tight):
+    GB = G * B
+    n_pad = single['shard_x'].shape[0]
+    assert n_pad % GB == 0
+    glob = np.arange(n_pad).reshape(-1, G, B)
+    for r, res in enumerate(ranks):
+        rows = glob[:, r].reshape(-1)
+        # the shard is the rank's slice of every global minibatch (padding rows included: the same seeded draws as alignData's)
+        assert np.array_equal(res['shard_x'], single['shard_x'][rows]) and np.array_equal(res['shard_com'], single['shard_com'][rows])
+        vrows = np.arange(single['shard_val'].shape[0]).reshape(-1, G, B)[:, r].reshape(-1)
+        assert np.array_equal(res['shard_val'], single['shard_val'][vrows])
+        # device draws are keyed by the GLOBAL sample index: the augmented crops / labels of the last macro-batch reload are the rows
+        # the single process produced, bit for bit
+        assert np.array_equal(res['aug_x'], single['aug_x'][rows]) and np.array_equal(res['aug_y'], single['aug_y'][rows])
+        assert (res['aug_x'] != res['shard_x']).mean() > 0.005
+    a, b = ranks[0], ranks[1]
+    assert np.array_equal(a['w'], b['w']) and np.array_equal(a['costs'], b['costs']) and np.array_equal(a['val'], b['val'])   # replicas
+    assert bool(a['snapshot'][0]) and not bool(b['snapshot'][0])                 # rank 0 writes the snapshots
+    assert len(a['costs']) == len(single['costs']) and np.all(np.isfinite(a['costs']))
+    # the first minibatch: the same global batch, sync-BN statistics, one cost
+    assert abs(a['costs'][0] - single['costs'][0]) < tight * abs(single['costs'][0]), (a['costs'][0], single['costs'][0])
+    # later steps: ADAM turns round-off-sized gradient differences into +-lr steps (in the reference's float32 graph too)
+    np.testing.assert_allclose(a['costs'], single['costs'], rtol=3e-2)
+    np.testing.assert_allclose(a['val'], single['val'], rtol=3e-2)
+
+
+def test_trainer_on_two_ranks_equals_one_rank_on_the_same_global_batch(tmp_path):
+    """PoseRegNetTrainer(..., dp=DataParallel(sync_bn=True)) on 2 gloo ranks x batch 4 against the plain trainer at batch 8 (emulator)."""
+    ranks = _run_trainer(tmp_path, 2, True, 8, 1)
+    (single,) = _run_trainer(tmp_path, 1, True, 8, 1)
+    _check_trainer_ranks_against_single_process(ranks, single, 2, 4, tight=2e-5)
+
+
+@pytest.mark.gpu
+def test_trainer_two_gloo_ranks_share_the_gpu_and_equal_one_process(tmp_path):
+    """The same on the real kernels: two ranks (gloo, host-staged collectives) sharing the one MI355X against a single HIP process:
+    sharding, global-index augmentation draws, gradient all-reduce (early FC1 bucket from the side stream + the rest), sync-BN
+    all-gathers, replicated ADAM, averaged validation, rank-0 snapshots."""
+    ranks = _run_trainer(tmp_path, 2, True, 16, 2, backend='hip', DPP_DIST_BACKEND='gloo')
+    (single,) = _run_trainer(tmp_path, 1, True, 16, 2, backend='hip')
+    _check_trainer_ranks_against_single_process(ranks, single, 2, 8, tight=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('sync', [False, True])
+def test_two_gloo_ranks_on_one_gpu_gradients(tmp_path, sync):
+    """Engine level, two ranks on the real kernels (DPP_DIST_BACKEND=gloo on one MI355X): with sync-BN the all-reduced gradients equal
+    the single-process HIP gradients on the same global batch at the 2e-4 bar; with local BN the replicas stay bit-identical."""
+    B = 8
+    r0, r1 = _run_ranks(tmp_path, sync=sync, world=2, wd=1e-3, DPP_WORKER_BACKEND='hip-gloo', DPP_DIST_BACKEND='gloo', DPP_WORKER_BATCH=str(B))
+    for k in r0.files:
+        if k.startswith('g_') or k == 'w_last':
+            assert np.array_equal(r0[k], r1[k]), k
+    if not sync:
+        assert not np.array_equal(r0['bn_mean'], r1['bn_mean'])
+        return
+    rt = get_runtime('hip')
+    net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, wIn=32, hIn=32, batchSize=2 * B, numJoints=1, nDims=30))
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), fuse_bn=False, weight_decay=1e-3)
+    rng = np.random.RandomState(99)
+    x = nets.synthetic_crops(rng, 2 * B, 32, 32, np.float32)
+    y = rng.normal(0, 0.3, (2 * B, 30)).astype(np.float32)
+    cost, _ = eng.cost_and_grads(x, y)
+    assert abs(float(r0['global_cost'][0]) - cost) < 1e-5 * abs(cost)
+    gmax = max(np.abs(eng.store.read_grad(p)).max() for l in net.layers for p in l.params)
+    for i, l in enumerate(net.layers):
+        for s, p in enumerate(l.params):
+            g = eng.store.read_grad(p)
+            np.testing.assert_allclose(r0['g_%d_%d' % (i, s)], g, rtol=0, atol=2e-4 * max(np.abs(g).max(), 5e-3 * gmax), err_msg='%d %d' % (i, s))

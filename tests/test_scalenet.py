@@ -211,3 +211,29 @@ def _torch_with_dropout(torch_ref, onet, P64, xs, y, dropout_masks, pin):
         if T[i][0].grad is not None:
             G[i] = [T[i][0].grad.numpy(), T[i][1].grad.numpy()]
     return float(cost.detach()), G, out.detach().numpy()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_scalenet_twin_runs_on_the_first_nets_parameters(backend):
+    """ScaleNet(rng, cfgParams=, twin=net) (scalenet.py:136, 178): every layer is a copyLayer of the twin's -- the same regressor at
+    another batch size.  One device copy of the weights: training the first net moves the twin's outputs, and the twin draws nothing
+    from the RandomState."""
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    net, onet, P = make(rt, 4)
+    rng = np.random.RandomState(1)
+    state = rng.get_state()[1].copy()
+    twin = ScaleNet(rng, cfgParams=ScaleNetParams(type=1, batchSize=2, numJoints=1, nDims=3), twin=net)
+    assert all(a.W is b.W and a.b is b.b for a, b in zip(net.layers, twin.layers) if hasattr(a, 'W'))
+    assert np.array_equal(rng.get_state()[1], state)
+    x = nets.synthetic_crops(np.random.RandomState(5), 4, 128, 128, np.float32)
+    xs = nets.scalenet_inputs(x)
+    net.setDeterministic()
+    twin.setDeterministic()
+    o4, o2 = net.computeOutput(xs), twin.computeOutput(xs)                # batches of 4 and of 2
+    assert np.abs(o4 - o2).max() * MM < 1e-4
+    assert twin._param_store is net._param_store
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    eng.train_step(xs, np.random.RandomState(2).normal(0, 0.3, (4, 3)).astype(np.float32), 1e-2)
+    n4, n2 = net.computeOutput(xs), twin.computeOutput(xs)
+    assert np.abs(n4 - o4).max() > 1e-4 and np.abs(n4 - n2).max() * MM < 1e-4
