@@ -51,6 +51,51 @@ __global__ __launch_bounds__(DPP_THREADS) void loss_sse_kernel(const float* __re
     if (threadIdx.x == 0) cost[0] = (float)(s[0] * (double)inv_denom);
 }
 
+// The scalar-target cost of poseregnettrainer.py:84-85, 92-93 (numJoints == nDims == 1): the net output reshaped to (B, 1) -- a
+// broadcastable column in Theano -- minus the VECTOR y (B,) is the (B, B) matrix o_i - y_j, so
+//   cost = mean_i mean_j (o_i - y_j)^2 ,   d cost / d o_i = (2 / B) (o_i - mean(y)).
+// (Whatever the authors meant, this is what the graph computes.)  One block; sums in f64.
+__global__ __launch_bounds__(DPP_THREADS) void loss_sse_bcast_kernel(const float* __restrict__ out, const float* __restrict__ y, int n,
+                                                                     float* __restrict__ cost, float* __restrict__ dout,
+                                                                     float* __restrict__ err) {
+    __shared__ double s[4][DPP_THREADS];
+    double so = 0.0, soo = 0.0, sy = 0.0, syy = 0.0;
+    for (int i = threadIdx.x; i < n; i += DPP_THREADS) {
+        const double o = out[i], t = y[i];
+        so += o; soo += o * o; sy += t; syy += t * t;
+    }
+    s[0][threadIdx.x] = so; s[1][threadIdx.x] = soo; s[2][threadIdx.x] = sy; s[3][threadIdx.x] = syy;
+    __syncthreads();
+    for (int w = DPP_THREADS / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int k = 0; k < 4; ++k) s[k][threadIdx.x] += s[k][threadIdx.x + w];
+        __syncthreads();
+    }
+    const double B = (double)n, ybar = s[2][0] / B;
+    if (threadIdx.x == 0) cost[0] = (float)((B * s[1][0] - 2.0 * s[0][0] * s[2][0] + B * s[3][0]) / (B * B));
+    if (dout)
+        for (int i = threadIdx.x; i < n; i += DPP_THREADS) dout[i] = (float)(2.0 / B * ((double)out[i] - ybar));
+    if (err == nullptr) return;
+    // the monitor of poseregnettrainer.py:115 under the same broadcast: mean (and max) over all pairs of |o_i - y_j|
+    __syncthreads();
+    double acc = 0.0, mx = 0.0;
+    for (int p = threadIdx.x; p < n * n; p += DPP_THREADS) {
+        const double e = fabs((double)out[p / n] - (double)y[p % n]);
+        acc += e;
+        mx = e > mx ? e : mx;
+    }
+    s[0][threadIdx.x] = acc; s[1][threadIdx.x] = mx;
+    __syncthreads();
+    for (int w = DPP_THREADS / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            s[0][threadIdx.x] += s[0][threadIdx.x + w];
+            s[1][threadIdx.x] = s[1][threadIdx.x + w] > s[1][threadIdx.x] ? s[1][threadIdx.x + w] : s[1][threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { err[0] = (float)(s[0][0] / (B * B)); err[1] = (float)s[1][0]; }
+}
+
 // err[0] = mean_rows sqrt(sum_d (out-y)^2), err[1] = max_rows of the same: the monitors of poseregnettrainer.py:114-129
 // (errors / errors_avg / errors_max).
 __global__ __launch_bounds__(DPP_THREADS) void error_l2_kernel(const float* __restrict__ out, const float* __restrict__ y, int rows,
@@ -88,6 +133,18 @@ __global__ __launch_bounds__(DPP_THREADS) void error_l2_kernel(const float* __re
 __global__ __launch_bounds__(DPP_THREADS) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
                                                            float* __restrict__ v, size_t n, const float* __restrict__ state) {
     const float lr = state[0], t = state[1], beta1 = state[2], b2 = state[3], eps = state[4], gamma = state[5];
+    if (state[6] != 0.0f) {
+        // RMSProp (optimizer.py:92-116): msg = decay * msg + (1 - decay) * g^2;  w += -lr * g / max(sqrt(msg), epsilon).
+        // state[3] = decay, state[4] = epsilon (the clip); msg lives in v, m is not used.
+        const float od = 1.0f - b2;
+        for (size_t i = (size_t)blockIdx.x * DPP_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * DPP_THREADS) {
+            const float gg = g[i];
+            const float ms = b2 * v[i] + od * (gg * gg);
+            w[i] = w[i] + (-lr * gg) / fmaxf(sqrtf(ms), eps);
+            v[i] = ms;
+        }
+        return;
+    }
     const float b1 = beta1 * powf(gamma, t - 1.0f);
     const float ob1 = 1.0f - b1, ob2 = 1.0f - b2;
     const float c1 = 1.0f - powf(beta1, t), c2 = 1.0f - powf(b2, t);
@@ -227,6 +284,12 @@ extern "C" int dpp_loss_sse(const float* out, const float* y, int rows, int d, i
     if (!out || !y || !cost || rows < 1 || d < 1 || denom < 1) return DPP_E_BADARG;
     DPP_LAUNCH(loss_sse_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), out, y, rows * d,
                        1.0f / (float)denom, cost, dout);
+    return dpp_launch_status();
+}
+
+extern "C" int dpp_loss_sse_bcast(const float* out, const float* y, int n, float* cost, float* dout, float* err, dpp_stream_t stream) {
+    if (!out || !y || !cost || n < 1 || n > 32768) return DPP_E_BADARG;
+    DPP_LAUNCH(loss_sse_bcast_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), out, y, n, cost, dout, err);
     return dpp_launch_status();
 }
 

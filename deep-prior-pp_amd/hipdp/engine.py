@@ -417,18 +417,21 @@ def wgrad_plan(Co, Ci, K):
 
 
 class CompiledNet(object):
-    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None, fuse_bn=True, bf16=None):
+    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None, fuse_bn=True, bf16=None, optimizer=None):
         """
         :param bf16:  True -> the 3x3 convolutions (forward, data gradient) and the HiddenLayer behind the last conv map (FC1:
                       forward, data and weight gradient) round their operands to bf16 and accumulate in f32 on the bf16 matrix
                       pipe (BASELINE config 5).  Opt-in (default: DPP_BF16=1 in the environment): the f32 path is the one that
                       meets the 1e-3 mm bar.
+        :param optimizer: None (the reference's ADAM defaults) or trainer.optimizer.Optimizer(...).rule: dict(name='ADAM', beta1=, beta2=,
+                      epsilon=, gamma=) / dict(name='RMSProp', decay=, epsilon=) -- the constants of the fused update kernel
         :param train: True -> BatchNorm uses batch statistics (and updates the running ones), dropout uses masks,
                       and the loss / backward / ADAM plans are built; False -> deterministic forward only.
         :param loss:  None, or dict(kind='embedding'|'joints', numJoints=, nDims=) -- the cost of
                       poseregnettrainer.py:92-99; also available in eval mode (validation cost / error).
         """
         self.rt = rt = runtime or default_runtime()
+        self.optimizer = dict(optimizer) if optimizer else dict(name='ADAM')
         self.prec = int(bool(BF16_DEFAULT if bf16 is None else bf16))
         self.dp = dp                                  # hipdp.parallel.DataParallel or None
         # BatchNorm statistics / backward sums produced by the conv epilogues (off with sync-BN, whose partials are
@@ -474,12 +477,21 @@ class CompiledNet(object):
             self.err = rt.alloc(2)
             self.lossplan = Plan('loss')
             gN = self.N * (dp.world if (dp is not None and train) else 1)      # cost normalised by the GLOBAL batch
-            denom = gN if loss.get('kind', 'embedding') == 'embedding' else gN * loss['numJoints']
+            denom = gN if loss.get('kind', 'embedding') in ('embedding', 'scalar') else gN * loss['numJoints']
             if train:
                 self.out.grad = rt.alloc(self.out.shape)
                 self.out.grad_written = True
-            self.lossplan.add(ops.loss_sse(rt, self.out.buf, self.y_in, self.N, self.out_dim, denom, self.cost,
-                                           self.out.grad if train else None))
+            if loss.get('kind') == 'scalar':
+                # numJoints == nDims == 1 (poseregnettrainer.py:84-85, 92-93): the (B, 1) output broadcast against the vector y
+                if self.out_dim != 1:
+                    raise ValueError("the scalar cost needs a one-dimensional output")
+                if dp is not None and train:
+                    raise NotImplementedError("the broadcast cost of the scalar target couples all samples of the global batch")
+                self.lossplan.add(ops.loss_sse_bcast(rt, self.out.buf, self.y_in, self.N, self.cost, self.out.grad if train else None,
+                                                     err=None if train else self.err))
+            else:
+                self.lossplan.add(ops.loss_sse(rt, self.out.buf, self.y_in, self.N, self.out_dim, denom, self.cost,
+                                               self.out.grad if train else None))
             if self.weight_decay and not net.hasDropout():
                 # cost += weightreg_factor * sum(W^2) over the conv / FC weights, only for nets without dropout
                 # (poseregnettrainer.py:101-107); the kernel-layout W holds the same values in another order
@@ -487,9 +499,9 @@ class CompiledNet(object):
                 share = self.weight_decay / (dp.world if (dp is not None and train) else 1)
                 for W in self._unique_weights():
                     self.lossplan.add(ops.sumsq(rt, self.store.view(W), int(np.prod(W.shape)), share, self.cost, 1))
-            if not train:
-                d = loss['nDims'] if loss.get('kind', 'embedding') != 'embedding' else self.out_dim
-                rows = self.N * (loss['numJoints'] if loss.get('kind', 'embedding') != 'embedding' else 1)
+            if not train and loss.get('kind') != 'scalar':
+                d = loss['nDims'] if loss.get('kind', 'embedding') == 'joints' else self.out_dim
+                rows = self.N * (loss['numJoints'] if loss.get('kind', 'embedding') == 'joints' else 1)
                 self.lossplan.add(ops.error_l2(rt, self.out.buf, self.y_in, rows, d, self.err))
         if train:
             if loss is None:
@@ -1317,7 +1329,12 @@ class CompiledNet(object):
         """ADAM state of optimizer.py:58-90: t = 1, m = v = 0; python-float constants become floatX (float32) constants,
         so gamma = 1 - 1e-8 is exactly 1 as in the reference."""
         f = np.float32
-        self.hyper.set(np.array([f(lr), f(1.0), f(0.9), f(0.999), f(1e-8), f(1 - 1e-8), 0, 0], np.float32))
+        o = self.optimizer
+        if o.get('name', 'ADAM') == 'RMSProp':              # optimizer.py:92-116; slots 3 / 4 = decay / epsilon, slot 6 selects the rule
+            self.hyper.set(np.array([f(lr), f(1.0), 0, f(o.get('decay', 0.9)), f(o.get('epsilon', 1.0 / 100.)), 0, 1, 0], np.float32))
+        else:
+            self.hyper.set(np.array([f(lr), f(1.0), f(o.get('beta1', 0.9)), f(o.get('beta2', 0.999)), f(o.get('epsilon', 1e-8)),
+                                     f(o.get('gamma', 1 - 1e-8)), 0, 0], np.float32))
         self.store.m.zero()
         self.store.v.zero()
         self._lr = float(lr)

@@ -98,6 +98,7 @@ SIGNATURES = {
     'dpp_reduce_multi': (C.c_int, [C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_colsum_partial': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_loss_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, stream_t]),
+    'dpp_loss_sse_bcast': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_error_l2': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, stream_t]),
     'dpp_adam_tick': (C.c_int, [C.c_void_p, stream_t]),

@@ -368,6 +368,10 @@ def loss_sse(rt, out, y, rows, d, denom, cost, dout=None, name='loss_sse'):
     return Launch(rt.lib.dpp_loss_sse, (out.ptr, y.ptr, rows, d, denom, cost.ptr, _p(dout)), (out, y, cost, dout), name)
 
 
+def loss_sse_bcast(rt, out, y, n, cost, dout=None, err=None, name='loss_sse_bcast'):
+    return Launch(rt.lib.dpp_loss_sse_bcast, (out.ptr, y.ptr, n, cost.ptr, _p(dout), _p(err)), (out, y, cost, dout, err), name)
+
+
 def error_l2(rt, out, y, rows, d, err, name='error_l2'):
     return Launch(rt.lib.dpp_error_l2, (out.ptr, y.ptr, rows, d, err.ptr), (out, y, err), name)
 

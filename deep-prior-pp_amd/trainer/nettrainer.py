@@ -17,7 +17,6 @@ import time
 import numpy
 
 from hipdp.runtime import default_runtime
-from util.helpers import chunks
 
 
 class NetTrainerParams(object):
@@ -308,25 +307,28 @@ class NetTrainer(object):
     def isLastMacroBatch(self, macro_idx):
         return macro_idx >= self.getNumMacroBatches() - 1
 
+    def _macro_range(self, mbi, use_all_last=True):
+        """(first index, one past the last index, is-last) of macro-batch `mbi` in the indexing the augmentation hooks use: the
+        full macro-batches index keyDB, the last one indexes keyDBlast from 0 -- all of it, or only the minibatches that hold real
+        samples (nettrainer.py:726-739)."""
+        spm = self.getNumSamplesPerMacroBatch()
+        if not self.isLastMacroBatch(mbi):
+            return mbi * spm, min((mbi + 1) * spm, self.train_data_xDB.shape[0]), False
+        if use_all_last is True:
+            return 0, spm, True
+        B = self.cfgParams.batch_size
+        real_minibatches = int(numpy.ceil(self.numTrainSamplesMB / float(B))) - self.getNumMiniBatchesPerMacroBatch() * (self.getNumMacroBatches() - 1)
+        return 0, B * real_minibatches, True
+
     def chunksForMP(self, mbi, use_all_last=True):
-        """Index partition the reference hands to its worker processes (nettrainer.py:726-744); kept for callers /
-        tests that inspect it -- the device kernels process the whole range at once."""
-        if self.isLastMacroBatch(mbi):
-            start_idx = 0
-            if use_all_last is True:
-                end_idx = self.getNumSamplesPerMacroBatch()
-            else:
-                num_mb = int(numpy.ceil(self.numTrainSamplesMB / float(self.cfgParams.batch_size)))
-                end_idx = self.cfgParams.batch_size * (num_mb - self.getNumMiniBatchesPerMacroBatch() * (self.getNumMacroBatches() - 1))
-            last = True
-        else:
-            start_idx = mbi * self.getNumSamplesPerMacroBatch()
-            end_idx = min((mbi + 1) * self.getNumSamplesPerMacroBatch(), self.train_data_xDB.shape[0])
-            last = False
-        num_chunks = int(numpy.ceil((end_idx - start_idx) / float(self.cfgParams.para_num_proc)))
-        idxs = list(chunks(list(range(start_idx, end_idx)), num_chunks))
-        tidxs = list(chunks(list(range(0, (end_idx - start_idx))), num_chunks))
-        return last, tidxs, idxs
+        """(last, target index lists, source index lists) of macro-batch `mbi`, dealt into para_num_proc slices the way the reference
+        hands them to its worker processes (nettrainer.py:726-744).  loadMacroBatch flattens the slices again: one kernel launch
+        augments the whole range."""
+        lo, hi, last = self._macro_range(mbi, use_all_last)
+        per = int(numpy.ceil((hi - lo) / float(self.cfgParams.para_num_proc)))
+        cuts = list(range(0, hi - lo, per)) if per > 0 else []
+        tidxs = [list(range(c, min(c + per, hi - lo))) for c in cuts]
+        return last, tidxs, [[lo + t for t in sl] for sl in tidxs]
 
     # ---- macro-batch handling ------------------------------------------------------------------------------
     def loadMiniBatch(self, mini_idx):

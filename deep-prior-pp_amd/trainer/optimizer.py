@@ -1,6 +1,7 @@
 """Optimizer (API of /root/reference/src/trainer/optimizer.py:38-116).  In the reference this builds Theano update
-expressions; here it records which update rule the trainer's compiled step applies.  ADAM (with the gamma-decayed
-beta1) is executed by the fused dpp_adam kernel over the flat parameter buffer; see hipdp.engine."""
+expressions; here it records the update rule and its constants for the trainer's compiled step: `rule` goes to
+hipdp.engine.CompiledNet(optimizer=), which writes it into the device-resident hyper-parameter block that the fused update kernel
+(csrc/elementwise.hip: adam_kernel, one launch over the flat parameter buffer) reads."""
 
 
 class Optimizer(object):
@@ -17,10 +18,13 @@ class Optimizer(object):
         """Adam (Kingma & Ba) with momentum decay, optimizer.py:58-90: t starts at 1; beta1_t = beta1*gamma^(t-1);
         m = beta1_t*m + (1-beta1_t)*g; v = beta2*v + (1-beta2)*g^2; w -= lr*(m/(1-beta1^t)) / (sqrt(v/(1-beta2^t)) + eps)."""
         self.rule = dict(name='ADAM', learning_rate=learning_rate, beta1=beta1, beta2=beta2, epsilon=epsilon, gamma=gamma)
-        if (beta1, beta2, epsilon) != (0.9, 0.999, 1e-8):
-            raise NotImplementedError("the fused ADAM kernel is configured with the reference's defaults")
+        self.shared = [(k, p) for p in self.params for k in ('m', 'v')]          # 1st / 2nd moment per parameter
         self.updates = [('adam', p) for p in self.params]
         return self.updates
 
     def RMSProp(self, learning_rate=0.01, decay=0.9, epsilon=1.0 / 100.):
-        raise NotImplementedError("RMSProp is never selected by the reference's trainers (poseregnettrainer.py:147-149)")
+        """RMSProp of Tieleman et al., optimizer.py:92-116: msg = decay*msg + (1-decay)*g^2; w += -lr * g / max(sqrt(msg), epsilon)."""
+        self.rule = dict(name='RMSProp', learning_rate=learning_rate, decay=decay, epsilon=epsilon)
+        self.shared = [('msg', p) for p in self.params]
+        self.updates = [('rmsprop', p) for p in self.params]
+        return self.updates

@@ -34,8 +34,8 @@ class PoseRegNetTrainer(NetTrainer):
         target); otherwise mean_n mean_j sum_d; L2 weight decay only for nets without dropout."""
         cfg = self.poseNet.cfgParams
         if cfg.numJoints == 1 and cfg.nDims == 1:
-            raise NotImplementedError("scalar regression target")
-        if cfg.numJoints == 1:
+            self.loss_cfg = dict(kind='scalar')           # y is a VECTOR: the (B, 1) output broadcasts against it (:84-85, 92-93)
+        elif cfg.numJoints == 1:
             self.loss_cfg = dict(kind='embedding')
         else:
             self.loss_cfg = dict(kind='joints', numJoints=cfg.numJoints, nDims=cfg.nDims)
@@ -52,7 +52,7 @@ class PoseRegNetTrainer(NetTrainer):
 
     # ---- train ------------------------------------------------------------------------------------------
     def setupTrain(self):
-        opt = Optimizer(self.grads, self.params)
+        opt = self.optimizer = Optimizer(self.grads, self.params)
         self.updates = opt.ADAM(self.cfgParams.learning_rate)
         print("compiling train_model() ... ")
         wd = self.cfgParams.weightreg_factor if not self.poseNet.hasDropout() else 0.0
@@ -87,7 +87,8 @@ class PoseRegNetTrainer(NetTrainer):
         """The two compiled engines over the same device-resident parameters.  Data parallel (self.dp): the train engine's step
         all-reduces the flat gradient buffer (early FC1 bucket + the rest) between backward and the replicated ADAM, and its cost
         buffer -- this rank's share of the global minibatch's cost -- is summed over the ranks right after the step."""
-        self.train_engine = engine.CompiledNet(self.poseNet, train=True, runtime=self.rt, loss=self.loss_cfg, weight_decay=wd, dp=self.dp)
+        self.train_engine = engine.CompiledNet(self.poseNet, train=True, runtime=self.rt, loss=self.loss_cfg, weight_decay=wd, dp=self.dp,
+                                               optimizer=getattr(getattr(self, 'optimizer', None), 'rule', None))
         self.eval_engine = engine.CompiledNet(self.poseNet, train=False, runtime=self.rt, loss=self.loss_cfg, weight_decay=wd)
         self._allreduce = None                         # (kept for callers that drive the engines by hand: a callable on the flat gradient)
         self._cost_sum = self.dp.allreduce_sum_op(self.train_engine.cost, 'cost_allreduce') if self.dp is not None else None

@@ -37,7 +37,7 @@ class ScaleNetTrainer(PoseRegNetTrainer):
 
     # ---- train ------------------------------------------------------------------------------------------
     def setupTrain(self):
-        opt = Optimizer(self.grads, self.params)
+        opt = self.optimizer = Optimizer(self.grads, self.params)
         self.updates = opt.ADAM(self.cfgParams.learning_rate)
         print("compiling train_model() ... ")
         wd = self.cfgParams.weightreg_factor if not self.poseNet.hasDropout() else 0.0

@@ -228,6 +228,10 @@ int dpp_colsum_partial(const float* X, int M, int C, int rows_per_block, float* 
 /* cost = (1/denom) sum (out-y)^2, dout = (2/denom)(out-y): /root/reference/src/trainer/poseregnettrainer.py:92-99
  * (denom = batch for the embedding loss, batch*numJoints for the joint loss); dout may be NULL */
 int dpp_loss_sse(const float* out, const float* y, int rows, int d, int denom, float* cost, float* dout, dpp_stream_t stream);
+/* The scalar-target case (numJoints == nDims == 1, poseregnettrainer.py:84-85, 92-93): Theano broadcasts the (B, 1) output against
+ * the VECTOR y, so the cost is mean_i mean_j (out_i - y_j)^2 and dout_i = (2 / B)(out_i - mean(y)); n = B.  err (may be NULL):
+ * the monitor of :115 under the same broadcast, err[0] = mean, err[1] = max over all pairs of |out_i - y_j|. */
+int dpp_loss_sse_bcast(const float* out, const float* y, int n, float* cost, float* dout, float* err, dpp_stream_t stream);
 /* err[0] = mean_rows sqrt(sum_d (out-y)^2), err[1] = max_rows: poseregnettrainer.py:114-129 (errors, errors_avg, errors_max) */
 int dpp_error_l2(const float* out, const float* y, int rows, int d, float* err, dpp_stream_t stream);
 /* The reference's ADAM (/root/reference/src/trainer/optimizer.py:58-90) over a flat parameter buffer.

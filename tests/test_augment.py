@@ -304,3 +304,32 @@ def test_rotation_coefficients_are_the_correctly_rounded_ones(backend):
                                        cam, abs(cam.fx), abs(cam.fy))
         assert np.array_equal(got[i], ref), (i, rots[i], int((got[i] != ref).sum()))
         np.testing.assert_allclose(lab[i], rlab, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_binarize_image_flag(backend):
+    """augment_poses' binarizeImage (poseregnettrainer.py:255-257): the augmented crop thresholded at 0.5 -- with normZeroOne crops,
+    where it separates hand from background -- as an epilogue flag of the fused kernel."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(41)
+    cam = A.Camera.icvl()
+    J, B = 16, 8
+    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, B, cam, cube=(250.,) * 3, joints=J)
+    imgs01 = ((imgs + 1.0) * 0.5).astype(np.float32)
+    names = ['com', 'rot', 'sc', 'none'] * 2
+    _, offs, rots, scs = A.draw_params(rng, B, 4)
+    f32 = lambda a: rt.upload(np.asarray(a, np.float32))          # noqa: E731
+    out_x, out_y = rt.alloc((B, 128, 128), zero=False), rt.alloc((B, J * 3), zero=False)
+    ops.augment(rt, f32(imgs01), f32(coms), f32(cubes), f32(Ms.reshape(B, 9)), f32(gts), B, J, 128, (cam.fx, cam.fy, cam.ux, cam.uy, cam.flip_y),
+                out_x, out_y, mode=rt.upload(np.array([MODES[n] for n in names], np.int32)), off=rt.upload(offs), rot=rt.upload(rots),
+                sc=rt.upload(scs), norm_zero_one=True, binarize=True)(rt.stream)
+    rt.synchronize()
+    got = out_x.get()
+    for i in range(B):
+        ref, *_ = A.augment_crop(imgs01[i].copy(), gts[i].copy(), cam.joint3DToImg(coms[i]), cubes[i], Ms[i], names[i], offs[i], rots[i], scs[i],
+                                 cam, abs(cam.fx), abs(cam.fy), normZeroOne=True)
+        ref = ref.copy()
+        ref[ref < 0.5] = 0
+        ref[ref >= 0.5] = 1
+        assert np.array_equal(got[i], ref), (i, names[i])
+    assert set(np.unique(got)) == {0.0, 1.0}

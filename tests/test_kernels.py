@@ -218,6 +218,19 @@ def test_loss_colsum_adam_elementwise(backend):
         # b1*m + (1-b1)*g may cancel: the round-off bound is relative to the terms, not to the result
         assert (np.abs(m.get() - Mo[0]) <= 2e-7 * (np.abs(m_prev) + np.abs(g)) + 1e-30).all()
         np.testing.assert_allclose(v.get(), Vo[0], rtol=2e-6, atol=1e-20)
+    # RMSProp (optimizer.py:92-116) through the same kernel (hyper slot 6 selects the rule; slots 3 / 4 = decay / epsilon)
+    w = rng.normal(size=n).astype(np.float32)
+    wb, msg = rt.upload(w), rt.alloc(n)
+    hyper = rt.upload(np.array([1e-2, 1.0, 0, 0.9, 1.0 / 100., 0, 1, 0], np.float32))
+    ref_w, ref_ms = w.copy(), np.zeros(n, np.float32)
+    for step in range(3):
+        g = (rng.normal(size=n) * 10 ** rng.uniform(-4, 0, n)).astype(np.float32)
+        ops.adam(rt, wb, rt.upload(g), m, msg, n, hyper)(rt.stream)
+        rt.synchronize()
+        ref_ms = (np.float32(0.9) * ref_ms + np.float32(1 - np.float32(0.9)) * (g * g)).astype(np.float32)
+        ref_w = (ref_w + (-np.float32(1e-2) * g) / np.maximum(np.sqrt(ref_ms), np.float32(1.0 / 100.))).astype(np.float32)
+        np.testing.assert_allclose(msg.get(), ref_ms, rtol=2e-6, atol=1e-20)
+        np.testing.assert_allclose(wb.get(), ref_w, rtol=2e-6, atol=1e-7)
     # dropout forward (deterministic + mask) and relu backward
     pre = rng.normal(size=500).astype(np.float32)
     mask = (rng.uniform(size=500) < 0.7).astype(np.float32)

@@ -289,3 +289,35 @@ def test_para_load_swaps_chunks_at_the_last_macro_batch(backend, tmp_path):
     np.testing.assert_array_equal(tr.train_data_x.get_value(), np.roll(x, 3, axis=0))
     np.testing.assert_array_equal(tr.train_data_com.get_value(), np.roll(com, 3, axis=0))
     assert tr._load_thread is None                                 # the worker was shut down by train()
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_scalar_regression_target(backend, tmp_path):
+    """numJoints == nDims == 1 (poseregnettrainer.py:84-85, 92-93, 115): y is a VECTOR, the (B, 1) output broadcasts against it, so cost
+    and monitor run over all (i, j) pairs -- what the reference's graph computes.  Cost, gradient (through one ADAM step's direction)
+    and validation error against NumPy's own broadcasting."""
+    from hipdp import engine
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    rng = np.random.RandomState(23455)
+    B, size = 4, 48
+    net = PoseRegNet(rng, cfgParams=PoseRegNetParams(type=0, nChan=1, wIn=size, hIn=size, batchSize=B, numJoints=1, nDims=1))
+    p = PoseRegNetTrainerParams()
+    p.batch_size = B
+    tr = PoseRegNetTrainer(net, p, rng, str(tmp_path))
+    assert tr.loss_cfg == dict(kind='scalar')
+    x = synth(B, size, 16, 3)[0]
+    y = np.random.RandomState(4).normal(0, 0.3, B).astype(np.float32)
+    net.setDeterministic()
+    ev = engine.CompiledNet(net, train=False, runtime=rt, loss=tr.loss_cfg)
+    cost, err = ev.evaluate(x, y)
+    o = ev.out.buf.get().astype(np.float64)                    # (B, 1)
+    d = o.reshape(B, 1) - y.astype(np.float64)                 # NumPy broadcasts like Theano here: (B, B)
+    assert abs(cost - (d ** 2).mean(axis=1).mean()) < 1e-6 * max(1.0, (d ** 2).mean())
+    assert abs(err - np.sqrt(d ** 2).mean(axis=1).mean()) < 1e-6
+    net.unsetDeterministic()
+    te = engine.CompiledNet(net, train=True, runtime=rt, loss=tr.loss_cfg)
+    c, _ = te.cost_and_grads(x, y)
+    ot = te.out.buf.get().astype(np.float64).reshape(B)
+    np.testing.assert_allclose(te.out.grad.get().reshape(B), 2.0 / B * (ot - y.mean(dtype=np.float64)), rtol=1e-5, atol=1e-7)
+    assert abs(c - ((ot[:, None] - y[None, :].astype(np.float64)) ** 2).mean()) < 1e-6 * max(1.0, c)
