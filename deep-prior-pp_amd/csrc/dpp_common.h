@@ -100,6 +100,14 @@ extern unsigned long long* dpp_prof_buffer;                // host-side: where i
 #define DPP_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #endif
 
+// Nothing may be scheduled across this point: the LLVM machine scheduler otherwise sinks loads that were issued early ON PURPOSE
+// (a software prefetch ring) down to their first use to save registers, which serialises the memory round trips again.
+#ifdef DPP_HIP_EMU
+#define DPP_SCHED_FENCE()
+#else
+#define DPP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 template <int NBYTES>
 __device__ __forceinline__ void dpp_kernarg_warm() {
 #ifndef DPP_HIP_EMU

@@ -1,0 +1,180 @@
+// wgrad.hip -- filter gradient of the 1x1 convolutions as a barrier-free row stream (gfx950, v_mfma_f32_16x16x4_f32).
+//
+//   dW[o][c] = sum_m dY[m][o] * act(X)[map(m)][c]            T.grad of /root/reference/src/net/convlayer.py:230-240
+//                                                             (/root/reference/src/trainer/poseregnettrainer.py:110-111)
+// M = pixels (8 192 .. 131 072 at batch 128), Co x Ci = 16 x 64 .. 256 x 64: a reduction over a long, thin pair of tensors into a
+// small matrix -- an HBM stream with a tiny product inside.  The LDS-tiled GEMM of gemm.hip ran these as <1, 1, 256> grids, one
+// workgroup per CU, one 64-row chunk in flight each: 0.93 TB/s on 40 MB (profiles/r02_kernel_stats_single_stream_by_grid.txt), and
+// the 44 launches were most of the 1.9 ms gradient branch.  Here:
+//   * no LDS, no barrier: a WAVE owns a range of pixel rows and a block of the output; its operands go from global memory straight
+//     into MFMA fragments.  The MFMA wants lane (i, kq) to hold A[i][k = kq]: the lane loads VA CONTIGUOUS floats of pixel row
+//     m0 + kq at channel VA * i (16 lanes x 16 bytes = one 256-byte row for 64 channels) and component e of that vector is the A
+//     operand of the MFMAs that produce output rows o = VA * i + e -- the channel permutation lives in the epilogue's addresses,
+//     nothing is transposed.  The same on the X side (VB contiguous floats, columns c = VB * j + f), with the BatchNorm + ReLU
+//     prologue applied in registers (the lane's VB channels never change: coefficients are loaded once).
+//   * a ring of U stages (4 pixel rows each) keeps U steps of loads in flight: a stage is refilled the moment it is consumed;
+//   * wide outputs are split over the waves of a workgroup by channel blocks (64 x 256: four waves x 64 columns), narrow ones by
+//     rows; every (workgroup, row split) writes its own partial slice [Co][Ci], summed in fixed order by dpp_reduce_multi.
+#include "dpp_common.h"
+
+namespace {
+
+struct WgradArgs {
+    const float* dY; const float* X; float* partial;
+    dpp_rowmap mapX; dpp_act actX;
+    int M, Co, Ci, rpw;                  // rpw: pixel rows per wave
+};
+
+template <int V>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[V]) {
+    if (V == 1) v[0] = p[0];
+    else if (V == 2) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    else {
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(p + q * 4);
+            v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+        }
+    }
+}
+
+// TA = Co / 16, TB = Ci / 16 (vector lengths of a full row per lane); the 4 waves split A channels WA ways, B channels WB ways and
+// rows WR = 4 / (WA * WB) ways.  VA = TA / WA, VB = TB / WB floats per lane and operand; VA * VB accumulator tiles per wave.
+template <int TA, int TB, int WA, int WB, int U, bool STRIDED>
+__global__ __launch_bounds__(DPP_THREADS) void wgrad_stream_kernel(WgradArgs a) {
+    constexpr int WR = 4 / (WA * WB), VA = TA / WA, VB = TB / WB;
+    static_assert(WA * WB * WR == 4 && VA >= 1 && VB >= 1 && VA <= 4 && VB <= 8, "wave split");
+    dpp_kernarg_warm<sizeof(WgradArgs)>();
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wa = wave % WA, wb = (wave / WA) % WB, wr = wave / (WA * WB);
+    const int slice = blockIdx.x * WR + wr;
+    const int row_begin = slice * a.rpw, row_end = (row_begin + a.rpw < a.M) ? row_begin + a.rpw : a.M;
+    const int ca = wa * 16 * VA + VA * l15;              // first dY channel of this lane
+    const int cb = wb * 16 * VB + VB * l15;              // first X channel of this lane
+    float mu[VB], sc[VB], be[VB];
+    const int mode = a.actX.mode;
+#pragma unroll
+    for (int f = 0; f < VB; ++f) { mu[f] = 0.f; sc[f] = 1.f; be[f] = 0.f; }
+    if (mode & 2) { load_vec<VB>(a.actX.mean + cb, mu); load_vec<VB>(a.actX.scale + cb, sc); load_vec<VB>(a.actX.beta + cb, be); }
+    f32x4 acc[VA][VB];
+#pragma unroll
+    for (int e = 0; e < VA; ++e)
+#pragma unroll
+        for (int f = 0; f < VB; ++f) acc[e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // A ring of U stages, one step (4 pixel rows) each: stage s is consumed and at once refilled with the step U ahead, so U steps
+    // of loads are in flight at any time (vmcnt retires loads in order: consuming a stage waits for ITS loads only).  With one wave
+    // per SIMD on the wide layers nothing else hides the memory round trip: loads consumed in the iteration that issued them made
+    // the stage-3 / 4 launches 30 us for 3.4 us of MFMA work.  The loop body is BRANCH-FREE (the refill past the end re-reads the
+    // last row, whose dY operand is zeroed when the stage is consumed; the row map is a template flag): any branch between issue and
+    // use makes the compiler wait for all outstanding loads (s_waitcnt vmcnt(0)) at the merge point.
+    float av[U][VA], bv[U][VB];
+    bool okv[U];
+    const int last = row_end - 1;
+    auto fetch = [&](int u, int m0) {
+        const int m = m0 + kq;
+        okv[u] = m < row_end;
+        const int mm = m < row_end ? m : last;
+        load_vec<VA>(a.dY + (size_t)mm * a.Co + ca, av[u]);
+        const int xr = STRIDED ? dpp_map_row(a.mapX, mm) : mm;
+        load_vec<VB>(a.X + (size_t)xr * a.Ci + cb, bv[u]);
+    };
+    if (row_begin < row_end) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(u, row_begin + 4 * u);
+        DPP_SCHED_FENCE();
+        for (int m0 = row_begin; m0 < row_end; m0 += 4 * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float bq[VB], aq[VA];
+#pragma unroll
+                for (int f = 0; f < VB; ++f) {
+                    float v = bv[u][f];
+                    if (mode & 2) v = (v - mu[f]) * sc[f] + be[f];
+                    if (mode & 1) v = fmaxf(v, 0.0f);
+                    bq[f] = v;
+                }
+#pragma unroll
+                for (int e = 0; e < VA; ++e) aq[e] = okv[u] ? av[u][e] : 0.0f;
+                DPP_SCHED_FENCE();
+                fetch(u, m0 + 4 * (U + u));                               // refill: the step U ahead
+                DPP_SCHED_FENCE();
+#pragma unroll
+                for (int e = 0; e < VA; ++e)
+#pragma unroll
+                    for (int f = 0; f < VB; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[e], bq[f], acc[e][f], 0, 0, 0);
+            }
+        }
+    }
+    // D layout: lane (j = l15, kq) holds rows i = 4 kq + r of tile (e, f): output element (o = wa*16*VA + VA*i + e, c = cb + f)
+    float* out = a.partial + (size_t)slice * a.Co * a.Ci;
+#pragma unroll
+    for (int e = 0; e < VA; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = wa * 16 * VA + VA * (kq * 4 + r) + e;
+            float* po = out + (size_t)o * a.Ci + cb;
+            if (VB == 1) po[0] = acc[e][0][r];
+            else if (VB == 2) *reinterpret_cast<float2*>(po) = make_float2(acc[e][0][r], acc[e][1][r]);
+            else {
+#pragma unroll
+                for (int q = 0; q < VB / 4; ++q)
+                    *reinterpret_cast<float4*>(po + q * 4) = make_float4(acc[e][q * 4][r], acc[e][q * 4 + 1][r], acc[e][q * 4 + 2][r], acc[e][q * 4 + 3][r]);
+            }
+        }
+}
+
+struct Shape { int Co, Ci, WR; };
+
+// (Co, Ci) -> rows split WR of the instantiation that handles it, or 0
+int shape_wr(int Co, int Ci) {
+    static const Shape table[] = {{16, 64, 4}, {64, 16, 4}, {16, 32, 4}, {64, 32, 4}, {32, 64, 4}, {32, 128, 2}, {128, 32, 2},
+                                  {128, 64, 2}, {64, 128, 2}, {64, 256, 1}, {256, 64, 1}, {256, 128, 1}};
+    for (const Shape& s : table)
+        if (s.Co == Co && s.Ci == Ci) return s.WR;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dpp_wgrad_stream_slices(int Co, int Ci, int M, int rows_per_wave) {
+    const int WR = shape_wr(Co, Ci);
+    if (!WR || M < 1 || rows_per_wave < 4 || (rows_per_wave & 3)) return 0;
+    return dpp_cdiv(M, rows_per_wave * WR) * WR;
+}
+
+extern "C" int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
+                                int rows_per_wave, float* partial, dpp_stream_t stream) {
+    if (!dY || !X || !partial) return DPP_E_BADARG;
+    const int nsl = dpp_wgrad_stream_slices(Co, Ci, M, rows_per_wave);
+    if (!nsl) return DPP_E_UNSUPPORTED;
+    WgradArgs a;
+    a.dY = dY; a.X = X; a.partial = partial; a.M = M; a.Co = Co; a.Ci = Ci; a.rpw = rows_per_wave;
+    a.mapX.s = 1; a.mapX.Wo = a.mapX.HoWo = a.mapX.Wi = a.mapX.HiWi = 0;
+    if (mapX) a.mapX = *mapX;
+    a.actX.mean = a.actX.scale = a.actX.beta = nullptr; a.actX.mode = 0; a.actX.cmod = Ci; a.actX.x2 = a.actX.aux = nullptr; a.actX.out = nullptr;
+    if (actX) a.actX = *actX;
+    if (a.actX.mode & ~3) return DPP_E_UNSUPPORTED;
+    if ((a.actX.mode & 2) && !(a.actX.mean && a.actX.scale && a.actX.beta && a.actX.cmod == Ci)) return DPP_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(partial)) & 15) return DPP_E_BADARG;
+    const int WR = shape_wr(Co, Ci);
+    const dim3 grid(nsl / WR), block(DPP_THREADS);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define DPP_WG(CO_, CI_, WA_, WB_, U_) if (Co == CO_ && Ci == CI_) { \
+        if (a.mapX.s != 1) DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, true>), grid, block, 0, st, a); \
+        else DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, false>), grid, block, 0, st, a); \
+        return dpp_launch_status(); }
+    DPP_WG(16, 64, 1, 1, 8)
+    DPP_WG(64, 16, 1, 1, 8)
+    DPP_WG(16, 32, 1, 1, 8)
+    DPP_WG(64, 32, 1, 1, 8)
+    DPP_WG(32, 64, 1, 1, 8)
+    DPP_WG(32, 128, 1, 2, 8)
+    DPP_WG(128, 32, 2, 1, 8)
+    DPP_WG(128, 64, 2, 1, 8)
+    DPP_WG(64, 128, 1, 2, 8)
+    DPP_WG(64, 256, 1, 4, 8)
+    DPP_WG(256, 64, 4, 1, 8)
+    DPP_WG(256, 128, 4, 1, 4)
+#undef DPP_WG
+    return DPP_E_UNSUPPORTED;
+}

@@ -416,6 +416,26 @@ def wgrad_plan(Co, Ci, K):
     return tile, splitk
 
 
+# 1x1 filter gradients on the row-streaming kernel of csrc/wgrad.hip.  Measured on the MI355X (profiles/r03_wgrad_stream.txt): alone
+# (one stream) the kernel beats dpp_gemm's filter-gradient layout on every stage (stage 1: 14 vs 43 us per launch under the
+# profiler), but the gradient branch runs BESIDE the data-gradient chain, and there what counts is how little a launch takes
+# from the chain, not how fast it is: with 512 workgroups per launch the step got SLOWER (3.84 vs 3.77 ms), with 128 long-running
+# workgroups (256 rows per wave) on the stage-1 layers only it is 3.72 ms.  Stages 2-4 stay on dpp_gemm (3.76 / 3.84 ms with the
+# stream kernel there), as does the two-tensor dY operand of DPP_LAZY_BN_BWD.
+WGRAD_STREAM = knob('DPP_WGRAD_STREAM', '1') != '0'
+WGRAD_STREAM_RPW = tuple(int(v) for v in knob('DPP_WGRAD_STREAM_RPW', '256,128,128').split(','))      # stage 1 | stage 2 | stages 3-4
+WGRAD_STREAM_STAGES = knob('DPP_WGRAD_STREAM_STAGES', '1')            # which of them take the kernel
+
+
+def wgrad_stream_rows(M):
+    """Pixel rows per wave of dpp_wgrad_stream for a layer with M pixel rows, or 0: leave the layer on dpp_gemm."""
+    stage = 0 if M >= 65536 else (1 if M >= 16384 else 2)
+    if str(stage + 1) not in WGRAD_STREAM_STAGES:
+        return 0
+    r = WGRAD_STREAM_RPW[min(stage, len(WGRAD_STREAM_RPW) - 1)]
+    return r if M >= 1024 else 32
+
+
 class CompiledNet(object):
     def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None, fuse_bn=True, bf16=None, optimizer=None):
         """
@@ -511,7 +531,10 @@ class CompiledNet(object):
             self.early_side = []
             self._early_slice, self._early_work = None, [None]
             self._early_adam = None
+            self._wtrans_jobs = []
             self._emit_backward()
+            if self._wtrans_jobs:
+                self.early_side.append(ops.conv3x3_wtrans_multi(rt, self._wtrans_jobs))
             if self.early_side:
                 self.fwd.ops[0:0] = [(ops.Fork(), False)] + [(o, True) for o in self.early_side]
                 self.fwd.uses_side = True
@@ -1151,6 +1174,16 @@ class CompiledNet(object):
                 return
             mp = RowMap.strided(s, Ho, Wo, Hi, Wi) if s != 1 else None
             # filter gradient dW[o][c] = sum_m dY[m][o] * act(X)[map(m)][c]
+            rpw = wgrad_stream_rows(M)
+            if dy_act is None and WGRAD_STREAM and rpw > 0 and rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rpw) > 0:
+                # the row-streaming kernel (csrc/wgrad.hip): operands straight from memory into MFMA fragments, one partial slice per
+                # (workgroup, row split), all of them summed by the pass's single reduction launch
+                nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rpw)
+                part = rt.alloc(nsl * Co * Ci, zero=False)
+                self.bwd.add(ops.wgrad_stream(rt, dy, Co, src.base.buf, Ci, M, rpw, part, mapX=mp, actX=act,
+                                              name='wgrad1x1_%d' % layer.layerNum), side=True)
+                self.reduce_jobs.add(part, nsl, Co * Ci, gW)
+                return
             tile, splitk = wgrad_plan(Co, Ci, M)
             part = rt.alloc(splitk * Co * Ci, zero=False) if splitk > 1 else None     # persistent: reduced at the end of backward
             self.bwd.add(ops.gemm(rt, dy, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actA=dy_act,
@@ -1208,7 +1241,7 @@ class CompiledNet(object):
                 Wd = rt.alloc(Co * 9 * Ci, zero=False)
                 # the mirrored weights only depend on the parameters: they are prepared on the side stream while the forward
                 # pass runs (the side stream is idle then) instead of sitting in the data-gradient chain
-                self.early_side.append(ops.conv3x3_wtrans(rt, st.view(layer.W), Co, Ci, Wd))
+                self._wtrans_jobs.append((st.view(layer.W), Co, Ci, Wd))       # one batched launch, see _emit_backward
                 bmd = conv3x3_bm(N * Hi * Wi, Ci)
                 epi = None
                 if not acc and self._sole_consumer_bn_view(src):

@@ -97,6 +97,10 @@ SIGNATURES = {
     'dpp_reduce_multi_block_cols': (C.c_int, []),
     'dpp_reduce_multi': (C.c_int, [C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_colsum_partial': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_wgrad_stream_slices': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'dpp_wgrad_stream': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_wtrans_job_bytes': (C.c_size_t, []),
+    'dpp_conv3x3_wtrans_multi': (C.c_int, [C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_loss_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_loss_sse_bcast': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_error_l2': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),

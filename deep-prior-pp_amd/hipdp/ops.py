@@ -238,6 +238,14 @@ def gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, mapA=None, mapB=N
     return Launch(rt.lib.dpp_gemm, (C.byref(d),), (d, A, B, Cbuf, bias, residual, partial, actA, actB, epi), name, meta)
 
 
+def wgrad_stream(rt, dY, Co, X, Ci, M, rows_per_wave, partial, mapX=None, actX=None, name='wgrad_stream'):
+    """dpp_wgrad_stream: the filter gradient of a 1x1 convolution as per-slice partials [slices][Co][Ci]."""
+    nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rows_per_wave)
+    meta = dict(kernel='gemm_mfma_f32', flops=2.0 * M * Co * Ci, bytes=4.0 * (M * Co + M * Ci + nsl * Co * Ci))
+    return Launch(rt.lib.dpp_wgrad_stream, (dY.ptr, int(Co), X.ptr, int(Ci), C.byref(mapX) if mapX is not None else None, _actp(actX), int(M),
+                                            int(rows_per_wave), partial.ptr), (dY, X, partial, mapX, actX), name, meta)
+
+
 def fc_gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, actA=None, actB=None, bias=None, residual=None, splitk=1, partial=None,
             precision=0, kchunk=0, name='fc_gemm'):
     """dpp_fc_gemm: dpp_gemm's contract on the weight-streaming kernel (f32 or bf16 operands), see include/dpp_hip.h."""
@@ -276,6 +284,18 @@ def conv3x3(rt, X, N, H, W, Ci, Wk, Co, Y, actX=None, bias=None, residual=None, 
 
 def conv3x3_wtrans(rt, Wk, Co, Ci, Wd, name='conv3x3_wtrans'):
     return Launch(rt.lib.dpp_conv3x3_wtrans, (Wk.ptr, Co, Ci, Wd.ptr), (Wk, Wd), name)
+
+
+def conv3x3_wtrans_multi(rt, jobs, name='conv3x3_wtrans'):
+    """jobs: [(Wk buffer, Co, Ci, Wd buffer)]: the mirrored data-gradient weights of every 3x3 layer in ONE launch."""
+    import struct
+    assert rt.lib.dpp_wtrans_job_bytes() == 32
+    raw, block0 = b'', 0
+    for (Wk, Co, Ci, Wd) in jobs:
+        raw += struct.pack('<QQiiii', Wk.ptr, Wd.ptr, int(Co), int(Ci), block0, 0)
+        block0 += -(-(Co * 9 * Ci) // 256)
+    table = rt.upload(np.frombuffer(raw, np.uint8).copy())
+    return Launch(rt.lib.dpp_conv3x3_wtrans_multi, (table.ptr, len(jobs), block0), (table, list(jobs)), name)
 
 
 def conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, partial, actX=None, bm=64, name='conv3x3_wgrad'):

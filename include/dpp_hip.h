@@ -123,6 +123,18 @@ typedef struct {
 } dpp_gemm_desc;
 int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);
 
+/* Filter gradient of a 1x1 ConvLayer as a barrier-free row stream (csrc/wgrad.hip):
+ *   partial[s][o][c] = sum over the pixel rows m of slice s of  dY[m][o] * act(X)[mapX(m)][c]
+ * dY [M][Co] and X [rows][Ci] pixel-major (NHWC), mapX the stride row map of the layer (NULL = identity), actX the BatchNorm +
+ * ReLU prologue of the layer's input (NULL = none; modes 0-3).  rows_per_wave (a multiple of 4) pixel rows go to one wave; the
+ * number of slices written is dpp_wgrad_stream_slices(Co, Ci, M, rows_per_wave) -- 0 when (Co, Ci) is not one of the shapes of the
+ * ResNet's 1x1 layers (16x64, 64x16, 16x32, 64x32, 32x64, 32x128, 128x32, 128x64, 64x128, 64x256, 256x64, 256x128), for which
+ * dpp_gemm's generic filter-gradient layout (a_kc = b_kc = 0, splitk) remains.  Sum the slices with dpp_reduce_multi /
+ * dpp_reduce_partials (fixed order).  T.grad of convlayer.py:230-240 (poseregnettrainer.py:110-111). */
+int dpp_wgrad_stream_slices(int Co, int Ci, int M, int rows_per_wave);
+int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
+                     int rows_per_wave, float* partial, dpp_stream_t stream);
+
 /* The same contract on the weight-streaming kernel for the HiddenLayer behind the last convolution map (FC1: 16 384 x 1 024
  * weights at 128x128 input, 65 536 x 1 024 at 256x256; hiddenlayer.py:136-139 and its T.grad): tile 128 x 64, both operands
  * K-contiguous in LDS (memory-MN-contiguous operands are transposed while staged), double-buffered LDS.
@@ -159,6 +171,10 @@ int dpp_conv3x3_bf16(const float* X, int N, int H, int W, int Ci, const dpp_act*
 int dpp_conv3x3_tiling(int N, int H, int W, int bm, int* th, int* tw, int* img);
 /* Wd[c][8-tap][o] = Wk[o][tap][c] (mirrored taps, channels swapped): weights of the data-gradient correlation. */
 int dpp_conv3x3_wtrans(const float* Wk, int Co, int Ci, float* Wd, dpp_stream_t stream);
+/* Batched form: jobs_dev = device array of { const float* Wk; float* Wd; int Co, Ci, block0, pad; } sorted by block0, job j owning
+ * workgroups [block0_j, block0_j + ceil(Co*9*Ci / 256)); one launch mirrors the weights of every 3x3 layer of a net. */
+size_t dpp_wtrans_job_bytes(void);
+int dpp_conv3x3_wtrans_multi(const void* jobs_dev, int njobs, int total_blocks, dpp_stream_t stream);
 /* Filter gradient partials: partial[blk][o][tap][c] = sum over the workgroup's pixels of dY[.,o] * act(X)[.+tap, c];
  * blk < dpp_conv3x3_wgrad_blocks(N,H,W,Ci,Co,bm); sum over blk with dpp_reduce_partials.  (T.grad, poseregnettrainer.py:110-111) */
 int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int Ci, int Co, int bm);

@@ -369,3 +369,46 @@ def test_fc_gemm_layouts_and_precisions(backend, precision, layout):
             tol *= 2        # v_mfma_f32_16x16x32_bf16 adds the 32 products of a k-step in its own order before the f32 accumulate
         assert np.abs(got - want).max() < tol, (layout, precision, (M, N, K, splitk), np.abs(got - want).max(), tol)
 
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('shape', [(16, 64), (64, 16), (16, 32), (64, 32), (32, 64), (32, 128), (128, 32), (128, 64), (64, 128), (64, 256),
+                                   (256, 64), (256, 128)])
+def test_wgrad_stream_matches_float64(backend, shape):
+    """dpp_wgrad_stream (csrc/wgrad.hip): the filter gradient of every 1x1 layer shape of the ResNet as per-slice partials -- with the
+    BatchNorm + ReLU prologue on X, a ragged last slice, and the stride-2 row map of the projection blocks -- against float64."""
+    rt = get_runtime(backend)
+    Co, Ci = shape
+    rng = np.random.RandomState(Co * 1000 + Ci)
+    for strided in (False, True):
+        if strided:
+            N, Ho, Wo, s = 3, 5, 7, 2
+            Hi, Wi = Ho * s, Wo * s
+            M, rows_x = N * Ho * Wo, N * Hi * Wi
+            mp = RowMap.strided(s, Ho, Wo, Hi, Wi)
+            n, q = np.divmod(np.arange(M), Ho * Wo)
+            y, x = np.divmod(q, Wo)
+            xrow = n * Hi * Wi + (y * s) * Wi + x * s
+        else:
+            M = rows_x = 150                               # not a multiple of the slice: the last one is ragged
+            mp, xrow = None, np.arange(M)
+        dY = rng.normal(size=(M, Co)).astype(np.float32)
+        X = rng.normal(size=(rows_x, Ci)).astype(np.float32)
+        mean, scale, beta = (rng.normal(size=Ci).astype(np.float32), rng.uniform(0.5, 1.5, Ci).astype(np.float32),
+                             rng.normal(0, 0.3, Ci).astype(np.float32))
+        for mode in (0, 3):
+            rpw = 32
+            nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rpw)
+            assert nsl >= 1
+            part = rt.upload(np.full((nsl, Co, Ci), np.nan, np.float32))
+            bufs = [rt.upload(a) for a in (mean, scale, beta)]
+            act = ops.act(mode, *bufs, cmod=Ci) if mode else None
+            ops.wgrad_stream(rt, rt.upload(dY), Co, rt.upload(X), Ci, M, rpw, part, mapX=mp, actX=act)(rt.stream)
+            rt.synchronize()
+            got = part.get().astype(np.float64).sum(axis=0)
+            Xa = X[xrow].astype(np.float64)
+            if mode:
+                Xa = np.maximum((Xa - mean) * scale + beta, 0.0)
+            ref = dY.astype(np.float64).T @ Xa
+            _check(got, ref, M, 4)
+    assert rt.lib.dpp_wgrad_stream_slices(48, 64, 100, 32) == 0          # other shapes stay on dpp_gemm
