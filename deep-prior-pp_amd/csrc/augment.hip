@@ -22,6 +22,7 @@
 //                           gather hits L2 (a 64 KB crop is resident).
 // Compiled with -ffp-contract=off: the reference's NumPy/OpenCV arithmetic rounds after every operation, so no
 // fused multiply-add may be formed here (pixel coordinates at rounding boundaries would move).
+#include <stdlib.h>
 #include "dpp_common.h"
 
 namespace {
@@ -194,6 +195,9 @@ __device__ void philox4(unsigned long long seed, unsigned long long ctr, unsigne
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+__device__ __forceinline__ float u01f(unsigned a) {                   // (0,1), 24 bits
+    return ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
 __device__ __forceinline__ double u01(unsigned a, unsigned b) {       // (0,1), 53 bits
     unsigned long long v = (((unsigned long long)a << 32) | b) >> 11;
     return ((double)v + 0.5) * (1.0 / 9007199254740992.0);
@@ -225,6 +229,7 @@ struct PrepArgs {
     AugRec* rec;             // [B]
     float* out_y;            // [B][E] or [B][J*3]
     int* out_mode;           // [B] (optional: the mode actually used)
+    unsigned long long* prof; // phase stamps (profiling build only, see dpp_stamp)
 };
 
 // What the per-joint label transforms need from the per-sample geometry (written by thread 0, read by the joint threads).
@@ -241,31 +246,52 @@ struct AugLabelCtx {
 __device__ void aug_prepare_geometry(const PrepArgs& a, int b, float mx, AugRec& r, AugLabelCtx& lc) {
     const AugCam cam = a.cam;
     const double fx = fabs(cam.fx), fy = fabs(cam.fy);      // HandDetector(..., abs(di.fx), abs(di.fy))
+    // every global value this lane needs, requested BEFORE anything is computed: the draws, the mode table lookup and the geometry
+    // used to reach them one after the other -- five dependent memory round trips on a lane that does nothing else (tools/
+    // augment_phase.py: 9 us of geometry even in 'none' mode)
+    const float g_cube[3] = {a.cube[b * 3], a.cube[b * 3 + 1], a.cube[b * 3 + 2]};
+    const float g_com[3] = {a.com3d[b * 3], a.com3d[b * 3 + 1], a.com3d[b * 3 + 2]};
+    float g_M[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) g_M[i] = a.Mcrop[b * 9 + i];
+    int g_tab[4] = {0, 0, 0, 0};
+    if (!a.mode) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g_tab[i] = a.mode_table[i < a.n_modes ? i : 0];
+    }
+    const unsigned long long g_ctr = (!a.mode && a.counter_dev) ? *a.counter_dev : 0ull;
+    DPP_SCHED_FENCE();
     // ---- the four draws of augmentCrop (nettrainer.py:954-957) ----
     int mode; double off[3], rot, sc;
     if (a.mode) {
         mode = a.mode[b]; off[0] = a.off[b * 3]; off[1] = a.off[b * 3 + 1]; off[2] = a.off[b * 3 + 2]; rot = a.rot[b]; sc = a.sc[b];
     } else {
         unsigned r0[4], r1[4], r2[4];
-        unsigned long long ctr = (a.counter + (a.counter_dev ? *a.counter_dev : 0ull)) * a.gbatch + a.sample0 + b;
+        unsigned long long ctr = (a.counter + g_ctr) * a.gbatch + a.sample0 + b;
         philox4(a.seed, ctr, 0, r0); philox4(a.seed, ctr, 1, r1); philox4(a.seed, ctr, 2, r2);
-        mode = a.mode_table[r0[0] % (unsigned)a.n_modes];
-        double u1 = u01(r0[1], r0[2]), u2 = u01(r0[3], r1[0]), u3 = u01(r1[1], r1[2]), u4 = u01(r1[3], r2[0]);
-        double ra = sqrt(-2.0 * log(u1)), rb = sqrt(-2.0 * log(u3));
-        const double TWO_PI = 6.283185307179586;
-        off[0] = ra * cos(TWO_PI * u2) * a.sigma_com;
-        off[1] = ra * sin(TWO_PI * u2) * a.sigma_com;
-        off[2] = rb * cos(TWO_PI * u4) * a.sigma_com;
+        const unsigned mi = r0[0] % (unsigned)a.n_modes;
+        mode = mi < 4u ? (mi == 0 ? g_tab[0] : (mi == 1 ? g_tab[1] : (mi == 2 ? g_tab[2] : g_tab[3]))) : a.mode_table[mi];
+        // Box-Muller in float32 (hardware log / sin / cos rates): the draws are this kernel's own random numbers -- nothing pins
+        // their low bits (the reference draws from NumPy's Mersenne twister) -- and in float64 the six ocml transcendentals were
+        // ~8 us of the ~25 us this lane spends before the first pixel moves.  Everything DOWNSTREAM of the draws stays float64.
+        const float v1 = u01f(r0[1]), v2 = u01f(r0[3]), v3 = u01f(r1[1]), v4 = u01f(r1[3]);
+        const float ra = sqrtf(-2.0f * logf(v1)), rb = sqrtf(-2.0f * logf(v3));
+        float s2, c2, s4, c4;
+        sincosf(6.2831853f * v2, &s2, &c2);
+        sincosf(6.2831853f * v4, &s4, &c4);
+        off[0] = (double)(ra * c2) * a.sigma_com;
+        off[1] = (double)(ra * s2) * a.sigma_com;
+        off[2] = (double)(rb * c4) * a.sigma_com;
         rot = (2.0 * u01(r2[1], r2[2]) - 1.0) * a.rot_range;
-        sc = fabs(1.0 + rb * sin(TWO_PI * u4) * a.sigma_sc);
+        sc = fabs(1.0 + (double)(rb * s4) * a.sigma_sc);
     }
     if (a.out_mode) a.out_mode[b] = mode;
 
-    double cube[3] = {(double)a.cube[b * 3], (double)a.cube[b * 3 + 1], (double)a.cube[b * 3 + 2]};
+    double cube[3] = {(double)g_cube[0], (double)g_cube[1], (double)g_cube[2]};
     float com[3];           // CoM in image coordinates (float32 array in the reference)
-    toimg(cam, a.com3d[b * 3], a.com3d[b * 3 + 1], a.com3d[b * 3 + 2], true, com);
+    toimg(cam, g_com[0], g_com[1], g_com[2], true, com);
     double Mold[9];
-    for (int i = 0; i < 9; ++i) Mold[i] = (double)a.Mcrop[b * 9 + i];
+    for (int i = 0; i < 9; ++i) Mold[i] = (double)g_M[i];
 
     r.warp = WARP_NONE; r.thresh = 0; r.zlo = 0.f; r.zhi = 0.f;
     for (int i = 0; i < 9; ++i) r.m[i] = (i % 4 == 0) ? 1.0 : 0.0;
@@ -304,9 +330,12 @@ __device__ void aug_prepare_geometry(const PrepArgs& a, int b, float mx, AugRec&
         if (!zero) {
             rot = rot - floor(rot / 360.0) * 360.0;                 // numpy.mod(rot, 360)
             // cv2.getRotationMatrix2D((W//2, H//2), -rot, 1) then the inversion at the top of cv::warpAffine
-            double ang = -rot * 3.141592653589793 / 180.;
-            double al, be;
-            dpp_sincos_cr(ang, &be, &al);
+            // the warp angle -rot*pi/180 is exactly the negative of the label angle rot*pi/180 (negation is exact and commutes with
+            // the two roundings), and the correctly rounded sine / cosine are odd / even: ONE evaluation serves both
+            double sl, cl;
+            dpp_sincos_cr(rot * 3.141592653589793 / 180., &sl, &cl);
+            lc.sa = sl; lc.ca = cl;
+            const double al = cl, be = -sl;
             double cx = (double)(a.dsz / 2), cy = (double)(a.dsz / 2);
             double F[6] = {al, be, (1 - al) * cx - be * cy, -be, al, be * cx + (1 - al) * cy};
             double D = F[0] * F[4] - F[1] * F[3];
@@ -317,8 +346,10 @@ __device__ void aug_prepare_geometry(const PrepArgs& a, int b, float mx, AugRec&
             r.m[5] = -r.m[3] * F[2] - r.m[4] * F[5];
             r.warp = WARP_AFFINE;
         }
-        const double alpha = rot * 3.141592653589793 / 180.;
-        dpp_sincos_cr(alpha, &lc.sa, &lc.ca);
+        if (zero) {
+            const double alpha = rot * 3.141592653589793 / 180.;
+            dpp_sincos_cr(alpha, &lc.sa, &lc.ca);
+        }
     } else if (mode == AUG_SC) {
         const bool one = fabs(sc - 1.0) <= (1e-8 + 1e-5);                  // numpy.allclose(sc, 1.)
         if (!one) {
@@ -372,18 +403,41 @@ __device__ __forceinline__ void aug_label_joint(const PrepArgs& a, int b, const 
     }
 }
 
-// label -> PCA prior (poseregnettrainer.py:262) or the raw normalised joints; all threads of the workgroup
-__device__ __forceinline__ void aug_project_label(const PrepArgs& a, int b, const float* s_label) {
-    const int tid = threadIdx.x;
+// label -> PCA prior (poseregnettrainer.py:262) or the raw normalised joints, by threads t = 0 .. nt-1 (nt a multiple of 8: the whole
+// workgroup, or one wave)
+__device__ __forceinline__ void aug_project_label(const PrepArgs& a, int b, const float* s_label, int t, int nt) {
     const int D = a.J * 3;
     if (a.pca_comp) {
-        for (int e = tid; e < a.E; e += DPP_THREADS) {
-            double s = 0.0;
-            for (int d = 0; d < D; ++d) s += ((double)s_label[d] - (double)a.pca_mean[d]) * (double)a.pca_comp[(size_t)e * D + d];
-            a.out_y[(size_t)b * a.E + e] = (float)s;
+        // 8 lanes per output: lane p sums d = p, p + 8, ..., the eight partial sums meet in an xor butterfly (a fixed order).  One
+        // thread per output walked D dependent multiply-adds with two global loads each: 11 us for 30 x 48.
+        const int p = t & 7;
+        for (int e0 = 0; e0 < a.E; e0 += nt / 8) {
+            const int e = e0 + (t >> 3);
+            double sum = 0.0;
+            if (e < a.E) {
+                const float* comp = a.pca_comp + (size_t)e * D;
+                for (int d0 = p; d0 < D; d0 += 48) {               // six terms per round, their loads issued together
+                    float c[6], m[6];
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) {
+                        const int d = d0 + 8 * u;
+                        c[u] = d < D ? comp[d] : 0.0f;
+                        m[u] = d < D ? a.pca_mean[d] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) {
+                        const int d = d0 + 8 * u;
+                        if (d < D) sum += ((double)s_label[d] - (double)m[u]) * (double)c[u];
+                    }
+                }
+            }
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            sum += __shfl_xor(sum, 4);
+            if (e < a.E && p == 0) a.out_y[(size_t)b * a.E + e] = (float)sum;
         }
     } else {
-        for (int d = tid; d < D; d += DPP_THREADS) a.out_y[(size_t)b * D + d] = s_label[d];
+        for (int d = t; d < D; d += nt) a.out_y[(size_t)b * D + d] = s_label[d];
     }
 }
 
@@ -425,7 +479,7 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_prepare_kernel(PrepArgs a
     __syncthreads();
     if ((int)threadIdx.x < a.J) aug_label_joint(a, b, s_lc, threadIdx.x, s_label);
     __syncthreads();
-    aug_project_label(a, b, s_label);
+    aug_project_label(a, b, s_label, threadIdx.x, DPP_THREADS);
 }
 
 __device__ __forceinline__ long long cv_round(double v) { return (long long)rint(v); }
@@ -473,6 +527,69 @@ __device__ __forceinline__ float aug_warp_pixel(const AugRec& r, const float* __
     return v;
 }
 
+// Four consecutive output pixels (x .. x + 3, x % 4 == 0: one row, one 64-wide block of cv::warpPerspective) with the terms that
+// do not depend on x formed once: the row part of the perspective map (nine float64 products) and of the affine map (two cvRound).
+// The same expressions on the same inputs as aug_warp_pixel -- bit-identical results, a third of the float64 work per pixel.
+__device__ __forceinline__ float4 aug_warp_quad(const AugRec& r, const float* __restrict__ im, int dsz, int x, int y) {
+    float out[4];
+    if (r.warp == WARP_NONE) {
+        const float4 t = *reinterpret_cast<const float4*>(im + y * dsz + x);
+        out[0] = t.x * r.den_scale + r.den_off; out[1] = t.y * r.den_scale + r.den_off;
+        out[2] = t.z * r.den_scale + r.den_off; out[3] = t.w * r.den_scale + r.den_off;
+    } else {
+        long long X[4], Y[4];
+        if (r.warp == WARP_AFFINE) {
+            const long long X0 = cv_round((r.m[1] * (double)y + r.m[2]) * 1024.) + 512;
+            const long long Y0 = cv_round((r.m[4] * (double)y + r.m[5]) * 1024.) + 512;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long long ad = cv_round(r.m[0] * (double)(x + j) * 1024.), bd = cv_round(r.m[3] * (double)(x + j) * 1024.);
+                X[j] = (X0 + ad) >> 10; Y[j] = (Y0 + bd) >> 10;
+            }
+        } else {
+            const int bx = (x >> 6) << 6;
+            const double fbx = (double)bx, fy_ = (double)y;
+            const double X0 = r.m[0] * fbx + r.m[1] * fy_ + r.m[2];
+            const double Y0 = r.m[3] * fbx + r.m[4] * fy_ + r.m[5];
+            const double W0 = r.m[6] * fbx + r.m[7] * fy_ + r.m[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double x1 = (double)(x + j - bx);
+                double Wv = W0 + r.m[6] * x1;
+                Wv = (Wv != 0.0) ? 1. / Wv : 0.;
+                const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + r.m[0] * x1) * Wv));
+                const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + r.m[3] * x1) * Wv));
+                long long Xj = cv_round(fX), Yj = cv_round(fY);
+                X[j] = Xj < -32768 ? -32768 : (Xj > 32767 ? 32767 : Xj);
+                Y[j] = Yj < -32768 ? -32768 : (Yj > 32767 ? 32767 : Yj);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = 0.0f;                                          // BORDER_CONSTANT 0
+            if (X[j] >= 0 && X[j] < dsz && Y[j] >= 0 && Y[j] < dsz) v = im[(int)Y[j] * dsz + (int)X[j]] * r.den_scale + r.den_off;
+            if (r.thresh) {
+                if (fabs((double)v - 32000.0) <= 1e-8 + 1e-5 * 32000.0) v = 0.0f;     // numpy.isclose(warped, nv_val)
+                if (v < r.zlo && v != 0.0f) v = r.zlo;
+                else if (v > r.zhi && v != 0.0f) v = 0.0f;
+            }
+            out[j] = v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = out[j];
+        if (v == r.premax) v = r.far_v;
+        if (v == 0.0f) v = r.far_v;
+        if (v >= r.far_v) v = r.far_v;
+        if (v <= r.near_v) v = r.near_v;
+        v = (v - r.norm_off) / r.norm_div;
+        if (r.binarize) v = v < 0.5f ? 0.0f : 1.0f;
+        out[j] = v;
+    }
+    return make_float4(out[0], out[1], out[2], out[3]);
+}
+
 __global__ __launch_bounds__(DPP_THREADS) void augment_warp_kernel(const float* __restrict__ img, const AugRec* __restrict__ rec, int dsz,
                                                                    float* __restrict__ out) {
     const int b = blockIdx.y;
@@ -482,6 +599,20 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_warp_kernel(const float* 
     const AugRec r = rec[b];
     const int y = p / dsz, x = p - y * dsz;
     out[(size_t)b * npix + p] = aug_warp_pixel(r, img + (size_t)b * npix, dsz, x, y);
+}
+
+// Advance the device draw counter: every workgroup takes a ticket once its own read of the counter is done (it is: the geometry
+// consumed it before the barrier), the last one bumps the counter for the next launch and resets the ticket.  At the END of the
+// kernel: an atomic with a returned value is a memory round trip, and in front of the barrier it delayed every pixel of the crop.
+__device__ __forceinline__ void aug_take_ticket(unsigned long long* counter_rw, unsigned* ticket) {
+    if (ticket == nullptr || threadIdx.x != 0) return;
+    const unsigned long long c = *counter_rw;
+    const unsigned one = 1u + (unsigned)(c >> 63);
+    const unsigned t = atomicAdd(ticket, one);
+    if (t == gridDim.x - 1) {
+        *counter_rw = c + 1ull;
+        *ticket = 0u;
+    }
 }
 
 // The whole augmentation of a (macro-)batch as ONE launch.  Crop b is handled by S workgroups (S = a power of two chosen by the
@@ -505,40 +636,76 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_fused_kernel(PrepArgs a, 
     const bool live = b < a.B;
     const float* im = a.img + (size_t)(live ? b : 0) * npix;
     __shared__ AugLabelCtx s_lc;
-    const float mx = aug_crop_max(im, npix, s_red);
-    if (tid == 0) {
-        if (live) aug_prepare_geometry(a, b, mx, s_rec, s_lc);
-        if (ticket != nullptr) {
-            // the ticket is taken only after this workgroup's read of the counter has returned (data dependence)
-            unsigned long long c = *counter_rw;
-            unsigned one = 1u + (unsigned)(c >> 63);
-            unsigned t = atomicAdd(ticket, one);
-            if (t == gridDim.x - 1) {
-                *counter_rw = c + 1ull;
-                *ticket = 0u;
+    dpp_stamp(a.prof, 0);
+    // Two jobs side by side: waves 1-3 find the maximum of the stored crop (`premax`, one pass over 64 KB), wave 0's first lane runs
+    // the per-sample geometry, which needs the maximum only for ONE value (premax, patched in after the barrier).
+    // (rotating the serial lane's wave with the workgroup index, so that co-resident workgroups do not queue their serial lanes on one
+    //  SIMD, changed nothing: 26.0-26.5 us for every rotation, profiles/r03_augment_phases.txt)
+    const int vt = tid;
+    if (vt >= DPP_WAVE) {
+        float mx = -3.4e38f;
+        const int t = vt - DPP_WAVE, nt = DPP_THREADS - DPP_WAVE;
+        int i0 = 0;
+        if ((npix & 3) == 0 && (reinterpret_cast<uintptr_t>(im) & 15) == 0) {
+            // batches of 8 loads in flight per thread: one load per iteration made this pass ~20 dependent L2 / HBM round trips,
+            // the longest single item of the kernel at training batch sizes
+            const float4* im4 = reinterpret_cast<const float4*>(im);
+            const int n4 = npix >> 2;
+            for (int i = t; i < n4; i += 8 * nt) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int j = i + u * nt;
+                    v[u] = im4[j < n4 ? j : t];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mx = fmaxf(mx, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
             }
+            i0 = npix;
         }
+        for (int i = i0 + t; i < npix; i += nt) mx = fmaxf(mx, im[i]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        if ((vt & 63) == 0) s_red[vt >> 6] = mx;
+    }
+    if (vt == 0) {
+        if (live) aug_prepare_geometry(a, b, 0.0f, s_rec, s_lc);
+    }
+    if (vt == 0) dpp_stamp(a.prof, 1);                 // geometry (+ ticket) done on lane 0
+    __syncthreads();
+    dpp_stamp(a.prof, 2);                              // ... and the crop maximum on waves 1-3
+    if (!live) { aug_take_ticket(counter_rw, ticket); return; }
+    if (vt == 0) {
+        const float mx = fmaxf(fmaxf(s_red[1], s_red[2]), s_red[3]);
+        s_rec.premax = mx * s_rec.den_scale + s_rec.den_off;      // two roundings (contraction is off), as in aug_prepare_geometry
     }
     __syncthreads();
-    if (!live) return;
-    if (split == 0) {                                    // (uniform per workgroup: the barrier below is safe)
-        if (tid < a.J) aug_label_joint(a, b, s_lc, tid, s_label);      // one thread per joint
-        __syncthreads();
-        aug_project_label(a, b, s_label);
-        if (a.rec != nullptr && tid == 0) a.rec[b] = s_rec;
-    }
-    const AugRec r = s_rec;
+    // Split 0 also owns the labels: wave 0 transforms the joints (one lane per joint) and projects them while waves 1-3 are already
+    // moving pixels; it then takes a small share of the pixels itself (an eighth of the workgroup's, against its normal quarter).
     const int chunk = npix / S;                          // host guarantees npix % (4 * S) == 0 and dsz % 4 == 0
-    float* o = out_x + (size_t)b * npix;
-    for (int p = split * chunk + tid * 4; p < (split + 1) * chunk; p += DPP_THREADS * 4) {
-        const int y = p / a.dsz, x = p - y * a.dsz;
-        float4 v;
-        v.x = aug_warp_pixel(r, im, a.dsz, x, y);
-        v.y = aug_warp_pixel(r, im, a.dsz, x + 1, y);
-        v.z = aug_warp_pixel(r, im, a.dsz, x + 2, y);
-        v.w = aug_warp_pixel(r, im, a.dsz, x + 3, y);
-        *reinterpret_cast<float4*>(o + p) = v;
+    const int Q = chunk >> 2;                            // pixel quads of this workgroup
+    int q0 = 0, q1 = Q, t = tid, nt = DPP_THREADS;
+    if (split == 0) {
+        const int Qw = Q >= 8 * DPP_WAVE ? ((Q / 8) & ~(DPP_WAVE - 1)) : 0;
+        if (vt < DPP_WAVE) {
+            if (vt < a.J) aug_label_joint(a, b, s_lc, vt, s_label);
+            DPP_WAVE_SYNC();
+            aug_project_label(a, b, s_label, vt, DPP_WAVE);
+            if (a.rec != nullptr && vt == 0) a.rec[b] = s_rec;
+            q1 = Qw; t = vt; nt = DPP_WAVE;
+        } else {
+            q0 = Qw; t = vt - DPP_WAVE; nt = DPP_THREADS - DPP_WAVE;
+        }
     }
+    dpp_stamp(a.prof, 3);                              // labels + projection (split 0, wave 0)
+    const AugRec r = s_rec;
+    float* o = out_x + (size_t)b * npix;
+    for (int q = q0 + t; q < q1; q += nt) {
+        const int p = split * chunk + q * 4;
+        const int y = p / a.dsz, x = p - y * a.dsz;
+        *reinterpret_cast<float4*>(o + p) = aug_warp_quad(r, im, a.dsz, x, y);        // p, dsz multiples of 4: x % 4 == 0
+    }
+    dpp_stamp(a.prof, 4);
+    aug_take_ticket(counter_rw, ticket);
 }
 
 
@@ -769,7 +936,7 @@ extern "C" int dpp_augment_prepare(const float* img, const float* com3d, const f
     a.cam.fx = fx; a.cam.fy = fy; a.cam.ux = ux; a.cam.uy = uy; a.cam.flip_y = flip_y;
     a.B = B; a.J = J; a.dsz = dsz; a.norm01 = norm_zero_one & 1; a.binarize = (norm_zero_one >> 1) & 1; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
     a.rec = static_cast<AugRec*>(records); a.out_y = out_y; a.out_mode = out_mode;
-    a.sample0 = 0; a.gbatch = (unsigned long long)B;
+    a.sample0 = 0; a.gbatch = (unsigned long long)B; a.prof = nullptr;
     DPP_LAUNCH(augment_prepare_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return dpp_launch_status();
 }
@@ -801,7 +968,7 @@ extern "C" int dpp_augment(const float* img, const float* com3d, const float* cu
     a.cam.fx = fx; a.cam.fy = fy; a.cam.ux = ux; a.cam.uy = uy; a.cam.flip_y = flip_y;
     a.B = B; a.J = J; a.dsz = dsz; a.norm01 = norm_zero_one & 1; a.binarize = (norm_zero_one >> 1) & 1; a.pca_mean = pca_mean; a.pca_comp = pca_comp; a.E = E;
     a.rec = static_cast<AugRec*>(records); a.out_y = out_y; a.out_mode = out_mode;
-    a.sample0 = sample0; a.gbatch = global_batch;
+    a.sample0 = sample0; a.gbatch = global_batch; a.prof = dpp_prof_buffer;
     const int groups = dpp_cdiv(B, 8);             // crops are dealt to XCDs round-robin: 8 per group
     DPP_LAUNCH(augment_fused_kernel, dim3(groups * S * 8), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a, out_x, S,
                counter_dev, ticket);

@@ -108,6 +108,14 @@ extern unsigned long long* dpp_prof_buffer;                // host-side: where i
 #define DPP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// All lanes of a wave have executed what precedes before any executes what follows (LDS traffic between the lanes of ONE wave: the
+// hardware runs a wave's LDS instructions in order, so this only has to stop the compiler; the emulator's fibers meet in a shuffle).
+#ifdef DPP_HIP_EMU
+#define DPP_WAVE_SYNC() ((void)__shfl_xor(0, 1))
+#else
+#define DPP_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
 template <int NBYTES>
 __device__ __forceinline__ void dpp_kernarg_warm() {
 #ifndef DPP_HIP_EMU
