@@ -274,29 +274,42 @@ def main():
     value = world * B * args.steps / elapsed
 
     # ---- per-kernel-family timing with HIP events on the launch stream (after the timed region, rank 0) ----
+    # Every family's launches (in plan order) are re-issued back to back by the C++ plan runner between TWO events on the launch
+    # stream: the interval is the sum of the family's kernel durations plus the 1.6 us boundary behind each.  (Rounds 1-2 put an
+    # event behind every launch; an event is a marker packet of its own that costs the queue ~5 us -- profiles/r02_join_probe.txt --
+    # which inflated the average launch of the 10-20 us GEMMs by a third against the rocprofv3 kernel trace.)
     fam = {}
     if rank == 0 and not emu:
         stream = torch.cuda.current_stream()
         allops = [('aug', o) for o in step_plans[0][0].launches()] + eng.all_launches()
+        groups = {}
+        for ph, o in allops:
+            m = o.meta or dict(kernel=o.name, flops=0.0, bytes=0.0)
+            g = groups.setdefault(m['kernel'], dict(ops=[], flops=0.0, bytes=0.0))
+            g['ops'].append(o)
+            g['flops'] += m['flops']
+            g['bytes'] += m['bytes']
         reps = 3
-        for r in range(reps):
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(allops) + 1)]
+        for kname, g in groups.items():
+            plan = ops.NativePlan(rt, [(o, False) for o in g['ops']], mode='native')
+            plan.run(rt)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                plan.run(rt)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            fam[kname] = dict(ms=e0.elapsed_time(e1) / reps, n=len(g['ops']), flops=g['flops'], bytes=g['bytes'])
+        tot = sum(f['ms'] for f in fam.values())
+        if args.profile_ops:
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(allops) + 1)]        # per-launch detail: event after every launch
             evs[0].record(stream)
             for k, (_, o) in enumerate(allops):
                 o(rt.stream)
                 evs[k + 1].record(stream)
             torch.cuda.synchronize()
-            for k, (ph, o) in enumerate(allops):
-                m = o.meta or dict(kernel=o.name, flops=0.0, bytes=0.0)
-                f = fam.setdefault(m['kernel'], dict(ms=0.0, n=0, flops=0.0, bytes=0.0))
-                f['ms'] += evs[k].elapsed_time(evs[k + 1]) / reps
-                if r == 0:
-                    f['n'] += 1
-                    f['flops'] += m['flops']
-                    f['bytes'] += m['bytes']
-        tot = sum(f['ms'] for f in fam.values())
-        if args.profile_ops:
-            for k, (ph, o) in enumerate(allops):          # per-launch detail of the last repetition
+            for k, (ph, o) in enumerate(allops):          # (each interval carries ~5 us of event-marker cost)
                 m = o.meta or dict(kernel=o.name, flops=0.0, bytes=0.0)
                 t = evs[k].elapsed_time(evs[k + 1])
                 print('OP %-4s %-22s %-22s %8.2f us %8.2f TF/s %8.1f GB/s' % (ph, o.name, m['kernel'], t * 1e3,
@@ -305,7 +318,7 @@ def main():
                 print('%-26s n=%4d  %8.3f ms  %5.1f%%  %8.2f TFLOP/s  %8.1f GB/s' % (
                     kname, f['n'], f['ms'], 100 * f['ms'] / tot, f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] else 0,
                     f['bytes'] / (f['ms'] * 1e-3) / 1e9 if f['ms'] else 0), file=sys.stderr)
-            print('sum of per-launch event intervals: %.3f ms (step %.3f ms)' % (tot, ms), file=sys.stderr)
+            print('sum of the family intervals (one stream, back to back): %.3f ms (step %.3f ms)' % (tot, ms), file=sys.stderr)
 
     if rank == 0:
         roof = None
