@@ -134,6 +134,135 @@ int shape_wr(int Co, int Ci) {
     return 0;
 }
 
+// ---- 3x3 filter gradient as the same kind of stream ---------------------------------------------------------------------------------
+//   dW[o][t][c] = sum_p dY[p][o] * act(X)[p + (dy, dx)][c],   t = 3 (dy + 1) + (dx + 1), zero outside the image
+// The LDS-tiled conv3x3_wgrad_kernel stages a halo tile and the dY tile in LDS and spends 17 VALU instructions per MFMA on LDS
+// addressing and the prologue (profiles/r02_instruction_mix.txt): 18 TF/s, 0.67 ms of the gradient branch.  A 3x3 tap is only a
+// shifted row of the same tensor, so the row stream above takes it as it is: a step is 4 CONSECUTIVE pixels of one image row (W % 4
+// == 0), lane (l15, kq) loads its VA channels of dY at pixel p0 + kq and, per tap, its VB channels of X at the shifted pixel (the
+// centre pixel's address and a zero operand where the tap leaves the image); TG taps x VA x VB accumulator tiles per wave.  The nine
+// shifted reads of a pixel row hit the same cache lines (neighbouring taps, neighbouring steps): HBM sees each tensor about once
+// per tap group.
+struct Wgrad3sArgs {
+    const float* dY; const float* X; float* partial;
+    dpp_act actX;
+    int M, H, W, Co, Ci, rpw;
+};
+
+template <int V>
+__device__ __forceinline__ void load_vec_at(const char* base, unsigned byte_off, float (&v)[V]) {     // uniform base + 32-bit lane offset
+    load_vec<V>(reinterpret_cast<const float*>(base + byte_off), v);
+}
+
+template <int TA, int TB, int WA, int WB, int TG, int U>
+__global__ __launch_bounds__(DPP_THREADS) void wgrad3_stream_kernel(Wgrad3sArgs a) {
+    constexpr int WR = 4 / (WA * WB), VA = TA / WA, VB = TB / WB;
+    static_assert(WA * WB * WR == 4 && VA >= 1 && VB >= 1 && VA <= 4 && VB <= 4 && (TG == 3 || TG == 9), "wave split");
+    dpp_kernarg_warm<sizeof(Wgrad3sArgs)>();
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);              // row ranges and cursors below stay in scalar registers
+    const int wa = wave % WA, wb = (wave / WA) % WB, wr = wave / (WA * WB);
+    const int slice = blockIdx.x * WR + wr;
+    const int tap0 = blockIdx.y * TG;                    // TG == 3: one filter row (dy = blockIdx.y - 1) per blockIdx.y
+    const int row_begin = slice * a.rpw, row_end = (row_begin + a.rpw < a.M) ? row_begin + a.rpw : a.M;
+    const int H = a.H, W = a.W, Co = a.Co, Ci = a.Ci;
+    const int ca = wa * 16 * VA + VA * l15, cb = wb * 16 * VB + VB * l15;
+    // the prologue without selects: (v - 0) * 1 + 0 and max(v, -inf) are exact identities
+    float mu[VB], sc[VB], be[VB];
+    const int mode = a.actX.mode;
+#pragma unroll
+    for (int f = 0; f < VB; ++f) { mu[f] = 0.f; sc[f] = 1.f; be[f] = 0.f; }
+    if (mode & 2) { load_vec<VB>(a.actX.mean + cb, mu); load_vec<VB>(a.actX.scale + cb, sc); load_vec<VB>(a.actX.beta + cb, be); }
+    const float lo = (mode & 1) ? 0.0f : -__builtin_inff();
+    f32x4 acc[TG][VA][VB];
+#pragma unroll
+    for (int j = 0; j < TG; ++j)
+#pragma unroll
+        for (int e = 0; e < VA; ++e)
+#pragma unroll
+            for (int f = 0; f < VB; ++f) acc[j][e][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float av[U][VA], bv[U][TG][VB];
+    unsigned okv[U];                                     // bit j: tap j of the stage is inside the image; bit 16: the pixel row exists
+    const int last = row_end - 1;
+    const char* baseA = reinterpret_cast<const char*>(a.dY);
+    const char* baseB = reinterpret_cast<const char*>(a.X);
+    const unsigned strideA = (unsigned)Co * 4u, strideB = (unsigned)Ci * 4u, offA = (unsigned)ca * 4u, offB = (unsigned)cb * 4u;
+    int fp = row_begin, fx = row_begin % W, fy = (row_begin / W) % H;         // the fetch cursor: pixel, its column and image row
+    auto fetch = [&](int u) {
+        const int p = fp + kq, x = fx + kq;
+        const bool ok = p < row_end;
+        const int pp = ok ? p : last;
+        unsigned mask = ok ? 0x10000u : 0u;
+        load_vec_at<VA>(baseA, (unsigned)pp * strideA + offA, av[u]);
+#pragma unroll
+        for (int j = 0; j < TG; ++j) {
+            const int dy = (TG == 9 ? j / 3 : (int)blockIdx.y) - 1, dx = (TG == 9 ? j % 3 : j) - 1;
+            const bool v = ok & ((unsigned)(fy + dy) < (unsigned)H) & ((unsigned)(x + dx) < (unsigned)W);    // no short-circuit: no branches
+            const int q = v ? pp + dy * W + dx : pp;
+            mask |= (v ? 1u : 0u) << j;
+            load_vec_at<VB>(baseB, (unsigned)q * strideB + offB, bv[u][j]);
+        }
+        okv[u] = mask;
+        fp += 4; fx += 4;
+        const bool wrap = fx >= W;
+        fx = wrap ? 0 : fx;
+        fy += wrap ? 1 : 0;
+        fy = fy >= H ? 0 : fy;
+    };
+    if (row_begin < row_end) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) fetch(u);
+        DPP_SCHED_FENCE();
+        for (int m0 = row_begin; m0 < row_end; m0 += 4 * U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float bq[TG][VB], aq[VA];
+                const unsigned mask = okv[u];
+#pragma unroll
+                for (int j = 0; j < TG; ++j) {
+                    const bool in = (mask >> j) & 1u;
+#pragma unroll
+                    for (int f = 0; f < VB; ++f) bq[j][f] = in ? fmaxf((bv[u][j][f] - mu[f]) * sc[f] + be[f], lo) : 0.0f;
+                }
+#pragma unroll
+                for (int e = 0; e < VA; ++e) aq[e] = (mask & 0x10000u) ? av[u][e] : 0.0f;
+                DPP_SCHED_FENCE();
+                fetch(u);                                                  // refill: the step U ahead
+                DPP_SCHED_FENCE();
+#pragma unroll
+                for (int j = 0; j < TG; ++j)
+#pragma unroll
+                    for (int e = 0; e < VA; ++e)
+#pragma unroll
+                        for (int f = 0; f < VB; ++f) acc[j][e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[e], bq[j][f], acc[j][e][f], 0, 0, 0);
+            }
+        }
+    }
+    float* out = a.partial + (size_t)slice * Co * 9 * Ci;
+#pragma unroll
+    for (int e = 0; e < VA; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = wa * 16 * VA + VA * (kq * 4 + r) + e;
+#pragma unroll
+            for (int j = 0; j < TG; ++j) {
+                float* po = out + ((size_t)o * 9 + tap0 + j) * Ci + cb;
+                if (VB == 1) po[0] = acc[j][e][0][r];
+                else if (VB == 2) *reinterpret_cast<float2*>(po) = make_float2(acc[j][e][0][r], acc[j][e][1][r]);
+                else *reinterpret_cast<float4*>(po) = make_float4(acc[j][e][0][r], acc[j][e][1][r], acc[j][e][2][r], acc[j][e][3][r]);
+            }
+        }
+}
+
+// channels C = Co = Ci -> (rows split WR, taps per blockIdx.y TG) of the instantiation, or WR = 0
+void shape3(int Co, int Ci, int& WR, int& TG) {
+    WR = 0; TG = 9;
+    if (Co != Ci) return;
+    if (Co == 16) { WR = 4; TG = 9; }
+    else if (Co == 32) { WR = 4; TG = 3; }
+    else if (Co == 64) { WR = 1; TG = 3; }
+}
+
 }  // namespace
 
 extern "C" int dpp_wgrad_stream_slices(int Co, int Ci, int M, int rows_per_wave) {
@@ -177,4 +306,34 @@ extern "C" int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci,
     DPP_WG(256, 128, 4, 1, 4)
 #undef DPP_WG
     return DPP_E_UNSUPPORTED;
+}
+
+extern "C" int dpp_wgrad3_stream_slices(int Co, int Ci, int N, int H, int W, int rows_per_wave) {
+    int WR, TG;
+    shape3(Co, Ci, WR, TG);
+    if (!WR || N < 1 || H < 1 || W < 4 || (W & 3) || rows_per_wave < 4 || (rows_per_wave & 3)) return 0;
+    if ((long long)N * H * W * (Co > Ci ? Co : Ci) * 4 > 0x7fffffffLL) return 0;       // 32-bit byte offsets
+    return dpp_cdiv(N * H * W, rows_per_wave * WR) * WR;
+}
+
+extern "C" int dpp_wgrad3_stream(const float* dY, int Co, const float* X, int Ci, int N, int H, int W, const dpp_act* actX,
+                                 int rows_per_wave, float* partial, dpp_stream_t stream) {
+    if (!dY || !X || !partial) return DPP_E_BADARG;
+    const int nsl = dpp_wgrad3_stream_slices(Co, Ci, N, H, W, rows_per_wave);
+    if (!nsl) return DPP_E_UNSUPPORTED;
+    Wgrad3sArgs a;
+    a.dY = dY; a.X = X; a.partial = partial; a.M = N * H * W; a.H = H; a.W = W; a.Co = Co; a.Ci = Ci; a.rpw = rows_per_wave;
+    a.actX.mean = a.actX.scale = a.actX.beta = nullptr; a.actX.mode = 0; a.actX.cmod = Ci; a.actX.x2 = a.actX.aux = nullptr; a.actX.out = nullptr;
+    if (actX) a.actX = *actX;
+    if (a.actX.mode & ~3) return DPP_E_UNSUPPORTED;
+    if ((a.actX.mode & 2) && !(a.actX.mean && a.actX.scale && a.actX.beta && a.actX.cmod == Ci)) return DPP_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(partial)) & 15) return DPP_E_BADARG;
+    int WR, TG;
+    shape3(Co, Ci, WR, TG);
+    const dim3 grid(nsl / WR, 9 / TG), block(DPP_THREADS);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (Co == 16) DPP_LAUNCH((wgrad3_stream_kernel<1, 1, 1, 1, 9, 4>), grid, block, 0, st, a);
+    else if (Co == 32) DPP_LAUNCH((wgrad3_stream_kernel<2, 2, 1, 1, 3, 8>), grid, block, 0, st, a);
+    else DPP_LAUNCH((wgrad3_stream_kernel<4, 4, 2, 2, 3, 8>), grid, block, 0, st, a);
+    return dpp_launch_status();
 }

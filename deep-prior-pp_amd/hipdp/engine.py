@@ -427,6 +427,20 @@ WGRAD_STREAM_RPW = tuple(int(v) for v in knob('DPP_WGRAD_STREAM_RPW', '256,128,1
 WGRAD_STREAM_STAGES = knob('DPP_WGRAD_STREAM_STAGES', '1')            # which of them take the kernel
 
 
+# 3x3 filter gradients on dpp_wgrad3_stream for these channel counts (the rest stays on the LDS-tiled dpp_conv3x3_wgrad)
+WGRAD3_STREAM_C = tuple(int(v) for v in knob('DPP_WGRAD3_STREAM_C', '64').split(',') if v)
+
+
+def wgrad3_stream_rows(M, C):
+    """Pixel rows per wave of dpp_wgrad3_stream for a C -> C 3x3 layer over M pixels, or 0 (LDS-tiled kernel).  The partial slices of
+    a layer are held to ~9.4 MB (1 024 slices of 16 x 9 x 16, 256 of 32 x 9 x 32, 64 of 64 x 9 x 64): more slices is more waves but
+    the partials' write + re-read grows past the tensors themselves (tools/gemm_micro.py conv3, profiles/r03_wgrad3_stream.txt)."""
+    if C not in WGRAD3_STREAM_C:
+        return 0
+    slices = max(1, 1024 // max(1, (C // 16) ** 2))
+    return max(64, (M // slices) & ~3)
+
+
 def wgrad_stream_rows(M):
     """Pixel rows per wave of dpp_wgrad_stream for a layer with M pixel rows, or 0: leave the layer on dpp_gemm."""
     stage = 0 if M >= 65536 else (1 if M >= 16384 else 2)
@@ -1231,9 +1245,15 @@ class CompiledNet(object):
                 emit_param_grads(dY_keep, None)               # after the data gradient, which wrote dY_keep
         else:
             bm = 64
-            nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, Hi, Wi, Ci, Co, bm)
-            part = rt.alloc(nblk * Co * 9 * Ci, zero=False)
-            self.bwd.add(ops.conv3x3_wgrad(rt, src.base.buf, N, Hi, Wi, Ci, dY, Co, part, actX=act, bm=bm), side=True)
+            rpw = wgrad3_stream_rows(N * Hi * Wi, Ci) if Ci == Co else 0
+            nblk = rt.lib.dpp_wgrad3_stream_slices(Co, Ci, N, Hi, Wi, rpw) if rpw > 0 else 0
+            if nblk > 0:
+                part = rt.alloc(nblk * Co * 9 * Ci, zero=False)
+                self.bwd.add(ops.wgrad3_stream(rt, dY, Co, src.base.buf, Ci, N, Hi, Wi, rpw, part, actX=act), side=True)
+            else:
+                nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, Hi, Wi, Ci, Co, bm)
+                part = rt.alloc(nblk * Co * 9 * Ci, zero=False)
+                self.bwd.add(ops.conv3x3_wgrad(rt, src.base.buf, N, Hi, Wi, Ci, dY, Co, part, actX=act, bm=bm), side=True)
             self.reduce_jobs.add(part, nblk, Co * 9 * Ci, gW)
             if need_dx:
                 tgt, dst = self._view_grad(src)

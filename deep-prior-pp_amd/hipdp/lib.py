@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'lib', 'libdpp_hip.so')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 c_float_p = C.c_void_p      # device pointers travel as integers
 stream_t = C.c_void_p
 
@@ -99,6 +99,8 @@ SIGNATURES = {
     'dpp_colsum_partial': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_wgrad_stream_slices': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'dpp_wgrad_stream': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_wgrad3_stream_slices': (C.c_int, [C.c_int] * 6),
+    'dpp_wgrad3_stream': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
     'dpp_wtrans_job_bytes': (C.c_size_t, []),
     'dpp_conv3x3_wtrans_multi': (C.c_int, [C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_loss_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, stream_t]),

@@ -246,6 +246,15 @@ def wgrad_stream(rt, dY, Co, X, Ci, M, rows_per_wave, partial, mapX=None, actX=N
                                             int(rows_per_wave), partial.ptr), (dY, X, partial, mapX, actX), name, meta)
 
 
+def wgrad3_stream(rt, dY, Co, X, Ci, N, H, W, rows_per_wave, partial, actX=None, name='conv3x3_wgrad_stream'):
+    """dpp_wgrad3_stream: the filter gradient of a 3x3 convolution as per-slice partials [slices][Co][9][Ci]."""
+    nsl = rt.lib.dpp_wgrad3_stream_slices(Co, Ci, N, H, W, rows_per_wave)
+    px = float(N) * H * W
+    meta = dict(kernel='conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co, bytes=4.0 * (px * (Ci + Co) + nsl * 9.0 * Ci * Co))
+    return Launch(rt.lib.dpp_wgrad3_stream, (dY.ptr, int(Co), X.ptr, int(Ci), int(N), int(H), int(W), _actp(actX), int(rows_per_wave),
+                                             partial.ptr), (dY, X, partial, actX), name, meta)
+
+
 def fc_gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, actA=None, actB=None, bias=None, residual=None, splitk=1, partial=None,
             precision=0, kchunk=0, name='fc_gemm'):
     """dpp_fc_gemm: dpp_gemm's contract on the weight-streaming kernel (f32 or bf16 operands), see include/dpp_hip.h."""

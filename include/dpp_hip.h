@@ -34,7 +34,7 @@ typedef void* dpp_stream_t; /* a hipStream_t */
 #define DPP_E_BADARG 10001
 #define DPP_E_UNSUPPORTED 10002
 
-#define DPP_ABI_VERSION 7
+#define DPP_ABI_VERSION 8
 int dpp_abi_version(void);
 
 /* Pixel row map: row m of a compact (N,Ho,Wo) map -> row of a (N,Hi,Wi) map sampled with stride s.
@@ -134,6 +134,15 @@ int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);
 int dpp_wgrad_stream_slices(int Co, int Ci, int M, int rows_per_wave);
 int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
                      int rows_per_wave, float* partial, dpp_stream_t stream);
+
+/* Filter gradient of a 3x3 'half'-padded, stride-1 ConvLayer on the same kind of stream:
+ *   partial[s][o][t][c] = sum over the pixels p of slice s of  dY[p][o] * act(X)[p + (dy, dx)][c],  t = 3 (dy + 1) + (dx + 1),
+ * taps outside the image contribute zero.  X [N][H][W][Ci], dY [N][H][W][Co], W % 4 == 0 (a step is four neighbouring pixels of a
+ * row).  Shapes: Co == Ci in {16, 32, 64} (the bottleneck convolutions of resnet.py:300-420); dpp_wgrad3_stream_slices returns 0
+ * for anything else and dpp_conv3x3_wgrad (the LDS-tiled kernel, same partial layout per block) remains.  Same T.grad. */
+int dpp_wgrad3_stream_slices(int Co, int Ci, int N, int H, int W, int rows_per_wave);
+int dpp_wgrad3_stream(const float* dY, int Co, const float* X, int Ci, int N, int H, int W, const dpp_act* actX, int rows_per_wave,
+                      float* partial, dpp_stream_t stream);
 
 /* The same contract on the weight-streaming kernel for the HiddenLayer behind the last convolution map (FC1: 16 384 x 1 024
  * weights at 128x128 input, 65 536 x 1 024 at 256x256; hiddenlayer.py:136-139 and its T.grad): tile 128 x 64, both operands

@@ -16,7 +16,7 @@ def up(rt, **kw):
 
 @pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('cfg', [(3, 8, 8, 16, 16, 64), (2, 16, 16, 32, 32, 128), (5, 4, 4, 64, 64, 64), (2, 6, 10, 16, 32, 128),
-                                 (20, 2, 2, 16, 16, 64)])
+                                 (20, 2, 2, 16, 16, 64), (3, 5, 12, 64, 64, 64)])
 def test_conv3x3_fwd_dgrad_wgrad(backend, cfg):
     rt = get_runtime(backend)
     N, H, W, Ci, Co, bm = cfg
@@ -55,6 +55,19 @@ def test_conv3x3_fwd_dgrad_wgrad(backend, cfg):
     rt.synchronize()
     dW = layout.conv_w_from_kernel(dWk.get(), (Co, Ci, 3, 3))
     np.testing.assert_allclose(dW, dW_ref, rtol=0, atol=3e-6 * np.sqrt(N * H * W) * np.abs(dW_ref).max())
+    # the same gradient on the row-streaming kernel (shapes of the bottleneck convolutions, W % 4 == 0), ragged row ranges
+    for rpw in (8, 20, 256):
+        nsl = rt.lib.dpp_wgrad3_stream_slices(Co, Ci, N, H, W, rpw)
+        if Co != Ci or Co not in (16, 32, 64) or W % 4:
+            assert nsl == 0
+            continue
+        assert nsl > 0
+        part = rt.alloc((nsl, Co, 9, Ci), zero=False)
+        ops.wgrad3_stream(rt, dYb, Co, d['X'], Ci, N, H, W, rpw, part, actX=act)(rt.stream)
+        ops.reduce_partials(rt, part, nsl, Co * 9 * Ci, dWk)(rt.stream)
+        rt.synchronize()
+        dW = layout.conv_w_from_kernel(dWk.get(), (Co, Ci, 3, 3))
+        np.testing.assert_allclose(dW, dW_ref, rtol=0, atol=3e-6 * np.sqrt(N * H * W) * np.abs(dW_ref).max())
 
 
 @pytest.mark.parametrize('backend', BACKENDS)

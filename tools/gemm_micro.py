@@ -132,7 +132,8 @@ def main_feats():
 
 
 def main_conv3():
-    for label, N, H, C in (('stage1 3x3 16->16', 128, 32, 16), ('stage2 3x3 32->32', 128, 16, 32), ('stage3/4 3x3 64->64', 128, 8, 64)):
+    for label, N, H, C in (('stage1 3x3 16->16', 128, 32, 16), ('stage2 3x3 32->32', 128, 16, 32), ('stage3/4 3x3 64->64', 128, 8, 64),
+                           ('256: stage1 16->16', 128, 64, 16), ('256: stage2 32->32', 128, 32, 32), ('256: stage3/4 64->64', 128, 16, 64)):
         X = rt.alloc((N, H, H, C), zero=False)
         rt.tensor(X).normal_()
         Wk = rt.alloc((C, 9, C), zero=False)
@@ -153,6 +154,17 @@ def main_conv3():
             us = timeit(ops.conv3x3_wgrad(rt, X, N, H, H, C, dY, C, part, bm=bm))
             print('%-22s bm=%3d wgrad  %7.2f us  %6.1f TFLOP/s  %6.0f GB/s (%d partial blocks)' %
                   (label, bm, us, 2.0 * px * 9 * C * C / us * 1e-6, 8.0 * px * C / us * 1e-3, nblk))
+        mean, scale, beta = rt.alloc(C), rt.alloc(C), rt.alloc(C)
+        act = Act(mean.ptr, scale.ptr, beta.ptr, 3, C)
+        for rpw in (64, 128, 256, 512):
+            nsl = rt.lib.dpp_wgrad3_stream_slices(C, C, N, H, H, rpw)
+            if nsl <= 0 or nsl * C * 9 * C * 4 > 64 << 20:
+                continue
+            part = rt.alloc((nsl, C * 9 * C), zero=False)
+            us = timeit(ops.wgrad3_stream(rt, dY, C, X, C, N, H, H, rpw, part, actX=act))
+            red = timeit(ops.reduce_partials(rt, part, nsl, C * 9 * C, Wk))
+            print('%-22s rpw=%3d wgrad stream %7.2f us  %6.1f TFLOP/s  %6.0f GB/s (%d slices, %.1f MB; reduce %.2f us)' %
+                  (label, rpw, us, 2.0 * px * 9 * C * C / us * 1e-6, 8.0 * px * C / us * 1e-3, nsl, nsl * C * 9 * C * 4e-6, red))
 
 
 def main_floor():
