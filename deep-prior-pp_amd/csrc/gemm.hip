@@ -1063,13 +1063,9 @@ int launch_layout(const GemmArgs& ga, hipStream_t st) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-}  // namespace
-
-extern "C" int dpp_abi_version(void) { return DPP_ABI_VERSION; }
-
-extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
+// argument checks and the alignment facts every kernel choice rests on (shared by dpp_gemm and dpp_gemm_variant_rows)
+static int gemm_prepare(const dpp_gemm_desc* dp, GemmArgs& ga) {
     if (!dp || !dp->A || !dp->B || dp->M <= 0 || dp->N <= 0 || dp->K <= 0) return DPP_E_BADARG;
-    GemmArgs ga;
     ga.d = *dp;
     ga.prof = dpp_prof_buffer;
     dpp_gemm_desc& d = ga.d;
@@ -1095,6 +1091,26 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
               aligned16(d.epi.bn_beta) && aligned16(d.epi.bn_inv_std);
     if ((d.actA.mode & 2) && !(aligned16(d.actA.mean) && aligned16(d.actA.scale) && aligned16(d.actA.beta))) return DPP_E_BADARG;
     if ((d.actB.mode & 2) && !(aligned16(d.actB.mean) && aligned16(d.actB.scale) && aligned16(d.actB.beta))) return DPP_E_BADARG;
+    return DPP_OK;
+}
+
+}  // namespace
+
+extern "C" int dpp_abi_version(void) { return DPP_ABI_VERSION; }
+
+extern "C" int dpp_gemm_variant_rows(const dpp_gemm_desc* dp) {
+    GemmArgs ga;
+    if (gemm_prepare(dp, ga) != DPP_OK) return 0;
+    if (ga.d.variant == 2) return ksplit_bn(ga.d, ga) ? 32 : 0;
+    if (ga.d.variant == 3) return stream16_rows(ga.d, ga);
+    return 0;
+}
+
+extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
+    GemmArgs ga;
+    const int prep = gemm_prepare(dp, ga);
+    if (prep != DPP_OK) return prep;
+    dpp_gemm_desc& d = ga.d;
     const bool red_layout = !d.a_kc && !d.b_kc;
     static const int bk64_min_k = []() { const char* e = getenv("DPP_GEMM_BK64_MINK"); return e ? atoi(e) : 128; }();
     ga.bk = (d.K > 16) ? 32 : 16;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(DPP_THREADS) void pose_sample_kernel(const float* _
 
 // ---- PCA: column sums (f64 partials per block of rows), scatter matrix about the mean, Jacobi ---------------------------------
 constexpr int PCA_ROWS = 256;          // rows per workgroup
-constexpr int PCA_MAXD = 192;
+constexpr int PCA_MAXD = 80;           // 26 joints: the 256-row scatter tile (256 * D * 8 bytes) and the two D x D Jacobi matrices live in LDS
 
 __global__ __launch_bounds__(DPP_THREADS) void pca_colsum_kernel(const float* __restrict__ X, long N, int D, double* __restrict__ partial) {
     // partial[block][d] = sum of the block's rows of column d; thread d walks its column (rows are D floats apart: the block's
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(DPP_THREADS) void pca_jacobi_kernel(double* __restr
     double* a = sm;                 // [D][D]
     double* v = sm + D * D;         // [D][D], columns = eigenvectors
     __shared__ double cs[2];
+    __shared__ double red[2][DPP_THREADS];
     __shared__ int order[PCA_MAXD];
     const int tid = threadIdx.x;
     for (int e = tid; e < D * D; e += DPP_THREADS) {
@@ -213,6 +214,23 @@ __global__ __launch_bounds__(DPP_THREADS) void pca_jacobi_kernel(double* __restr
                 __syncthreads();
             }
         }
+        // converged when the off-diagonal mass is at rounding level of the diagonal's: ||off||_F <= eps * ||diag||_F (cyclic Jacobi
+        // converges quadratically, the sweep after 1e-8 is already there); `sweeps` caps the loop for pathological input
+        double off = 0.0, dg = 0.0;
+        for (int e = tid; e < D * D; e += DPP_THREADS) {
+            const int i = e / D, j = e - i * D;
+            const double x = a[e] * a[e];
+            if (i == j) dg += x; else off += x;
+        }
+        red[0][tid] = off; red[1][tid] = dg;
+        __syncthreads();
+        for (int st = DPP_THREADS / 2; st > 0; st >>= 1) {
+            if (tid < st) { red[0][tid] += red[0][tid + st]; red[1][tid] += red[1][tid + st]; }
+            __syncthreads();
+        }
+        const bool done = red[0][0] <= 4.93e-32 * red[1][0];
+        __syncthreads();
+        if (done) break;
     }
     // sort by eigenvalue, descending (selection by rank; ties broken by index)
     for (int k = tid; k < D; k += DPP_THREADS) {
@@ -373,14 +391,16 @@ extern "C" int dpp_pca_fit(const float* X, long N, int D, void* workspace, doubl
     DPP_LAUNCH(pca_reduce_kernel, dim3(dpp_cdiv(D, DPP_THREADS)), dim3(DPP_THREADS), 0, st, (const double*)partial, nblk, D, 1.0 / (double)N, mean);
     const size_t lds1 = (size_t)PCA_ROWS * D * sizeof(double);
     if (lds1 > 160 * 1024) return DPP_E_UNSUPPORTED;
-    if (lds1 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pca_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (lds1 > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&pca_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess)
+        return DPP_E_UNSUPPORTED;                        // a part with less LDS than the MI355X's 160 KB
     DPP_LAUNCH(pca_scatter_kernel, dim3(nblk), dim3(DPP_THREADS), lds1, st, X, N, D, (const double*)mean, partial);
     DPP_LAUNCH(pca_reduce_kernel, dim3(dpp_cdiv(D * D, DPP_THREADS)), dim3(DPP_THREADS), 0, st, (const double*)partial, nblk, D * D,
                1.0 / (double)(N - 1), scatter);
     const size_t lds2 = (size_t)2 * D * D * sizeof(double);
     if (lds2 > 160 * 1024) return DPP_E_UNSUPPORTED;
-    if (lds2 > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pca_jacobi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    DPP_LAUNCH(pca_jacobi_kernel, dim3(1), dim3(DPP_THREADS), lds2, st, scatter, D, evals, components, 12);
+    if (lds2 > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&pca_jacobi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+        return DPP_E_UNSUPPORTED;
+    DPP_LAUNCH(pca_jacobi_kernel, dim3(1), dim3(DPP_THREADS), lds2, st, scatter, D, evals, components, 30);      // sweeps: a cap, see the kernel
     return dpp_launch_status();
 }
 

@@ -630,7 +630,10 @@ class CompiledNet(object):
         if FC1_STREAM != 'auto':
             return False
         # f32: whole 128-row tiles in all three GEMMs (forward / data gradient rows = samples, filter gradient reduces over them),
-        # whole 32-deep chunks per K slice
+        # whole 32-deep chunks per K slice.  This is the one kernel choice that DOES depend on the batch (stream16_plan's rule, above,
+        # is about the convolutions): batches that are no multiple of 128 stay on dpp_gemm, whose K order differs.  The bar that
+        # bounds the difference: tests/test_full_size.py evaluates the same frames in batches of 8 (dpp_gemm) and 128 (this kernel)
+        # and holds the joints to 1e-4 mm.
         splitk = max(1, min(FC1_SLICES, K // 512))
         return Nb % 128 == 0 and K % 128 == 0 and Nout % 64 == 0 and K % splitk == 0 and (K // splitk) % 32 == 0
 
@@ -854,15 +857,21 @@ class CompiledNet(object):
             s16 = stream16_plan(M, Co, Ci, True) if (s[0] == 1 and rs is None and ks is None) else None
             if s16 is not None:
                 tile = s16
+            mp = RowMap.strided(s[0], Ho, Wo, Hi, Wi) if s[0] != 1 else None
+            variant = 1 if rs is not None else (2 if ks is not None else (3 if s16 is not None else 0))
+
+            def build(tile, variant, epi):
+                return ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
+                                bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=variant,
+                                name='conv1x1_%d' % layer.layerNum)
+            if variant in (2, 3) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
+                # the shape asks for the kernel, the buffers rule it out (alignment / prologue): the generic tile, not a failed build
+                variant, (tile, _) = 0, gemm_plan(M, Co, Ci, allow_split=False)
             if want_stats:
                 nblk = -(-M // tile[0])
                 out.stats = (rt.alloc((nblk, 2, Co), zero=False), nblk, tile[0])
                 epi = ops.epilogue(stats=out.stats[0])
-            mp = RowMap.strided(s[0], Ho, Wo, Hi, Wi) if s[0] != 1 else None
-            variant = 1 if rs is not None else (2 if ks is not None else (3 if s16 is not None else 0))
-            self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
-                                  bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=variant,
-                                  name='conv1x1_%d' % layer.layerNum))
+            self.fwd.add(build(tile, variant, epi))
         else:
             bm = conv3x3_bm(M, Co)
             if want_stats:
@@ -1226,6 +1235,14 @@ class CompiledNet(object):
                 s16 = stream16_plan(M, Ci, Co, False) if (s == 1 and rs is None and ks is None and dY_act is None) else None
                 if s16 is not None:
                     tile = s16
+                variant = 1 if (rs is not None and dY_act is None) else (2 if ks is not None else (3 if s16 is not None else 0))
+
+                def build(tile, variant, epi):
+                    return ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
+                                    residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
+                                    name='dgrad1x1_%d' % layer.layerNum)
+                if variant in (2, 3) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
+                    variant, (tile, _) = 0, gemm_plan(M, Ci, Co, allow_split=False)       # see the forward twin
                 epi = None
                 if (s == 1 and not acc and self._sole_consumer_bn_view(src)) or (acc and self._two_conv1x1_consumers(src)):
                     # ReLU mask + (sum G, sum G*xhat) of the BatchNorm backward in this kernel's epilogue.  A projection block
@@ -1235,10 +1252,7 @@ class CompiledNet(object):
                     nb2 = -(-M // tile[0])
                     tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
                     epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
-                variant = 1 if (rs is not None and dY_act is None) else (2 if ks is not None else (3 if s16 is not None else 0))
-                self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
-                                      residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
-                                      name='dgrad1x1_%d' % layer.layerNum))
+                self.bwd.add(build(tile, variant, epi))
                 tgt.grad_written = True
             if dY_keep is not None:
                 assert need_dx

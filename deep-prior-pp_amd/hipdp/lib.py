@@ -59,6 +59,7 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     'dpp_abi_version': (C.c_int, []),
     'dpp_gemm': (C.c_int, [C.POINTER(GemmDesc), stream_t]),
+    'dpp_gemm_variant_rows': (C.c_int, [C.POINTER(GemmDesc)]),
     'dpp_fc_gemm': (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_int, stream_t]),
     'dpp_reduce_partials': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
     'dpp_conv3x3': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,

@@ -238,6 +238,12 @@ def gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, mapA=None, mapB=N
     return Launch(rt.lib.dpp_gemm, (C.byref(d),), (d, A, B, Cbuf, bias, residual, partial, actA, actB, epi), name, meta)
 
 
+def gemm_variant_rows(rt, launch):
+    """dpp_gemm_variant_rows for a launch built by gemm(): rows per workgroup of the kernel its `variant` asks for, or 0 when the C
+    side would answer DPP_E_UNSUPPORTED (alignment, prologue mode, epilogue) -- the caller then describes it with variant 0."""
+    return int(rt.lib.dpp_gemm_variant_rows(C.byref(launch.keep[0])))
+
+
 def wgrad_stream(rt, dY, Co, X, Ci, M, rows_per_wave, partial, mapX=None, actX=None, name='wgrad_stream'):
     """dpp_wgrad_stream: the filter gradient of a 1x1 convolution as per-slice partials [slices][Co][Ci]."""
     nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rows_per_wave)

@@ -122,6 +122,11 @@ typedef struct {
     dpp_epilogue epi; /* fused statistics / BatchNorm-backward epilogue (requires splitk == 1) */
 } dpp_gemm_desc;
 int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);
+/* Would dpp_gemm run `d` on the kernel d->variant asks for (2 or 3)?  Returns that kernel's rows per workgroup (the row-block count of
+ * the fused-epilogue partials is M / rows), or 0: alignment, prologue mode or the epilogue rule it out and the caller should describe
+ * the problem with variant 0 and a generic tile instead (dpp_gemm itself returns DPP_E_UNSUPPORTED rather than change the partial
+ * layout behind the caller's back).  Launches nothing. */
+int dpp_gemm_variant_rows(const dpp_gemm_desc* d);
 
 /* Filter gradient of a 1x1 ConvLayer as a barrier-free row stream (csrc/wgrad.hip):
  *   partial[s][o][c] = sum over the pixel rows m of slice s of  dY[m][o] * act(X)[mapX(m)][c]
@@ -361,7 +366,8 @@ int dpp_crop_refine(const float* frames, const void* records, int B, int H, int 
  *   projections, f32 storage) runs here.  out_poses [n][J][3] normalised by the (new) cube_z / 2; out_com / out_cube may be NULL.
  * pca_fit: sklearn PCA.fit on X [N][D] f32 (main_nyu_posereg_embedding.py:86-92): mean[D], the eigenvalues of the covariance
  *   (1 / (N - 1)) in descending order and the eigenvectors as ROWS (components_, largest-magnitude entry of each row positive),
- *   all f64; D <= 192.  workspace: dpp_pca_workspace_bytes(N, D) bytes of device memory.
+ *   all f64; D <= 80 (26 joints: the scatter tile and the Jacobi matrices are LDS-resident; DPP_E_BADARG beyond).  The Jacobi sweeps
+ *   run until the off-diagonal mass is at f64 rounding level of the diagonal's (at most 30).  workspace: dpp_pca_workspace_bytes(N, D) bytes of device memory.
  * pose_eval: HandposeEvaluation's numeric methods (/root/reference/src/util/handpose_evaluation.py:92-228) on gt / pred [N][J][3]:
  *   err [N][J] Euclidean errors, frame [N][4] = per-frame (nanmean, nanmax, count, nanstd) over joints, and out (4 + 3J + 2T
  *   doubles): mean error, max error, mean of the frame stds, frames counted; per-joint nanmean / nanstd / nanmax; for each of the T

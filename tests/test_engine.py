@@ -7,7 +7,7 @@ Tolerances: the north-star bar is 1e-3 mm on the 3-D joint output, i.e. 1e-3 / 1
 import numpy as np
 import pytest
 
-from hipdp import engine
+from hipdp import engine, ops
 from net.resnet import ResNet, ResNetParams
 from oracle import layers as L
 from oracle import nets, torch_ref
@@ -122,7 +122,7 @@ def test_resnet_forward_eval_matches_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'fc1stream', 'early_reduce'])
+@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'fc1stream', 'early_reduce', 'no_variants'])
 def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatch):
     """'lazy': type 0 with the opt-in plan in which the 1x1 convolutions form the gradient through a BatchNorm from (G, x) in
     their operand prologue (engine.LAZY_BN_BWD) instead of reading a tensor written by bn_bwd_apply.
@@ -139,6 +139,12 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
     if type_ == 'early_reduce':
         monkeypatch.setattr(engine, 'EARLY_REDUCE_BYTES', 1 << 14)
         type_ = 0
+    no_variants = type_ == 'no_variants'
+    if no_variants:
+        # the C side rules the K-split / 16-column stream kernels out for every launch (as misaligned buffers or
+        # DPP_GEMM_WIDE_EPILOGUE=0 would): the engine describes those convolutions with the generic tile instead of failing the build
+        monkeypatch.setattr(ops, 'gemm_variant_rows', lambda rt, launch: 0)
+        type_ = 0
     if type_ == 'fc1stream':
         monkeypatch.setattr(engine, 'FC1_MIN_K', 512)
         monkeypatch.setattr(engine, 'FC1_STREAM', '1')
@@ -147,6 +153,8 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
     nJ, nD = (1, 30) if type_ == 0 else (14, 3)
     net, onet, P = make_net(rt, type_, 4, 32, nJ, nD)
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    variants = [l.keep[0].variant for _, l in eng.all_launches() if l.fn is rt.lib.dpp_gemm]
+    assert (not any(v in (2, 3) for v in variants)) if no_variants else any(v in (2, 3) for v in variants)
     if engine.LAZY_BN_BWD:
         assert any(l.name.startswith('dgrad1x1') and l.keep[0].actA.mode == 4 for l in eng.bwd.launches())
     if engine.FC1_MIN_K == 512:

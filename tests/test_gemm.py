@@ -233,6 +233,13 @@ def test_ksplit_variant_fwd_and_dgrad(backend, cfg):
     # what the kernel does not take is refused, not mis-computed
     with pytest.raises(Exception):
         ops.gemm(rt, b['X'], b['Wk'], Y, M - 8, N, K, 1, 1, K, K, N, tile=(32, bn, 4), variant=2)(rt.stream)
+    # ... and the host can ask first (dpp_gemm_variant_rows): rows per workgroup when the kernel takes it, 0 for ragged rows or an
+    # operand that is not 16-byte aligned, so that the engine describes those with the generic tile
+    assert ops.gemm_variant_rows(rt, ops.gemm(rt, b['X'], b['Wk'], Y, M, N, K, 1, 1, K, K, N, tile=(32, bn, 4), variant=2)) == 32
+    assert ops.gemm_variant_rows(rt, ops.gemm(rt, b['X'], b['Wk'], Y, M - 8, N, K, 1, 1, K, K, N, tile=(32, bn, 4), variant=2)) == 0
+    Xo = rt.alloc(M * K + 4, zero=False).view(1, (M, K))                                     # 4 bytes off a 16-byte boundary
+    assert ops.gemm_variant_rows(rt, ops.gemm(rt, Xo, b['Wk'], Y, M, N, K, 1, 1, K, K, N, tile=(32, bn, 4), variant=2)) == 0
+    assert ops.gemm_variant_rows(rt, ops.gemm(rt, b['X'], b['Wk'], Y, M, N, K, 1, 1, K, K, N, tile=(64, bn, 4), variant=0)) == 0
 
 
 @pytest.mark.parametrize('backend', BACKENDS)

@@ -84,6 +84,30 @@ def test_device_pca_matches_sklearn(backend, J):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+def test_device_pca_converges_at_the_largest_dimension(backend):
+    """D = 78 (26 joints; dpp_pca_fit takes D <= 80) with clustered eigenvalues: the Jacobi sweeps run until the off-diagonal mass is at rounding
+    level (not a fixed count), so the eigenpairs satisfy C v = lambda v to f64 precision."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(6)
+    D, N = 78, 1200
+    basis, _ = np.linalg.qr(rng.normal(size=(D, D)))
+    spectrum = np.concatenate([np.full(20, 3.0), 3.0 - 1e-3 * np.arange(20), 0.5 ** np.arange(38)])
+    X = ((rng.normal(size=(N, D)) * np.sqrt(spectrum)) @ basis.T).astype(np.float32)
+    dev = DevicePCA(n_components=D, runtime=rt).fit(X)
+    Xc = X.astype(np.float64) - X.astype(np.float64).mean(0)
+    C = Xc.T @ Xc / (N - 1)
+    V = dev.components_.astype(np.float64)
+    lam = dev.explained_variance_.astype(np.float64)
+    assert np.all(np.diff(lam) <= 1e-12)
+    with pytest.raises(Exception):
+        DevicePCA(n_components=3, runtime=rt).fit(np.zeros((100, 81), np.float32))        # beyond the LDS-resident limit: refused
+    resid = np.abs(C @ V.T - V.T * lam[None, :]).max()
+    assert resid < 1e-12 * lam[0] * D, resid
+    np.testing.assert_allclose(V @ V.T, np.eye(D), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(lam, np.linalg.eigvalsh(C)[::-1], rtol=0, atol=1e-12 * lam[0])
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_device_evaluation_equals_numpy_metrics(backend):
     rt = get_runtime(backend)
     rng = np.random.RandomState(9)
