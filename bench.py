@@ -201,11 +201,17 @@ def main():
         pca_comp = np.asarray(Proj.components_, np.float32)
         db = dict(frames=f32(frames), com=f32(coms0), cube=f32(np.tile(np.float32((300., 300., 300.)), (NDB, 1))), gt=f32(gt3d))
         imgs = None
+        # The cascade never touches x_in / y_in: it crops into staging buffers, so that the cascade of step i + 1 runs on the gradient
+        # branch BESIDE the forward pass of step i (engine.step_plan(early=)) and only two copies (34 MB) sit under the ADAM update.
+        x_stage, y_stage = rt.alloc((B, S, S), zero=False), rt.alloc((B, 30), zero=False)
+        stage_copy = ops.Plan('cascade_to_input')
+        stage_copy.add(ops.copy2d(rt, x_stage.reshape(B * S * S), S * S, x_out.reshape(B * S * S), S * S, B, S * S, name='load_crops'))
+        stage_copy.add(ops.copy2d(rt, y_stage.reshape(B * 30), 30, eng.y_in.reshape(B * 30), 30, B, 30, name='load_labels'))
         for sl in range(nsl):
             o = sl * B
             cc = CascadeCropper(rt, di, rnet, B, H, W, dsize=S, frames=db['frames'].view(o * H * W, (B, H, W)), coms=db['com'].view(o * 3, (B, 3)),
-                                cubes=db['cube'].view(o * 3, (B, 3)), out=x_out, gt3d=db['gt'].view(o * J * 3, (B, J, 3)), J=J, proj=Proj,
-                                out_y=eng.y_in)
+                                cubes=db['cube'].view(o * 3, (B, 3)), out=x_stage, gt3d=db['gt'].view(o * J * 3, (B, J, 3)), J=J, proj=Proj,
+                                out_y=y_stage)
             aug_plans[sl] = cc.plan
     else:
         di, imgs, coms, cubes, Ms, gts, pca_mean, pca_comp = synth.crop_db(NDB, S, J, seed=23455 + rank)
@@ -236,13 +242,20 @@ def main():
     # background augmentation workers (nettrainer.py:601-628) as one kernel on an idle stream; every step still launches exactly one
     # augmentation.  --augment-inline: the augmentation of slice i is the first launch of step i, on the main stream.
     pipelined = not args.augment_inline
+    if args.workload == 'cascade' and not pipelined:
+        for sl in range(nsl):
+            aug_plans[sl] = ops.Plan.concat('cascade_inline', [aug_plans[sl], stage_copy])
     for sl in range(nsl):
-        if pipelined:
+        if pipelined and args.workload == 'cascade':
+            step_plans[sl] = (aug_plans[sl], eng.step_plan(prefetch=stage_copy, early=aug_plans[(sl + 1) % nsl]))
+        elif pipelined:
             step_plans[sl] = (aug_plans[sl], eng.step_plan(prefetch=aug_plans[(sl + 1) % nsl]))
         else:
             step_plans[sl] = (aug_plans[sl], eng.step_plan(before=aug_plans[sl]))
     if pipelined:
         aug_plans[0].run(rt)              # the minibatch of the first step
+        if args.workload == 'cascade':
+            stage_copy.run(rt)
     if args.no_augment and args.workload == 'train':
         eng.y_in.set(np.random.RandomState(5).normal(0, 0.3, (B, 30)).astype(np.float32))
     eng.set_lr(1e-3)

@@ -805,30 +805,54 @@ __device__ __forceinline__ float crop_window_value(const float* __restrict__ fra
     return v;
 }
 
-// calculateCoM of the crop window (handdetector.py:91-108, as called by cropArea3D with docom=True, :413-421): mean
-// column, mean row and mean depth of the pixels inside the detector's range, moved back to frame coordinates; an empty
-// window falls back to the depth of its centre pixel, then to 300 mm.
-__global__ __launch_bounds__(DPP_THREADS) void crop_com_kernel(const float* __restrict__ frames, int H, int W, const CropRec* __restrict__ rec,
-                                                               float* __restrict__ com_out) {
+constexpr int COM_BANDS = 16;           // row bands of a crop window, one workgroup each
+
+// One band of window rows: (sum x, sum y, sum depth, count) of its valid pixels in f64 -> partial[b][band][4].  A wave walks whole
+// rows (lane = column), so there is no division per pixel and a row's loads are contiguous.
+__global__ __launch_bounds__(DPP_THREADS) void crop_com_partial_kernel(const float* __restrict__ frames, int H, int W,
+                                                                       const CropRec* __restrict__ rec, double* __restrict__ partial) {
     __shared__ double s_red[4][DPP_THREADS / DPP_WAVE];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, band = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const CropRec r = rec[b];
     const float* f = frames + (size_t)b * H * W;
+    const int rows = (r.ch + COM_BANDS - 1) / COM_BANDS;
+    const int y0 = band * rows, y1 = (y0 + rows < r.ch) ? y0 + rows : r.ch;
     double sx = 0.0, sy = 0.0, sd = 0.0, cnt = 0.0;
-    const int n = r.cw * r.ch;
-    for (int i = tid; i < n; i += DPP_THREADS) {
-        int y = i / r.cw, x = i - y * r.cw;
-        float v = crop_window_value(f, H, W, r, x, y);
-        if (v < r.min_depth || v > r.max_depth) v = 0.0f;       // calculateCoM's own range test
-        if (v > 0.0f) { sx += x; sy += y; sd += (double)v; cnt += 1.0; }
+    for (int y = y0 + wave; y < y1; y += DPP_THREADS / DPP_WAVE) {
+        double rs = 0.0, rc = 0.0, rx = 0.0;
+        for (int x = lane; x < r.cw; x += DPP_WAVE) {
+            float v = crop_window_value(f, H, W, r, x, y);
+            if (v < r.min_depth || v > r.max_depth) v = 0.0f;       // calculateCoM's own range test
+            if (v > 0.0f) { rx += x; rs += (double)v; rc += 1.0; }
+        }
+        sx += rx; sd += rs; cnt += rc; sy += rc * (double)y;
     }
     for (int o = 32; o > 0; o >>= 1) {
         sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sd += __shfl_xor(sd, o); cnt += __shfl_xor(cnt, o);
     }
-    if ((tid & 63) == 0) { s_red[0][tid >> 6] = sx; s_red[1][tid >> 6] = sy; s_red[2][tid >> 6] = sd; s_red[3][tid >> 6] = cnt; }
+    if (lane == 0) { s_red[0][wave] = sx; s_red[1][wave] = sy; s_red[2][wave] = sd; s_red[3][wave] = cnt; }
     __syncthreads();
     if (tid != 0) return;
     for (int w = 1; w < DPP_THREADS / DPP_WAVE; ++w) { sx += s_red[0][w]; sy += s_red[1][w]; sd += s_red[2][w]; cnt += s_red[3][w]; }
+    double* out = partial + ((size_t)b * COM_BANDS + band) * 4;
+    out[0] = sx; out[1] = sy; out[2] = sd; out[3] = cnt;
+}
+
+// calculateCoM of the crop window (handdetector.py:91-108, as called by cropArea3D with docom=True, :413-421): mean
+// column, mean row and mean depth of the pixels inside the detector's range, moved back to frame coordinates; an empty
+// window falls back to the depth of its centre pixel, then to 300 mm.  One thread per frame sums the bands in order.
+__global__ __launch_bounds__(DPP_THREADS) void crop_com_finish_kernel(const float* __restrict__ frames, int B, int H, int W,
+                                                                      const CropRec* __restrict__ rec, const double* __restrict__ partial,
+                                                                      float* __restrict__ com_out) {
+    const int b = blockIdx.x * DPP_THREADS + threadIdx.x;
+    if (b >= B) return;
+    const CropRec r = rec[b];
+    const float* f = frames + (size_t)b * H * W;
+    double sx = 0.0, sy = 0.0, sd = 0.0, cnt = 0.0;
+    for (int k = 0; k < COM_BANDS; ++k) {
+        const double* p = partial + ((size_t)b * COM_BANDS + k) * 4;
+        sx += p[0]; sy += p[1]; sd += p[2]; cnt += p[3];
+    }
     double c0 = 0.0, c1 = 0.0, c2 = 0.0;
     if (cnt > 0.0) { c0 = sx / cnt; c1 = sy / cnt; c2 = sd / cnt; }
     if (fabs(c0) <= 1e-8 && fabs(c1) <= 1e-8 && fabs(c2) <= 1e-8) {       // numpy.allclose(com, 0.)
@@ -1014,10 +1038,16 @@ extern "C" int dpp_crop_warp(const float* frames, const void* records, int B, in
     return dpp_launch_status();
 }
 
-extern "C" int dpp_crop_com(const float* frames, const void* records, int B, int H, int W, float* com_out, dpp_stream_t stream) {
-    if (!frames || !records || !com_out || B < 1 || H < 1 || W < 1) return DPP_E_BADARG;
-    DPP_LAUNCH(crop_com_kernel, dim3(B), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), frames, H, W,
-                       static_cast<const CropRec*>(records), com_out);
+extern "C" size_t dpp_crop_com_workspace_bytes(int B) { return (size_t)(B > 0 ? B : 0) * COM_BANDS * 4 * sizeof(double); }
+
+extern "C" int dpp_crop_com(const float* frames, const void* records, int B, int H, int W, void* workspace, float* com_out,
+                            dpp_stream_t stream) {
+    if (!frames || !records || !workspace || !com_out || B < 1 || H < 1 || W < 1) return DPP_E_BADARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    DPP_LAUNCH(crop_com_partial_kernel, dim3(COM_BANDS, B), dim3(DPP_THREADS), 0, st, frames, H, W, static_cast<const CropRec*>(records),
+               static_cast<double*>(workspace));
+    DPP_LAUNCH(crop_com_finish_kernel, dim3(dpp_cdiv(B, DPP_THREADS)), dim3(DPP_THREADS), 0, st, frames, B, H, W,
+               static_cast<const CropRec*>(records), static_cast<const double*>(workspace), com_out);
     return dpp_launch_status();
 }
 

@@ -103,6 +103,91 @@ __global__ __launch_bounds__(DPP_THREADS) void convpool_fwd_kernel(const float* 
     }
 }
 
+// The same layer for the shapes the nets use (square K x K filter, pool P, at most 2 output channels per wave: PoseRegNet / ScaleNet,
+// 8 filters), compile-time K and P.  The generic kernel above re-reads every input value from LDS once per (window position, tap)
+// and fetches its weights with scalar loads INSIDE the innermost loop (one s_waitcnt per multiply-add group: 100 us for the 0.28 GFLOP
+// second ScaleNet layer at batch 128).  Here a lane keeps the (P + K - 1)^2 input patch of its pooling window in registers per input
+// channel and all P * P window positions accumulate from it: (P + K - 1)^2 + 2 K^2 LDS reads for 2 P^2 K^2 multiply-adds (64 + 50
+// for 800 at K = 5, P = 4); weights are staged in LDS once per workgroup.  Sums run over (ci, dy, dx) -- ci outermost.
+template <int K, int P, int CPT>
+__global__ __launch_bounds__(DPP_THREADS) void convpool_fwd_fast_kernel(const float* __restrict__ X, dpp_act act, const float* __restrict__ Wk,
+                                                                        const float* __restrict__ bias, float* __restrict__ Y,
+                                                                        uint16_t* __restrict__ ties, cp_geom g) {
+    HIP_DYNAMIC_SHARED(float, sm)
+    constexpr int R = P + K - 1, taps = K * K;
+    const int plane = g.sy * g.sx;
+    float* xs = sm;                         // [Ci][sy][sx]: channel planes, a patch row is contiguous
+    float* ws = sm + g.Ci * plane;          // [Co][taps][Ci]
+    const int tile = blockIdx.x;
+    const int tx = tile % g.tiles_x, ty = (tile / g.tiles_x) % g.tiles_y, n = tile / (g.tiles_x * g.tiles_y);
+    {
+        const int y0 = ty * TP * P - g.pad, x0 = tx * TP * P - g.pad;
+        const int total = plane * g.Ci;
+        for (int s = threadIdx.x; s < total; s += DPP_THREADS) {            // global order (pixel-major), planar in LDS
+            const int ci = s % g.Ci, r = s / g.Ci;
+            const int hx = r % g.sx, hy = r / g.sx;
+            const int y = y0 + hy, x = x0 + hx;
+            float v = 0.0f;
+            if (y >= 0 && y < g.H && x >= 0 && x < g.W) v = dpp_act1(X[(((size_t)n * g.H + y) * g.W + x) * g.Ci + ci], act, ci);
+            xs[ci * plane + r] = v;
+        }
+        for (int s = threadIdx.x; s < g.Co * taps * g.Ci; s += DPP_THREADS) ws[s] = Wk[s];
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ply = q >> 3, plx = q & 7;
+    const int py = ty * TP + ply, px = tx * TP + plx;
+    for (int c0 = wave * CPT; c0 < g.Co; c0 += WG_WAVES * CPT) {       // wave-uniform channel group
+        float acc[P * P][CPT];
+#pragma unroll
+        for (int j = 0; j < P * P; ++j)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) acc[j][c] = 0.0f;
+        int wbase[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) wbase[c] = (c0 + c < g.Co ? c0 + c : g.Co - 1) * taps * g.Ci;
+        for (int ci = 0; ci < g.Ci; ++ci) {
+            float patch[R][R];
+            const float* xp = xs + ci * plane + (ply * P) * g.sx + plx * P;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < R; ++c) patch[r][c] = xp[r * g.sx + c];
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) {
+                    float w[CPT];
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) w[c] = ws[wbase[c] + (dy * K + dx) * g.Ci + ci];
+#pragma unroll
+                    for (int wy = 0; wy < P; ++wy)
+#pragma unroll
+                        for (int wx = 0; wx < P; ++wx)
+#pragma unroll
+                            for (int c = 0; c < CPT; ++c) acc[wy * P + wx][c] = fmaf(patch[wy + dy][wx + dx], w[c], acc[wy * P + wx][c]);
+                }
+        }
+        if (py < g.Hp && px < g.Wp) {
+            const size_t o = (((size_t)n * g.Hp + py) * g.Wp + px) * g.Co;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                float best = -INFINITY;
+                int mask = 0;
+#pragma unroll
+                for (int j = 0; j < P * P; ++j) {
+                    if (acc[j][c] > best) { best = acc[j][c]; mask = 1 << j; }
+                    else if (acc[j][c] == best) mask |= 1 << j;
+                }
+                if (c0 + c < g.Co) {
+                    Y[o + c0 + c] = best + bias[c0 + c];
+                    if (ties) ties[o + c0 + c] = (uint16_t)mask;
+                }
+            }
+        }
+    }
+}
+
 // Filter gradient: thread = a few (co, tap, ci) elements; workgroups walk tiles keeping their sums in registers and
 // write one partial each (fixed order, deterministic).
 constexpr int EPT = 8;     // weight elements per thread per pass
@@ -229,6 +314,14 @@ extern "C" int dpp_convpool_fwd(const float* X, int N, int H, int W, int Ci, con
     dim3 grid(N * g.tiles_x * g.tiles_y), block(DPP_THREADS);
     hipStream_t st = static_cast<hipStream_t>(stream);
     int cpt = dpp_cdiv(Co, WG_WAVES);
+    const size_t lds_fast = lds + (size_t)Co * kh * kw * Ci * sizeof(float);
+    if (kh == kw && cpt <= 2 && lds_fast <= 64 * 1024) {
+#define DPP_CPF(K_, P_) if (kh == K_ && pool == P_) { \
+            DPP_LAUNCH((convpool_fwd_fast_kernel<K_, P_, 2>), grid, block, lds_fast, st, X, cp_act(act), Wk, bias, Y, ties, g); \
+            return dpp_launch_status(); }
+        DPP_CPF(5, 4) DPP_CPF(5, 2) DPP_CPF(5, 1) DPP_CPF(3, 1) DPP_CPF(3, 2)
+#undef DPP_CPF
+    }
     if (cpt <= 2)
         DPP_LAUNCH((convpool_fwd_kernel<2>), grid, block, lds, st, X, cp_act(act), Wk, bias, Y, ties, g);
     else if (cpt <= 4)

@@ -1424,14 +1424,17 @@ class CompiledNet(object):
         allreduce(self.store.g)
         self.upd.run(st)
 
-    def step_plan(self, before=None, prefetch=None):
+    def step_plan(self, before=None, prefetch=None, early=None):
         """forward + loss + backward + update as ONE plan (one native call per step); `before`: a Plan issued ahead of the
         forward pass inside the same call (the augmentation kernels).  `prefetch`: a Plan whose launches run on the gradient
         branch between the backward pass and the update -- the augmentation of the NEXT step's minibatch, written straight into
         x_in / y_in (their last readers, the first layer's filter gradient and the loss, are done by then) while the main stream is
         busy with the ADAM update; the plan then opens with a join, so that the forward pass waits for the prefetch of the previous
-        call.  What the reference does with its background augmentation processes (nettrainer.py:601-628)."""
-        key = (id(before) if before is not None else 0, id(prefetch) if prefetch is not None else 0)
+        call.  What the reference does with its background augmentation processes (nettrainer.py:601-628).
+        `early`: a Plan issued on the gradient branch at the START of the step, beside the forward pass (that stream is idle until
+        the backward pass): work for the next minibatch that does not touch x_in / y_in -- the refinement cascade cropping into
+        staging buffers, which `prefetch` then only has to copy."""
+        key = (id(before) if before is not None else 0, id(prefetch) if prefetch is not None else 0, id(early) if early is not None else 0)
         cache = self.__dict__.setdefault('_step_plans', {})
         if key not in cache:
             bwd, upd = self._early_adam_plans()
@@ -1443,13 +1446,20 @@ class CompiledNet(object):
                 for op in prefetch.steps():
                     post.add(op, side=True)
                 parts = [pre] + parts + [post]
+            if early is not None:
+                head = Plan('early')
+                head.fork()
+                for op in early.steps():
+                    head.add(op, side=True)
+                at = 1 if prefetch is not None else 0          # behind the join that waits for the previous call's prefetch
+                parts = parts[:at] + [head] + parts[at:]
             plan = Plan.concat('step', parts + [upd])
             skip = tuple(x for x in knob('DPP_WHATIF_SKIP', '').split(',') if x)
             if skip:
                 # ablation for tools/whatif.sh ONLY (results are wrong): the step without the launches whose name starts with one of
                 # the prefixes -- what the step would cost if those kernels were free
                 plan.ops = [(op, side) for (op, side) in plan.ops if not str(getattr(op, 'name', '')).startswith(skip)]
-            cache[key] = (before, prefetch, plan)
+            cache[key] = (before, prefetch, early, plan)
         return cache[key][-1]
 
     def _early_adam_plans(self):

@@ -133,7 +133,8 @@ SIGNATURES = {
     'dpp_crop_record_bytes': (C.c_size_t, []),
     'dpp_crop_prepare': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, stream_t]),
-    'dpp_crop_com': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_crop_com_workspace_bytes': (C.c_size_t, [C.c_int]),
+    'dpp_crop_com': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_crop_warp': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, stream_t]),
     'dpp_crop_refine': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
                                   C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,

@@ -14,10 +14,11 @@ from .lib import Act, DppError, Epilogue, GemmDesc, RowMap, check
 class Launch(object):
     """One prepared kernel launch.  `meta` = dict(kernel=<family>, flops=<algorithmic flops>, bytes=<algorithmic HBM
     bytes>) is what bench.py's roofline accounting reads."""
-    __slots__ = ('fn', 'args', 'keep', 'name', 'meta')
+    __slots__ = ('fn', 'args', 'keep', 'name', 'meta', 'kernels')
 
-    def __init__(self, fn, args, keep, name, meta=None):
+    def __init__(self, fn, args, keep, name, meta=None, kernels=1):
         self.fn, self.args, self.keep, self.name, self.meta = fn, args, keep, name, meta
+        self.kernels = kernels         # kernels the entry point issues (the plan recorder checks what it captured against this)
 
     def __call__(self, stream):
         st = self.fn(*self.args, stream)
@@ -73,7 +74,7 @@ class NativePlan(object):
             check(lib.dpp_plan_record_end(h), 'dpp_plan_record_end')
         n = C.c_int()
         check(lib.dpp_plan_count(h, C.byref(n), None, None), 'dpp_plan_count')
-        want = sum(1 for op, _ in items if isinstance(op, Launch))
+        want = sum(op.kernels for op, _ in items if isinstance(op, Launch))
         if n.value != want:
             raise DppError("plan recording captured %d launches, expected %d" % (n.value, want))
         self.graph_ready = False
@@ -486,7 +487,9 @@ def crop_prepare(rt, frames, B, H, W, com, cube, fx, fy, dsz, records, M_out=Non
 
 
 def crop_com(rt, frames, records, B, H, W, com_out, name='crop_com'):
-    return Launch(rt.lib.dpp_crop_com, (frames.ptr, records.ptr, B, H, W, com_out.ptr), (frames, records, com_out), name)
+    ws = rt.alloc(max(1, int(rt.lib.dpp_crop_com_workspace_bytes(B)) // 8), np.float64, zero=False)     # per-band partial sums
+    return Launch(rt.lib.dpp_crop_com, (frames.ptr, records.ptr, B, H, W, ws.ptr, com_out.ptr), (frames, records, ws, com_out), name,
+                  kernels=2)
 
 
 def crop_warp(rt, frames, records, B, H, W, dsz, out, normalize=True, nd_value=0.0, name='crop_warp'):

@@ -344,7 +344,8 @@ int dpp_crop_warp(const float* frames, const void* records, int B, int H, int W,
                   float* out, dpp_stream_t stream);
 /* docom = True (handdetector.py:413-427): the centre of mass (calculateCoM, :91-108) of the crop window described by
  * `records`, in image coordinates -> com_out [B][3]; re-run dpp_crop_prepare with it, then dpp_crop_warp. */
-int dpp_crop_com(const float* frames, const void* records, int B, int H, int W, float* com_out, dpp_stream_t stream);
+size_t dpp_crop_com_workspace_bytes(int B);       /* device scratch of dpp_crop_com: per-band partial sums, summed in a fixed order */
+int dpp_crop_com(const float* frames, const void* records, int B, int H, int W, void* workspace, float* com_out, dpp_stream_t stream);
 /* docom = True WITH a refinement net (handdetector.py:429-440 and refineCoM, :634-676), batched: net_out [B][3] is the net's
  * output for the re-centred crops (normalised offset of the hand centre), com_in [B][3] the centre those crops were cut around
  * (dpp_crop_com's output), records the crop records of that second dpp_crop_prepare.
