@@ -531,8 +531,12 @@ class CompiledNet(object):
                 # (poseregnettrainer.py:101-107); the kernel-layout W holds the same values in another order
                 # (data parallel: every rank's cost is its share of the global cost, so each adds 1/world of the regulariser)
                 share = self.weight_decay / (dp.world if (dp is not None and train) else 1)
-                for W in self._unique_weights():
-                    self.lossplan.add(ops.sumsq(rt, self.store.view(W), int(np.prod(W.shape)), share, self.cost, 1))
+                seg = self._weight_segments()
+                if seg is not None:                      # all weights in one launch over the flat parameter buffer
+                    self.lossplan.add(ops.sumsq_multi(rt, self.store.w, seg[0], seg[1], share, self.cost, 1))
+                else:
+                    for W in self._unique_weights():
+                        self.lossplan.add(ops.sumsq(rt, self.store.view(W), int(np.prod(W.shape)), share, self.cost, 1))
             if not train and loss.get('kind') != 'scalar':
                 d = loss['nDims'] if loss.get('kind', 'embedding') == 'joints' else self.out_dim
                 rows = self.N * (loss['numJoints'] if loss.get('kind', 'embedding') == 'joints' else 1)
@@ -621,6 +625,16 @@ class CompiledNet(object):
                 seen.add(l.W.auto_name)
                 out.append(l.W)
         return out
+
+    def _weight_segments(self):
+        """(device table, count) of the (offset, length) pairs of every conv / FC weight inside the flat TRAINED buffer, for the
+        one-launch regulariser (ops.sumsq_multi / axpy_multi); None when a weight lives elsewhere (frozen: per-layer launches)."""
+        if '_wseg' not in self.__dict__:
+            st = self.store
+            Ws = self._unique_weights()
+            ok = bool(Ws) and all(st.slots[st.by_param[W.auto_name]]['trained'] for W in Ws)
+            self._wseg = ops.segment_table(self.rt, st.w, [st.view(W) for W in Ws]) if ok else None
+        return self._wseg
 
     def _fc1_stream(self, Nb, K, Nout):
         if not is_fc1_shape(Nb, K, Nout) or FC1_STREAM == '0':
@@ -1123,9 +1137,13 @@ class CompiledNet(object):
         # still has in flight)
         self._wd_ops, self._wd_of = [], {}
         if self.weight_decay and not self.net.hasDropout():
-            for W in self._unique_weights():
-                self._wd_ops.append(ops.axpy(rt, st.view(W, 'g'), st.view(W), 2.0 * self.weight_decay, int(np.prod(W.shape))))
-                self._wd_of[id(self._wd_ops[-1])] = W.auto_name
+            seg = self._weight_segments()
+            if seg is not None and not EARLY_ADAM:       # (EARLY_ADAM moves FC1's share next to FC1's update: per-layer launches)
+                self._wd_ops.append(ops.axpy_multi(rt, st.g, st.w, seg[0], seg[1], 2.0 * self.weight_decay))
+            else:
+                for W in self._unique_weights():
+                    self._wd_ops.append(ops.axpy(rt, st.view(W, 'g'), st.view(W), 2.0 * self.weight_decay, int(np.prod(W.shape))))
+                    self._wd_of[id(self._wd_ops[-1])] = W.auto_name
         if self.dp is None:
             for o in self._wd_ops:
                 self.bwd.add(o)

@@ -112,6 +112,9 @@ SIGNATURES = {
     'dpp_counter_add': (C.c_int, [C.c_void_p, C.c_ulonglong, stream_t]),
     'dpp_axpy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_size_t, stream_t]),
     'dpp_sumsq': (C.c_int, [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_int, stream_t]),
+    'dpp_sumsq_multi_workspace_bytes': (C.c_size_t, []),
+    'dpp_sumsq_multi': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, stream_t]),
+    'dpp_axpy_multi': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, stream_t]),
     'dpp_scale': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_size_t, stream_t]),
     'dpp_relu_bwd': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_size_t, stream_t]),
     'dpp_fill_zero': (C.c_int, [C.c_void_p, C.c_size_t, stream_t]),

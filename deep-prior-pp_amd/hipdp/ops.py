@@ -425,6 +425,26 @@ def sumsq(rt, x, n, alpha, out, accumulate, name='sumsq'):
     return Launch(rt.lib.dpp_sumsq, (x.ptr, n, float(alpha), out.ptr, int(accumulate)), (x, out), name)
 
 
+def segment_table(rt, base, views):
+    """(offset, length) pairs of `views` inside the flat buffer `base`, as a device array for sumsq_multi / axpy_multi."""
+    seg = []
+    for v in views:
+        off = (v.ptr - base.ptr) // 4
+        assert 0 <= off and off + v.size <= base.size and (v.ptr - base.ptr) % 4 == 0, "view outside the flat buffer"
+        seg += [off, v.size]
+    return rt.upload(np.asarray(seg, np.int64)), len(seg) // 2
+
+
+def sumsq_multi(rt, base, seg, nseg, alpha, out, accumulate, name='sumsq_multi'):
+    ws = rt.alloc(int(rt.lib.dpp_sumsq_multi_workspace_bytes()) // 8, np.float64, zero=False)
+    return Launch(rt.lib.dpp_sumsq_multi, (base.ptr, seg.ptr, int(nseg), float(alpha), ws.ptr, out.ptr, int(accumulate)),
+                  (base, seg, ws, out), name, kernels=2)
+
+
+def axpy_multi(rt, ybase, xbase, seg, nseg, alpha, name='axpy_multi'):
+    return Launch(rt.lib.dpp_axpy_multi, (ybase.ptr, xbase.ptr, seg.ptr, int(nseg), float(alpha)), (ybase, xbase, seg), name)
+
+
 def scale(rt, x, y, n, a=1.0, relu=False, mask=None, name='scale'):
     return Launch(rt.lib.dpp_scale, (x.ptr, _p(mask), float(a), int(relu), y.ptr, n), (x, y, mask), name)
 

@@ -271,6 +271,14 @@ int dpp_adam(float* w, const float* g, float* m, float* v, size_t n, const float
 int dpp_adam_tick(float* state, dpp_stream_t stream);
 int dpp_axpy(float* y, const float* x, float alpha, size_t n, dpp_stream_t stream);              /* y += alpha x */
 int dpp_sumsq(const float* x, size_t n, float alpha, float* out, int accumulate, dpp_stream_t stream);
+/* The two above over nseg segments of ONE flat buffer in one launch: seg (DEVICE memory) holds (offset, length) pairs in elements
+ * -- the weights of all layers inside the flat parameter / gradient buffers (cost += weightreg_factor * sum(W^2) and its gradient
+ * 2 * weightreg_factor * W, poseregnettrainer.py:101-107).  Deterministic: fixed shares per block, f64 partials summed in order.
+ * workspace: dpp_sumsq_multi_workspace_bytes() bytes of device memory. */
+size_t dpp_sumsq_multi_workspace_bytes(void);
+int dpp_sumsq_multi(const float* base, const long long* seg, int nseg, float alpha, void* workspace, float* out, int accumulate,
+                    dpp_stream_t stream);
+int dpp_axpy_multi(float* ybase, const float* xbase, const long long* seg, int nseg, float alpha, dpp_stream_t stream);
 /* y = mask ? mask*relu?(x) : a*relu?(x): DropoutLayer, /root/reference/src/net/dropoutlayer.py:98-104 */
 int dpp_scale(const float* x, const float* mask, float a, int relu, float* y, size_t n, dpp_stream_t stream);
 /* g = (mask ? mask : a) * dy * [pre >= 0] */

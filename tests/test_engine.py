@@ -284,6 +284,11 @@ def test_weight_decay_cost_and_gradients(backend):
     reg = sum(wd * (P64[i][0] ** 2).sum() for i, l in enumerate(onet['layers']) if l['kind'] in ('conv', 'convpool', 'fc'))
     assert abs(c_ev - (((o_ev - y) ** 2).sum(axis=1).mean() + reg)) < 1e-5 * c_ev
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), weight_decay=wd)
+    # ONE launch each for the regulariser and its gradient (all weights as segments of the flat buffer): the per-layer version -- 67
+    # launches for the ResNet, a single-workgroup sum over FC1's 16.8 M weights among them -- made the default trainer
+    # (weightreg_factor = 0.001, nettrainer.py:52) six times slower than a step without (tools/trainer_throughput.py)
+    assert [l.name for l in eng.lossplan.launches()].count('sumsq_multi') == 1 and not any(l.name == 'sumsq' for l in eng.lossplan.launches())
+    assert sum(l.name == 'axpy_multi' for l in eng.bwd.launches()) == 1
 
     def run(seed):
         r = np.random.RandomState(seed)
