@@ -47,3 +47,68 @@ def test_nyu_driver_end_to_end(backend, tmp_path):
     assert len(costs) == 3 and np.all(np.isfinite(costs))        # 5 crops padded to 3 minibatches of 2
     assert set(results) == {'test_1', 'test_2'} and all(np.isfinite(v).all() and v[0] > 0 for v in results.values())
     assert os.path.isfile(str(tmp_path / 'eval' / 'network_prior.pkl'))
+
+
+def _write_msra(base, subject, n, seed, cube):
+    import struct
+    cam = A.Camera.msra()
+    frames, gt3D, _ = _frames_and_joints(cam, n, 21, 240, 320, cube, 5, seed)
+    d = os.path.join(base, subject, '1')
+    os.makedirs(d)
+    with open(os.path.join(d, 'joint.txt'), 'w') as f:
+        f.write('%d\n' % n)
+        for i in range(n):
+            j = gt3D[i].copy()
+            j[:, 2] *= -1.                                       # the files hold -z
+            f.write(' '.join('%.4f' % v for v in j.reshape(-1)) + '\n')
+            ys, xs = np.nonzero(frames[i])
+            top, bottom, left, right = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+            with open(os.path.join(d, '%06d_depth.bin' % i), 'wb') as fb:
+                fb.write(struct.pack('6i', 320, 240, left, top, right, bottom))
+                frames[i][top:bottom, left:right].astype(np.float32).tofile(fb)
+
+
+def _load_driver(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, 'examples', name + '.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_msra_crossval_driver_end_to_end(backend, tmp_path):
+    """examples/main_msra15_posereg_embedding_crossval.py (BASELINE configs[3]) on three tiny subjects in the original file format
+    (<subject>/<gesture>/joint.txt + NNNNNN_depth.bin): every fold trains on the other two, appends its prior, tests on the third."""
+    R.set_default_runtime(get_runtime(backend))
+    base = str(tmp_path / 'MSRA15')
+    for k, (subj, cube) in enumerate((('P0', (200., 200., 200.)), ('P3', (180., 180., 180.)), ('P8', (150., 150., 150.)))):
+        _write_msra(base, subj, 2, 10 + k, cube)
+    net = 'resnet' if backend == 'hip' else 'poseregnet'
+    costs, results = _load_driver('main_msra15_posereg_embedding_crossval').main(
+        ['--data', base, '--subjects', 'P0,P3,P8', '--net', net, '--epochs', '1', '--batch', '2', '--embedding', '6', '--prior-poses', '200',
+         '--out', str(tmp_path / 'eval'), '--cache', str(tmp_path / 'cache')])
+    assert set(results) == {'P0', 'P3', 'P8', 'all'} and all(np.isfinite(v).all() and v[0] > 0 for v in results.values())
+    assert all(len(c) == 2 and np.all(np.isfinite(c)) for c in costs.values())          # 4 training crops = 2 minibatches of 2 per fold
+    assert all(os.path.isfile(str(tmp_path / 'eval' / ('network_prior_%d.pkl' % i))) for i in range(3))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_nyu_com_refine_driver_then_cascade(backend, tmp_path):
+    """examples/main_nyu_com_refine.py trains the ScaleNet on a tiny NYU-format dataset and writes net_ScaleNet.pkl; the pose
+    regression driver then takes that checkpoint (--refine) and crops every frame through the device cascade."""
+    R.set_default_runtime(get_runtime(backend))
+    base = str(tmp_path / 'NYU')
+    for name, n, seed in (('train', 4, 1), ('test_1', 2, 2), ('test_2', 2, 3)):
+        _write_nyu(base, name, n, seed)
+    costs, results = _load_driver('main_nyu_com_refine').main(['--data', base, '--epochs', '1', '--batch', '4', '--out', str(tmp_path / 'refine'),
+                                                               '--cache', str(tmp_path / 'cache_refine')])
+    assert len(costs) == 2 and np.all(np.isfinite(costs))           # 4 frames x (annotated centre, centre of mass) = 2 minibatches of 4
+    assert set(results) == {'test_1', 'test_2'} and all(np.isfinite(v).all() for v in results.values())
+    ckpt = str(tmp_path / 'refine' / 'net_ScaleNet.pkl')
+    assert os.path.isfile(ckpt)
+    net = 'resnet' if backend == 'hip' else 'poseregnet'
+    costs2, results2 = _load_driver('main_nyu_posereg_embedding').main(
+        ['--data', base, '--net', net, '--epochs', '1', '--batch', '2', '--embedding', '6', '--prior-poses', '300', '--refine', ckpt,
+         '--out', str(tmp_path / 'eval'), '--cache', str(tmp_path / 'cache_posereg')])
+    assert len(costs2) == 2 and np.all(np.isfinite(costs2))
+    assert all(np.isfinite(v).all() and v[0] > 0 for v in results2.values())

@@ -1,7 +1,7 @@
 # Regenerate the rocprofv3 evidence of the current round on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
 # Outputs land in gpurun_out/<round>/ and are then copied to profiles/<round>_*.
 set -x
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
@@ -28,6 +28,9 @@ python $R/bench.py --no-cpu-baseline --dtype bf16 > $O/bench_bf16_128.json 2>/de
 python $R/bench.py --no-cpu-baseline --size 256 --steps 20 --warmup 5 > $O/bench_f32_256.json 2>/dev/null
 python $R/bench.py --no-cpu-baseline --size 256 --steps 20 --warmup 5 --dtype bf16 > $O/bench_bf16_256.json 2>/dev/null
 python $R/bench.py --no-cpu-baseline --batch 256 > $O/bench_bs256.json 2>/dev/null
+python $R/bench.py --no-cpu-baseline --workload cascade --size 256 --steps 20 --warmup 5 > $O/bench_cascade_f32_256.json 2>/dev/null
+python $R/bench.py --no-cpu-baseline --workload cascade --size 256 --steps 20 --warmup 5 --dtype bf16 > $O/bench_cascade_bf16_256.json 2>/dev/null
+python $R/tools/trainer_throughput.py 2>/dev/null | tail -1 > $O/trainer_throughput.txt
 python $R/tools/augment_bench.py > $O/augment_bench.json 2> $O/augment_bench.err
 python $R/tools/augment_bench.py --batch 4096 --iters 50 >> $O/augment_bench.json 2>> $O/augment_bench.err
 ls -la $O
