@@ -223,7 +223,9 @@ class ICVLImporter(DepthImporter):
         if self.hand is not None and self.hand != self.sides[seqName]:
             raise NotImplementedError()
         objdir = '{}/Depth/'.format(self.basepath)
-        records = self._crop_stream(config, docom, self.sides[seqName])
+        # every ICVL frame is recorded as 'left' (importers.py:401-402); the table of sides -- whose key for the first test sequence
+        # is misspelt in the reference, :211 -- is only consulted when a hand was asked for
+        records = self._crop_stream(config, docom, 'left')
         with open('{}/{}.txt'.format(self.basepath, seqName)) as inputfile:
             for line in inputfile:
                 if len(records) >= Nmax:

@@ -112,3 +112,33 @@ def test_nyu_com_refine_driver_then_cascade(backend, tmp_path):
          '--out', str(tmp_path / 'eval'), '--cache', str(tmp_path / 'cache_posereg')])
     assert len(costs2) == 2 and np.all(np.isfinite(costs2))
     assert all(np.isfinite(v).all() and v[0] > 0 for v in results2.values())
+
+
+def _write_icvl(base, name, n, seed):
+    cam = A.Camera.icvl()
+    frames, _, gtuvd = _frames_and_joints(cam, n, 16, 240, 320, (250., 250., 250.), 0, seed)
+    lines = []
+    for i in range(n):
+        os.makedirs(os.path.join(base, 'Depth', '201403121135'), exist_ok=True)
+        rel = '201403121135/%s_%04d.png' % (name, i)
+        Image.fromarray(frames[i].astype(np.uint16)).save(os.path.join(base, 'Depth', rel))
+        lines.append(rel + ' ' + ' '.join('%.4f' % v for v in gtuvd[i].reshape(-1)) + ' \n')
+    with open(os.path.join(base, name + '.txt'), 'w') as f:
+        f.writelines(lines)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_icvl_driver_end_to_end(backend, tmp_path):
+    """examples/main_icvl_posereg_embedding.py (BASELINE configs[2]) on a tiny ICVL-format dataset (labels file + 16-bit PNGs), with all
+    four augmentation modes."""
+    R.set_default_runtime(get_runtime(backend))
+    base = str(tmp_path / 'ICVL')
+    _write_icvl(base, 'train', 4, 21)
+    _write_icvl(base, 'test_seq_1', 2, 22)
+    net = 'resnet' if backend == 'hip' else 'poseregnet'
+    costs, results = _load_driver('main_icvl_posereg_embedding').main(
+        ['--data', base, '--net', net, '--epochs', '1', '--batch', '2', '--embedding', '6', '--prior-poses', '300', '--aug-modes', 'com,rot,sc,none',
+         '--out', str(tmp_path / 'eval'), '--cache', str(tmp_path / 'cache')])
+    assert len(costs) == 2 and np.all(np.isfinite(costs))
+    assert np.isfinite(results['test_seq_1']).all() and results['test_seq_1'][0] > 0
+    assert os.path.isfile(str(tmp_path / 'eval' / 'network_prior.pkl'))
