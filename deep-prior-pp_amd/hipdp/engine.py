@@ -431,13 +431,16 @@ WGRAD_STREAM_STAGES = knob('DPP_WGRAD_STREAM_STAGES', '1')            # which of
 WGRAD3_STREAM_C = tuple(int(v) for v in knob('DPP_WGRAD3_STREAM_C', '64').split(',') if v)
 
 
+WGRAD3_STREAM_SLICE_BUDGET = int(knob('DPP_WGRAD3_STREAM_SLICES', '1024'))       # slices of a 16-channel layer (9.2 KB each)
+
+
 def wgrad3_stream_rows(M, C):
     """Pixel rows per wave of dpp_wgrad3_stream for a C -> C 3x3 layer over M pixels, or 0 (LDS-tiled kernel).  The partial slices of
     a layer are held to ~9.4 MB (1 024 slices of 16 x 9 x 16, 256 of 32 x 9 x 32, 64 of 64 x 9 x 64): more slices is more waves but
     the partials' write + re-read grows past the tensors themselves (tools/gemm_micro.py conv3, profiles/r03_wgrad3_stream.txt)."""
     if C not in WGRAD3_STREAM_C:
         return 0
-    slices = max(1, 1024 // max(1, (C // 16) ** 2))
+    slices = max(1, WGRAD3_STREAM_SLICE_BUDGET // max(1, (C // 16) ** 2))
     return max(64, (M // slices) & ~3)
 
 
