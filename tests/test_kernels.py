@@ -345,6 +345,9 @@ def test_fused_epilogues_stats_and_bn_backward(backend, kind):
     (3, 31, 31, 8, 8, 5, 'valid', 2, True),       # conv-pool 2: odd conv map 27 -> pool ignores the border
     (3, 13, 13, 8, 8, 3, 'valid', 1, True),       # conv-pool 3: no pooling (poolType -1)
     (2, 20, 18, 3, 12, 3, 'half', 3, True),       # odd sizes: 'half' padding, pool 3, channel counts off the wave grid
+    (2, 40, 36, 8, 8, 5, 'valid', 2, True),       # several 32 x 32 input tiles with ragged edges (register-patch kernels)
+    (2, 14, 14, 8, 8, 5, 'valid', 1, True),       # ScaleNet's third tower: 5x5 without pooling on a small map
+    (2, 30, 22, 12, 8, 5, 'half', 2, True),       # 'half' padding and two groups of input channels on the register-patch kernels
 ])
 def test_convpool_fwd_wgrad_dgrad(backend, cfg):
     """Generic ConvPoolLayer kernels against the oracle, incl. Theano's gradient-to-every-tied-maximum rule on a constant

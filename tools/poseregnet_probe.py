@@ -28,3 +28,22 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 50
 print('PoseRegNet type 0 bs128 train step: %.3f ms  (%.0f crops/s), launches fwd %d bwd %d upd %d' %
       (dt * 1e3, B / dt, len(eng.fwd), len(eng.bwd), len(eng.upd)))
+
+if '--ops' in sys.argv:
+    # GPU-side time of every launch of the step on its own (50 copies chained in one explicit hipGraph lane, incl. the 1.6 us boundary)
+    from hipdp import ops
+
+    def timeit(launch, rep=50):
+        plan = ops.NativePlan(rt, [(launch, False)] * rep, mode='graph1')
+        plan.run(rt)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        plan.run(rt)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / rep
+    for ph, plan in (('fwd', eng.fwd), ('loss', eng.lossplan), ('bwd', eng.bwd), ('upd', eng.upd)):
+        for l in plan.launches():
+            if l.kernels == 1:
+                print('%-5s %-28s %8.2f us' % (ph, l.name, timeit(l)))
