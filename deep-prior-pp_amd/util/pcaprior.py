@@ -54,7 +54,7 @@ def sample_random_poses_device(importer, rng, base_poses, base_com, base_cube, n
                                  d_rot.ptr, n, float(importer.fx), float(importer.fy), float(importer.ux), float(importer.uy), int(flip),
                                  out.ptr, None, None, rt.stream), 'dpp_pose_sample')
     if keep_on_device:
-        out._inputs = (d_poses, d_com, d_cube, d_mode, d_ridx, d_off, d_sc, d_rot)      # alive until the kernel has run
+        out.owner = (out.owner, d_poses, d_com, d_cube, d_mode, d_ridx, d_off, d_sc, d_rot)      # inputs alive until the kernel has run
         return out
     rt.synchronize()
     return out.get()
@@ -62,7 +62,7 @@ def sample_random_poses_device(importer, rng, base_poses, base_com, base_cube, n
 
 class DevicePCA(object):
     """sklearn.decomposition.PCA's fit / transform / inverse_transform on the device (no whitening), for X of shape (N, D),
-    D <= 192.  `fit` accepts a NumPy array or a device Buffer (e.g. from sample_random_poses_device(keep_on_device=True))."""
+    D <= 80 (26 joints).  `fit` accepts a NumPy array or a device Buffer (e.g. from sample_random_poses_device(keep_on_device=True))."""
 
     def __init__(self, n_components=None, runtime=None):
         self.n_components = n_components

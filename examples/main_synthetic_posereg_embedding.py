@@ -79,13 +79,16 @@ class SyntheticImporter(ICVLImporter):
         return NamedImgSequence(seqName, data, {'cube': cube})
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--net', choices=['poseregnet', 'resnet'], default='poseregnet')
     ap.add_argument('--frames', type=int, default=2048)
     ap.add_argument('--epochs', type=int, default=8)
+    ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--embedding', type=int, default=30)
+    ap.add_argument('--prior-poses', type=int, default=20000)
     ap.add_argument('--out', default='./eval/SYNTH_EMB')
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     os.makedirs(args.out, exist_ok=True)
     rng = numpy.random.RandomState(23455)
 
@@ -94,7 +97,7 @@ def main():
     di = SyntheticImporter()
     t0 = time.time()
     Seq1 = di.loadSequence('train', Nmax=args.frames, shuffle=True, rng=rng)
-    Seq2 = di.loadSequence('test_1', Nmax=max(256, args.frames // 8))
+    Seq2 = di.loadSequence('test_1', Nmax=max(2 * args.batch, args.frames // 8))
     print("  rendered and cropped {} frames in {:.1f} s".format(len(Seq1.data) + len(Seq2.data), time.time() - t0))
     trainDataSet, testDataSet = Dataset([Seq1]), Dataset([Seq2])
     train_data, train_gt3D = trainDataSet.imgStackDepthOnly('train')
@@ -108,13 +111,13 @@ def main():
     # convert data to embedding
     # (the reference: sklearn PCA on HandDetector.sampleRandomPoses(...), main_nyu_posereg_embedding.py:86-88; here the sampling,
     # the scatter matrix and its eigen-decomposition run on the device, the samples never visit the host)
-    pca = DevicePCA(n_components=30)
-    pca.fit(sample_random_poses_device(di, rng, train_gt3Dcrop, train_data_com, train_data_cube, 20000, aug_modes, keep_on_device=True))
+    pca = DevicePCA(n_components=args.embedding)
+    pca.fit(sample_random_poses_device(di, rng, train_gt3Dcrop, train_data_com, train_data_cube, args.prior_poses, aug_modes, keep_on_device=True))
     train_gt3D_embed = pca.transform(train_gt3D.reshape((train_gt3D.shape[0], -1))).astype('float32')
     val_gt3D_embed = pca.transform(val_gt3D.reshape((val_gt3D.shape[0], -1))).astype('float32')
 
     print("create network")
-    batchSize = 128
+    batchSize = args.batch
     Net, NetParams = (PoseRegNet, PoseRegNetParams) if args.net == 'poseregnet' else (ResNet, ResNetParams)
     poseNetParams = NetParams(type=0, nChan=train_data.shape[1], wIn=train_data.shape[3], hIn=train_data.shape[2], batchSize=batchSize,
                               numJoints=1, nDims=train_gt3D_embed.shape[1])
@@ -167,6 +170,7 @@ def main():
     hpe = HandposeEvaluation(gt3D, joints)
     mean_pose_err = HandposeEvaluation(gt3D, [di.mean_pose + s.com for s in Seq2.data]).getMeanError()
     print("Mean error: {:.2f}mm, max error: {:.2f}mm  (predicting the mean pose: {:.2f}mm)".format(hpe.getMeanError(), hpe.getMaxError(), mean_pose_err))
+    return train_costs, (float(hpe.getMeanError()), float(hpe.getMaxError()), float(mean_pose_err))
 
 
 if __name__ == '__main__':

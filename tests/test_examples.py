@@ -142,3 +142,16 @@ def test_icvl_driver_end_to_end(backend, tmp_path):
     assert len(costs) == 2 and np.all(np.isfinite(costs))
     assert np.isfinite(results['test_seq_1']).all() and results['test_seq_1'][0] > 0
     assert os.path.isfile(str(tmp_path / 'eval' / 'network_prior.pkl'))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_synthetic_driver_end_to_end(backend, tmp_path):
+    """examples/main_synthetic_posereg_embedding.py -- the reference's training script with rendered frames as the data source -- runs
+    through: device crops, pose sampling + PCA kept on the device, trainer, prior layer, evaluation."""
+    R.set_default_runtime(get_runtime(backend))
+    net = 'resnet' if backend == 'hip' else 'poseregnet'
+    costs, (mean_err, max_err, mean_pose_err) = _load_driver('main_synthetic_posereg_embedding').main(
+        ['--net', net, '--frames', '8', '--epochs', '1', '--batch', '4', '--embedding', '6', '--prior-poses', '200', '--out', str(tmp_path / 'eval')])
+    assert len(costs) == 2 and np.all(np.isfinite(costs))
+    assert np.isfinite([mean_err, max_err, mean_pose_err]).all() and mean_err > 0
+    assert os.path.isfile(str(tmp_path / 'eval' / 'network_prior.pkl'))
