@@ -14,7 +14,7 @@ from hipdp.runtime import TorchHipRuntime  # noqa: E402
 from net.scalenet import ScaleNet, ScaleNetParams  # noqa: E402
 
 rt = TorchHipRuntime()
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64            # main_nyu_com_refine.py:149
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64            # main_nyu_com_refine.py:149
 net = ScaleNet(np.random.RandomState(23455), cfgParams=ScaleNetParams(type=1, batchSize=B, numJoints=1, nDims=3))
 eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
 eng.set_lr(5e-4)
@@ -27,3 +27,26 @@ for _ in range(100):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 100
 print('ScaleNet type 1 bs%d train step: %.3f ms  (%.0f crops/s), launches %s' % (B, dt * 1e3, B / dt, eng.num_launches()))
+
+if '--ops' in sys.argv:
+    # GPU-side time of every launch of the step on its own (50 copies chained in one explicit hipGraph lane, incl. the 1.6 us boundary)
+    from hipdp import ops
+
+    def timeit(launch, rep=50):
+        plan = ops.NativePlan(rt, [(launch, False)] * rep, mode='graph1')
+        plan.run(rt)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        plan.run(rt)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / rep
+    tot = 0.0
+    for ph, plan in (('fwd', eng.fwd), ('loss', eng.lossplan), ('bwd', eng.bwd), ('upd', eng.upd)):
+        for l in plan.launches():
+            if l.kernels == 1:
+                t = timeit(l)
+                tot += t
+                print('%-5s %-28s %8.2f us' % (ph, l.name, t))
+    print('sum of the launches, one by one: %.1f us' % tot)
