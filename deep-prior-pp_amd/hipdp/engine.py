@@ -325,6 +325,7 @@ EARLY_REDUCE_BYTES = int(knob('DPP_EARLY_REDUCE_MB', '0')) << 20
 # bf16 (config 5) always uses dpp_fc_gemm: dpp_gemm has no bf16 counterpart.
 #   DPP_FC1_STREAM=auto (default) | bf16: bf16 only | 1: always | 0: never (bf16 FC1 then falls back to f32 dpp_gemm)
 FC1_STREAM = knob('DPP_FC1_STREAM', 'auto')
+FC1_WGRAD_DEFER = int(knob('DPP_FC1_WGRAD_DEFER', '0'))          # see CompiledNet._defer_fc1_wgrad
 FC1_KCHUNK = int(knob('DPP_FC1_KCHUNK', '0'))
 FC1_SLICES = int(knob('DPP_FC1_SLICES', '32'))
 FC1_MIN_K = int(knob('DPP_FC1_MIN_K', '4096'))
@@ -1130,6 +1131,7 @@ class CompiledNet(object):
             if EARLY_REDUCE_BYTES > 0 and self.reduce_jobs.pending_bytes() >= EARLY_REDUCE_BYTES:
                 self.bwd.fork()
                 self.bwd.add(self.reduce_jobs.flush('reduce_multi_early'), side=True)
+        self._defer_fc1_wgrad()
         self.bwd.join()
         self.bwd.add(self.reduce_jobs.flush())        # the remaining filter / bias gradient partials of the pass, one launch
         for slot, priv in self.__dict__.get('_shared_grad_adds', []):
@@ -1150,6 +1152,28 @@ class CompiledNet(object):
         if self.dp is None:
             for o in self._wd_ops:
                 self.bwd.add(o)
+
+    def _defer_fc1_wgrad(self):
+        """FC1's filter gradient (4.3 GFLOP, f32-MFMA-bound like FC1's data gradient) is the first big launch of the gradient branch
+        and runs BESIDE FC1's data gradient: the two share the matrix cores and the main chain waits longer for its first link.  Nothing
+        needs this gradient before the end of the pass, and a few launches later the chain is in the latency-bound stage-4 / 3
+        convolutions that leave the matrix cores idle -- so the launch moves FC1_WGRAD_DEFER side launches down the branch (it then
+        sits behind a later fork, i.e. waits for more of the chain than it needs).  Not under data parallelism (its all-reduce
+        bucket wants the gradient early) or EARLY_ADAM (its update sits right behind it).
+        Measured on the MI355X (tools/knob_sweep.sh, 300 steps each): 3.659 / 3.675 / 3.676 / 3.678 / 3.649 / 3.675 ms for 2 / 4 / 8 /
+        16 / 30 / 60 launches against 3.680-3.682 without -- inside the run-to-run noise, so it stays off (DPP_FC1_WGRAD_DEFER = 0)."""
+        op = self.__dict__.get('_fc1_wgrad_op')
+        if op is None or FC1_WGRAD_DEFER <= 0 or self.dp is not None or EARLY_ADAM:
+            return
+        ops_ = self.bwd.ops
+        i = [k for k, (o, _) in enumerate(ops_) if o is op][0]
+        entry = ops_.pop(i)
+        seen, j = 0, i
+        while j < len(ops_) and seen < FC1_WGRAD_DEFER:
+            if ops_[j][1] and isinstance(ops_[j][0], ops.Launch):
+                seen += 1
+            j += 1
+        ops_.insert(j, entry)
 
     def _sole_consumer_bn_view(self, view):
         """A BatchNorm(+ReLU) view read by exactly one conv: that conv's data-gradient epilogue may finish the BatchNorm
@@ -1317,8 +1341,10 @@ class CompiledNet(object):
         self._bias_grad(dY, Nb, Nout, gb)
         stream_kernel = self._fc1_stream(Nb, K, Nout)
         if stream_kernel:
-            self.bwd.add(ops.fc_gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, precision=self.prec,
-                                     kchunk=FC1_KCHUNK, name='fc_wgrad_%d' % layer.layerNum), side=True)
+            op = self.bwd.add(ops.fc_gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, precision=self.prec,
+                                          kchunk=FC1_KCHUNK, name='fc_wgrad_%d' % layer.layerNum), side=True)
+            if K * Nout >= EARLY_BUCKET_MIN:
+                self._fc1_wgrad_op = op
         else:
             tile, _ = gemm_plan(K, Nout, Nb, allow_split=False)
             if K >= 4096 and Nout >= 64 and knob('DPP_FC1_TILE128', '1') != '0':
