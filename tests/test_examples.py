@@ -155,3 +155,16 @@ def test_synthetic_driver_end_to_end(backend, tmp_path):
     assert len(costs) == 2 and np.all(np.isfinite(costs))
     assert np.isfinite([mean_err, max_err, mean_pose_err]).all() and mean_err > 0
     assert os.path.isfile(str(tmp_path / 'eval' / 'network_prior.pkl'))
+
+
+@pytest.mark.gpu
+def test_resnet_learns_the_synthetic_pose_manifold(tmp_path):
+    """Not a parity test but the thing parity is for: six epochs of the bs128 ResNet through PoseRegNetTrainer (online augmentation,
+    PCA prior, ADAM, BatchNorm in training mode) on rendered depth frames of a 16-joint hand bring the mean joint error well below
+    what predicting the mean pose gives, and the training cost falls by more than half."""
+    R.set_default_runtime(get_runtime('hip'))
+    costs, (mean_err, max_err, mean_pose_err) = _load_driver('main_synthetic_posereg_embedding').main(
+        ['--net', 'resnet', '--frames', '4096', '--epochs', '6', '--out', str(tmp_path / 'eval')])
+    assert np.all(np.isfinite(costs)) and len(costs) == 6 * 32
+    assert np.mean(costs[-8:]) < 0.5 * np.mean(costs[:8]), (np.mean(costs[:8]), np.mean(costs[-8:]))
+    assert mean_err < 0.75 * mean_pose_err, (mean_err, mean_pose_err)
