@@ -168,3 +168,15 @@ def test_resnet_learns_the_synthetic_pose_manifold(tmp_path):
     assert np.all(np.isfinite(costs)) and len(costs) == 6 * 32
     assert np.mean(costs[-8:]) < 0.5 * np.mean(costs[:8]), (np.mean(costs[:8]), np.mean(costs[-8:]))
     assert mean_err < 0.75 * mean_pose_err, (mean_err, mean_pose_err)
+
+
+@pytest.mark.gpu
+def test_resnet_learns_with_bf16_operands_too(tmp_path, monkeypatch):
+    """The same run with bf16 MFMA operands in the 3x3 convolutions and FC1 (BASELINE config 5's arithmetic) learns as well."""
+    from hipdp import engine
+    monkeypatch.setattr(engine, 'BF16_DEFAULT', True)
+    R.set_default_runtime(get_runtime('hip'))
+    costs, (mean_err, max_err, mean_pose_err) = _load_driver('main_synthetic_posereg_embedding').main(
+        ['--net', 'resnet', '--frames', '4096', '--epochs', '6', '--out', str(tmp_path / 'eval')])
+    assert np.all(np.isfinite(costs)) and np.mean(costs[-8:]) < 0.5 * np.mean(costs[:8])
+    assert mean_err < 0.75 * mean_pose_err, (mean_err, mean_pose_err)
