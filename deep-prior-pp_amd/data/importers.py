@@ -149,6 +149,26 @@ class DepthImporter(object):
         640x480 frames of NYU's 72 757-frame training sequence would need 89 GB of host memory."""
         return _CropStream(self, config, docom, side, chunk)
 
+    def _read_ahead(self, entries, window=32, workers=8):
+        """(entry, depth map or None when the file is missing) in the order of `entries` = [(filename, ...), ...]: the frames are
+        decoded by a small thread pool a window ahead of the consumer (PNG inflation and file reads release the GIL; the reference
+        decodes its 72 757 NYU training frames one by one), so the device crops never wait for a file."""
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+
+        def load(fn):
+            return self.loadDepthMap(fn) if os.path.isfile(fn) else None
+        pending = collections.deque()
+        with ThreadPoolExecutor(workers) as pool:
+            for e in entries:
+                pending.append((e, pool.submit(load, e[0])))
+                if len(pending) >= window:
+                    e0, f = pending.popleft()
+                    yield e0, f.result()
+            while pending:
+                e0, f = pending.popleft()
+                yield e0, f.result()
+
     @staticmethod
     def _has_content(dpt, tol=1.):
         """HandDetector.checkImage on the detector-preprocessed frame (handdetector.py:53-68, 110-120)."""
@@ -226,10 +246,9 @@ class ICVLImporter(DepthImporter):
         # every ICVL frame is recorded as 'left' (importers.py:401-402); the table of sides -- whose key for the first test sequence
         # is misspelt in the reference, :211 -- is only consulted when a hand was asked for
         records = self._crop_stream(config, docom, 'left')
+        entries = []
         with open('{}/{}.txt'.format(self.basepath, seqName)) as inputfile:
             for line in inputfile:
-                if len(records) >= Nmax:
-                    break
                 part = line.split(' ')
                 subSeqName = ''
                 if subSeq is not None:
@@ -238,20 +257,22 @@ class ICVLImporter(DepthImporter):
                     if (long_name and '0' not in subSeq) or (not long_name and p[0] not in subSeq):
                         continue
                     subSeqName = p[0] if not long_name else '0'
-                dptFileName = '{}/{}'.format(objdir, part[0])
-                if not os.path.isfile(dptFileName):
-                    print("File {} does not exist!".format(dptFileName))
-                    continue
-                dpt = self.loadDepthMap(dptFileName)
-                gtorig = np.zeros((self.numJoints, 3), np.float32)
-                for joint in range(self.numJoints):
-                    for xyz in range(0, 3):
-                        gtorig[joint, xyz] = part[joint * 3 + xyz + 1]
-                gt3Dorig = self.jointsImgTo3D(gtorig)        # normalized joints in 3D coordinates
-                if not self._has_content(dpt, 1):
-                    print("Skipping image {}, no content".format(dptFileName))
-                    continue
-                records.append((dpt, gtorig, gt3Dorig, dptFileName, subSeqName))
+                entries.append(('{}/{}'.format(objdir, part[0]), part, subSeqName))
+        for (dptFileName, part, subSeqName), dpt in self._read_ahead(entries):
+            if len(records) >= Nmax:
+                break
+            if dpt is None:
+                print("File {} does not exist!".format(dptFileName))
+                continue
+            gtorig = np.zeros((self.numJoints, 3), np.float32)
+            for joint in range(self.numJoints):
+                for xyz in range(0, 3):
+                    gtorig[joint, xyz] = part[joint * 3 + xyz + 1]
+            gt3Dorig = self.jointsImgTo3D(gtorig)        # normalized joints in 3D coordinates
+            if not self._has_content(dpt, 1):
+                print("Skipping image {}, no content".format(dptFileName))
+                continue
+            records.append((dpt, gtorig, gt3Dorig, dptFileName, subSeqName))
         print("Loaded {} samples.".format(len(records)))
         data = records.finish()
         return self._finish(seqName, data, config, cache, shuffle, rng)
@@ -298,6 +319,7 @@ class MSRA15Importer(DepthImporter):
         objdir = '{}/{}/'.format(self.basepath, seqName)
         subdirs = sorted([name for name in os.listdir(objdir) if os.path.isdir(os.path.join(objdir, name))])
         records = self._crop_stream(config, docom, self.sides[seqName])
+        entries = []
         for subdir in subdirs:
             subSeqName = ''
             if subSeq is not None:
@@ -307,30 +329,30 @@ class MSRA15Importer(DepthImporter):
             with open('{}/{}/joint.txt'.format(objdir, subdir)) as inputfile:
                 nImgs = int(inputfile.readline())
                 for i in range(nImgs):
-                    if len(records) >= Nmax:
-                        break
                     part = inputfile.readline().split(' ')
-                    dptFileName = '{}/{}/{}_depth.bin'.format(objdir, subdir, str(i).zfill(6))
-                    if not os.path.isfile(dptFileName):
-                        print("File {} does not exist!".format(dptFileName))
-                        continue
-                    dpt = self.loadDepthMap(dptFileName)
-                    gt3Dorig = np.zeros((self.numJoints, 3), np.float32)
-                    for joint in range(gt3Dorig.shape[0]):
-                        for xyz in range(0, 3):
-                            gt3Dorig[joint, xyz] = part[joint * 3 + xyz]
-                    gt3Dorig[:, 2] *= (-1.)                  # the files hold -z
-                    gtorig = self.joints3DToImg(gt3Dorig)
-                    if self.hand is not None and self.hand != self.sides[seqName]:
-                        gtorig[:, 0] -= dpt.shape[1] / 2.
-                        gtorig[:, 0] *= (-1)
-                        gtorig[:, 0] += dpt.shape[1] / 2.
-                        gt3Dorig = self.jointsImgTo3D(gtorig)
-                        dpt = dpt[:, ::-1]
-                    if not self._has_content(dpt, 1.):
-                        print("Skipping image {}, no content".format(dptFileName))
-                        continue
-                    records.append((dpt, gtorig, gt3Dorig, dptFileName, subSeqName))
+                    entries.append(('{}/{}/{}_depth.bin'.format(objdir, subdir, str(i).zfill(6)), part, subSeqName))
+        for (dptFileName, part, subSeqName), dpt in self._read_ahead(entries):
+            if len(records) >= Nmax:
+                break
+            if dpt is None:
+                print("File {} does not exist!".format(dptFileName))
+                continue
+            gt3Dorig = np.zeros((self.numJoints, 3), np.float32)
+            for joint in range(gt3Dorig.shape[0]):
+                for xyz in range(0, 3):
+                    gt3Dorig[joint, xyz] = part[joint * 3 + xyz]
+            gt3Dorig[:, 2] *= (-1.)                  # the files hold -z
+            gtorig = self.joints3DToImg(gt3Dorig)
+            if self.hand is not None and self.hand != self.sides[seqName]:
+                gtorig[:, 0] -= dpt.shape[1] / 2.
+                gtorig[:, 0] *= (-1)
+                gtorig[:, 0] += dpt.shape[1] / 2.
+                gt3Dorig = self.jointsImgTo3D(gtorig)
+                dpt = dpt[:, ::-1]
+            if not self._has_content(dpt, 1.):
+                print("Skipping image {}, no content".format(dptFileName))
+                continue
+            records.append((dpt, gtorig, gt3Dorig, dptFileName, subSeqName))
         print("Loaded {} samples.".format(len(records)))
         data = records.finish()
         return self._finish(seqName, data, config, cache, shuffle, rng)
@@ -385,14 +407,13 @@ class NYUImporter(DepthImporter):
         eval_idxs = np.arange(36) if self.allJoints else np.asarray(self.restrictedJointsEval)
         self.numJoints = len(eval_idxs)
         records = self._crop_stream(config, docom, self.sides[seqName])
-        for line in range(joints3D.shape[0]):
+        entries = [('{0:s}/depth_1_{1:07d}.png'.format(objdir, line + 1), line) for line in range(joints3D.shape[0])]
+        for (dptFileName, line), dpt in self._read_ahead(entries):
             if len(records) >= Nmax:
                 break
-            dptFileName = '{0:s}/depth_1_{1:07d}.png'.format(objdir, line + 1)
-            if not os.path.isfile(dptFileName):
+            if dpt is None:
                 print("File {} does not exist!".format(dptFileName))
                 continue
-            dpt = self.loadDepthMap(dptFileName)
             gtorig = np.asarray(joints2D[line, eval_idxs, 0:3], np.float32)     # joints in image coordinates
             gt3Dorig = np.asarray(joints3D[line, eval_idxs, 0:3], np.float32)   # normalized joints in 3D coordinates
             if not self._has_content(dpt, 1):
