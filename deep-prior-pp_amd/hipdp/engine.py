@@ -318,6 +318,9 @@ EARLY_ADAM = knob('DPP_EARLY_ADAM', '0') != '0'
 # this many bytes (their producers are on that branch or already issued on the main stream), and the tail launch keeps the rest.
 # Measured: 4.21 (16 MB) / 4.19 (64 MB) vs 4.18 ms with the single launch, for the same reason as EARLY_ADAM.  0 = one launch (default).
 EARLY_REDUCE_BYTES = int(knob('DPP_EARLY_REDUCE_MB', '0')) << 20
+# the partials collected before the stem reduced on the branch beside the stem's filter gradient: 3.661-3.669 vs 3.673-3.680 ms over
+# 300-step runs -- the branch, not the main stream, is what the join waits for; off
+TAIL_REDUCE = knob('DPP_TAIL_REDUCE', '0') != '0'
 # FC1 (the HiddenLayer behind the last conv map) on the weight-streaming kernels of dpp_fc_gemm instead of the generic dpp_gemm.
 # f32: the three-stage kernel (fc_stream_kernel: 128 x 128 / 128 x 64 tiles, whole tiles only) runs the batch-128 FC1 forward /
 # data gradient in 53 / 70 us against dpp_gemm's 102 / 104 us; the older double-buffered kernel, which takes ragged shapes, only
@@ -1118,6 +1121,11 @@ class CompiledNet(object):
             elif kind == 'HiddenLayer':
                 self._bwd_fc(layer, io, src, dY)
             elif kind == 'ConvPoolLayer':
+                if TAIL_REDUCE and self.reduce_jobs.jobs:
+                    # the partials collected so far are reduced on the gradient branch BESIDE the stem's filter gradient (the last
+                    # launch of the main stream, which otherwise idles at the join while reduce_multi waits behind it)
+                    self.bwd.fork()
+                    self.bwd.add(self.reduce_jobs.flush('reduce_multi_side'), side=True)
                 self._bwd_stem(layer, io, dY)
             elif kind == 'DropoutLayer':
                 tgt, dst = self._view_grad(src)
