@@ -5,9 +5,7 @@ CoM-refinement regressor of main_nyu_com_refine.py.  The three network inputs ar
 normalised 3-D offset of the crop joint (numJoints = 1, nDims = 3).  `augment_poses` augments the resident macro-batch on
 the device and re-derives the two centre crops from it (scalenettrainer.py:239-251).
 """
-import numpy
-
-from hipdp import engine, ops
+from hipdp import ops
 from hipdp.augmenter import DeviceAugmenter
 from net.scalenet import ScaleNet, ScaleNetParams      # noqa: F401  (re-exported like the reference module)
 from trainer.nettrainer import NetTrainerParams

@@ -10,8 +10,6 @@ from the script's numpy RandomState in the reference's order, so the sampled pos
 
 `DevicePCA` offers the attributes and methods of sklearn.decomposition.PCA that the scripts and the trainer use (`mean_`,
 `components_`, `explained_variance_`, `transform`, `inverse_transform`); it can be handed to PoseRegNetTrainer as `proj`."""
-import ctypes as C
-
 import numpy
 
 from hipdp.lib import check

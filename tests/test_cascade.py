@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from data.importers import ICVLImporter, NYUImporter
-from hipdp import engine, ops
+from hipdp import engine
 from hipdp import runtime as R
 from hipdp.cascade import CascadeCropper
 from net.scalenet import ScaleNet, ScaleNetParams
