@@ -328,6 +328,7 @@ TAIL_REDUCE = knob('DPP_TAIL_REDUCE', '0') != '0'
 # bf16 (config 5) always uses dpp_fc_gemm: dpp_gemm has no bf16 counterpart.
 #   DPP_FC1_STREAM=auto (default) | bf16: bf16 only | 1: always | 0: never (bf16 FC1 then falls back to f32 dpp_gemm)
 FC1_STREAM = knob('DPP_FC1_STREAM', 'auto')
+FC1_WGRAD_STREAM = knob('DPP_FC1_WGRAD_STREAM', '1') != '0'       # FC1's filter gradient on dpp_fc_wgrad_stream (f32)
 FC1_WGRAD_DEFER = int(knob('DPP_FC1_WGRAD_DEFER', '0'))          # see CompiledNet._defer_fc1_wgrad
 FC1_KCHUNK = int(knob('DPP_FC1_KCHUNK', '0'))
 FC1_SLICES = int(knob('DPP_FC1_SLICES', '32'))
@@ -1348,7 +1349,13 @@ class CompiledNet(object):
         self.bwd.fork()
         self._bias_grad(dY, Nb, Nout, gb)
         stream_kernel = self._fc1_stream(Nb, K, Nout)
-        if stream_kernel:
+        if stream_kernel and self.prec == 0 and FC1_WGRAD_STREAM and (act is None or act.mode < 4) and rt.lib.dpp_fc_wgrad_stream_ok(Nb, K, Nout):
+            # the reduction is only the batch: every 64 x 64 block of dW is owned by one wave of the row stream (csrc/wgrad.hip),
+            # no LDS pipeline to fill and drain for four chunks, no partials
+            op = self.bwd.add(ops.fc_wgrad_stream(rt, src.base.buf, dY, gW, Nb, K, Nout, actX=act, name='fc_wgrad_%d' % layer.layerNum), side=True)
+            if K * Nout >= EARLY_BUCKET_MIN:
+                self._fc1_wgrad_op = op
+        elif stream_kernel:
             op = self.bwd.add(ops.fc_gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, precision=self.prec,
                                           kchunk=FC1_KCHUNK, name='fc_wgrad_%d' % layer.layerNum), side=True)
             if K * Nout >= EARLY_BUCKET_MIN:

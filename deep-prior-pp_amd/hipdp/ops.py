@@ -280,6 +280,12 @@ def fc_gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, actA=None, act
     return Launch(rt.lib.dpp_fc_gemm, (C.byref(d), int(precision), int(kchunk)), (d, A, B, Cbuf, bias, residual, partial, actA, actB), name, meta)
 
 
+def fc_wgrad_stream(rt, X, dY, dW, Nb, K, N, actX=None, name='fc_wgrad_stream'):
+    """dpp_fc_wgrad_stream: dW [K][N] = act(X)^T . dY over the Nb rows, each output block owned by one wave (no partials)."""
+    meta = dict(kernel='gemm_mfma_f32', flops=2.0 * Nb * K * N, bytes=4.0 * (Nb * K + Nb * N + K * N))
+    return Launch(rt.lib.dpp_fc_wgrad_stream, (X.ptr, dY.ptr, dW.ptr, int(Nb), int(K), int(N), _actp(actX)), (X, dY, dW, actX), name, meta)
+
+
 def reduce_partials(rt, partial, nz, n, out, bias=None, nbias=1, name='reduce_partials'):
     return Launch(rt.lib.dpp_reduce_partials, (partial.ptr, int(nz), int(n), _p(bias), int(nbias), out.ptr),
                   (partial, out, bias), name, dict(kernel='reduce_partials', flops=float(nz) * n, bytes=4.0 * (nz + 1) * n))

@@ -145,6 +145,12 @@ int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_
  * taps outside the image contribute zero.  X [N][H][W][Ci], dY [N][H][W][Co], W % 4 == 0 (a step is four neighbouring pixels of a
  * row).  Shapes: Co == Ci in {16, 32, 64} (the bottleneck convolutions of resnet.py:300-420); dpp_wgrad3_stream_slices returns 0
  * for anything else and dpp_conv3x3_wgrad (the LDS-tiled kernel, same partial layout per block) remains.  Same T.grad. */
+/* Filter gradient of a HiddenLayer whose reduction is only the batch (FC1: dW[k][n] = sum_b act(X)[b][k] * dY[b][n]; X [Nb][K],
+ * dY [Nb][N], dW [K][N], all row-major; actX = the BatchNorm + ReLU prologue of the flattened map, channel = column % cmod) on the
+ * row stream: a wave owns a 64 x 64 block of dW over all rows, no LDS, no partials.  K and N multiples of 128
+ * (dpp_fc_wgrad_stream_ok), otherwise dpp_fc_gemm's layout remains.  T.grad of hiddenlayer.py:136-139. */
+int dpp_fc_wgrad_stream_ok(int Nb, int K, int N);
+int dpp_fc_wgrad_stream(const float* X, const float* dY, float* dW, int Nb, int K, int N, const dpp_act* actX, dpp_stream_t stream);
 int dpp_wgrad3_stream_slices(int Co, int Ci, int N, int H, int W, int rows_per_wave);
 int dpp_wgrad3_stream(const float* dY, int Co, const float* X, int Ci, int N, int H, int W, const dpp_act* actX, int rows_per_wave,
                       float* partial, dpp_stream_t stream);

@@ -419,3 +419,34 @@ def test_wgrad_stream_matches_float64(backend, shape):
             ref = dY.astype(np.float64).T @ Xa
             _check(got, ref, M, 4)
     assert rt.lib.dpp_wgrad_stream_slices(48, 64, 100, 32) == 0          # other shapes stay on dpp_gemm
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(128, 256, 128, True), (6, 128, 256, True), (9, 384, 128, False)])
+def test_fc_wgrad_stream(backend, cfg):
+    """dpp_fc_wgrad_stream: dW [K][N] = act(X)^T . dY with the BatchNorm + ReLU prologue of the flattened map (channel = column % cmod)
+    against float64 -- whole steps of four rows, a ragged last step, and no prologue; shapes it does not take are refused."""
+    rt = get_runtime(backend)
+    Nb, K, N, with_act = cfg
+    rng = np.random.RandomState(77)
+    X = rng.normal(size=(Nb, K)).astype('float32')
+    dY = rng.normal(size=(Nb, N)).astype('float32')
+    cmod = 32
+    mean, scale, beta = (rng.normal(size=cmod) * 0.3).astype('float32'), rng.uniform(0.5, 1.5, cmod).astype('float32'), (rng.normal(size=cmod) * 0.3).astype('float32')
+    A = X.astype('f8')
+    act = None
+    keep = None
+    if with_act:
+        ch = np.arange(K) % cmod
+        A = np.maximum((A - mean[ch]) * scale[ch] + beta[ch], 0)
+        keep = [rt.upload(v) for v in (mean, scale, beta)]
+        act = ops.act(Act.BN_RELU, keep[0], keep[1], keep[2], cmod)
+    dW = rt.alloc((K, N), zero=False)
+    assert rt.lib.dpp_fc_wgrad_stream_ok(Nb, K, N) == 1
+    ops.fc_wgrad_stream(rt, rt.upload(X), rt.upload(dY), dW, Nb, K, N, actX=act)(rt.stream)
+    rt.synchronize()
+    ref = A.T @ dY.astype('f8')
+    np.testing.assert_allclose(dW.get(), ref, rtol=0, atol=3e-6 * np.sqrt(Nb) * np.abs(ref).max())
+    assert rt.lib.dpp_fc_wgrad_stream_ok(Nb, K + 64, N) == 0 and rt.lib.dpp_fc_wgrad_stream_ok(Nb, K, 96) == 0
+    with pytest.raises(Exception):
+        ops.fc_wgrad_stream(rt, rt.upload(X), rt.upload(dY), dW, Nb, K, 96, actX=act)(rt.stream)

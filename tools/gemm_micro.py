@@ -110,6 +110,23 @@ def main_fc():
         bench_fc('fc2 wgrad', 1024, 1024, 128, 0, 0, tile, 1)
 
 
+def main_fcw():
+    """FC1's filter gradient: dpp_fc_gemm's layout against dpp_fc_wgrad_stream."""
+    for Nb, K, N in ((128, 16384, 1024), (128, 65536, 1024), (256, 16384, 1024)):
+        X = rt.alloc((Nb, K), zero=False)
+        rt.tensor(X).normal_()
+        dY = rt.alloc((Nb, N), zero=False)
+        rt.tensor(dY).normal_()
+        dW = rt.alloc((K, N), zero=False)
+        mean, scale, beta = rt.alloc(256), rt.alloc(256), rt.alloc(256)
+        act = Act(mean.ptr, scale.ptr, beta.ptr, 3, 256)
+        t0 = timeit(ops.fc_gemm(rt, X, dY, dW, K, N, Nb, 0, 0, K, N, N, actA=act), 20)
+        t1 = timeit(ops.fc_wgrad_stream(rt, X, dY, dW, Nb, K, N, actX=act), 20)
+        fl = 2.0 * Nb * K * N
+        print('FC wgrad Nb=%d K=%d N=%d: fc_gemm %7.2f us (%5.1f TFLOP/s) | fc_wgrad_stream %7.2f us (%5.1f TFLOP/s, %4.0f GB/s of output)' %
+              (Nb, K, N, t0, fl / t0 * 1e-6, t1, fl / t1 * 1e-6, 4.0 * K * N / t1 * 1e-3))
+
+
 def main_wgrad():
     # 1x1 filter gradients: dW[Co][Ci] = dY^T . act(X), reduction over pixels
     for label, Co, Ci, px in (('stage1 a', 16, 64, 131072), ('stage1 c', 64, 16, 131072), ('stage2 a', 32, 128, 32768),
@@ -193,6 +210,8 @@ def main():
         return main_feats()
     if 'fc' in sys.argv[1:]:
         return main_fc()
+    if 'fcw' in sys.argv[1:]:
+        return main_fcw()
     if 'wgrad' in sys.argv[1:]:
         return main_wgrad()
     z = rt.alloc(4)
