@@ -66,7 +66,10 @@ def test_train_gradients_match_oracle_at_benchmarked_batch_128():
     eng = _gradients_vs_pinned_oracle(128, 16)
     tiles = set((l.keep[0].bm, l.keep[0].bn) for _, l in eng.all_launches() if l.fn is eng.rt.lib.dpp_gemm)
     n_fc = sum(l.fn is eng.rt.lib.dpp_fc_gemm for _, l in eng.all_launches())
-    assert n_fc == 3 or (128, 64) in tiles          # FC1 on the three-stage weight-streaming kernel (default) or on dpp_gemm's 128 x 64 tile
+    n_fcw = sum(l.fn is eng.rt.lib.dpp_fc_wgrad_stream for _, l in eng.all_launches())
+    # FC1 forward / data gradient on the three-stage weight-streaming kernel and its filter gradient on the row stream (defaults), or on
+    # dpp_gemm's 128 x 64 tile
+    assert (n_fc == 2 and n_fcw == 1) or n_fc == 3 or (128, 64) in tiles
 
 
 def test_bf16_train_gradients_match_the_bf16_oracle_at_benchmarked_batch_128():
@@ -95,7 +98,8 @@ def test_every_bs128_gemm_instantiation_against_float64():
     assert any(t[2] >= 32 for t in tiles)                                                   # deep split-K is among them
     # FC1's three GEMMs: on the three-stage weight-streaming kernel (dpp_fc_gemm, keyed with tile -1) by default, else dpp_gemm's 128 x 64 tile
     fc = [k for _, k in checked if k[11] == -1]
-    assert len(fc) == 3 or any(t[:2] == (128, 64) for t in tiles), (fc, tiles)
+    n_fcw = sum(l.fn is rt.lib.dpp_fc_wgrad_stream for _, l in eng.all_launches())      # (held to the oracle by the gradient tests above
+    assert (len(fc) == 2 and n_fcw == 1) or len(fc) == 3 or any(t[:2] == (128, 64) for t in tiles), (fc, tiles)   # and tests/test_gemm.py)
 
 
 def test_full_batch_properties():
