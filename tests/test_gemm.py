@@ -422,7 +422,7 @@ def test_wgrad_stream_matches_float64(backend, shape):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('cfg', [(128, 256, 128, True), (6, 128, 256, True), (9, 384, 128, False)])
+@pytest.mark.parametrize('cfg', [(128, 256, 128, True), (6, 128, 256, True), (9, 384, 128, False), (1, 128, 128, True), (37, 128, 128, True)])
 def test_fc_wgrad_stream(backend, cfg):
     """dpp_fc_wgrad_stream: dW [K][N] = act(X)^T . dY with the BatchNorm + ReLU prologue of the flattened map (channel = column % cmod)
     against float64 -- whole steps of four rows, a ragged last step, and no prologue; shapes it does not take are refused."""
