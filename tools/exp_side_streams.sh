@@ -1,3 +1,4 @@
+# The gradient branch spread over several side streams (DPP_SIDE_STREAMS) against the bench step time:  gpurun -- 'bash tools/exp_side_streams.sh'
 export DPP_EXPERIMENT=1      # the engine reads its experiment knobs only with this set (hipdp/engine.py: knob)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02s; mkdir -p $O

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""One-off set-up steps of the training scripts on the device: pose sampling (20 k and 1e6 poses), PCA fit, evaluation of 8 252 frames:
+   python tools/setup_time.py"""
 import sys, os, time
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'deep-prior-pp_amd'))

@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Bare bs128 ResNet train step (no augmentation, no bench plumbing), timed over 50 steps:   python tools/step_probe.py"""
 import sys, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/deep-prior-pp_amd')
 import numpy as np, torch
