@@ -31,7 +31,7 @@ def pytest_cmdline_main(config):
         return None
     if not config.pluginmanager.hasplugin('xdist') or getattr(config.option, 'numprocesses', None):
         return None
-    n = int(os.environ.get('DPP_TEST_WORKERS', min(4, os.cpu_count() or 1)))
+    n = int(os.environ.get('DPP_TEST_WORKERS', max(1, min(6, (os.cpu_count() or 1) - 2))))
     if n > 1:                           # what xdist's own (tryfirst) hook derives from `-n <n>`
         os.environ['DPP_TEST_WORKERS'] = '0'    # inherited by the popen workers: second guard against recursive spawning
         config.option.numprocesses = n
