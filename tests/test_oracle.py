@@ -102,6 +102,61 @@ def test_chunks_partition():
         n, k = c['n'], c['k']
         mine = [[i, min(i + k, n)] for i in range(0, n, k)]
         assert mine == c['chunks']
+        from util.helpers import chunks
+        got = list(chunks(list(range(n)), k))
+        assert [[g[0], g[-1] + 1] for g in got] == c['chunks'] and sum(got, []) == list(range(n))
+    from util.helpers import chunks
+    assert list(chunks([], 3)) == [] and list(chunks('abcde', 2)) == ['ab', 'cd', 'e']
+
+
+def test_shuffle_many_inplace_applies_the_references_permutation():
+    """helpers.json: the reference's own shuffle_many_inplace (/root/reference/src/util/helpers.py:87-108) on arange(n)."""
+    from util.helpers import shuffle_many_inplace
+    for c in json.load(open(os.path.join(GOLD, 'helpers.json'))):
+        rng = np.random.RandomState(c['seed'])
+        a = np.arange(c['n'])
+        b = np.arange(c['n'] * 6, dtype=np.float32).reshape(c['n'], 2, 3)
+        shuffle_many_inplace([a, b], random_state=rng)
+        assert a.tolist() == c['perm'] and np.array_equal(b[:, 0, 0], 6. * a)
+        assert int(rng.randint(1 << 30)) == c['next_draw']          # the stream was consumed draw for draw
+    with pytest.raises(ValueError):
+        shuffle_many_inplace([np.arange(3)], random_state=5)
+    with pytest.raises(AssertionError):
+        shuffle_many_inplace([np.arange(3), np.arange(4)])
+    np.random.seed(3)
+    a = np.arange(9)
+    shuffle_many_inplace([a])                                        # global stream when no state is given
+    assert sorted(a.tolist()) == list(range(9))
+
+
+def test_dataset_stacks_against_the_reference():
+    """dataset.npz: the reference's Dataset.imgStackDepthOnly (/root/reference/src/data/dataset.py:72-111), both normalisations."""
+    import sys
+    sys.path.insert(0, GOLD)
+    try:
+        from make_golden_r4 import synthetic_sequences
+    finally:
+        sys.path.remove(GOLD)
+    from data.dataset import Dataset, ICVLDataset, MSRA15Dataset, NYUDataset
+    from data import importers
+    g = np.load(os.path.join(GOLD, 'dataset.npz'))
+    seqs = synthetic_sequences()
+    for s in seqs:
+        for nz in (False, True):
+            img, lab = Dataset(seqs, localCache=False).imgStackDepthOnly(s.name, normZeroOne=nz)
+            assert img.dtype == np.float32 and lab.dtype == np.float32
+            assert np.array_equal(img, g['%s_img_%d' % (s.name, nz)]) and np.array_equal(lab, g['%s_lab_%d' % (s.name, nz)])
+    ds = Dataset(seqs)
+    assert ds.imgSeq('test_1') is seqs[1] and ds.imgSeq('nope') == [] and ds.imgStackDepthOnly('nope') == []
+    first = ds.imgStackDepthOnly('train')
+    assert ds.imgStackDepthOnly('train')[0] is first[0]              # localCache
+    ds.imgSeqs = seqs[:1]
+    assert ds.imgStackDepthOnly('train')[0] is not first[0] and ds.imgSeqs == seqs[:1]
+    for cls, imp, default in ((ICVLDataset, importers.ICVLImporter, '../../data/ICVL/'), (MSRA15Dataset, importers.MSRA15Importer, '../../data/MSRA15/'),
+                              (NYUDataset, importers.NYUImporter, '../../data/NYU/')):
+        assert isinstance(cls().lmi, imp) and cls().lmi.basepath == default
+        d = cls(seqs, basepath='/data/x/', localCache=False)
+        assert d.lmi.basepath == '/data/x/' and d.imgSeqs is seqs and cls.__name__ == type(d).__name__
 
 
 def test_conv_is_true_convolution():
