@@ -161,11 +161,20 @@ class ParamStore(object):
         s = self.slots[self.by_param[param.auto_name]]
         return self._from_kernel(s, self.g.view(s['off'], (s['size'],)).get())
 
+    released = False
+
     def release(self):
-        """Pull every value back to the host copies and unbind (before the store is rebuilt)."""
+        """Pull every value back to the host copies and unbind (before the store is rebuilt).  Engines compiled on this store keep
+        views into its buffers: they refuse to run from here on (`check_live`) instead of computing with weights nobody updates."""
         for i, s in enumerate(self.slots):
             s['param']._host = np.asarray(self.read_param(i), np.float32)
             s['param']._binding = None
+        self.released = True
+
+    def check_live(self):
+        if self.released:
+            raise RuntimeError("this engine was compiled before the net's parameter list changed (a layer was added or removed and the "
+                               "device parameter store was rebuilt): compile the net again")
 
 
 def _fc_rows(W, info, fn):
@@ -259,6 +268,9 @@ def get_store(net, rt, layers):
         net._param_store = store
         return store
     if store is not None:
+        if owner is not net:
+            raise RuntimeError("twin net: its parameter list differs from the one of the net it shares its weights with (%d vs %d "
+                               "parameters); the shared store is not rebuilt under the owner's engines" % (len(names), len(store.slots)))
         store.release()
     store = ParamStore(rt, specs)
     owner._param_store = store
@@ -1449,6 +1461,7 @@ class CompiledNet(object):
             t.buf.set(a if a.shape[1] == 1 else layout.nchw_to_nhwc(a))
 
     def forward(self, x=None):
+        self.store.check_live()
         if x is not None:
             self.set_input(x)
         self.fwd.run(self.rt)
@@ -1477,6 +1490,7 @@ class CompiledNet(object):
         """forward + loss + backward (+ gradient all-reduce) + ADAM on x_in / y_in; no host<->device traffic, so the
         whole sequence can be captured into a hipGraph (runtime.capture) and replayed."""
         st = self.rt
+        self.store.check_live()
         if allreduce is None:
             self.step_plan().run(st)
             return

@@ -117,20 +117,35 @@ class DataParallel(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return [float(v) / self.world for v in t.cpu()]
 
-    def shard(self, data, batch, pad_rng_seed=None):
+    def shard(self, data, batch, pad_rng_seed=None, pad='cut', what='array'):
         """This rank's rows of a per-sample array under the minibatch layout of SURVEY.md section 8(e): the global minibatch k is rows
-        [k*G*B, (k+1)*G*B) and rank r owns its contiguous slice [r*B, (r+1)*B).  pad_rng_seed None: the array is cut to whole
-        global minibatches (validation data: the reference drops the remainder too, nettrainer.py:793); otherwise it is first padded
-        to whole global minibatches with rows drawn by RandomState(seed) (alignData's rule, nettrainer.py:365-413)."""
+        [k*G*B, (k+1)*G*B) and rank r owns its contiguous slice [r*B, (r+1)*B).  How an array that is not a whole number of global
+        minibatches is completed first:
+          pad='cut'     dropped remainder (validation data: the reference drops it too, nettrainer.py:793) -- an array shorter than
+                        one global minibatch would leave every rank without a single validation batch, which is refused;
+          pad='random'  rows drawn by RandomState(pad_rng_seed) (alignData's pad_random rule, nettrainer.py:365-413; passing
+                        pad_rng_seed alone selects it);
+          pad='last'    the last row repeated (alignData with pad_random=False, nettrainer.py:404-411)."""
         import numpy as np
         data = np.asarray(data)
         G, B = self.world, int(batch)
         n, gb = data.shape[0], G * B
-        if pad_rng_seed is None:
+        if pad_rng_seed is not None:
+            pad = 'random'
+        if pad == 'cut':
+            if n < gb:
+                raise ValueError("data parallel: %s has %d samples, fewer than one global minibatch (%d ranks x %d): every rank's shard "
+                                 "would be empty" % (what, n, G, B))
             data = data[:(n // gb) * gb]
         elif n % gb:
-            rng = np.random.RandomState(pad_rng_seed)
-            fill = np.stack([data[rng.randint(0, n)] for _ in range(gb - n % gb)])
+            fill_n = gb - n % gb
+            if pad == 'random':
+                rng = np.random.RandomState(pad_rng_seed)
+                fill = np.stack([data[rng.randint(0, n)] for _ in range(fill_n)])
+            elif pad == 'last':
+                fill = np.repeat(data[n - 1:n], fill_n, axis=0)
+            else:
+                raise ValueError("pad must be 'cut', 'random' or 'last'")
             data = np.concatenate([data, fill], axis=0)
         return np.ascontiguousarray(data.reshape((-1, G, B) + data.shape[1:])[:, self.rank].reshape((-1,) + data.shape[1:]))
 
@@ -138,6 +153,26 @@ class DataParallel(object):
         """Replicas start from rank 0's parameters and running statistics."""
         self.broadcast(store.w)
         self.broadcast(store.nt)
+
+
+def local_device_index():
+    """The GPU this process owns under torchrun (LOCAL_RANK, wrapped when several ranks share the visible GPUs: the gloo control-flow
+    tests put two ranks on one MI355X); None outside a multi-process launch or without a GPU."""
+    import torch
+    if int(os.environ.get('WORLD_SIZE', '1')) <= 1 or not torch.cuda.is_available():
+        return None
+    return int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
+
+
+def bind_local_device():
+    """Make the rank's GPU the current device.  Everything that creates device state -- TorchHipRuntime binds
+    torch.cuda.current_device() and creates its streams there -- has to come after this; `hipdp.runtime.default_runtime()` calls it
+    itself, so the importers / PCA / pose sampling of a main that run before the trainer exists land on the right GPU too."""
+    idx = local_device_index()
+    if idx is not None:
+        import torch
+        torch.cuda.set_device(idx)
+    return idx
 
 
 def init_from_env(backend=None):
@@ -150,12 +185,22 @@ def init_from_env(backend=None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         backend = os.environ.get('DPP_DIST_BACKEND', backend)      # e.g. gloo: several ranks on ONE GPU to test the control flow
-        if torch.cuda.is_available():
-            # NO device_id in init_process_group: it makes torch create the RCCL communicator eagerly, BEFORE the engine's
-            # streams exist, and the side stream then shares a hardware queue with the main stream (measured on the MI355X: the
-            # two-stream step drops from 5.16 to 6.82 ms).  Created lazily by the first collective, after TorchHipRuntime() has
-            # its streams, it does not disturb them.
-            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count())
-        kw = {}
-        dist.init_process_group(backend=backend, **kw)
+        # NO device_id in init_process_group: it makes torch create the RCCL communicator eagerly, BEFORE the engine's
+        # streams exist, and the side stream then shares a hardware queue with the main stream (measured on the MI355X: the
+        # two-stream step drops from 5.16 to 6.82 ms).  Created lazily by the first collective, after TorchHipRuntime() has
+        # its streams, it does not disturb them.
+        bind_local_device()
+        dist.init_process_group(backend=backend)
+    elif world > 1:
+        bind_local_device()
     return rank, world
+
+
+def check_runtime_device(rt):
+    """A runtime created before the rank's GPU was selected holds buffers and streams on another GPU than the collectives and the
+    launches of this process will use: refuse it instead of hanging in RCCL."""
+    idx = local_device_index()
+    dev = getattr(rt, 'device', None)
+    if idx is not None and dev is not None and getattr(dev, 'index', idx) != idx:
+        raise RuntimeError("data parallel: this rank owns cuda:%d but its runtime was created on %s -- call hipdp.parallel.init_from_env() "
+                           "(or hipdp.runtime.default_runtime()) before creating device state" % (idx, dev))

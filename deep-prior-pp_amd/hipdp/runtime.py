@@ -14,11 +14,13 @@ from . import lib as _lib
 
 
 class Buffer(object):
-    """A typed view of device memory: `ptr` (int), `shape`, `dtype`; `owner` keeps the allocation alive."""
-    __slots__ = ('ptr', 'shape', 'dtype', 'owner', 'rt')
+    """A typed view of device memory: `ptr` (int), `shape`, `dtype`; `owner` (the allocation's tensor) keeps the allocation alive,
+    `keep` whatever else has to outlive the kernels queued on it (the inputs of an asynchronous producer)."""
+    __slots__ = ('ptr', 'shape', 'dtype', 'owner', 'rt', 'keep')
 
     def __init__(self, rt, ptr, shape, dtype, owner):
         self.rt, self.ptr, self.shape, self.dtype, self.owner = rt, int(ptr), tuple(int(s) for s in shape), np.dtype(dtype), owner
+        self.keep = None
 
     @property
     def size(self):
@@ -33,13 +35,17 @@ class Buffer(object):
         dt = np.dtype(dtype or self.dtype)
         n = int(np.prod(shape)) if len(shape) else 1
         assert offset >= 0 and offset * self.dtype.itemsize + n * dt.itemsize <= self.nbytes, "view out of range"
-        return Buffer(self.rt, self.ptr + offset * self.dtype.itemsize, shape, dt, self.owner)
+        b = Buffer(self.rt, self.ptr + offset * self.dtype.itemsize, shape, dt, self.owner)
+        b.keep = self.keep
+        return b
 
     def reshape(self, *shape):
         if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
             shape = tuple(shape[0])
         assert int(np.prod(shape)) == self.size
-        return Buffer(self.rt, self.ptr, shape, self.dtype, self.owner)
+        b = Buffer(self.rt, self.ptr, shape, self.dtype, self.owner)
+        b.keep = self.keep
+        return b
 
     def get(self):
         return self.rt.download(self)
@@ -201,6 +207,8 @@ def default_runtime():
     """The process-wide product runtime (one per process / GPU)."""
     global _default
     if _default is None:
+        from . import parallel
+        parallel.bind_local_device()          # under torchrun: the rank's own GPU, whoever asks for the runtime first
         _default = TorchHipRuntime()
     return _default
 

@@ -99,10 +99,13 @@ class NetTrainer(object):
         self.rng = numpy.random.RandomState(23455)
         if not isinstance(cfgParams, NetTrainerParams):
             raise ValueError("cfgParams must be an instance of NetTrainerParams")
-        self.rt = runtime or default_runtime()
+        world = 1
         if dp == 'env':
             from hipdp import parallel
-            _, world = parallel.init_from_env()
+            _, world = parallel.init_from_env()        # selects the rank's GPU: before any runtime is created
+        self.rt = runtime or default_runtime()
+        if dp == 'env':
+            parallel.check_runtime_device(self.rt)
             dp = parallel.DataParallel(self.rt) if world > 1 else None
         self.dp = dp
         self.memorySize = self._free_device_mb() / float(memory_factor)    # MB, nettrainer.py:100-112
@@ -203,10 +206,12 @@ class NetTrainer(object):
 
     def _shard_train(self, data):
         """Data parallel: this rank's slice of every global minibatch, the global array first padded to whole global minibatches by
-        alignData's rule (rows drawn by RandomState(n)); single process: the array as it is."""
+        alignData's rule (rows drawn by RandomState(n), or the last row repeated without pad_random); single process: the array as it is."""
         if self.dp is None:
             return data
-        return self.dp.shard(data, self.cfgParams.batch_size, pad_rng_seed=data.shape[0] if self.cfgParams.pad_random else None)
+        if self.cfgParams.pad_random:
+            return self.dp.shard(data, self.cfgParams.batch_size, pad_rng_seed=data.shape[0])
+        return self.dp.shard(data, self.cfgParams.batch_size, pad='last')
 
     def _dp_layout(self):
         """(G, rank, B) for the augmenter: how this rank's samples sit in the global macro-batch (None: single process)."""
@@ -219,7 +224,7 @@ class NetTrainer(object):
             self._global_train_n, self._global_val_n = train_data.shape[0], val_data.shape[0]
             max_train_size = max_train_size / float(self.dp.world)
             train_data, train_y = self._shard_train(train_data), self._shard_train(train_y)
-            val_data, val_y = self.dp.shard(val_data, self.cfgParams.batch_size), self.dp.shard(val_y, self.cfgParams.batch_size)
+            val_data, val_y = (self.dp.shard(v, self.cfgParams.batch_size, what='the validation set') for v in (val_data, val_y))
         self.trainSize = max(train_data.nbytes, train_y.nbytes, max_train_size) / 1024. / 1024.
         self.numTrainSamplesMB = train_data.shape[0]
         self.numTrainSamples = self.numTrainSamplesMB

@@ -52,7 +52,7 @@ def sample_random_poses_device(importer, rng, base_poses, base_com, base_cube, n
                                  d_rot.ptr, n, float(importer.fx), float(importer.fy), float(importer.ux), float(importer.uy), int(flip),
                                  out.ptr, None, None, rt.stream), 'dpp_pose_sample')
     if keep_on_device:
-        out.owner = (out.owner, d_poses, d_com, d_cube, d_mode, d_ridx, d_off, d_sc, d_rot)      # inputs alive until the kernel has run
+        out.keep = (d_poses, d_com, d_cube, d_mode, d_ridx, d_off, d_sc, d_rot)      # inputs alive until the kernel has run
         return out
     rt.synchronize()
     return out.get()

@@ -42,6 +42,9 @@ def main(argv=None):
     ap.add_argument('--out', default='./eval/icvl_posereg_embedding')
     ap.add_argument('--cache', default='./cache/')
     args = ap.parse_args(argv)
+    if args.dp:
+        from hipdp import parallel
+        parallel.init_from_env()          # selects this rank's GPU: before the importers / PCA / trainer create device state
     os.makedirs(args.out, exist_ok=True)
     rng = numpy.random.RandomState(23455)
     aug_modes = args.aug_modes.split(',')

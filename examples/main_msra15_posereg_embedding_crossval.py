@@ -55,6 +55,9 @@ def main(argv=None):
     ap.add_argument('--out', default='./eval/msra15_posereg_embedding_cv')
     ap.add_argument('--cache', default='./cache/')
     args = ap.parse_args(argv)
+    if args.dp:
+        from hipdp import parallel
+        parallel.init_from_env()          # selects this rank's GPU: before the importers / PCA / trainer create device state
     os.makedirs(args.out, exist_ok=True)
     rng = numpy.random.RandomState(23455)
     aug_modes = ['com', 'rot', 'none']

@@ -58,6 +58,9 @@ def main(argv=None):
     ap.add_argument('--cache', default='./cache/')
     ap.add_argument('--prior-poses', type=float, default=1e6, help='augmented poses the PCA prior is fitted on')
     args = ap.parse_args(argv)
+    if args.dp:
+        from hipdp import parallel
+        parallel.init_from_env()          # selects this rank's GPU: before the importers / PCA / trainer create device state
     os.makedirs(args.out, exist_ok=True)
     rng = numpy.random.RandomState(23455)
     aug_modes = ['com', 'rot', 'none']

@@ -193,3 +193,76 @@ def test_two_gloo_ranks_on_one_gpu_gradients(tmp_path, sync):
         for s, p in enumerate(l.params):
             g = eng.store.read_grad(p)
             np.testing.assert_allclose(r0['g_%d_%d' % (i, s)], g, rtol=0, atol=2e-4 * max(np.abs(g).max(), 5e-3 * gmax), err_msg='%d %d' % (i, s))
+
+
+# ---- host logic of the data-parallel layer (no process group needed) ------------------------------------------------------------------
+def _fake_dp(world, rank):
+    from hipdp.parallel import DataParallel
+    dp = DataParallel.__new__(DataParallel)
+    dp.world, dp.rank = world, rank
+    return dp
+
+
+def test_shard_padding_modes_follow_align_data():
+    """Training arrays are completed to whole GLOBAL minibatches the way alignData completes them (/root/reference/src/trainer/
+    nettrainer.py:365-413): rows drawn by RandomState(n) with pad_random, the last row repeated without; validation arrays are cut, and
+    a validation set shorter than one global minibatch is refused instead of becoming an empty shard on every rank (NaN validation loss)."""
+    G, B, n = 2, 4, 21
+    data = np.arange(n * 3, dtype=np.float32).reshape(n, 3)
+    parts = {m: [_fake_dp(G, r).shard(data, B, **kw) for r in range(G)] for m, kw in
+             (('last', dict(pad='last')), ('random', dict(pad_rng_seed=n)), ('cut', dict()))}
+    for m, want_n in (('last', 24), ('random', 24), ('cut', 16)):
+        glob = np.empty((want_n, 3), np.float32)
+        idx = np.arange(want_n).reshape(-1, G, B)
+        for r in range(G):
+            glob[idx[:, r].reshape(-1)] = parts[m][r]
+        assert np.array_equal(glob[:min(n, want_n)], data[:min(n, want_n)])
+        if m == 'last':
+            assert np.array_equal(glob[n:], np.repeat(data[-1:], 3, axis=0))
+        if m == 'random':
+            rng = np.random.RandomState(n)
+            assert np.array_equal(glob[n:], np.stack([data[rng.randint(0, n)] for _ in range(3)]))
+    with pytest.raises(ValueError, match='fewer than one global minibatch'):
+        _fake_dp(G, 0).shard(data[:7], B, what='the validation set')
+    # the trainer picks the mode from cfgParams.pad_random
+    from trainer.nettrainer import NetTrainer
+
+    class _T(object):
+        pass
+    for pad_random, mode in ((True, 'random'), (False, 'last')):
+        t = _T()
+        t.dp, t.cfgParams = _fake_dp(G, 1), _T()
+        t.cfgParams.batch_size, t.cfgParams.pad_random = B, pad_random
+        assert np.array_equal(NetTrainer._shard_train(t, data), parts[mode][1])
+
+
+def test_default_runtime_binds_the_ranks_own_gpu(monkeypatch):
+    """Under torchrun whoever asks for the process-wide runtime first (the importers' device crops, DevicePCA, the trainer) gets one on
+    cuda:LOCAL_RANK; a trainer handed a runtime on another GPU with dp='env' refuses (every rank used to end up on cuda:0)."""
+    import torch
+    from hipdp import parallel, runtime
+    state = dict(cur=0)
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: True)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    monkeypatch.setattr(torch.cuda, 'set_device', lambda i: state.__setitem__('cur', int(i)))
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: state['cur'])
+
+    class _Rt(object):
+        def __init__(self):
+            self.device = torch.device('cuda', torch.cuda.current_device())
+    monkeypatch.setattr(runtime, 'TorchHipRuntime', _Rt)
+    monkeypatch.setattr(runtime, '_default', None)
+    monkeypatch.setenv('WORLD_SIZE', '8')
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    assert parallel.local_device_index() == 3
+    rt = runtime.default_runtime()
+    assert rt.device.index == 3 and state['cur'] == 3
+    parallel.check_runtime_device(rt)
+    stale = _Rt.__new__(_Rt)
+    stale.device = torch.device('cuda', 0)
+    with pytest.raises(RuntimeError, match='owns cuda:3'):
+        parallel.check_runtime_device(stale)
+    monkeypatch.setenv('LOCAL_RANK', '11')                 # several ranks per visible GPU wrap (two gloo ranks on one MI355X)
+    assert parallel.local_device_index() == 3
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    assert parallel.local_device_index() is None

@@ -391,3 +391,32 @@ def test_early_fc1_adam_step_equals_plain_step(backend, monkeypatch):
         state[early] = (costs, eng.store.w.get(), eng.store.m.get(), eng.store.v.get(), eng.hyper.get())
     for a, b in zip(state[True], state[False]):
         assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_engines_of_a_rebuilt_parameter_store_refuse_to_run(backend):
+    """Appending the PCA-prior layer to a trained net (what the mains do, /root/reference/src/main_nyu_posereg_embedding.py:175-190)
+    rebuilds the device parameter store: the values survive, the net evaluates through the new layer, and an engine compiled before
+    the change raises instead of computing with buffers nobody updates any more."""
+    from hipdp import runtime as R
+    from net.hiddenlayer import HiddenLayer, HiddenLayerParams
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    net, onet, P = make_net(rt, 0, 4, 32, 1, 30)
+    x = nets.synthetic_crops(np.random.RandomState(5), 4, 32, 32, np.float32)
+    net.setDeterministic()
+    emb = net.computeOutput(x)
+    old = engine.CompiledNet(net, train=False, runtime=rt)
+    assert np.array_equal(old.forward(x), emb)
+    rng = np.random.RandomState(3)
+    comp, mean = rng.normal(0, 1, (30, 42)).astype(np.float32), rng.normal(0, 1, 42).astype(np.float32)
+    prior = HiddenLayer(rng, net.layers[-1].output, HiddenLayerParams(inputDim=(4, 30), outputDim=(4, 42), activation=None), layerNum=len(net.layers))
+    prior.W.set_value(comp)
+    prior.b.set_value(mean)
+    net.layers.append(prior)
+    net.output = prior.output
+    net.cfgParams.numJoints, net.cfgParams.nDims, net.cfgParams.outputDim = 14, 3, (4, 42)
+    joints = net.computeOutput(x)
+    np.testing.assert_allclose(joints, emb.astype(np.float64) @ comp + mean, rtol=0, atol=1e-4)
+    with pytest.raises(RuntimeError, match='compile the net again'):
+        old.forward(x)

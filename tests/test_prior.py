@@ -134,3 +134,23 @@ def test_device_evaluation_equals_numpy_metrics(backend):
         for d in (0, 10, 20, 35.5, 80):
             assert dev.getNumFramesWithinMaxDist(d) == host.getNumFramesWithinMaxDist(d)
             assert dev.getNumFramesWithinMeanDist(d) == host.getNumFramesWithinMeanDist(d)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_poses_kept_on_the_device_are_ordinary_buffers(backend):
+    """sample_random_poses_device(keep_on_device=True) hands DevicePCA a device buffer; it must still download, view and feed
+    fit_transform like any other buffer (its `owner` had been replaced by a tuple)."""
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    imp = ICVLImporter('../data/ICVL/')
+    poses, com, cubes = _base(np.random.RandomState(3), 9, 16)
+    modes = ['com', 'rot', 'none']
+    host = sample_random_poses_device(imp, np.random.RandomState(7), poses, com, cubes, 400, modes, runtime=rt)
+    dev = sample_random_poses_device(imp, np.random.RandomState(7), poses, com, cubes, 400, modes, runtime=rt, keep_on_device=True)
+    assert dev.keep is not None and np.array_equal(dev.get(), host)
+    flat = dev.reshape((400, 48))
+    assert flat.keep is dev.keep and np.array_equal(flat.view(48, (48,)).get(), host[1].reshape(-1))
+    a = DevicePCA(n_components=10, runtime=rt).fit(flat)
+    b = DevicePCA(n_components=10, runtime=rt).fit(host.reshape(400, 48))
+    np.testing.assert_allclose(a.components_, b.components_, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(DevicePCA(n_components=10, runtime=rt).fit_transform(flat), b.transform(host.reshape(400, 48)), rtol=0, atol=1e-3)
