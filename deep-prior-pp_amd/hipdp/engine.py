@@ -316,6 +316,12 @@ EARLY_BUCKET_MIN = int(knob('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elemen
 #      (4.87 vs 4.71 ms per step).
 #   2: only the data gradient does, and it leaves the dX it forms in memory for the filter gradient (dpp_act.out), which
 #      then starts after it instead of beside it.
+#   3 (round 4): as 2, but only where that data gradient runs on the wave-autonomous kernel (dpp_gemm variant 4: the bottleneck
+#      ENTRIES, whose data gradient expands K = 16 / 32 / 64 channels to 4 K).  There the operand is a few registers of a kernel that
+#      is bound by its OUTPUT: alone the launch costs +1.2 .. 2 us (tools/gemm_micro.py expand: 8.8 -> 10.3 us at stage 3/4) against
+#      the 6-9 us bn_bwd_apply launch it replaces.  In the step it still loses (3.60 vs 3.50 ms): the 16 filter gradients that read
+#      the kept dX start one launch later, the gradient branch -- which ends together with the chain -- costs 0.27 instead of 0.18 ms
+#      (tools/branch_probe.py), and the chain itself measures the same (3.26 vs 3.27 ms without the branch).  Off.
 LAZY_BN_BWD = int(knob('DPP_LAZY_BN_BWD', '0'))
 BF16_DEFAULT = os.environ.get('DPP_BF16', '0') == '1'
 # ADAM of the FC1 weight (90 % of the parameters, 470 MB of optimizer traffic) inside the backward pass: its gradient is final a few
@@ -407,6 +413,25 @@ def stream16_plan(M, N, K, forward):
     if N == 64 and K == 16 and M % 64 == 0 and (STREAM16 >= 3 or (STREAM16 >= 2 and not forward)):
         return (64, 64, 4)
     return None
+
+
+# dpp_gemm variant 4 (gemm_expand_kernel): the channel-expanding 1x1 convolutions (K = 16 / 32 / 64 -> N = 64 / 128 / 256 columns: the
+# bottleneck exits, with bias + residual + statistics) and the data gradients of the reducing ones (same shapes, BatchNorm-backward
+# epilogue) as wave-autonomous 64-column strips -- no LDS, no barrier, 16-byte accesses straight from the MFMA D layout, see
+# csrc/gemm.hip.  DPP_EXPAND = 0 | 1 (forward) | 2 (data gradients) | 3 (both).  Rows per wave (= rows per statistics block) by stage.
+EXPAND = int(knob('DPP_EXPAND', '3'))
+EXPAND_RPW = tuple(int(v) for v in knob('DPP_EXPAND_RPW', '128,64,32').split(','))      # stage 1 | stage 2 | stages 3-4
+
+
+def expand_plan(M, N, K, forward):
+    if not (EXPAND & (1 if forward else 2)) or K not in (16, 32, 64) or N % 64 or N < 2 * K:
+        return None
+    rpw = EXPAND_RPW[0 if M >= 65536 else (1 if M >= 16384 else 2)]
+    while rpw > 32 and M % rpw:
+        rpw //= 2
+    if M % rpw:
+        return None
+    return (rpw, 64, 4)
 
 
 def conv3x3_bm(pixels, Co):
@@ -888,17 +913,20 @@ class CompiledNet(object):
             ks = ksplit_plan(M, Co, Ci) if (s[0] == 1 and rs is None) else None
             if ks is not None:
                 tile = ks
-            s16 = stream16_plan(M, Co, Ci, True) if (s[0] == 1 and rs is None and ks is None) else None
+            ex = expand_plan(M, Co, Ci, True) if (s[0] == 1 and rs is None and ks is None) else None
+            s16 = stream16_plan(M, Co, Ci, True) if (s[0] == 1 and rs is None and ks is None and ex is None) else None
             if s16 is not None:
                 tile = s16
+            if ex is not None:
+                tile = ex
             mp = RowMap.strided(s[0], Ho, Wo, Hi, Wi) if s[0] != 1 else None
-            variant = 1 if rs is not None else (2 if ks is not None else (3 if s16 is not None else 0))
+            variant = 1 if rs is not None else (2 if ks is not None else (4 if ex is not None else (3 if s16 is not None else 0)))
 
             def build(tile, variant, epi):
                 return ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
                                 bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=variant,
                                 name='conv1x1_%d' % layer.layerNum)
-            if variant in (2, 3) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
+            if variant in (2, 3, 4) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
                 # the shape asks for the kernel, the buffers rule it out (alignment / prologue): the generic tile, not a failed build
                 variant, (tile, _) = 0, gemm_plan(M, Co, Ci, allow_split=False)
             if want_stats:
@@ -1030,6 +1058,10 @@ class CompiledNet(object):
         # (G, x) while they stage their operand (dpp_act mode 4), which removes a launch from the dependent chain and a pass
         # over the tensor.  The finalize then also writes the two per-channel constants that prologue needs.
         lazy = LAZY_BN_BWD and not t.grad_written and not t.pending and self._produced_by_conv1x1(t)
+        if lazy and LAZY_BN_BWD == 3:
+            pl = self._producer(t)                       # conv Ci -> C; its data gradient is the GEMM  [M x C] . [C x Ci]
+            src_t = self.layer_io[id(pl)]['in_view'].base
+            lazy = pl.cfgParams.stride[0] == 1 and src_t not in self.x_ins and expand_plan(M, src_t.C, C, False) is not None
         q, p = (rt.alloc(_pad4(C)), rt.alloc(_pad4(C))) if lazy else (None, None)
         fin = dict(bn=b, q=q, p=p) if lazy else {}
         fused = getattr(vg, 'fused_reduce', None)
@@ -1059,12 +1091,17 @@ class CompiledNet(object):
             return
         self._emit_bn_bwd_apply(t, vg.grad, b, c1, c2)
 
-    def _produced_by_conv1x1(self, t):
+    def _producer(self, t):
         for l in self.layers:
             io = self.layer_io.get(id(l))
             if io is not None and io.get('out') is t:
-                return (_layer_kind(l) == 'ConvLayer' and tuple(l.cfgParams.filterDim) == (1, 1) and io.get('residual') is None)
-        return False
+                return l
+        return None
+
+    def _produced_by_conv1x1(self, t):
+        l = self._producer(t)
+        return (l is not None and _layer_kind(l) == 'ConvLayer' and tuple(l.cfgParams.filterDim) == (1, 1) and
+                self.layer_io[id(l)].get('residual') is None)
 
     def _materialise_lazy(self, t):
         """Fallback: write the lazily represented gradient of t after all (a consumer that cannot take the two-tensor operand)."""
@@ -1118,7 +1155,7 @@ class CompiledNet(object):
                 out.lazy = None
                 b = lz['bn']
                 keep = None
-                if LAZY_BN_BWD == 2:
+                if LAZY_BN_BWD >= 2:
                     if out.grad is None:
                         out.grad = rt.alloc(out.shape, zero=False)
                     keep = out.grad
@@ -1298,16 +1335,19 @@ class CompiledNet(object):
                 ks = ksplit_plan(M, Ci, Co) if (s == 1 and rs is None and dY_act is None) else None
                 if ks is not None:
                     tile = ks
-                s16 = stream16_plan(M, Ci, Co, False) if (s == 1 and rs is None and ks is None and dY_act is None) else None
+                ex = expand_plan(M, Ci, Co, False) if (s == 1 and rs is None and ks is None) else None
+                s16 = stream16_plan(M, Ci, Co, False) if (s == 1 and rs is None and ks is None and dY_act is None and ex is None) else None
                 if s16 is not None:
                     tile = s16
-                variant = 1 if (rs is not None and dY_act is None) else (2 if ks is not None else (3 if s16 is not None else 0))
+                if ex is not None:
+                    tile = ex
+                variant = 1 if (rs is not None and dY_act is None) else (2 if ks is not None else (4 if ex is not None else (3 if s16 is not None else 0)))
 
                 def build(tile, variant, epi):
                     return ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
                                     residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
                                     name='dgrad1x1_%d' % layer.layerNum)
-                if variant in (2, 3) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
+                if variant in (2, 3, 4) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
                     variant, (tile, _) = 0, gemm_plan(M, Ci, Co, allow_split=False)       # see the forward twin
                 epi = None
                 if (s == 1 and not acc and self._sole_consumer_bn_view(src)) or (acc and self._two_conv1x1_consumers(src)):

@@ -122,7 +122,7 @@ def test_resnet_forward_eval_matches_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'fc1stream', 'early_reduce', 'no_variants'])
+@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'lazy3', 'fc1stream', 'early_reduce', 'no_variants'])
 def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatch):
     """'lazy': type 0 with the opt-in plan in which the 1x1 convolutions form the gradient through a BatchNorm from (G, x) in
     their operand prologue (engine.LAZY_BN_BWD) instead of reading a tensor written by bn_bwd_apply.
@@ -131,10 +131,13 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
     (K = 1 024) only with the threshold lowered.
     'early_reduce': the filter / bias gradient partials reduced in several dpp_reduce_multi launches on the gradient branch while the
     pass runs (engine.EARLY_REDUCE_BYTES; the bs128 net flushes every 16 MB) instead of one launch at its end."""
+    if type_ == 'lazy3':
+        pass
     if type_ == 'lazy2' and backend == 'emu':
         pytest.skip("the opt-in lazy2 plan (measured slower, off by default) is exercised on the GPU tier only; 'lazy' covers the mode-4 operand here")
-    if type_ in ('lazy', 'lazy2'):       # lazy2: only the data gradient does, and leaves the tensor it forms for the filter gradient
-        monkeypatch.setattr(engine, 'LAZY_BN_BWD', 1 if type_ == 'lazy' else 2)
+    if type_ in ('lazy', 'lazy2', 'lazy3'):       # lazy2: only the data gradient does, and leaves the tensor it forms for the filter gradient
+        # (lazy3: lazy2 restricted to the data gradients that run on the wave-autonomous kernel, dpp_gemm variant 4)
+        monkeypatch.setattr(engine, 'LAZY_BN_BWD', {'lazy': 1, 'lazy2': 2, 'lazy3': 3}[type_])
         type_ = 0
     if type_ == 'early_reduce':
         monkeypatch.setattr(engine, 'EARLY_REDUCE_BYTES', 1 << 14)
@@ -154,7 +157,7 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
     net, onet, P = make_net(rt, type_, 4, 32, nJ, nD)
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
     variants = [l.keep[0].variant for _, l in eng.all_launches() if l.fn is rt.lib.dpp_gemm]
-    assert (not any(v in (2, 3) for v in variants)) if no_variants else any(v in (2, 3) for v in variants)
+    assert (not any(v in (2, 3, 4) for v in variants)) if no_variants else (any(v in (2, 3) for v in variants) and any(v == 4 for v in variants))
     if engine.LAZY_BN_BWD:
         assert any(l.name.startswith('dgrad1x1') and l.keep[0].actA.mode == 4 for l in eng.bwd.launches())
     if engine.FC1_MIN_K == 512:

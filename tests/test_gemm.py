@@ -305,6 +305,86 @@ def test_stream16_variant_against_the_tiled_kernel(backend, shape):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(64, 256, 96, 32), (64, 256, 192, 96), (32, 128, 128, 64), (16, 64, 256, 128), (16, 64, 96, 32), (64, 64, 64, 32),
+                                 (32, 192, 64, 64)])
+def test_expand_variant_fwd_and_dgrad(backend, cfg):
+    """The wave-autonomous kernel for the channel-expanding 1x1 convolutions (variant 4: a wave owns rpw rows x 64 columns x the whole
+    K, columns dealt interleaved to the accumulator tiles so that the MFMA D layout yields 16-byte accesses; no LDS, no barrier):
+    forward with BN+ReLU prologue, bias, residual (aliasing the output) and fused statistics -- merged over the wave's 32-row iterations
+    by Chan's update -- and the data gradient (B in [k][n] layout) with the fused BatchNorm-backward epilogue accumulating onto an
+    earlier share, both against float64 and against the LDS-tiled kernel."""
+    rt = get_runtime(backend)
+    K, N, M, rpw = cfg
+    rng = np.random.RandomState(44)
+    X = rng.normal(size=(M, K)).astype('float32')
+    Wk = (rng.normal(size=(N, K)) * 0.3).astype('float32')
+    mean, scale, beta = (rng.normal(size=K).astype('float32') for _ in range(3))
+    bias = rng.normal(size=N).astype('float32')
+    res = (rng.normal(size=(M, N)) + np.linspace(-3, 3, N)).astype('float32')          # column means well away from 0: the M2 merge matters
+    b = {k: rt.upload(v) for k, v in dict(X=X, Wk=Wk, mean=mean, scale=scale, beta=beta, bias=bias).items()}
+    ref = np.maximum((X.astype('f8') - mean) * scale + beta, 0) @ Wk.astype('f8').T + bias + res
+    nblk = M // rpw
+    for act_mode in (Act.BN_RELU, None):
+        Y = rt.upload(res)
+        stats = rt.alloc((nblk, 2, N), zero=False)
+        a = ops.act(act_mode, b['mean'], b['scale'], b['beta'], K) if act_mode is not None else None
+        L = ops.gemm(rt, b['X'], b['Wk'], Y, M, N, K, 1, 1, K, K, N, actA=a, bias=b['bias'], residual=Y, tile=(rpw, 64, 4), variant=4,
+                     epi=ops.epilogue(stats=stats))
+        assert ops.gemm_variant_rows(rt, L) == rpw
+        L(rt.stream)
+        gamma, mo, io, so = rt.upload(np.ones(N, 'float32')), rt.alloc(N), rt.alloc(N), rt.alloc(N)
+        ops.bn_finalize(rt, stats, nblk, M, rpw, N, gamma, 1e-4, mo, io, so)(rt.stream)
+        rt.synchronize()
+        want = ref if act_mode is not None else X.astype('f8') @ Wk.astype('f8').T + bias + res
+        _check(Y.get(), want, K, 8)
+        np.testing.assert_allclose(mo.get(), want.mean(0), rtol=0, atol=3e-6 * np.abs(want).max())
+        np.testing.assert_allclose(io.get(), 1 / np.sqrt(want.var(0) + np.float32(1e-4)), rtol=3e-5)
+    # plain (no bias / residual / statistics), rows chosen by the library
+    Y = rt.alloc((M, N), zero=False)
+    L = ops.gemm(rt, b['X'], b['Wk'], Y, M, N, K, 1, 1, K, K, N, tile=(0, 64, 4), variant=4)
+    assert ops.gemm_variant_rows(rt, L) == 32
+    L(rt.stream)
+    rt.synchronize()
+    _check(Y.get(), X.astype('f8') @ Wk.astype('f8').T, K, 8)
+    # data gradient with the fused BatchNorm-backward epilogue, on this kernel and on the LDS-tiled one
+    W2 = (rng.normal(size=(K, N)) * 0.3).astype('float32')
+    dY = rng.normal(size=(M, K)).astype('float32')
+    bnx = rng.normal(size=(M, N)).astype('float32')
+    share = rng.normal(size=(M, N)).astype('float32')
+
+    class BN(object):
+        pass
+    bnl = BN()
+    bm, bs, bb, bi = (rng.normal(0, 0.3, N).astype('float32'), rng.uniform(0.5, 1.5, N).astype('float32'), rng.normal(0, 0.3, N).astype('float32'),
+                      rng.uniform(0.5, 1.5, N).astype('float32'))
+    bnl.mean, bnl.scale, bnl.beta_buf, bnl.inv_std = rt.upload(bm), rt.upload(bs), rt.upload(bb), rt.upload(bi)
+    out = {}
+    for variant, tile, acc in ((4, (rpw, 64, 4), True), (0, (32, 64, 1), True), (4, (rpw, 64, 4), False)):
+        dH = rt.upload(share)
+        nb = M // tile[0]
+        part = rt.alloc((nb, 2, N), zero=False)
+        ops.gemm(rt, rt.upload(dY), rt.upload(W2), dH, M, N, K, 1, 0, K, N, N, residual=dH if acc else None, tile=tile, variant=variant,
+                 epi=ops.epilogue(bn=bnl, bn_x=rt.upload(bnx), bn_relu=True, bn_partial=part))(rt.stream)
+        rt.synchronize()
+        out[(variant, acc)] = (dH.get(), part.get().reshape(2, N, nb).sum(axis=2))           # [s][c][b], block index fastest
+    keep = ((bnx.astype('f8') - bm) * bs + bb) >= 0
+    xhat = (bnx.astype('f8') - bm) * bi
+    for acc in (True, False):
+        g = np.where(keep, (share.astype('f8') if acc else 0.0) + dY.astype('f8') @ W2.astype('f8'), 0.0)
+        _check(out[(4, acc)][0], g, K, 8)
+        np.testing.assert_allclose(out[(4, acc)][1][0], g.sum(0), rtol=0, atol=2e-5 * np.abs(g).sum(0).max())
+        np.testing.assert_allclose(out[(4, acc)][1][1], (g * xhat).sum(0), rtol=0, atol=2e-5 * np.abs(g * xhat).sum(0).max())
+    np.testing.assert_allclose(out[(4, True)][0], out[(0, True)][0], rtol=0, atol=1e-5 * np.abs(out[(0, True)][0]).max())
+    # what the kernel does not take is refused, and the host can ask first
+    with pytest.raises(Exception):
+        ops.gemm(rt, b['X'], b['Wk'], Y, M - 8, N, K, 1, 1, K, K, N, tile=(32, 64, 4), variant=4)(rt.stream)
+    assert ops.gemm_variant_rows(rt, ops.gemm(rt, b['X'], b['Wk'], Y, M - 8, N, K, 1, 1, K, K, N, tile=(32, 64, 4), variant=4)) == 0
+    assert ops.gemm_variant_rows(rt, ops.gemm(rt, b['X'], b['Wk'], Y, M, N, K, 1, 1, K, K, N, tile=(48, 64, 4), variant=4)) == 0
+    Xo = rt.alloc(M * K + 4, zero=False).view(1, (M, K))                                     # 4 bytes off a 16-byte boundary
+    assert ops.gemm_variant_rows(rt, ops.gemm(rt, Xo, b['Wk'], Y, M, N, K, 1, 1, K, K, N, tile=(32, 64, 4), variant=4)) == 0
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_every_gemm_instantiation_of_a_small_resnet(backend):
     """Every distinct dpp_gemm problem the train plans of a small ResNet launch (tile / split-K heuristics, strided row maps,
     BN+ReLU prologues, bias / residual / statistics epilogues), stand-alone against float64 (tests/gemm_cases.py); the

@@ -481,6 +481,59 @@ def test_gemm_operand_through_batchnorm_backward(backend, a_kc):
     np.testing.assert_allclose(out.get(), ref, rtol=0, atol=2e-5 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(64, 256, 96, 32), (32, 128, 128, 64), (16, 64, 256, 128)])
+def test_expand_kernel_operand_through_batchnorm_backward(backend, cfg):
+    """The mode-4 operand on dpp_gemm variant 4 (the data gradient of a bottleneck entry): dX = scale*G - p*(x - mean) - q formed in
+    registers, the product accumulated onto an earlier share with the BatchNorm-backward epilogue of the block input, the operand left
+    in `out` for the filter gradient -- against float64, and bit for bit against the LDS-tiled kernel's operand copy."""
+    rt = get_runtime(backend)
+    K, N, M, rpw = cfg                       # K = channels of the BatchNorm the operand goes through, N = channels of the conv input
+    rng = np.random.RandomState(78)
+    G = rng.normal(size=(M, K)).astype(np.float32)
+    X = (rng.normal(size=(M, K)) * 2 + 5).astype(np.float32)
+    mean = X.mean(0).astype(np.float32)
+    istd = (1 / np.sqrt(X.var(0) + 1e-4)).astype(np.float32)
+    scale = (rng.uniform(0.5, 1.5, K) * istd).astype(np.float32)
+    c1, c2 = rng.normal(size=K).astype(np.float32) * 0.1, rng.normal(size=K).astype(np.float32) * 0.1
+    bn = _BN()
+    bn.mean, bn.inv_std, bn.scale = rt.upload(mean), rt.upload(istd), rt.upload(scale)
+    q, p = rt.upload(scale * c1), rt.upload(scale * istd * c2)
+    Gb, Xb = rt.upload(G), rt.upload(X)
+    dX = scale.astype('f8') * (G.astype('f8') - c1 - (X.astype('f8') - mean) * istd * c2)
+    Wm = (rng.normal(size=(K, N)) * 0.3).astype(np.float32)
+    share = rng.normal(size=(M, N)).astype(np.float32)
+    bnx = rng.normal(size=(M, N)).astype(np.float32)
+    eb = _BN()
+    bm_, bs_, bb_, bi_ = (rng.normal(0, 0.3, N).astype('float32'), rng.uniform(0.5, 1.5, N).astype('float32'), rng.normal(0, 0.3, N).astype('float32'),
+                          rng.uniform(0.5, 1.5, N).astype('float32'))
+    eb.mean, eb.scale, eb.beta_buf, eb.inv_std = rt.upload(bm_), rt.upload(bs_), rt.upload(bb_), rt.upload(bi_)
+    got = {}
+    for variant, tile in ((4, (rpw, 64, 4)), (0, (32, 64, 1))):
+        copy = rt.alloc((M, K), zero=True)
+        out = rt.upload(share)
+        nb = M // tile[0]
+        part = rt.alloc((nb, 2, N), zero=False)
+        L = ops.gemm(rt, Gb, rt.upload(Wm), out, M, N, K, 1, 0, K, N, N, actA=ops.act_bn_bwd(bn, q, p, Xb, K, out=copy), residual=out, tile=tile,
+                     variant=variant, epi=ops.epilogue(bn=eb, bn_x=rt.upload(bnx), bn_relu=True, bn_partial=part))
+        if variant == 4:
+            assert ops.gemm_variant_rows(rt, L) == rpw
+        L(rt.stream)
+        rt.synchronize()
+        got[variant] = (out.get(), copy.get(), part.get().reshape(2, N, nb).sum(axis=2))
+    keep = ((bnx.astype('f8') - bm_) * bs_ + bb_) >= 0
+    ref = np.where(keep, share.astype('f8') + dX @ Wm.astype('f8'), 0.0)
+    np.testing.assert_allclose(got[4][1], dX, rtol=0, atol=2e-6 * np.abs(dX).max())
+    assert np.array_equal(got[4][1], got[0][1])                        # the same expression, operation for operation
+    np.testing.assert_allclose(got[4][0], ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+    np.testing.assert_allclose(got[4][2][0], ref.sum(0), rtol=0, atol=2e-5 * np.abs(ref).sum(0).max())
+    # without the epilogue and without a copy
+    out = rt.alloc((M, N), zero=False)
+    ops.gemm(rt, Gb, rt.upload(Wm), out, M, N, K, 1, 0, K, N, N, actA=ops.act_bn_bwd(bn, q, p, Xb, K), tile=(rpw, 64, 4), variant=4)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_allclose(out.get(), dX @ Wm.astype('f8'), rtol=0, atol=2e-5 * np.abs(ref).max())
+
+
 def _bf16(a):
     """Round-to-nearest-even to bfloat16 (returned as float64): what the bf16 kernels do to an operand when they stage it."""
     u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)

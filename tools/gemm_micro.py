@@ -51,6 +51,12 @@ def bench_gemm(M, N, K, b_kc, tile, variant, feats, label):
         a = Act(mean.ptr, scale.ptr, beta.ptr, 3, K)
         a._keep = (mean, scale, beta)
         kw['actA'] = a
+    if 'lazy' in feats or 'lazykeep' in feats:                    # the mode-4 operand: gradient through a BatchNorm formed from (G, x)
+        bn = BN()
+        bn.mean, bn.scale = rt.alloc(K), rt.alloc(K)
+        q, pp, x2 = rt.alloc(K), rt.alloc(K), rt.alloc((M, K))
+        kw['actA'] = ops.act_bn_bwd(bn, q, pp, x2, K, out=rt.alloc((M, K)) if 'lazykeep' in feats else None)
+        kw['actA']._keep2 = (bn, q, pp, x2)
     if 'bias' in feats:
         kw['bias'] = rt.alloc(N)
     if 'res' in feats:
@@ -201,7 +207,23 @@ def main_floor():
         print('bn_bwd_apply     M=%6d C=%3d                     %6.2f us  %6.0f GB/s' % (M, C, us, 12.0 * M * C / us * 1e-3))
 
 
+def main_expand():
+    """Variant 4 (gemm_expand_kernel) against the kernels the engine used before, forward (bias + residual + statistics, BN+ReLU prologue) and
+    data gradient (BatchNorm-backward epilogue) of the three expanding shapes."""
+    for label, M, N, K, tile0, rpws in (('stage3/4 64->256', 8192, 256, 64, (64, 32, 4), (32, 64)), ('stage2 32->128', 32768, 128, 32, (64, 64, 4), (32, 64, 128)),
+                                       ('stage1 16->64', 131072, 64, 16, (64, 64, 4), (64, 128, 256))):
+        for feats, b_kc in ((('act', 'bias', 'res', 'stats'), True), (('bnbwd',), False), (('bnbwd', 'res'), False), (('bnbwd', 'res', 'lazy'), False),
+                            (('bnbwd', 'res', 'lazykeep'), False)):
+            bench_gemm(M, N, K, b_kc, tile0, 0, feats, label + (' fwd' if b_kc else ' dgrad'))
+            if K == 16 and not b_kc and 'lazy' not in feats and 'lazykeep' not in feats:
+                bench_gemm(M, N, K, b_kc, (64, 64, 4), 3, feats, label + ' dgrad s16')
+            for rpw in rpws:
+                bench_gemm(M, N, K, b_kc, (rpw, 64, 4), 4, feats, label + (' fwd' if b_kc else ' dgrad'))
+
+
 def main():
+    if 'expand' in sys.argv[1:]:
+        return main_expand()
     if 'floor' in sys.argv[1:]:
         return main_floor()
     if 'conv3' in sys.argv[1:]:
