@@ -61,9 +61,8 @@ PLUMBING_ENV = ('DPP_LAUNCH_MODE', 'DPP_BF16', 'DPP_DIST_BACKEND', 'DPP_BENCH_EM
 ABLATION_ENV = ('DPP_WHATIF_SKIP',)            # drops launches from the timed plan: results are wrong on purpose
 
 
-def cpu_baseline(batch, size, budget_s=45.0):
-    """The oracle's PyTorch-CPU restatement of the identical fp32 train step, bounded sample: one warm-up
-    step, then at least 5 timed steps (more while the budget lasts, 12 at most).  The only place this script touches oracle/."""
+def _time_cpu_steps(batch, size, min_steps, max_steps, budget_s):
+    """(seconds per step over the timed steps, their median, the count) of the oracle's PyTorch-CPU train step at `batch`."""
     import torch
     from oracle import nets, torch_ref
     onet = nets.build_resnet(type=0, wIn=size, hIn=size, batchSize=batch, numJoints=1, nDims=30)
@@ -73,13 +72,137 @@ def cpu_baseline(batch, size, budget_s=45.0):
     x = torch.tensor(nets.synthetic_crops(rng, batch, size, size, np.float32))
     y = torch.tensor(rng.normal(0, 0.3, (batch, 30)).astype(np.float32))
     tr.step(x, y, 1e-3)                      # warm-up (thread pools, allocator)
-    t0, n = time.time(), 0
-    while n < 5 or (time.time() - t0 < budget_s and n < 12):
+    times = []
+    t_start = time.time()
+    while len(times) < min_steps or (time.time() - t_start < budget_s and len(times) < max_steps):
+        t0 = time.time()
         tr.step(x, y, 1e-3)
-        n += 1
-    dt = (time.time() - t0) / n
-    return dict(value=round(batch / dt, 2), unit='depth-crops/sec', cores=int(torch.get_num_threads()), kind='port',
-                sample='%d train steps of batch %d (PyTorch-CPU fp32 restatement, not Theano), %.2f s/step' % (n, batch, dt))
+        times.append(time.time() - t0)
+    return sum(times) / len(times), float(np.median(times)), len(times)
+
+
+def _augment_worker(job):
+    """One of the reference's augmentation worker processes (nettrainer.py:601-628 starts para_num_proc = 8 of them): `n` crops through
+    the oracle's NumPy restatement of NetTrainer.augmentCrop."""
+    seed, n = job
+    from oracle import augment as A
+    rng = np.random.RandomState(seed)
+    cam = A.Camera.nyu()
+    imgs, coms, cubes, Ms, gts = A.synthetic_augment_inputs(rng, 8, cam, cube=(300., 300., 300.), joints=14)
+    modes = ['com', 'rot', 'none']
+    mi, offs, rots, scs = A.draw_params(np.random.RandomState(seed + 1), n, len(modes))
+    t0 = time.perf_counter()
+    for i in range(n):
+        k = i % 8
+        A.augment_crop(imgs[k].copy(), gts[k].copy(), cam.joint3DToImg(coms[k]), cubes[k], Ms[k], modes[mi[i]], offs[i], rots[i], scs[i],
+                       cam, abs(cam.fx), abs(cam.fy))
+    return time.perf_counter() - t0
+
+
+def cpu_augment_baseline(procs, crops_per_proc=2048):
+    """The online augmentation on the host the way the reference runs it: NumPy per crop, in `procs` worker processes (started and
+    warmed before the timed region: the reference keeps its workers alive across epochs)."""
+    import multiprocessing as mp
+    if procs == 1:
+        _augment_worker((3, 8))
+        t0 = time.perf_counter()
+        _augment_worker((11, crops_per_proc))
+        dt = time.perf_counter() - t0
+    else:
+        with mp.get_context('fork').Pool(procs) as pool:
+            pool.map(_augment_worker, [(3 + k, 8) for k in range(procs)])
+            t0 = time.perf_counter()
+            pool.map(_augment_worker, [(11 + 7 * k, crops_per_proc) for k in range(procs)], chunksize=1)
+            dt = time.perf_counter() - t0
+    return dict(value=round(procs * crops_per_proc / dt, 1), unit='augmented depth-crops/sec', processes=procs, kind='port',
+                sample='%d crops per process through the NumPy restatement of augmentCrop (oracle/augment.py; modes com / rot / none, NYU '
+                       'geometry)' % crops_per_proc)
+
+
+def cpu_baseline(batch, size, budget_s=60.0):
+    """The oracle's PyTorch-CPU restatement of the identical fp32 train step on bounded samples, as legs of
+    the SAME JSON line.  PyTorch-CPU does NOT get faster with every core on these small convolutions (round 4 measured 19.8 crops/s
+    on 128 threads against 38.3 on ONE thread at batch 16), so the headline leg is the best of {all threads, 32, 16} at the benchmarked
+    batch -- chosen on one probe step each, then timed for the rest of the budget (median step) -- and the all-thread and one-thread
+    figures are reported beside it, plus the NumPy augmentation in 1 and 8 processes (the reference's para_num_proc = 8,
+    nettrainer.py:59).  The only place this script touches oracle/."""
+    import torch
+    threads = int(torch.get_num_threads())
+    extra = {}
+    try:
+        probes = {}
+        for t in sorted(set([threads, min(threads, 32), min(threads, 16)]), reverse=True):
+            torch.set_num_threads(t)
+            probes[t] = _time_cpu_steps(batch, size, 1, 1, 0.0)[0]
+        best = min(probes, key=probes.get)
+        torch.set_num_threads(best)
+        left = max(15.0, budget_s - 2.0 * sum(probes.values()))
+        mean_s, med_s, n = _time_cpu_steps(batch, size, 5, 12, left)
+        out = dict(value=round(batch / med_s, 2), unit='depth-crops/sec', cores=best, kind='port',
+                   sample='%d train steps of batch %d (PyTorch-CPU fp32 restatement, not Theano) on %d of %d threads (the fastest of %s on a '
+                          'probe step): median %.2f s/step, mean %.2f' % (n, batch, best, threads, sorted(probes), med_s, mean_s))
+        extra['cpu_baseline_all_threads'] = dict(value=round(batch / probes[threads], 2), unit='depth-crops/sec', cores=threads, kind='port',
+                                                 sample='one train step of batch %d after a warm-up step: %.2f s' % (batch, probes[threads]))
+        torch.set_num_threads(1)
+        b1 = min(16, batch)
+        mean1, med1, n1 = _time_cpu_steps(b1, size, 2, 6, 15.0)
+        extra['cpu_baseline_1thread'] = dict(value=round(b1 / med1, 3), unit='depth-crops/sec', cores=1, kind='port',
+                                             sample='%d train steps of batch %d of the same graph on ONE thread: median %.2f s/step' % (n1, b1, med1))
+    finally:
+        torch.set_num_threads(threads)
+    if size == 128:
+        extra['cpu_augment_baseline'] = [cpu_augment_baseline(1), cpu_augment_baseline(8)]
+    return out, extra
+
+
+def trainer_ms_per_minibatch(rt, B, S, epochs=4):
+    """What the reference's class API delivers on this build: PoseRegNetTrainer.train() (per-epoch re-augmentation of the resident set,
+    one train_model + cost read-back per minibatch, validation every epoch, the trainer's DEFAULT regulariser weightreg_factor = 0.001)
+    on 8 minibatches of resident crops, WITHOUT the per-epoch pickle snapshot (net.save is a no-op here: a 75 MB protocol-2 pickle is
+    0.4 s of host time that the reference pays as well)."""
+    import contextlib
+    import io
+    import tempfile
+    import torch
+    from hipdp import runtime as R
+    from net.resnet import ResNet, ResNetParams
+    from tools import synth
+    from trainer.poseregnettrainer import PoseRegNetTrainer, PoseRegNetTrainerParams
+    from util.handdetector import HandDetector
+    R.set_default_runtime(rt)
+    N, J = 8 * B, 14
+    di, imgs, coms, cubes, Ms, gts, pca_mean, pca_comp = synth.crop_db(N, S, J)
+    rng = np.random.RandomState(23455)
+
+    class Proj(object):
+        mean_, components_ = pca_mean, pca_comp
+
+        @staticmethod
+        def transform(x):
+            return (np.asarray(x, np.float64) - pca_mean) @ pca_comp.T
+
+    labels = (gts / (cubes[:, 2] / 2.)[:, None, None]).astype(np.float32)
+    embed = Proj.transform(labels.reshape(N, -1)).astype(np.float32)
+    net = ResNet(rng, cfgParams=ResNetParams(type=0, nChan=1, wIn=S, hIn=S, batchSize=B, numJoints=1, nDims=30))
+    net.save = lambda filename: None
+    p = PoseRegNetTrainerParams()
+    p.batch_size, p.learning_rate, p.force_macrobatch_reload, p.para_augment = B, 1e-3, True, True
+    p.augment_fun_params = {'fun': 'augment_poses', 'args': {'normZeroOne': False, 'di': di, 'aug_modes': ['com', 'rot', 'none'], 'proj': Proj,
+                                                             'hd': HandDetector(imgs[0].copy(), abs(di.fx), abs(di.fy), importer=di)}}
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+        tr = PoseRegNetTrainer(net, p, rng, tmp, runtime=rt)
+        tr.setData(imgs[:, None], embed, imgs[:B, None], embed[:B])
+        tr.addStaticData({'val_data_y3D': labels[:B]})
+        tr.addStaticData({'pca_data': pca_comp, 'mean_data': pca_mean})
+        tr.addManagedData({'train_data_cube': cubes, 'train_data_com': coms, 'train_data_M': Ms, 'train_gt3Dcrop': gts})
+        tr.compileFunctions()
+        tr.train(n_epochs=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        costs, _, _ = tr.train(n_epochs=epochs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return round(dt / len(costs) * 1e3, 3)
 
 
 def spawn_ranks(n):
@@ -115,6 +238,7 @@ def main():
                     help='augment the minibatch at the start of its own step on the main stream (default: the previous step does it '
                          'on the gradient-branch stream while ADAM runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-trainer', action='store_true', help="skip config.trainer_ms_per_minibatch (a short PoseRegNetTrainer.train() run)")
     ap.add_argument('--sync-bn', action='store_true', help='all-gather BatchNorm partial statistics across ranks (parity mode)')
     ap.add_argument('--launch', choices=['native', 'python', 'graph', 'graph1'], default=None,
                     help='native = the step is one C call that issues every launch on two HIP streams (default); python = one '
@@ -352,8 +476,8 @@ def main():
             # is the one measured with rocprofv3 --pmc on this workload (separate FETCH_SIZE / WRITE_SIZE passes, tools/pmc_summary.py).
             # The file records the fingerprint of the kernel sources it was measured on (`_csrc_sha16`); it is used only when that is the
             # fingerprint of the sources this run was built from -- otherwise `traffic` stays null (stale counters are not evidence).
-            pmc_family = {'gemm_mfma_f32': ('gemm_kernel', 'gemm_ksplit_kernel', 'gemm_stream16_kernel', 'gemm_rowstream_kernel', 'fc_stream_kernel',
-                                            'fc_gemm_kernel', 'wgrad_stream_kernel'),
+            pmc_family = {'gemm_mfma_f32': ('gemm_kernel', 'gemm_ksplit_kernel', 'gemm_stream16_kernel', 'gemm_expand_kernel', 'gemm_rowstream_kernel',
+                                            'fc_stream_kernel', 'fc_gemm_kernel', 'wgrad_stream_kernel', 'fc_wgrad_stream_kernel'),
                           'conv3x3_mfma_f32': ('conv3x3_kernel',), 'bn_bwd_apply': ('bn_bwd_apply_kernel',), 'adam': ('adam_kernel',)}.get(dom_name, ())
             sha = csrc_sha16()
             import glob
@@ -391,18 +515,28 @@ def main():
                                knobs=knobs or None, ablation=ablation or None, kernel_sources=csrc_sha16()),
                    roofline=roof)
         if args.dtype == 'bf16':
-            # forward error of the bf16 path against the fp32 path on the SAME (just trained) weights, deterministic mode:
-            # embedding difference pushed through the PCA prior to joints, in mm of the 300 mm cube (SURVEY.md section 8(d) cfg 5:
-            # "parity reported vs fp32, not vs the 1e-3 mm bar")
+            # forward error of the bf16 path against the fp32 path on the SAME (just trained) weights, deterministic mode (SURVEY.md
+            # section 8(d) cfg 5: "parity reported vs fp32, not vs the 1e-3 mm bar").  The number to read is RELATIVE: the embedding of
+            # this synthetic run is untrained and its PCA prior a random orthonormal basis, so "mm" obtained by pushing the difference
+            # through that prior scale with an arbitrary embedding magnitude (reported as nominal_mm for continuity with rounds 2-3 only;
+            # the physical figure is measured on a trained net by tests/test_configs.py / test_engine.py).
             xb = np.ascontiguousarray((imgs[:B] if imgs is not None else eng.x_in.buf.get()).reshape(B, 1, S, S), np.float32)
             o32 = engine.CompiledNet(net, train=False, runtime=rt, bf16=False).forward(xb)
             o16 = engine.CompiledNet(net, train=False, runtime=rt, bf16=True).forward(xb)
             dj = (o16.astype(np.float64) - o32.astype(np.float64)) @ pca_comp.astype(np.float64)
-            res['config']['bf16_forward_error_mm_vs_fp32'] = dict(max=round(float(np.abs(dj).max() * 150.0), 4),
-                                                                   mean=round(float(np.abs(dj).mean() * 150.0), 4),
-                                                                   relative_to_output=round(float(np.abs(o16 - o32).max() / max(1e-30, np.abs(o32).max())), 5))
+            d32 = o32.astype(np.float64)
+            rel_rms = float(np.sqrt(((o16 - d32) ** 2).sum() / max(1e-30, (d32 ** 2).sum())))
+            res['config']['bf16_forward_error_vs_fp32'] = dict(relative_embedding_max=round(float(np.abs(o16 - d32).max() / max(1e-30, np.abs(d32).max())), 5),
+                                                                relative_embedding_rms=round(rel_rms, 5),
+                                                                nominal_mm=dict(max=round(float(np.abs(dj).max() * 150.0), 4),
+                                                                                mean=round(float(np.abs(dj).mean() * 150.0), 4),
+                                                                                note='untrained embedding through a random orthonormal prior: not a physical error'))
+        if world == 1 and not emu and args.workload == 'train' and S == 128 and args.dtype == 'f32' and not args.no_trainer:
+            # the drop-in class API next to the engine's number (same GPU, same build, right after the timed region)
+            res['config']['trainer_ms_per_minibatch'] = trainer_ms_per_minibatch(rt, B, S)
         if world == 1 and not args.no_cpu_baseline and not emu and args.workload == 'train':
-            res['cpu_baseline'] = cpu_baseline(B, S)
+            res['cpu_baseline'], extra = cpu_baseline(B, S)
+            res.update(extra)
         print(json.dumps(res))
         sys.stdout.flush()
     if dist is not None:

@@ -161,6 +161,30 @@ class ParamStore(object):
         s = self.slots[self.by_param[param.auto_name]]
         return self._from_kernel(s, self.g.view(s['off'], (s['size'],)).get())
 
+    def bulk_values(self):
+        """{auto_name: value in the reference's layout} of every parameter from TWO device -> host copies (the flat trained and
+        non-trained buffers) instead of one round trip per parameter: what a checkpoint needs (NetBase.save)."""
+        flat = {'w': self.w.get(), 'nt': self.nt.get()}
+        out = {}
+        for s in self.slots:
+            base = flat['w' if s['trained'] else 'nt']
+            out[s['param'].auto_name] = self._from_kernel(s, base[s['off']:s['off'] + s['size']])
+        return out
+
+    def snapshot(self, into=None):
+        """Device copy of all parameters and running statistics (two device-to-device copies of the flat buffers): the epoch loop's
+        "best weights so far" (nettrainer.py:871-876 pulls every array to the host for that)."""
+        if into is None:
+            into = (self.rt.alloc(self.n_w, zero=False), self.rt.alloc(self.n_nt, zero=False))
+        self.rt.copy(into[0], self.w)
+        self.rt.copy(into[1], self.nt)
+        return into
+
+    def restore(self, snap):
+        self.check_live()
+        self.rt.copy(self.w, snap[0])
+        self.rt.copy(self.nt, snap[1])
+
     released = False
 
     def release(self):

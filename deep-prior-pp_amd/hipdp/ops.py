@@ -100,6 +100,26 @@ class NativePlan(object):
             pass
 
 
+class _OpList(list):
+    """The (op, side) list of a Plan.  Every mutation bumps `version`: a compiled plan stays valid exactly as long as the list it was
+    recorded from is untouched -- the engine splices plans in place (Plan.ops[0:0] = ..., pop / insert) -- without rebuilding a
+    400-tuple identity key on every step."""
+    version = 0
+
+    def _bump(name):
+        base = getattr(list, name)
+
+        def method(self, *a, **k):
+            self.version += 1
+            return base(self, *a, **k)
+        method.__name__ = name
+        return method
+
+    for _n in ('append', 'extend', 'insert', 'pop', 'remove', 'clear', 'sort', 'reverse', '__setitem__', '__delitem__', '__iadd__', '__imul__'):
+        locals()[_n] = _bump(_n)
+    del _n, _bump
+
+
 class Plan(object):
     """An ordered list of launches.  Every launch belongs to the main stream or (side=True) to an auxiliary stream that
     the runtime provides; Fork / Join markers order the two (event wait).  Run on a runtime, consecutive launches are
@@ -108,9 +128,19 @@ class Plan(object):
 
     def __init__(self, name=''):
         self.name = name
-        self.ops = []          # (op, side)
+        self._ops = _OpList()  # (op, side)
         self.uses_side = False
         self._compiled = None
+
+    @property
+    def ops(self):
+        return self._ops
+
+    @ops.setter
+    def ops(self, value):          # assigning a new list replaces the recording's source as well
+        new = _OpList(value)
+        new.version = self._ops.version + 1
+        self._ops = new
 
     @staticmethod
     def concat(name, plans):
@@ -141,7 +171,7 @@ class Plan(object):
     def _compile(self, rt):
         # keyed on the identity of the ops: a plan whose ops are replaced or reordered (the engine splices plans) must be re-recorded,
         # a recording freezes each launch's grid and arguments
-        key = (id(rt), LAUNCH_MODE, tuple((id(op), bool(side)) for op, side in self.ops))
+        key = (id(rt), LAUNCH_MODE, id(self._ops), self._ops.version)
         if self._compiled is not None and self._compiled[0] == key:
             return self._compiled[1]
         segs, cur = [], []

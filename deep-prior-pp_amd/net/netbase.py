@@ -222,12 +222,33 @@ class NetBase(object):
         return param.get_value()
 
     # ---- checkpoints -------------------------------------------------------------------------------------
+    def _live_store(self):
+        """The device parameter store the net's parameters are bound to (None before the first compile / after a rebuild)."""
+        store = getattr(self, '_param_store', None)
+        return store if store is not None and not store.released else None
+
+    def deviceWeightSnapshot(self, into=None):
+        """A device-resident copy of all weights and running statistics (None when the net has no device store yet): the epoch loop
+        keeps its best weights this way instead of pulling ~270 arrays to the host at every improved validation."""
+        store = self._live_store()
+        return None if store is None else (store, store.snapshot(into[1] if into is not None and into[0] is store else None))
+
+    def restoreDeviceWeightSnapshot(self, snap):
+        store, bufs = snap
+        store.restore(bufs)
+
     def save(self, filename):
         state = dict([('class', self.__class__.__name__), ('network', self.__str__())])
+        store = self._live_store()
+        bulk = store.bulk_values() if store is not None else {}      # two device -> host copies for the whole net
+
+        def value(p):
+            v = bulk.get(getattr(p, 'auto_name', None))
+            return numpy.array(p.get_value() if v is None else v)
         for layer in self.layers:
             key = '{}-values'.format(layer.layerNum)
-            state[key] = [numpy.array(p.get_value()) for p in layer.params]
-            state[key].extend([numpy.array(p.get_value()) for p in layer.params_nontrained])
+            state[key] = [value(p) for p in layer.params]
+            state[key].extend([value(p) for p in layer.params_nontrained])
         opener = gzip.open if filename.lower().endswith('.gz') else open
         with opener(filename, 'wb') as handle:
             pickle.dump(state, handle, 2)          # protocol 2 = what cPickle wrote; readable by the reference

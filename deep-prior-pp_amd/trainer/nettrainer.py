@@ -515,6 +515,7 @@ class NetTrainer(object):
         n_val_batches = self.val_data_xDB.shape[0] // self.cfgParams.batch_size
         best_validation_loss = numpy.inf
         bestParams = None
+        best_device = None             # (store, device buffers) of the best weights so far
         bestParamsEp = -1
         start_time = time.time()
         train_costs = []
@@ -591,7 +592,12 @@ class NetTrainer(object):
                     if this_validation_loss < best_validation_loss:
                         best_validation_loss = this_validation_loss
                         print("Best validation loss so far, store network weights!")
-                        bestParams = self.poseNet.weightVals
+                        # (nettrainer.py:871-876 copies every array to the host; here the copy stays on the device when it can)
+                        snap = getattr(self.poseNet, 'deviceWeightSnapshot', lambda into=None: None)(best_device)
+                        if snap is not None:
+                            best_device, bestParams = snap, None
+                        else:
+                            best_device, bestParams = None, self.poseNet.weightVals
                         bestParamsEp = self.epoch
             if self.cfgParams.post_epoch_fn is not None:
                 getattr(self, self.cfgParams.post_epoch_fn)()
@@ -599,8 +605,11 @@ class NetTrainer(object):
         end_time = time.time()
         print('Optimization complete with best validation score of %f,' % best_validation_loss)
         print('The code run for %d epochs, with %f epochs/sec' % (self.epoch, self.epoch / max(1e-9, end_time - start_time)))
-        if bestParams is not None and self.cfgParams.use_early_stopping is True:
-            self.poseNet.weightVals = bestParams
+        if (bestParams is not None or best_device is not None) and self.cfgParams.use_early_stopping is True:
+            if best_device is not None:
+                self.poseNet.restoreDeviceWeightSnapshot(best_device)
+            else:
+                self.poseNet.weightVals = bestParams
             print('Best params at epoch %d' % bestParamsEp)
         if self.cfgParams.augment_fun_params['fun'] is not None or self.cfgParams.load_fun_params['fun'] is not None:
             self.unsetDataLoading()

@@ -131,8 +131,6 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
     (K = 1 024) only with the threshold lowered.
     'early_reduce': the filter / bias gradient partials reduced in several dpp_reduce_multi launches on the gradient branch while the
     pass runs (engine.EARLY_REDUCE_BYTES; the bs128 net flushes every 16 MB) instead of one launch at its end."""
-    if type_ == 'lazy3':
-        pass
     if type_ == 'lazy2' and backend == 'emu':
         pytest.skip("the opt-in lazy2 plan (measured slower, off by default) is exercised on the GPU tier only; 'lazy' covers the mode-4 operand here")
     if type_ in ('lazy', 'lazy2', 'lazy3'):       # lazy2: only the data gradient does, and leaves the tensor it forms for the filter gradient
@@ -423,3 +421,38 @@ def test_engines_of_a_rebuilt_parameter_store_refuse_to_run(backend):
     np.testing.assert_allclose(joints, emb.astype(np.float64) @ comp + mean, rtol=0, atol=1e-4)
     with pytest.raises(RuntimeError, match='compile the net again'):
         old.forward(x)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_device_weight_snapshot_and_bulk_checkpoint_values(backend, tmp_path):
+    """The epoch loop's "best weights so far" stay on the device (NetBase.deviceWeightSnapshot / restoreDeviceWeightSnapshot: two
+    device-to-device copies instead of the reference's host copy of every array, nettrainer.py:871-876), and a checkpoint reads the
+    whole parameter store with two device -> host copies: both must give exactly what the per-parameter path gives."""
+    import pickle
+    from hipdp import runtime as R
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    net, onet, P = make_net(rt, 0, 4, 32, 1, 30)
+    assert net.deviceWeightSnapshot() is None                      # no device store before the first compile
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    rng = np.random.RandomState(7)
+    x = nets.synthetic_crops(rng, 4, 32, 32, np.float32)
+    y = rng.normal(0, 0.3, (4, 30)).astype(np.float32)
+    eng.train_step(x, y, 1e-2)
+    before = [[p.get_value() for p in l.params + l.params_nontrained] for l in net.layers]
+    snap = net.deviceWeightSnapshot()
+    net.save(str(tmp_path / 'a.pkl'))
+    saved = pickle.load(open(str(tmp_path / 'a.pkl'), 'rb'))
+    for l, vals in zip(net.layers, before):
+        if vals:
+            got = saved['%d-values' % l.layerNum]
+            assert len(got) == len(vals) and all(np.array_equal(a, b) and a.shape == b.shape and a.dtype == b.dtype for a, b in zip(got, vals))
+    eng.train_step(x, y, 1e-2)
+    moved = [[p.get_value() for p in l.params + l.params_nontrained] for l in net.layers]
+    assert any(not np.array_equal(a, b) for va, vb in zip(before, moved) for a, b in zip(va, vb))
+    snap2 = net.deviceWeightSnapshot(snap)                          # reuses the buffers of the earlier snapshot
+    assert snap2[1][0].ptr == snap[1][0].ptr
+    eng.train_step(x, y, 1e-2)
+    net.restoreDeviceWeightSnapshot(snap2)
+    after = [[p.get_value() for p in l.params + l.params_nontrained] for l in net.layers]
+    assert all(np.array_equal(a, b) for va, vb in zip(moved, after) for a, b in zip(va, vb))

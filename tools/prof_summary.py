@@ -13,6 +13,13 @@ key = "name || ' <' || (grid_x/workgroup_x) || ',' || (grid_y/workgroup_y) || ',
 rows = db.execute("select %s, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3, "
                   "max(vgpr_count), max(lds_size) from kernels group by 1 order by 3 desc" % key).fetchall()
 tot = sum(r[2] for r in rows)
+# a train step launches adam_kernel exactly once: when the trace holds it, the number of traced steps is COUNTED, not taken from the
+# command line (round 3's header said 28 steps for a trace with 29 -- warm-up, timed region and the family re-issues of bench.py)
+adam_calls = sum(r[1] for r in rows if re.search(r'\badam_kernel\b', r[0]))
+if adam_calls and not by_grid and adam_calls != steps:
+    print("# steps: %g given on the command line, %d adam_kernel launches in the trace -- using %d" % (steps, adam_calls, adam_calls))
+if adam_calls:
+    steps = float(adam_calls)
 print("rocprofv3 --kernel-trace summary: %d kernels, %d dispatches, total %.1f us (%.1f us per step over %g steps)" %
       (len(rows), sum(r[1] for r in rows), tot, tot / steps, steps))
 print("%-66s %7s %11s %9s %9s %9s %6s %5s %6s" % ('kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%', 'vgpr', 'lds'))

@@ -1,7 +1,7 @@
 # Regenerate the rocprofv3 evidence of the current round on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
 # Outputs land in gpurun_out/<round>/ and are then copied to profiles/<round>_*.
 set -x
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
