@@ -108,6 +108,18 @@ class DataParallel(object):
     def broadcast(self, buf, src=0):
         self._collective(lambda t: self.dist.broadcast(t, src=src), buf)
 
+    def all_gather_host(self, arr):
+        """[rank 0's array, rank 1's, ...] of equally shaped host arrays (test-time outputs: NetBase.computeOutput(dp=)); through the
+        device under RCCL, on the host tensors under gloo.  A collective."""
+        import numpy as np
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if self.dist.get_backend() == 'nccl':
+            t = t.to(getattr(self.rt, 'device', 'cuda'))
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t)
+        return [o.cpu().numpy() for o in outs]
+
     def mean_scalars(self, values):
         """Mean over the ranks of a few host floats (validation costs / errors of equally sized shards); a collective."""
         import torch

@@ -141,9 +141,14 @@ class NetBase(object):
             self._compiled = eng
         return eng
 
-    def computeOutput(self, inputs, timeit=False):
+    def computeOutput(self, inputs, timeit=False, dp=None):
         """Batched deterministic forward; the last batch is padded by repeating the last sample
-        (/root/reference/src/net/netbase.py:217-316)."""
+        (/root/reference/src/net/netbase.py:217-316).
+        dp (a hipdp.parallel.DataParallel; default: the one a data-parallel trainer attached to the net as `net.dp`): the test set is
+        dealt to the ranks batch by batch -- rank r evaluates batches r, r + G, r + 2G, ... on its own GPU -- and the outputs are
+        all-gathered, so every rank returns the full array ("Validation / computeOutput: shard batches,
+        all-gather outputs").  A collective: every rank has to call it with the same inputs.  The replicas hold identical weights
+        and a batch goes through the same kernels whichever rank runs it, so the result equals the single-process one bit for bit."""
         if not isinstance(inputs, list):
             inputs = [inputs]
         assert all(i.shape[0] == inputs[0].shape[0] for i in inputs[1:])
@@ -152,6 +157,9 @@ class NetBase(object):
         if not self.isDeterministic():
             print("WARNING: network is probabilistic for testing, DISABLING")
             self.setDeterministic()
+        if dp is None:
+            dp = getattr(self, 'dp', None)
+        G, rank = (dp.world, dp.rank) if dp is not None else (1, 0)
         batch_size = self.cfgParams.batch_size
         nSamp = inputs[0].shape[0]
         padSize = int(batch_size * numpy.ceil(nSamp / float(batch_size)))
@@ -161,7 +169,7 @@ class NetBase(object):
         eng = self._engine()
         n_test_batches = padSize // batch_size
         start = time.time()
-        for i in range(n_test_batches):
+        for i in range(rank, n_test_batches, G):
             chunks = []
             for x in inputs:                              # one array per network input (three for ScaleNet)
                 chunk = x[i * batch_size:(i + 1) * batch_size]
@@ -173,6 +181,15 @@ class NetBase(object):
                 chunks.append(chunk)
             o = eng.forward(chunks if len(chunks) > 1 else chunks[0])
             out[i * batch_size:(i + 1) * batch_size] = o.reshape(self.cfgParams.outputDim)
+        if G > 1:
+            # every rank sends the rows of ITS batches (padded to the same count) and places the others' by batch index
+            per = -(-n_test_batches // G)
+            mine = numpy.zeros((per * batch_size,) + tuple(outSize[1:]), dtype='float32')
+            for k, i in enumerate(range(rank, n_test_batches, G)):
+                mine[k * batch_size:(k + 1) * batch_size] = out[i * batch_size:(i + 1) * batch_size]
+            for r, rows in enumerate(dp.all_gather_host(mine)):
+                for k, i in enumerate(range(r, n_test_batches, G)):
+                    out[i * batch_size:(i + 1) * batch_size] = rows[k * batch_size:(k + 1) * batch_size]
         end = time.time()
         if timeit:
             print("{} in {}s, {}ms per frame".format(padSize, end - start, (end - start) * 1000. / padSize))

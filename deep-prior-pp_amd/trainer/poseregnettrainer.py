@@ -24,6 +24,8 @@ class PoseRegNetTrainer(NetTrainer):
     def __init__(self, poseNet=None, cfgParams=None, rng=None, subfolder='./eval/', numChunks=1, runtime=None, dp=None):
         super(PoseRegNetTrainer, self).__init__(cfgParams, 5, subfolder, numChunks, runtime=runtime, dp=dp)
         self.poseNet = poseNet
+        if self.dp is not None and poseNet is not None:
+            poseNet.dp = self.dp           # test-time computeOutput shards its batches over the ranks too (NetBase.computeOutput)
         self.rng = rng if rng is not None else self.rng
         if not isinstance(cfgParams, PoseRegNetTrainerParams):
             raise ValueError("cfgParams must be an instance of PoseRegNetTrainerParams")

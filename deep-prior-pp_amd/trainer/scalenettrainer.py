@@ -23,6 +23,8 @@ class ScaleNetTrainer(PoseRegNetTrainer):
         from trainer.nettrainer import NetTrainer
         NetTrainer.__init__(self, cfgParams, 8, subfolder, numChunks, runtime=runtime, dp=dp)         # memory factor 8, :61
         self.poseNet = poseNet
+        if self.dp is not None and poseNet is not None:
+            poseNet.dp = self.dp           # test-time computeOutput shards its batches over the ranks too (NetBase.computeOutput)
         self.rng = rng if rng is not None else self.rng
         if not isinstance(cfgParams, ScaleNetTrainerParams):
             raise ValueError("cfgParams must be an instance of ScaleNetTrainerParams")

@@ -167,6 +167,44 @@ def test_trainer_two_gloo_ranks_share_the_gpu_and_equal_one_process(tmp_path):
     _check_trainer_ranks_against_single_process(ranks, single, 2, 8, tight=2e-5)
 
 
+def _check_local_bn_sum_of_shard_gradients(r0, B, wd, backend='hip'):
+    """The FAST data-parallel mode (local BatchNorm statistics, fused-statistics kernels -- what bench.py --gpus N measures): rank r's
+    gradient is the single-process gradient of ITS shard under the global-batch cost normalisation, so the all-reduced gradient must be
+    (g(shard 0) + g(shard 1)) / G with g() from a plain single-process engine at batch B (per-shard statistics, the same fused kernels),
+    plus the weight decay 2 wd W added ONCE after the all-reduce; the global cost is the mean of the shard costs plus the regulariser."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(99)
+    x = nets.synthetic_crops(rng, 2 * B, 32, 32, np.float32)
+    y = rng.normal(0, 0.3, (2 * B, 30)).astype(np.float32)
+    shard_g, shard_cost = [], []
+    net = None
+    for r in range(2):
+        net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, wIn=32, hIn=32, batchSize=B, numJoints=1, nDims=30))
+        eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))        # fuse_bn default, no weight decay
+        cost, _ = eng.cost_and_grads(x[r * B:(r + 1) * B], y[r * B:(r + 1) * B])
+        shard_cost.append(cost)
+        shard_g.append({(i, s): eng.store.read_grad(p) for i, l in enumerate(net.layers) for s, p in enumerate(l.params)})
+    reg = sum(float((l.W.get_value().astype(np.float64) ** 2).sum()) for l in net.layers if hasattr(l, 'W'))
+    want_cost = 0.5 * (shard_cost[0] + shard_cost[1]) + wd * reg
+    assert abs(float(r0['global_cost'][0]) - want_cost) < 2e-5 * abs(want_cost), (float(r0['global_cost'][0]), want_cost)
+    gmax = max(np.abs(v).max() for v in shard_g[0].values())
+    for (i, s_), g0 in shard_g[0].items():
+        want = 0.5 * (g0.astype(np.float64) + shard_g[1][(i, s_)])
+        l = net.layers[i]
+        if hasattr(l, 'W') and s_ == 0:
+            want = want + 2.0 * wd * l.W.get_value().astype(np.float64)
+        np.testing.assert_allclose(r0['g_%d_%d' % (i, s_)], want, rtol=0, atol=2e-5 * max(np.abs(want).max(), 5e-3 * gmax), err_msg='%d %d' % (i, s_))
+
+
+def test_local_bn_allreduced_gradient_is_the_sum_of_the_shard_gradients(tmp_path):
+    """Emulator form of the check below (2 gloo ranks, local BatchNorm, batch 4 per rank)."""
+    r0, r1 = _run_ranks(tmp_path, sync=False, world=2, wd=1e-3)
+    for k in r0.files:
+        if k.startswith('g_'):
+            assert np.array_equal(r0[k], r1[k]), k
+    _check_local_bn_sum_of_shard_gradients(r0, 4, wd=1e-3, backend='emu')
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('sync', [False, True])
 def test_two_gloo_ranks_on_one_gpu_gradients(tmp_path, sync):
@@ -179,6 +217,7 @@ def test_two_gloo_ranks_on_one_gpu_gradients(tmp_path, sync):
             assert np.array_equal(r0[k], r1[k]), k
     if not sync:
         assert not np.array_equal(r0['bn_mean'], r1['bn_mean'])
+        _check_local_bn_sum_of_shard_gradients(r0, B, wd=1e-3)
         return
     rt = get_runtime('hip')
     net = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, wIn=32, hIn=32, batchSize=2 * B, numJoints=1, nDims=30))
@@ -193,6 +232,49 @@ def test_two_gloo_ranks_on_one_gpu_gradients(tmp_path, sync):
         for s, p in enumerate(l.params):
             g = eng.store.read_grad(p)
             np.testing.assert_allclose(r0['g_%d_%d' % (i, s)], g, rtol=0, atol=2e-4 * max(np.abs(g).max(), 5e-3 * gmax), err_msg='%d %d' % (i, s))
+
+
+# ---- test-time inference under data parallelism: NetBase.computeOutput(dp=) ------------------------------------------------------------
+def _run_output_ranks(tmp_path, world, **extra_env):
+    port = _free_port()
+    procs, outs = [], []
+    for r in range(world):
+        env = dict(os.environ)
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        if world > 1:
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.update(extra_env)
+        out = os.path.join(str(tmp_path), 'output_w%d_r%d.npz' % (world, r))
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_output_worker.py'), out], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        log = p.communicate(timeout=900)[0].decode()
+        assert p.returncode == 0, log[-3000:]
+    return [np.load(o) for o in outs]
+
+
+def _check_sharded_outputs(ranks, single):
+    for res in ranks:                       # every rank returns the FULL array, equal to the single-process one bit for bit
+        assert res['out'].shape == single['out'].shape == (11, 42)
+        assert np.array_equal(res['out'], single['out']) and np.array_equal(res['out_attr'], single['out'])
+        assert np.array_equal(res['few'], single['few']) and res['few'].shape == (3, 42)
+    assert np.abs(single['out']).max() > 0.01
+
+
+def test_compute_output_shards_batches_over_two_ranks(tmp_path):
+    """SURVEY.md section 8(e), "computeOutput: shard batches, all-gather outputs" (/root/reference/src/net/netbase.py:217-316 is the
+    single-device loop): 11 samples at batch 4 = 3 batches, rank 0 evaluates batches 0 and 2, rank 1 batch 1 (the last one padded by
+    repeating the last sample); 2 gloo ranks on the emulator against one process."""
+    _check_sharded_outputs(_run_output_ranks(tmp_path, 2), _run_output_ranks(tmp_path, 1)[0])
+
+
+@pytest.mark.gpu
+def test_compute_output_two_gloo_ranks_share_the_gpu(tmp_path):
+    """The same on the real kernels: two gloo ranks sharing the one MI355X against a single HIP process, bit for bit."""
+    _check_sharded_outputs(_run_output_ranks(tmp_path, 2, DPP_WORKER_BACKEND='hip-gloo', DPP_DIST_BACKEND='gloo'),
+                           _run_output_ranks(tmp_path, 1, DPP_WORKER_BACKEND='hip-gloo')[0])
 
 
 # ---- host logic of the data-parallel layer (no process group needed) ------------------------------------------------------------------
