@@ -15,7 +15,9 @@ namespace {
 
 constexpr int MAXQ = 256;   // float4 lanes per row => C <= 1024
 
-__global__ __launch_bounds__(DPP_THREADS) void bn_stats_partial_kernel(const float* __restrict__ X, int M, int C,
+// TX: element type of the activation tensor (float, or dpp_bf16 in the bf16 storage mode)
+template <class TX>
+__global__ __launch_bounds__(DPP_THREADS) void bn_stats_partial_kernel(const TX* __restrict__ X, int M, int C,
                                                                        int rpb, float* __restrict__ partial) {
     __shared__ float s_mean[DPP_THREADS * 4];
     __shared__ float s_m2[DPP_THREADS * 4];
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_stats_partial_kernel(const flo
     int n = 0;
     if (rr < RP) {
         for (int r = r_begin + rr; r < r_end; r += RP) {
-            float4 v = *reinterpret_cast<const float4*>(X + (size_t)r * C + q * 4);
+            float4 v = dpp_ld4(X + (size_t)r * C + q * 4);
             if (n == 0) K = v;
             float dx = v.x - K.x, dy = v.y - K.y, dz = v.z - K.z, dw = v.w - K.w;
             s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_eval_coeffs_kernel(const float
 
 // G = dA * [bn(x) >= 0]  (Theano's Maximum.grad passes the gradient where out == x, i.e. v >= 0) and the
 // per-block partial sums of  sum(G), sum(G * xhat)  needed by the BN backward.
-__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float* dA, const float* __restrict__ X, int M, int C,
+template <class TX>
+__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float* dA, const TX* __restrict__ X, int M, int C,
                                                                     const float* __restrict__ mean, const float* __restrict__ inv_std,
                                                                     const float* __restrict__ scale, const float* __restrict__ beta,
                                                                     int relu, float* G, int rpb, float* __restrict__ partial) {
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float*
         const float4 be = *reinterpret_cast<const float4*>(beta + q * 4);
         for (int r = r_begin + rr; r < r_end; r += RP) {
             size_t o = (size_t)r * C + q * 4;
-            float4 x = *reinterpret_cast<const float4*>(X + o);
+            float4 x = dpp_ld4(X + o);
             float4 g = *reinterpret_cast<const float4*>(dA + o);
             float dx = x.x - mu.x, dy = x.y - mu.y, dz = x.z - mu.z, dw = x.w - mu.w;
             if (relu) {
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const floa
 // dX = scale * (G - c1 - xhat * c2) (+ add): gradient through the batch statistics.  Row-chunked like the reductions so
 // that the column sums of dX -- the bias gradient of the conv that produced X (T.grad of `+ b.dimshuffle`,
 // convlayer.py:238) -- can be emitted as per-block partials in the same pass (colsum != nullptr).
-__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ X,
+template <class TX>
+__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ G, const TX* __restrict__ X,
                                                                    int M, int C, const float* __restrict__ mean,
                                                                    const float* __restrict__ inv_std, const float* __restrict__ scale,
                                                                    const float* __restrict__ c1, const float* __restrict__ c2,
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const float* 
             for (int u = 0; u < 4; ++u) {
                 const size_t i = (size_t)(r + u * RP) * Q + q;
                 g[u] = reinterpret_cast<const float4*>(G)[i];
-                x[u] = reinterpret_cast<const float4*>(X)[i];
+                x[u] = dpp_ld4(X + 4 * i);
                 o[u] = add ? reinterpret_cast<const float4*>(add)[i] : zero4;
             }
 #pragma unroll
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const float* 
         for (; r < r_end; r += RP) {
             const size_t i = (size_t)r * Q + q;
             const float4 g = reinterpret_cast<const float4*>(G)[i];
-            const float4 x = reinterpret_cast<const float4*>(X)[i];
+            const float4 x = dpp_ld4(X + 4 * i);
             const float4 o = one(g, x, add ? reinterpret_cast<const float4*>(add)[i] : zero4);
             reinterpret_cast<float4*>(dX)[i] = o;
             sa.x += o.x; sa.y += o.y; sa.z += o.z; sa.w += o.w;
@@ -366,11 +370,14 @@ bool ok_c(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= MAXQ && (DPP_THR
 
 }  // namespace
 
-extern "C" int dpp_bn_stats_partial(const float* X, int M, int C, int rows_per_block, float* partial, dpp_stream_t stream) {
-    if (!X || !partial || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS) return DPP_E_BADARG;
+extern "C" int dpp_bn_stats_partial(const float* X, int M, int C, int rows_per_block, float* partial, int store, dpp_stream_t stream) {
+    if (!X || !partial || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS || (store & ~DPP_ST_A)) return DPP_E_BADARG;
     int nb = dpp_cdiv(M, rows_per_block);
-    DPP_LAUNCH(bn_stats_partial_kernel, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), X, M, C,
-                       rows_per_block, partial);
+    if (store & DPP_ST_A)
+        DPP_LAUNCH(bn_stats_partial_kernel<dpp_bf16>, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+                   reinterpret_cast<const dpp_bf16*>(X), M, C, rows_per_block, partial);
+    else
+        DPP_LAUNCH(bn_stats_partial_kernel<float>, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), X, M, C, rows_per_block, partial);
     return dpp_launch_status();
 }
 
@@ -399,11 +406,15 @@ extern "C" int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, con
 
 extern "C" int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, const float* mean, const float* inv_std,
                                  const float* scale, const float* beta, int relu, float* G, int rows_per_block, float* partial,
-                                 dpp_stream_t stream) {
-    if (!dA || !X || !G || !partial || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS) return DPP_E_BADARG;
+                                 int store, dpp_stream_t stream) {
+    if (!dA || !X || !G || !partial || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS || (store & ~DPP_ST_BNX)) return DPP_E_BADARG;
     int nb = dpp_cdiv(M, rows_per_block);
-    DPP_LAUNCH(bn_bwd_reduce_kernel, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dA, X, M, C, mean,
-                       inv_std, scale, beta, relu, G, rows_per_block, partial);
+    if (store & DPP_ST_BNX)
+        DPP_LAUNCH(bn_bwd_reduce_kernel<dpp_bf16>, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dA,
+                   reinterpret_cast<const dpp_bf16*>(X), M, C, mean, inv_std, scale, beta, relu, G, rows_per_block, partial);
+    else
+        DPP_LAUNCH(bn_bwd_reduce_kernel<float>, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dA, X, M, C, mean,
+                   inv_std, scale, beta, relu, G, rows_per_block, partial);
     return dpp_launch_status();
 }
 
@@ -421,9 +432,13 @@ extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M
 
 extern "C" int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
                                 const float* scale, const float* c1, const float* c2, const float* add, float* dX,
-                                int rows_per_block, float* colsum_partial, dpp_stream_t stream) {
-    if (!G || !X || !dX || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS) return DPP_E_BADARG;
-    DPP_LAUNCH(bn_bwd_apply_kernel, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), G, X,
-                       M, C, mean, inv_std, scale, c1, c2, add, dX, rows_per_block, colsum_partial);
+                                int rows_per_block, float* colsum_partial, int store, dpp_stream_t stream) {
+    if (!G || !X || !dX || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS || (store & ~DPP_ST_BNX)) return DPP_E_BADARG;
+    if (store & DPP_ST_BNX)
+        DPP_LAUNCH(bn_bwd_apply_kernel<dpp_bf16>, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), G,
+                   reinterpret_cast<const dpp_bf16*>(X), M, C, mean, inv_std, scale, c1, c2, add, dX, rows_per_block, colsum_partial);
+    else
+        DPP_LAUNCH(bn_bwd_apply_kernel<float>, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), G, X,
+                   M, C, mean, inv_std, scale, c1, c2, add, dX, rows_per_block, colsum_partial);
     return dpp_launch_status();
 }

@@ -43,6 +43,7 @@ struct Conv3Args {
     const float* residual;
     float* Y;             // [N][H][W][Co]
     dpp_epilogue epi;     // fused BatchNorm statistics / BatchNorm-backward epilogue
+    int store;            // DPP_ST_* mask: X (A), Y + residual (C), epi.bn_x (BNX) hold bf16 elements
     int lth, ltw;         // log2 of tile height / width
     int img;              // images per workgroup
     int tiles_x, tiles_y;
@@ -80,8 +81,9 @@ __device__ __forceinline__ void tile_origin(const Conv3Args& a, int bid, int& n0
 // Stage the activated input halo of the tile into LDS: Ah[(img*(TH+2)+hy)*(TW+2)+hx][KP+pad] (KP >= Ci: channels Ci..KP-1 zero).
 // A thread owns ONE channel quad (its BatchNorm coefficients are loaded once) and walks halo positions; the loads of up to 8
 // positions are issued before the first is used, so the usual tile (<= 8 slots per thread) costs one memory round trip.
-template <int UB, class E>
-__device__ __forceinline__ void stage_halo(const float* __restrict__ X, int N, int H, int W, int Ci, const dpp_act& act, int n0,
+// TX: element type of X in memory (float, or dpp_bf16 in the bf16 storage mode: 8-byte loads, widened exactly).
+template <int UB, class E, class TX>
+__device__ __forceinline__ void stage_halo(const TX* __restrict__ X, int N, int H, int W, int Ci, const dpp_act& act, int n0,
                                            int y0, int x0, int TH, int TW, int IMG, E* Ah, int LDA, int KP, const C3Stage& sg) {
     if (KP < Ci) KP = Ci;
     const int HW2 = (TH + 2) * (TW + 2), TW2 = TW + 2;
@@ -107,7 +109,7 @@ __device__ __forceinline__ void stage_halo(const float* __restrict__ X, int N, i
             const int n = n0 + im, y = y0 + hy - 1, x = x0 + hx - 1;
             in[u] = hp < HP && cld && n < N && y >= 0 && y < H && x >= 0 && x < W;
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in[u]) v[u] = *reinterpret_cast<const float4*>(X + (((size_t)n * H + y) * W + x) * Ci + c0);
+            if (in[u]) v[u] = dpp_ld4(X + (((size_t)n * H + y) * W + x) * Ci + c0);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -127,7 +129,7 @@ __device__ __forceinline__ void stage_halo(const float* __restrict__ X, int N, i
     }
 }
 
-template <int BM, int BN, int PREC = 0>
+template <int BM, int BN, int PREC = 0, class TX = float>
 __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     dpp_kernarg_warm<sizeof(Conv3Args)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
@@ -151,9 +153,9 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     if (a.wide) wco.load<BN>(col0, a.Co, a.bias, a.epi, a.Y);
     // halo slots per thread: 3 for the 16- and 32-channel layers, 7 for the 64-channel ones; unrolling 8 for 3 wastes 5 slots of index arithmetic
     if (((HP + (DPP_THREADS >> a.sg.lqp) - 1) >> (8 - a.sg.lqp)) <= 4)
-        stage_halo<4>(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP, a.sg);
+        stage_halo<4>(reinterpret_cast<const TX*>(a.X), a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP, a.sg);
     else
-        stage_halo<8>(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP, a.sg);
+        stage_halo<8>(reinterpret_cast<const TX*>(a.X), a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, KP, a.sg);
     dpp_stamp(a.prof, 1);
 
     // halo index of this lane's A rows (centre tap)
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
             const int n = n0 + im, y = y0 + ty, x = x0 + tx;
             const bool ok = !(im >= a.img || n >= a.N || y >= a.H || x >= a.W);
             return ok ? (long)((((size_t)n * a.H + y) * a.W + x) * a.Co) : -1L;
-        });
+        }, 0, a.store);
         dpp_stamp(a.prof, 4);
         return;
     }
@@ -438,7 +440,7 @@ struct Wgrad3Args {
     int lqy;              // log2 of the power-of-two quad group of the dY rows (>= Co/4 quads per row)
 };
 
-template <int BM, int MAXACC>
+template <int BM, int MAXACC, class TX = float>
 __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a) {
     dpp_kernarg_warm<sizeof(Wgrad3Args)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a
         int n0, y0, x0;
         tile_origin(ta, tile_id, n0, y0, x0);
         __syncthreads();               // previous tile's fragments are consumed before LDS is overwritten
-        stage_halo<4>(a.X, a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, Ci, a.sg);
+        stage_halo<4>(reinterpret_cast<const TX*>(a.X), a.N, a.H, a.W, Ci, a.act, n0, y0, x0, TH, TW, a.img, Ah, LDA, Ci, a.sg);
         {   // stage dY rows of the tile (zeros for out-of-range rows): a thread owns one channel quad and walks rows
             const int c0 = (tid & ((1 << a.lqy) - 1)) * 4, rstep = DPP_THREADS >> a.lqy;
             if (c0 < Co) {
@@ -566,16 +568,18 @@ extern "C" int dpp_conv3x3_tiling(int N, int H, int W, int bm, int* th, int* tw,
 }
 
 static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
-                          const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, int precision,
+                          const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, int precision, int store,
                           dpp_stream_t stream) {
     if (!X || !Wk || !Y || N < 1 || H < 1 || W < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15)) return DPP_E_BADARG;
+    if (store & ~(DPP_ST_A | DPP_ST_C | DPP_ST_BNX)) return DPP_E_BADARG;
     Conv3Args a;
+    a.store = store;
     a.X = X; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
     a.prof = dpp_prof_buffer;
     if (act && (act->mode & 4)) return DPP_E_UNSUPPORTED;       // the two-tensor BatchNorm-backward operand is a dpp_gemm feature
     if (act) a.act = *act; else { a.act.mode = 0; a.act.cmod = 1; a.act.mean = a.act.scale = a.act.beta = nullptr; }
     a.Wk = Wk; a.bias = bias; a.residual = residual; a.Y = Y;
-    if (epi) a.epi = *epi; else { a.epi.stats = nullptr; a.epi.bn_x = nullptr; a.epi.bn_partial = nullptr; }
+    if (epi) a.epi = *epi; else a.epi = dpp_epilogue{};      // (all pointers null: the alignment test of the wide epilogue below reads every one)
     if (a.epi.bn_x && !(a.epi.bn_mean && a.epi.bn_inv_std && a.epi.bn_scale && a.epi.bn_beta && a.epi.bn_partial)) return DPP_E_BADARG;
     long pixels = (long)N * H * W;
     if (bm == 0) bm = (pixels / 128) * dpp_cdiv(Co, 64) >= 512 ? 128 : 64;
@@ -601,31 +605,33 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     a.wide = wide_ok && al16(Y) && al16(residual) && al16(a.epi.bn_x) && al16(bias) && al16(a.epi.bn_mean) && al16(a.epi.bn_scale) &&
              al16(a.epi.bn_beta) && al16(a.epi.bn_inv_std);
+    if ((store & (DPP_ST_C | DPP_ST_BNX)) && !a.wide) return DPP_E_UNSUPPORTED;      // bf16-stored tensors go through the 16-byte epilogue only
     size_t need = a.wide ? ((size_t)bm * (bn + 4) + 16 * bn) * sizeof(float) : (size_t)4 * bn * sizeof(float);
     if (lds < need) lds = need;
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, dpp_cdiv(Co, bn));
     hipStream_t st = static_cast<hipStream_t>(stream);
     // gfx950 has 160 KiB of LDS per CU; requests above the default 64 KiB window need the opt-in attribute
+#define DPP_C3K(BM_, BN_, P_, T_) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_, P_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        DPP_LAUNCH((conv3x3_kernel<BM_, BN_, P_, T_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
 #define DPP_C3(BM_, BN_) if (bm == BM_ && bn == BN_) { \
-        if (precision) { \
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            DPP_LAUNCH((conv3x3_kernel<BM_, BN_, 1>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        DPP_LAUNCH((conv3x3_kernel<BM_, BN_, 0>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
+        if (precision) { if (store & DPP_ST_A) DPP_C3K(BM_, BN_, 1, dpp_bf16); else DPP_C3K(BM_, BN_, 1, float); } \
+        if (store & DPP_ST_A) DPP_C3K(BM_, BN_, 0, dpp_bf16); else DPP_C3K(BM_, BN_, 0, float); }
     DPP_C3(128, 64) DPP_C3(128, 32) DPP_C3(128, 16) DPP_C3(64, 64) DPP_C3(64, 32) DPP_C3(64, 16)
 #undef DPP_C3
+#undef DPP_C3K
     return DPP_E_UNSUPPORTED;
 }
 
 extern "C" int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
-                           const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream) {
-    return conv3x3_launch(X, N, H, W, Ci, act, Wk, Co, bias, residual, Y, bm, epi, 0, stream);
+                           const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, int store, dpp_stream_t stream) {
+    return conv3x3_launch(X, N, H, W, Ci, act, Wk, Co, bias, residual, Y, bm, epi, 0, store, stream);
 }
 
 extern "C" int dpp_conv3x3_bf16(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
-                                const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream) {
-    return conv3x3_launch(X, N, H, W, Ci, act, Wk, Co, bias, residual, Y, bm, epi, 1, stream);
+                                const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, int store, dpp_stream_t stream) {
+    return conv3x3_launch(X, N, H, W, Ci, act, Wk, Co, bias, residual, Y, bm, epi, 1, store, stream);
 }
 
 extern "C" int dpp_conv3x3_wtrans(const float* Wk, int Co, int Ci, float* Wd, dpp_stream_t stream) {
@@ -669,8 +675,8 @@ extern "C" int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int Ci, int Co, int
 }
 
 extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
-                                 float* partial, int bm, dpp_stream_t stream) {
-    if (!X || !dY || !partial || N < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15) || (bm != 64 && bm != 128)) return DPP_E_BADARG;
+                                 float* partial, int bm, int store, dpp_stream_t stream) {
+    if (!X || !dY || !partial || N < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15) || (bm != 64 && bm != 128) || (store & ~DPP_ST_A)) return DPP_E_BADARG;
     Wgrad3Args a;
     a.X = X; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.dY = dY; a.partial = partial;
     if (act && (act->mode & 4)) return DPP_E_UNSUPPORTED;       // the two-tensor BatchNorm-backward operand is a dpp_gemm feature
@@ -693,9 +699,10 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, 9 / taps_pb);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<BM_, MA_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        DPP_LAUNCH((conv3x3_wgrad_kernel<BM_, MA_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); }
+#define DPP_W3K(BM_, MA_, T_) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<BM_, MA_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        DPP_LAUNCH((conv3x3_wgrad_kernel<BM_, MA_, T_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
+#define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { if (store & DPP_ST_A) DPP_W3K(BM_, MA_, dpp_bf16); else DPP_W3K(BM_, MA_, float); }
     DPP_W3(128, 3) DPP_W3(128, 4) DPP_W3(128, 9) DPP_W3(128, 12) DPP_W3(128, 16)
     DPP_W3(64, 3) DPP_W3(64, 4) DPP_W3(64, 9) DPP_W3(64, 12) DPP_W3(64, 16)
 #undef DPP_W3

@@ -6,6 +6,50 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- bf16 STORAGE of activation tensors (BASELINE config 5, include/dpp_hip.h DPP_ST_*) ---------------------------------------------
+// The [pixels][channels] tensors the convolutions write may be held as bfloat16 (round-to-nearest-even of the f32 value the epilogue
+// formed; BatchNorm statistics still come from the f32 values): half the bytes on every pass over them.  Kernels address such a
+// tensor with the SAME element offsets as an f32 one and go through dpp_ld4 / dpp_st4: four consecutive elements as 16 (f32) or 8
+// (bf16) bytes.
+typedef __bf16 dpp_bf16;
+typedef __bf16 dpp_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 dpp_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <class T> __device__ __forceinline__ float4 dpp_ld4(const T* p);
+template <> __device__ __forceinline__ float4 dpp_ld4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <> __device__ __forceinline__ float4 dpp_ld4<dpp_bf16>(const dpp_bf16* p) {
+    const dpp_bf16x4 v = *reinterpret_cast<const dpp_bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+template <class T> __device__ __forceinline__ float dpp_ld1(const T* p) { return (float)p[0]; }
+template <class T> __device__ __forceinline__ void dpp_st4(T* p, float4 v);
+template <> __device__ __forceinline__ void dpp_st4<float>(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+template <> __device__ __forceinline__ void dpp_st4<dpp_bf16>(dpp_bf16* p, float4 v) {
+    dpp_bf16x4 o;
+    o[0] = (dpp_bf16)v.x; o[1] = (dpp_bf16)v.y; o[2] = (dpp_bf16)v.z; o[3] = (dpp_bf16)v.w;
+    *reinterpret_cast<dpp_bf16x4*>(p) = o;
+}
+// the value a bf16 store leaves behind, as f32 (what every later reader sees)
+__device__ __forceinline__ float dpp_bf16_round(float v) { return (float)(dpp_bf16)v; }
+// Raw / widen pair for software-pipelined operand staging: the 8-byte load of four bf16 elements lands in .x / .y of a float4 register
+// set UNCONVERTED (a conversion at the load would make the wave wait for the data right where the load was issued), and is widened
+// when the chunk is committed to LDS.  Element 0 sits in the low half of .x (little endian).
+__device__ __forceinline__ float4 dpp_raw8(const void* p) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(t.x), __uint_as_float(t.y), 0.0f, 0.0f);
+}
+__device__ __forceinline__ float4 dpp_widen4(const float4& raw) {
+    const unsigned x = __float_as_uint(raw.x), y = __float_as_uint(raw.y);
+    return make_float4(__uint_as_float(x << 16), __uint_as_float(x & 0xffff0000u), __uint_as_float(y << 16), __uint_as_float(y & 0xffff0000u));
+}
+// run-time typed forms for the epilogues (one uniform branch per access; not for inner loops): `p` addresses f32 or bf16 elements
+__device__ __forceinline__ float4 dpp_ld4_rt(const float* p, size_t off, bool b16) {
+    return b16 ? dpp_ld4(reinterpret_cast<const dpp_bf16*>(p) + off) : dpp_ld4(p + off);
+}
+__device__ __forceinline__ float dpp_ld1_rt(const float* p, size_t off, bool b16) {
+    return b16 ? (float)reinterpret_cast<const dpp_bf16*>(p)[off] : p[off];
+}
+
 #define DPP_WAVE 64
 #define DPP_THREADS 256
 
@@ -259,10 +303,13 @@ struct dpp_wide_coef {
 // NIMG > 1 (the K-split kernel): the tile is the sum of NIMG images -- every wave holds a partial sum of the WHOLE tile over its K
 // slice (WM = WN = 1) and drops it into image `img`; the images are added in a fixed order when the tile is read back.  `smem` must
 // then hold NIMG*BM*(BN+4) + 16*BN floats.
+// `store` (DPP_ST_C: C and residual, DPP_ST_BNX: bn_x) marks the tensors held as bf16: the value written is rounded on the store, the
+// statistics are formed from the UNROUNDED f32 values (see oracle/torch_ref.py: stats of v, normalisation of round(v)).
 template <int RM, int CN, int WM, int WN, int BM, int BN, int NIMG = 1, class RowOff>
 __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* smem, int col0, int N, dpp_wide_coef& co,
                                                   const float* residual, float* C, const dpp_epilogue& ep, int nvalid, int wm,
-                                                  int wn, int l15, int kq, RowOff rowoff, int img = 0) {
+                                                  int wn, int l15, int kq, RowOff rowoff, int img = 0, int store = 0) {
+    const bool c16 = (store & DPP_ST_C) != 0, x16 = (store & DPP_ST_BNX) != 0;
     co.finish();
     constexpr int LDT = BN + 4;
     constexpr int Q = BN / 4;                                // column quads per tile row
@@ -306,11 +353,11 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
             v[0] = t.x + co.cbias[0]; v[1] = t.y + co.cbias[1]; v[2] = t.z + co.cbias[2]; v[3] = t.w + co.cbias[3];
             const size_t o = (size_t)ro + col;
             if (residual) {
-                const float4 rr = *reinterpret_cast<const float4*>(residual + o);
+                const float4 rr = dpp_ld4_rt(residual, o, c16);
                 v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
             }
             if (bn) {
-                const float4 xx = *reinterpret_cast<const float4*>(ep.bn_x + o);
+                const float4 xx = dpp_ld4_rt(ep.bn_x, o, x16);
                 const float x[4] = {xx.x, xx.y, xx.z, xx.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -320,7 +367,8 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
                     sy[j] += v[j] * (dx * co.cistd[j]);
                 }
             }
-            *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
+            if (c16) dpp_st4(reinterpret_cast<dpp_bf16*>(C) + o, make_float4(v[0], v[1], v[2], v[3]));
+            else *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
         }
         valid[it] = ro >= 0;
 #pragma unroll

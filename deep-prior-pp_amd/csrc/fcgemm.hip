@@ -41,7 +41,17 @@ struct FcArgs {
     int Kper;
 };
 
-__device__ __forceinline__ float4 fc_load4(const float* p, int idx0, int limit, bool vec) {
+__device__ __forceinline__ float4 fc_load4(const float* p, int idx0, int limit, bool vec, bool b16 = false) {
+    if (b16) {                                   // `p` addresses bf16 elements (DPP_ST_A: the flattened activation map)
+        const dpp_bf16* q = reinterpret_cast<const dpp_bf16*>(p);
+        if (vec && idx0 + 3 < limit) return dpp_ld4(q);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx0 + 0 < limit) v.x = (float)q[0];
+        if (idx0 + 1 < limit) v.y = (float)q[1];
+        if (idx0 + 2 < limit) v.z = (float)q[2];
+        if (idx0 + 3 < limit) v.w = (float)q[3];
+        return v;
+    }
     if (vec && idx0 + 3 < limit) return *reinterpret_cast<const float4*>(p);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx0 + 0 < limit) v.x = p[0];
@@ -86,8 +96,9 @@ struct Stage {
 
     // base: operand pointer; ld: leading dimension; map: row map of the NON-contiguous index; r0: first row (m / n) of the tile;
     // rlim: number of rows of the problem; kc .. k_end: the chunk; act: prologue (channel = contiguous index % cmod)
+    // sh = 1: the operand's elements are bf16 (whole-quad geometry: every element offset is a multiple of 4 and is halved on the cursor)
     __device__ __forceinline__ void fetch(const float* base, int ld, const dpp_rowmap& map, int r0, int rlim, int kc, int k_end,
-                                          const dpp_act& act, bool vec) {
+                                          const dpp_act& act, bool vec, int sh = 0) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
@@ -98,10 +109,10 @@ struct Stage {
             if (KCONT) {
                 const int row = r0 + slot / (KC / EPT), k = kc + (slot % (KC / EPT)) * EPT;
                 if (row < rlim) {
-                    const float* p = base + (size_t)dpp_map_row(map, row) * ld + k;
+                    const float* p = base + (((size_t)dpp_map_row(map, row) * ld + k) >> sh);
 #pragma unroll
                     for (int j = 0; j < NLD; ++j)
-                        if (k + 4 * j < k_end) r[s][j] = fc_act4(fc_load4(p + 4 * j, k + 4 * j, k_end, vec), act, k + 4 * j, k_end);
+                        if (k + 4 * j < k_end) r[s][j] = fc_act4(fc_load4(p + ((4 * j) >> sh), k + 4 * j, k_end, vec, sh != 0), act, k + 4 * j, k_end);
                 }
             } else {
                 const int q = slot % (ROWS / 4), kr = slot / (ROWS / 4);
@@ -110,7 +121,7 @@ struct Stage {
 #pragma unroll
                     for (int j = 0; j < NLD; ++j)
                         if (k + j < k_end)
-                            r[s][j] = fc_act4(fc_load4(base + (size_t)dpp_map_row(map, k + j) * ld + row, row, rlim, vec), act, row, rlim);
+                            r[s][j] = fc_act4(fc_load4(base + (((size_t)dpp_map_row(map, k + j) * ld + row) >> sh), row, rlim, vec, sh != 0), act, row, rlim);
                 }
             }
         }
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_gemm_kernel(FcArgs ga) {
     const dpp_rowmap ident = {1, 0, 0, 0, 0};
     auto fetch = [&](int c) __attribute__((always_inline)) {
         const int kc = k_begin + c * KC;
-        sa.fetch(d.A, d.lda, d.mapA, row0, M, kc, k_end, d.actA, ga.vecA);
+        sa.fetch(d.A, d.lda, d.mapA, row0, M, kc, k_end, d.actA, ga.vecA, (d.store & DPP_ST_A) ? 1 : 0);
         sb.fetch(d.B, d.ldb, BKC ? ident : d.mapB, col0, N, kc, k_end, d.actB, ga.vecB);
     };
     if (nchunks > 0) fetch(0);
@@ -298,6 +309,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void fc_stream_
     // 16-byte LDS store per slot.  MN-contiguous operand [k][R]: thread (kg = tid / (R/4), cq = tid % (R/4)) loads the four k-rows
     // 4kg .. 4kg+3 of column quad cq and stores four k-runs (one per column): the transposition happens in registers.
     constexpr int SA = AKC ? BM / 32 : 4, SB = BKC ? BN / 32 : 4;
+    const int shA = (d.store & DPP_ST_A) ? 1 : 0;            // bf16-stored operand A (the flattened activation map): halved cursors, 8-byte loads
     const float* pa[SA];
     const float* pb[SB];
     int la, lb;                                   // LDS offset of slot 0 (floats)
@@ -305,12 +317,12 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void fc_stream_
     if (AKC) {
         const int r = tid >> 3, quad = (tid & 7) * 4;
 #pragma unroll
-        for (int s = 0; s < SA; ++s) pa[s] = d.A + (size_t)(row0 + r + 32 * s) * d.lda + k_begin + quad;
+        for (int s = 0; s < SA; ++s) pa[s] = d.A + (((size_t)(row0 + r + 32 * s) * d.lda + k_begin + quad) >> shA);
         la = r * LD + quad;
     } else {
         const int cq = tid % (BM / 4), kg = tid / (BM / 4);
 #pragma unroll
-        for (int s = 0; s < SA; ++s) pa[s] = d.A + (size_t)(k_begin + 4 * kg + s) * d.lda + row0 + 4 * cq;
+        for (int s = 0; s < SA; ++s) pa[s] = d.A + (((size_t)(k_begin + 4 * kg + s) * d.lda + row0 + 4 * cq) >> shA);
         la = (4 * cq) * LD + 4 * kg;
     }
     if (BKC) {
@@ -351,8 +363,13 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void fc_stream_
             cidx += KC;
             if (cidx >= d.actA.cmod) cidx -= d.actA.cmod;
         }
+        if (shA) {
 #pragma unroll
-        for (int s = 0; s < SA; ++s) ra[s] = *reinterpret_cast<const float4*>(pa[s] + c * stepA);
+            for (int s = 0; s < SA; ++s) ra[s] = dpp_raw8(pa[s] + ((c * stepA) >> 1));
+        } else {
+#pragma unroll
+            for (int s = 0; s < SA; ++s) ra[s] = *reinterpret_cast<const float4*>(pa[s] + c * stepA);
+        }
         if (BKC || bvalid) {
 #pragma unroll
             for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const f32x4*>(pb[s] + c * stepB);
@@ -372,13 +389,14 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void fc_stream_
         if constexpr (AKC) {
 #pragma unroll
             for (int s = 0; s < SA; ++s) {
-                const float4 v = modeA ? act(ra[s]) : ra[s];
+                const float4 w = shA ? dpp_widen4(ra[s]) : ra[s];
+                const float4 v = modeA ? act(w) : w;
                 put4(&As[la + 32 * s * LD], v.x, v.y, v.z, v.w);
             }
         } else {
             float4 v[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) v[s] = modeA ? act(ra[s]) : ra[s];
+            for (int s = 0; s < 4; ++s) { const float4 w = shA ? dpp_widen4(ra[s]) : ra[s]; v[s] = modeA ? act(w) : w; }
             put4(&As[la + 0 * LD], v[0].x, v[1].x, v[2].x, v[3].x);
             put4(&As[la + 1 * LD], v[0].y, v[1].y, v[2].y, v[3].y);
             put4(&As[la + 2 * LD], v[0].z, v[1].z, v[2].z, v[3].z);
@@ -535,6 +553,8 @@ extern "C" int dpp_fc_gemm(const dpp_gemm_desc* dp, int precision, int kchunk, d
     if (precision != 0 && precision != 1) return DPP_E_BADARG;
     if (d.actA.mode > 3 || d.actB.mode > 3 || d.epi.stats || d.epi.bn_x) return DPP_E_UNSUPPORTED;
     if (d.N % 4) return DPP_E_UNSUPPORTED;                                  // the 16-byte epilogue
+    if (d.store & ~DPP_ST_A) return DPP_E_UNSUPPORTED;                      // only operand A (the flattened activation map) may be bf16-stored
+    if ((d.store & DPP_ST_A) && ((reinterpret_cast<uintptr_t>(d.A) & 15) || (d.lda & 3))) return DPP_E_UNSUPPORTED;
     const int ldc = d.splitk > 1 ? d.N : d.ldc;
     if (ldc % 4 || (reinterpret_cast<uintptr_t>(d.splitk > 1 ? d.partial : d.C) & 15)) return DPP_E_UNSUPPORTED;
     if (d.residual && (reinterpret_cast<uintptr_t>(d.residual) & 15)) return DPP_E_UNSUPPORTED;

@@ -27,11 +27,23 @@ struct GemmArgs {
     int Kper;         // K-slice length per blockIdx.z (multiple of the chunk depth)
     int bk;           // chunk depth for K-contiguous A: 16 or 32 (both-MN-contiguous layout always uses 64)
     int wide;         // epilogue goes through an LDS image of the tile and touches C / residual / bn_x with 16-B accesses
+    int shA, shB;     // 1: the operand's elements are bf16 (DPP_ST_A / DPP_ST_B): a `const float*` cursor advances by (element offset >> 1)
     unsigned long long* prof;   // phase stamps (profiling build only, see dpp_stamp)
 };
 
 // Load 4 consecutive floats p[0..3] where element e is valid iff (idx0 + e) < limit.
-__device__ __forceinline__ float4 load4(const float* p, int idx0, int limit, bool vec) {
+// (b16: `p` addresses bf16 elements -- 8-byte vector load or 2-byte element loads, widened exactly)
+__device__ __forceinline__ float4 load4(const float* p, int idx0, int limit, bool vec, bool b16 = false) {
+    if (b16) {
+        const dpp_bf16* q = reinterpret_cast<const dpp_bf16*>(p);
+        if (vec && idx0 + 3 < limit) return dpp_ld4(q);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx0 + 0 < limit) v.x = (float)q[0];
+        if (idx0 + 1 < limit) v.y = (float)q[1];
+        if (idx0 + 2 < limit) v.z = (float)q[2];
+        if (idx0 + 3 < limit) v.w = (float)q[3];
+        return v;
+    }
     if (vec && idx0 + 3 < limit) return *reinterpret_cast<const float4*>(p);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx0 + 0 < limit) v.x = p[0];
@@ -236,6 +248,9 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     const int M = d.M, N = d.N;
     const int k_begin = blockIdx.z * ga.Kper;
     const int k_end = (k_begin + ga.Kper < d.K) ? (k_begin + ga.Kper) : d.K;
+    // bf16-stored operands (DPP_ST_A / DPP_ST_B; the host only sets them with 16-byte-quad geometry, so every element offset below is a
+    // multiple of 4): the `const float*` cursors advance by half the element offset, the loads fetch 8 instead of 16 bytes
+    const int shA = ga.shA, shB = ga.shB;
     dpp_stamp(ga.prof, 0);
 
     // ---- per-thread staging slots: base pointers that do not depend on the chunk -----------------------
@@ -247,10 +262,10 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         a_base[s] = nullptr;
         if (AKC) {
             int gi = row0 + slot / SA::QK;
-            if (slot < BM * SA::QK && gi < M) a_base[s] = d.A + (size_t)dpp_map_row(d.mapA, gi) * d.lda;
+            if (slot < BM * SA::QK && gi < M) a_base[s] = d.A + (((size_t)dpp_map_row(d.mapA, gi) * d.lda) >> shA);
         } else {
             int gi = row0 + (slot % (BM / 4)) * 4;
-            if (slot < BKT * (BM / 4) && gi < M) a_base[s] = d.A + gi;
+            if (slot < BKT * (BM / 4) && gi < M) a_base[s] = d.A + (gi >> shA);
         }
     }
 #pragma unroll
@@ -259,10 +274,10 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         b_base[s] = nullptr;
         if (BKC) {
             int gj = col0 + slot / SB::QK;
-            if (slot < BN * SB::QK && gj < N) b_base[s] = d.B + (size_t)gj * d.ldb;
+            if (slot < BN * SB::QK && gj < N) b_base[s] = d.B + (((size_t)gj * d.ldb) >> shB);
         } else {
             int gj = col0 + (slot % (BN / 4)) * 4;
-            if (slot < BKT * (BN / 4) && gj < N) b_base[s] = d.B + gj;
+            if (slot < BKT * (BN / 4) && gj < N) b_base[s] = d.B + (gj >> shB);
         }
     }
 
@@ -325,8 +340,17 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         if (fastA) {
             if (AKC) {
                 if (modeA & 2) coA[dd] = load_co(d.actA, kc + qa);
+                if (shA) {
 #pragma unroll
-                for (int s = 0; s < SA::SLOTS; ++s) ra_[s] = *reinterpret_cast<const float4*>(a_base[s] + kc + qa);
+                    for (int s = 0; s < SA::SLOTS; ++s) ra_[s] = dpp_raw8(a_base[s] + ((kc + qa) >> 1));
+                } else {
+#pragma unroll
+                    for (int s = 0; s < SA::SLOTS; ++s) ra_[s] = *reinterpret_cast<const float4*>(a_base[s] + kc + qa);
+                }
+            } else if (shA) {
+#pragma unroll
+                for (int s = 0; s < SA::SLOTS; ++s)
+                    ra_[s] = dpp_raw8(a_base[s] + (((size_t)dpp_map_row(d.mapA, kc + tid / QA + s * (DPP_THREADS / QA)) * d.lda) >> 1));
             } else {
 #pragma unroll
                 for (int s = 0; s < SA::SLOTS; ++s)
@@ -341,8 +365,8 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
                 if (AKC) {
                     int k = kc + (slot % SA::QK) * 4;
                     if (k < k_end) {
-                        const float* pa = a_base[s] + k;
-                        const float4 g = load4(pa, k, k_end, ga.vecA);
+                        const float* pa = a_base[s] + (k >> shA);
+                        const float4 g = load4(pa, k, k_end, ga.vecA, shA != 0);
                         if constexpr (LAZY) {
                             v = bnbwd4_masked(g, load4(pa + a2off, k, k_end, ga.vecA), d.actA, k, k_end);
                             if (d.actA.out != nullptr && blockIdx.y == 0) {
@@ -360,8 +384,8 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
                 } else {
                     int k = kc + slot / (BM / 4), gi = row0 + (slot % (BM / 4)) * 4;
                     if (k < k_end) {
-                        const float* pa = a_base[s] + (size_t)dpp_map_row(d.mapA, k) * d.lda;
-                        const float4 g = load4(pa, gi, M, ga.vecA);
+                        const float* pa = a_base[s] + (((size_t)dpp_map_row(d.mapA, k) * d.lda) >> shA);
+                        const float4 g = load4(pa, gi, M, ga.vecA, shA != 0);
                         if constexpr (LAZY) v = bnbwd4_masked(g, load4(pa + a2off, gi, M, ga.vecA), d.actA, gi, M);
                         else v = g;
                     }
@@ -372,8 +396,17 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         if (fastB) {
             if (BKC) {
                 if (modeB & 2) coB[dd] = load_co(d.actB, kc + qb);
+                if (shB) {
 #pragma unroll
-                for (int s = 0; s < SB::SLOTS; ++s) rb_[s] = *reinterpret_cast<const float4*>(b_base[s] + kc + qb);
+                    for (int s = 0; s < SB::SLOTS; ++s) rb_[s] = dpp_raw8(b_base[s] + ((kc + qb) >> 1));
+                } else {
+#pragma unroll
+                    for (int s = 0; s < SB::SLOTS; ++s) rb_[s] = *reinterpret_cast<const float4*>(b_base[s] + kc + qb);
+                }
+            } else if (shB) {
+#pragma unroll
+                for (int s = 0; s < SB::SLOTS; ++s)
+                    rb_[s] = dpp_raw8(b_base[s] + (((size_t)dpp_map_row(d.mapB, kc + tid / QB + s * (DPP_THREADS / QB)) * d.ldb) >> 1));
             } else {
 #pragma unroll
                 for (int s = 0; s < SB::SLOTS; ++s)
@@ -387,10 +420,10 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
             if (b_base[s] != nullptr) {
                 if (BKC) {
                     int k = kc + (slot % SB::QK) * 4;
-                    if (k < k_end) v = load4(b_base[s] + k, k, k_end, ga.vecB);
+                    if (k < k_end) v = load4(b_base[s] + (k >> shB), k, k_end, ga.vecB, shB != 0);
                 } else {
                     int k = kc + slot / (BN / 4), gj = col0 + (slot % (BN / 4)) * 4;
-                    if (k < k_end) v = load4(b_base[s] + (size_t)dpp_map_row(d.mapB, k) * d.ldb, gj, N, ga.vecB);
+                    if (k < k_end) v = load4(b_base[s] + (((size_t)dpp_map_row(d.mapB, k) * d.ldb) >> shB), gj, N, ga.vecB, shB != 0);
                 }
             }
             rb_[s] = v;
@@ -406,7 +439,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         if (fastA) {
 #pragma unroll
             for (int s = 0; s < SA::SLOTS; ++s) {
-                float4 v = ra_[s];
+                float4 v = shA ? dpp_widen4(ra_[s]) : ra_[s];
                 if (modeA != 0) v = apply_co(v, coA[AKC ? dd : 0], modeA);
                 *reinterpret_cast<float4*>(&As[ldsA0 + s * (DPP_THREADS / QA) * LDA_]) = v;
             }
@@ -425,7 +458,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         if (fastB) {
 #pragma unroll
             for (int s = 0; s < SB::SLOTS; ++s) {
-                float4 v = rb_[s];
+                float4 v = shB ? dpp_widen4(rb_[s]) : rb_[s];
                 if (modeB != 0) v = apply_co(v, coB[BKC ? dd : 0], modeB);
                 *reinterpret_cast<float4*>(&Bs[ldsB0 + s * (DPP_THREADS / QB) * LDB_]) = v;
             }
@@ -512,7 +545,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
         dpp_epilogue_wide<RM, CN, WM, WN, BM, BN>(acc, smem, col0, N, wco, d.residual, d.C, d.epi, nvalid, wm, wn, l15, kq, [&](int rl) {
             const int row = row0 + rl;
             return row < M ? (long)dpp_map_row(d.mapC, row) * d.ldc : -1L;
-        });
+        }, 0, d.store);
     }
     else gemm_epilogue<RM, CN, WM, WN, BM, BN>(acc, d, row0, col0, wm, wn, l15, kq, As);
     dpp_stamp(ga.prof, 4);
@@ -650,9 +683,15 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
 #pragma unroll
             for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb + (size_t)s * (DPP_THREADS / QN) * d.ldb);
         }
-        const float* pa = d.A + (size_t)(row0 + tid / QK) * d.lda + ka;
+        if (ga.shA) {                                       // bf16-stored activations: 8-byte loads, widened at the commit
+            const float* pa = d.A + (((size_t)(row0 + tid / QK) * d.lda + ka) >> 1);
 #pragma unroll
-        for (int s = 0; s < SA; ++s) ra[s] = *reinterpret_cast<const float4*>(pa + (size_t)s * (DPP_THREADS / QK) * d.lda);
+            for (int s = 0; s < SA; ++s) ra[s] = dpp_raw8(pa + (((size_t)s * (DPP_THREADS / QK) * d.lda) >> 1));
+        } else {
+            const float* pa = d.A + (size_t)(row0 + tid / QK) * d.lda + ka;
+#pragma unroll
+            for (int s = 0; s < SA; ++s) ra[s] = *reinterpret_cast<const float4*>(pa + (size_t)s * (DPP_THREADS / QK) * d.lda);
+        }
     }
     dpp_wide_coef wco;
     wco.load<BN>(col0, d.N, d.bias, d.epi, d.C);
@@ -672,7 +711,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
         float* la = As + (tid / QK) * LDA_ + ka;
 #pragma unroll
         for (int s = 0; s < SA; ++s) {
-            float4 v = ra[s];
+            float4 v = ga.shA ? dpp_widen4(ra[s]) : ra[s];
             if (modeA & 2) {
                 v.x = (v.x - mu.x) * sc.x + be.x; v.y = (v.y - mu.y) * sc.y + be.y;
                 v.z = (v.z - mu.z) * sc.z + be.z; v.w = (v.w - mu.w) * sc.w + be.w;
@@ -721,7 +760,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
     __syncthreads();                         // the operand images are dead: the epilogue's tile images take their place
     dpp_stamp(ga.prof, 3);
     dpp_epilogue_wide<RM, CN, 1, 1, BM, BN, 4>(acc, smem, col0, d.N, wco, d.residual, d.C, d.epi, BM, 0, 0, l15, kq,
-                                               [&](int rl) { return (long)(row0 + rl) * d.ldc; }, wave);
+                                               [&](int rl) { return (long)(row0 + rl) * d.ldc; }, wave, d.store);
     dpp_stamp(ga.prof, 4);
 }
 
@@ -764,10 +803,17 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga)
     float4 ra[TPW][G];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const float* pa = d.A + (size_t)(wrow0 + t * 16 + mrow) * d.lda + kq * 4;
+        if (ga.shA) {                                       // bf16-stored activations: 8-byte loads, widened where they are consumed
+            const float* pa = d.A + (((size_t)(wrow0 + t * 16 + mrow) * d.lda + kq * 4) >> 1);
 #pragma unroll
-        for (int g = 0; g < G; ++g) ra[t][g] = *reinterpret_cast<const float4*>(pa + g * 16);
+            for (int g = 0; g < G; ++g) ra[t][g] = dpp_raw8(pa + g * 8);
+        } else {
+            const float* pa = d.A + (size_t)(wrow0 + t * 16 + mrow) * d.lda + kq * 4;
+#pragma unroll
+            for (int g = 0; g < G; ++g) ra[t][g] = *reinterpret_cast<const float4*>(pa + g * 16);
+        }
     }
+    const bool c16 = (d.store & DPP_ST_C) != 0, x16 = (d.store & DPP_ST_BNX) != 0;
     float4 mu[G], sc[G], be[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -794,8 +840,8 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const size_t o = (size_t)(wrow0 + t * 16 + r * 4 + kq) * d.ldc + ct * 16 + l15;
-                xr[t][ct][r] = bn ? ep.bn_x[o] : 0.0f;
-                rr[t][ct][r] = (EPI && d.residual) ? d.residual[o] : 0.0f;
+                xr[t][ct][r] = bn ? dpp_ld1_rt(ep.bn_x, o, x16) : 0.0f;
+                rr[t][ct][r] = (EPI && d.residual) ? dpp_ld1_rt(d.residual, o, c16) : 0.0f;
             }
 
     float vals[TPW][CN][4];
@@ -809,7 +855,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga)
         for (int ct = 0; ct < CN; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            float4 v = ra[t][g];
+            float4 v = ga.shA ? dpp_widen4(ra[t][g]) : ra[t][g];
             if (modeA & 2) {
                 v.x = (v.x - mu[g].x) * sc[g].x + be[g].x; v.y = (v.y - mu[g].y) * sc[g].y + be[g].y;
                 v.z = (v.z - mu[g].z) * sc[g].z + be[g].z; v.w = (v.w - mu[g].w) * sc[g].w + be[g].w;
@@ -836,7 +882,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga)
                     sx[ct] += v;
                     sy[ct] += v * (dx * cistd[ct]);
                 }
-                d.C[o] = v;
+                if (c16) reinterpret_cast<dpp_bf16*>(d.C)[o] = (dpp_bf16)v; else d.C[o] = v;
                 vals[t][ct][r] = v;
             }
     }
@@ -921,6 +967,8 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
     const dpp_epilogue& ep = d.epi;
     const int modeA = ACT ? d.actA.mode : 0;
     const bool relu_mask = BNB && ep.bn_relu != 0;
+    // bf16-stored tensors (DPP_ST_*): A (forward: the activations), C + residual (forward: the output), epi.bn_x (data gradient)
+    const bool a16 = !LZ && ga.shA != 0, c16 = (d.store & DPP_ST_C) != 0, x16 = (d.store & DPP_ST_BNX) != 0;
     dpp_stamp(ga.prof, 0);
 
     // ---- the filter slice, the prologue coefficients of this lane's k range, the per-column vectors of its four columns ----
@@ -946,10 +994,15 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             const size_t oa = (size_t)(r0 + rt * 16 + l15) * d.lda + kq * KL;
+            if (a16) {                                      // bf16-stored activations: 8-byte loads, widened where they are consumed
 #pragma unroll
-            for (int j = 0; j < KV; ++j) {
-                g.a[rt][j] = *reinterpret_cast<const float4*>(d.A + oa + 4 * j);
-                if (LZ) g.a2[rt][j] = *reinterpret_cast<const float4*>(d.actA.x2 + oa + 4 * j);
+                for (int j = 0; j < KV; ++j) g.a[rt][j] = dpp_raw8(d.A + ((oa + 4 * j) >> 1));
+            } else {
+#pragma unroll
+                for (int j = 0; j < KV; ++j) {
+                    g.a[rt][j] = *reinterpret_cast<const float4*>(d.A + oa + 4 * j);
+                    if (LZ) g.a2[rt][j] = *reinterpret_cast<const float4*>(d.actA.x2 + oa + 4 * j);
+                }
             }
         }
 #pragma unroll
@@ -957,8 +1010,8 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const size_t o = (size_t)(r0 + rt * 16 + kq * 4 + r) * d.ldc + n0;
-                if (RES) g.res[rt][r] = *reinterpret_cast<const float4*>(d.residual + o);
-                if (BNB) g.bx[rt][r] = *reinterpret_cast<const float4*>(ep.bn_x + o);
+                if (RES) g.res[rt][r] = c16 ? dpp_raw8(d.residual + (o >> 1)) : *reinterpret_cast<const float4*>(d.residual + o);
+                if (BNB) g.bx[rt][r] = x16 ? dpp_raw8(ep.bn_x + (o >> 1)) : *reinterpret_cast<const float4*>(ep.bn_x + o);
             }
     };
     Regs g0, g1;
@@ -1003,7 +1056,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
             float av[RT][4];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                float4 v = g.a[rt][j];
+                float4 v = a16 ? dpp_widen4(g.a[rt][j]) : g.a[rt][j];
                 if (LZ) {
                     const float4 x = g.a2[rt][j];
                     v = make_float4(sc[j].x * v.x - ax[j].x * (x.x - mu[j].x) - be[j].x, sc[j].y * v.y - ax[j].y * (x.y - mu[j].y) - be[j].y,
@@ -1032,9 +1085,13 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v[4] = {acc[rt][0][r] + cbias.x, acc[rt][1][r] + cbias.y, acc[rt][2][r] + cbias.z, acc[rt][3][r] + cbias.w};
-                if (RES) { v[0] += g.res[rt][r].x; v[1] += g.res[rt][r].y; v[2] += g.res[rt][r].z; v[3] += g.res[rt][r].w; }
+                if (RES) {
+                    const float4 rr = c16 ? dpp_widen4(g.res[rt][r]) : g.res[rt][r];
+                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                }
                 if (BNB) {
-                    const float x[4] = {g.bx[rt][r].x, g.bx[rt][r].y, g.bx[rt][r].z, g.bx[rt][r].w};
+                    const float4 bxv = x16 ? dpp_widen4(g.bx[rt][r]) : g.bx[rt][r];
+                    const float x[4] = {bxv.x, bxv.y, bxv.z, bxv.w};
                     const float cm[4] = {cmean.x, cmean.y, cmean.z, cmean.w}, cs[4] = {cscale.x, cscale.y, cscale.z, cscale.w};
                     const float cb[4] = {cbeta.x, cbeta.y, cbeta.z, cbeta.w}, ci[4] = {cistd.x, cistd.y, cistd.z, cistd.w};
 #pragma unroll
@@ -1045,7 +1102,11 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
                         sy[j] += v[j] * (dx * ci[j]);
                     }
                 }
-                *reinterpret_cast<float4*>(d.C + (size_t)(r0 + rt * 16 + kq * 4 + r) * d.ldc + n0) = make_float4(v[0], v[1], v[2], v[3]);
+                {
+                    const size_t oc = (size_t)(r0 + rt * 16 + kq * 4 + r) * d.ldc + n0;
+                    if (c16) dpp_st4(reinterpret_cast<dpp_bf16*>(d.C) + oc, make_float4(v[0], v[1], v[2], v[3]));      // rounded on the store;
+                    else *reinterpret_cast<float4*>(d.C + oc) = make_float4(v[0], v[1], v[2], v[3]);                      // statistics below from the f32 values
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) vals[rt][r][j] = v[j];
             }
@@ -1125,6 +1186,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
 // dpp_gemm variant 4: rows per wave (= rows per statistics block) of gemm_expand_kernel for this problem, or 0.  d.bm carries the
 // caller's wish (a multiple of 32 that divides M), 0 = choose by the row count.
 static int expand_rows(const dpp_gemm_desc& d, const GemmArgs& ga) {
+    if ((d.store & DPP_ST_B) || (d.store && (d.actA.mode & 4))) return 0;
     if (!d.a_kc || d.splitk != 1 || !d.C || !ga.vecA || !ga.vecB || !ga.wide) return 0;
     if (d.K != 16 && d.K != 32 && d.K != 64) return 0;
     if (d.N % 64 || d.M % 32) return 0;
@@ -1167,6 +1229,7 @@ static int launch_expand(const GemmArgs& ga, int rpw, hipStream_t st) {
 // 64), or 0 when the kernel does not take it
 static int stream16_rows(const dpp_gemm_desc& d, const GemmArgs& ga) {
     const bool narrow = d.N == 16 && d.K == 64, wide = d.N == 64 && d.K == 16;
+    if (d.store & DPP_ST_B) return 0;
     if (!d.a_kc || d.splitk != 1 || !(narrow || wide) || !ga.vecA || !d.C || d.M % (narrow ? 128 : 64)) return 0;
     if (d.mapA.s != 1 || d.mapB.s != 1 || d.mapC.s != 1 || d.actB.mode != 0 || (d.actA.mode & ~3)) return 0;
     if ((d.actA.mode & 2) && d.actA.cmod < d.K) return 0;        // (dpp_gemm has checked that the prologue vectors are 16-byte aligned)
@@ -1177,6 +1240,7 @@ static int stream16_rows(const dpp_gemm_desc& d, const GemmArgs& ga) {
 
 // dpp_gemm variant 2: can this problem run on gemm_ksplit_kernel, and with which tile?
 static int ksplit_bn(const dpp_gemm_desc& d, const GemmArgs& ga) {
+    if (d.store & DPP_ST_B) return 0;
     if (!d.a_kc || d.splitk != 1 || !ga.wide || !ga.vecA || !ga.vecB || d.M % 32 || (d.K != 256 && d.K != 128)) return 0;
     if (d.mapA.s != 1 || d.mapB.s != 1 || d.mapC.s != 1 || d.actB.mode != 0 || (d.actA.mode & ~3)) return 0;
     if ((d.actA.mode & 2) && d.actA.cmod < d.K) return 0;
@@ -1365,12 +1429,21 @@ static int gemm_prepare(const dpp_gemm_desc* dp, GemmArgs& ga) {
         if (!(aligned16(d.actA.mean) && aligned16(d.actA.scale) && aligned16(d.actA.beta) && aligned16(d.actA.aux))) return DPP_E_BADARG;
     }
     ga.vecB = aligned16(d.B) && (d.ldb % 4 == 0);
+    // bf16-stored operands / outputs (DPP_ST_*): only with whole-quad geometry (element offsets are halved on `const float*` cursors)
+    // and through the 16-byte epilogue; the mode-4 operand (two f32 tensors) does not combine with them
+    if (d.store & ~(DPP_ST_A | DPP_ST_B | DPP_ST_C | DPP_ST_BNX)) return DPP_E_BADARG;
+    if ((d.store & DPP_ST_A) && (!ga.vecA || (d.actA.mode & 4))) return DPP_E_UNSUPPORTED;
+    if ((d.store & DPP_ST_B) && !ga.vecB) return DPP_E_UNSUPPORTED;
+    if ((d.store & (DPP_ST_C | DPP_ST_BNX)) && d.splitk != 1) return DPP_E_UNSUPPORTED;
+    ga.shA = (d.store & DPP_ST_A) ? 1 : 0;
+    ga.shB = (d.store & DPP_ST_B) ? 1 : 0;
     static const bool wide_ok = []() { const char* e = getenv("DPP_GEMM_WIDE_EPILOGUE"); return !(e && e[0] == '0'); }();
     ga.wide = wide_ok && d.splitk == 1 && d.N % 4 == 0 && d.ldc % 4 == 0 && aligned16(d.C) && aligned16(d.residual) &&
               aligned16(d.epi.bn_x) && aligned16(d.bias) && aligned16(d.epi.bn_mean) && aligned16(d.epi.bn_scale) &&
               aligned16(d.epi.bn_beta) && aligned16(d.epi.bn_inv_std);
     if ((d.actA.mode & 2) && !(aligned16(d.actA.mean) && aligned16(d.actA.scale) && aligned16(d.actA.beta))) return DPP_E_BADARG;
     if ((d.actB.mode & 2) && !(aligned16(d.actB.mean) && aligned16(d.actB.scale) && aligned16(d.actB.beta))) return DPP_E_BADARG;
+    if ((d.store & (DPP_ST_C | DPP_ST_BNX)) && !ga.wide) return DPP_E_UNSUPPORTED;
     return DPP_OK;
 }
 
@@ -1440,7 +1513,7 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
     }
     if (d.variant == 1) {
         // row-streaming kernel: bm in {64, 128} rows per workgroup, bn in {16, 32, 64} columns, whole K staged for B
-        if (!d.a_kc || d.splitk != 1) return DPP_E_UNSUPPORTED;
+        if (!d.a_kc || d.splitk != 1 || d.store) return DPP_E_UNSUPPORTED;
         if (bm != 64 && bm != 128) bm = 64;
         if (bn != 16 && bn != 32 && bn != 64) bn = d.N > 32 ? 64 : (d.N > 16 ? 32 : 16);
         const int K16 = (d.K + 15) & ~15;

@@ -29,7 +29,7 @@ template <int CN>   // CN = Co / 16 column tiles
 __global__ __launch_bounds__(DPP_THREADS) void stem_fwd_kernel(const float* __restrict__ X, int N, int H, int W, const float* __restrict__ Wk,
                                                                const float* __restrict__ bias, int Co, float* __restrict__ Y,
                                                                uint8_t* __restrict__ arg, int tiles_x, int tiles_y,
-                                                               float* __restrict__ stats) {
+                                                               float* __restrict__ stats, int y16) {
     dpp_kernarg_warm<128>();
     __shared__ float xs[LX * LXP];
     __shared__ float Ws[KPAD * CN * 16];
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_fwd_kernel(const float* __re
                     int ties = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ties |= (acc[ct][r] == best) ? (1 << r) : 0;
-                    Y[o + col] = best + bias[col];
+                    if (y16) reinterpret_cast<dpp_bf16*>(Y)[o + col] = (dpp_bf16)(best + bias[col]);      // bf16 storage: rounded on the store,
+                    else Y[o + col] = best + bias[col];                                                    // statistics from the f32 value
                     vals[rt][ct] = best + bias[col];
                     if (arg) arg[o + col] = (uint8_t)ties;
                 }
@@ -276,17 +277,18 @@ __global__ __launch_bounds__(DPP_THREADS) void stem_wgrad_kernel(const float* __
 }  // namespace
 
 extern "C" int dpp_stem_fwd(const float* X, int N, int H, int W, const float* Wk, const float* bias, int Co, float* Y, uint8_t* argmax,
-                            float* stats,
+                            float* stats, int store,
                             dpp_stream_t stream) {
-    if (!X || !Wk || !bias || !Y || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || Co < 1 || Co > 32) return DPP_E_BADARG;
+    if (!X || !Wk || !bias || !Y || N < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || Co < 1 || Co > 32 || (store & ~DPP_ST_C)) return DPP_E_BADARG;
+    const int y16 = (store & DPP_ST_C) ? 1 : 0;
     if (stats && ((H % TC) || (W % TC))) return DPP_E_BADARG;     // per-tile statistics assume full 16x16 conv tiles
     int tiles_x = dpp_cdiv(W, TC), tiles_y = dpp_cdiv(H, TC);
     dim3 grid(tiles_x * tiles_y * N);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (Co <= 16)
-        DPP_LAUNCH((stem_fwd_kernel<1>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y, stats);
+        DPP_LAUNCH((stem_fwd_kernel<1>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y, stats, y16);
     else
-        DPP_LAUNCH((stem_fwd_kernel<2>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y, stats);
+        DPP_LAUNCH((stem_fwd_kernel<2>), grid, dim3(DPP_THREADS), 0, st, X, N, H, W, Wk, bias, Co, Y, argmax, tiles_x, tiles_y, stats, y16);
     return dpp_launch_status();
 }
 

@@ -25,6 +25,29 @@ struct WgradArgs {
     int M, Co, Ci, rpw;                  // rpw: pixel rows per wave
 };
 
+// The X operand (the forward activations) may be a bf16-stored tensor (DPP_ST_B): V consecutive bf16 elements as ONE 2 / 4 / 8 / 16
+// byte load, widened exactly.
+template <int V>
+__device__ __forceinline__ void load_vec(const dpp_bf16* p, float (&v)[V]) {
+    if (V == 1) v[0] = (float)p[0];
+    else if (V == 2) {
+        typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+        const b2 t = *reinterpret_cast<const b2*>(p);
+        v[0] = (float)t[0]; v[1] = (float)t[1];
+    } else if (V == 4) {
+        const dpp_bf16x4 t = *reinterpret_cast<const dpp_bf16x4*>(p);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (float)t[q];
+    } else {
+#pragma unroll
+        for (int h = 0; h < V / 8; ++h) {
+            const dpp_bf16x8 t = *reinterpret_cast<const dpp_bf16x8*>(p + h * 8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[h * 8 + q] = (float)t[q];
+        }
+    }
+}
+
 template <int V>
 __device__ __forceinline__ void load_vec(const float* p, float (&v)[V]) {
     if (V == 1) v[0] = p[0];
@@ -40,7 +63,7 @@ __device__ __forceinline__ void load_vec(const float* p, float (&v)[V]) {
 
 // TA = Co / 16, TB = Ci / 16 (vector lengths of a full row per lane); the 4 waves split A channels WA ways, B channels WB ways and
 // rows WR = 4 / (WA * WB) ways.  VA = TA / WA, VB = TB / WB floats per lane and operand; VA * VB accumulator tiles per wave.
-template <int TA, int TB, int WA, int WB, int U, bool STRIDED>
+template <int TA, int TB, int WA, int WB, int U, bool STRIDED, class TX = float>
 __global__ __launch_bounds__(DPP_THREADS) void wgrad_stream_kernel(WgradArgs a) {
     constexpr int WR = 4 / (WA * WB), VA = TA / WA, VB = TB / WB;
     static_assert(WA * WB * WR == 4 && VA >= 1 && VB >= 1 && VA <= 4 && VB <= 8, "wave split");
@@ -76,7 +99,7 @@ __global__ __launch_bounds__(DPP_THREADS) void wgrad_stream_kernel(WgradArgs a) 
         const int mm = m < row_end ? m : last;
         load_vec<VA>(a.dY + (size_t)mm * a.Co + ca, av[u]);
         const int xr = STRIDED ? dpp_map_row(a.mapX, mm) : mm;
-        load_vec<VB>(a.X + (size_t)xr * a.Ci + cb, bv[u]);
+        load_vec<VB>(reinterpret_cast<const TX*>(a.X) + (size_t)xr * a.Ci + cb, bv[u]);
     };
     if (row_begin < row_end) {
 #pragma unroll
@@ -149,12 +172,12 @@ struct Wgrad3sArgs {
     int M, H, W, Co, Ci, rpw;
 };
 
-template <int V>
+template <int V, class T = float>
 __device__ __forceinline__ void load_vec_at(const char* base, unsigned byte_off, float (&v)[V]) {     // uniform base + 32-bit lane offset
-    load_vec<V>(reinterpret_cast<const float*>(base + byte_off), v);
+    load_vec<V>(reinterpret_cast<const T*>(base + byte_off), v);
 }
 
-template <int TA, int TB, int WA, int WB, int TG, int U>
+template <int TA, int TB, int WA, int WB, int TG, int U, class TX = float>
 __global__ __launch_bounds__(DPP_THREADS) void wgrad3_stream_kernel(Wgrad3sArgs a) {
     constexpr int WR = 4 / (WA * WB), VA = TA / WA, VB = TB / WB;
     static_assert(WA * WB * WR == 4 && VA >= 1 && VB >= 1 && VA <= 4 && VB <= 4 && (TG == 3 || TG == 9), "wave split");
@@ -186,7 +209,7 @@ __global__ __launch_bounds__(DPP_THREADS) void wgrad3_stream_kernel(Wgrad3sArgs 
     const int last = row_end - 1;
     const char* baseA = reinterpret_cast<const char*>(a.dY);
     const char* baseB = reinterpret_cast<const char*>(a.X);
-    const unsigned strideA = (unsigned)Co * 4u, strideB = (unsigned)Ci * 4u, offA = (unsigned)ca * 4u, offB = (unsigned)cb * 4u;
+    const unsigned strideA = (unsigned)Co * 4u, strideB = (unsigned)Ci * (unsigned)sizeof(TX), offA = (unsigned)ca * 4u, offB = (unsigned)cb * (unsigned)sizeof(TX);
     int fp = row_begin, fx = row_begin % W, fy = (row_begin / W) % H;         // the fetch cursor: pixel, its column and image row
     auto fetch = [&](int u) {
         const int p = fp + kq, x = fx + kq;
@@ -200,7 +223,7 @@ __global__ __launch_bounds__(DPP_THREADS) void wgrad3_stream_kernel(Wgrad3sArgs 
             const bool v = ok & ((unsigned)(fy + dy) < (unsigned)H) & ((unsigned)(x + dx) < (unsigned)W);    // no short-circuit: no branches
             const int q = v ? pp + dy * W + dx : pp;
             mask |= (v ? 1u : 0u) << j;
-            load_vec_at<VB>(baseB, (unsigned)q * strideB + offB, bv[u][j]);
+            load_vec_at<VB, TX>(baseB, (unsigned)q * strideB + offB, bv[u][j]);
         }
         okv[u] = mask;
         fp += 4; fx += 4;
@@ -267,7 +290,7 @@ struct FcWgradArgs {
     int Nb, K, N;                        // rows (samples), columns of X (= rows of dW), columns of dY
 };
 
-template <int U>
+template <int U, class TX = float>
 __global__ __launch_bounds__(DPP_THREADS) void fc_wgrad_stream_kernel(FcWgradArgs a) {
     constexpr int V = 4;                 // 4 x 4 tiles of 16 x 16 per wave
     dpp_kernarg_warm<sizeof(FcWgradArgs)>();
@@ -292,13 +315,13 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_wgrad_stream_kernel(FcWgradArg
     float av[U][V], bv[U][V];
     const char* baseA = reinterpret_cast<const char*>(a.X);
     const char* baseB = reinterpret_cast<const char*>(a.dY);
-    const unsigned strideA = (unsigned)a.K * 4u, strideB = (unsigned)a.N * 4u, offA = (unsigned)ka * 4u, offB = (unsigned)nb * 4u;
+    const unsigned strideA = (unsigned)a.K * (unsigned)sizeof(TX), strideB = (unsigned)a.N * 4u, offA = (unsigned)ka * (unsigned)sizeof(TX), offB = (unsigned)nb * 4u;
     const int last = a.Nb - 1;
     int fb = 0;                                                  // the fetch cursor (row of lane group kq = 0)
     auto fetch = [&](int u) {
         const int b = fb + kq;
         const int bb = b < a.Nb ? b : last;                      // rows past the end re-read the last row; their A operand is zeroed
-        load_vec_at<V>(baseA, (unsigned)bb * strideA + offA, av[u]);
+        load_vec_at<V, TX>(baseA, (unsigned)bb * strideA + offA, av[u]);
         load_vec_at<V>(baseB, (unsigned)bb * strideB + offB, bv[u]);
         fb += 4;
     };
@@ -351,8 +374,9 @@ extern "C" int dpp_wgrad_stream_slices(int Co, int Ci, int M, int rows_per_wave)
 }
 
 extern "C" int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
-                                int rows_per_wave, float* partial, dpp_stream_t stream) {
-    if (!dY || !X || !partial) return DPP_E_BADARG;
+                                int rows_per_wave, float* partial, int store, dpp_stream_t stream) {
+    if (!dY || !X || !partial || (store & ~DPP_ST_B)) return DPP_E_BADARG;
+    const bool x16 = (store & DPP_ST_B) != 0;
     const int nsl = dpp_wgrad_stream_slices(Co, Ci, M, rows_per_wave);
     if (!nsl) return DPP_E_UNSUPPORTED;
     WgradArgs a;
@@ -368,7 +392,10 @@ extern "C" int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci,
     const dim3 grid(nsl / WR), block(DPP_THREADS);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define DPP_WG(CO_, CI_, WA_, WB_, U_) if (Co == CO_ && Ci == CI_) { \
-        if (a.mapX.s != 1) DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, true>), grid, block, 0, st, a); \
+        if (x16) { \
+            if (a.mapX.s != 1) DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, true, dpp_bf16>), grid, block, 0, st, a); \
+            else DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, false, dpp_bf16>), grid, block, 0, st, a); \
+        } else if (a.mapX.s != 1) DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, true>), grid, block, 0, st, a); \
         else DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, false>), grid, block, 0, st, a); \
         return dpp_launch_status(); }
     DPP_WG(16, 64, 1, 1, 8)
@@ -396,8 +423,9 @@ extern "C" int dpp_wgrad3_stream_slices(int Co, int Ci, int N, int H, int W, int
 }
 
 extern "C" int dpp_wgrad3_stream(const float* dY, int Co, const float* X, int Ci, int N, int H, int W, const dpp_act* actX,
-                                 int rows_per_wave, float* partial, dpp_stream_t stream) {
-    if (!dY || !X || !partial) return DPP_E_BADARG;
+                                 int rows_per_wave, float* partial, int store, dpp_stream_t stream) {
+    if (!dY || !X || !partial || (store & ~DPP_ST_B)) return DPP_E_BADARG;
+    const bool x16 = (store & DPP_ST_B) != 0;
     const int nsl = dpp_wgrad3_stream_slices(Co, Ci, N, H, W, rows_per_wave);
     if (!nsl) return DPP_E_UNSUPPORTED;
     Wgrad3sArgs a;
@@ -411,7 +439,11 @@ extern "C" int dpp_wgrad3_stream(const float* dY, int Co, const float* X, int Ci
     shape3(Co, Ci, WR, TG);
     const dim3 grid(nsl / WR, 9 / TG), block(DPP_THREADS);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (Co == 16) DPP_LAUNCH((wgrad3_stream_kernel<1, 1, 1, 1, 9, 4>), grid, block, 0, st, a);
+    if (x16) {
+        if (Co == 16) DPP_LAUNCH((wgrad3_stream_kernel<1, 1, 1, 1, 9, 4, dpp_bf16>), grid, block, 0, st, a);
+        else if (Co == 32) DPP_LAUNCH((wgrad3_stream_kernel<2, 2, 1, 1, 3, 8, dpp_bf16>), grid, block, 0, st, a);
+        else DPP_LAUNCH((wgrad3_stream_kernel<4, 4, 2, 2, 3, 8, dpp_bf16>), grid, block, 0, st, a);
+    } else if (Co == 16) DPP_LAUNCH((wgrad3_stream_kernel<1, 1, 1, 1, 9, 4>), grid, block, 0, st, a);
     else if (Co == 32) DPP_LAUNCH((wgrad3_stream_kernel<2, 2, 1, 1, 3, 8>), grid, block, 0, st, a);
     else DPP_LAUNCH((wgrad3_stream_kernel<4, 4, 2, 2, 3, 8>), grid, block, 0, st, a);
     return dpp_launch_status();
@@ -424,8 +456,9 @@ extern "C" int dpp_fc_wgrad_stream_ok(int Nb, int K, int N) {
     return 1;
 }
 
-extern "C" int dpp_fc_wgrad_stream(const float* X, const float* dY, float* dW, int Nb, int K, int N, const dpp_act* actX, dpp_stream_t stream) {
-    if (!X || !dY || !dW) return DPP_E_BADARG;
+extern "C" int dpp_fc_wgrad_stream(const float* X, const float* dY, float* dW, int Nb, int K, int N, const dpp_act* actX, int store,
+                                   dpp_stream_t stream) {
+    if (!X || !dY || !dW || (store & ~DPP_ST_B)) return DPP_E_BADARG;
     if (!dpp_fc_wgrad_stream_ok(Nb, K, N)) return DPP_E_UNSUPPORTED;
     FcWgradArgs a;
     a.X = X; a.dY = dY; a.dW = dW; a.Nb = Nb; a.K = K; a.N = N;
@@ -434,6 +467,7 @@ extern "C" int dpp_fc_wgrad_stream(const float* X, const float* dY, float* dW, i
     if (a.actX.mode & ~3) return DPP_E_UNSUPPORTED;
     if ((a.actX.mode & 2) && !(a.actX.mean && a.actX.scale && a.actX.beta && a.actX.cmod >= 4 && (a.actX.cmod & 3) == 0)) return DPP_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(dW)) & 15) return DPP_E_BADARG;
-    DPP_LAUNCH((fc_wgrad_stream_kernel<8>), dim3(K / 128, N / 128), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    if (store & DPP_ST_B) DPP_LAUNCH((fc_wgrad_stream_kernel<8, dpp_bf16>), dim3(K / 128, N / 128), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    else DPP_LAUNCH((fc_wgrad_stream_kernel<8>), dim3(K / 128, N / 128), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), a);
     return dpp_launch_status();
 }

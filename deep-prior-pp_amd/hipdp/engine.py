@@ -41,8 +41,14 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+def bf16_bits_to_f32(a):
+    """uint16 bfloat16 bit patterns -> float32 (exact)."""
+    return (np.ascontiguousarray(a, np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
 class TensorV(object):
-    """A materialised device tensor: NHWC (N,H,W,C) or (N,D)."""
+    """A materialised device tensor: NHWC (N,H,W,C) or (N,D); float32, or bfloat16 bits (dtype uint16) for a bf16-STORED activation
+    tensor (CompiledNet.store16)."""
 
     def __init__(self, buf, shape, name):
         self.buf, self.shape, self.name = buf, tuple(shape), name
@@ -57,6 +63,15 @@ class TensorV(object):
     @property
     def C(self):
         return self.shape[-1]
+
+    @property
+    def is16(self):
+        return self.buf.dtype == ops.BF16
+
+    def get_f32(self):
+        """The tensor's values as float32, whatever its storage."""
+        a = self.buf.get()
+        return bf16_bits_to_f32(a).reshape(self.shape) if self.is16 else a
 
 
 class BNState(object):
@@ -348,6 +363,10 @@ EARLY_BUCKET_MIN = int(knob('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elemen
 #      (tools/branch_probe.py), and the chain itself measures the same (3.26 vs 3.27 ms without the branch).  Off.
 LAZY_BN_BWD = int(knob('DPP_LAZY_BN_BWD', '0'))
 BF16_DEFAULT = os.environ.get('DPP_BF16', '0') == '1'
+# bf16 mode (BASELINE config 5) also STORES the activation tensors -- every [pixels][channels] tensor a convolution writes -- as
+# bfloat16 (ABI v9, DPP_ST_*): rounded by the producer's epilogue (statistics from the f32 values), widened by every reader.  At
+# 256x256 the step is bandwidth-bound and these tensors are read five to six times each.  DPP_BF16_STORE=0: f32 storage (rounds 2-3).
+BF16_STORE = knob('DPP_BF16_STORE', '1') != '0'
 # ADAM of the FC1 weight (90 % of the parameters, 470 MB of optimizer traffic) inside the backward pass: its gradient is final a few
 # kernels into the pass, so the update runs on the gradient branch under the latency-bound data-gradient chain instead of in the
 # serial tail of the step (step_plan only: cost_and_grads / allreduce paths keep backward and update apart).
@@ -536,6 +555,7 @@ class CompiledNet(object):
         self.rt = rt = runtime or default_runtime()
         self.optimizer = dict(optimizer) if optimizer else dict(name='ADAM')
         self.prec = int(bool(BF16_DEFAULT if bf16 is None else bf16))
+        self.store16 = bool(self.prec and BF16_STORE)           # conv outputs held as bf16 (see BF16_STORE)
         self.dp = dp                                  # hipdp.parallel.DataParallel or None
         # BatchNorm statistics / backward sums produced by the conv epilogues (off with sync-BN, whose partials are
         # all-gathered by row block, and for tests that want the stand-alone BatchNorm kernels)
@@ -659,8 +679,9 @@ class CompiledNet(object):
             self._scratch2 = self.rt.alloc(max(nfloats, 1 << 20), zero=False)
         return self._scratch2
 
-    def _new_tensor(self, shape, name):
-        t = TensorV(self.rt.alloc(shape, zero=False), shape, name)
+    def _new_tensor(self, shape, name, act=False):
+        """act: a convolution's output map -- the tensors that are bf16-stored in the bf16 mode."""
+        t = TensorV(self.rt.alloc(shape, np.uint16 if (act and self.store16) else np.float32, zero=False), shape, name)
         self.tensors.append(t)
         return t
 
@@ -761,6 +782,8 @@ class CompiledNet(object):
         """T.concatenate of flattened tower outputs (scalenet.py:167-171): every part is packed (with its pending ReLU) into
         its column range of one [N][sum] buffer, which the following HiddenLayer reads as a plain operand."""
         parts = [self._emit(p) for p in var.inputs]
+        if any(p.base.is16 for p in parts):
+            raise NotImplementedError("concatenation of bf16-stored maps")
         N = parts[0].shape[0]
         widths = [int(p.shape[1]) for p in parts]
         total = sum(widths)
@@ -877,7 +900,7 @@ class CompiledNet(object):
         if not ok:
             return self._emit_convpool(layer, src)
         Co = c.nFilters
-        out = self._new_tensor((N, H // 2, W // 2, Co), 'stem')
+        out = self._new_tensor((N, H // 2, W // 2, Co), 'stem', act=True)
         arg = self.rt.alloc((N, H // 2, W // 2, Co), np.uint8, zero=False) if self.train else None
         stats = None
         if self.train and self.fuse_bn and H % 16 == 0 and W % 16 == 0 and out_var is not None and self._feeds_batchnorm(out_var):
@@ -896,6 +919,8 @@ class CompiledNet(object):
         kh, kw = c.filterDim[0], c.filterDim[1]
         if len(src.shape) != 4:
             raise NotImplementedError("ConvPoolLayer on a flattened input")
+        if self.store16:
+            raise NotImplementedError("bf16 storage is built for the ResNet path (stem + ConvLayer); the generic ConvPoolLayer kernels are f32")
         if c.border_mode not in ('valid', 'half') or tuple(c.stride) != (1, 1) or c.poolsize[0] != c.poolsize[1]:
             raise NotImplementedError("ConvPoolLayer border %s stride %s pool %s" % (c.border_mode, c.stride, c.poolsize))
         if c.border_mode == 'half' and (kh % 2 == 0 or kw % 2 == 0):
@@ -921,7 +946,7 @@ class CompiledNet(object):
         k, s = tuple(c.filterDim), tuple(c.stride)
         if c.border_mode != 'half' or k not in ((1, 1), (3, 3)) or s[0] != s[1] or (k == (3, 3) and s != (1, 1)):
             raise NotImplementedError("ConvLayer %s stride %s border %s" % (k, s, c.border_mode))
-        out = self._new_tensor((N, Ho, Wo, Co), 'conv%d' % layer.layerNum)
+        out = self._new_tensor((N, Ho, Wo, Co), 'conv%d' % layer.layerNum, act=True)
         act = self._act(src)
         rt, st = self.rt, self.store
         res = residual.buf if residual is not None else None

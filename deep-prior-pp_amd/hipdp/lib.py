@@ -11,7 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'lib', 'libdpp_hip.so')
 
-ABI_VERSION = 8
+ABI_VERSION = 9
+ST_A, ST_B, ST_C, ST_BNX = 1, 2, 4, 8      # DPP_ST_*: which pointers of a call address bf16-stored activation tensors
 c_float_p = C.c_void_p      # device pointers travel as integers
 stream_t = C.c_void_p
 
@@ -52,7 +53,7 @@ class GemmDesc(C.Structure):
                 ('bias', C.c_void_p), ('residual', C.c_void_p),
                 ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
                 ('splitk', C.c_int), ('partial', C.c_void_p),
-                ('bm', C.c_int), ('bn', C.c_int), ('wm', C.c_int), ('variant', C.c_int), ('epi', Epilogue)]
+                ('bm', C.c_int), ('bn', C.c_int), ('wm', C.c_int), ('variant', C.c_int), ('epi', Epilogue), ('store', C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/dpp_hip.h declares must be listed here
@@ -63,16 +64,16 @@ SIGNATURES = {
     'dpp_fc_gemm': (C.c_int, [C.POINTER(GemmDesc), C.c_int, C.c_int, stream_t]),
     'dpp_reduce_partials': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
     'dpp_conv3x3': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
-                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Epilogue), stream_t]),
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Epilogue), C.c_int, stream_t]),
     'dpp_conv3x3_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Epilogue), stream_t]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Epilogue), C.c_int, stream_t]),
     'dpp_conv3x3_tiling': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'dpp_conv3x3_wtrans': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_conv3x3_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'dpp_conv3x3_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
-                                    C.c_void_p, C.c_int, stream_t]),
+                                    C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_stem_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                               C.c_void_p, C.c_void_p, stream_t]),
+                               C.c_void_p, C.c_void_p, C.c_int, stream_t]),
     'dpp_stem_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'dpp_stem_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_int, stream_t]),
@@ -83,27 +84,27 @@ SIGNATURES = {
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_convpool_dgrad': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
-    'dpp_bn_stats_partial': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_bn_stats_partial': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_bn_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, stream_t]),
     'dpp_bn_eval_coeffs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      stream_t]),
     'dpp_bn_bwd_reduce': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
+                                    C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_bn_bwd_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_bn_bwd_apply': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_reduce_job_bytes': (C.c_size_t, []),
     'dpp_reduce_multi_block_cols': (C.c_int, []),
     'dpp_reduce_multi': (C.c_int, [C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_colsum_partial': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_wgrad_stream_slices': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    'dpp_wgrad_stream': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_wgrad_stream': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_fc_wgrad_stream_ok': (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    'dpp_fc_wgrad_stream': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, stream_t]),
+    'dpp_fc_wgrad_stream': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_wgrad3_stream_slices': (C.c_int, [C.c_int] * 6),
-    'dpp_wgrad3_stream': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, stream_t]),
+    'dpp_wgrad3_stream': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_wtrans_job_bytes': (C.c_size_t, []),
     'dpp_conv3x3_wtrans_multi': (C.c_int, [C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_loss_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, stream_t]),

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .lib import Act, DppError, Epilogue, GemmDesc, RowMap, check
+from .lib import ST_A, ST_B, ST_BNX, ST_C, Act, DppError, Epilogue, GemmDesc, RowMap, check
 
 
 class Launch(object):
@@ -221,6 +221,23 @@ def _p(buf):
     return None if buf is None else buf.ptr
 
 
+BF16 = np.dtype(np.uint16)          # storage dtype of a bf16 activation tensor (runtime buffers have no bfloat16: the bits travel as uint16)
+
+
+def _is16(buf):
+    """Does this buffer hold a bf16-stored activation tensor (DPP_ST_* of include/dpp_hip.h)?"""
+    return buf is not None and getattr(buf, 'dtype', None) == BF16
+
+
+def _store(a=None, b=None, c=None, bnx=None):
+    """DPP_ST_* mask of a call from the dtypes of the buffers in its A / B / C (+ residual) / epilogue.bn_x roles."""
+    return (ST_A if _is16(a) else 0) | (ST_B if _is16(b) else 0) | (ST_C if _is16(c) else 0) | (ST_BNX if _is16(bnx) else 0)
+
+
+def _esz(buf):
+    return 2.0 if _is16(buf) else 4.0
+
+
 def act(mode=0, mean=None, scale=None, beta=None, cmod=1, x2=None, aux=None, out=None):
     a = Act(_p(mean), _p(scale), _p(beta), int(mode), int(cmod), _p(x2), _p(aux), _p(out))
     a._keep = (mean, scale, beta, x2, aux, out)
@@ -241,6 +258,7 @@ def epilogue(stats=None, bn=None, bn_x=None, bn_relu=True, bn_partial=None):
     if bn is not None:
         e.bn_x, e.bn_mean, e.bn_inv_std, e.bn_scale, e.bn_beta = bn_x.ptr, bn.mean.ptr, bn.inv_std.ptr, bn.scale.ptr, bn.beta_buf.ptr
         e.bn_relu, e.bn_partial = int(bn_relu), bn_partial.ptr
+    e._bn_x = bn_x
     e._keep = (stats, bn, bn_x, bn_partial)
     return e
 
@@ -264,8 +282,12 @@ def gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, mapA=None, mapB=N
     d.variant = int(variant)
     if epi is not None:
         d.epi = epi
+    if _is16(residual) != _is16(Cbuf) and residual is not None and Cbuf is not None:
+        raise ValueError("dpp_gemm: C and residual must be stored alike")
+    d.store = _store(A, B, Cbuf, getattr(epi, '_bn_x', None) if epi is not None else None)
     meta = dict(kernel='gemm_mfma_f32', flops=2.0 * M * N * K,
-                bytes=4.0 * (M * K + K * N + M * N * (max(1, splitk) if splitk > 1 else 1) + (M * N if residual is not None else 0)))
+                bytes=_esz(A) * M * K + _esz(B) * K * N + (4.0 * M * N * max(1, splitk) if splitk > 1 else _esz(Cbuf) * M * N) +
+                (_esz(residual) * M * N if residual is not None else 0))
     return Launch(rt.lib.dpp_gemm, (C.byref(d),), (d, A, B, Cbuf, bias, residual, partial, actA, actB, epi), name, meta)
 
 
@@ -278,18 +300,18 @@ def gemm_variant_rows(rt, launch):
 def wgrad_stream(rt, dY, Co, X, Ci, M, rows_per_wave, partial, mapX=None, actX=None, name='wgrad_stream'):
     """dpp_wgrad_stream: the filter gradient of a 1x1 convolution as per-slice partials [slices][Co][Ci]."""
     nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rows_per_wave)
-    meta = dict(kernel='gemm_mfma_f32', flops=2.0 * M * Co * Ci, bytes=4.0 * (M * Co + M * Ci + nsl * Co * Ci))
+    meta = dict(kernel='gemm_mfma_f32', flops=2.0 * M * Co * Ci, bytes=4.0 * (M * Co + nsl * Co * Ci) + _esz(X) * M * Ci)
     return Launch(rt.lib.dpp_wgrad_stream, (dY.ptr, int(Co), X.ptr, int(Ci), C.byref(mapX) if mapX is not None else None, _actp(actX), int(M),
-                                            int(rows_per_wave), partial.ptr), (dY, X, partial, mapX, actX), name, meta)
+                                            int(rows_per_wave), partial.ptr, _store(b=X)), (dY, X, partial, mapX, actX), name, meta)
 
 
 def wgrad3_stream(rt, dY, Co, X, Ci, N, H, W, rows_per_wave, partial, actX=None, name='conv3x3_wgrad_stream'):
     """dpp_wgrad3_stream: the filter gradient of a 3x3 convolution as per-slice partials [slices][Co][9][Ci]."""
     nsl = rt.lib.dpp_wgrad3_stream_slices(Co, Ci, N, H, W, rows_per_wave)
     px = float(N) * H * W
-    meta = dict(kernel='conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co, bytes=4.0 * (px * (Ci + Co) + nsl * 9.0 * Ci * Co))
+    meta = dict(kernel='conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co, bytes=4.0 * (px * Co + nsl * 9.0 * Ci * Co) + _esz(X) * px * Ci)
     return Launch(rt.lib.dpp_wgrad3_stream, (dY.ptr, int(Co), X.ptr, int(Ci), int(N), int(H), int(W), _actp(actX), int(rows_per_wave),
-                                             partial.ptr), (dY, X, partial, actX), name, meta)
+                                             partial.ptr, _store(b=X)), (dY, X, partial, actX), name, meta)
 
 
 def fc_gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, actA=None, actB=None, bias=None, residual=None, splitk=1, partial=None,
@@ -305,6 +327,9 @@ def fc_gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, actA=None, act
     d.bias, d.residual = _p(bias), _p(residual)
     d.M, d.N, d.K = int(M), int(N), int(K)
     d.splitk, d.partial = int(splitk), _p(partial)
+    d.store = _store(A, B, Cbuf)
+    if _is16(residual) != _is16(Cbuf) and residual is not None and Cbuf is not None:
+        raise ValueError("dpp_fc_gemm: C and residual must be stored alike")
     meta = dict(kernel='fc_gemm_mfma_bf16' if precision else 'gemm_mfma_f32', flops=2.0 * M * N * K,
                 bytes=4.0 * (M * K + K * N + M * N * (max(1, splitk) if splitk > 1 else 1) + (M * N if residual is not None else 0)))
     return Launch(rt.lib.dpp_fc_gemm, (C.byref(d), int(precision), int(kchunk)), (d, A, B, Cbuf, bias, residual, partial, actA, actB), name, meta)
@@ -313,7 +338,7 @@ def fc_gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, actA=None, act
 def fc_wgrad_stream(rt, X, dY, dW, Nb, K, N, actX=None, name='fc_wgrad_stream'):
     """dpp_fc_wgrad_stream: dW [K][N] = act(X)^T . dY over the Nb rows, each output block owned by one wave (no partials)."""
     meta = dict(kernel='gemm_mfma_f32', flops=2.0 * Nb * K * N, bytes=4.0 * (Nb * K + Nb * N + K * N))
-    return Launch(rt.lib.dpp_fc_wgrad_stream, (X.ptr, dY.ptr, dW.ptr, int(Nb), int(K), int(N), _actp(actX)), (X, dY, dW, actX), name, meta)
+    return Launch(rt.lib.dpp_fc_wgrad_stream, (X.ptr, dY.ptr, dW.ptr, int(Nb), int(K), int(N), _actp(actX), _store(b=X)), (X, dY, dW, actX), name, meta)
 
 
 def reduce_partials(rt, partial, nz, n, out, bias=None, nbias=1, name='reduce_partials'):
@@ -328,9 +353,12 @@ def _actp(a):
 def conv3x3(rt, X, N, H, W, Ci, Wk, Co, Y, actX=None, bias=None, residual=None, bm=0, epi=None, name='conv3x3', precision=0):
     px = float(N) * H * W
     meta = dict(kernel='conv3x3_mfma_bf16' if precision else 'conv3x3_mfma_f32', flops=2.0 * px * 9 * Ci * Co,
-                bytes=4.0 * (px * (Ci + Co + (Co if residual is not None else 0)) + 9 * Ci * Co))
+                bytes=px * (_esz(X) * Ci + _esz(Y) * Co + (_esz(residual) * Co if residual is not None else 0)) + 4.0 * 9 * Ci * Co)
+    if residual is not None and _is16(residual) != _is16(Y):
+        raise ValueError("dpp_conv3x3: Y and residual must be stored alike")
+    st = _store(X, None, Y, getattr(epi, '_bn_x', None) if epi is not None else None)
     return Launch(rt.lib.dpp_conv3x3_bf16 if precision else rt.lib.dpp_conv3x3, (X.ptr, N, H, W, Ci, _actp(actX), Wk.ptr, Co, _p(bias), _p(residual), Y.ptr, bm,
-                                       C.byref(epi) if epi is not None else None),
+                                       C.byref(epi) if epi is not None else None, st),
                   (X, Wk, Y, actX, bias, residual, epi), name, meta)
 
 
@@ -353,15 +381,15 @@ def conv3x3_wtrans_multi(rt, jobs, name='conv3x3_wtrans'):
 def conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, partial, actX=None, bm=64, name='conv3x3_wgrad'):
     px = float(N) * H * W
     nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, Ci, Co, bm)
-    meta = dict(kernel='conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co, bytes=4.0 * (px * (Ci + Co) + nblk * 9.0 * Ci * Co))
-    return Launch(rt.lib.dpp_conv3x3_wgrad, (X.ptr, N, H, W, Ci, _actp(actX), dY.ptr, Co, partial.ptr, bm),
+    meta = dict(kernel='conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co, bytes=4.0 * (px * Co + nblk * 9.0 * Ci * Co) + _esz(X) * px * Ci)
+    return Launch(rt.lib.dpp_conv3x3_wgrad, (X.ptr, N, H, W, Ci, _actp(actX), dY.ptr, Co, partial.ptr, bm, _store(a=X)),
                   (X, dY, partial, actX), name, meta)
 
 
 def stem_fwd(rt, X, N, H, W, Wk, bias, Co, Y, argmax, stats=None, name='stem_fwd'):
     px = float(N) * H * W
-    return Launch(rt.lib.dpp_stem_fwd, (X.ptr, N, H, W, Wk.ptr, bias.ptr, Co, Y.ptr, _p(argmax), _p(stats)), (X, Wk, bias, Y, argmax, stats), name,
-                  dict(kernel='stem_fwd_mfma_f32', flops=2.0 * px * 25 * Co, bytes=4.0 * px + px / 4 * Co * 5.0))
+    return Launch(rt.lib.dpp_stem_fwd, (X.ptr, N, H, W, Wk.ptr, bias.ptr, Co, Y.ptr, _p(argmax), _p(stats), _store(c=Y)), (X, Wk, bias, Y, argmax, stats), name,
+                  dict(kernel='stem_fwd_mfma_f32', flops=2.0 * px * 25 * Co, bytes=4.0 * px + px / 4 * Co * (1.0 + _esz(Y))))
 
 
 def stem_wgrad(rt, X, N, H, W, dY, argmax, Co, partial, tiles_per_block, name='stem_wgrad'):
@@ -391,8 +419,8 @@ def convpool_dgrad(rt, dY, ties, N, H, W, Ci, Wk, kh, kw, pad, Co, pool, dX, nam
 
 
 def bn_stats_partial(rt, X, M, Cc, rpb, partial, name='bn_stats_partial'):
-    return Launch(rt.lib.dpp_bn_stats_partial, (X.ptr, M, Cc, rpb, partial.ptr), (X, partial), name,
-                  dict(kernel='bn_stats_partial', flops=3.0 * M * Cc, bytes=4.0 * M * Cc))
+    return Launch(rt.lib.dpp_bn_stats_partial, (X.ptr, M, Cc, rpb, partial.ptr, _store(a=X)), (X, partial), name,
+                  dict(kernel='bn_stats_partial', flops=3.0 * M * Cc, bytes=_esz(X) * M * Cc))
 
 
 def bn_finalize(rt, partial, nb, M, rpb, Cc, gamma, eps, mean, inv_std, scale, run_mean=None, run_inv_std=None, alpha=0.0,
@@ -411,8 +439,8 @@ def bn_eval_coeffs(rt, gamma, run_mean, run_inv_std, Cc, mean, inv_std, scale, n
 
 def bn_bwd_reduce(rt, dA, X, M, Cc, mean, inv_std, scale, beta, relu, G, rpb, partial, name='bn_bwd_reduce'):
     return Launch(rt.lib.dpp_bn_bwd_reduce, (dA.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, beta.ptr, int(relu), G.ptr, rpb,
-                                             partial.ptr), (dA, X, mean, inv_std, scale, beta, G, partial), name,
-                  dict(kernel='bn_bwd_reduce', flops=8.0 * M * Cc, bytes=12.0 * M * Cc))
+                                             partial.ptr, _store(bnx=X)), (dA, X, mean, inv_std, scale, beta, G, partial), name,
+                  dict(kernel='bn_bwd_reduce', flops=8.0 * M * Cc, bytes=(8.0 + _esz(X)) * M * Cc))
 
 
 def bn_bwd_finalize(rt, partial, nb, M, Cc, dbeta, dgamma, c1, c2, nseg=1, bn=None, q=None, p=None, name='bn_bwd_finalize'):
@@ -426,9 +454,9 @@ def bn_bwd_finalize(rt, partial, nb, M, Cc, dbeta, dgamma, c1, c2, nseg=1, bn=No
 def bn_bwd_apply(rt, G, X, M, Cc, mean, inv_std, scale, c1, c2, dX, add=None, rpb=None, colsum=None, name='bn_bwd_apply'):
     rpb = rpb or max(32, -(-M // 1024))
     return Launch(rt.lib.dpp_bn_bwd_apply, (G.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, c1.ptr, c2.ptr, _p(add), dX.ptr,
-                                            int(rpb), _p(colsum)),
+                                            int(rpb), _p(colsum), _store(bnx=X)),
                   (G, X, mean, inv_std, scale, c1, c2, add, dX, colsum), name,
-                  dict(kernel='bn_bwd_apply', flops=6.0 * M * Cc, bytes=(16.0 if add is not None else 12.0) * M * Cc))
+                  dict(kernel='bn_bwd_apply', flops=6.0 * M * Cc, bytes=((12.0 if add is not None else 8.0) + _esz(X)) * M * Cc))
 
 
 def colsum_partial(rt, X, M, Cc, rpb, partial, name='colsum_partial'):

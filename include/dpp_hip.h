@@ -10,7 +10,7 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm allocations in the product);
  *     nothing is allocated, freed or retained across calls;
- *   - all tensors are float32; activations are NHWC ("pixel-major": row m = (n*H + y)*W + x holds the C
+ *   - all tensors are float32 (exception: the bf16 STORAGE mode below); activations are NHWC ("pixel-major": row m = (n*H + y)*W + x holds the C
  *     channels of one pixel); a single-channel NCHW depth crop is bit-identical to its NHWC form;
  *   - every call is asynchronous on `stream`; return value 0 = launched, otherwise a hipError_t or a
  *     DPP_E_* code; no exceptions cross the boundary; thread-compatible (one stream per process/GPU);
@@ -34,8 +34,19 @@ typedef void* dpp_stream_t; /* a hipStream_t */
 #define DPP_E_BADARG 10001
 #define DPP_E_UNSUPPORTED 10002
 
-#define DPP_ABI_VERSION 8
+#define DPP_ABI_VERSION 9
 int dpp_abi_version(void);
+
+/* bf16 STORAGE of activation tensors (ABI v9; BASELINE config 5 "bf16 MFMA, 256x256 input stress").  The [pixels][channels] tensors the
+ * convolutions write -- and only those: weights, gradients, FC outputs and every vector stay float32 -- may be held as bfloat16: the
+ * producer's epilogue rounds the f32 value it formed (accumulator + bias + residual) to nearest-even on the store, the fused BatchNorm
+ * statistics are still those of the UNROUNDED values, and every reader widens on the load (exact).  A `store` bit mask on the entry
+ * points that can see such a tensor says which of its pointers address bf16 elements (same element offsets / leading dimensions as
+ * f32; 8-byte alignment instead of 16).  0 everywhere = the float32 layout of ABI v8. */
+#define DPP_ST_A 1    /* operand A / the input map X */
+#define DPP_ST_B 2    /* operand B (the forward activations in a filter-gradient call) */
+#define DPP_ST_C 4    /* the output C / Y and, when given, the residual */
+#define DPP_ST_BNX 8  /* dpp_epilogue.bn_x (the BatchNorm input a data-gradient epilogue reads) */
 
 /* Pixel row map: row m of a compact (N,Ho,Wo) map -> row of a (N,Hi,Wi) map sampled with stride s.
  * s == 1 is the identity.  Used for Theano's `subsample` (convlayer.py:230-235) and its gradient. */
@@ -117,12 +128,20 @@ typedef struct {
                        load issued up front, the four waves split K; statistics blocks of 32 rows;
                        3: barrier-free row stream (a_kc = 1, splitk = 1, identity row maps, no actB; K = 64 -> N = 16
                        with M % 128 == 0, statistics blocks of 128 rows, or K = 16 -> N = 64 with M % 64 == 0, blocks of
-                       64 rows): a wave owns whole 16-row tiles, epilogue in the MFMA D layout.
-                       Variants 2 and 3 return DPP_E_UNSUPPORTED for anything else (bm / bn / wm are ignored). */
+                       64 rows): a wave owns whole 16-row tiles, epilogue in the MFMA D layout;
+                       4: wave-autonomous strips for the channel-EXPANDING shapes (a_kc = 1, splitk = 1, identity row maps,
+                       no actB; K in {16, 32, 64}, N % 64 == 0, M % bm == 0 with bm = rows per wave = rows per statistics
+                       block, a multiple of 32, 0 = choose): a wave owns bm rows x 64 columns x the whole K, columns dealt
+                       interleaved to the accumulator tiles so that the D layout gives 16-byte accesses; no LDS, no
+                       barrier.  b_kc = 1 with the modes 0-3 prologue (forward), b_kc = 0 with a plain or mode-4
+                       operand and the BatchNorm-backward epilogue (data gradient).
+                       Variants 2-4 return DPP_E_UNSUPPORTED for anything else (bn / wm are ignored). */
     dpp_epilogue epi; /* fused statistics / BatchNorm-backward epilogue (requires splitk == 1) */
+    int store;        /* DPP_ST_* mask: which of A, B, C (+ residual), epi.bn_x hold bf16 elements (0 = all float32).  Variant 4 and the
+                         generic tiles with 16-byte-aligned whole-quad shapes take it; DPP_E_UNSUPPORTED otherwise. */
 } dpp_gemm_desc;
 int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);
-/* Would dpp_gemm run `d` on the kernel d->variant asks for (2 or 3)?  Returns that kernel's rows per workgroup (the row-block count of
+/* Would dpp_gemm run `d` on the kernel d->variant asks for (2, 3 or 4)?  Returns that kernel's rows per workgroup (the row-block count of
  * the fused-epilogue partials is M / rows), or 0: alignment, prologue mode or the epilogue rule it out and the caller should describe
  * the problem with variant 0 and a generic tile instead (dpp_gemm itself returns DPP_E_UNSUPPORTED rather than change the partial
  * layout behind the caller's back).  Launches nothing. */
@@ -138,7 +157,7 @@ int dpp_gemm_variant_rows(const dpp_gemm_desc* d);
  * dpp_reduce_partials (fixed order).  T.grad of convlayer.py:230-240 (poseregnettrainer.py:110-111). */
 int dpp_wgrad_stream_slices(int Co, int Ci, int M, int rows_per_wave);
 int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
-                     int rows_per_wave, float* partial, dpp_stream_t stream);
+                     int rows_per_wave, float* partial, int store /* DPP_ST_B: X holds bf16 */, dpp_stream_t stream);
 
 /* Filter gradient of a 3x3 'half'-padded, stride-1 ConvLayer on the same kind of stream:
  *   partial[s][o][t][c] = sum over the pixels p of slice s of  dY[p][o] * act(X)[p + (dy, dx)][c],  t = 3 (dy + 1) + (dx + 1),
@@ -150,10 +169,11 @@ int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_
  * row stream: a wave owns a 64 x 64 block of dW over all rows, no LDS, no partials.  K and N multiples of 128
  * (dpp_fc_wgrad_stream_ok), otherwise dpp_fc_gemm's layout remains.  T.grad of hiddenlayer.py:136-139. */
 int dpp_fc_wgrad_stream_ok(int Nb, int K, int N);
-int dpp_fc_wgrad_stream(const float* X, const float* dY, float* dW, int Nb, int K, int N, const dpp_act* actX, dpp_stream_t stream);
+int dpp_fc_wgrad_stream(const float* X, const float* dY, float* dW, int Nb, int K, int N, const dpp_act* actX,
+                        int store /* DPP_ST_B: X holds bf16 */, dpp_stream_t stream);
 int dpp_wgrad3_stream_slices(int Co, int Ci, int N, int H, int W, int rows_per_wave);
 int dpp_wgrad3_stream(const float* dY, int Co, const float* X, int Ci, int N, int H, int W, const dpp_act* actX, int rows_per_wave,
-                      float* partial, dpp_stream_t stream);
+                      float* partial, int store /* DPP_ST_B: X holds bf16 */, dpp_stream_t stream);
 
 /* The same contract on the weight-streaming kernel for the HiddenLayer behind the last convolution map (FC1: 16 384 x 1 024
  * weights at 128x128 input, 65 536 x 1 024 at 256x256; hiddenlayer.py:136-139 and its T.grad): tile 128 x 64, both operands
@@ -182,11 +202,12 @@ int dpp_reduce_multi(const void* jobs_dev, int njobs, int total_blocks, dpp_stre
  * /root/reference/src/net/convlayer.py:230-240.  The data gradient is the same call on dY with the weights from
  * dpp_conv3x3_wtrans.  bm = 64 | 128 rows per workgroup (0 = choose).  Ci, Co multiples of 16. */
 int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
-                const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream);
+                const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi,
+                int store /* DPP_ST_A: X, DPP_ST_C: Y + residual, DPP_ST_BNX: epi->bn_x hold bf16 */, dpp_stream_t stream);
 /* The same with the activated input and the weights rounded to bf16 (RNE) as they are staged in LDS, f32 accumulation
  * (v_mfma_f32_16x16x32_bf16): BASELINE config 5, not for the 1e-3 mm parity path.  Same tiling, epilogues and results layout. */
 int dpp_conv3x3_bf16(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
-                     const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, dpp_stream_t stream);
+                     const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, int store, dpp_stream_t stream);
 /* tile geometry chosen for (N,H,W,bm): returns the number of workgroup row blocks, writes tile height / width / images */
 int dpp_conv3x3_tiling(int N, int H, int W, int bm, int* th, int* tw, int* img);
 /* Wd[c][8-tap][o] = Wk[o][tap][c] (mirrored taps, channels swapped): weights of the data-gradient correlation. */
@@ -199,7 +220,7 @@ int dpp_conv3x3_wtrans_multi(const void* jobs_dev, int njobs, int total_blocks, 
  * blk < dpp_conv3x3_wgrad_blocks(N,H,W,Ci,Co,bm); sum over blk with dpp_reduce_partials.  (T.grad, poseregnettrainer.py:110-111) */
 int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int Ci, int Co, int bm);
 int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
-                      float* partial, int bm, dpp_stream_t stream);
+                      float* partial, int bm, int store /* DPP_ST_A: X holds bf16 */, dpp_stream_t stream);
 
 /* ---- ResNet stem: ConvPoolLayer 5x5 'half' 1 -> Co (<= 32), 2x2 max-pool, bias AFTER the pool ----------------
  * /root/reference/src/net/convpoollayer.py:251-282 as built at /root/reference/src/net/resnet.py:128-133.
@@ -210,7 +231,7 @@ int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act
  * stats (may be NULL; needs H % 16 == W % 16 == 0): [2][Co][N * H/16 * W/16] per-tile (mean, M2) of the 64 pooled outputs a
  * workgroup writes -- the BatchNorm statistics partial of Y, combined by dpp_bn_finalize(rows_per_block = 64). */
 int dpp_stem_fwd(const float* X, int N, int H, int W, const float* Wk, const float* bias, int Co, float* Y, uint8_t* argmax,
-                 float* stats, dpp_stream_t stream);
+                 float* stats, int store /* DPP_ST_C: Y holds bf16 */, dpp_stream_t stream);
 int dpp_stem_wgrad_blocks(int N, int H, int W, int tiles_per_block);
 int dpp_stem_wgrad(const float* X, int N, int H, int W, const float* dY, const uint8_t* argmax, int Co, float* partial,
                    int tiles_per_block, dpp_stream_t stream);
@@ -243,7 +264,8 @@ int dpp_convpool_dgrad(const float* dY, const uint16_t* ties, int N, int H, int 
  * bwd_finalize:  dbeta, dgamma and c1 = dbeta/M, c2 = dgamma/M; if q != NULL also q = scale*c1 and p = scale*inv_std*c2, the
  *                per-channel constants of the mode-4 operand prologue (dpp_act)
  * bwd_apply:     dX = scale * (G - c1 - xhat*c2) + add      (gradient through the batch statistics) */
-int dpp_bn_stats_partial(const float* X, int M, int C, int rows_per_block, float* partial, dpp_stream_t stream);
+int dpp_bn_stats_partial(const float* X, int M, int C, int rows_per_block, float* partial, int store /* DPP_ST_A: X holds bf16 */,
+                         dpp_stream_t stream);
 int dpp_bn_finalize(const float* partial, int nb, int nseg, int M, int rows_per_block, int C, const float* gamma, float eps,
                     float* mean, float* inv_std, float* scale, float* run_mean, float* run_inv_std, float alpha,
                     dpp_stream_t stream);
@@ -251,12 +273,13 @@ int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, const float* r
                        float* inv_std, float* scale, dpp_stream_t stream);
 int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, const float* mean, const float* inv_std,
                       const float* scale, const float* beta, int relu, float* G, int rows_per_block, float* partial,
-                      dpp_stream_t stream);
+                      int store /* DPP_ST_BNX: X holds bf16 */, dpp_stream_t stream);
 int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M, int C, float* dbeta, float* dgamma, float* c1, float* c2,
                         const float* inv_std, const float* scale, float* q, float* p, dpp_stream_t stream);
 int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
                      const float* scale, const float* c1, const float* c2, const float* add, float* dX,
-                     int rows_per_block, float* colsum_partial /* [nb][C] column sums of dX, or NULL */, dpp_stream_t stream);
+                     int rows_per_block, float* colsum_partial /* [nb][C] column sums of dX, or NULL */,
+                     int store /* DPP_ST_BNX: X holds bf16 */, dpp_stream_t stream);
 
 /* ---- loss / optimiser / small elementwise ------------------------------------------------------------------ */
 /* partial[b][c] = sum of rows of chunk b (bias gradients; reduce with dpp_reduce_partials) */

@@ -250,17 +250,41 @@ def trained_param_list(net, P):
 
 
 # --------------------------------------------------------------------------- forward / backward
-def forward(net, P, x, train, dropout_masks=None, masks=None, bf16=None):
+def fused_convs(net):
+    """'conv' layers whose output the device never holds on its own: the engine fuses `a + conv(...)` into the epilogue of the LATER
+    conv of the sum (hipdp/engine.py:_emit_add), so the tensor it materialises -- and, in the bf16 storage mode, rounds -- is the sum."""
+    fused = set()
+
+    def walk(ref):
+        if ref[0] == 'add':
+            cand = [r[1] for r in ref[1:] if r[0] == 'layer' and net['layers'][r[1]]['kind'] == 'conv']
+            if cand:
+                fused.add(max(cand))
+        for r in ref[1:]:
+            if isinstance(r, tuple):
+                walk(r)
+
+    for l in net['layers']:
+        walk(l['src'])
+    walk(net['out'])
+    return fused
+
+
+def forward(net, P, x, train, dropout_masks=None, masks=None, bf16=None, store16=False):
     """Returns (output, cache).  train=True <=> unsetDeterministic (BN batch statistics, dropout masks).
     masks (optional): {layer index: bool array} pins the pass / block decision of a 'relu' layer or of an 'fc' layer's ReLU
     to the given pattern (the device's own, when comparing gradients: see oracle/torch_ref.forward).
     bf16 (optional): the set of 'conv' / 'fc' layer indices whose two MFMA operands (activated input, weight) are rounded to
     bfloat16 before the product, accumulation and everything else staying in the array dtype -- the arithmetic of the bf16 kernels
     (BASELINE config 5).  Forward only: backward() differentiates the unrounded graph; the gradient-parity tests use
-    oracle/torch_ref.py, which models the rounded backward operands as well."""
-    vals, cache, memo = {}, {}, {}
+    oracle/torch_ref.py, which models the rounded backward operands as well.
+    store16: the bf16 STORAGE mode of config 5 -- every tensor a convolution materialises (the stem's pooled map, a conv's output, or
+    the residual sum a conv's epilogue forms) is rounded to bfloat16 when it is written; the (training-mode) BatchNorm that reads it
+    takes its statistics from the UNROUNDED values and normalises the rounded ones, as the kernels do."""
+    vals, cache, memo, raw = {}, {}, {}, {}
     masks = masks or {}
     bf16 = bf16 or ()
+    fused = fused_convs(net) if store16 else set()
 
     def get(ref):
         if ref[0] == 'input':
@@ -270,6 +294,9 @@ def forward(net, P, x, train, dropout_masks=None, masks=None, bf16=None):
         if ref[0] == 'add':
             if ref not in memo:
                 memo[ref] = get(ref[1]) + get(ref[2])
+                if store16:
+                    raw[ref] = memo[ref]
+                    memo[ref] = L.bf16_round(memo[ref])
             return memo[ref]
         if ref[0] == 'flatten':
             v = get(ref[1])
@@ -278,6 +305,12 @@ def forward(net, P, x, train, dropout_masks=None, masks=None, bf16=None):
             return np.concatenate([get(r) for r in ref[1:]], axis=1)
         raise ValueError(ref)
 
+    def stored(i):
+        """Layer i's output as the device holds it (store16: rounded, unless it only exists inside a later residual sum)."""
+        if store16 and i not in fused:
+            raw[('layer', i)] = vals[i]
+            vals[i] = L.bf16_round(vals[i])
+
     for i, l in enumerate(net['layers']):
         a = get(l['src'])
         k = l['kind']
@@ -285,15 +318,22 @@ def forward(net, P, x, train, dropout_masks=None, masks=None, bf16=None):
             vals[i], cache[i] = L.convpool_fwd(a, P[i][0], P[i][1], l['stride'], l['border'], l['pool'],
                                                l['act'] == 'relu')
             cache[i] = (a,) + cache[i]
+            stored(i)
         elif k == 'conv':
             if i in bf16:
                 vals[i] = L.conv2d_fwd(L.bf16_round(a), L.bf16_round(P[i][0]), P[i][1], l['stride'], l['border'])
             else:
                 vals[i] = L.conv2d_fwd(a, P[i][0], P[i][1], l['stride'], l['border'])
             cache[i] = (a,)
+            stored(i)
         elif k == 'bn':
             beta, gamma, rm, ris = P[i]
-            if train:
+            if train and store16 and l['src'] in raw:
+                # statistics of the values the epilogue formed, normalisation of the tensor it stored
+                _, mean, inv_std = L.bn_fwd_train(raw[l['src']], gamma, beta)
+                vals[i] = L.bn_fwd_eval(a, gamma, beta, mean, inv_std)
+                cache[i] = (a, mean, inv_std)
+            elif train:
                 vals[i], mean, inv_std = L.bn_fwd_train(a, gamma, beta)
                 cache[i] = (a, mean, inv_std)
             else:
@@ -443,7 +483,7 @@ def train_step(net, P, state, x, y, lr, dropout_masks=None, weight_decay=0.0):
     return cost, G
 
 
-def compute_output(net, P, inputs, bf16=None):
+def compute_output(net, P, inputs, bf16=None, store16=False):
     """NetBase.computeOutput, /root/reference/src/net/netbase.py:217-316: deterministic forward in
     batches of batch_size, the last batch padded by repeating the last sample, result trimmed.  bf16: see forward()."""
     bs = net['batch_size']
@@ -459,7 +499,7 @@ def compute_output(net, P, inputs, bf16=None):
             if chunk.shape[0] < bs:
                 chunk = np.concatenate([chunk, np.repeat(a[-1:], bs - chunk.shape[0], axis=0)], axis=0)
             chunks.append(chunk)
-        o, _ = forward(net, P, chunks if multi else chunks[0], train=False, bf16=bf16)
+        o, _ = forward(net, P, chunks if multi else chunks[0], train=False, bf16=bf16, store16=store16)
         out[i * bs:(i + 1) * bs] = o.reshape((bs,) + tuple(net['out_dim'][1:]))
     return out[:n]
 

@@ -102,14 +102,57 @@ class _QBilinear(torch.autograd.Function):
         return da, dW, None, None
 
 
+class _StoredBN(torch.autograd.Function):
+    """BatchNorm over a bf16-STORED tensor (BASELINE config 5, ABI v9 DPP_ST_*): the conv epilogue forms v in the working precision,
+    takes the batch statistics FROM v and stores y = bf16(v); every later reader -- this BatchNorm's normalisation in the consumer's
+    prologue, the ReLU-mask and the xhat of its backward pass -- sees y.  Forward: (y - mean(v)) * gamma * inv_std(v) + beta.
+    Backward: what the kernels compute (csrc/bn.hip, the data-gradient epilogues): with xhat = (y - mean) * inv_std,
+        dbeta = sum g, dgamma = sum g * xhat, dv = gamma * inv_std * (g - mean(g) - xhat * mean(g * xhat))
+    -- the batchnormlayer.py:154-192 gradient with y in place of x (rounding is not differentiated; with y == v it IS the exact
+    gradient).  Deterministic mode (running statistics): dv = gamma * inv_std * g."""
+
+    @staticmethod
+    def forward(ctx, v, y, gamma, beta, rm, ris, train):
+        if train:
+            mean = v.mean(dim=(0, 2, 3))
+            inv_std = 1.0 / torch.sqrt(v.var(dim=(0, 2, 3), unbiased=False) + BN_EPS)
+        else:
+            mean, inv_std = rm, ris
+        xhat = (y - mean[None, :, None, None]) * inv_std[None, :, None, None]
+        ctx.save_for_backward(xhat, gamma, inv_std)
+        ctx.train = train
+        ctx.stats = (mean.detach(), inv_std.detach())
+        return xhat * gamma[None, :, None, None] + beta[None, :, None, None]
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat, gamma, inv_std = ctx.saved_tensors
+        dbeta = g.sum(dim=(0, 2, 3))
+        dgamma = (g * xhat).sum(dim=(0, 2, 3))
+        M = g.shape[0] * g.shape[2] * g.shape[3]
+        s = (gamma * inv_std)[None, :, None, None]
+        if ctx.train:
+            dv = s * (g - (dbeta / M)[None, :, None, None] - xhat * (dgamma / M)[None, :, None, None])
+        else:
+            dv = s * g
+        return dv, None, dgamma, dbeta, None, None, None
+
+
 def _relu(a, mask=None):
     """T.maximum(a, 0); with `mask` the pass / block decision of every element is the given one (value a where it passes,
     gradient 1 there): pins the ReLU pattern of a float32 evaluation when comparing gradients, see forward()."""
     return torch.clamp_min(a, 0) if mask is None else a * mask.to(a.dtype)
 
 
-def forward(net, T, x, train, masks=None, quant=None):
-    """quant (optional): {layer index of a 'conv' / 'fc' layer: dict(fwd=, dgrad=, wgrad=, pin=)} -- the layers whose products run
+def forward(net, T, x, train, masks=None, quant=None, store=None):
+    """store (optional): the bf16 STORAGE mode -- a dict {layer index: pin or None} naming every layer whose materialised output the
+    device holds as bfloat16: the stem ('convpool') and every 'conv' (for a conv fused into a residual add the tensor is the SUM, see
+    oracle.nets.fused_convs).  The value is the device's own stored tensor (NCHW, bf16 values as float32) when the comparison pins it
+    -- a float32 and a float64 evaluation of v round to different bfloat16 neighbours for a few elements in 1e4, and one flip is worth
+    a hundred float32 rounding errors (the reason for `pin` in _QBilinear) -- or None: round here.  Statistics come from the unrounded
+    value, see _StoredBN.  `stored_out` of the returned stats dict collects what this evaluation would have stored (unpinned), so
+    that a test can ALSO check the pins themselves against it.
+    quant (optional): {layer index of a 'conv' / 'fc' layer: dict(fwd=, dgrad=, wgrad=, pin=)} -- the layers whose products run
     on bf16 operands, see _QBilinear.
     masks (optional): {layer index: bool array} -- for a 'relu' layer or an 'fc' layer with ReLU the elements that pass,
     for a 'convpool' layer with pooling the tie pattern [N][C][oh][ow][ph*pw] of the windows (and, under the key
@@ -121,6 +164,20 @@ def forward(net, T, x, train, masks=None, quant=None):
     vals, stats = {}, {}
     masks = masks or {}
     quant = quant or {}
+    raw, memo, own_round = {}, {}, {}
+    fused = set()
+    if store is not None:
+        from oracle.nets import fused_convs
+        fused = fused_convs(net)
+
+    def keep(key, i, v):
+        """Materialise v as layer i's stored tensor: forward value = the rounded one (pinned or own), gradient straight through."""
+        own = bf16r(v)
+        own_round[i] = own
+        pin = store.get(i)
+        y = own if pin is None else torch.as_tensor(np.asarray(pin)).to(v.dtype)
+        raw[key] = v
+        return v + (y - v).detach()
 
     def qd(i):
         q = quant.get(i)
@@ -142,7 +199,12 @@ def forward(net, T, x, train, masks=None, quant=None):
         if ref[0] == 'layer':
             return vals[ref[1]]
         if ref[0] == 'add':
-            return get(ref[1]) + get(ref[2])
+            if store is None:
+                return get(ref[1]) + get(ref[2])
+            if ref not in memo:                              # one tensor, however many consumers: rounded once
+                cand = [r[1] for r in ref[1:] if r[0] == 'layer' and r[1] in fused]
+                memo[ref] = keep(ref, max(cand), get(ref[1]) + get(ref[2]))
+            return memo[ref]
         if ref[0] == 'flatten':
             return get(ref[1]).flatten(1)
         if ref[0] == 'concat':
@@ -163,6 +225,8 @@ def forward(net, T, x, train, masks=None, quant=None):
                 c = _MaxPoolTies.apply(c, ph, pw, ties)
             c = c + T[i][1][None, :, None, None]
             vals[i] = _relu(c, mk(('relu', i))) if l['act'] == 'relu' else c
+            if store is not None and i in store:
+                vals[i] = keep(('layer', i), i, vals[i])
         elif k == 'conv':
             q = qd(i)
             if q is None:
@@ -170,8 +234,17 @@ def forward(net, T, x, train, masks=None, quant=None):
             else:
                 c = _QBilinear.apply(a, T[i][0], (lambda u, w, l=l: _conv(u, w, l['stride'], l['border'])), q)
             vals[i] = c + T[i][1][None, :, None, None]
+            if store is not None and i in store and i not in fused:
+                vals[i] = keep(('layer', i), i, vals[i])
         elif k == 'bn':
             beta, gamma, rm, ris = T[i]
+            if store is not None and l['src'] in raw:
+                fn = _StoredBN.apply(raw[l['src']], a.detach(), gamma, beta, rm, ris, bool(train))
+                if train:
+                    v_ = raw[l['src']].detach()
+                    stats[i] = (v_.mean(dim=(0, 2, 3)), 1.0 / torch.sqrt(v_.var(dim=(0, 2, 3), unbiased=False) + BN_EPS))
+                vals[i] = fn
+                continue
             if train:
                 mean = a.mean(dim=(0, 2, 3))
                 var = a.var(dim=(0, 2, 3), unbiased=False)
@@ -191,15 +264,20 @@ def forward(net, T, x, train, masks=None, quant=None):
             vals[i] = a * float(np.float32(1.0 - l['p'])) if not train else a   # masks not modelled here
         else:
             raise NotImplementedError(k)
+    if store is not None:
+        stats['stored_out'] = {i: t.detach().numpy() for i, t in own_round.items()}
     return get(net['out']), stats
 
 
-def cost_and_grads(net, P, x, y, dtype=torch.float64, masks=None, quant=None):
-    """Returns (cost, {layer: [g0, g1]}, out) with autograd gradients (numpy arrays); `masks`, `quant`: see forward()."""
+def cost_and_grads(net, P, x, y, dtype=torch.float64, masks=None, quant=None, store=None, stored_out=None):
+    """Returns (cost, {layer: [g0, g1]}, out) with autograd gradients (numpy arrays); `masks`, `quant`, `store`: see forward().
+    stored_out (a dict, optional) receives forward()'s own roundings of the stored tensors."""
     T = to_torch(P, dtype)
     xt = [torch.as_tensor(a, dtype=dtype) for a in x] if isinstance(x, (list, tuple)) else torch.tensor(x, dtype=dtype)
     yt = torch.tensor(y, dtype=dtype)
-    out, _ = forward(net, T, xt, True, masks, quant)
+    out, st = forward(net, T, xt, True, masks, quant, store)
+    if stored_out is not None and store is not None:
+        stored_out.update(st['stored_out'])
     cost = ((out - yt) ** 2).sum(dim=1).mean()
     cost.backward()
     G = {i: [T[i][0].grad.numpy(), T[i][1].grad.numpy()] for i in T}

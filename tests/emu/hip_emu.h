@@ -326,6 +326,8 @@ static inline int __float2int_rn(float x) { return (int)lrintf(x); }
 static inline int __double2int_rn(double x) { return (int)lrint(x); }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }

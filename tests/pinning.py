@@ -9,6 +9,11 @@ def _layer_index(net):
     return {id(l): i for i, l in enumerate(net.layers)}
 
 
+def _f32(t):
+    """A device tensor's values as float32, whatever its storage (bf16-stored activation tensors widen exactly)."""
+    return t.get_f32() if hasattr(t, 'get_f32') else t.buf.get()
+
+
 def device_masks(eng, net):
     idx = _layer_index(net)
     masks = {}
@@ -17,7 +22,7 @@ def device_masks(eng, net):
             v = eng._memo[id(var)]
             if not v.relu:
                 continue
-            x = v.base.buf.get()                                  # NHWC (or [N][D]) pre-activation tensor
+            x = _f32(v.base)                                      # NHWC (or [N][D]) pre-activation tensor
             if v.bn is not None:
                 C = v.bn.C
                 mean, scale, beta = (b.get()[:C] for b in (v.bn.mean, v.bn.scale, v.bn.beta_buf))
@@ -32,7 +37,7 @@ def device_masks(eng, net):
             # output is the pre-activation
             lay = var.inputs[0].layer
             io = eng.layer_io[id(lay)]
-            pre = io['out'].buf.get()
+            pre = _f32(io['out'])
             m = pre >= 0
             if lay.__class__.__name__ == 'HiddenLayer':
                 masks[idx[id(lay)]] = m
@@ -59,7 +64,7 @@ def _activated_operand(view):
     """The float32 value the kernels form from a (base tensor, pending BatchNorm, pending ReLU) view while they stage it, NCHW (or
     [N][D] for a flattened view): (x - mean) in float32, then ONE fused multiply-add with scale / beta, then the ReLU -- the
     arithmetic of dpp_act4 (csrc/dpp_common.h), reproduced with exact float64 products rounded once."""
-    x = view.base.buf.get().astype(np.float32)
+    x = _f32(view.base).astype(np.float32)
     if view.bn is not None:
         C = view.bn.C
         mean, scale, beta = (b.get()[:C].astype(np.float32) for b in (view.bn.mean, view.bn.scale, view.bn.beta_buf))
@@ -104,3 +109,23 @@ def device_quant(eng, net):
             g = io['out'].grad.get().astype(np.float32)
             q['pin_dy'] = L.bf16_round(np.ascontiguousarray(np.moveaxis(g, -1, 1)) if g.ndim == 4 else g)
     return quant
+
+
+# ---- bf16 STORAGE (BASELINE config 5, ABI v9) -----------------------------------------------------------------------------------
+def device_store(eng, net, pin=True):
+    """The layers whose materialised output the compiled net holds as bfloat16, in the form oracle.torch_ref.forward takes as `store`:
+    {layer index: the device's stored tensor as float32 NCHW} (pin=False: {layer index: None}, the oracle rounds by itself)."""
+    store = {}
+    for i, l in enumerate(net.layers):
+        io = eng.layer_io.get(id(l))
+        if io is None or not getattr(io.get('out'), 'is16', False):
+            continue
+        store[i] = np.ascontiguousarray(np.moveaxis(io['out'].get_f32(), -1, 1)) if pin else None
+    return store
+
+
+def store_agreement(store, stored_out):
+    """Per layer, the fraction of elements where the oracle's OWN rounding of the tensor it would have stored equals the device's
+    stored tensor (the pin): the un-pinned check of the pins themselves.  A float32 and a float64 evaluation of the same value land on
+    different bfloat16 neighbours only when it sits within float32 round-off of a rounding boundary."""
+    return {i: float((np.asarray(stored_out[i], np.float32) == np.asarray(p, np.float32)).mean()) for i, p in store.items() if p is not None}

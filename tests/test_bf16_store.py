@@ -1,0 +1,310 @@
+"""bf16 STORAGE of activation tensors (ABI v9, DPP_ST_*; BASELINE config 5) at the kernel level.
+
+The contract is crisp, so the tests are exact: a kernel that READS a bf16-stored tensor must give, bit for bit, what the same kernel
+gives on the float32 tensor holding the widened values; a kernel that WRITES one must leave round-to-nearest-even(bfloat16) of the
+float32 value the float32 kernel writes -- and its fused BatchNorm statistics must be those of the UNROUNDED values (identical to the
+float32 kernel's).  Every entry point that can see an activation tensor is covered: the four dpp_gemm kernels (generic tile, K-split,
+16-column stream, wave-autonomous strips) in forward / data-gradient / filter-gradient roles, dpp_conv3x3 (f32 and bf16 operands) and
+its two filter-gradient kernels, the 1x1 / FC filter-gradient streams, dpp_fc_gemm on both of its kernels, the BatchNorm kernels and
+the stem."""
+import numpy as np
+import pytest
+
+from hipdp import ops
+from hipdp.lib import Act
+from tests.backends import BACKENDS, get_runtime
+
+
+def bf16_bits(a):
+    """float32 -> bfloat16 bit patterns (uint16), round to nearest even."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) & 0xFFFF).astype(np.uint16)
+
+
+def widen(bits):
+    return (np.ascontiguousarray(bits, np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def both(rt, a):
+    """(buffer holding `a` rounded to bf16 as bf16 bits, float32 buffer holding the same values widened)"""
+    b = bf16_bits(a)
+    return rt.upload(b), rt.upload(widen(b).reshape(np.shape(a)))
+
+
+class _BN(object):
+    pass
+
+
+def _bn_coeffs(rt, rng, C):
+    bn = _BN()
+    vals = (rng.normal(0, 0.3, C), rng.uniform(0.5, 1.5, C), rng.normal(0, 0.3, C), rng.uniform(0.5, 1.5, C))
+    bn.mean, bn.scale, bn.beta_buf, bn.inv_std = (rt.upload(v.astype(np.float32)) for v in vals)
+    return bn
+
+
+FWD_CASES = [  # (K, N, M, tile, variant)
+    (64, 32, 128, (64, 32, 4), 0), (64, 64, 128, (64, 64, 4), 0), (16, 64, 256, (64, 16, 4), 0), (40, 24, 100, (0, 0, 0), 0),
+    (256, 64, 96, (32, 64, 4), 2), (128, 32, 96, (32, 32, 4), 2), (64, 16, 128, (128, 16, 4), 3),
+    (64, 256, 96, (32, 64, 4), 4), (32, 128, 128, (64, 64, 4), 4), (16, 64, 256, (128, 64, 4), 4)]
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', FWD_CASES)
+def test_gemm_forward_reads_and_writes_bf16_tensors(backend, cfg):
+    """1x1 convolution forward: A (with the BatchNorm + ReLU prologue), the residual and the output bf16-stored."""
+    rt = get_runtime(backend)
+    K, N, M, tile, variant = cfg
+    rng = np.random.RandomState(61)
+    X16, X32 = both(rt, rng.normal(size=(M, K)) * 2 + 1)
+    R16, R32 = both(rt, rng.normal(size=(M, N)))
+    Wk = rt.upload((rng.normal(size=(N, K)) * 0.3).astype(np.float32))
+    mean, scale, beta = (rt.upload(rng.normal(size=K).astype(np.float32)) for _ in range(3))
+    bias = rt.upload(rng.normal(size=N).astype(np.float32))
+    rows = tile[0] if tile[0] else 64
+    nblk = -(-M // rows)
+    out = {}
+    for tag, X, R, dt in (('f32', X32, R32, np.float32), ('bf16', X16, R16, np.uint16)):
+        Y = rt.alloc((M, N), dt, zero=False)
+        stats = rt.alloc((nblk, 2, N), zero=False) if tile[0] else None
+        L = ops.gemm(rt, X, Wk, Y, M, N, K, 1, 1, K, K, N, actA=ops.act(Act.BN_RELU, mean, scale, beta, K), bias=bias, residual=R, tile=tile,
+                     variant=variant, epi=ops.epilogue(stats=stats) if stats is not None else None)
+        if variant:
+            assert ops.gemm_variant_rows(rt, L) == tile[0], "variant %d refuses the %s layout" % (variant, tag)
+        L(rt.stream)
+        rt.synchronize()
+        out[tag] = (Y.get(), stats.get() if stats is not None else None)
+    assert np.array_equal(out['bf16'][0], bf16_bits(out['f32'][0]))
+    if out['f32'][1] is not None:
+        assert np.array_equal(out['bf16'][1], out['f32'][1])           # statistics of the UNROUNDED values
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(64, 32, 128, (64, 32, 4), 0), (256, 64, 96, (32, 64, 4), 2), (16, 64, 128, (64, 64, 4), 3), (64, 256, 96, (32, 64, 4), 4),
+                                 (32, 128, 128, (64, 64, 4), 4)])
+def test_gemm_data_gradient_reads_a_bf16_batchnorm_input(backend, cfg):
+    """Data gradient with the fused BatchNorm-backward epilogue: bn_x is the (bf16-stored) forward tensor, everything else float32."""
+    rt = get_runtime(backend)
+    K, N, M, tile, variant = cfg
+    rng = np.random.RandomState(62)
+    dY = rt.upload(rng.normal(size=(M, K)).astype(np.float32))
+    W2 = rt.upload((rng.normal(size=(K, N)) * 0.3).astype(np.float32))
+    share = rng.normal(size=(M, N)).astype(np.float32)
+    bx16, bx32 = both(rt, rng.normal(size=(M, N)))
+    bn = _bn_coeffs(rt, rng, N)
+    nb = M // tile[0]
+    out = {}
+    for tag, bx in (('f32', bx32), ('bf16', bx16)):
+        dH = rt.upload(share)
+        part = rt.alloc((nb, 2, N), zero=False)
+        L = ops.gemm(rt, dY, W2, dH, M, N, K, 1, 0, K, N, N, residual=dH, tile=tile, variant=variant,
+                     epi=ops.epilogue(bn=bn, bn_x=bx, bn_relu=True, bn_partial=part))
+        if variant:
+            assert ops.gemm_variant_rows(rt, L) == tile[0]
+        L(rt.stream)
+        rt.synchronize()
+        out[tag] = (dH.get(), part.get())
+    assert np.array_equal(out['bf16'][0], out['f32'][0]) and np.array_equal(out['bf16'][1], out['f32'][1])
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(16, 64, 256, 1), (64, 16, 256, 1), (64, 256, 128, 1), (32, 128, 192, 2), (24, 40, 100, 1)])
+def test_filter_gradients_read_bf16_activations(backend, cfg):
+    """dW = dY^T . act(X) with X bf16-stored: the generic split-K layout of dpp_gemm and the row stream of dpp_wgrad_stream."""
+    rt = get_runtime(backend)
+    Co, Ci, M, stride = cfg
+    rng = np.random.RandomState(63)
+    rows = M * stride * stride
+    X16, X32 = both(rt, rng.normal(size=(rows, Ci)) + 0.5)
+    dY = rt.upload(rng.normal(size=(M, Co)).astype(np.float32))
+    mean, scale, beta = (rt.upload(rng.normal(size=Ci).astype(np.float32)) for _ in range(3))
+    act = ops.act(Act.BN_RELU, mean, scale, beta, Ci)
+    mp = None
+    if stride == 2:
+        from hipdp.lib import RowMap
+        Ho = Wo = int(round((M // 3) ** 0.5))
+        assert 3 * Ho * Wo == M
+        mp = RowMap.strided(2, Ho, Wo, 2 * Ho, 2 * Wo)
+    got = {}
+    for tag, X in (('f32', X32), ('bf16', X16)):
+        part = rt.alloc((3, Co, Ci), zero=False)
+        ops.gemm(rt, dY, X, None, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actB=act, splitk=3, partial=part)(rt.stream)
+        res = [part]
+        nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, 32)
+        if nsl > 0:
+            p2 = rt.alloc((nsl, Co, Ci), zero=False)
+            ops.wgrad_stream(rt, dY, Co, X, Ci, M, 32, p2, mapX=mp, actX=act)(rt.stream)
+            res.append(p2)
+        rt.synchronize()
+        got[tag] = [r.get() for r in res]
+    assert all(np.array_equal(a, b) for a, b in zip(got['bf16'], got['f32']))
+    assert np.abs(got['f32'][0]).max() > 0.1
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 64, 64, 64), (3, 16, 16, 16, 16, 64), (2, 12, 20, 32, 32, 128), (1, 8, 8, 64, 32, 64)])
+@pytest.mark.parametrize('precision', [0, 1])
+def test_conv3x3_on_bf16_stored_tensors(backend, cfg, precision):
+    """dpp_conv3x3 / dpp_conv3x3_bf16: forward with bf16 X, residual and Y (+ fused statistics); data gradient reading a bf16 bn_x;
+    both filter-gradient kernels reading a bf16 X."""
+    rt = get_runtime(backend)
+    N, H, W, Ci, Co, bm = cfg
+    rng = np.random.RandomState(64)
+    X16, X32 = both(rt, rng.normal(size=(N, H, W, Ci)) + 0.3)
+    R16, R32 = both(rt, rng.normal(size=(N, H, W, Co)))
+    Wk = rt.upload((rng.normal(size=(Co, 9, Ci)) * 0.2).astype(np.float32))
+    bias = rt.upload(rng.normal(size=Co).astype(np.float32))
+    mean, scale, beta = (rt.upload(v.astype(np.float32)) for v in (rng.normal(size=Ci) * 0.3, rng.uniform(0.5, 1.5, Ci), rng.normal(size=Ci) * 0.3))
+    act = ops.act(Act.BN_RELU, mean, scale, beta, Ci)
+    th, tw, img = (__import__('ctypes').c_int() for _ in range(3))
+    nblk = rt.lib.dpp_conv3x3_tiling(N, H, W, bm, th, tw, img)
+    full = H % th.value == 0 and W % tw.value == 0 and (N % img.value == 0 or nblk == 1)
+    out = {}
+    for tag, X, R, dt in (('f32', X32, R32, np.float32), ('bf16', X16, R16, np.uint16)):
+        Y = rt.alloc((N, H, W, Co), dt, zero=False)
+        stats = rt.alloc((nblk, 2, Co), zero=False) if full else None
+        ops.conv3x3(rt, X, N, H, W, Ci, Wk, Co, Y, actX=act, bias=bias, residual=R, bm=bm, epi=ops.epilogue(stats=stats) if full else None,
+                    precision=precision)(rt.stream)
+        rt.synchronize()
+        out[tag] = (Y.get(), stats.get() if full else None)
+    assert np.array_equal(out['bf16'][0], bf16_bits(out['f32'][0]))
+    if full:
+        assert np.array_equal(out['bf16'][1], out['f32'][1])
+    # data gradient: dY f32 -> dX f32, the epilogue reads the bf16-stored BatchNorm input of the layer below
+    dY = rt.upload(rng.normal(size=(N, H, W, Co)).astype(np.float32))
+    Wd = rt.alloc((Ci, 9, Co), zero=False)
+    ops.conv3x3_wtrans(rt, Wk, Co, Ci, Wd)(rt.stream)
+    bn = _bn_coeffs(rt, rng, Ci)
+    nb2 = rt.lib.dpp_conv3x3_tiling(N, H, W, bm, None, None, None)
+    got = {}
+    for tag, bx in (('f32', X32), ('bf16', X16)):
+        dX = rt.alloc((N, H, W, Ci), zero=False)
+        part = rt.alloc((nb2, 2, Ci), zero=False)
+        ops.conv3x3(rt, dY, N, H, W, Co, Wd, Ci, dX, bm=bm, epi=ops.epilogue(bn=bn, bn_x=bx, bn_relu=True, bn_partial=part), precision=precision)(rt.stream)
+        rt.synchronize()
+        got[tag] = (dX.get(), part.get())
+    assert np.array_equal(got['bf16'][0], got['f32'][0]) and np.array_equal(got['bf16'][1], got['f32'][1])
+    if precision:
+        return
+    # filter gradients (f32 MFMA in both modes): LDS-tiled kernel and row stream
+    wg = {}
+    for tag, X in (('f32', X32), ('bf16', X16)):
+        nb3 = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, Ci, Co, 64)
+        part = rt.alloc((nb3, Co, 9, Ci), zero=False)
+        ops.conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, part, actX=act, bm=64)(rt.stream)
+        res = [part]
+        nsl = rt.lib.dpp_wgrad3_stream_slices(Co, Ci, N, H, W, 20)
+        if nsl > 0:
+            p2 = rt.alloc((nsl, Co, 9, Ci), zero=False)
+            ops.wgrad3_stream(rt, dY, Co, X, Ci, N, H, W, 20, p2, actX=act)(rt.stream)
+            res.append(p2)
+        rt.synchronize()
+        wg[tag] = [r.get() for r in res]
+    assert all(np.array_equal(a, b) for a, b in zip(wg['bf16'], wg['f32']))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('precision', [0, 1])
+@pytest.mark.parametrize('shape', [(128, 128, 1024), (24, 40, 200)])
+def test_fc1_reads_a_bf16_stored_map(backend, precision, shape):
+    """The HiddenLayer behind the last conv map: forward (A = the flattened bf16 map with its BatchNorm + ReLU prologue) on both kernels
+    of dpp_fc_gemm (whole 128-row tiles: the three-stage stream; ragged: the double-buffered one), the weight gradient on dpp_fc_gemm
+    (A = X^T) and on dpp_fc_wgrad_stream."""
+    rt = get_runtime(backend)
+    Nb, Nout, K = shape
+    Cc = 8 if K == 200 else 32
+    rng = np.random.RandomState(65)
+    X16, X32 = both(rt, rng.normal(size=(Nb, K)) + 0.2)
+    Wm = rt.upload((rng.normal(size=(K, Nout)) * 0.1).astype(np.float32))
+    mean, scale, beta = (rt.upload(rng.normal(size=Cc).astype(np.float32)) for _ in range(3))
+    act = ops.act(Act.BN_RELU, mean, scale, beta, Cc)
+    bias = rt.upload(rng.normal(size=Nout).astype(np.float32))
+    dY = rt.upload(rng.normal(size=(Nb, Nout)).astype(np.float32))
+    got = {}
+    for tag, X in (('f32', X32), ('bf16', X16)):
+        Y = rt.alloc((Nb, Nout), zero=False)
+        ops.fc_gemm(rt, X, Wm, Y, Nb, Nout, K, 1, 0, K, Nout, Nout, actA=act, bias=bias, precision=precision)(rt.stream)
+        dW = rt.alloc((K, Nout), zero=False)
+        ops.fc_gemm(rt, X, dY, dW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, precision=precision)(rt.stream)
+        res = [Y, dW]
+        if precision == 0 and rt.lib.dpp_fc_wgrad_stream_ok(Nb, K, Nout):
+            dW2 = rt.alloc((K, Nout), zero=False)
+            ops.fc_wgrad_stream(rt, X, dY, dW2, Nb, K, Nout, actX=act)(rt.stream)
+            res.append(dW2)
+        # and the generic dpp_gemm (what batches that are no multiple of 128 take)
+        Y2 = rt.alloc((Nb, Nout), zero=False)
+        ops.gemm(rt, X, Wm, Y2, Nb, Nout, K, 1, 0, K, Nout, Nout, actA=act, bias=bias)(rt.stream)
+        res.append(Y2)
+        rt.synchronize()
+        got[tag] = [r.get() for r in res]
+    assert all(np.array_equal(a, b) for a, b in zip(got['bf16'], got['f32']))
+    assert np.abs(got['f32'][0]).max() > 0.1
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(96, 16, 32), (200, 64, 48), (64, 256, 32)])
+def test_batchnorm_kernels_read_bf16_tensors(backend, cfg):
+    """bn_stats_partial (the non-fused statistics path), bn_bwd_reduce and bn_bwd_apply on a bf16-stored x."""
+    rt = get_runtime(backend)
+    M, Cc, rpb = cfg
+    rng = np.random.RandomState(66)
+    x16, x32 = both(rt, rng.normal(size=(M, Cc)) * 1.5 + 3.0)
+    nb = -(-M // rpb)
+    bn = _bn_coeffs(rt, rng, Cc)
+    c1, c2 = (rt.upload((rng.normal(size=Cc) * 0.1).astype(np.float32)) for _ in range(2))
+    dA = rt.upload(rng.normal(size=(M, Cc)).astype(np.float32))
+    add = rt.upload(rng.normal(size=(M, Cc)).astype(np.float32))
+    got = {}
+    for tag, x in (('f32', x32), ('bf16', x16)):
+        part = rt.alloc((nb, 2, Cc), zero=False)
+        ops.bn_stats_partial(rt, x, M, Cc, rpb, part)(rt.stream)
+        G, part2 = rt.alloc((M, Cc), zero=False), rt.alloc((nb, 2, Cc), zero=False)
+        ops.bn_bwd_reduce(rt, dA, x, M, Cc, bn.mean, bn.inv_std, bn.scale, bn.beta_buf, 1, G, rpb, part2)(rt.stream)
+        dX, cs = rt.alloc((M, Cc), zero=False), rt.alloc((nb, Cc), zero=False)
+        ops.bn_bwd_apply(rt, G, x, M, Cc, bn.mean, bn.inv_std, bn.scale, c1, c2, dX, add=add, rpb=rpb, colsum=cs)(rt.stream)
+        rt.synchronize()
+        got[tag] = [b.get() for b in (part, G, part2, dX, cs)]
+    assert all(np.array_equal(a, b) for a, b in zip(got['bf16'], got['f32']))
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_stem_writes_a_bf16_tensor(backend):
+    rt = get_runtime(backend)
+    N, H, W, Co = 2, 32, 32, 32
+    rng = np.random.RandomState(67)
+    x = rng.uniform(-1, 1, size=(N, H, W)).astype(np.float32)
+    x[:, :, W // 2:] = 1.0
+    X, Wk, b = rt.upload(x), rt.upload((rng.normal(size=(Co, 25)) * 0.3).astype(np.float32)), rt.upload(rng.normal(size=Co).astype(np.float32))
+    out = {}
+    for tag, dt in (('f32', np.float32), ('bf16', np.uint16)):
+        Y = rt.alloc((N, H // 2, W // 2, Co), dt, zero=False)
+        arg = rt.alloc((N, H // 2, W // 2, Co), np.uint8, zero=False)
+        stats = rt.alloc((N * 4, 2, Co), zero=False)
+        ops.stem_fwd(rt, X, N, H, W, Wk, b, Co, Y, arg, stats)(rt.stream)
+        rt.synchronize()
+        out[tag] = (Y.get(), arg.get(), stats.get())
+    assert np.array_equal(out['bf16'][0], bf16_bits(out['f32'][0]))
+    assert np.array_equal(out['bf16'][1], out['f32'][1]) and np.array_equal(out['bf16'][2], out['f32'][2])
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_unsupported_storage_combinations_are_refused(backend):
+    """What the kernels do not take in the storage mode is refused, not mis-read: mixed C / residual storage, the mode-4 operand,
+    a bf16 B operand on the variants, unknown bits."""
+    rt = get_runtime(backend)
+    M, N, K = 64, 64, 64
+    A16 = rt.alloc((M, K), np.uint16)
+    A32, Wk = rt.alloc((M, K)), rt.alloc((N, K))
+    Y16, Y32 = rt.alloc((M, N), np.uint16), rt.alloc((M, N))
+    with pytest.raises(ValueError):
+        ops.gemm(rt, A32, Wk, Y16, M, N, K, 1, 1, K, K, N, residual=Y32)
+    L = ops.gemm(rt, A32, rt.alloc((N, K), np.uint16), Y32, M, N, K, 1, 1, K, K, N, tile=(32, 64, 4), variant=4)
+    assert ops.gemm_variant_rows(rt, L) == 0
+    L = ops.gemm(rt, A16, Wk, Y32, M, N, K, 1, 1, K, K, N)
+    L.keep[0].store = 64
+    with pytest.raises(Exception):
+        L(rt.stream)
+    bn = _BN()
+    bn.mean, bn.scale = rt.alloc(K), rt.alloc(K)
+    L = ops.gemm(rt, A16, rt.alloc((K, N)), Y32, M, N, K, 1, 0, K, N, N, actA=ops.act_bn_bwd(bn, rt.alloc(K), rt.alloc(K), rt.alloc((M, K)), K))
+    with pytest.raises(Exception):
+        L(rt.stream)

@@ -318,13 +318,22 @@ def bf16_gradients_vs_pinned_oracle(rt, net, onet, P, x, y, bar=2e-4):
     bfloat16 in each of the three passes (oracle/torch_ref.py:_QBilinear, configured from the net's own launches by
     tests/pinning.py:device_quant) on the device's own ReLU / pooling decisions and rounded forward operands: forward output at the
     1e-3 mm bar, cost at 1e-5, every parameter gradient at `bar` of its tensor's scale -- the bars of the fp32 path."""
-    from tests.pinning import device_quant
+    from tests.pinning import device_quant, device_store, store_agreement
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), bf16=True)
     cost, out = eng.cost_and_grads(x, y)
     quant = device_quant(eng, net)
     assert any(q['fwd'] for q in quant.values()) and any(q['dgrad'] for q in quant.values())
+    # bf16 STORAGE (the default of the bf16 mode): the device's own stored tensors are pinned like its rounded MFMA operands ...
+    store = device_store(eng, net) if eng.store16 else None
+    assert (store is not None and len(store) >= 10) == bool(engine.BF16_STORE)
+    own = {}
     c_ref, G_ref, out_ref = torch_ref.cost_and_grads(onet, nets.cast_params(P, np.float64), x.astype(np.float64), y.astype(np.float64),
-                                                     masks=device_masks(eng, net), quant=quant)
+                                                     masks=device_masks(eng, net), quant=quant, store=store, stored_out=own)
+    if store is not None:
+        # ... and the pins themselves are checked WITHOUT pinning: the float64 oracle's own rounding of what it would have stored equals
+        # the device's stored tensor everywhere except where the value sits within float32 round-off of a bfloat16 rounding boundary
+        agree = store_agreement(store, own)
+        assert min(agree.values()) >= 0.998 and np.mean(list(agree.values())) >= 0.9995, sorted(agree.items(), key=lambda kv: kv[1])[:4]
     assert np.abs(out - out_ref).max() * MM < 1e-3, np.abs(out - out_ref).max() * MM
     assert abs(cost - c_ref) < 1e-5 * abs(c_ref)
     G = grads_from_store(eng, net)

@@ -99,7 +99,7 @@ def test_stem_fwd_and_wgrad(backend, cfg):
         np.testing.assert_allclose(mean.get(), yv.mean(0), rtol=0, atol=1e-6 * np.abs(yv).max())
         np.testing.assert_allclose(istd.get(), 1.0 / np.sqrt(yv.var(0) + 1e-4), rtol=1e-5)
     else:
-        assert rt.lib.dpp_stem_fwd(d['X'].ptr, N, H, W, d['Wk'].ptr, d['b'].ptr, Co, Y.ptr, arg.ptr, rt.alloc((4, 2, Co)).ptr, rt.stream) != 0
+        assert rt.lib.dpp_stem_fwd(d['X'].ptr, N, H, W, d['Wk'].ptr, d['b'].ptr, Co, Y.ptr, arg.ptr, rt.alloc((4, 2, Co)).ptr, 0, rt.stream) != 0
     # the tie mask agrees with the oracle wherever the oracle's window is either clearly decided or exactly tied
     cshape, ties_ref, _ = cache
     c = L.conv2d_fwd(x, Wr, None, (1, 1), 'half')
