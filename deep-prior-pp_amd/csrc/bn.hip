@@ -201,11 +201,13 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_eval_coeffs_kernel(const float
 
 // G = dA * [bn(x) >= 0]  (Theano's Maximum.grad passes the gradient where out == x, i.e. v >= 0) and the
 // per-block partial sums of  sum(G), sum(G * xhat)  needed by the BN backward.
-template <class TX>
-__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float* dA, const TX* __restrict__ X, int M, int C,
+// TG: element type of the gradient tensors dA / G (float, or dpp_bf16 when the gradients of the activation tensors are bf16-stored too:
+// G is rounded on the store, the sums are those of the unrounded values)
+template <class TX, class TG>
+__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const TG* dA, const TX* __restrict__ X, int M, int C,
                                                                     const float* __restrict__ mean, const float* __restrict__ inv_std,
                                                                     const float* __restrict__ scale, const float* __restrict__ beta,
-                                                                    int relu, float* G, int rpb, float* __restrict__ partial) {
+                                                                    int relu, TG* G, int rpb, float* __restrict__ partial) {
     dpp_kernarg_warm<128>();
     __shared__ float s_a[DPP_THREADS * 4];
     __shared__ float s_b[DPP_THREADS * 4];
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float*
         for (int r = r_begin + rr; r < r_end; r += RP) {
             size_t o = (size_t)r * C + q * 4;
             float4 x = dpp_ld4(X + o);
-            float4 g = *reinterpret_cast<const float4*>(dA + o);
+            float4 g = dpp_ld4(dA + o);
             float dx = x.x - mu.x, dy = x.y - mu.y, dz = x.z - mu.z, dw = x.w - mu.w;
             if (relu) {
                 if (dx * sc.x + be.x < 0.0f) g.x = 0.0f;
@@ -230,7 +232,10 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_reduce_kernel(const float*
                 if (dz * sc.z + be.z < 0.0f) g.z = 0.0f;
                 if (dw * sc.w + be.w < 0.0f) g.w = 0.0f;
             }
-            *reinterpret_cast<float4*>(G + o) = g;
+            dpp_st4(G + o, g);
+            if (sizeof(TG) == 2) {               // bf16-stored gradient: the sums are those of the values as stored (dpp_epilogue_wide)
+                g.x = dpp_bf16_round(g.x); g.y = dpp_bf16_round(g.y); g.z = dpp_bf16_round(g.z); g.w = dpp_bf16_round(g.w);
+            }
             sa.x += g.x; sa.y += g.y; sa.z += g.z; sa.w += g.w;
             sb.x += g.x * (dx * is.x); sb.y += g.y * (dy * is.y); sb.z += g.z * (dz * is.z); sb.w += g.w * (dw * is.w);
         }
@@ -298,12 +303,12 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_kernel(const floa
 // dX = scale * (G - c1 - xhat * c2) (+ add): gradient through the batch statistics.  Row-chunked like the reductions so
 // that the column sums of dX -- the bias gradient of the conv that produced X (T.grad of `+ b.dimshuffle`,
 // convlayer.py:238) -- can be emitted as per-block partials in the same pass (colsum != nullptr).
-template <class TX>
-__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ G, const TX* __restrict__ X,
+template <class TX, class TG, class TO>
+__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const TG* __restrict__ G, const TX* __restrict__ X,
                                                                    int M, int C, const float* __restrict__ mean,
                                                                    const float* __restrict__ inv_std, const float* __restrict__ scale,
                                                                    const float* __restrict__ c1, const float* __restrict__ c2,
-                                                                   const float* add, float* dX, int rpb, float* __restrict__ colsum) {
+                                                                   const TO* add, TO* dX, int rpb, float* __restrict__ colsum) {
     dpp_kernarg_warm<128>();
     __shared__ float s_a[DPP_THREADS * 4];
     const int Q = C >> 2, RP = DPP_THREADS / Q;
@@ -334,24 +339,28 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const float* 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const size_t i = (size_t)(r + u * RP) * Q + q;
-                g[u] = reinterpret_cast<const float4*>(G)[i];
+                g[u] = dpp_ld4(G + 4 * i);
                 x[u] = dpp_ld4(X + 4 * i);
-                o[u] = add ? reinterpret_cast<const float4*>(add)[i] : zero4;
+                o[u] = add ? dpp_ld4(add + 4 * i) : zero4;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const size_t i = (size_t)(r + u * RP) * Q + q;
                 o[u] = one(g[u], x[u], o[u]);
-                reinterpret_cast<float4*>(dX)[i] = o[u];
+                dpp_st4(dX + 4 * i, o[u]);
+                if (sizeof(TO) == 2) {                           // bf16-stored dX: the column sums (a bias gradient) are those of the values as stored
+                    o[u].x = dpp_bf16_round(o[u].x); o[u].y = dpp_bf16_round(o[u].y); o[u].z = dpp_bf16_round(o[u].z); o[u].w = dpp_bf16_round(o[u].w);
+                }
                 sa.x += o[u].x; sa.y += o[u].y; sa.z += o[u].z; sa.w += o[u].w;
             }
         }
         for (; r < r_end; r += RP) {
             const size_t i = (size_t)r * Q + q;
-            const float4 g = reinterpret_cast<const float4*>(G)[i];
+            const float4 g = dpp_ld4(G + 4 * i);
             const float4 x = dpp_ld4(X + 4 * i);
-            const float4 o = one(g, x, add ? reinterpret_cast<const float4*>(add)[i] : zero4);
-            reinterpret_cast<float4*>(dX)[i] = o;
+            float4 o = one(g, x, add ? dpp_ld4(add + 4 * i) : zero4);
+            dpp_st4(dX + 4 * i, o);
+            if (sizeof(TO) == 2) { o.x = dpp_bf16_round(o.x); o.y = dpp_bf16_round(o.y); o.z = dpp_bf16_round(o.z); o.w = dpp_bf16_round(o.w); }
             sa.x += o.x; sa.y += o.y; sa.z += o.z; sa.w += o.w;
         }
     }
@@ -407,14 +416,17 @@ extern "C" int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, con
 extern "C" int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, const float* mean, const float* inv_std,
                                  const float* scale, const float* beta, int relu, float* G, int rows_per_block, float* partial,
                                  int store, dpp_stream_t stream) {
-    if (!dA || !X || !G || !partial || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS || (store & ~DPP_ST_BNX)) return DPP_E_BADARG;
+    if (!dA || !X || !G || !partial || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS || (store & ~(DPP_ST_BNX | DPP_ST_A | DPP_ST_C)))
+        return DPP_E_BADARG;
+    const bool x16 = (store & DPP_ST_BNX) != 0, g16 = (store & DPP_ST_A) != 0;
+    if (g16 != ((store & DPP_ST_C) != 0)) return DPP_E_UNSUPPORTED;            // dA and G are stored alike (G usually overwrites dA)
     int nb = dpp_cdiv(M, rows_per_block);
-    if (store & DPP_ST_BNX)
-        DPP_LAUNCH(bn_bwd_reduce_kernel<dpp_bf16>, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dA,
-                   reinterpret_cast<const dpp_bf16*>(X), M, C, mean, inv_std, scale, beta, relu, G, rows_per_block, partial);
-    else
-        DPP_LAUNCH(bn_bwd_reduce_kernel<float>, dim3(nb), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), dA, X, M, C, mean,
-                   inv_std, scale, beta, relu, G, rows_per_block, partial);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define DPP_BR(TX_, TG_) DPP_LAUNCH((bn_bwd_reduce_kernel<TX_, TG_>), dim3(nb), dim3(DPP_THREADS), 0, st, reinterpret_cast<const TG_*>(dA), \
+                                    reinterpret_cast<const TX_*>(X), M, C, mean, inv_std, scale, beta, relu, reinterpret_cast<TG_*>(G), rows_per_block, partial)
+    if (x16) { if (g16) DPP_BR(dpp_bf16, dpp_bf16); else DPP_BR(dpp_bf16, float); }
+    else { if (g16) DPP_BR(float, dpp_bf16); else DPP_BR(float, float); }
+#undef DPP_BR
     return dpp_launch_status();
 }
 
@@ -433,12 +445,18 @@ extern "C" int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M
 extern "C" int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
                                 const float* scale, const float* c1, const float* c2, const float* add, float* dX,
                                 int rows_per_block, float* colsum_partial, int store, dpp_stream_t stream) {
-    if (!G || !X || !dX || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS || (store & ~DPP_ST_BNX)) return DPP_E_BADARG;
-    if (store & DPP_ST_BNX)
-        DPP_LAUNCH(bn_bwd_apply_kernel<dpp_bf16>, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), G,
-                   reinterpret_cast<const dpp_bf16*>(X), M, C, mean, inv_std, scale, c1, c2, add, dX, rows_per_block, colsum_partial);
-    else
-        DPP_LAUNCH(bn_bwd_apply_kernel<float>, dim3(dpp_cdiv(M, rows_per_block)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), G, X,
-                   M, C, mean, inv_std, scale, c1, c2, add, dX, rows_per_block, colsum_partial);
+    if (!G || !X || !dX || M < 1 || rows_per_block < 1 || !ok_c(C) || (C >> 2) > DPP_THREADS || (store & ~(DPP_ST_BNX | DPP_ST_A | DPP_ST_C)))
+        return DPP_E_BADARG;
+    const bool x16 = (store & DPP_ST_BNX) != 0, g16 = (store & DPP_ST_A) != 0, o16 = (store & DPP_ST_C) != 0;
+    const dim3 grid(dpp_cdiv(M, rows_per_block));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define DPP_BA(TX_, TG_, TO_) DPP_LAUNCH((bn_bwd_apply_kernel<TX_, TG_, TO_>), grid, dim3(DPP_THREADS), 0, st, reinterpret_cast<const TG_*>(G), \
+                                         reinterpret_cast<const TX_*>(X), M, C, mean, inv_std, scale, c1, c2, reinterpret_cast<const TO_*>(add), \
+                                         reinterpret_cast<TO_*>(dX), rows_per_block, colsum_partial)
+#define DPP_BA_O(TX_, TG_) do { if (o16) DPP_BA(TX_, TG_, dpp_bf16); else DPP_BA(TX_, TG_, float); } while (0)
+    if (x16) { if (g16) DPP_BA_O(dpp_bf16, dpp_bf16); else DPP_BA_O(dpp_bf16, float); }
+    else { if (g16) DPP_BA_O(float, dpp_bf16); else DPP_BA_O(float, float); }
+#undef DPP_BA_O
+#undef DPP_BA
     return dpp_launch_status();
 }

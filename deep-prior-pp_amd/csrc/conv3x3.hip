@@ -441,7 +441,7 @@ struct Wgrad3Args {
 };
 
 template <int BM, int MAXACC, class TX = float>
-__global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a) {
+__global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a, int y16) {
     dpp_kernarg_warm<sizeof(Wgrad3Args)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a
                     int n = n0 + im, y = y0 + ty, x = x0 + tx;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (im < a.img && n < a.N && y < a.H && x < a.W)
-                        v = *reinterpret_cast<const float4*>(a.dY + (((size_t)n * a.H + y) * a.W + x) * Co + c0);
+                        v = dpp_ld4_rt(a.dY, (((size_t)n * a.H + y) * a.W + x) * Co + c0, y16 != 0);     // (dY may be bf16-stored: DPP_ST_B)
                     *reinterpret_cast<float4*>(&Ys[row * LDY + c0]) = v;
                 }
             }
@@ -676,7 +676,8 @@ extern "C" int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int Ci, int Co, int
 
 extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
                                  float* partial, int bm, int store, dpp_stream_t stream) {
-    if (!X || !dY || !partial || N < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15) || (bm != 64 && bm != 128) || (store & ~DPP_ST_A)) return DPP_E_BADARG;
+    if (!X || !dY || !partial || N < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15) || (bm != 64 && bm != 128) || (store & ~(DPP_ST_A | DPP_ST_B))) return DPP_E_BADARG;
+    const int y16 = (store & DPP_ST_B) ? 1 : 0;
     Wgrad3Args a;
     a.X = X; a.N = N; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.dY = dY; a.partial = partial;
     if (act && (act->mode & 4)) return DPP_E_UNSUPPORTED;       // the two-tensor BatchNorm-backward operand is a dpp_gemm feature
@@ -701,7 +702,7 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define DPP_W3K(BM_, MA_, T_) do { \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<BM_, MA_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        DPP_LAUNCH((conv3x3_wgrad_kernel<BM_, MA_, T_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
+        DPP_LAUNCH((conv3x3_wgrad_kernel<BM_, MA_, T_>), grid, dim3(DPP_THREADS), lds, st, a, y16); return dpp_launch_status(); } while (0)
 #define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { if (store & DPP_ST_A) DPP_W3K(BM_, MA_, dpp_bf16); else DPP_W3K(BM_, MA_, float); }
     DPP_W3(128, 3) DPP_W3(128, 4) DPP_W3(128, 9) DPP_W3(128, 12) DPP_W3(128, 16)
     DPP_W3(64, 3) DPP_W3(64, 4) DPP_W3(64, 9) DPP_W3(64, 12) DPP_W3(64, 16)

@@ -363,6 +363,9 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
                 for (int j = 0; j < 4; ++j) {
                     float dx = x[j] - co.cmean[j];
                     if (ep.bn_relu && dx * co.cscale[j] + co.cbeta[j] < 0.0f) v[j] = 0.0f;
+                    // a bf16-stored gradient: the sums are those of the values AS STORED, so that the c1 / c2 bn_bwd_apply gets are
+                    // exactly the means of the G it reads (masked elements have dX = -scale (c1 + xhat c2): they see nothing else)
+                    if (c16) v[j] = dpp_bf16_round(v[j]);
                     sx[j] += v[j];
                     sy[j] += v[j] * (dx * co.cistd[j]);
                 }

@@ -879,6 +879,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga)
                 if (bn) {
                     const float dx = xr[t][ct][r] - cmean[ct];
                     if (ep.bn_relu && dx * cscale[ct] + cbeta[ct] < 0.0f) v = 0.0f;
+                    if (c16) v = dpp_bf16_round(v);          // bf16-stored gradient: sums of the values as stored (dpp_epilogue_wide)
                     sx[ct] += v;
                     sy[ct] += v * (dx * cistd[ct]);
                 }
@@ -1098,6 +1099,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
                     for (int j = 0; j < 4; ++j) {
                         const float dx = x[j] - cm[j];
                         if (relu_mask && dx * cs[j] + cb[j] < 0.0f) v[j] = 0.0f;
+                        if (c16) v[j] = dpp_bf16_round(v[j]);   // bf16-stored gradient: sums of the values as stored (dpp_epilogue_wide)
                         sx[j] += v[j];
                         sy[j] += v[j] * (dx * ci[j]);
                     }

@@ -63,7 +63,7 @@ __device__ __forceinline__ void load_vec(const float* p, float (&v)[V]) {
 
 // TA = Co / 16, TB = Ci / 16 (vector lengths of a full row per lane); the 4 waves split A channels WA ways, B channels WB ways and
 // rows WR = 4 / (WA * WB) ways.  VA = TA / WA, VB = TB / WB floats per lane and operand; VA * VB accumulator tiles per wave.
-template <int TA, int TB, int WA, int WB, int U, bool STRIDED, class TX = float>
+template <int TA, int TB, int WA, int WB, int U, bool STRIDED, class TX = float, class TY = float>
 __global__ __launch_bounds__(DPP_THREADS) void wgrad_stream_kernel(WgradArgs a) {
     constexpr int WR = 4 / (WA * WB), VA = TA / WA, VB = TB / WB;
     static_assert(WA * WB * WR == 4 && VA >= 1 && VB >= 1 && VA <= 4 && VB <= 8, "wave split");
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(DPP_THREADS) void wgrad_stream_kernel(WgradArgs a) 
         const int m = m0 + kq;
         okv[u] = m < row_end;
         const int mm = m < row_end ? m : last;
-        load_vec<VA>(a.dY + (size_t)mm * a.Co + ca, av[u]);
+        load_vec<VA>(reinterpret_cast<const TY*>(a.dY) + (size_t)mm * a.Co + ca, av[u]);
         const int xr = STRIDED ? dpp_map_row(a.mapX, mm) : mm;
         load_vec<VB>(reinterpret_cast<const TX*>(a.X) + (size_t)xr * a.Ci + cb, bv[u]);
     };
@@ -177,7 +177,7 @@ __device__ __forceinline__ void load_vec_at(const char* base, unsigned byte_off,
     load_vec<V>(reinterpret_cast<const T*>(base + byte_off), v);
 }
 
-template <int TA, int TB, int WA, int WB, int TG, int U, class TX = float>
+template <int TA, int TB, int WA, int WB, int TG, int U, class TX = float, class TY = float>
 __global__ __launch_bounds__(DPP_THREADS) void wgrad3_stream_kernel(Wgrad3sArgs a) {
     constexpr int WR = 4 / (WA * WB), VA = TA / WA, VB = TB / WB;
     static_assert(WA * WB * WR == 4 && VA >= 1 && VB >= 1 && VA <= 4 && VB <= 4 && (TG == 3 || TG == 9), "wave split");
@@ -209,14 +209,15 @@ __global__ __launch_bounds__(DPP_THREADS) void wgrad3_stream_kernel(Wgrad3sArgs 
     const int last = row_end - 1;
     const char* baseA = reinterpret_cast<const char*>(a.dY);
     const char* baseB = reinterpret_cast<const char*>(a.X);
-    const unsigned strideA = (unsigned)Co * 4u, strideB = (unsigned)Ci * (unsigned)sizeof(TX), offA = (unsigned)ca * 4u, offB = (unsigned)cb * (unsigned)sizeof(TX);
+    const unsigned strideA = (unsigned)Co * (unsigned)sizeof(TY), strideB = (unsigned)Ci * (unsigned)sizeof(TX), offA = (unsigned)ca * (unsigned)sizeof(TY),
+                   offB = (unsigned)cb * (unsigned)sizeof(TX);
     int fp = row_begin, fx = row_begin % W, fy = (row_begin / W) % H;         // the fetch cursor: pixel, its column and image row
     auto fetch = [&](int u) {
         const int p = fp + kq, x = fx + kq;
         const bool ok = p < row_end;
         const int pp = ok ? p : last;
         unsigned mask = ok ? 0x10000u : 0u;
-        load_vec_at<VA>(baseA, (unsigned)pp * strideA + offA, av[u]);
+        load_vec_at<VA, TY>(baseA, (unsigned)pp * strideA + offA, av[u]);
 #pragma unroll
         for (int j = 0; j < TG; ++j) {
             const int dy = (TG == 9 ? j / 3 : (int)blockIdx.y) - 1, dx = (TG == 9 ? j % 3 : j) - 1;
@@ -375,8 +376,8 @@ extern "C" int dpp_wgrad_stream_slices(int Co, int Ci, int M, int rows_per_wave)
 
 extern "C" int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
                                 int rows_per_wave, float* partial, int store, dpp_stream_t stream) {
-    if (!dY || !X || !partial || (store & ~DPP_ST_B)) return DPP_E_BADARG;
-    const bool x16 = (store & DPP_ST_B) != 0;
+    if (!dY || !X || !partial || (store & ~(DPP_ST_A | DPP_ST_B))) return DPP_E_BADARG;
+    const bool x16 = (store & DPP_ST_B) != 0, y16 = (store & DPP_ST_A) != 0;
     const int nsl = dpp_wgrad_stream_slices(Co, Ci, M, rows_per_wave);
     if (!nsl) return DPP_E_UNSUPPORTED;
     WgradArgs a;
@@ -391,12 +392,12 @@ extern "C" int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci,
     const int WR = shape_wr(Co, Ci);
     const dim3 grid(nsl / WR), block(DPP_THREADS);
     hipStream_t st = static_cast<hipStream_t>(stream);
+#define DPP_WGK(CO_, CI_, WA_, WB_, U_, S_, TX_, TY_) DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, S_, TX_, TY_>), grid, block, 0, st, a)
+#define DPP_WGS(CO_, CI_, WA_, WB_, U_, TX_, TY_) do { if (a.mapX.s != 1) DPP_WGK(CO_, CI_, WA_, WB_, U_, true, TX_, TY_); \
+                                                       else DPP_WGK(CO_, CI_, WA_, WB_, U_, false, TX_, TY_); } while (0)
 #define DPP_WG(CO_, CI_, WA_, WB_, U_) if (Co == CO_ && Ci == CI_) { \
-        if (x16) { \
-            if (a.mapX.s != 1) DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, true, dpp_bf16>), grid, block, 0, st, a); \
-            else DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, false, dpp_bf16>), grid, block, 0, st, a); \
-        } else if (a.mapX.s != 1) DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, true>), grid, block, 0, st, a); \
-        else DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, false>), grid, block, 0, st, a); \
+        if (x16) { if (y16) DPP_WGS(CO_, CI_, WA_, WB_, U_, dpp_bf16, dpp_bf16); else DPP_WGS(CO_, CI_, WA_, WB_, U_, dpp_bf16, float); } \
+        else { if (y16) DPP_WGS(CO_, CI_, WA_, WB_, U_, float, dpp_bf16); else DPP_WGS(CO_, CI_, WA_, WB_, U_, float, float); } \
         return dpp_launch_status(); }
     DPP_WG(16, 64, 1, 1, 8)
     DPP_WG(64, 16, 1, 1, 8)
@@ -411,6 +412,8 @@ extern "C" int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci,
     DPP_WG(256, 64, 4, 1, 8)
     DPP_WG(256, 128, 4, 1, 4)
 #undef DPP_WG
+#undef DPP_WGS
+#undef DPP_WGK
     return DPP_E_UNSUPPORTED;
 }
 
@@ -424,8 +427,8 @@ extern "C" int dpp_wgrad3_stream_slices(int Co, int Ci, int N, int H, int W, int
 
 extern "C" int dpp_wgrad3_stream(const float* dY, int Co, const float* X, int Ci, int N, int H, int W, const dpp_act* actX,
                                  int rows_per_wave, float* partial, int store, dpp_stream_t stream) {
-    if (!dY || !X || !partial || (store & ~DPP_ST_B)) return DPP_E_BADARG;
-    const bool x16 = (store & DPP_ST_B) != 0;
+    if (!dY || !X || !partial || (store & ~(DPP_ST_A | DPP_ST_B))) return DPP_E_BADARG;
+    const bool x16 = (store & DPP_ST_B) != 0, y16 = (store & DPP_ST_A) != 0;
     const int nsl = dpp_wgrad3_stream_slices(Co, Ci, N, H, W, rows_per_wave);
     if (!nsl) return DPP_E_UNSUPPORTED;
     Wgrad3sArgs a;
@@ -439,13 +442,13 @@ extern "C" int dpp_wgrad3_stream(const float* dY, int Co, const float* X, int Ci
     shape3(Co, Ci, WR, TG);
     const dim3 grid(nsl / WR, 9 / TG), block(DPP_THREADS);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (x16) {
-        if (Co == 16) DPP_LAUNCH((wgrad3_stream_kernel<1, 1, 1, 1, 9, 4, dpp_bf16>), grid, block, 0, st, a);
-        else if (Co == 32) DPP_LAUNCH((wgrad3_stream_kernel<2, 2, 1, 1, 3, 8, dpp_bf16>), grid, block, 0, st, a);
-        else DPP_LAUNCH((wgrad3_stream_kernel<4, 4, 2, 2, 3, 8, dpp_bf16>), grid, block, 0, st, a);
-    } else if (Co == 16) DPP_LAUNCH((wgrad3_stream_kernel<1, 1, 1, 1, 9, 4>), grid, block, 0, st, a);
-    else if (Co == 32) DPP_LAUNCH((wgrad3_stream_kernel<2, 2, 1, 1, 3, 8>), grid, block, 0, st, a);
-    else DPP_LAUNCH((wgrad3_stream_kernel<4, 4, 2, 2, 3, 8>), grid, block, 0, st, a);
+#define DPP_W3S(TX_, TY_) do { \
+        if (Co == 16) DPP_LAUNCH((wgrad3_stream_kernel<1, 1, 1, 1, 9, 4, TX_, TY_>), grid, block, 0, st, a); \
+        else if (Co == 32) DPP_LAUNCH((wgrad3_stream_kernel<2, 2, 1, 1, 3, 8, TX_, TY_>), grid, block, 0, st, a); \
+        else DPP_LAUNCH((wgrad3_stream_kernel<4, 4, 2, 2, 3, 8, TX_, TY_>), grid, block, 0, st, a); } while (0)
+    if (x16) { if (y16) DPP_W3S(dpp_bf16, dpp_bf16); else DPP_W3S(dpp_bf16, float); }
+    else { if (y16) DPP_W3S(float, dpp_bf16); else DPP_W3S(float, float); }
+#undef DPP_W3S
     return dpp_launch_status();
 }
 

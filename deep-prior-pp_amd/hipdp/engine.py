@@ -367,6 +367,9 @@ BF16_DEFAULT = os.environ.get('DPP_BF16', '0') == '1'
 # bfloat16 (ABI v9, DPP_ST_*): rounded by the producer's epilogue (statistics from the f32 values), widened by every reader.  At
 # 256x256 the step is bandwidth-bound and these tensors are read five to six times each.  DPP_BF16_STORE=0: f32 storage (rounds 2-3).
 BF16_STORE = knob('DPP_BF16_STORE', '1') != '0'
+# ... and the GRADIENTS of those tensors (the masked gradient G a data-gradient epilogue writes into a BatchNorm view, the dX that
+# bn_bwd_apply writes): the backward pass moves twice the bytes of the forward pass.  DPP_BF16_GRADS=0: float32 gradients.
+BF16_GRADS = knob('DPP_BF16_GRADS', '1') != '0'
 # ADAM of the FC1 weight (90 % of the parameters, 470 MB of optimizer traffic) inside the backward pass: its gradient is final a few
 # kernels into the pass, so the update runs on the gradient branch under the latency-bound data-gradient chain instead of in the
 # serial tail of the step (step_plan only: cost_and_grads / allreduce paths keep backward and update apart).
@@ -556,6 +559,7 @@ class CompiledNet(object):
         self.optimizer = dict(optimizer) if optimizer else dict(name='ADAM')
         self.prec = int(bool(BF16_DEFAULT if bf16 is None else bf16))
         self.store16 = bool(self.prec and BF16_STORE)           # conv outputs held as bf16 (see BF16_STORE)
+        self.grad16 = bool(self.store16 and BF16_GRADS)         # ... and their gradients (see BF16_GRADS)
         self.dp = dp                                  # hipdp.parallel.DataParallel or None
         # BatchNorm statistics / backward sums produced by the conv epilogues (off with sync-BN, whose partials are
         # all-gathered by row block, and for tests that want the stand-alone BatchNorm kernels)
@@ -1050,17 +1054,34 @@ class CompiledNet(object):
         return View(out)
 
     # ------------------------------------------------------------------------------------------ backward
+    def _grad_dtype(self, t, flattened=False):
+        """Storage of the gradient of activation tensor t (or of a BatchNorm / ReLU view over it): bf16 in the bf16 mode for the big
+        [pixels][channels] maps, float32 where a float32-only kernel touches it -- the stem's output (its gradient feeds stem_wgrad),
+        a view the FC head reads (written by dpp_fc_gemm) or one whose gradient is accumulated by two kernels, and maps of at most 256 rows (their gradient doubles as the list of
+        bias-gradient partials of dpp_reduce_multi)."""
+        if not self.grad16 or not t.is16 or flattened or t.rows <= 256:
+            return np.float32
+        for io in self.layer_io.values():
+            if io.get('out') is t and io.get('stem'):
+                return np.float32
+        return np.uint16
+
     def _view_grad(self, view):
         """The buffer holding d(cost)/d(view value); plain views write straight into the base tensor's gradient."""
         if view.plain:
             t = view.base
             if t.grad is None:
-                t.grad = self.rt.alloc(t.shape, zero=False)
+                t.grad = self.rt.alloc(t.shape, self._grad_dtype(t), zero=False)
             return t, t.grad
         key = view.key()
         vg = self.view_grads.get(key)
         if vg is None:
-            vg = TensorV(self.rt.alloc(view.base.shape, zero=False), view.base.shape, 'dA')
+            # a view with several consumers (the BatchNorm a projection block feeds to its main path AND its shortcut) collects its
+            # gradient in two kernels: the first share would make a bf16 round trip before the second is added -- kept float32
+            var = getattr(view, 'var', None)
+            shared = var is not None and len(self.consumers.get(id(var), [])) > 1
+            vg = TensorV(self.rt.alloc(view.base.shape, self._grad_dtype(view.base, flattened=len(view.shape) == 2 or shared), zero=False),
+                         view.base.shape, 'dA')
             vg.grad = vg.buf
             vg.view = view
             self.view_grads[key] = vg
@@ -1101,6 +1122,8 @@ class CompiledNet(object):
             return
         b = view.bn
         M, C, W = b.M, b.C, b.world
+        # (the masked gradient G of this BatchNorm, as its backward kernels read it: kept for the tests' pins)
+        self.__dict__.setdefault('bn_view_grad', {})[id(b.layer)] = vg.grad
         c1, c2 = rt.alloc(_pad4(C)), rt.alloc(_pad4(C))
         # If t was produced by a 1x1 convolution and nothing else flows into it, the gradient through the batch statistics
         # dX = scale*(G - c1 - xhat*c2) is never written: that convolution's data- and filter-gradient GEMMs form it from
@@ -1163,13 +1186,14 @@ class CompiledNet(object):
         M, C = b.M, b.C
         addends = ([t.grad] if t.grad_written else []) + t.pending
         t.pending = []
-        if t.grad is None:
-            t.grad = rt.alloc(t.shape, zero=False)
         add = None
         if addends:
             add = addends[0]
             for extra in addends[1:]:
                 raise NotImplementedError("more than one extra gradient path into a BatchNorm input")
+        if t.grad is None:
+            # (the gradient added to dX -- the identity path of a residual sum -- and dX are stored alike)
+            t.grad = rt.alloc(t.shape, add.dtype if add is not None else self._grad_dtype(t), zero=False)
         # t.grad is the dY of the conv(s) that produced t: emit its column sums (their bias gradients) in the same pass
         cs = rt.alloc((b.nb, C), zero=False)
         self.bwd.add(ops.bn_bwd_apply(rt, G, t.buf, M, C, b.mean, b.inv_std, b.scale, c1, c2, t.grad, add=add, rpb=b.rpb, colsum=cs))

@@ -302,7 +302,7 @@ def wgrad_stream(rt, dY, Co, X, Ci, M, rows_per_wave, partial, mapX=None, actX=N
     nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rows_per_wave)
     meta = dict(kernel='gemm_mfma_f32', flops=2.0 * M * Co * Ci, bytes=4.0 * (M * Co + nsl * Co * Ci) + _esz(X) * M * Ci)
     return Launch(rt.lib.dpp_wgrad_stream, (dY.ptr, int(Co), X.ptr, int(Ci), C.byref(mapX) if mapX is not None else None, _actp(actX), int(M),
-                                            int(rows_per_wave), partial.ptr, _store(b=X)), (dY, X, partial, mapX, actX), name, meta)
+                                            int(rows_per_wave), partial.ptr, _store(a=dY, b=X)), (dY, X, partial, mapX, actX), name, meta)
 
 
 def wgrad3_stream(rt, dY, Co, X, Ci, N, H, W, rows_per_wave, partial, actX=None, name='conv3x3_wgrad_stream'):
@@ -311,7 +311,7 @@ def wgrad3_stream(rt, dY, Co, X, Ci, N, H, W, rows_per_wave, partial, actX=None,
     px = float(N) * H * W
     meta = dict(kernel='conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co, bytes=4.0 * (px * Co + nsl * 9.0 * Ci * Co) + _esz(X) * px * Ci)
     return Launch(rt.lib.dpp_wgrad3_stream, (dY.ptr, int(Co), X.ptr, int(Ci), int(N), int(H), int(W), _actp(actX), int(rows_per_wave),
-                                             partial.ptr, _store(b=X)), (dY, X, partial, actX), name, meta)
+                                             partial.ptr, _store(a=dY, b=X)), (dY, X, partial, actX), name, meta)
 
 
 def fc_gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, actA=None, actB=None, bias=None, residual=None, splitk=1, partial=None,
@@ -382,7 +382,7 @@ def conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, partial, actX=None, bm=64, name='c
     px = float(N) * H * W
     nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, Ci, Co, bm)
     meta = dict(kernel='conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co, bytes=4.0 * (px * Co + nblk * 9.0 * Ci * Co) + _esz(X) * px * Ci)
-    return Launch(rt.lib.dpp_conv3x3_wgrad, (X.ptr, N, H, W, Ci, _actp(actX), dY.ptr, Co, partial.ptr, bm, _store(a=X)),
+    return Launch(rt.lib.dpp_conv3x3_wgrad, (X.ptr, N, H, W, Ci, _actp(actX), dY.ptr, Co, partial.ptr, bm, _store(a=X, b=dY)),
                   (X, dY, partial, actX), name, meta)
 
 
@@ -439,7 +439,7 @@ def bn_eval_coeffs(rt, gamma, run_mean, run_inv_std, Cc, mean, inv_std, scale, n
 
 def bn_bwd_reduce(rt, dA, X, M, Cc, mean, inv_std, scale, beta, relu, G, rpb, partial, name='bn_bwd_reduce'):
     return Launch(rt.lib.dpp_bn_bwd_reduce, (dA.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, beta.ptr, int(relu), G.ptr, rpb,
-                                             partial.ptr, _store(bnx=X)), (dA, X, mean, inv_std, scale, beta, G, partial), name,
+                                             partial.ptr, _store(a=dA, c=G, bnx=X)), (dA, X, mean, inv_std, scale, beta, G, partial), name,
                   dict(kernel='bn_bwd_reduce', flops=8.0 * M * Cc, bytes=(8.0 + _esz(X)) * M * Cc))
 
 
@@ -453,13 +453,17 @@ def bn_bwd_finalize(rt, partial, nb, M, Cc, dbeta, dgamma, c1, c2, nseg=1, bn=No
 
 def bn_bwd_apply(rt, G, X, M, Cc, mean, inv_std, scale, c1, c2, dX, add=None, rpb=None, colsum=None, name='bn_bwd_apply'):
     rpb = rpb or max(32, -(-M // 1024))
+    if add is not None and _is16(add) != _is16(dX):
+        raise ValueError("dpp_bn_bwd_apply: dX and the gradient added to it must be stored alike")
     return Launch(rt.lib.dpp_bn_bwd_apply, (G.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, c1.ptr, c2.ptr, _p(add), dX.ptr,
-                                            int(rpb), _p(colsum), _store(bnx=X)),
+                                            int(rpb), _p(colsum), _store(a=G, c=dX, bnx=X)),
                   (G, X, mean, inv_std, scale, c1, c2, add, dX, colsum), name,
                   dict(kernel='bn_bwd_apply', flops=6.0 * M * Cc, bytes=((12.0 if add is not None else 8.0) + _esz(X)) * M * Cc))
 
 
 def colsum_partial(rt, X, M, Cc, rpb, partial, name='colsum_partial'):
+    if _is16(X):
+        raise NotImplementedError("dpp_colsum_partial reads float32 gradients")
     return Launch(rt.lib.dpp_colsum_partial, (X.ptr, M, Cc, rpb, partial.ptr), (X, partial), name,
                   dict(kernel='colsum_partial', flops=1.0 * M * Cc, bytes=4.0 * M * Cc))
 
@@ -481,7 +485,13 @@ def adam(rt, w, g, m, v, n, hyper, name='adam'):
                   dict(kernel='adam', flops=12.0 * n, bytes=28.0 * n))
 
 
+def _f32_only(what, *bufs):
+    if any(_is16(b) for b in bufs):
+        raise NotImplementedError("%s reads / writes float32 tensors only (a bf16-stored tensor reached it)" % what)
+
+
 def axpy(rt, y, x, alpha, n, name='axpy'):
+    _f32_only('dpp_axpy', y, x)
     return Launch(rt.lib.dpp_axpy, (y.ptr, x.ptr, float(alpha), n), (y, x), name)
 
 
@@ -514,6 +524,7 @@ def scale(rt, x, y, n, a=1.0, relu=False, mask=None, name='scale'):
 
 
 def relu_bwd(rt, dy, pre, g, n, a=1.0, mask=None, name='relu_bwd'):
+    _f32_only('dpp_relu_bwd', dy, pre, g)
     return Launch(rt.lib.dpp_relu_bwd, (dy.ptr, pre.ptr, _p(mask), float(a), g.ptr, n), (dy, pre, g, mask), name)
 
 

@@ -42,7 +42,10 @@ int dpp_abi_version(void);
  * producer's epilogue rounds the f32 value it formed (accumulator + bias + residual) to nearest-even on the store, the fused BatchNorm
  * statistics are still those of the UNROUNDED values, and every reader widens on the load (exact).  A `store` bit mask on the entry
  * points that can see such a tensor says which of its pointers address bf16 elements (same element offsets / leading dimensions as
- * f32; 8-byte alignment instead of 16).  0 everywhere = the float32 layout of ABI v8. */
+ * f32; 8-byte alignment instead of 16).  0 everywhere = the float32 layout of ABI v8.
+ * The GRADIENTS of those tensors -- the masked gradient G a data-gradient epilogue writes, the dX dpp_bn_bwd_apply writes -- may be
+ * bf16-stored in the same way (rounded on the store, partial sums from the unrounded values): they take the A / C roles of the calls
+ * that read / write them. */
 #define DPP_ST_A 1    /* operand A / the input map X */
 #define DPP_ST_B 2    /* operand B (the forward activations in a filter-gradient call) */
 #define DPP_ST_C 4    /* the output C / Y and, when given, the residual */
@@ -157,7 +160,7 @@ int dpp_gemm_variant_rows(const dpp_gemm_desc* d);
  * dpp_reduce_partials (fixed order).  T.grad of convlayer.py:230-240 (poseregnettrainer.py:110-111). */
 int dpp_wgrad_stream_slices(int Co, int Ci, int M, int rows_per_wave);
 int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
-                     int rows_per_wave, float* partial, int store /* DPP_ST_B: X holds bf16 */, dpp_stream_t stream);
+                     int rows_per_wave, float* partial, int store /* DPP_ST_B: X, DPP_ST_A: dY hold bf16 */, dpp_stream_t stream);
 
 /* Filter gradient of a 3x3 'half'-padded, stride-1 ConvLayer on the same kind of stream:
  *   partial[s][o][t][c] = sum over the pixels p of slice s of  dY[p][o] * act(X)[p + (dy, dx)][c],  t = 3 (dy + 1) + (dx + 1),
@@ -173,7 +176,7 @@ int dpp_fc_wgrad_stream(const float* X, const float* dY, float* dW, int Nb, int 
                         int store /* DPP_ST_B: X holds bf16 */, dpp_stream_t stream);
 int dpp_wgrad3_stream_slices(int Co, int Ci, int N, int H, int W, int rows_per_wave);
 int dpp_wgrad3_stream(const float* dY, int Co, const float* X, int Ci, int N, int H, int W, const dpp_act* actX, int rows_per_wave,
-                      float* partial, int store /* DPP_ST_B: X holds bf16 */, dpp_stream_t stream);
+                      float* partial, int store /* DPP_ST_B: X, DPP_ST_A: dY hold bf16 */, dpp_stream_t stream);
 
 /* The same contract on the weight-streaming kernel for the HiddenLayer behind the last convolution map (FC1: 16 384 x 1 024
  * weights at 128x128 input, 65 536 x 1 024 at 256x256; hiddenlayer.py:136-139 and its T.grad): tile 128 x 64, both operands
@@ -220,7 +223,7 @@ int dpp_conv3x3_wtrans_multi(const void* jobs_dev, int njobs, int total_blocks, 
  * blk < dpp_conv3x3_wgrad_blocks(N,H,W,Ci,Co,bm); sum over blk with dpp_reduce_partials.  (T.grad, poseregnettrainer.py:110-111) */
 int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int Ci, int Co, int bm);
 int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
-                      float* partial, int bm, int store /* DPP_ST_A: X holds bf16 */, dpp_stream_t stream);
+                      float* partial, int bm, int store /* DPP_ST_A: X, DPP_ST_B: dY hold bf16 */, dpp_stream_t stream);
 
 /* ---- ResNet stem: ConvPoolLayer 5x5 'half' 1 -> Co (<= 32), 2x2 max-pool, bias AFTER the pool ----------------
  * /root/reference/src/net/convpoollayer.py:251-282 as built at /root/reference/src/net/resnet.py:128-133.
@@ -273,13 +276,13 @@ int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, const float* r
                        float* inv_std, float* scale, dpp_stream_t stream);
 int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, const float* mean, const float* inv_std,
                       const float* scale, const float* beta, int relu, float* G, int rows_per_block, float* partial,
-                      int store /* DPP_ST_BNX: X holds bf16 */, dpp_stream_t stream);
+                      int store /* DPP_ST_BNX: X, DPP_ST_A: the incoming gradient (dA / G), DPP_ST_C: the outgoing one (G / dX + add) hold bf16 */, dpp_stream_t stream);
 int dpp_bn_bwd_finalize(const float* partial, int nb, int nseg, int M, int C, float* dbeta, float* dgamma, float* c1, float* c2,
                         const float* inv_std, const float* scale, float* q, float* p, dpp_stream_t stream);
 int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
                      const float* scale, const float* c1, const float* c2, const float* add, float* dX,
                      int rows_per_block, float* colsum_partial /* [nb][C] column sums of dX, or NULL */,
-                     int store /* DPP_ST_BNX: X holds bf16 */, dpp_stream_t stream);
+                     int store /* DPP_ST_BNX: X, DPP_ST_A: the incoming gradient (dA / G), DPP_ST_C: the outgoing one (G / dX + add) hold bf16 */, dpp_stream_t stream);
 
 /* ---- loss / optimiser / small elementwise ------------------------------------------------------------------ */
 /* partial[b][c] = sum of rows of chunk b (bias gradients; reduce with dpp_reduce_partials) */

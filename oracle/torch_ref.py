@@ -112,7 +112,8 @@ class _StoredBN(torch.autograd.Function):
     gradient).  Deterministic mode (running statistics): dv = gamma * inv_std * g."""
 
     @staticmethod
-    def forward(ctx, v, y, gamma, beta, rm, ris, train):
+    def forward(ctx, v, y, gamma, beta, rm, ris, train, pin_g=None, rec=None):
+        ctx.pin_g, ctx.rec = pin_g, rec
         if train:
             mean = v.mean(dim=(0, 2, 3))
             inv_std = 1.0 / torch.sqrt(v.var(dim=(0, 2, 3), unbiased=False) + BN_EPS)
@@ -127,6 +128,10 @@ class _StoredBN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         xhat, gamma, inv_std = ctx.saved_tensors
+        if ctx.rec is not None:
+            ctx.rec(bf16r(g))                    # what THIS evaluation would have stored as the masked gradient G
+        if ctx.pin_g is not None:                # bf16-stored gradients: the device's own G (see forward(): grad_pins)
+            g = ctx.pin_g.to(g.dtype)
         dbeta = g.sum(dim=(0, 2, 3))
         dgamma = (g * xhat).sum(dim=(0, 2, 3))
         M = g.shape[0] * g.shape[2] * g.shape[3]
@@ -135,7 +140,7 @@ class _StoredBN(torch.autograd.Function):
             dv = s * (g - (dbeta / M)[None, :, None, None] - xhat * (dgamma / M)[None, :, None, None])
         else:
             dv = s * g
-        return dv, None, dgamma, dbeta, None, None, None
+        return dv, None, dgamma, dbeta, None, None, None, None, None
 
 
 def _relu(a, mask=None):
@@ -144,8 +149,13 @@ def _relu(a, mask=None):
     return torch.clamp_min(a, 0) if mask is None else a * mask.to(a.dtype)
 
 
-def forward(net, T, x, train, masks=None, quant=None, store=None):
-    """store (optional): the bf16 STORAGE mode -- a dict {layer index: pin or None} naming every layer whose materialised output the
+def forward(net, T, x, train, masks=None, quant=None, store=None, grad_pins=None):
+    """grad_pins (optional, with `store`): (G, dV) -- the bf16-stored GRADIENT tensors of the device, pinned like the stored activations:
+    G {index of a 'bn' layer: the masked gradient its backward kernels read}, dV {index of a stored layer: the gradient of its tensor
+    as the device holds it, i.e. the BatchNorm-backward dX plus the identity path of a residual sum}.  Each replaces the oracle's own
+    value at that point of the backward pass (the oracle's own rounding is collected in stats['stored_grads'] for the un-pinned
+    agreement check), so what is compared downstream is the arithmetic of each layer on the device's own operands.
+    store (optional): the bf16 STORAGE mode -- a dict {layer index: pin or None} naming every layer whose materialised output the
     device holds as bfloat16: the stem ('convpool') and every 'conv' (for a conv fused into a residual add the tensor is the SUM, see
     oracle.nets.fused_convs).  The value is the device's own stored tensor (NCHW, bf16 values as float32) when the comparison pins it
     -- a float32 and a float64 evaluation of v round to different bfloat16 neighbours for a few elements in 1e4, and one flip is worth
@@ -164,7 +174,8 @@ def forward(net, T, x, train, masks=None, quant=None, store=None):
     vals, stats = {}, {}
     masks = masks or {}
     quant = quant or {}
-    raw, memo, own_round = {}, {}, {}
+    raw, memo, own_round, own_grads = {}, {}, {}, {}
+    gpin, dvpin = grad_pins if grad_pins is not None else ({}, {})
     fused = set()
     if store is not None:
         from oracle.nets import fused_convs
@@ -177,6 +188,13 @@ def forward(net, T, x, train, masks=None, quant=None, store=None):
         pin = store.get(i)
         y = own if pin is None else torch.as_tensor(np.asarray(pin)).to(v.dtype)
         raw[key] = v
+        if i in dvpin and v.requires_grad:
+            dpin = torch.as_tensor(np.asarray(dvpin[i])).to(v.dtype)
+
+            def hook(grad, i=i, dpin=dpin):
+                own_grads[('dv', i)] = bf16r(grad)
+                return dpin
+            v.register_hook(hook)
         return v + (y - v).detach()
 
     def qd(i):
@@ -239,7 +257,9 @@ def forward(net, T, x, train, masks=None, quant=None, store=None):
         elif k == 'bn':
             beta, gamma, rm, ris = T[i]
             if store is not None and l['src'] in raw:
-                fn = _StoredBN.apply(raw[l['src']], a.detach(), gamma, beta, rm, ris, bool(train))
+                pg = torch.as_tensor(np.asarray(gpin[i])) if i in gpin else None
+                fn = _StoredBN.apply(raw[l['src']], a.detach(), gamma, beta, rm, ris, bool(train), pg,
+                                     (lambda t, i=i: own_grads.__setitem__(('g', i), t)) if i in gpin else None)
                 if train:
                     v_ = raw[l['src']].detach()
                     stats[i] = (v_.mean(dim=(0, 2, 3)), 1.0 / torch.sqrt(v_.var(dim=(0, 2, 3), unbiased=False) + BN_EPS))
@@ -266,20 +286,23 @@ def forward(net, T, x, train, masks=None, quant=None, store=None):
             raise NotImplementedError(k)
     if store is not None:
         stats['stored_out'] = {i: t.detach().numpy() for i, t in own_round.items()}
+        stats['stored_grads'] = own_grads                    # filled by the backward pass
     return get(net['out']), stats
 
 
-def cost_and_grads(net, P, x, y, dtype=torch.float64, masks=None, quant=None, store=None, stored_out=None):
+def cost_and_grads(net, P, x, y, dtype=torch.float64, masks=None, quant=None, store=None, stored_out=None, grad_pins=None, stored_grads=None):
     """Returns (cost, {layer: [g0, g1]}, out) with autograd gradients (numpy arrays); `masks`, `quant`, `store`: see forward().
     stored_out (a dict, optional) receives forward()'s own roundings of the stored tensors."""
     T = to_torch(P, dtype)
     xt = [torch.as_tensor(a, dtype=dtype) for a in x] if isinstance(x, (list, tuple)) else torch.tensor(x, dtype=dtype)
     yt = torch.tensor(y, dtype=dtype)
-    out, st = forward(net, T, xt, True, masks, quant, store)
+    out, st = forward(net, T, xt, True, masks, quant, store, grad_pins)
     if stored_out is not None and store is not None:
         stored_out.update(st['stored_out'])
     cost = ((out - yt) ** 2).sum(dim=1).mean()
     cost.backward()
+    if stored_grads is not None and store is not None:
+        stored_grads.update({k: t.detach().numpy() for k, t in st['stored_grads'].items()})
     G = {i: [T[i][0].grad.numpy(), T[i][1].grad.numpy()] for i in T}
     return float(cost.detach()), G, out.detach().numpy()
 

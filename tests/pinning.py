@@ -106,7 +106,10 @@ def device_quant(eng, net):
             q['pin'] = L.bf16_round(_activated_operand(io['in_view']))
         if (q['dgrad'] or q['wgrad']) and io['out'].grad is not None and getattr(eng, 'train', False):
             # the gradient w.r.t. the layer's output as the backward kernels read it (call after the backward pass has run)
-            g = io['out'].grad.get().astype(np.float32)
+            g = io['out'].grad.get()
+            if g.dtype == np.uint16:                                # a bf16-stored gradient tensor: its bits, widened
+                g = (g.astype(np.uint32) << 16).view(np.float32)
+            g = g.astype(np.float32)
             q['pin_dy'] = L.bf16_round(np.ascontiguousarray(np.moveaxis(g, -1, 1)) if g.ndim == 4 else g)
     return quant
 
@@ -129,3 +132,26 @@ def store_agreement(store, stored_out):
     stored tensor (the pin): the un-pinned check of the pins themselves.  A float32 and a float64 evaluation of the same value land on
     different bfloat16 neighbours only when it sits within float32 round-off of a rounding boundary."""
     return {i: float((np.asarray(stored_out[i], np.float32) == np.asarray(p, np.float32)).mean()) for i, p in store.items() if p is not None}
+
+
+def device_grad_pins(eng, net):
+    """The bf16-stored GRADIENT tensors of the compiled net after a backward pass, for oracle.torch_ref.forward(grad_pins=): (G, dV) with
+    G {index of a BatchNorm layer: its masked gradient as the backward kernels read it} and dV {index of a stored layer: the gradient
+    of its tensor}, float32 NCHW.  Only the tensors the device really holds as bfloat16 are pinned."""
+    from hipdp.engine import bf16_bits_to_f32
+    from hipdp import ops
+
+    def nchw(buf, shape):
+        return np.ascontiguousarray(np.moveaxis(bf16_bits_to_f32(buf.get()).reshape(shape), -1, 1))
+    G, dV = {}, {}
+    for i, l in enumerate(net.layers):
+        if l.__class__.__name__ == 'BatchNormLayer':
+            g = getattr(eng, 'bn_view_grad', {}).get(id(l))
+            b = eng.bn_states.get(id(l))
+            if g is not None and g.dtype == ops.BF16:
+                G[i] = nchw(g, g.shape)
+        io = eng.layer_io.get(id(l))
+        t = io.get('out') if io is not None else None
+        if t is not None and t.grad is not None and t.grad.dtype == ops.BF16:
+            dV[i] = nchw(t.grad, t.shape)
+    return G, dV

@@ -308,3 +308,148 @@ def test_unsupported_storage_combinations_are_refused(backend):
     L = ops.gemm(rt, A16, rt.alloc((K, N)), Y32, M, N, K, 1, 0, K, N, N, actA=ops.act_bn_bwd(bn, rt.alloc(K), rt.alloc(K), rt.alloc((M, K)), K))
     with pytest.raises(Exception):
         L(rt.stream)
+
+
+# ---- bf16-stored GRADIENTS of the activation tensors (the A / C roles of the backward calls) ------------------------------------------
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(64, 32, 128, (64, 32, 4), 0), (256, 64, 96, (32, 64, 4), 2), (64, 16, 128, (128, 16, 4), 3), (16, 64, 128, (64, 64, 4), 3),
+                                 (64, 256, 96, (32, 64, 4), 4), (32, 128, 128, (64, 64, 4), 4), (16, 64, 256, (128, 64, 4), 4)])
+def test_gemm_data_gradient_with_bf16_gradients(backend, cfg):
+    """Data gradient on bf16-stored gradients: dY (A) read as bf16, the masked gradient written as bf16 onto an earlier bf16 share
+    (residual = C), bn_x bf16 -- the written tensor is the rounded float32 result, the BatchNorm-backward sums are those of the
+    UNROUNDED values."""
+    rt = get_runtime(backend)
+    K, N, M, tile, variant = cfg
+    rng = np.random.RandomState(71)
+    dY16, dY32 = both(rt, rng.normal(size=(M, K)))
+    W2 = rt.upload((rng.normal(size=(K, N)) * 0.3).astype(np.float32))
+    share = rng.normal(size=(M, N))
+    bx16, bx32 = both(rt, rng.normal(size=(M, N)))
+    bn = _bn_coeffs(rt, rng, N)
+    nb = M // tile[0]
+    out = {}
+    for tag, dY, bx in (('f32', dY32, bx32), ('bf16', dY16, bx16)):
+        s16, s32 = both(rt, share)
+        dH = s32 if tag == 'f32' else s16
+        part = rt.alloc((nb, 2, N), zero=False)
+        L = ops.gemm(rt, dY, W2, dH, M, N, K, 1, 0, K, N, N, residual=dH, tile=tile, variant=variant,
+                     epi=ops.epilogue(bn=bn, bn_x=bx, bn_relu=True, bn_partial=part))
+        if variant:
+            assert ops.gemm_variant_rows(rt, L) == tile[0]
+        L(rt.stream)
+        rt.synchronize()
+        out[tag] = (dH.get(), part.get())
+    assert np.array_equal(out['bf16'][0], bf16_bits(out['f32'][0]))
+    # the BatchNorm-backward sums of a bf16-stored gradient are those of the values AS STORED (bn_bwd_apply's c1 / c2 are then exactly
+    # the means of the G it reads): against float64 sums of the widened stored tensor
+    Gs = widen(out['bf16'][0]).astype('f8').reshape(M, N)
+    bx = widen(bx16.get()).astype('f8').reshape(M, N)
+    xhat = (bx - bn.mean.get().astype('f8')) * bn.inv_std.get().astype('f8')
+    p = out['bf16'][1].reshape(2, N, nb).astype('f8').sum(axis=2)
+    np.testing.assert_allclose(p[0], Gs.sum(0), rtol=0, atol=2e-6 * np.abs(Gs).sum(0).max())
+    np.testing.assert_allclose(p[1], (Gs * xhat).sum(0), rtol=0, atol=2e-6 * np.abs(Gs * xhat).sum(0).max())
+    assert not np.array_equal(out['bf16'][1], out['f32'][1])
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(16, 64, 256, 1), (64, 16, 256, 1), (64, 256, 128, 1), (32, 128, 192, 2)])
+def test_filter_gradients_read_bf16_gradients(backend, cfg):
+    """dW = dY^T . act(X) with BOTH operands bf16-stored (and each alone): the generic layout and the row stream."""
+    rt = get_runtime(backend)
+    Co, Ci, M, stride = cfg
+    rng = np.random.RandomState(72)
+    rows = M * stride * stride
+    X16, X32 = both(rt, rng.normal(size=(rows, Ci)) + 0.5)
+    Y16, Y32 = both(rt, rng.normal(size=(M, Co)))
+    mean, scale, beta = (rt.upload(rng.normal(size=Ci).astype(np.float32)) for _ in range(3))
+    act = ops.act(Act.BN_RELU, mean, scale, beta, Ci)
+    mp = None
+    if stride == 2:
+        from hipdp.lib import RowMap
+        Ho = Wo = int(round((M // 3) ** 0.5))
+        mp = RowMap.strided(2, Ho, Wo, 2 * Ho, 2 * Wo)
+    got = {}
+    for tag, X, dY in (('f32', X32, Y32), ('both', X16, Y16), ('dy', X32, Y16)):
+        part = rt.alloc((3, Co, Ci), zero=False)
+        ops.gemm(rt, dY, X, None, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actB=act, splitk=3, partial=part)(rt.stream)
+        res = [part]
+        nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, 32)
+        if nsl > 0:
+            p2 = rt.alloc((nsl, Co, Ci), zero=False)
+            ops.wgrad_stream(rt, dY, Co, X, Ci, M, 32, p2, mapX=mp, actX=act)(rt.stream)
+            res.append(p2)
+        rt.synchronize()
+        got[tag] = [r.get() for r in res]
+    for tag in ('both', 'dy'):
+        assert all(np.array_equal(a, b) for a, b in zip(got[tag], got['f32'])), tag
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 64, 64), (3, 16, 16, 16, 16), (2, 12, 20, 32, 32)])
+def test_conv3x3_filter_gradients_read_bf16_gradients(backend, cfg):
+    rt = get_runtime(backend)
+    N, H, W, Ci, Co = cfg
+    rng = np.random.RandomState(73)
+    X16, X32 = both(rt, rng.normal(size=(N, H, W, Ci)) + 0.3)
+    Y16, Y32 = both(rt, rng.normal(size=(N, H, W, Co)))
+    mean, scale, beta = (rt.upload(v.astype(np.float32)) for v in (rng.normal(size=Ci) * 0.3, rng.uniform(0.5, 1.5, Ci), rng.normal(size=Ci) * 0.3))
+    act = ops.act(Act.BN_RELU, mean, scale, beta, Ci)
+    wg = {}
+    for tag, X, dY in (('f32', X32, Y32), ('both', X16, Y16), ('dy', X32, Y16)):
+        nb3 = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, Ci, Co, 64)
+        part = rt.alloc((nb3, Co, 9, Ci), zero=False)
+        ops.conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, part, actX=act, bm=64)(rt.stream)
+        res = [part]
+        nsl = rt.lib.dpp_wgrad3_stream_slices(Co, Ci, N, H, W, 20)
+        if nsl > 0:
+            p2 = rt.alloc((nsl, Co, 9, Ci), zero=False)
+            ops.wgrad3_stream(rt, dY, Co, X, Ci, N, H, W, 20, p2, actX=act)(rt.stream)
+            res.append(p2)
+        rt.synchronize()
+        wg[tag] = [r.get() for r in res]
+    for tag in ('both', 'dy'):
+        assert all(np.array_equal(a, b) for a, b in zip(wg[tag], wg['f32'])), tag
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(96, 16, 32), (200, 64, 48), (64, 256, 32)])
+def test_batchnorm_backward_on_bf16_gradients(backend, cfg):
+    """bn_bwd_reduce (dA / G bf16, in place) and bn_bwd_apply in every storage combination of G and dX (+ the added gradient)."""
+    rt = get_runtime(backend)
+    M, Cc, rpb = cfg
+    rng = np.random.RandomState(74)
+    x16, x32 = both(rt, rng.normal(size=(M, Cc)) * 1.5 + 3.0)
+    nb = -(-M // rpb)
+    bn = _bn_coeffs(rt, rng, Cc)
+    c1, c2 = (rt.upload((rng.normal(size=Cc) * 0.1).astype(np.float32)) for _ in range(2))
+    dA = rng.normal(size=(M, Cc))
+    G16, G32 = both(rt, rng.normal(size=(M, Cc)))
+    A16, A32 = both(rt, rng.normal(size=(M, Cc)))
+    # reduce: the masked gradient is written rounded, the sums are those of the unrounded values
+    red = {}
+    for tag in ('f32', 'bf16'):
+        d16, d32 = both(rt, dA)
+        d = d32 if tag == 'f32' else d16
+        part2 = rt.alloc((nb, 2, Cc), zero=False)
+        ops.bn_bwd_reduce(rt, d, x16, M, Cc, bn.mean, bn.inv_std, bn.scale, bn.beta_buf, 1, d, rpb, part2)(rt.stream)
+        rt.synchronize()
+        red[tag] = (d.get(), part2.get())
+    assert np.array_equal(red['bf16'][0], bf16_bits(red['f32'][0]))
+    Gs = widen(red['bf16'][0]).astype('f8').reshape(M, Cc)             # sums of the values as stored
+    p = red['bf16'][1].reshape(2, Cc, nb).astype('f8').sum(axis=2)
+    np.testing.assert_allclose(p[0], Gs.sum(0), rtol=0, atol=2e-6 * np.abs(Gs).sum(0).max())
+    ref = {}
+    for g16 in (False, True):
+        for o16 in (False, True):
+            dX, cs = rt.alloc((M, Cc), np.uint16 if o16 else np.float32, zero=False), rt.alloc((nb, Cc), zero=False)
+            ops.bn_bwd_apply(rt, G16 if g16 else G32, x16, M, Cc, bn.mean, bn.inv_std, bn.scale, c1, c2, dX, add=A16 if o16 else A32, rpb=rpb,
+                             colsum=cs)(rt.stream)
+            rt.synchronize()
+            ref[(g16, o16)] = (dX.get(), cs.get())
+    base = ref[(False, False)]
+    assert np.array_equal(ref[(True, False)][0], base[0]) and np.array_equal(ref[(True, False)][1], base[1])
+    for g16 in (False, True):
+        assert np.array_equal(ref[(g16, True)][0], bf16_bits(base[0]))
+        # column sums (the bias gradient of the producing conv) of a bf16-stored dX: of the values as stored
+        stored = widen(ref[(g16, True)][0]).astype('f8').reshape(M, Cc)
+        np.testing.assert_allclose(ref[(g16, True)][1].astype('f8').sum(0), stored.sum(0), rtol=0, atol=2e-6 * np.abs(stored).sum(0).max())

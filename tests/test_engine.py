@@ -318,7 +318,7 @@ def bf16_gradients_vs_pinned_oracle(rt, net, onet, P, x, y, bar=2e-4):
     bfloat16 in each of the three passes (oracle/torch_ref.py:_QBilinear, configured from the net's own launches by
     tests/pinning.py:device_quant) on the device's own ReLU / pooling decisions and rounded forward operands: forward output at the
     1e-3 mm bar, cost at 1e-5, every parameter gradient at `bar` of its tensor's scale -- the bars of the fp32 path."""
-    from tests.pinning import device_quant, device_store, store_agreement
+    from tests.pinning import device_grad_pins, device_quant, device_store, store_agreement
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), bf16=True)
     cost, out = eng.cost_and_grads(x, y)
     quant = device_quant(eng, net)
@@ -326,9 +326,22 @@ def bf16_gradients_vs_pinned_oracle(rt, net, onet, P, x, y, bar=2e-4):
     # bf16 STORAGE (the default of the bf16 mode): the device's own stored tensors are pinned like its rounded MFMA operands ...
     store = device_store(eng, net) if eng.store16 else None
     assert (store is not None and len(store) >= 10) == bool(engine.BF16_STORE)
-    own = {}
+    own, own_g = {}, {}
+    gpins = device_grad_pins(eng, net) if eng.grad16 else None
     c_ref, G_ref, out_ref = torch_ref.cost_and_grads(onet, nets.cast_params(P, np.float64), x.astype(np.float64), y.astype(np.float64),
-                                                     masks=device_masks(eng, net), quant=quant, store=store, stored_out=own)
+                                                     masks=device_masks(eng, net), quant=quant, store=store, stored_out=own, grad_pins=gpins,
+                                                     stored_grads=own_g)
+    if gpins is not None:
+        # the same un-pinned check for the bf16-stored gradient tensors (where the net is big enough to have any: maps of > 256 rows)
+        # (the device forms the BatchNorm-backward sums from the values AS STORED, so the oracle on the pinned tensors reproduces c1 / c2;
+        # what is left are elements within float32 round-off of a bfloat16 rounding boundary: the neighbouring value, or -- for an
+        # element that is the result of a cancellation -- float32 noise at the tensor's scale)
+        for (kind, i), mine in own_g.items():
+            pin = gpins[0][i] if kind == 'g' else gpins[1][i]
+            mine = np.asarray(mine, np.float32)
+            same = mine == pin
+            bound = np.maximum(np.abs(pin) * np.float32(2.0 ** -7), np.float32(2e-5) * np.abs(pin).max())
+            assert same.mean() >= 0.995 and (np.abs(mine - pin)[~same] <= bound[~same]).all(), (kind, i, float(same.mean()))
     if store is not None:
         # ... and the pins themselves are checked WITHOUT pinning: the float64 oracle's own rounding of what it would have stored equals
         # the device's stored tensor everywhere except where the value sits within float32 round-off of a bfloat16 rounding boundary
@@ -372,6 +385,33 @@ def test_bf16_step_matches_the_bf16_oracle(backend, monkeypatch):
                                              masks=device_masks(eng, net))
     far = max(np.abs(G16[i][0] - G_plain[i][0]).max() / np.abs(G_plain[i][0]).max() for i in G_plain if onet['layers'][i]['kind'] == 'conv')
     assert far > 20 * 2e-4, far                                               # ... and the plain oracle would not pass the bar
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_bf16_gradient_storage_on_maps_large_enough_to_use_it(backend, monkeypatch):
+    """The bf16 mode also stores the GRADIENTS of the activation tensors as bfloat16 -- for maps of more than 256 rows (engine.
+    _grad_dtype).  A 64x64 net at batch 4 has such maps in stages 1 and 2 (1 024 and 256+ rows): the masked gradients G and the
+    BatchNorm-backward outputs dX there really are bf16 on the device, every parameter gradient still meets the 2e-4 bar against the
+    oracle on the device's own stored operands, the oracle's own roundings agree with the device's stored gradients, and with
+    BF16_GRADS off the gradients come out float32 and different."""
+    from tests.pinning import device_grad_pins
+    monkeypatch.setattr(engine, 'FC1_MIN_K', 512)
+    rt = get_runtime(backend)
+    net, onet, P = make_net(rt, 0, 4, 64, 1, 30, calib_batch=4)
+    rng = np.random.RandomState(16)
+    x = nets.synthetic_crops(rng, 4, 64, 64, np.float32)
+    y = rng.normal(0, 0.3, (4, 30)).astype(np.float32)
+    eng, quant, (c16, o16, G16), _ = bf16_gradients_vs_pinned_oracle(rt, net, onet, P, x, y)
+    assert eng.grad16
+    gp, dv = device_grad_pins(eng, net)
+    assert len(gp) >= 6 and len(dv) >= 6, (len(gp), len(dv))
+    monkeypatch.setattr(engine, 'BF16_GRADS', False)
+    e2 = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), bf16=True)
+    assert e2.store16 and not e2.grad16
+    e2.cost_and_grads(x, y)
+    assert device_grad_pins(e2, net) == ({}, {})
+    G2 = grads_from_store(e2, net)
+    assert any(not np.array_equal(G16[i][0], G2[i][0]) for i in G16)
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
