@@ -370,6 +370,9 @@ BF16_STORE = knob('DPP_BF16_STORE', '1') != '0'
 # ... and the GRADIENTS of those tensors (the masked gradient G a data-gradient epilogue writes into a BatchNorm view, the dX that
 # bn_bwd_apply writes): the backward pass moves twice the bytes of the forward pass.  DPP_BF16_GRADS=0: float32 gradients.
 BF16_GRADS = knob('DPP_BF16_GRADS', '1') != '0'
+# ... and runs the channel-expanding 1x1 convolutions / the data gradients of the reducing ones (dpp_gemm variant 4, K = 32 / 64) on
+# bf16 MFMA operands (dpp_gemm_desc.precision).  DPP_BF16_GEMM=0: f32 MFMA there (rounds 2-3: only the 3x3 convolutions and FC1).
+BF16_GEMM = knob('DPP_BF16_GEMM', '1') != '0'
 # ADAM of the FC1 weight (90 % of the parameters, 470 MB of optimizer traffic) inside the backward pass: its gradient is final a few
 # kernels into the pass, so the update runs on the gradient branch under the latency-bound data-gradient chain instead of in the
 # serial tail of the step (step_plan only: cost_and_grads / allreduce paths keep backward and update apart).
@@ -976,9 +979,10 @@ class CompiledNet(object):
             variant = 1 if rs is not None else (2 if ks is not None else (4 if ex is not None else (3 if s16 is not None else 0)))
 
             def build(tile, variant, epi):
+                # (bf16 mode: the wave-autonomous kernel multiplies on the bf16 matrix pipe where K is a whole 32-deep step)
                 return ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
                                 bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=variant,
-                                name='conv1x1_%d' % layer.layerNum)
+                                name='conv1x1_%d' % layer.layerNum, precision=self.prec if (variant == 4 and Ci >= 32 and BF16_GEMM) else 0)
             if variant in (2, 3, 4) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
                 # the shape asks for the kernel, the buffers rule it out (alignment / prologue): the generic tile, not a failed build
                 variant, (tile, _) = 0, gemm_plan(M, Co, Ci, allow_split=False)
@@ -1419,7 +1423,8 @@ class CompiledNet(object):
                 def build(tile, variant, epi):
                     return ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
                                     residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
-                                    name='dgrad1x1_%d' % layer.layerNum)
+                                    name='dgrad1x1_%d' % layer.layerNum,
+                                    precision=self.prec if (variant == 4 and Co >= 32 and dY_act is None and BF16_GEMM) else 0)
                 if variant in (2, 3, 4) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
                     variant, (tile, _) = 0, gemm_plan(M, Ci, Co, allow_split=False)       # see the forward twin
                 epi = None

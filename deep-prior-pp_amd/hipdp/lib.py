@@ -53,7 +53,7 @@ class GemmDesc(C.Structure):
                 ('bias', C.c_void_p), ('residual', C.c_void_p),
                 ('M', C.c_int), ('N', C.c_int), ('K', C.c_int),
                 ('splitk', C.c_int), ('partial', C.c_void_p),
-                ('bm', C.c_int), ('bn', C.c_int), ('wm', C.c_int), ('variant', C.c_int), ('epi', Epilogue), ('store', C.c_int)]
+                ('bm', C.c_int), ('bn', C.c_int), ('wm', C.c_int), ('variant', C.c_int), ('epi', Epilogue), ('store', C.c_int), ('precision', C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/dpp_hip.h declares must be listed here

@@ -264,7 +264,7 @@ def epilogue(stats=None, bn=None, bn_x=None, bn_relu=True, bn_partial=None):
 
 
 def gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, mapA=None, mapB=None, mapC=None, actA=None, actB=None,
-         bias=None, residual=None, splitk=1, partial=None, tile=(0, 0, 0), epi=None, variant=0, name='gemm'):
+         bias=None, residual=None, splitk=1, partial=None, tile=(0, 0, 0), epi=None, variant=0, name='gemm', precision=0):
     """C = A_op . B_op, see dpp_gemm in include/dpp_hip.h."""
     d = GemmDesc()
     d.A, d.lda, d.a_kc = A.ptr, lda, int(a_kc)
@@ -285,7 +285,8 @@ def gemm(rt, A, B, Cbuf, M, N, K, a_kc, b_kc, lda, ldb, ldc=0, mapA=None, mapB=N
     if _is16(residual) != _is16(Cbuf) and residual is not None and Cbuf is not None:
         raise ValueError("dpp_gemm: C and residual must be stored alike")
     d.store = _store(A, B, Cbuf, getattr(epi, '_bn_x', None) if epi is not None else None)
-    meta = dict(kernel='gemm_mfma_f32', flops=2.0 * M * N * K,
+    d.precision = int(precision)
+    meta = dict(kernel='gemm_mfma_bf16' if precision else 'gemm_mfma_f32', flops=2.0 * M * N * K,
                 bytes=_esz(A) * M * K + _esz(B) * K * N + (4.0 * M * N * max(1, splitk) if splitk > 1 else _esz(Cbuf) * M * N) +
                 (_esz(residual) * M * N if residual is not None else 0))
     return Launch(rt.lib.dpp_gemm, (C.byref(d),), (d, A, B, Cbuf, bias, residual, partial, actA, actB, epi), name, meta)

@@ -142,6 +142,9 @@ typedef struct {
     dpp_epilogue epi; /* fused statistics / BatchNorm-backward epilogue (requires splitk == 1) */
     int store;        /* DPP_ST_* mask: which of A, B, C (+ residual), epi.bn_x hold bf16 elements (0 = all float32).  Variant 4 and the
                          generic tiles with 16-byte-aligned whole-quad shapes take it; DPP_E_UNSUPPORTED otherwise. */
+    int precision;    /* 0: f32 MFMA (exact); 1: both operands rounded to bf16 (RNE, A after its prologue), f32 accumulation on
+                         v_mfma_f32_16x16x32_bf16 -- BASELINE config 5.  Variant 4 with K = 32 / 64 only (dpp_gemm_variant_rows says
+                         0 otherwise); dpp_fc_gemm takes its precision as an argument and ignores this field. */
 } dpp_gemm_desc;
 int dpp_gemm(const dpp_gemm_desc* d, dpp_stream_t stream);
 /* Would dpp_gemm run `d` on the kernel d->variant asks for (2, 3 or 4)?  Returns that kernel's rows per workgroup (the row-block count of

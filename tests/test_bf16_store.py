@@ -453,3 +453,64 @@ def test_batchnorm_backward_on_bf16_gradients(backend, cfg):
         # column sums (the bias gradient of the producing conv) of a bf16-stored dX: of the values as stored
         stored = widen(ref[(g16, True)][0]).astype('f8').reshape(M, Cc)
         np.testing.assert_allclose(ref[(g16, True)][1].astype('f8').sum(0), stored.sum(0), rtol=0, atol=2e-6 * np.abs(stored).sum(0).max())
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(64, 256, 96, 32), (32, 128, 128, 64), (64, 64, 64, 32)])
+@pytest.mark.parametrize('stored', [False, True])
+def test_expand_kernel_on_bf16_mfma_operands(backend, cfg, stored):
+    """dpp_gemm variant 4 with precision = 1: both operands rounded to bfloat16 (the activation AFTER its BatchNorm + ReLU prologue),
+    f32 accumulation on v_mfma_f32_16x16x32_bf16 -- forward and data gradient against the float64 product of the ROUNDED operands
+    (the rounding is the whole difference to the f32 kernel, so the f32 tolerance applies), on float32 and on bf16-stored tensors;
+    K = 16 and the other dpp_gemm kernels refuse the precision."""
+    rt = get_runtime(backend)
+    K, N, M, rpw = cfg
+    rng = np.random.RandomState(81)
+    X16, X32 = both(rt, rng.normal(size=(M, K)) * 2 + 1)
+    R16, R32 = both(rt, rng.normal(size=(M, N)))
+    Wk = (rng.normal(size=(N, K)) * 0.3).astype(np.float32)
+    mean, scale, beta = (rng.normal(size=K).astype(np.float32) for _ in range(3))
+    bias = rng.normal(size=N).astype(np.float32)
+    X, R = (X16, R16) if stored else (X32, R32)
+    xv, rv = widen(X16.get()).reshape(M, K), widen(R16.get()).reshape(M, N)
+    Y = rt.alloc((M, N), np.uint16 if stored else np.float32, zero=False)
+    nblk = M // rpw
+    stats = rt.alloc((nblk, 2, N), zero=False)
+    L = ops.gemm(rt, X, rt.upload(Wk), Y, M, N, K, 1, 1, K, K, N, actA=ops.act(Act.BN_RELU, rt.upload(mean), rt.upload(scale), rt.upload(beta), K),
+                 bias=rt.upload(bias), residual=R, tile=(rpw, 64, 4), variant=4, epi=ops.epilogue(stats=stats), precision=1)
+    assert ops.gemm_variant_rows(rt, L) == rpw
+    L(rt.stream)
+    rt.synchronize()
+    dx = (xv - mean).astype(np.float32)
+    a = np.maximum((dx.astype('f8') * scale.astype('f8') + beta.astype('f8')).astype(np.float32), 0)        # dpp_act4's arithmetic
+    ref = widen(bf16_bits(a)).astype('f8') @ widen(bf16_bits(Wk)).astype('f8').T + bias + rv
+    got = widen(Y.get()).reshape(M, N) if stored else Y.get()
+    tol = 3e-6 * np.sqrt(K) * np.abs(ref).max()
+    if stored:
+        assert np.abs(got - ref).max() <= np.abs(ref).max() * 2.0 ** -8 + tol        # within one bf16 rounding of the f32 result ...
+        assert (got == widen(bf16_bits(ref.astype(np.float32)))).mean() > 0.99          # ... and almost always THE rounding of it
+    else:
+        np.testing.assert_allclose(got, ref, rtol=0, atol=tol)
+    p = stats.get().reshape(2, N, nblk)
+    np.testing.assert_allclose(p[0].mean(axis=1), ref.mean(0), rtol=0, atol=1e-5 * np.abs(ref).max())
+    # data gradient: dX = bf16(dY) . bf16(W2) (+ share), BatchNorm-backward epilogue
+    W2 = (rng.normal(size=(K, N)) * 0.3).astype(np.float32)
+    dY16, dY32 = both(rt, rng.normal(size=(M, K)))
+    bnx = rng.normal(size=(M, N)).astype(np.float32)
+    bn = _bn_coeffs(rt, rng, N)
+    dH = rt.alloc((M, N), zero=False)
+    part = rt.alloc((nblk, 2, N), zero=False)
+    L = ops.gemm(rt, dY16 if stored else dY32, rt.upload(W2), dH, M, N, K, 1, 0, K, N, N, tile=(rpw, 64, 4), variant=4, precision=1,
+                 epi=ops.epilogue(bn=bn, bn_x=rt.upload(bnx), bn_relu=True, bn_partial=part))
+    assert ops.gemm_variant_rows(rt, L) == rpw
+    L(rt.stream)
+    rt.synchronize()
+    keep = ((bnx.astype('f8') - bn.mean.get()) * bn.scale.get() + bn.beta_buf.get()) >= 0
+    g = np.where(keep, widen(dY16.get()).reshape(M, K).astype('f8') @ widen(bf16_bits(W2)).astype('f8'), 0.0)
+    np.testing.assert_allclose(dH.get(), g, rtol=0, atol=3e-6 * np.sqrt(K) * np.abs(g).max())
+    # refused where it is not built
+    A16k = rt.alloc((M, 16))
+    assert ops.gemm_variant_rows(rt, ops.gemm(rt, A16k, rt.alloc((64, 16)), rt.alloc((M, 64)), M, 64, 16, 1, 1, 16, 16, 64, tile=(32, 64, 4), variant=4,
+                                              precision=1)) == 0
+    with pytest.raises(Exception):
+        ops.gemm(rt, X32, rt.upload(Wk), rt.alloc((M, N)), M, N, K, 1, 1, K, K, N, precision=1)(rt.stream)
