@@ -129,7 +129,8 @@ __device__ __forceinline__ void stage_halo(const TX* __restrict__ X, int N, int 
     }
 }
 
-template <int BM, int BN, int PREC = 0, class TX = float>
+// EST: the epilogue may meet bf16-stored tensors (Y / residual / bn_x); TX: element type of X
+template <int BM, int BN, int PREC = 0, class TX = float, bool EST = false>
 __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     dpp_kernarg_warm<sizeof(Conv3Args)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
         const int vi = (a.N - n0 < a.img) ? (a.N - n0) : a.img;
         const int vy = (a.H - y0 < TH) ? (a.H - y0) : TH;
         const int vx = (a.W - x0 < TW) ? (a.W - x0) : TW;
-        dpp_epilogue_wide<RM, CN, 4, 1, BM, BN>(acc, smem, col0, a.Co, wco, a.residual, a.Y, a.epi, vi * vy * vx, wave, 0, l15, kq,
+        dpp_epilogue_wide<RM, CN, 4, 1, BM, BN, 1, EST>(acc, smem, col0, a.Co, wco, a.residual, a.Y, a.epi, vi * vy * vx, wave, 0, l15, kq,
                                                 [&](int rl) {
             const int im = rl >> (a.lth + a.ltw);
             const int ty = (rl >> a.ltw) & (TH - 1);
@@ -440,8 +441,8 @@ struct Wgrad3Args {
     int lqy;              // log2 of the power-of-two quad group of the dY rows (>= Co/4 quads per row)
 };
 
-template <int BM, int MAXACC, class TX = float>
-__global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a, int y16) {
+template <int BM, int MAXACC, class TX = float, class TY = float>
+__global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a) {
     dpp_kernarg_warm<sizeof(Wgrad3Args)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_kernel(Wgrad3Args a
                     int n = n0 + im, y = y0 + ty, x = x0 + tx;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (im < a.img && n < a.N && y < a.H && x < a.W)
-                        v = dpp_ld4_rt(a.dY, (((size_t)n * a.H + y) * a.W + x) * Co + c0, y16 != 0);     // (dY may be bf16-stored: DPP_ST_B)
+                        v = dpp_ld4(reinterpret_cast<const TY*>(a.dY) + (((size_t)n * a.H + y) * a.W + x) * Co + c0);     // (TY: dY may be bf16-stored, DPP_ST_B)
                     *reinterpret_cast<float4*>(&Ys[row * LDY + c0]) = v;
                 }
             }
@@ -612,14 +613,16 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     dim3 grid(nblk, dpp_cdiv(Co, bn));
     hipStream_t st = static_cast<hipStream_t>(stream);
     // gfx950 has 160 KiB of LDS per CU; requests above the default 64 KiB window need the opt-in attribute
-#define DPP_C3K(BM_, BN_, P_, T_) do { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_, P_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        DPP_LAUNCH((conv3x3_kernel<BM_, BN_, P_, T_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
+#define DPP_C3K(BM_, BN_, P_, T_, E_) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_, P_, T_, E_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        DPP_LAUNCH((conv3x3_kernel<BM_, BN_, P_, T_, E_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
+#define DPP_C3E(BM_, BN_, P_, T_) do { if (store & (DPP_ST_C | DPP_ST_BNX)) DPP_C3K(BM_, BN_, P_, T_, true); else DPP_C3K(BM_, BN_, P_, T_, false); } while (0)
 #define DPP_C3(BM_, BN_) if (bm == BM_ && bn == BN_) { \
-        if (precision) { if (store & DPP_ST_A) DPP_C3K(BM_, BN_, 1, dpp_bf16); else DPP_C3K(BM_, BN_, 1, float); } \
-        if (store & DPP_ST_A) DPP_C3K(BM_, BN_, 0, dpp_bf16); else DPP_C3K(BM_, BN_, 0, float); }
+        if (precision) { if (store & DPP_ST_A) DPP_C3E(BM_, BN_, 1, dpp_bf16); else DPP_C3E(BM_, BN_, 1, float); } \
+        if (store & DPP_ST_A) DPP_C3E(BM_, BN_, 0, dpp_bf16); else DPP_C3E(BM_, BN_, 0, float); }
     DPP_C3(128, 64) DPP_C3(128, 32) DPP_C3(128, 16) DPP_C3(64, 64) DPP_C3(64, 32) DPP_C3(64, 16)
 #undef DPP_C3
+#undef DPP_C3E
 #undef DPP_C3K
     return DPP_E_UNSUPPORTED;
 }
@@ -700,10 +703,12 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, 9 / taps_pb);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DPP_W3K(BM_, MA_, T_) do { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<BM_, MA_, T_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        DPP_LAUNCH((conv3x3_wgrad_kernel<BM_, MA_, T_>), grid, dim3(DPP_THREADS), lds, st, a, y16); return dpp_launch_status(); } while (0)
-#define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { if (store & DPP_ST_A) DPP_W3K(BM_, MA_, dpp_bf16); else DPP_W3K(BM_, MA_, float); }
+#define DPP_W3K(BM_, MA_, T_, Y_) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_kernel<BM_, MA_, T_, Y_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        DPP_LAUNCH((conv3x3_wgrad_kernel<BM_, MA_, T_, Y_>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
+#define DPP_W3(BM_, MA_) if (bm == BM_ && maxacc <= MA_) { \
+        if (store & DPP_ST_A) { if (y16) DPP_W3K(BM_, MA_, dpp_bf16, dpp_bf16); else DPP_W3K(BM_, MA_, dpp_bf16, float); } \
+        else { if (y16) DPP_W3K(BM_, MA_, float, dpp_bf16); else DPP_W3K(BM_, MA_, float, float); } }
     DPP_W3(128, 3) DPP_W3(128, 4) DPP_W3(128, 9) DPP_W3(128, 12) DPP_W3(128, 16)
     DPP_W3(64, 3) DPP_W3(64, 4) DPP_W3(64, 9) DPP_W3(64, 12) DPP_W3(64, 16)
 #undef DPP_W3

@@ -16,3 +16,5 @@ struct GemmArgs {
 // dpp_gemm variant 4 (gemm_expand.hip): rows per wave for this problem (0: the kernel does not take it), and its launch
 int dpp_gemm_expand_rows(const dpp_gemm_desc& d, const GemmArgs& ga);
 int dpp_gemm_expand_launch(const GemmArgs& ga, int rpw, hipStream_t st);
+// variants 0-3 on bf16-stored tensors (gemm_st.hip)
+int dpp_gemm_dispatch_st(GemmArgs& ga, int bm, int bn, int wm, hipStream_t st);

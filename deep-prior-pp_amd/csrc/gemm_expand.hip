@@ -29,7 +29,8 @@ namespace {
 //     prologue) and multiplied on v_mfma_f32_16x16x32_bf16 with f32 accumulation: a lane's 8 / 16 k values are one / two 8-element
 //     operands, so the 128 f32 MFMAs of a 32-row iteration at K = 64 become 16.  The filter slice is packed once per wave.
 // KT = K; BKC: B is [N][K] (forward) or [K][N] (data gradient); IT2: two register sets (iterations > 1); ACT / RES / BNB / LZ: register diets.
-template <int KT, bool BKC, bool IT2, bool ACT, bool RES, bool BNB, bool LZ = false, bool PB = false>
+// ST: the instantiation may meet bf16-stored tensors (the float32 ones carry none of the run-time type tests).
+template <int KT, bool BKC, bool IT2, bool ACT, bool RES, bool BNB, bool LZ = false, bool PB = false, bool ST = false>
 __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expand_kernel(GemmArgs ga, int rpw) {
     static_assert(!PB || (KT % 32 == 0 && !LZ), "bf16 MFMA operands: whole 32-deep steps");
     dpp_kernarg_warm<sizeof(GemmArgs)>();
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
     const int modeA = ACT ? d.actA.mode : 0;
     const bool relu_mask = BNB && ep.bn_relu != 0;
     // bf16-stored tensors (DPP_ST_*): A (forward: the activations), C + residual (forward: the output), epi.bn_x (data gradient)
-    const bool a16 = !LZ && ga.shA != 0, c16 = (d.store & DPP_ST_C) != 0, x16 = (d.store & DPP_ST_BNX) != 0;
+    const bool a16 = ST && !LZ && ga.shA != 0, c16 = ST && (d.store & DPP_ST_C) != 0, x16 = ST && (d.store & DPP_ST_BNX) != 0;
     dpp_stamp(ga.prof, 0);
 
     // ---- the filter slice, the prologue coefficients of this lane's k range, the per-column vectors of its four columns ----
@@ -320,7 +321,9 @@ int launch_expand(const GemmArgs& ga, int rpw, hipStream_t st) {
     const dim3 grid(dpp_cdiv(waves, 4));
     const bool it2 = rpw > 32, act = d.actA.mode != 0, res = d.residual != nullptr, bnb = d.epi.bn_x != nullptr, lz = d.actA.mode == 4;
     const bool pb = d.precision == 1;
-#define DPP_EX(K_, I_, A_, R_, B_, L_, P_) DPP_LAUNCH((gemm_expand_kernel<KT, K_, I_, A_, R_, B_, L_, P_>), grid, dim3(DPP_THREADS), 0, st, ga, rpw)
+    const bool stg = d.store != 0;
+#define DPP_EXS(K_, I_, A_, R_, B_, L_, P_, S_) DPP_LAUNCH((gemm_expand_kernel<KT, K_, I_, A_, R_, B_, L_, P_, S_>), grid, dim3(DPP_THREADS), 0, st, ga, rpw)
+#define DPP_EX(K_, I_, A_, R_, B_, L_, P_) do { if (!(L_) && stg) DPP_EXS(K_, I_, A_, R_, B_, L_, P_, !(L_)); else DPP_EXS(K_, I_, A_, R_, B_, L_, P_, false); } while (0)
 #define DPP_EX_P(K_, I_, A_, R_, B_) do { if constexpr (KT >= 32) { if (pb) { DPP_EX(K_, I_, A_, R_, B_, false, true); break; } } \
                                           DPP_EX(K_, I_, A_, R_, B_, false, false); } while (0)
 #define DPP_EX_I(K_, A_, R_, B_, L_) do { if (L_) { if (it2) DPP_EX(K_, true, A_, R_, B_, true, false); else DPP_EX(K_, false, A_, R_, B_, true, false); } \
@@ -334,6 +337,7 @@ int launch_expand(const GemmArgs& ga, int rpw, hipStream_t st) {
         if (bnb) DPP_EX_R(false, false, true, false); else DPP_EX_R(false, false, false, false);
     }
 #undef DPP_EX_P
+#undef DPP_EXS
 #undef DPP_EX_R
 #undef DPP_EX_I
 #undef DPP_EX

@@ -561,8 +561,7 @@ class CompiledNet(object):
         self.rt = rt = runtime or default_runtime()
         self.optimizer = dict(optimizer) if optimizer else dict(name='ADAM')
         self.prec = int(bool(BF16_DEFAULT if bf16 is None else bf16))
-        self.store16 = bool(self.prec and BF16_STORE)           # conv outputs held as bf16 (see BF16_STORE)
-        self.grad16 = bool(self.store16 and BF16_GRADS)         # ... and their gradients (see BF16_GRADS)
+        self.store16 = self.grad16 = False                      # set below, once the layer list is known
         self.dp = dp                                  # hipdp.parallel.DataParallel or None
         # BatchNorm statistics / backward sums produced by the conv epilogues (off with sync-BN, whose partials are
         # all-gathered by row block, and for tests that want the stand-alone BatchNorm kernels)
@@ -572,6 +571,13 @@ class CompiledNet(object):
         self.key = None
         self.weight_decay = float(weight_decay)
         self.order, self.consumers, self.layers = _collect(net)
+        # bf16 storage is built for the ResNet path (stem + ConvLayer + FC head); a net with generic ConvPoolLayers / concatenations
+        # (PoseRegNet, ScaleNet -- e.g. the refinement net of the config-5 cascade) keeps float32 tensors in the bf16 mode
+        resnet_like = all(_layer_kind(l) != 'ConvPoolLayer' or (tuple(l.cfgParams.filterDim) == (5, 5) and tuple(l.cfgParams.poolsize) == (2, 2)
+                                                                 and l.cfgParams.nFilters <= 32 and l.cfgParams.activation is None)
+                          for l in self.layers) and not any(v.kind == 'concat' for v in self.order)
+        self.store16 = bool(self.prec and BF16_STORE and resnet_like)         # conv outputs held as bf16 (see BF16_STORE)
+        self.grad16 = bool(self.store16 and BF16_GRADS)                        # ... and their gradients (see BF16_GRADS)
         self.store = get_store(net, rt, self.layers)
         self.fwd, self.bwd, self.upd = Plan('forward'), Plan('backward'), Plan('update')
         self.views = {}
