@@ -65,7 +65,17 @@ def _augment_and_step(rt, cam, cube, J, B, names_cycle, seed, sample0=0, global_
     c_ref = float(((o.numpy() - ys.astype('f8')) ** 2).sum(axis=1).mean())
     assert abs(cost - c_ref) < 2e-5 * abs(c_ref), (cost, c_ref)
     # (a freshly initialised net: embeddings of magnitude ~10, so the bar is relative here; the 1e-3 mm bar on calibrated nets is in test_full_size.py)
-    assert np.abs(eng.out.buf.get() - o.numpy()).max() < 1e-5 * max(1.0, np.abs(o.numpy()).max())
+    # 1e-5 of the output scale is where float32 itself sits on this 50-layer training-mode forward at batch 256 (round 4 measured the
+    # HIP path at 1.01-1.14e-5 on other inputs whichever kernel variants run, the float32 ORACLE at about the same): the bar is the
+    # larger of 1e-5 and twice the distance of the oracle's own float32 evaluation from float64 -- a kernel error would be far outside
+    err = np.abs(eng.out.buf.get() - o.numpy()).max()
+    scale_o = max(1.0, np.abs(o.numpy()).max())
+    if err >= 1e-5 * scale_o:
+        with torch.no_grad():
+            T32 = torch_ref.to_torch(P, dtype=torch.float32, requires_grad=False)
+            o32, _ = torch_ref.forward(onet, T32, torch.tensor(xs, dtype=torch.float32), True)
+        noise = np.abs(o32.numpy().astype('f8') - o.numpy()).max()
+        assert err < 2.0 * noise and err < 3e-5 * scale_o, (err / scale_o, noise / scale_o)
     step = eng.store.w.get() - w0
     assert np.isfinite(step).all() and np.abs(step).max() <= 1e-3 * (1 + 1e-3) + 1e-6 and (np.abs(step) > 1e-4).mean() > 0.3
 
@@ -123,7 +133,7 @@ def test_config5_bf16_forward_matches_the_bf16_oracle_and_reports_its_error():
     """configs[4]'s arithmetic at 256x256 (FC1 65 536 x 1 024), deterministic forward on a calibrated net: the device against the
     float64 oracle that rounds the SAME operands (the 3x3 convolutions' and FC1's) to bfloat16 -- the kernels' arithmetic, held to
     the 1e-3 mm bar on the device's own rounded operands -- and the distance of the bf16 result from the fp32 path, which SURVEY.md section 8(d) asks to REPORT: measured 2-4 mm max on this net, bounded at 1.5x."""
-    from tests.pinning import device_quant
+    from tests.pinning import device_quant, device_store, store_agreement
     rt = get_runtime('hip')
     R.set_default_runtime(rt)
     net, onet, P = make_net(rt, 1, 2, 256, 14, 3)
@@ -141,18 +151,25 @@ def test_config5_bf16_forward_matches_the_bf16_oracle_and_reports_its_error():
     # bf16 neighbour in a float64 evaluation, and one such flip is worth 100 float32 rounding errors: unpinned the two sit 0.6 mm apart)
     import torch
     quant = device_quant(e16, net)
-    assert len(quant) == 21 and all(q['pin'] is not None for q in quant.values())
+    # 20 3x3 convolutions + FC1 (rounds 2-3) + the 1x1 convolutions that run on the wave-autonomous kernel with K = 32 / 64 (round 4)
+    assert len(quant) >= 21 + 12 and all(q['pin'] is not None for q in quant.values())
+    store = device_store(e16, net)                              # the bf16-STORED conv outputs of the deterministic forward, pinned
+    assert e16.store16 and len(store) >= 50
     with torch.no_grad():
         T = torch_ref.to_torch(P64, requires_grad=False)
-        ref16, _ = torch_ref.forward(onet, T, torch.tensor(x, dtype=torch.float64), False, quant=quant)
+        ref16, st16 = torch_ref.forward(onet, T, torch.tensor(x, dtype=torch.float64), False, quant=quant, store=store)
+    agree = store_agreement(store, st16['stored_out'])          # ... and the pins checked un-pinned
+    assert min(agree.values()) >= 0.995 and np.mean(list(agree.values())) >= 0.999, sorted(agree.items(), key=lambda kv: kv[1])[:3]
     err_oracle = np.abs(o16 - ref16.numpy()).max() * MM
-    unpinned = nets.compute_output(onet, P64, x.astype(np.float64), bf16=set(quant))
+    unpinned = nets.compute_output(onet, P64, x.astype(np.float64), bf16=set(quant), store16=True)
     err_mm = np.abs(o16 - o32).max() * MM
     print('bf16 forward at 256x256: %.5f mm from the bf16 oracle on the device operands (%.3f mm unpinned); %.4f mm (max), %.4f mm (mean) from '
           'the fp32 path' % (err_oracle, np.abs(o16 - unpinned).max() * MM, err_mm, np.abs(o16 - o32).mean() * MM))
     assert err_oracle < 1e-3, err_oracle                        # the bar of the fp32 path
-    assert np.abs(o16 - unpinned).max() * MM < 2.0
-    assert 1e-4 < err_mm < 6.2, err_mm                         # 1.5 x the 4.1 mm measured on this net (bf16 keeps 8 bits of mantissa)
+    assert np.abs(o16 - unpinned).max() * MM < 5.5             # (3.6 mm measured: every stored tensor is a chance to land on the other neighbour)
+    # REPORTED, not a parity bar: round 3 (bf16 operands in the 3x3 convolutions and FC1 only) measured 4.1 mm max; round 4 stores every
+    # conv output as bfloat16 (8 bits of mantissa on 53 tensors in a row): 9.1 mm max / 2.7 mm mean on this calibrated random net
+    assert 1e-4 < err_mm < 14.0, err_mm
 
 
 def test_config5_bf16_train_step_gradients_match_the_bf16_oracle_at_256():
@@ -166,7 +183,7 @@ def test_config5_bf16_train_step_gradients_match_the_bf16_oracle_at_256():
     x = nets.synthetic_crops(rng, B, 256, 256, np.float32)
     y = rng.normal(0, 0.3, (B, 30)).astype(np.float32)
     eng, quant, _, _ = bf16_gradients_vs_pinned_oracle(rt, net, onet, P, x, y)
-    assert len(quant) == 21                                    # twenty 3x3 convolutions and FC1
+    assert len(quant) >= 21 + 12                               # twenty 3x3 convolutions, FC1, and the 1x1 convolutions on bf16 MFMA operands (K = 32 / 64)
     w0 = eng.store.w.get().copy()
     cost = eng.train_step(x, y, 1e-3)
     step = eng.store.w.get() - w0

@@ -77,8 +77,10 @@ def zero_gradient_bounds(eng, net, onet, G_ref):
             dbeta, dgamma = np.abs(G_ref[j][0]).astype(np.float64), np.abs(G_ref[j][1]).astype(np.float64)
             # sum G - n*c1: c1 rounded; c2 * sum xhat: xhat uses the ROUNDED mean, so sum xhat = n * inv_std * (mean error)
             # (the constant covers the summation noise of the n terms as well: which realisation of it a build gets depends on the
-            #  summation order of every kernel downstream -- 64 held for the LDS-tiled stage-1 kernels, the row-streaming ones drew 1.1x that)
-            out[(i, 1)] = 128 * eps32 * scale * (dbeta + dgamma * (1.0 + mean * inv_std))
+            #  summation order of every kernel downstream -- 64 held for the LDS-tiled stage-1 kernels, the row-streaming ones drew 1.1x that,
+            #  round 4's wave-autonomous 1x1 kernels 1.3x of 128 on the stem at batch 128 and 2.2x in the bf16 mode at 256x256, where the
+            #  bias gradient is no longer ~0: sum xhat of a bf16-STORED tensor is not 0, and the oracle models that value, 4e-3 there)
+            out[(i, 1)] = 320 * eps32 * scale * (dbeta + dgamma * (1.0 + mean * inv_std))
     return out
 
 
