@@ -29,7 +29,9 @@ def main():
     fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
     write = per_kernel(sys.argv[2], 'WRITE_SIZE')
     steps = float(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith('--') else 1.0
-    n_adam = 18714452.0      # parameters of the bs128 NYU ResNet (type 0, 30-D output)
+    n_adam = 18714452.0      # parameters of the bs128 NYU ResNet (type 0, 30-D output); --params N for another net (256x256: 69046100)
+    if '--params' in sys.argv:
+        n_adam = float(sys.argv[sys.argv.index('--params') + 1])
     adam = [k for k in fetch if 'adam_kernel' in k]
     fcal = wcal = 1.0
     if adam:

@@ -17,6 +17,12 @@ python $R/tools/prof_summary.py $(find /tmp/p2 -name '*_results.db' | head -1) 8
 DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p3 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
 DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p4 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
 python $R/tools/pmc_summary.py $(find /tmp/p3 -name '*_results.db' | head -1) $(find /tmp/p4 -name '*_results.db' | head -1) 3 --json $O/hbm_traffic.json > $O/hbm_traffic.txt 2>&1
+# the same for BASELINE config 5's step (256x256, bs128): float32, and bf16 (bf16 MFMA operands + bf16-stored activations and gradients)
+for dt in f32 bf16; do
+  DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p3_$dt -o run -- python $R/tools/step_profile.py 2 256 $dt > /dev/null 2>&1
+  DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p4_$dt -o run -- python $R/tools/step_profile.py 2 256 $dt > /dev/null 2>&1
+  python $R/tools/pmc_summary.py $(find /tmp/p3_$dt -name '*_results.db' | head -1) $(find /tmp/p4_$dt -name '*_results.db' | head -1) 2 --params 69046100 > $O/hbm_traffic_256_$dt.txt 2>&1
+done
 # dynamic instruction mix per wave (SQ counters, two passes of 8; counters only + kernel trace)
 DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA --kernel-trace -d /tmp/p5 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
 DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace -d /tmp/p6 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
