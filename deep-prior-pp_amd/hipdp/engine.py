@@ -489,6 +489,16 @@ def conv3x3_bm(pixels, Co):
     return 128 if (pixels // 128) * (-(-Co // 64)) >= 512 else 64
 
 
+# 3x3 convolutions of the narrow square layers (and their data gradients) on the barrier-free dpp_conv3x3_stream for these channel
+# counts.  OFF by default: measured on the MI355X (profiles/r04_conv3x3_stream.txt) the kernel is no faster than the LDS-tiled one on
+# the shapes it was written for -- stage 1 (131 072 px, 16 -> 16) 14.7 us plain / 17.4 us with prologue + statistics against 12.1 /
+# 13.4 us, insensitive to the tiles per wave (1 | 2 | 4), and the bs128 step is 3.55 ms with it against 3.49 ms; stage 2 (32 -> 32,
+# 144 filter registers, one wave per SIMD) 16-22 us against 11-12 us.  Every wave re-loads the 9 KB filter through the texture path
+# (twice the operand traffic) and redoes the BatchNorm prologue for each of the nine taps; the tiled kernel pays one barrier per tap
+# but stages and activates each pixel once.
+CONV3_STREAM_C = tuple(int(v) for v in knob('DPP_CONV3_STREAM_C', '').split(',') if v)
+
+
 WGRAD_TARGET_BLOCKS = int(knob('DPP_WGRAD_TARGET_BLOCKS', '256'))
 
 
@@ -997,6 +1007,13 @@ class CompiledNet(object):
                 out.stats = (rt.alloc((nblk, 2, Co), zero=False), nblk, tile[0])
                 epi = ops.epilogue(stats=out.stats[0])
             self.fwd.add(build(tile, variant, epi))
+        elif self._conv3_stream(N, Hi, Wi, Ci, Co, src.base.buf, out.buf) and residual is None:
+            rows = rt.lib.dpp_conv3x3_stream_rows(N, Hi, Wi, Ci)
+            if want_stats:
+                out.stats = (rt.alloc((M // rows, 2, Co), zero=False), M // rows, rows)
+                epi = ops.epilogue(stats=out.stats[0])
+            self.fwd.add(ops.conv3x3_stream(rt, src.base.buf, N, Hi, Wi, Ci, st.view(layer.W), out.buf, actX=act, bias=st.view(layer.b), epi=epi,
+                                            name='conv3x3_%d' % layer.layerNum))
         else:
             bm = conv3x3_bm(M, Co)
             if want_stats:
@@ -1009,6 +1026,15 @@ class CompiledNet(object):
                                      residual=res, bm=bm, epi=epi, name='conv3x3_%d' % layer.layerNum, precision=self.prec))
         self.layer_io[id(layer)] = dict(in_view=src, out=out, residual=residual)
         return View(out)
+
+    def _conv3_stream(self, N, H, W, Ci, Co, *bufs):
+        """Whether a 3x3 layer (or its data gradient) runs on dpp_conv3x3_stream: a narrow square layer on float32 tensors in the
+        float32 mode (the bf16 mode multiplies the 3x3 layers on the bf16 matrix pipe of the LDS-tiled kernel)."""
+        if Ci != Co or Ci not in CONV3_STREAM_C or self.prec:
+            return False
+        if any(b is not None and b.dtype == ops.BF16 for b in bufs):
+            return False
+        return self.rt.lib.dpp_conv3x3_stream_rows(N, H, W, Ci) > 0
 
     def _emit_fc(self, layer, src):
         c = layer.cfgParams
@@ -1468,7 +1494,16 @@ class CompiledNet(object):
                 self._wtrans_jobs.append((st.view(layer.W), Co, Ci, Wd))       # one batched launch, see _emit_backward
                 bmd = conv3x3_bm(N * Hi * Wi, Ci)
                 epi = None
-                if not acc and self._sole_consumer_bn_view(src):
+                fuse = not acc and self._sole_consumer_bn_view(src)
+                if not acc and self._conv3_stream(N, Hi, Wi, Ci, Co, dY, dst, src.base.buf if fuse else None):
+                    if fuse:
+                        nb2 = N * Hi * Wi // rt.lib.dpp_conv3x3_stream_rows(N, Hi, Wi, Ci)
+                        tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
+                        epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])
+                    self.bwd.add(ops.conv3x3_stream(rt, dY, N, Hi, Wi, Ci, Wd, dst, epi=epi, name='dgrad3x3_%d' % layer.layerNum))
+                    tgt.grad_written = True
+                    return
+                if fuse:
                     nb2 = rt.lib.dpp_conv3x3_tiling(N, Hi, Wi, bmd, None, None, None)
                     tgt.fused_reduce = (rt.alloc((nb2, 2, Ci), zero=False), nb2)
                     epi = ops.epilogue(bn=src.bn, bn_x=src.base.buf, bn_relu=src.relu, bn_partial=tgt.fused_reduce[0])

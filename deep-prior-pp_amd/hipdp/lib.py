@@ -68,6 +68,9 @@ SIGNATURES = {
     'dpp_conv3x3_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Epilogue), C.c_int, stream_t]),
     'dpp_conv3x3_tiling': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'dpp_conv3x3_stream_rows': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'dpp_conv3x3_stream': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.POINTER(Epilogue), stream_t]),
     'dpp_conv3x3_wtrans': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_conv3x3_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'dpp_conv3x3_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,

@@ -363,6 +363,15 @@ def conv3x3(rt, X, N, H, W, Ci, Wk, Co, Y, actX=None, bias=None, residual=None, 
                   (X, Wk, Y, actX, bias, residual, epi), name, meta)
 
 
+def conv3x3_stream(rt, X, N, H, W, Cc, Wk, Y, actX=None, bias=None, epi=None, name='conv3x3'):
+    """dpp_conv3x3_stream: the 3x3 convolution of a narrow square layer on the barrier-free kernel (float32 tensors only)."""
+    _f32_only('dpp_conv3x3_stream', X, Y, getattr(epi, '_bn_x', None) if epi is not None else None)
+    px = float(N) * H * W
+    meta = dict(kernel='conv3x3_mfma_f32', flops=2.0 * px * 9 * Cc * Cc, bytes=px * 8.0 * Cc + 4.0 * 9 * Cc * Cc)
+    return Launch(rt.lib.dpp_conv3x3_stream, (X.ptr, N, H, W, Cc, _actp(actX), Wk.ptr, _p(bias), Y.ptr, C.byref(epi) if epi is not None else None),
+                  (X, Wk, Y, actX, bias, epi), name, meta)
+
+
 def conv3x3_wtrans(rt, Wk, Co, Ci, Wd, name='conv3x3_wtrans'):
     return Launch(rt.lib.dpp_conv3x3_wtrans, (Wk.ptr, Co, Ci, Wd.ptr), (Wk, Wd), name)
 

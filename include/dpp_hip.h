@@ -214,6 +214,14 @@ int dpp_conv3x3(const float* X, int N, int H, int W, int Ci, const dpp_act* act,
  * (v_mfma_f32_16x16x32_bf16): BASELINE config 5, not for the 1e-3 mm parity path.  Same tiling, epilogues and results layout. */
 int dpp_conv3x3_bf16(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* Wk, int Co,
                      const float* bias, const float* residual, float* Y, int bm, const dpp_epilogue* epi, int store, dpp_stream_t stream);
+/* The same convolution for the narrow square layers (C = Ci = Co in {16, 32}, W % 16 == 0, float32 tensors, no residual) as a
+ * wave-autonomous stream: a wave owns 16-pixel pieces of image rows, keeps the 9 x C x C filter in registers and loads every tap
+ * straight from global memory -- no halo tile, no barrier before the column reductions.  dpp_conv3x3_stream_rows = pixels per
+ * workgroup (= per block of epi->stats / epi->bn_partial), or 0 when the shape is not taken (then dpp_conv3x3_stream returns
+ * DPP_E_UNSUPPORTED and dpp_conv3x3 remains).  Same arithmetic per output element as dpp_conv3x3 up to the summation order. */
+int dpp_conv3x3_stream_rows(int N, int H, int W, int C);
+int dpp_conv3x3_stream(const float* X, int N, int H, int W, int C, const dpp_act* act, const float* Wk, const float* bias, float* Y,
+                       const dpp_epilogue* epi, dpp_stream_t stream);
 /* tile geometry chosen for (N,H,W,bm): returns the number of workgroup row blocks, writes tile height / width / images */
 int dpp_conv3x3_tiling(int N, int H, int W, int bm, int* th, int* tw, int* img);
 /* Wd[c][8-tap][o] = Wk[o][tap][c] (mirrored taps, channels swapped): weights of the data-gradient correlation. */

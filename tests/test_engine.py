@@ -124,7 +124,7 @@ def test_resnet_forward_eval_matches_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'lazy3', 'fc1stream', 'early_reduce', 'no_variants'])
+@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'lazy3', 'fc1stream', 'early_reduce', 'no_variants', 'conv3stream'])
 def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatch):
     """'lazy': type 0 with the opt-in plan in which the 1x1 convolutions form the gradient through a BatchNorm from (G, x) in
     their operand prologue (engine.LAZY_BN_BWD) instead of reading a tensor written by bn_bwd_apply.
@@ -132,7 +132,13 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
     data gradient, weight gradient with the BN+ReLU prologue) -- the full-size nets take that path for FC1, this 32x32 net
     (K = 1 024) only with the threshold lowered.
     'early_reduce': the filter / bias gradient partials reduced in several dpp_reduce_multi launches on the gradient branch while the
-    pass runs (engine.EARLY_REDUCE_BYTES; the bs128 net flushes every 16 MB) instead of one launch at its end."""
+    pass runs (engine.EARLY_REDUCE_BYTES; the bs128 net flushes every 16 MB) instead of one launch at its end.
+    'conv3stream': a 64x64 net, whose stage-1 maps are 16 pixels wide, with the opt-in engine.CONV3_STREAM_C: its 16 -> 16 3x3 layers
+    and their data gradients run on the barrier-free dpp_conv3x3_stream (measured no faster than the tiled kernel: off by default)."""
+    size = 32
+    if type_ == 'conv3stream':
+        size, type_ = 64, 0
+        monkeypatch.setattr(engine, 'CONV3_STREAM_C', (16, 32))
     if type_ == 'lazy2' and backend == 'emu':
         pytest.skip("the opt-in lazy2 plan (measured slower, off by default) is exercised on the GPU tier only; 'lazy' covers the mode-4 operand here")
     if type_ in ('lazy', 'lazy2', 'lazy3'):       # lazy2: only the data gradient does, and leaves the tensor it forms for the filter gradient
@@ -154,8 +160,10 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
         type_ = 0
     rt = get_runtime(backend)
     nJ, nD = (1, 30) if type_ == 0 else (14, 3)
-    net, onet, P = make_net(rt, type_, 4, 32, nJ, nD)
+    net, onet, P = make_net(rt, type_, 4, size, nJ, nD, **(dict(calib_batch=4) if size != 32 else {}))
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    n3s = sum(l.fn is rt.lib.dpp_conv3x3_stream for _, l in eng.all_launches())
+    assert n3s == (10 if size == 64 else 0), n3s          # 5 stage-1 blocks: forward + data gradient each
     variants = [l.keep[0].variant for _, l in eng.all_launches() if l.fn is rt.lib.dpp_gemm]
     assert (not any(v in (2, 3, 4) for v in variants)) if no_variants else (any(v in (2, 3) for v in variants) and any(v == 4 for v in variants))
     if engine.LAZY_BN_BWD:
@@ -169,7 +177,7 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
 
     def run(seed):
         rng = np.random.RandomState(seed)
-        x = nets.synthetic_crops(rng, 4, 32, 32, np.float32)
+        x = nets.synthetic_crops(rng, 4, size, size, np.float32)
         y = rng.normal(0, 0.3, (4, nJ * nD)).astype(np.float32)
         cost, out = eng.cost_and_grads(x, y)          # train mode: batch statistics, so the moving running stats do not matter
         c_ref, G_ref, out_ref = torch_ref.cost_and_grads(onet, P64, x.astype(np.float64), y.astype(np.float64), masks=device_masks(eng, net))

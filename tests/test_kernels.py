@@ -578,3 +578,70 @@ def test_conv3x3_bf16_operands(backend, cfg):
     ops.conv3x3(rt, dYb, N, H, W, Co, Wd, Ci, dA, bm=bm, precision=1)(rt.stream)
     rt.synchronize()
     np.testing.assert_allclose(layout.nhwc_to_nchw(dA.get()), da_ref, rtol=0, atol=3e-6 * np.sqrt(9 * Co) * np.abs(da_ref).max())
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(2, 8, 16, 16), (1, 6, 32, 16), (8, 32, 32, 16), (4, 3, 16, 16), (4, 16, 16, 32), (3, 8, 16, 16)])
+def test_conv3x3_stream_forward_statistics_and_fused_data_gradient(backend, cfg):
+    """dpp_conv3x3_stream (the barrier-free kernel of the narrow 3x3 layers): forward with the BatchNorm + ReLU prologue and the
+    statistics of the written tensor, and the data gradient with the BatchNorm-backward mask and sums, against float64."""
+    rt = get_runtime(backend)
+    N, H, W, Cc = cfg
+    M = N * H * W
+    rows = rt.lib.dpp_conv3x3_stream_rows(N, H, W, Cc)
+    rng = np.random.RandomState(71)
+    X = rt.upload(rng.normal(size=(N, H, W, Cc)).astype(np.float32))
+    Y = rt.alloc((N, H, W, Cc), zero=False)
+    Wr = (rng.normal(size=(Cc, Cc, 3, 3)) * 0.2).astype(np.float32)
+    Wk = rt.upload(layout.conv_w_to_kernel(Wr))
+    if M % 64:
+        assert rows == 0
+        assert rt.lib.dpp_conv3x3_stream(X.ptr, N, H, W, Cc, None, Wk.ptr, None, Y.ptr, None, rt.stream) != 0
+        return
+    assert rows in (64, 128) and M % rows == 0
+    x = X.get().astype('f8')
+    bias = rng.normal(size=Cc).astype(np.float32)
+    mean, scale, beta = (rng.normal(size=Cc) * 0.3).astype(np.float32), rng.uniform(0.5, 1.5, Cc).astype(np.float32), (rng.normal(size=Cc) * 0.3).astype(np.float32)
+    act = ops.act(Act.BN_RELU, rt.upload(mean), rt.upload(scale), rt.upload(beta), Cc)
+    nblk = M // rows
+    stats = rt.alloc((nblk, 2, Cc), zero=False)
+    ops.conv3x3_stream(rt, X, N, H, W, Cc, Wk, Y, actX=act, bias=rt.upload(bias), epi=ops.epilogue(stats=stats))(rt.stream)
+    a = np.maximum((x - mean) * scale + beta, 0)
+    y_ref = layout.nchw_to_nhwc(L.conv2d_fwd(layout.nhwc_to_nchw(a), Wr.astype('f8'), bias.astype('f8'), (1, 1), 'half'))
+    gamma = rng.uniform(0.5, 1.5, Cc).astype(np.float32)
+    mo, io, so = (rt.alloc(Cc, zero=False) for _ in range(3))
+    ops.bn_finalize(rt, stats, nblk, M, rows, Cc, rt.upload(gamma), 1e-4, mo, io, so)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_allclose(Y.get(), y_ref, rtol=0, atol=3e-6 * np.sqrt(9 * Cc) * np.abs(y_ref).max())
+    yv = Y.get().astype('f8').reshape(M, Cc)
+    np.testing.assert_allclose(mo.get(), yv.mean(0), rtol=0, atol=1e-6 * np.abs(yv).max())
+    np.testing.assert_allclose(io.get(), 1 / np.sqrt(yv.var(0) + np.float32(1e-4)), rtol=1e-5)
+    # plain call (no prologue, no bias, no epilogue) == the LDS-tiled kernel's contract
+    ops.conv3x3_stream(rt, X, N, H, W, Cc, Wk, Y)(rt.stream)
+    rt.synchronize()
+    y0 = layout.nchw_to_nhwc(L.conv2d_fwd(layout.nhwc_to_nchw(x), Wr.astype('f8'), None, (1, 1), 'half'))
+    np.testing.assert_allclose(Y.get(), y0, rtol=0, atol=3e-6 * np.sqrt(9 * Cc) * np.abs(y0).max())
+
+    # data gradient: the same kernel on dY with the mirrored weights, BatchNorm-backward epilogue
+    dy = rng.normal(size=(N, H, W, Cc)).astype(np.float32)
+    xs = (x + 1.0).astype(np.float32).reshape(M, Cc)
+    bn = _BN()
+    mu, sg, be = xs.mean(0).astype(np.float32), rng.uniform(0.5, 1.5, Cc).astype(np.float32), (rng.normal(size=Cc) * 0.5).astype(np.float32)
+    isd = (1 / np.sqrt(xs.var(0) + 1e-4)).astype(np.float32)
+    bn.mean, bn.inv_std, bn.scale, bn.beta_buf = rt.upload(mu), rt.upload(isd), rt.upload(sg * isd), rt.upload(be)
+    Wd = rt.alloc(Cc * 9 * Cc, zero=False)
+    G = rt.alloc((M, Cc), zero=False)
+    part = rt.alloc((nblk, 2, Cc), zero=False)
+    ops.conv3x3_wtrans(rt, Wk, Cc, Cc, Wd)(rt.stream)
+    ops.conv3x3_stream(rt, rt.upload(dy), N, H, W, Cc, Wd, G, epi=ops.epilogue(bn=bn, bn_x=rt.upload(xs), bn_relu=True, bn_partial=part))(rt.stream)
+    dbeta, dgamma, c1, c2 = (rt.alloc(Cc, zero=False) for _ in range(4))
+    ops.bn_bwd_finalize(rt, part, nblk, M, Cc, dbeta, dgamma, c1, c2)(rt.stream)
+    rt.synchronize()
+    da_ref = layout.nchw_to_nhwc(L.conv2d_bwd(layout.nhwc_to_nchw(x), Wr.astype('f8'), layout.nhwc_to_nchw(dy.astype('f8')), (1, 1), 'half')[0]).reshape(M, Cc)
+    v = (xs.astype('f8') - mu) * (sg * isd) + be
+    safe = np.abs(v) > 1e-4
+    got = G.get()
+    np.testing.assert_allclose(got[safe], (da_ref * (v >= 0))[safe], rtol=0, atol=3e-6 * np.sqrt(9 * Cc) * np.abs(da_ref).max())
+    xhat = (xs.astype('f8') - mu) * isd
+    np.testing.assert_allclose(dbeta.get(), got.astype('f8').sum(0), rtol=0, atol=3e-6 * np.sqrt(M) * np.abs(got).max())
+    np.testing.assert_allclose(dgamma.get(), (got.astype('f8') * xhat).sum(0), rtol=0, atol=3e-5 * np.sqrt(M) * np.abs(got).max())

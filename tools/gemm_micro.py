@@ -179,6 +179,18 @@ def main_conv3():
                   (label, bm, us, 2.0 * px * 9 * C * C / us * 1e-6, 8.0 * px * C / us * 1e-3, nblk))
         mean, scale, beta = rt.alloc(C), rt.alloc(C), rt.alloc(C)
         act = Act(mean.ptr, scale.ptr, beta.ptr, 3, C)
+        rows = rt.lib.dpp_conv3x3_stream_rows(N, H, H, C)
+        if rows:
+            px = N * H * H
+            stats = rt.alloc((px // rows, 2, C), zero=False)
+            for what, kw in (('plain', {}), ('act+bias+stats', dict(actX=act, bias=mean, epi=ops.epilogue(stats=stats)))):
+                us = timeit(ops.conv3x3_stream(rt, X, N, H, H, C, Wk, Y, **kw))
+                print('%-22s stream %-15s %7.2f us  %6.1f TFLOP/s  %6.0f GB/s' % (label, what, us, 2.0 * px * 9 * C * C / us * 1e-6, 8.0 * px * C / us * 1e-3))
+            bm = 128 if px // 128 >= 512 else 64
+            nb = rt.lib.dpp_conv3x3_tiling(N, H, H, bm, None, None, None)
+            st2 = rt.alloc((nb, 2, C), zero=False)
+            us = timeit(ops.conv3x3(rt, X, N, H, H, C, Wk, C, Y, actX=act, bias=mean, bm=bm, epi=ops.epilogue(stats=st2)))
+            print('%-22s tiled  %-15s %7.2f us' % (label, 'act+bias+stats', us))
         for rpw in (64, 128, 256, 512):
             nsl = rt.lib.dpp_wgrad3_stream_slices(C, C, N, H, H, rpw)
             if nsl <= 0 or nsl * C * 9 * C * 4 > 64 << 20:
