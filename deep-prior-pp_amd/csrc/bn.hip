@@ -375,6 +375,101 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_bwd_apply_kernel(const TG* __r
     }
 }
 
+// bn_bwd_finalize + bn_bwd_apply in ONE launch, for the small maps of the late stages: when the per-block sums of a BatchNorm are few
+// (nb <= 128 blocks), every workgroup of the apply pass can afford to reduce them itself -- the 2 x 32 x nb floats of ITS 32 channels,
+// 8 KB..32 KB out of L2, the same order in every workgroup, so all of them form the same (c1, c2) -- instead of waiting for a
+// finalize kernel whose whole duration is a launch and one memory round trip (4.8 us of a 10 us pair).  Grid (row blocks, C / 32);
+// the first four rows of a thread are requested BEFORE the reduction, so the two round trips overlap.  Workgroup (0, slice) also
+// writes dbeta / dgamma (the parameter gradients the finalize kernel writes).  Arithmetic of bn_bwd_finalize_kernel (f64 sums of the
+// f32 partials, one rounding) and of bn_bwd_apply_kernel.
+template <class TX, class TG, class TO>
+__global__ __launch_bounds__(DPP_THREADS) void bn_bwd_finalize_apply_kernel(const TG* __restrict__ G, const TX* __restrict__ X, int M, int C,
+                                                                            const float* __restrict__ mean, const float* __restrict__ inv_std,
+                                                                            const float* __restrict__ scale, const float* __restrict__ partial,
+                                                                            int nb, const TO* add, TO* dX, int rpb, float* __restrict__ colsum,
+                                                                            float* __restrict__ dbeta, float* __restrict__ dgamma) {
+    dpp_kernarg_warm<128>();
+    constexpr int CS = 32, Q = CS / 4, RP = DPP_THREADS / Q;
+    __shared__ double s_sum[2 * CS];
+    __shared__ float s_a[DPP_THREADS * 4];
+    const int tid = threadIdx.x, q = tid % Q, rr = tid / Q;
+    const int c0 = blockIdx.y * CS;
+    const int r_begin = blockIdx.x * rpb;
+    const int r_end = (r_begin + rpb < M) ? r_begin + rpb : M;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 g[4], x[4], o[4];
+    auto fetch = [&](int r) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ru = r + u * RP;
+            const size_t i = (size_t)(ru < r_end ? ru : r_end - 1) * C + c0 + q * 4;
+            g[u] = dpp_ld4(G + i);
+            x[u] = dpp_ld4(X + i);
+            o[u] = add ? dpp_ld4(add + i) : zero4;
+        }
+    };
+    int r = r_begin + rr;
+    fetch(r);
+    // ---- the sums of this slice's channels over the nb blocks: thread (pair = (s, c), quarter) ----
+    {
+        const int pair = tid >> 2, quarter = tid & 3, s = pair / CS, c = pair % CS;
+        const float* row = partial + dpp_partial_index(s, c0 + c, 0, C, nb);
+        double acc = 0.0;
+        if ((nb & 3) == 0) {
+            for (int b = quarter * 4; b < nb; b += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(row + b);
+                acc += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            }
+        } else {
+            for (int b = quarter; b < nb; b += 4) acc += (double)row[b];
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        if (quarter == 0) s_sum[pair] = acc;
+    }
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c0 + q * 4);
+    const float4 is = *reinterpret_cast<const float4*>(inv_std + c0 + q * 4);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c0 + q * 4);
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < CS) {
+        dbeta[c0 + tid] = (float)s_sum[tid];
+        dgamma[c0 + tid] = (float)s_sum[CS + tid];
+    }
+    float4 a1, a2;
+    a1.x = (float)(s_sum[q * 4 + 0] / (double)M); a1.y = (float)(s_sum[q * 4 + 1] / (double)M);
+    a1.z = (float)(s_sum[q * 4 + 2] / (double)M); a1.w = (float)(s_sum[q * 4 + 3] / (double)M);
+    a2.x = (float)(s_sum[CS + q * 4 + 0] / (double)M); a2.y = (float)(s_sum[CS + q * 4 + 1] / (double)M);
+    a2.z = (float)(s_sum[CS + q * 4 + 2] / (double)M); a2.w = (float)(s_sum[CS + q * 4 + 3] / (double)M);
+    float4 sa = zero4;
+    for (; r < r_end; r += 4 * RP) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ru = r + u * RP;
+            float4 v;
+            v.x = sc.x * (g[u].x - a1.x - (x[u].x - mu.x) * is.x * a2.x);
+            v.y = sc.y * (g[u].y - a1.y - (x[u].y - mu.y) * is.y * a2.y);
+            v.z = sc.z * (g[u].z - a1.z - (x[u].z - mu.z) * is.z * a2.z);
+            v.w = sc.w * (g[u].w - a1.w - (x[u].w - mu.w) * is.w * a2.w);
+            if (add) { v.x += o[u].x; v.y += o[u].y; v.z += o[u].z; v.w += o[u].w; }
+            if (ru < r_end) {
+                dpp_st4(dX + (size_t)ru * C + c0 + q * 4, v);
+                if (sizeof(TO) == 2) { v.x = dpp_bf16_round(v.x); v.y = dpp_bf16_round(v.y); v.z = dpp_bf16_round(v.z); v.w = dpp_bf16_round(v.w); }
+                sa.x += v.x; sa.y += v.y; sa.z += v.z; sa.w += v.w;
+            }
+        }
+        if (r + 4 * RP < r_end) fetch(r + 4 * RP);
+    }
+    if (colsum == nullptr) return;
+    s_a[tid * 4 + 0] = sa.x; s_a[tid * 4 + 1] = sa.y; s_a[tid * 4 + 2] = sa.z; s_a[tid * 4 + 3] = sa.w;
+    __syncthreads();
+    if (tid < CS) {
+        const int cq = tid >> 2, ce = tid & 3;
+        double a = 0.0;
+        for (int j = 0; j < RP; ++j) a += (double)s_a[(j * Q + cq) * 4 + ce];
+        colsum[(size_t)blockIdx.x * C + c0 + tid] = (float)a;
+    }
+}
+
 bool ok_c(int C) { return C >= 4 && (C & 3) == 0 && (C >> 2) <= MAXQ && (DPP_THREADS % (C >> 2) == 0 || (C >> 2) > DPP_THREADS); }
 
 }  // namespace
@@ -458,5 +553,29 @@ extern "C" int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, co
     else { if (g16) DPP_BA_O(float, dpp_bf16); else DPP_BA_O(float, float); }
 #undef DPP_BA_O
 #undef DPP_BA
+    return dpp_launch_status();
+}
+
+// Whether dpp_bn_bwd_finalize_apply takes the shape: 32-channel slices, and few enough blocks of sums that every workgroup reduces
+// its slice's share itself (2 x 32 x nb floats).
+extern "C" int dpp_bn_bwd_finalize_apply_ok(int M, int C, int nb) { return M >= 1 && C >= 32 && (C & 31) == 0 && nb >= 1 && nb <= 256; }
+
+extern "C" int dpp_bn_bwd_finalize_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
+                                         const float* scale, const float* partial, int nb, const float* add, float* dX,
+                                         int rows_per_block, float* colsum_partial, float* dbeta, float* dgamma, int store,
+                                         dpp_stream_t stream) {
+    if (!G || !X || !dX || !partial || !dbeta || !dgamma || rows_per_block < 1 || (store & ~(DPP_ST_BNX | DPP_ST_A | DPP_ST_C))) return DPP_E_BADARG;
+    if (!dpp_bn_bwd_finalize_apply_ok(M, C, nb)) return DPP_E_UNSUPPORTED;
+    const bool x16 = (store & DPP_ST_BNX) != 0, g16 = (store & DPP_ST_A) != 0, o16 = (store & DPP_ST_C) != 0;
+    const dim3 grid(dpp_cdiv(M, rows_per_block), C / 32);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define DPP_BFA(TX_, TG_, TO_) DPP_LAUNCH((bn_bwd_finalize_apply_kernel<TX_, TG_, TO_>), grid, dim3(DPP_THREADS), 0, st, reinterpret_cast<const TG_*>(G), \
+                                          reinterpret_cast<const TX_*>(X), M, C, mean, inv_std, scale, partial, nb, reinterpret_cast<const TO_*>(add), \
+                                          reinterpret_cast<TO_*>(dX), rows_per_block, colsum_partial, dbeta, dgamma)
+#define DPP_BFA_O(TX_, TG_) do { if (o16) DPP_BFA(TX_, TG_, dpp_bf16); else DPP_BFA(TX_, TG_, float); } while (0)
+    if (x16) { if (g16) DPP_BFA_O(dpp_bf16, dpp_bf16); else DPP_BFA_O(dpp_bf16, float); }
+    else { if (g16) DPP_BFA_O(float, dpp_bf16); else DPP_BFA_O(float, float); }
+#undef DPP_BFA_O
+#undef DPP_BFA
     return dpp_launch_status();
 }

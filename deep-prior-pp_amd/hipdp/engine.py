@@ -35,6 +35,16 @@ def knob(name, default):
 
 
 BN_RPB_TARGET_BLOCKS = int(knob('DPP_BN_BLOCKS', '1024'))
+# BatchNorm backward of the small maps: when the per-block sums of a BatchNorm are at most this many blocks, the finalize is done by
+# every workgroup of the apply pass itself (dpp_bn_bwd_finalize_apply: one launch instead of two in the data-gradient chain; the
+# stand-alone finalize is a launch + one memory round trip, 4.8 us).  0 = always two launches (the default).
+# Measured on the MI355X (profiles/r04_whatif.txt): the fused launch takes 5.9 us against 5.5 + 4.6 and the single-stream kernel time of
+# a bs128 step falls by 25 us (<= 128 blocks: 11 BatchNorms) / 54 us (<= 256: 31) -- but the two-stream step does not move: 3.503-3.508
+# ms (128) and 3.531 (256) against 3.490 with two launches.  The backward pass is not a chain any more: the data-gradient stream and
+# the filter-gradient branch end together and share the machine (dropping ALL 61 bn_bwd_finalize launches buys 0.07 ms, the 61
+# forward bn_finalize launches 0.37 ms), so a launch saved on the chain is not time saved.
+BN_BWD_FUSE_MAX_BLOCKS = int(knob('DPP_BN_BWD_FUSE_NB', '0'))
+BN_BWD_FUSE_TARGET_WGS = int(knob('DPP_BN_BWD_FUSE_WGS', '512'))
 
 
 def _pad4(n):
@@ -1173,10 +1183,14 @@ class CompiledNet(object):
         q, p = (rt.alloc(_pad4(C)), rt.alloc(_pad4(C))) if lazy else (None, None)
         fin = dict(bn=b, q=q, p=p) if lazy else {}
         fused = getattr(vg, 'fused_reduce', None)
+        # few blocks of sums: the apply pass reduces them itself (one launch for finalize + apply)
+        nbp = fused[1] if fused is not None else b.nb
+        one_launch = (not lazy and W <= 1 and 0 < nbp <= BN_BWD_FUSE_MAX_BLOCKS and rt.lib.dpp_bn_bwd_finalize_apply_ok(M, C, nbp))
         if fused is not None:
             # the data-gradient kernel already masked vg.grad and wrote the per-block sums
             part, nbp = fused
-            self.bwd.add(ops.bn_bwd_finalize(rt, part, nbp, M, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2, **fin))
+            if not one_launch:
+                self.bwd.add(ops.bn_bwd_finalize(rt, part, nbp, M, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2, **fin))
             W = 0
         else:
             part = self.scratch(b.nb * 2 * C * (W + 1)).view(0, (b.nb * 2 * C,))
@@ -1187,7 +1201,7 @@ class CompiledNet(object):
             part = allp
         # with sync-BN dbeta / dgamma are already global sums on every rank: pre-divide so that the gradient all-reduce
         # (a sum over ranks) leaves them unchanged
-        if fused is None:
+        if fused is None and not one_launch:
             self.bwd.add(ops.bn_bwd_finalize(rt, part, b.nb, M * W, C, st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), c1, c2,
                                              nseg=W, **fin))
         if W > 1:
@@ -1197,7 +1211,7 @@ class CompiledNet(object):
         if lazy:
             t.lazy = dict(G=vg.grad, bn=b, c1=c1, c2=c2, q=q, p=p)
             return
-        self._emit_bn_bwd_apply(t, vg.grad, b, c1, c2)
+        self._emit_bn_bwd_apply(t, vg.grad, b, c1, c2, sums=(part, nbp) if one_launch else None)
 
     def _producer(self, t):
         for l in self.layers:
@@ -1217,7 +1231,9 @@ class CompiledNet(object):
         t.lazy = None
         self._emit_bn_bwd_apply(t, lz['G'], lz['bn'], lz['c1'], lz['c2'])
 
-    def _emit_bn_bwd_apply(self, t, G, b, c1, c2):
+    def _emit_bn_bwd_apply(self, t, G, b, c1, c2, sums=None):
+        """dX = scale * (G - c1 - xhat * c2) (+ the gradient already flowing into t).  sums = (partial, nb): the finalize has not run,
+        the pass reduces the per-block sums itself (dpp_bn_bwd_finalize_apply) and writes dbeta / dgamma."""
         rt = self.rt
         M, C = b.M, b.C
         addends = ([t.grad] if t.grad_written else []) + t.pending
@@ -1231,6 +1247,17 @@ class CompiledNet(object):
             # (the gradient added to dX -- the identity path of a residual sum -- and dX are stored alike)
             t.grad = rt.alloc(t.shape, add.dtype if add is not None else self._grad_dtype(t), zero=False)
         # t.grad is the dY of the conv(s) that produced t: emit its column sums (their bias gradients) in the same pass
+        if sums is not None:
+            rpb = max(32, -(-(M * (C // 32)) // BN_BWD_FUSE_TARGET_WGS))
+            rpb = -(-rpb // 32) * 32
+            nbc = -(-M // rpb)
+            cs = rt.alloc((nbc, C), zero=False)
+            st = self.store
+            self.bwd.add(ops.bn_bwd_finalize_apply(rt, G, t.buf, M, C, b.mean, b.inv_std, b.scale, sums[0], sums[1], t.grad,
+                                                   st.view(b.layer.beta, 'g'), st.view(b.layer.gamma, 'g'), add=add, rpb=rpb, colsum=cs))
+            self.colsum_of[t.grad.ptr] = (cs, nbc, C)
+            t.grad_written = True
+            return
         cs = rt.alloc((b.nb, C), zero=False)
         self.bwd.add(ops.bn_bwd_apply(rt, G, t.buf, M, C, b.mean, b.inv_std, b.scale, c1, c2, t.grad, add=add, rpb=b.rpb, colsum=cs))
         self.colsum_of[t.grad.ptr] = (cs, b.nb, C)

@@ -96,6 +96,9 @@ SIGNATURES = {
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_bn_bwd_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
+    'dpp_bn_bwd_finalize_apply_ok': (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    'dpp_bn_bwd_finalize_apply': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, stream_t]),
     'dpp_bn_bwd_apply': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_reduce_job_bytes': (C.c_size_t, []),

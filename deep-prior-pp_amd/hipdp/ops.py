@@ -471,6 +471,17 @@ def bn_bwd_apply(rt, G, X, M, Cc, mean, inv_std, scale, c1, c2, dX, add=None, rp
                   dict(kernel='bn_bwd_apply', flops=6.0 * M * Cc, bytes=((12.0 if add is not None else 8.0) + _esz(X)) * M * Cc))
 
 
+def bn_bwd_finalize_apply(rt, G, X, M, Cc, mean, inv_std, scale, partial, nb, dX, dbeta, dgamma, add=None, rpb=32, colsum=None,
+                          name='bn_bwd_finalize_apply'):
+    """dpp_bn_bwd_finalize_apply: the finalize of the per-block sums and the apply pass of a BatchNorm backward in one launch."""
+    if add is not None and _is16(add) != _is16(dX):
+        raise ValueError("dpp_bn_bwd_finalize_apply: dX and the gradient added to it must be stored alike")
+    return Launch(rt.lib.dpp_bn_bwd_finalize_apply, (G.ptr, X.ptr, M, Cc, mean.ptr, inv_std.ptr, scale.ptr, partial.ptr, int(nb), _p(add), dX.ptr,
+                                                     int(rpb), _p(colsum), dbeta.ptr, dgamma.ptr, _store(a=G, c=dX, bnx=X)),
+                  (G, X, mean, inv_std, scale, partial, add, dX, colsum, dbeta, dgamma), name,
+                  dict(kernel='bn_bwd_apply', flops=6.0 * M * Cc, bytes=((12.0 if add is not None else 8.0) + _esz(X)) * M * Cc))
+
+
 def colsum_partial(rt, X, M, Cc, rpb, partial, name='colsum_partial'):
     if _is16(X):
         raise NotImplementedError("dpp_colsum_partial reads float32 gradients")

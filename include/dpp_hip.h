@@ -294,6 +294,15 @@ int dpp_bn_bwd_apply(const float* G, const float* X, int M, int C, const float* 
                      const float* scale, const float* c1, const float* c2, const float* add, float* dX,
                      int rows_per_block, float* colsum_partial /* [nb][C] column sums of dX, or NULL */,
                      int store /* DPP_ST_BNX: X, DPP_ST_A: the incoming gradient (dA / G), DPP_ST_C: the outgoing one (G / dX + add) hold bf16 */, dpp_stream_t stream);
+/* dpp_bn_bwd_finalize (nseg = 1, no q / p) + dpp_bn_bwd_apply in one launch, for BatchNorms whose per-block sums are few (the small
+ * maps of the late stages): every workgroup -- grid (ceil(M / rows_per_block), C / 32) -- reduces the `nb` blocks of `partial`
+ * ([2][C][nb], the layout dpp_bn_bwd_reduce and the fused data-gradient epilogues write) for its 32 channels itself, then applies.
+ * Writes dbeta / dgamma like the finalize kernel; c1 / c2 never reach memory.  dpp_bn_bwd_finalize_apply_ok: C % 32 == 0 and
+ * nb <= 256, else DPP_E_UNSUPPORTED (the two launches remain). */
+int dpp_bn_bwd_finalize_apply_ok(int M, int C, int nb);
+int dpp_bn_bwd_finalize_apply(const float* G, const float* X, int M, int C, const float* mean, const float* inv_std,
+                              const float* scale, const float* partial, int nb, const float* add, float* dX, int rows_per_block,
+                              float* colsum_partial, float* dbeta, float* dgamma, int store, dpp_stream_t stream);
 
 /* ---- loss / optimiser / small elementwise ------------------------------------------------------------------ */
 /* partial[b][c] = sum of rows of chunk b (bias gradients; reduce with dpp_reduce_partials) */

@@ -124,7 +124,7 @@ def test_resnet_forward_eval_matches_oracle(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'lazy3', 'fc1stream', 'early_reduce', 'no_variants', 'conv3stream'])
+@pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'lazy3', 'fc1stream', 'early_reduce', 'no_variants', 'conv3stream', 'bn_fuse'])
 def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatch):
     """'lazy': type 0 with the opt-in plan in which the 1x1 convolutions form the gradient through a BatchNorm from (G, x) in
     their operand prologue (engine.LAZY_BN_BWD) instead of reading a tensor written by bn_bwd_apply.
@@ -136,6 +136,9 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
     'conv3stream': a 64x64 net, whose stage-1 maps are 16 pixels wide, with the opt-in engine.CONV3_STREAM_C: its 16 -> 16 3x3 layers
     and their data gradients run on the barrier-free dpp_conv3x3_stream (measured no faster than the tiled kernel: off by default)."""
     size = 32
+    if type_ == 'bn_fuse':          # finalize + apply of the BatchNorm backward in one launch (opt-in engine.BN_BWD_FUSE_MAX_BLOCKS)
+        monkeypatch.setattr(engine, 'BN_BWD_FUSE_MAX_BLOCKS', 128)
+        type_ = 0
     if type_ == 'conv3stream':
         size, type_ = 64, 0
         monkeypatch.setattr(engine, 'CONV3_STREAM_C', (16, 32))
@@ -162,6 +165,8 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
     nJ, nD = (1, 30) if type_ == 0 else (14, 3)
     net, onet, P = make_net(rt, type_, 4, size, nJ, nD, **(dict(calib_batch=4) if size != 32 else {}))
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    nfa = sum(l.fn is rt.lib.dpp_bn_bwd_finalize_apply for _, l in eng.all_launches())
+    assert (nfa >= 20) if engine.BN_BWD_FUSE_MAX_BLOCKS else (nfa == 0), nfa
     n3s = sum(l.fn is rt.lib.dpp_conv3x3_stream for _, l in eng.all_launches())
     assert n3s == (10 if size == 64 else 0), n3s          # 5 stage-1 blocks: forward + data gradient each
     variants = [l.keep[0].variant for _, l in eng.all_launches() if l.fn is rt.lib.dpp_gemm]

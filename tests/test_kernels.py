@@ -645,3 +645,36 @@ def test_conv3x3_stream_forward_statistics_and_fused_data_gradient(backend, cfg)
     xhat = (xs.astype('f8') - mu) * isd
     np.testing.assert_allclose(dbeta.get(), got.astype('f8').sum(0), rtol=0, atol=3e-6 * np.sqrt(M) * np.abs(got).max())
     np.testing.assert_allclose(dgamma.get(), (got.astype('f8') * xhat).sum(0), rtol=0, atol=3e-5 * np.sqrt(M) * np.abs(got).max())
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(512, 64, 8, 32, True), (300, 32, 5, 64, False), (2048, 128, 32, 96, True), (96, 256, 3, 32, True), (64, 48, 2, 32, False)])
+def test_bn_bwd_finalize_apply_equals_the_two_launches(backend, cfg):
+    """dpp_bn_bwd_finalize_apply (finalize of the per-block sums + apply pass in one launch, small maps) against dpp_bn_bwd_finalize +
+    dpp_bn_bwd_apply on the same partial sums: dX, dbeta, dgamma and the column sums of dX."""
+    rt = get_runtime(backend)
+    M, Cc, nb, rpb, with_add = cfg
+    rng = np.random.RandomState(83)
+    assert bool(rt.lib.dpp_bn_bwd_finalize_apply_ok(M, Cc, nb)) == (Cc % 32 == 0)
+    G, X = (rt.upload(rng.normal(size=(M, Cc)).astype(np.float32)) for _ in range(2))
+    add = rt.upload(rng.normal(size=(M, Cc)).astype(np.float32)) if with_add else None
+    mean, istd, scale = (rt.upload(rng.uniform(0.5, 1.5, Cc).astype(np.float32)) for _ in range(3))
+    part = rt.upload(rng.normal(size=(2, Cc, nb)).astype(np.float32) * 10)
+    dX1, dX2 = rt.alloc((M, Cc), zero=False), rt.alloc((M, Cc), zero=False)
+    db1, dg1, db2, dg2, c1, c2 = (rt.alloc(Cc, zero=False) for _ in range(6))
+    nb1, nb2 = -(-M // 32), -(-M // rpb)
+    cs1, cs2 = rt.alloc((nb1, Cc), zero=False), rt.alloc((nb2, Cc), zero=False)
+    if Cc % 32:
+        assert rt.lib.dpp_bn_bwd_finalize_apply(G.ptr, X.ptr, M, Cc, mean.ptr, istd.ptr, scale.ptr, part.ptr, nb, None, dX2.ptr, rpb, cs2.ptr,
+                                                db2.ptr, dg2.ptr, 0, rt.stream) != 0
+        return
+    ops.bn_bwd_finalize(rt, part, nb, M, Cc, db1, dg1, c1, c2)(rt.stream)
+    ops.bn_bwd_apply(rt, G, X, M, Cc, mean, istd, scale, c1, c2, dX1, add=add, rpb=32, colsum=cs1)(rt.stream)
+    ops.bn_bwd_finalize_apply(rt, G, X, M, Cc, mean, istd, scale, part, nb, dX2, db2, dg2, add=add, rpb=rpb, colsum=cs2)(rt.stream)
+    rt.synchronize()
+    np.testing.assert_array_equal(db1.get(), db2.get())              # f64 sums of <= 256 floats, one rounding: order-independent in practice
+    np.testing.assert_array_equal(dg1.get(), dg2.get())
+    np.testing.assert_array_equal(dX1.get(), dX2.get())
+    s1, s2 = cs1.get().astype('f8').sum(0), cs2.get().astype('f8').sum(0)
+    np.testing.assert_allclose(s2, s1, rtol=0, atol=1e-5 * np.abs(dX1.get()).sum(0).max())
+    np.testing.assert_allclose(s2, dX2.get().astype('f8').sum(0), rtol=0, atol=1e-5 * np.abs(dX1.get()).sum(0).max())
