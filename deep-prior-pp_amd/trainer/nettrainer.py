@@ -19,6 +19,13 @@ import numpy
 from hipdp.runtime import default_runtime
 
 
+def _nanmean(values):
+    """numpy.nanmean, NaN (without NumPy's empty-slice warning) for a validation set with no minibatch -- what the reference's
+    observers return then (nettrainer.py:760-765 on an empty list)."""
+    values = numpy.asarray(values, dtype=numpy.float64)
+    return float('nan') if values.size == 0 or numpy.isnan(values).all() else float(numpy.nanmean(values))
+
+
 class NetTrainerParams(object):
     def __init__(self):
         self.batch_size = 128
@@ -524,7 +531,7 @@ class NetTrainer(object):
 
         self.poseNet.setDeterministic()
         for vi in range(1, len(self.validation_observer)):
-            validation_obs[vi - 1].append(numpy.nanmean([self.validation_observer[vi](i) for i in range(n_val_batches)]))
+            validation_obs[vi - 1].append(_nanmean([self.validation_observer[vi](i) for i in range(n_val_batches)]))
         self.poseNet.unsetDeterministic()
 
         class _Now(object):                       # a trainer without an asynchronous step: the value is already there
@@ -582,9 +589,9 @@ class NetTrainer(object):
                             if lay.__class__.__name__ in ('ConvPoolLayer', 'ConvLayer'):
                                 wvals.append(lay.W.get_value())
                     self.poseNet.setDeterministic()
-                    this_validation_loss = numpy.nanmean([self.validation_observer[0](i) for i in range(n_val_batches)])
+                    this_validation_loss = _nanmean([self.validation_observer[0](i) for i in range(n_val_batches)])
                     for vi in range(1, len(self.validation_observer)):
-                        validation_obs[vi - 1].append(numpy.nanmean([self.validation_observer[vi](i) for i in range(n_val_batches)]))
+                        validation_obs[vi - 1].append(_nanmean([self.validation_observer[vi](i) for i in range(n_val_batches)]))
                     self.poseNet.unsetDeterministic()
                     print("{}: epoch {}, LR {}, minibatch {}/{}, validation cost {} error {}".format(
                         time.ctime(), self.epoch, learning_rate, minibatch_index + 1, self.getNumFullMiniBatches(),

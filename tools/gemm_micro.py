@@ -37,8 +37,9 @@ class BN(object):
     pass
 
 
-def bench_gemm(M, N, K, b_kc, tile, variant, feats, label):
-    A = rt.alloc((M, K), zero=False)
+def bench_gemm(M, N, K, b_kc, tile, variant, feats, label, stride2=None):
+    """stride2 = (Ho, Wo): the A rows are the stride-2 samples of a (2 Ho, 2 Wo) map (the first 1x1 convolutions of a stage)."""
+    A = rt.alloc((M * (4 if stride2 else 1), K), zero=False)
     rt.tensor(A).normal_()
     B = rt.alloc((N, K) if b_kc else (K, N), zero=False)
     rt.tensor(B).normal_()
@@ -69,8 +70,15 @@ def bench_gemm(M, N, K, b_kc, tile, variant, feats, label):
         bn = BN()
         bn.mean, bn.inv_std, bn.scale, bn.beta_buf = rt.alloc(N), rt.alloc(N), rt.alloc(N), rt.alloc(N)
         kw['epi'] = ops.epilogue(bn=bn, bn_x=rt.alloc((M, N)), bn_partial=rt.alloc((nblk, 2, N), zero=False))
+    if stride2:
+        from hipdp.lib import RowMap
+        kw['mapA'] = RowMap.strided(2, stride2[0], stride2[1], 2 * stride2[0], 2 * stride2[1])
     L = ops.gemm(rt, A, B, Cb, M, N, K, 1, int(b_kc), K, K if b_kc else N, N, tile=tile, variant=variant, **kw)
-    us = timeit(L)
+    try:
+        us = timeit(L)
+    except Exception as e:      # noqa: BLE001
+        print('%-34s tile=%-12s %s' % (label, tile, e))
+        return
     byts = 4.0 * (M * K + K * N + M * N * (2 if 'res' in feats else 1) + (M * N if 'bnbwd' in feats else 0))
     print('%-34s M=%6d N=%4d K=%4d tile=%-12s v%d %-22s %7.2f us  %6.0f GB/s' %
           (label, M, N, K, tile, variant, '+'.join(feats) or '-', us, byts / us * 1e-3))
@@ -152,6 +160,18 @@ def main_feats():
                                  ('stage3/4 conv a 256->64', 8192, 64, 256, (64, 16, 4)), ('stage1 conv a 64->16', 131072, 16, 64, (128, 16, 4))):
         for feats in ((), ('relu',), ('act',), ('bias',), ('res',), ('stats',), ('act', 'bias', 'res'), ('act', 'bias', 'res', 'stats'), ('bnbwd',)):
             bench_gemm(M, N, K, True, tile, 0, feats, label)
+
+
+def main_stride2():
+    """The six stride-2 1x1 convolutions of the forward pass (first block of stages 1-3: bottleneck entry and projection shortcut)."""
+    for label, M, N, K, hw, feats in (('s1 entry 32->16', 131072, 16, 32, 32, ('act', 'bias', 'stats')), ('s1 proj 32->64', 131072, 64, 32, 32, ('act', 'bias', 'res', 'stats')),
+                                      ('s2 entry 64->32', 32768, 32, 64, 16, ('act', 'bias', 'stats')), ('s2 proj 64->128', 32768, 128, 64, 16, ('act', 'bias', 'res', 'stats')),
+                                      ('s3 entry 128->64', 8192, 64, 128, 8, ('act', 'bias', 'stats')), ('s3 proj 128->256', 8192, 256, 128, 8, ('act', 'bias', 'res', 'stats'))):
+        for tile in ((64, 64, 4), (128, 32, 4), (64, 32, 4), (128, 16, 4), (64, 16, 4), (32, 64, 1)):
+            if tile[1] > max(16, N):
+                continue
+            bench_gemm(M, N, K, True, tile, 0, feats, label + ' s2', stride2=(hw, hw))
+        bench_gemm(M, N, K, True, (64, min(64, N), 4) if N >= 64 else (64, 16, 4), 0, feats, label + ' s1 (contiguous rows)')
 
 
 def main_conv3():
@@ -238,6 +258,8 @@ def main():
         return main_expand()
     if 'floor' in sys.argv[1:]:
         return main_floor()
+    if 'stride2' in sys.argv[1:]:
+        return main_stride2()
     if 'conv3' in sys.argv[1:]:
         return main_conv3()
     if 'feats' in sys.argv[1:]:
