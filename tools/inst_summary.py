@@ -5,15 +5,17 @@ Every counter is summed over the dispatch; divided by SQ_WAVES it is the number 
 through the kernel.  A SIMD issues roughly one instruction of a wave per 4 cycles (tools/probes/icache_probe.hip: 4.3 cycles
 per dependent scalar instruction, and two waves on one SIMD take twice as long), so instructions per wave x waves per SIMD x
 ~4.3 cycles is a floor on the kernel's duration that no memory system can hide."""
+import os
 import re
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _names import pretty  # noqa: E402
+
 
 def short(name):
-    name = re.sub(r'\(anonymous namespace\)::', '', name)
-    name = re.sub(r'^void ', '', name)
-    return re.sub(r'\(.*$', '', name)
+    return pretty(name)
 
 
 def main():

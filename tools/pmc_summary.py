@@ -5,9 +5,13 @@
 Both counters are in KiB.  On gfx950 FETCH_SIZE tallies 128-B requests at 64 B for wide coalesced reads; instead of
 assuming the factor, both counters are CALIBRATED on adam_kernel, whose traffic is known exactly (reads w, g, m, v and
 writes w, m, v: 16 and 12 bytes per parameter, each element touched once, far larger than any cache)."""
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _names import pretty  # noqa: E402
 
 N_PARAMS_PAD = None
 
@@ -20,9 +24,7 @@ def per_kernel(path, counter):
 
 
 def short(name):
-    name = re.sub(r'\(anonymous namespace\)::', '', name)
-    name = re.sub(r'^void ', '', name)
-    return re.sub(r'\(.*$', '', name)[:70]
+    return pretty(name)[:70]
 
 
 def main():

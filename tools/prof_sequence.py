@@ -3,9 +3,13 @@
 dispatch, stream -- so that two engine plans can be compared launch by launch (tools/step_profile.py under DPP_NO_SIDE_STREAM=1 or not):
    python tools/prof_sequence.py x_results.db [which step, counted from the last = 1] > sequence.txt
 A step is delimited by adam_kernel (the one launch every step ends with)."""
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _names import pretty  # noqa: E402
 
 db = sqlite3.connect(sys.argv[1])
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -23,9 +27,7 @@ print("# %d dispatches, %.1f us from the first start to the last end, %.1f us of
 print("%9s %8s %8s %6s  %s" % ('start_us', 'dur_us', 'gap_us', 'stream', 'kernel <grid>'))
 prev_end = {}
 for name, s, e, gx, gy, gz, q in seq:
-    name = re.sub(r'\(anonymous namespace\)::', '', name)
-    name = re.sub(r'^void ', '', name)
-    name = re.sub(r'\(.*$', '', name)
+    name = pretty(name)
     gap = (s - prev_end[q]) / 1e3 if q in prev_end else 0.0
     prev_end[q] = e
     print("%9.2f %8.2f %8.2f %6s  %s <%d,%d,%d>" % ((s - t0) / 1e3, (e - s) / 1e3, gap, q, name[:90], gx, gy, gz))

@@ -1,9 +1,13 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace result database (rocpd SQLite) as a per-kernel table:
    python tools/prof_summary.py gpurun_out/prof/x_results.db [steps] > profiles/rNN_kernel_stats.txt"""
+import os
 import re
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _names import pretty  # noqa: E402
 
 by_grid = '--by-grid' in sys.argv                # one line per (kernel, grid) instead of per kernel
 argv = [a for a in sys.argv[1:] if not a.startswith('--')]
@@ -24,20 +28,18 @@ print("rocprofv3 --kernel-trace summary: %d kernels, %d dispatches, total %.1f u
       (len(rows), sum(r[1] for r in rows), tot, tot / steps, steps))
 print("%-66s %7s %11s %9s %9s %9s %6s %5s %6s" % ('kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%', 'vgpr', 'lds'))
 for r in rows:
-    name = re.sub(r'\(anonymous namespace\)::', '', r[0])
-    grid = ''
+    name, grid = r[0], ''
     if by_grid:
         name, grid = name.rsplit(' <', 1)
         grid = ' <' + grid
-    name = re.sub(r'\(.*$', '', name) if not name.startswith('void') else re.sub(r'\(.*$', '', name[5:])
+    name = pretty(name)
     name = name[:66 - len(grid)] + grid
     print("%-66s %7d %11.1f %9.2f %9.2f %9.2f %6.1f %5d %6d" % (name[:66], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot, r[6] or 0, r[7] or 0))
 
 # per kernel family (all template instances / grids together): the figure bench.py's roofline.avg_launch_us corresponds to
 fam = {}
 for r in rows:
-    name = re.sub(r'\(anonymous namespace\)::', '', r[0])
-    name = re.sub(r'^void ', '', name)
+    name = pretty(r[0].rsplit(' <', 1)[0] if by_grid else r[0])
     key = re.sub(r'[<( ].*$', '', name)
     a = fam.setdefault(key, [0, 0.0])
     a[0] += r[1]
