@@ -6,7 +6,6 @@ through the kernel.  A SIMD issues roughly one instruction of a wave per 4 cycle
 per dependent scalar instruction, and two waves on one SIMD take twice as long), so instructions per wave x waves per SIMD x
 ~4.3 cycles is a floor on the kernel's duration that no memory system can hide."""
 import os
-import re
 import sqlite3
 import sys
 

@@ -6,7 +6,6 @@ Both counters are in KiB.  On gfx950 FETCH_SIZE tallies 128-B requests at 64 B f
 assuming the factor, both counters are CALIBRATED on adam_kernel, whose traffic is known exactly (reads w, g, m, v and
 writes w, m, v: 16 and 12 bytes per parameter, each element touched once, far larger than any cache)."""
 import os
-import re
 import sqlite3
 import sys
 
