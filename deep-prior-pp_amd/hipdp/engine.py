@@ -499,6 +499,11 @@ def conv3x3_bm(pixels, Co):
     return 128 if (pixels // 128) * (-(-Co // 64)) >= 512 else 64
 
 
+# Projection shortcuts of the residual blocks on the second stream beside the bottleneck (see _emit_add).  DPP_SIDE_SHORTCUT=0: the
+# later convolution of a sum absorbs the add and everything stays on the main stream (rounds 1-3).
+SIDE_SHORTCUT = knob('DPP_SIDE_SHORTCUT', '1') != '0'
+
+
 # 3x3 convolutions of the narrow square layers (and their data gradients) on the barrier-free dpp_conv3x3_stream for these channel
 # counts.  OFF by default: measured on the MI355X (profiles/r04_conv3x3_stream.txt) the kernel is no faster than the LDS-tiled one on
 # the shapes it was written for -- stage 1 (131 072 px, 16 -> 16) 14.7 us plain / 17.4 us with prologue + statistics against 12.1 /
@@ -623,6 +628,7 @@ class CompiledNet(object):
             self.input_of[id(v)] = t
         self.x_in, self.in_shape = self.x_ins[0], self.x_ins[0].shape
         self._memo = {}
+        self._bwd_after = {}        # id(layer p) -> layer q: p's backward is emitted right after q's (see _emit_add)
         out_view = self._emit(net.output)
         self.out = self._materialize_plain(out_view)
         self.out_dim = int(np.prod(self.out.shape[1:]))
@@ -854,14 +860,39 @@ class CompiledNet(object):
         cand = [x for x in (a, b) if fusable(x)]
         if not cand:
             raise NotImplementedError("residual add whose operands are not conv outputs")
-        q = max(cand, key=lambda x: x.layer.layerNum)        # the later conv absorbs the add in its epilogue
+        # The conv at the end of the LONGER branch absorbs the add in its epilogue (ties: the later layer).  In a projection block
+        # (resnet.py:117-123: c + sc) that is the bottleneck exit c, not the shortcut sc -- which then depends on nothing but the
+        # block's input and runs on the second stream BESIDE the bottleneck's first two convolutions instead of behind them: the forward
+        # pass is a pure dependent chain (profiles/r04_whatif.txt), and the three projection convolutions were 72 us of it.
+        q = max(cand, key=lambda x: (self._depth(x) if SIDE_SHORTCUT else 0, x.layer.layerNum))
         p = b if q is a else a
+        beside = SIDE_SHORTCUT and self.train and p in cand and id(p) not in self._memo
+        if beside:
+            self._emit(p.inputs[0])                          # its input chain belongs to the main stream (normally emitted already)
+            n0 = len(self.fwd.ops)
         pv = self._emit(p)
         if not pv.plain:
             raise NotImplementedError("residual add on a non-materialised operand")
+        if beside:
+            moved = list(self.fwd.ops[n0:])
+            if all(isinstance(op, ops.Launch) for op, _ in moved):
+                self.fwd.ops[n0:] = [(ops.Fork(), False)] + [(op, True) for op, _ in moved]
+                self.fwd.uses_side = True
+                self._emit(q.inputs[0])                      # the longer branch, on the main stream
+                self.fwd.join()                              # ... whose last convolution reads the shortcut as its residual
+        if p.kind == 'layer' and p.layer.layerNum > q.layer.layerNum:
+            self._bwd_after[id(p.layer)] = q.layer           # backward: the sum's gradient reaches p through q's identity path
         out = self._emit(q, residual=pv.base, out_var=var)      # the conv's output tensor IS the sum
         self._memo[id(q)] = out
         return out
+
+    def _depth(self, var):
+        """Number of layers on the longest path from the inputs to this graph node."""
+        memo = self.__dict__.setdefault('_depth_memo', {})
+        if id(var) not in memo:
+            d = max([self._depth(i) for i in getattr(var, 'inputs', None) or []] or [0])
+            memo[id(var)] = d + (1 if var.kind == 'layer' else 0)
+        return memo[id(var)]
 
     def _feeds_batchnorm(self, var):
         """Does a BatchNorm consume the tensor this var denotes?  Then its producer emits the statistics partials."""
@@ -1272,7 +1303,12 @@ class CompiledNet(object):
                 created_by[id(var.layer)] = self._memo[id(var)]
             if var.kind == 'relu':
                 created_by[('relu', id(var.inputs[0].layer))] = self._memo[id(var)]
-        for layer in reversed(self.layers):
+        order = list(reversed(self.layers))
+        for pl_id, ql in self._bwd_after.items():              # a shortcut whose gradient arrives through the LATER-processed exit conv
+            pl = [l for l in order if id(l) == pl_id][0]
+            order.remove(pl)
+            order.insert(order.index(ql) + 1, pl)
+        for layer in order:
             kind = _layer_kind(layer)
             if kind in ('NonlinearityLayer', 'BatchNormLayer'):
                 v = created_by.get(id(layer))

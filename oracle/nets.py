@@ -251,15 +251,25 @@ def trained_param_list(net, P):
 
 # --------------------------------------------------------------------------- forward / backward
 def fused_convs(net):
-    """'conv' layers whose output the device never holds on its own: the engine fuses `a + conv(...)` into the epilogue of the LATER
-    conv of the sum (hipdp/engine.py:_emit_add), so the tensor it materialises -- and, in the bf16 storage mode, rounds -- is the sum."""
+    """'conv' layers whose output the device never holds on its own: the engine fuses `a + conv(...)` into the epilogue of the conv at
+    the end of the LONGER branch of the sum (ties: the later one; hipdp/engine.py:_emit_add), so the tensor it materialises -- and, in
+    the bf16 storage mode, rounds -- is the sum."""
     fused = set()
+    depth = {}
+
+    def ref_depth(ref):
+        if ref[0] == 'layer':
+            return depth[ref[1]]
+        return max([ref_depth(r) for r in ref[1:] if isinstance(r, tuple)] or [0])
+
+    for i, l in enumerate(net['layers']):
+        depth[i] = 1 + ref_depth(l['src'])
 
     def walk(ref):
         if ref[0] == 'add':
             cand = [r[1] for r in ref[1:] if r[0] == 'layer' and net['layers'][r[1]]['kind'] == 'conv']
             if cand:
-                fused.add(max(cand))
+                fused.add(max(cand, key=lambda i: (depth[i], i)))
         for r in ref[1:]:
             if isinstance(r, tuple):
                 walk(r)

@@ -131,7 +131,18 @@ def store_agreement(store, stored_out):
     """Per layer, the fraction of elements where the oracle's OWN rounding of the tensor it would have stored equals the device's
     stored tensor (the pin): the un-pinned check of the pins themselves.  A float32 and a float64 evaluation of the same value land on
     different bfloat16 neighbours only when it sits within float32 round-off of a rounding boundary."""
-    return {i: float((np.asarray(stored_out[i], np.float32) == np.asarray(p, np.float32)).mean()) for i, p in store.items() if p is not None}
+    out = {}
+    for i, p in store.items():
+        if p is None:
+            continue
+        p, mine = np.asarray(p, np.float32), np.asarray(stored_out[i], np.float32)
+        # ... or when the element is so small against its tensor that float32 accumulation noise (a few 1e-7 of the terms' magnitude)
+        # reaches its bfloat16 spacing: a channel whose outputs nearly cancel (the stage-1 projection shortcut of the 256x256 net has
+        # one: |y| ~ 1e-3 against a tensor of O(1), 59 % of it lands on the neighbouring bfloat16).  Those count as agreeing; a wrong
+        # rounding rule or a wrong operand shows up at the tensor's own magnitude, a thousand times this bound.
+        noise = np.float32(2e-6) * np.abs(p).max()
+        out[i] = float(((mine == p) | (np.abs(mine - p) <= noise)).mean())
+    return out
 
 
 def device_grad_pins(eng, net):
