@@ -628,6 +628,7 @@ class CompiledNet(object):
             self.input_of[id(v)] = t
         self.x_in, self.in_shape = self.x_ins[0], self.x_ins[0].shape
         self._memo = {}
+        self._beside = []           # (fork / join markers, launches) of the shortcuts moved beside the chain (see _emit_add)
         self._bwd_after = {}        # id(layer p) -> layer q: p's backward is emitted right after q's (see _emit_add)
         out_view = self._emit(net.output)
         self.out = self._materialize_plain(out_view)
@@ -876,10 +877,14 @@ class CompiledNet(object):
         if beside:
             moved = list(self.fwd.ops[n0:])
             if all(isinstance(op, ops.Launch) for op, _ in moved):
-                self.fwd.ops[n0:] = [(ops.Fork(), False)] + [(op, True) for op, _ in moved]
+                fork = ops.Fork()
+                self.fwd.ops[n0:] = [(fork, False)] + [(op, True) for op, _ in moved]
                 self.fwd.uses_side = True
                 self._emit(q.inputs[0])                      # the longer branch, on the main stream
                 self.fwd.join()                              # ... whose last convolution reads the shortcut as its residual
+                # (remembered: a step whose second stream is busy with other work during the forward pass -- step_plan(early=) --
+                #  keeps the shortcuts in the chain instead of queueing them behind that work)
+                self._beside.append(([id(fork), id(self.fwd.ops[-1][0])], [id(op) for op, _ in moved]))
         if p.kind == 'layer' and p.layer.layerNum > q.layer.layerNum:
             self._bwd_after[id(p.layer)] = q.layer           # backward: the sum's gradient reaches p through q's identity path
         out = self._emit(q, residual=pv.base, out_var=var)      # the conv's output tensor IS the sum
@@ -1736,7 +1741,15 @@ class CompiledNet(object):
         cache = self.__dict__.setdefault('_step_plans', {})
         if key not in cache:
             bwd, upd = self._early_adam_plans()
-            parts = ([before] if before is not None else []) + [self.fwd, self.lossplan, bwd]
+            fwd = self.fwd
+            if early is not None and self._beside:
+                # the second stream belongs to `early` during the forward pass: the projection shortcuts stay in the chain
+                marks = set(m for ms, _ in self._beside for m in ms)
+                chain = set(o for _, os_ in self._beside for o in os_)
+                fwd = Plan('forward')
+                fwd.ops = [(op, side and id(op) not in chain) for (op, side) in self.fwd.ops if id(op) not in marks]
+                fwd.uses_side = getattr(self.fwd, 'uses_side', False)
+            parts = ([before] if before is not None else []) + [fwd, self.lossplan, bwd]
             if prefetch is not None:
                 pre, post = Plan('prefetch_join'), Plan('prefetch')
                 pre.join()

@@ -459,6 +459,46 @@ def test_early_fc1_adam_step_equals_plain_step(backend, monkeypatch):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+def test_projection_shortcuts_beside_the_chain_and_in_it(backend, monkeypatch):
+    """The projection shortcut of a residual block runs on the second stream beside the bottleneck (the bottleneck's exit convolution
+    absorbs the add); a step whose second stream is busy during the forward pass (step_plan(early=): the cascade of bench.py) keeps the
+    shortcuts in the chain; with DPP_SIDE_SHORTCUT=0 the later convolution absorbs the add as in rounds 1-3.  Two steps leave
+    bit-identical parameters in the first two cases (the same kernels in another order) and the same to round-off in the third."""
+    from hipdp.ops import Fork, Join, Plan
+    rt = get_runtime(backend)
+    state = {}
+    for mode in ('beside', 'early', 'off'):
+        monkeypatch.setattr(engine, 'SIDE_SHORTCUT', mode != 'off')
+        net, _, _ = make_net(rt, 0, 4, 32, 1, 30)
+        eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+        side_convs = [o.name for (o, side) in eng.fwd.ops if side and getattr(o, 'name', '').startswith('conv1x1')]
+        assert len(side_convs) == (0 if mode == 'off' else 3) and len(eng._beside) == len(side_convs)
+        plan = eng.step_plan()
+        if mode == 'early':
+            scratch = rt.alloc(64)
+            other = Plan('other work')
+            other.add(ops.fill_zero(rt, scratch))
+            plan = eng.step_plan(early=other)
+            fwd_side = [getattr(o, 'name', '') for (o, side) in plan.ops if side]
+            assert not any(n.startswith('conv1x1') for n in fwd_side) and 'fill_zero' in fwd_side
+            nfj = lambda pl: sum(isinstance(o, (Fork, Join)) for o, _ in pl.ops)            # noqa: E731
+            assert nfj(plan) == nfj(eng.step_plan()) - 6 + 1                                # three fork / join pairs gone, one fork for `other`
+        for seed in (5, 6):
+            r = np.random.RandomState(seed)
+            eng.set_input(nets.synthetic_crops(r, 4, 32, 32, np.float32))
+            eng.y_in.set(r.normal(0, 0.3, (4, 30)).astype(np.float32))
+            eng.set_lr(1e-3)
+            plan.run(rt)
+        rt.synchronize()
+        state[mode] = (eng.store.w.get().copy(), float(eng.cost.get()[0]))
+    assert np.array_equal(state['beside'][0], state['early'][0]) and state['beside'][1] == state['early'][1]
+    # (ADAM normalises every gradient to a step of ~lr: a parameter whose gradient is ~0 may step the other way in either pass)
+    d = np.abs(state['beside'][0] - state['off'][0])
+    assert d.max() <= 2 * 2 * 1e-3 * 1.01 and np.mean(d > 1e-4) < 0.02, (d.max(), np.mean(d > 1e-4))
+    assert abs(state['beside'][1] - state['off'][1]) < 1e-4 * abs(state['off'][1])       # (the second step's cost, on weights one ADAM step apart)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_engines_of_a_rebuilt_parameter_store_refuse_to_run(backend):
     """Appending the PCA-prior layer to a trained net (what the mains do, /root/reference/src/main_nyu_posereg_embedding.py:175-190)
     rebuilds the device parameter store: the values survive, the net evaluates through the new layer, and an engine compiled before
