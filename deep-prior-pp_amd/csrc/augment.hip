@@ -552,11 +552,18 @@ __device__ __forceinline__ float4 aug_warp_quad(const AugRec& r, const float* __
             const double X0 = r.m[0] * fbx + r.m[1] * fy_ + r.m[2];
             const double Y0 = r.m[3] * fbx + r.m[4] * fy_ + r.m[5];
             const double W0 = r.m[6] * fbx + r.m[7] * fy_ + r.m[8];
+            // The maps the augmentation builds are products of comToTransform matrices and their cofactor inverses: the bottom row is
+            // EXACTLY (0, 0, 1) (0 / det and det / det of the same rounded products), so W = 0 * x + 0 * y + 1 = 1, 1. / W = 1 and
+            // X * 1. = X bit for bit -- the float64 division per pixel (a third of the pass) only runs for a truly projective map.
+            const bool unit_w = r.m[6] == 0.0 && r.m[7] == 0.0 && r.m[8] == 1.0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const double x1 = (double)(x + j - bx);
-                double Wv = W0 + r.m[6] * x1;
-                Wv = (Wv != 0.0) ? 1. / Wv : 0.;
+                double Wv = 1.0;
+                if (!unit_w) {
+                    Wv = W0 + r.m[6] * x1;
+                    Wv = (Wv != 0.0) ? 1. / Wv : 0.;
+                }
                 const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + r.m[0] * x1) * Wv));
                 const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + r.m[3] * x1) * Wv));
                 long long Xj = cv_round(fX), Yj = cv_round(fY);
