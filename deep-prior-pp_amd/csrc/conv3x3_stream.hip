@@ -17,7 +17,6 @@
 //   * no LDS and no barrier until the column reductions of the workgroup's 64 TPW rows at the very end.
 // The data gradient is the same kernel on dY with the mirrored weights of dpp_conv3x3_wtrans.
 #include "dpp_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -190,12 +189,8 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_stream_kernel(C3sArgs a) 
     }
 }
 
-int tiles_per_wave(int C, long pixels) {
-    static const int force = [] { const char* e = getenv("DPP_CONV3_STREAM_TPW"); return e ? atoi(e) : 0; }();
-    if (C != 16) return 1;
-    if (force == 1 || force == 2 || force == 4) return force;
-    return pixels >= 65536 ? 2 : 1;
-}
+// (tiles per wave 1 | 2 | 4 measured alike on stage 1: 15.5 | 14.8 | 15.9 us, profiles/r04_conv3x3_stream.txt)
+int tiles_per_wave(int C, long pixels) { return (C == 16 && pixels >= 65536) ? 2 : 1; }
 
 }  // namespace
 
@@ -234,7 +229,7 @@ extern "C" int dpp_conv3x3_stream(const float* X, int N, int H, int W, int C, co
                     else DPP_LAUNCH((conv3x3_stream_kernel<CN_, T_, true, false>), grid, block, 0, st, a); } \
         else { if (bnb) DPP_LAUNCH((conv3x3_stream_kernel<CN_, T_, false, true>), grid, block, 0, st, a); \
                else DPP_LAUNCH((conv3x3_stream_kernel<CN_, T_, false, false>), grid, block, 0, st, a); } } while (0)
-    if (C == 16) { if (rows == 256) DPP_C3S(1, 4); else if (rows == 128) DPP_C3S(1, 2); else DPP_C3S(1, 1); }
+    if (C == 16) { if (rows == 128) DPP_C3S(1, 2); else DPP_C3S(1, 1); }
     else DPP_C3S(2, 1);
 #undef DPP_C3S
     return dpp_launch_status();
