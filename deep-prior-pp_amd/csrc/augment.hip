@@ -405,13 +405,15 @@ __device__ __forceinline__ void aug_label_joint(const PrepArgs& a, int b, const 
 
 // label -> PCA prior (poseregnettrainer.py:262) or the raw normalised joints, by threads t = 0 .. nt-1 (nt a multiple of 8: the whole
 // workgroup, or one wave)
-__device__ __forceinline__ void aug_project_label(const PrepArgs& a, int b, const float* s_label, int t, int nt) {
+// (part / nparts: this caller's share of the outputs -- the rounds r = e0 / (nt / 8) with r % nparts == part; the fused launch deals
+//  them to the `splits` workgroups of a crop)
+__device__ __forceinline__ void aug_project_label(const PrepArgs& a, int b, const float* s_label, int t, int nt, int part = 0, int nparts = 1) {
     const int D = a.J * 3;
     if (a.pca_comp) {
         // 8 lanes per output: lane p sums d = p, p + 8, ..., the eight partial sums meet in an xor butterfly (a fixed order).  One
         // thread per output walked D dependent multiply-adds with two global loads each: 11 us for 30 x 48.
         const int p = t & 7;
-        for (int e0 = 0; e0 < a.E; e0 += nt / 8) {
+        for (int e0 = part * (nt / 8); e0 < a.E; e0 += nparts * (nt / 8)) {
             const int e = e0 + (t >> 3);
             double sum = 0.0;
             if (e < a.E) {
@@ -436,7 +438,7 @@ __device__ __forceinline__ void aug_project_label(const PrepArgs& a, int b, cons
             sum += __shfl_xor(sum, 4);
             if (e < a.E && p == 0) a.out_y[(size_t)b * a.E + e] = (float)sum;
         }
-    } else {
+    } else if (part == 0) {
         for (int d = t; d < D; d += nt) a.out_y[(size_t)b * D + d] = s_label[d];
     }
 }
@@ -674,8 +676,11 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_fused_kernel(PrepArgs a, 
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         if ((vt & 63) == 0) s_red[vt >> 6] = mx;
     }
-    if (vt == 0) {
-        if (live) aug_prepare_geometry(a, b, 0.0f, s_rec, s_lc);
+    if (vt < DPP_WAVE) {
+        // the serial lane is what the workgroup waits for: its wave issues ahead of the streaming waves that share its SIMD
+        DPP_SETPRIO(3);
+        if (vt == 0 && live) aug_prepare_geometry(a, b, 0.0f, s_rec, s_lc);
+        DPP_SETPRIO(0);
     }
     if (vt == 0) dpp_stamp(a.prof, 1);                 // geometry (+ ticket) done on lane 0
     __syncthreads();
@@ -686,18 +691,23 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_fused_kernel(PrepArgs a, 
         s_rec.premax = mx * s_rec.den_scale + s_rec.den_off;      // two roundings (contraction is off), as in aug_prepare_geometry
     }
     __syncthreads();
-    // Split 0 also owns the labels: wave 0 transforms the joints (one lane per joint) and projects them while waves 1-3 are already
-    // moving pixels; it then takes a small share of the pixels itself (an eighth of the workgroup's, against its normal quarter).
+    // The labels are shared out over the crop's S workgroups: in each, wave 0 transforms the joints (one lane per joint: every workgroup
+    // needs the whole label) and projects ITS rounds of the PCA outputs (8 outputs per round, round r to workgroup r % S) while waves
+    // 1-3 are already moving pixels; it then takes a small share of the pixels itself (an eighth of the workgroup's, against its normal
+    // quarter).  With the whole projection on split 0 that workgroup's wave 0 spent 10-14 us there (tools/augment_phase.py) and was
+    // what the launch waited for.
     const int chunk = npix / S;                          // host guarantees npix % (4 * S) == 0 and dsz % 4 == 0
     const int Q = chunk >> 2;                            // pixel quads of this workgroup
     int q0 = 0, q1 = Q, t = tid, nt = DPP_THREADS;
-    if (split == 0) {
+    {
         const int Qw = Q >= 8 * DPP_WAVE ? ((Q / 8) & ~(DPP_WAVE - 1)) : 0;
         if (vt < DPP_WAVE) {
+            DPP_SETPRIO(3);                              // (the label wave starts its pixels late: it issues first until then)
             if (vt < a.J) aug_label_joint(a, b, s_lc, vt, s_label);
             DPP_WAVE_SYNC();
-            aug_project_label(a, b, s_label, vt, DPP_WAVE);
-            if (a.rec != nullptr && vt == 0) a.rec[b] = s_rec;
+            aug_project_label(a, b, s_label, vt, DPP_WAVE, split, S);
+            if (split == 0 && a.rec != nullptr && vt == 0) a.rec[b] = s_rec;
+            DPP_SETPRIO(0);
             q1 = Qw; t = vt; nt = DPP_WAVE;
         } else {
             q0 = Qw; t = vt - DPP_WAVE; nt = DPP_THREADS - DPP_WAVE;

@@ -152,6 +152,13 @@ extern unsigned long long* dpp_prof_buffer;                // host-side: where i
 #define DPP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// Instruction-issue priority of the calling wave among the waves of its SIMD (0 .. 3; hardware hint, nothing for the emulator).
+#ifdef DPP_HIP_EMU
+#define DPP_SETPRIO(p)
+#else
+#define DPP_SETPRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
+
 // All lanes of a wave have executed what precedes before any executes what follows (LDS traffic between the lanes of ONE wave: the
 // hardware runs a wave's LDS instructions in order, so this only has to stop the compiler; the emulator's fibers meet in a shuffle).
 #ifdef DPP_HIP_EMU
