@@ -113,6 +113,8 @@ def test_resnet_forward_eval_matches_oracle(backend):
     out = net.computeOutput(x)                      # 6 samples, batch 4 -> padded by repeating the last sample
     ref = nets.compute_output(onet, nets.cast_params(P, np.float64), x.astype(np.float64))
     assert out.shape == (6, 42)
+    assert net.computeOutput(x[:0]).shape == (0, 42)                   # an empty test set: no batch, an empty result
+    assert np.array_equal(net.computeOutput(x[:1]), out[:1])           # a single sample: the batch is that sample repeated
     err_mm = np.abs(out - ref).max() * MM
     assert np.abs(ref).max() > 0.05
     # The bar is 1e-3 mm.  On this deliberately tiny net (batch 4, 2x2 maps: BN statistics from 16 values) float32
