@@ -39,95 +39,82 @@ class NetBaseParams(object):
         return sum(l.getMemoryRequirement() for l in self.layers)
 
 
-def _unique(prms):
-    seen, out = set(), []
-    for p in prms:
-        if p.auto_name not in seen:
-            seen.add(p.auto_name)
-            out.append(p)
-    return out
+def _shared_variables(layers, attr):
+    """The shared variables the layers list under `attr` ('params' | 'weights'), each once (twins and shared towers list the
+    same variable several times), in layer order."""
+    found = {}
+    for layer in layers:
+        for var in getattr(layer, attr):
+            found.setdefault(var.auto_name, var)
+    return list(found.values())
+
+
+def _blocklist(attr, what, match):
+    """The `<attr>` / `<attr>_filter` property pair of netbase.py:157-216: `<attr>` enumerates the layers' shared variables without
+    the ones on the block list, assigning the block list checks that every entry belongs to the model (UserWarning otherwise).
+    `match` names the attribute of a variable that is compared with the blocked auto_names (the reference compares `auto_name` for
+    the parameters and `name` for the weights)."""
+    slot = '_%s_filter' % attr
+
+    def current(net):
+        return net.__dict__.setdefault(slot, [])
+
+    def listed(net):
+        hidden = set(b.auto_name for b in current(net))
+        return [v for v in _shared_variables(net.layers, attr) if getattr(v, match) not in hidden]
+
+    def assign(net, blocked):
+        known = set(v.auto_name for v in _shared_variables(net.layers, attr))
+        for b in blocked:
+            if b.auto_name not in known:
+                raise UserWarning("%s {} not in model!".format(b) % what)
+        net.__dict__[slot] = blocked
+
+    return property(listed), property(current, assign)
 
 
 class NetBase(object):
     def __init__(self, rng, inputVar, cfgParams, twin=None):
-        self._params_filter = []
-        self._weights_filter = []
         self.inputVar = inputVar
         self.cfgParams = cfgParams
         self.rng = rng
         self._twin = twin                 # layers built with copyLayer = twin.layers[i] (netbase.py:117): one parameter store for both
         self.layers = []
-        for i, layerParam in enumerate(cfgParams.layers):
-            if i == 0:
-                inp = inputVar
-            else:
-                prev_out = self.layers[-1].cfgParams.outputDim
-                if len(prev_out) == 4 and len(layerParam.inputDim) == 2:
-                    inp = self.layers[-1].output.flatten(2)
-                    inp.name = "input_layer_{}".format(i)
-                elif len(layerParam.inputDim) == 4 and len(prev_out) == 2:
-                    inp = self.layers[-1].output.reshape(layerParam.inputDim, ndim=4)
-                    inp.name = "input_layer_{}".format(i)
-                else:
-                    inp = self.layers[-1].output
-            ctor = _LAYER_CLASSES[layerParam.__class__.__name__[:-6]]     # '<X>LayerParams' -> '<X>Layer'
-            self.layers.append(ctor(rng, inputVar=inp, cfgParams=layerParam,
-                                    copyLayer=None if (twin is None) else twin.layers[i], layerNum=i))
+        for num, spec in enumerate(cfgParams.layers):
+            build = _LAYER_CLASSES[type(spec).__name__[:-len('Params')]]            # '<X>LayerParams' -> '<X>Layer'
+            self.layers.append(build(rng, inputVar=self._input_of(num, spec), cfgParams=spec,
+                                     copyLayer=twin.layers[num] if twin is not None else None, layerNum=num))
         self.output = self.layers[-1].output
         self.load(self.cfgParams.loadFile)
 
+    def _input_of(self, num, spec):
+        """What layer `num` reads: the net's input, or the previous layer's output -- flattened in front of the first dense layer,
+        reshaped back to a map in front of a convolution that follows one (netbase.py:100-113)."""
+        if num == 0:
+            return self.inputVar
+        before = self.layers[-1]
+        rank_out, rank_in = len(before.cfgParams.outputDim), len(spec.inputDim)
+        if rank_out == rank_in:
+            return before.output
+        if (rank_out, rank_in) == (4, 2):
+            var = before.output.flatten(2)
+        elif (rank_out, rank_in) == (2, 4):
+            var = before.output.reshape(spec.inputDim, ndim=4)
+        else:
+            return before.output
+        var.name = "input_layer_{}".format(num)
+        return var
+
     def __str__(self):
-        cfg = "Network configuration:\n"
-        for i, l in enumerate(self.layers):
-            cfg += "Layer {}: {} with {} \n".format(i, l.__class__.__name__, l)
-        return cfg
+        # (part of the checkpoint format: load() compares it with the stored description)
+        rows = ["Layer {}: {} with {} \n".format(num, type(layer).__name__, layer) for num, layer in enumerate(self.layers)]
+        return "Network configuration:\n" + "".join(rows)
 
     # ---- parameter enumeration -------------------------------------------------------------------------
-    @property
-    def all_params(self):
-        return _unique([p for l in self.layers for p in l.params])
-
-    @property
-    def params(self):
-        if not hasattr(self, '_params_filter'):
-            self._params_filter = []
-        blocked = [an.auto_name for an in self._params_filter]
-        return _unique([p for l in self.layers for p in l.params if p.auto_name not in blocked])
-
-    @property
-    def params_filter(self):
-        return self._params_filter
-
-    @params_filter.setter
-    def params_filter(self, bl):
-        names = [p.auto_name for l in self.layers for p in l.params]
-        for b in bl:
-            if b.auto_name not in names:
-                raise UserWarning("Param {} not in model!".format(b))
-        self._params_filter = bl
-
-    @property
-    def all_weights(self):
-        return _unique([p for l in self.layers for p in l.weights])
-
-    @property
-    def weights(self):
-        if not hasattr(self, '_weights_filter'):
-            self._weights_filter = []
-        blocked = [an.auto_name for an in self._weights_filter]
-        return _unique([p for l in self.layers for p in l.weights if p.name not in blocked])
-
-    @property
-    def weights_filter(self):
-        return self._weights_filter
-
-    @weights_filter.setter
-    def weights_filter(self, bl):
-        names = [p.auto_name for l in self.layers for p in l.weights]
-        for b in bl:
-            if b.auto_name not in names:
-                raise UserWarning("Weight {} not in model!".format(b))
-        self._weights_filter = bl
+    all_params = property(lambda self: _shared_variables(self.layers, 'params'))
+    all_weights = property(lambda self: _shared_variables(self.layers, 'weights'))
+    params, params_filter = _blocklist('params', 'Param', 'auto_name')
+    weights, weights_filter = _blocklist('weights', 'Weight', 'name')
 
     # ---- inference ---------------------------------------------------------------------------------------
     def _engine(self, runtime=None):

@@ -321,3 +321,31 @@ def test_scalar_regression_target(backend, tmp_path):
     ot = te.out.buf.get().astype(np.float64).reshape(B)
     np.testing.assert_allclose(te.out.grad.get().reshape(B), 2.0 / B * (ot - y.mean(dtype=np.float64)), rtol=1e-5, atol=1e-7)
     assert abs(c - ((ot[:, None] - y[None, :].astype(np.float64)) ** 2).mean()) < 1e-6 * max(1.0, c)
+
+
+def test_parameter_and_weight_block_lists():
+    """NetBase.params / params_filter / weights / weights_filter (/root/reference/src/net/netbase.py:157-216): `params` lists every shared
+    variable of the layers once, without the ones on the block list; assigning a block list checks membership (UserWarning); the
+    weights' block list is compared by `name` against the blocked `auto_name`s in the reference, i.e. it never hides anything -- kept."""
+    from hipdp.graph import SharedParam
+    net = PoseRegNet(np.random.RandomState(1), cfgParams=PoseRegNetParams(type=0, nChan=1, wIn=48, hIn=48, batchSize=2, numJoints=3, nDims=3))
+    every = net.all_params
+    assert [p.auto_name for p in net.params] == [p.auto_name for p in every] and len(every) == len(set(p.auto_name for p in every)) > 4
+    assert net.params_filter == [] and net.weights_filter == []
+    net.params_filter = [every[0], every[3]]
+    assert [p.auto_name for p in net.params] == [p.auto_name for p in every if p not in (every[0], every[3])]
+    assert net.all_params == every                                   # the block list does not touch the full enumeration
+    stranger = SharedParam(np.zeros(3, np.float32), name='not_in_the_model')
+    with pytest.raises(UserWarning, match='Param'):
+        net.params_filter = [stranger]
+    assert net.params_filter == [every[0], every[3]]                 # a rejected list leaves the old one in place
+    net.params_filter = []
+    assert len(net.params) == len(every)
+    ws = net.all_weights
+    assert 0 < len(ws) < len(every) and all(w in every for w in ws)
+    net.weights_filter = [ws[0]]
+    assert net.weights_filter == [ws[0]] and len(net.weights) == len(ws)      # the reference's name / auto_name comparison: a no-op
+    with pytest.raises(UserWarning, match='Weight'):
+        net.weights_filter = [stranger]
+    assert str(net).startswith("Network configuration:\nLayer 0: ConvPoolLayer with ")
+    assert str(net).count('\n') == len(net.layers) + 1 and str(net).endswith(' \n')
