@@ -2,7 +2,12 @@
 // today), (b) an in-kernel hand-off inside the CONSUMER launch: the first C/4 workgroups combine the producer's per-block partials
 // (one wave per channel), publish (mean, scale) with write-through (sc1) stores and bump an arrival counter; every workgroup issues
 // its operand loads first, one lane polls the counter (relaxed, agent scope), then the coefficients are read with sc1 loads (no
-// fences on either side: MI355X_MICROARCH.md, "sc1 stores and loads both sides"), (c) not at all (lower bound, wrong numbers).
+// fences on either side: MI355X_MICROARCH.md, "sc1 stores and loads both sides"), (c) not at all (lower bound, wrong numbers),
+// (d) round 4, the two-level form of VERDICT r3 task 1(a), made placement-independent: the PRODUCER's workgroups are grouped by
+// block id (b % 8 -- the XCD the dispatcher is observed to give block b, used for speed only), every workgroup releases its partials
+// (agent scope) and takes a ticket on its group's counter, the group's last arriver acquires, folds the group's partials
+// ([2][C][8][NB/8], contiguous per group) and publishes ONE (sum, sumsq) row per channel; the CONSUMER -- the next launch, so the
+// kernel boundary orders it -- combines the 8 rows per channel in its prologue.  No finalize launch, no polling.
 // A chain of L "layers": y = relu((x - mean) * scale) over [M][C] f32, each layer also emits the per-row-block (sum, sumsq) partials
 // of what it writes -- an elementwise stand-in for a 1x1 convolution with the same memory behaviour and the same dependency chain.
 //   hipcc --offload-arch=gfx950 -O3 tools/probes/handoff_probe.hip -o /tmp/handoff_probe && /tmp/handoff_probe
@@ -53,7 +58,8 @@ __global__ __launch_bounds__(THREADS) void finalize_kernel(const float* __restri
 template <int MODE, int C, int ROWS>
 __global__ __launch_bounds__(THREADS) void layer_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ pin,
                                                         float* mean, float* scale, float* __restrict__ pout, int M, unsigned* counter,
-                                                        const unsigned* __restrict__ step_word) {
+                                                        const unsigned* __restrict__ step_word, const float* __restrict__ rows_in = nullptr,
+                                                        float* rows_out = nullptr) {
     constexpr int Q = C / 4, RSTEP = THREADS / Q, IT = ROWS / RSTEP;
     __shared__ float red[2][4][C];
     const int tid = threadIdx.x, cq = tid % Q, rb = tid / Q, NB = gridDim.x;
@@ -80,6 +86,26 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(const float* __restrict_
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) { mu[j] = ld_sc1(mean + cq * 4 + j); sc[j] = ld_sc1(scale + cq * 4 + j); }
+    } else if (MODE == 2) {
+        // eight (sum, sumsq) rows per channel, combined in group order: 16 independent 16-byte loads per thread
+        float4 rs[8], rq[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            rs[g] = *reinterpret_cast<const float4*>(rows_in + (size_t)g * C + cq * 4);
+            rq[g] = *reinterpret_cast<const float4*>(rows_in + (size_t)(8 + g) * C + cq * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double ss = 0.0, qq = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                ss += (double)(j == 0 ? rs[g].x : j == 1 ? rs[g].y : j == 2 ? rs[g].z : rs[g].w);
+                qq += (double)(j == 0 ? rq[g].x : j == 1 ? rq[g].y : j == 2 ? rq[g].z : rq[g].w);
+            }
+            const double m_ = ss / M, var = qq / M - m_ * m_;
+            mu[j] = (float)m_;
+            sc[j] = (float)(1.0 / sqrt(fabs(var) + 1e-4));
+        }
     } else {
         const float4 a = *reinterpret_cast<const float4*>(mean + cq * 4), b = *reinterpret_cast<const float4*>(scale + cq * 4);
         mu[0] = a.x; mu[1] = a.y; mu[2] = a.z; mu[3] = a.w;
@@ -113,8 +139,37 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(const float* __restrict_
             const int nw = Q <= 64 ? (THREADS / 64) : 1;
             for (int w = 0; w < nw; ++w) { a += red[0][w][tid]; b += red[1][w][tid]; }
             // Q < 64: waves hold different rows of the same quads; Q == 64: every wave holds all quads of its rows
-            pout[(size_t)tid * NB + blockIdx.x] = a;
-            pout[((size_t)C + tid) * NB + blockIdx.x] = b;
+            if (MODE == 2) {
+                const int NBG = NB >> 3, g = blockIdx.x & 7, bg = blockIdx.x >> 3;
+                pout[((size_t)tid * 8 + g) * NBG + bg] = a;
+                pout[(((size_t)C + tid) * 8 + g) * NBG + bg] = b;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // the storing threads release their partials
+            } else {
+                pout[(size_t)tid * NB + blockIdx.x] = a;
+                pout[((size_t)C + tid) * NB + blockIdx.x] = b;
+            }
+        }
+    }
+    if (MODE == 2) {
+        __shared__ int s_last;
+        const int NBG = NB >> 3, g = blockIdx.x & 7;
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned want = (*step_word + 1u) * (unsigned)NBG;
+            s_last = (__hip_atomic_fetch_add(counter + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == want);
+        }
+        __syncthreads();
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // 16 lanes per (statistic, channel) row of NBG contiguous partials; 16 rows per pass
+            const int l16 = tid & 15, r0 = tid >> 4;
+            for (int r = r0; r < 2 * C; r += THREADS / 16) {
+                const float* row = pout + ((size_t)r * 8 + g) * NBG;
+                double acc = 0.0;
+                for (int b = l16; b < NBG; b += 16) acc += (double)row[b];
+                acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
+                if (l16 == 0) st_sc1(rows_out + (size_t)((r / C) * 8 + g) * C + (r % C), (float)acc);
+            }
         }
     }
 }
@@ -124,11 +179,12 @@ __global__ void tick_kernel(unsigned* w) { *w += 1; }
 template <int C, int ROWS>
 void run(int M, int L) {
     const int NB = M / ROWS;
-    float *x[2], *part[2], *mean, *scale;
+    float *x[2], *part[2], *mean, *scale, *rows;
     unsigned *counters, *step;
     for (int i = 0; i < 2; ++i) { hipMalloc(&x[i], (size_t)M * C * 4); hipMalloc(&part[i], (size_t)2 * C * NB * 4); }
     hipMalloc(&mean, (size_t)L * C * 4); hipMalloc(&scale, (size_t)L * C * 4);
     hipMalloc(&counters, L * 64 * 4); hipMalloc(&step, 4);
+    hipMalloc(&rows, (size_t)(L + 1) * 16 * C * 4); hipMemset(rows, 0, (size_t)(L + 1) * 16 * C * 4);
     std::vector<float> h((size_t)M * C);
     for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) % 1000) / 500.0f - 1.0f;
     hipMemcpy(x[0], h.data(), h.size() * 4, hipMemcpyHostToDevice);
@@ -137,23 +193,27 @@ void run(int M, int L) {
     hipMemset(counters, 0, L * 64 * 4); hipMemset(step, 0, 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    auto chain = [&](int mode) {     // 0: finalize launches, 1: hand-off, 2: no finalize at all
+    auto chain = [&](int mode) {     // 0: finalize launches, 1: hand-off, 2: no finalize at all, 3: two-level last arriver in the producer
         for (int l = 0; l < L; ++l) {
             const int a = l & 1, b = a ^ 1;
             if (mode == 0) hipLaunchKernelGGL(finalize_kernel, dim3(C / 4), dim3(THREADS), 0, 0, part[a], C, NB, M, mean + l * C, scale + l * C);
             if (mode == 1)
                 hipLaunchKernelGGL((layer_kernel<1, C, ROWS>), dim3(NB), dim3(THREADS), 0, 0, x[a], x[b], part[a], mean + l * C, scale + l * C, part[b], M,
                                    counters + l * 16, step);
+            else if (mode == 3)
+                hipLaunchKernelGGL((layer_kernel<2, C, ROWS>), dim3(NB), dim3(THREADS), 0, 0, x[a], x[b], part[a], mean + l * C, scale + l * C, part[b], M,
+                                   counters + l * 16, step, rows + (size_t)l * 16 * C, rows + (size_t)(l + 1) * 16 * C);
             else
                 hipLaunchKernelGGL((layer_kernel<0, C, ROWS>), dim3(NB), dim3(THREADS), 0, 0, x[a], x[b], part[a], mean + l * C, scale + l * C, part[b], M,
                                    counters + l * 16, step);
         }
-        if (mode == 1) hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, 0, step);
+        if (mode == 1 || mode == 3) hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, 0, step);
     };
-    float res[3];
-    double sums[3];
-    for (int mode = 0; mode < 3; ++mode) {
+    float res[4];
+    double sums[4];
+    for (int mode = 0; mode < 4; ++mode) {
         hipMemcpy(x[0], h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        hipMemset(counters, 0, L * 64 * 4); hipMemset(step, 0, 4);
         for (int i = 0; i < 3; ++i) chain(mode);
         hipDeviceSynchronize();
         const int reps = 10;
@@ -165,16 +225,22 @@ void run(int M, int L) {
         hipEventElapsedTime(&ms, e0, e1);
         res[mode] = ms * 1e3f / (reps * L);
         std::vector<float> m(C);
-        hipMemcpy(m.data(), mean + (L - 1) * C, C * 4, hipMemcpyDeviceToHost);
         sums[mode] = 0;
-        for (int c = 0; c < C; ++c) sums[mode] += m[c];
+        if (mode == 3) {                       // the published group rows of the last layer: sum over groups / M = the mean
+            std::vector<float> r8((size_t)8 * C);
+            hipMemcpy(r8.data(), rows + (size_t)(L - 1) * 16 * C, (size_t)8 * C * 4, hipMemcpyDeviceToHost);
+            for (int c = 0; c < C; ++c) { double t = 0; for (int g = 0; g < 8; ++g) t += r8[(size_t)g * C + c]; sums[mode] += (float)(t / M); }
+        } else {
+            hipMemcpy(m.data(), mean + (L - 1) * C, C * 4, hipMemcpyDeviceToHost);
+            for (int c = 0; c < C; ++c) sums[mode] += m[c];
+        }
     }
     // the hand-off must give the same coefficients as the finalize launches (same arithmetic, same order): checksum of the last layer's means
-    printf("M %7d C %3d rows/wg %3d (%4d wgs, %5.1f MB/tensor): finalize launch %6.2f us/layer | in-consumer hand-off %6.2f | no finalize %6.2f   "
-           "[mean checksum %.6f vs %.6f %s]\n", M, C, ROWS, NB, M * C * 4 / 1e6, res[0], res[1], res[2], sums[0], sums[1],
-           sums[0] == sums[1] ? "equal" : "DIFFERENT");
+    printf("M %7d C %3d rows/wg %3d (%4d wgs, %5.1f MB/tensor): finalize launch %6.2f us/layer | in-consumer hand-off %6.2f | no finalize %6.2f | "
+           "two-level last arriver %6.2f   [mean checksum %.6f vs %.6f (hand-off) vs %.6f (two-level)]\n", M, C, ROWS, NB, M * C * 4 / 1e6, res[0], res[1],
+           res[2], res[3], sums[0], sums[1], sums[3]);
     for (int i = 0; i < 2; ++i) { hipFree(x[i]); hipFree(part[i]); }
-    hipFree(mean); hipFree(scale); hipFree(counters); hipFree(step);
+    hipFree(mean); hipFree(scale); hipFree(counters); hipFree(step); hipFree(rows);
 }
 
 int main() {
