@@ -10,7 +10,7 @@
 // kernel boundary orders it -- combines the 8 rows per channel in its prologue.  No finalize launch, no polling.
 // A chain of L "layers": y = relu((x - mean) * scale) over [M][C] f32, each layer also emits the per-row-block (sum, sumsq) partials
 // of what it writes -- an elementwise stand-in for a 1x1 convolution with the same memory behaviour and the same dependency chain.
-//   hipcc --offload-arch=gfx950 -O3 tools/probes/handoff_probe.hip -o /tmp/handoff_probe && /tmp/handoff_probe
+//   hipcc --offload-arch=gfx950 -O3 [-DHANDOFF_NOFENCE] tools/probes/handoff_probe.hip -o /tmp/handoff_probe && /tmp/handoff_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -143,7 +143,13 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(const float* __restrict_
                 const int NBG = NB >> 3, g = blockIdx.x & 7, bg = blockIdx.x >> 3;
                 pout[((size_t)tid * 8 + g) * NBG + bg] = a;
                 pout[(((size_t)C + tid) * 8 + g) * NBG + bg] = b;
+#ifdef HANDOFF_NOFENCE
+                // the fence-free form the proposal hoped for ("same XCD, same L2"): only correct while block b really runs on XCD b % 8,
+                // which the platform does not promise -- compiled with -DHANDOFF_NOFENCE to price it, never a design
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // the storing threads release their partials
+#endif
             } else {
                 pout[(size_t)tid * NB + blockIdx.x] = a;
                 pout[((size_t)C + tid) * NB + blockIdx.x] = b;
@@ -160,13 +166,19 @@ __global__ __launch_bounds__(THREADS) void layer_kernel(const float* __restrict_
         }
         __syncthreads();
         if (s_last) {
+#ifndef HANDOFF_NOFENCE
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
             // 16 lanes per (statistic, channel) row of NBG contiguous partials; 16 rows per pass
             const int l16 = tid & 15, r0 = tid >> 4;
             for (int r = r0; r < 2 * C; r += THREADS / 16) {
                 const float* row = pout + ((size_t)r * 8 + g) * NBG;
                 double acc = 0.0;
+#ifdef HANDOFF_NOFENCE
+                for (int b = l16; b < NBG; b += 16) acc += (double)ld_sc1(row + b);      // past this CU's L1
+#else
                 for (int b = l16; b < NBG; b += 16) acc += (double)row[b];
+#endif
                 acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
                 if (l16 == 0) st_sc1(rows_out + (size_t)((r / C) * 8 + g) * C + (r % C), (float)acc);
             }
