@@ -197,18 +197,17 @@ class ParamStore(object):
         return out
 
     def snapshot(self, into=None):
-        """Device copy of all parameters and running statistics (two device-to-device copies of the flat buffers): the epoch loop's
-        "best weights so far" (nettrainer.py:871-876 pulls every array to the host for that)."""
+        """Device copy of all TRAINED parameters (one device-to-device copy of the flat buffer): the epoch loop's "best weights so
+        far" (nettrainer.py:871-876 pulls `weightVals` = all_params, the trained parameters only, to the host for that; the BatchNorm
+        running statistics are not part of it, so early stopping keeps the FINAL statistics -- the same semantic as the host path)."""
         if into is None:
-            into = (self.rt.alloc(self.n_w, zero=False), self.rt.alloc(self.n_nt, zero=False))
+            into = (self.rt.alloc(self.n_w, zero=False),)
         self.rt.copy(into[0], self.w)
-        self.rt.copy(into[1], self.nt)
         return into
 
     def restore(self, snap):
         self.check_live()
         self.rt.copy(self.w, snap[0])
-        self.rt.copy(self.nt, snap[1])
 
     released = False
 
@@ -312,14 +311,17 @@ def get_store(net, rt, layers):
     while getattr(owner, '_twin', None) is not None:
         owner = owner._twin
     store = getattr(owner, '_param_store', None)
-    if store is not None and store.rt is rt and [s['param'].auto_name for s in store.slots] == names and \
-            [s['info'] for s in store.slots] == [i for (_, _, i, _) in specs]:
+    same_list = store is not None and [s['param'].auto_name for s in store.slots] == names and \
+        [s['info'] for s in store.slots] == [i for (_, _, i, _) in specs]
+    if same_list and store.rt is rt:
         net._param_store = store
         return store
     if store is not None:
-        if owner is not net:
+        if owner is not net and not same_list:
             raise RuntimeError("twin net: its parameter list differs from the one of the net it shares its weights with (%d vs %d "
                                "parameters); the shared store is not rebuilt under the owner's engines" % (len(names), len(store.slots)))
+        # same parameters on ANOTHER runtime (a twin, or the net itself, compiled on a different device / stream set): the store moves
+        # there -- values are pulled back to the host copies first, engines of the old runtime refuse to run (check_live)
         store.release()
     store = ParamStore(rt, specs)
     owner._param_store = store

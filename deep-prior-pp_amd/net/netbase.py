@@ -134,8 +134,13 @@ class NetBase(object):
         dp (a hipdp.parallel.DataParallel; default: the one a data-parallel trainer attached to the net as `net.dp`): the test set is
         dealt to the ranks batch by batch -- rank r evaluates batches r, r + G, r + 2G, ... on its own GPU -- and the outputs are
         all-gathered, so every rank returns the full array ("Validation / computeOutput: shard batches,
-        all-gather outputs").  A collective: every rank has to call it with the same inputs.  The replicas hold identical weights
-        and a batch goes through the same kernels whichever rank runs it, so the result equals the single-process one bit for bit."""
+        all-gather outputs").  A COLLECTIVE: every rank has to call it, with the same inputs -- a rank-conditional call (evaluation
+        under `if writer:`) deadlocks; pass dp=False for a private, un-sharded evaluation on one rank.
+        The trained parameters of the replicas are identical (replicated ADAM on the all-reduced gradient), the BatchNorm RUNNING
+        statistics are not: with per-GPU batch statistics (DataParallel(sync_bn=False), the default) every rank's EMA follows its own
+        shards.  Rank 0's statistics -- the ones in the checkpoint rank 0 writes -- are therefore broadcast before the batches are
+        dealt out, so a batch goes through the same numbers and the same kernels whichever rank runs it and the result equals the
+        single-process evaluation of rank 0's checkpoint bit for bit."""
         if not isinstance(inputs, list):
             inputs = [inputs]
         assert all(i.shape[0] == inputs[0].shape[0] for i in inputs[1:])
@@ -146,6 +151,8 @@ class NetBase(object):
             self.setDeterministic()
         if dp is None:
             dp = getattr(self, 'dp', None)
+        if dp is False:
+            dp = None
         G, rank = (dp.world, dp.rank) if dp is not None else (1, 0)
         batch_size = self.cfgParams.batch_size
         nSamp = inputs[0].shape[0]
@@ -154,6 +161,8 @@ class NetBase(object):
         outSize[0] = padSize
         out = numpy.zeros(tuple(outSize), dtype='float32')
         eng = self._engine()
+        if G > 1:
+            self.syncRunningStatistics(dp)
         n_test_batches = padSize // batch_size
         start = time.time()
         for i in range(rank, n_test_batches, G):
@@ -181,6 +190,13 @@ class NetBase(object):
         if timeit:
             print("{} in {}s, {}ms per frame".format(padSize, end - start, (end - start) * 1000. / padSize))
         return out[0:nSamp]
+
+    def syncRunningStatistics(self, dp):
+        """Rank 0's non-trained parameters (BatchNorm running mean / inv_std) on every rank.  A collective (one broadcast of the flat
+        statistics buffer, a few KB).  No-op before the net has a device store."""
+        store = self._live_store()
+        if store is not None and dp is not None and dp.world > 1:
+            dp.broadcast(store.nt)
 
     # ---- mode toggles ------------------------------------------------------------------------------------
     def unsetDeterministic(self):

@@ -618,6 +618,10 @@ class NetTrainer(object):
             else:
                 self.poseNet.weightVals = bestParams
             print('Best params at epoch %d' % bestParamsEp)
+        if self.dp is not None and hasattr(self.poseNet, 'syncRunningStatistics'):
+            # per-GPU BatchNorm statistics: every rank's running mean / inv_std followed its own shards.  From here on the replicas are
+            # ONE model again -- rank 0's, the one whose checkpoints were written (every rank runs train(), so this is a safe collective)
+            self.poseNet.syncRunningStatistics(self.dp)
         if self.cfgParams.augment_fun_params['fun'] is not None or self.cfgParams.load_fun_params['fun'] is not None:
             self.unsetDataLoading()
         return train_costs, wvals, validation_obs[0] if len(validation_obs) == 1 else validation_obs

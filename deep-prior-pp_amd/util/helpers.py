@@ -31,7 +31,31 @@ def shuffle_many_inplace(arrays, random_state=None):
         return
     perm = _swap_permutation(lengths.pop(), rng)
     for a in arrays:
+        _gather_rows_inplace(a, perm)
+
+
+def _gather_rows_inplace(a, perm):
+    """a[i] <- a[perm[i]] with O(1) extra memory (the reference swaps rows in place; `a[...] = a[perm]` would hold a second copy of
+    a 4.7 GB crop array for the duration of the call): the permutation is walked cycle by cycle with one saved row per cycle."""
+    n = len(perm)
+    if a.nbytes <= (64 << 20):                     # small arrays: one gather is faster than the row walk
         a[...] = a[perm]
+        return
+    done = numpy.zeros(n, dtype=bool)
+    for start in range(n):
+        if done[start] or perm[start] == start:
+            done[start] = True
+            continue
+        saved = a[start].copy()
+        i = start
+        while True:
+            done[i] = True
+            j = int(perm[i])
+            if j == start:
+                a[i] = saved
+                break
+            a[i] = a[j]
+            i = j
 
 
 def chunks(l, n):

@@ -31,6 +31,15 @@ def main():
     x = nets.synthetic_crops(np.random.RandomState(5), n, 32, 32, np.float32)
     net.setDeterministic()
     dp = parallel.DataParallel(rt) if world > 1 else None
+    if os.environ.get('DPP_WORKER_DIVERGE') == '1':
+        # what per-GPU BatchNorm statistics leave behind after a data-parallel training run: every rank's running mean / inv_std
+        # followed its own shards (the trained parameters are replicated).  The single process plays rank 0.
+        net.computeOutput(x[:1], dp=False)                # compiles the net: the parameters move into the device store
+        prng = np.random.RandomState(100 + rank)
+        for l in net.layers:
+            for p_ in l.params_nontrained:
+                v = p_.get_value()
+                p_.set_value((v + prng.normal(0, 0.05, v.shape) * (1.0 if 'mean' in p_.name else 0.2)).astype(np.float32))
     res = dict(out=net.computeOutput(x, dp=dp))
     if dp is not None:
         net.dp = dp                                   # what a data-parallel trainer attaches: the plain call shards as well

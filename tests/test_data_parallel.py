@@ -252,7 +252,7 @@ def _run_output_ranks(tmp_path, world, **extra_env):
     for p in procs:
         log = p.communicate(timeout=900)[0].decode()
         assert p.returncode == 0, log[-3000:]
-    return [np.load(o) for o in outs]
+    return [dict(np.load(o)) for o in outs]          # (read now: a later run with the same world size reuses the file names)
 
 
 def _check_sharded_outputs(ranks, single):
@@ -268,6 +268,16 @@ def test_compute_output_shards_batches_over_two_ranks(tmp_path):
     single-device loop): 11 samples at batch 4 = 3 batches, rank 0 evaluates batches 0 and 2, rank 1 batch 1 (the last one padded by
     repeating the last sample); 2 gloo ranks on the emulator against one process."""
     _check_sharded_outputs(_run_output_ranks(tmp_path, 2), _run_output_ranks(tmp_path, 1)[0])
+
+
+def test_compute_output_uses_rank0_running_statistics_after_local_bn_training(tmp_path):
+    """with per-GPU BatchNorm statistics the ranks' running mean / inv_std diverge during training; the sharded
+    computeOutput must still be ONE model -- rank 0's, whose checkpoint is the one written -- on every rank and for every batch."""
+    two = _run_output_ranks(tmp_path, 2, DPP_WORKER_DIVERGE='1')
+    one = _run_output_ranks(tmp_path, 1, DPP_WORKER_DIVERGE='1')[0]
+    plain = _run_output_ranks(tmp_path, 1)[0]
+    assert not np.array_equal(one['out'], plain['out'])           # the perturbed statistics matter
+    _check_sharded_outputs(two, one)
 
 
 @pytest.mark.gpu

@@ -559,6 +559,13 @@ def test_device_weight_snapshot_and_bulk_checkpoint_values(backend, tmp_path):
     snap2 = net.deviceWeightSnapshot(snap)                          # reuses the buffers of the earlier snapshot
     assert snap2[1][0].ptr == snap[1][0].ptr
     eng.train_step(x, y, 1e-2)
+    final_nt = [[p.get_value() for p in l.params_nontrained] for l in net.layers]
     net.restoreDeviceWeightSnapshot(snap2)
-    after = [[p.get_value() for p in l.params + l.params_nontrained] for l in net.layers]
-    assert all(np.array_equal(a, b) for va, vb in zip(moved, after) for a, b in zip(va, vb))
+    # the reference's early stopping restores `weightVals` = the TRAINED parameters (nettrainer.py:871-876, 893-895); the BatchNorm
+    # running statistics keep their final values -- on the device path exactly as on the host path
+    after = [[p.get_value() for p in l.params] for l in net.layers]
+    want = [vals[:len(l.params)] for l, vals in zip(net.layers, moved)]
+    assert all(np.array_equal(a, b) for va, vb in zip(want, after) for a, b in zip(va, vb))
+    after_nt = [[p.get_value() for p in l.params_nontrained] for l in net.layers]
+    assert all(np.array_equal(a, b) for va, vb in zip(final_nt, after_nt) for a, b in zip(va, vb))
+    assert any(not np.array_equal(a, b) for l, va, vb in zip(net.layers, moved, after_nt) for a, b in zip(va[len(l.params):], vb))
