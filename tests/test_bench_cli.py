@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,6 +32,41 @@ def test_gpus_2_spawns_two_ranks_and_reports_them():
     assert res['n_gpus'] == 2 and res['config']['parallelism'] == 'dp2' and res['config']['global_batch'] == 8
     assert res['scaling'] == 'weak' and res['unit'] == 'depth-crops/sec' and res['value'] > 0
     assert res['config']['final_cost'] == res['config']['final_cost'] and res['config']['final_cost'] > 0      # finite
+    d = res['config']['dist']                     # who took part, gathered from all ranks
+    assert d['backend'] == 'gloo' and d['world'] == 2 and len(d['devices']) == 2 and len(d['per_rank_ms_per_step']) == 2
+    assert all(v > 0 for v in d['per_rank_ms_per_step']) and max(d['per_rank_ms_per_step']) <= res['ms_per_step'] * 1.001
+
+
+@pytest.mark.gpu
+def test_gpus_2_with_gloo_ranks_sharing_the_one_mi355x():
+    """the multi-rank bench path on the real kernels.  Two gloo ranks (DPP_DIST_BACKEND=gloo: collectives on host
+    copies) share the one MI355X of the test box, each with its own 128-crop shard: n_gpus = 2, global batch 256, a finite cost, both
+    ranks' devices and clocks in config.dist.  (RCCL itself needs a second GPU; what it must then show -- one distinct device per
+    rank -- is asserted by bench.py.)"""
+    rc, out, err = _bench(['--gpus', '2', '--steps', '5', '--warmup', '2', '--no-cpu-baseline'], env=dict(DPP_DIST_BACKEND='gloo'), timeout=900)
+    assert rc == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['global_batch'] == 256 and res['config']['parallelism'] == 'dp2'
+    assert np.isfinite(res['config']['final_cost']) and res['config']['final_cost'] > 0 and res['value'] > 0
+    d = res['config']['dist']
+    assert d['backend'] == 'gloo' and d['world'] == 2 and len(d['devices']) == 2 and len(d['per_rank_ms_per_step']) == 2
+
+
+@pytest.mark.gpu
+def test_one_gpu_line_carries_the_forward_only_and_no_augment_legs():
+    """"crops/s (fwd only; fwd+bwd+ADAM; with/without augmentation)" in ONE line, plus the device's own clock and
+    the participating device."""
+    rc, out, err = _bench(['--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--no-trainer'], timeout=600)
+    assert rc == 0, err[-3000:]
+    res = json.loads([l for l in out.splitlines() if l.startswith('{')][0])
+    fo, na = res['forward_only'], res['no_augment']
+    assert fo['finite'] and fo['value'] > res['value'] and fo['launches'] > 0 and fo['batch'] == 128
+    assert na['value'] > 0.8 * res['value']
+    assert 0.5 * res['ms_per_step'] < res['config']['hip_event_ms_per_step'] <= res['ms_per_step'] * 1.05
+    d = res['config']['dist']
+    assert d['world'] == 1 and len(d['devices']) == 1 and d['devices'][0].startswith('cuda:0')
 
 
 def test_world_size_mismatch_is_an_error():
