@@ -117,6 +117,50 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
     // memory latency, so a saved round trip is a fifth of its run time (tools/gemm_micro.py floor).
     const bool one_sweep = nseg == 1 && nbs <= GT * U;
     float pm0[U], pq0[U];
+    if (one_sweep) {
+        // Round 5: ONE pass.  With the block means taken about a pivot K (block 0's mean, a broadcast load in the same round trip),
+        //     mean = K + S1 / M,  M2 = S2 - S1^2 / M,   S1 = sum_b n_b d_b,  S2 = sum_b [M2_b + n_b d_b^2],  d_b = mean_b - K
+        // the two sums are INDEPENDENT: their cross-lane butterflies interleave instead of the second one (deviations from the final
+        // mean) waiting for the first -- the forward finalize took 4.1-4.9 us against the backward finalize's 3.0-3.5 us for the same
+        // volume (profiles/r04_instruction_mix.txt), and this dependent reduction was the difference.  The subtraction cancels only
+        // the spread of the BLOCK means about K (not |mean| >> std), in f64: what is lost is ~1e-16 (spread / std)^2.
+        const float* pm_row = partial + dpp_partial_index(0, cc, 0, C, nbs);
+        const float* pq_row = partial + dpp_partial_index(1, cc, 0, C, nbs);
+        const float K = pm_row[0];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = lane + u * GT;
+            const int bb = b < nbs ? b : nbs - 1;
+            pm0[u] = pm_row[bb];
+            pq0[u] = pq_row[bb];
+        }
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = lane + u * GT;
+            if (b < nbs) {
+                const double d = (double)pm0[u] - (double)K, nb_ = (double)rows_of(b);
+                s1 += nb_ * d;
+                s2 += (double)pq0[u] + nb_ * d * d;
+            }
+        }
+        s1 = group_allsum<WPC>(s1, slot_a);
+        s2 = group_allsum<WPC>(s2, slot_b);
+        if (lane != 0 || c >= C) return;
+        const double mean1 = (double)K + s1 / (double)M;
+        const double var1 = (s2 - s1 * s1 / (double)M) / (double)M;       // biased, T.var
+        const float meanf = (float)mean1;
+        const float inv_std = (float)(1.0 / sqrt((var1 > 0.0 ? var1 : 0.0) + (double)eps));
+        mean_o[c] = meanf;
+        inv_std_o[c] = inv_std;
+        scale_o[c] = gam * inv_std;
+        if (upd) {
+            const float oma = 1.0f - alpha;                 // (1. - alpha) in floatX, batchnormlayer.py:165-172
+            run_mean[c] = oma * rm_old + alpha * meanf;
+            run_inv_std[c] = oma * ri_old + alpha * inv_std;
+        }
+        return;
+    }
     double snm = 0.0;
     for (int seg = 0; seg < nseg; ++seg) {
         const float* pm_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
@@ -197,6 +241,22 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_eval_coeffs_kernel(const float
     mean_o[c] = run_mean[c];
     inv_std_o[c] = run_inv_std[c];
     scale_o[c] = gamma[c] * run_inv_std[c];
+}
+
+// the same for every BatchNorm of a net in one launch: job j covers blocks [block0_j, block0_{j+1})
+struct BnEvalJob { const float* gamma; const float* run_mean; const float* run_inv_std; float* mean; float* inv_std; float* scale; int C, block0; };
+__global__ __launch_bounds__(DPP_THREADS) void bn_eval_coeffs_multi_kernel(const BnEvalJob* __restrict__ jobs, int njobs) {
+    int lo = 0, hi = njobs - 1;                       // the last job whose block0 <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int)blockIdx.x >= jobs[mid].block0) lo = mid; else hi = mid - 1;
+    }
+    const BnEvalJob jb = jobs[lo];
+    const int c = ((int)blockIdx.x - jb.block0) * DPP_THREADS + threadIdx.x;
+    if (c >= jb.C) return;
+    jb.mean[c] = jb.run_mean[c];
+    jb.inv_std[c] = jb.run_inv_std[c];
+    jb.scale[c] = jb.gamma[c] * jb.run_inv_std[c];
 }
 
 // G = dA * [bn(x) >= 0]  (Theano's Maximum.grad passes the gradient where out == x, i.e. v >= 0) and the
@@ -505,6 +565,15 @@ extern "C" int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, con
     if (!gamma || !run_mean || !run_inv_std || !mean || !inv_std || !scale || C < 1) return DPP_E_BADARG;
     DPP_LAUNCH(bn_eval_coeffs_kernel, dim3(dpp_cdiv(C, DPP_THREADS)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
                        gamma, run_mean, run_inv_std, C, mean, inv_std, scale);
+    return dpp_launch_status();
+}
+
+extern "C" size_t dpp_bn_eval_job_bytes(void) { return sizeof(BnEvalJob); }
+
+extern "C" int dpp_bn_eval_coeffs_multi(const void* jobs, int njobs, int total_blocks, dpp_stream_t stream) {
+    if (!jobs || njobs < 1 || total_blocks < 1) return DPP_E_BADARG;
+    DPP_LAUNCH(bn_eval_coeffs_multi_kernel, dim3(total_blocks), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream),
+               static_cast<const BnEvalJob*>(jobs), njobs);
     return dpp_launch_status();
 }
 

@@ -18,7 +18,7 @@ from ctypes import c_int as C_int
 
 import numpy as np
 
-from . import layout, ops
+from . import evalfuse, layout, ops
 from .lib import Act, RowMap
 from .ops import Plan
 from .runtime import default_runtime
@@ -359,6 +359,10 @@ def gemm_plan(M, N, K, allow_split=True):
     return (bm, bn, wm), splitk
 
 
+# Deterministic-mode engines (computeOutput, validation, the cascade's refinement net): a whole bottleneck block as ONE launch
+# (hipdp/evalfuse.py, csrc/resblock.hip) and the stored-statistics coefficients of all remaining BatchNorms in one launch.
+# DPP_EVAL_FUSE=0: the layer-by-layer decomposition of rounds 1-4 (131 launches per forward pass of the 128x128 ResNet).
+EVAL_FUSE = knob('DPP_EVAL_FUSE', '1') != '0'
 OVERLAP_ALLREDUCE = knob('DPP_OVERLAP_ALLREDUCE', '1') != '0'
 EARLY_BUCKET_MIN = int(knob('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elements; FC1 of the 128x128 ResNet has 16.8 M
 # 1x1 convolutions can read the BatchNorm gradient as (G, x) instead of a materialised dX (see _resolve_view).
@@ -572,8 +576,11 @@ def wgrad_stream_rows(M):
 
 
 class CompiledNet(object):
-    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None, fuse_bn=True, bf16=None, optimizer=None):
+    def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None, fuse_bn=True, bf16=None, optimizer=None,
+                 fuse_blocks=None):
         """
+        :param fuse_blocks: deterministic engines only: lower every recognised bottleneck block to one dpp_resblock_eval launch
+                      (default: on; False keeps one tensor per layer, which the per-layer tests read)
         :param bf16:  True -> the 3x3 convolutions (forward, data gradient) and the HiddenLayer behind the last conv map (FC1:
                       forward, data and weight gradient) round their operands to bf16 and accumulate in f32 on the bf16 matrix
                       pipe (BASELINE config 5).  Opt-in (default: DPP_BF16=1 in the environment): the f32 path is the one that
@@ -630,9 +637,15 @@ class CompiledNet(object):
             self.input_of[id(v)] = t
         self.x_in, self.in_shape = self.x_ins[0], self.x_ins[0].shape
         self._memo = {}
+        self.fuse_blocks = (EVAL_FUSE if fuse_blocks is None else bool(fuse_blocks)) and not train
+        self.fused_blocks = []         # the blocks that became one launch (evalfuse.match_block dicts)
+        self._bn_eval_jobs = []        # deterministic mode: (gamma, run_mean, run_inv_std, C, mean, inv_std, scale) of every BatchNorm
         self._beside = []           # (fork / join markers, launches) of the shortcuts moved beside the chain (see _emit_add)
         self._bwd_after = {}        # id(layer p) -> layer q: p's backward is emitted right after q's (see _emit_add)
         out_view = self._emit(net.output)
+        if self._bn_eval_jobs:
+            # one launch at the head of the pass instead of one per BatchNorm (61 of the 131 launches of the 128x128 ResNet's forward)
+            self.fwd.ops[0:0] = [(ops.bn_eval_coeffs_multi(rt, self._bn_eval_jobs), False)]
         self.out = self._materialize_plain(out_view)
         self.out_dim = int(np.prod(self.out.shape[1:]))
         self.loss_cfg = loss
@@ -855,6 +868,10 @@ class CompiledNet(object):
 
     def _emit_add(self, var):
         a, b = var.inputs
+        if self.fuse_blocks:
+            fused = evalfuse.emit_block(self, var)
+            if fused is not None:
+                return fused
 
         def fusable(x):
             return x.kind == 'layer' and _layer_kind(x.layer) in ('ConvLayer',) and self._single_consumer(x) \
@@ -940,6 +957,8 @@ class CompiledNet(object):
                     part = allp
                 self.fwd.add(ops.bn_finalize(rt, part, b.nb, M * W, b.rpb, C, b.gamma_buf, layer.cfgParams.epsilon, b.mean, b.inv_std,
                                              b.scale, b.run_mean, b.run_inv_std, layer.cfgParams.alpha, nseg=W))
+            elif EVAL_FUSE:
+                self._bn_eval_jobs.append((b.gamma_buf, b.run_mean, b.run_inv_std, C, b.mean, b.inv_std, b.scale))
             else:
                 self.fwd.add(ops.bn_eval_coeffs(rt, b.gamma_buf, b.run_mean, b.run_inv_std, C, b.mean, b.inv_std, b.scale))
             v = View(src.base, b, False, shape=src.shape, chan=src.chan)

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'lib', 'libdpp_hip.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 ST_A, ST_B, ST_C, ST_BNX = 1, 2, 4, 8      # DPP_ST_*: which pointers of a call address bf16-stored activation tensors
 c_float_p = C.c_void_p      # device pointers travel as integers
 stream_t = C.c_void_p
@@ -56,6 +56,18 @@ class GemmDesc(C.Structure):
                 ('bm', C.c_int), ('bn', C.c_int), ('wm', C.c_int), ('variant', C.c_int), ('epi', Epilogue), ('store', C.c_int), ('precision', C.c_int)]
 
 
+class BnEval(C.Structure):
+    _fields_ = [('mean', C.c_void_p), ('inv_std', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p)]
+
+
+class ResblockDesc(C.Structure):
+    _fields_ = [('X', C.c_void_p), ('N', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int),
+                ('stride', C.c_int), ('Ho', C.c_int), ('Wo', C.c_int), ('Cout', C.c_int), ('Nb', C.c_int),
+                ('bn0', BnEval), ('bn1', BnEval), ('bn2', BnEval),
+                ('W1', C.c_void_p), ('b1', C.c_void_p), ('W2', C.c_void_p), ('b2', C.c_void_p), ('W3', C.c_void_p), ('b3', C.c_void_p),
+                ('Wsc', C.c_void_p), ('bsc', C.c_void_p), ('Y', C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/dpp_hip.h declares must be listed here
 SIGNATURES = {
     'dpp_abi_version': (C.c_int, []),
@@ -92,6 +104,10 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, stream_t]),
     'dpp_bn_eval_coeffs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      stream_t]),
+    'dpp_bn_eval_job_bytes': (C.c_size_t, []),
+    'dpp_bn_eval_coeffs_multi': (C.c_int, [C.c_void_p, C.c_int, C.c_int, stream_t]),
+    'dpp_resblock_eval_ok': (C.c_int, [C.c_int] * 5),
+    'dpp_resblock_eval': (C.c_int, [C.POINTER(ResblockDesc), stream_t]),
     'dpp_bn_bwd_reduce': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_bn_bwd_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

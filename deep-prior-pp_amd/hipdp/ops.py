@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from .lib import ST_A, ST_B, ST_BNX, ST_C, Act, DppError, Epilogue, GemmDesc, RowMap, check
+from .lib import ST_A, ST_B, ST_BNX, ST_C, Act, BnEval, DppError, Epilogue, GemmDesc, ResblockDesc, RowMap, check
 
 
 class Launch(object):
@@ -445,6 +445,43 @@ def bn_finalize(rt, partial, nb, M, rpb, Cc, gamma, eps, mean, inv_std, scale, r
 def bn_eval_coeffs(rt, gamma, run_mean, run_inv_std, Cc, mean, inv_std, scale, name='bn_eval_coeffs'):
     return Launch(rt.lib.dpp_bn_eval_coeffs, (gamma.ptr, run_mean.ptr, run_inv_std.ptr, Cc, mean.ptr, inv_std.ptr, scale.ptr),
                   (gamma, run_mean, run_inv_std, mean, inv_std, scale), name)
+
+
+def bn_eval_coeffs_multi(rt, jobs, name='bn_eval_coeffs'):
+    """jobs: [(gamma, run_mean, run_inv_std, C, mean, inv_std, scale)] -- dpp_bn_eval_coeffs for every BatchNorm of a net in ONE launch."""
+    import struct
+    assert rt.lib.dpp_bn_eval_job_bytes() == 56
+    raw, block0 = b'', 0
+    for (gamma, rm, ris, Cc, mean, inv_std, scale) in jobs:
+        raw += struct.pack('<QQQQQQii', gamma.ptr, rm.ptr, ris.ptr, mean.ptr, inv_std.ptr, scale.ptr, int(Cc), block0)
+        block0 += -(-int(Cc) // 256)
+    table = rt.upload(np.frombuffer(raw, np.uint8).copy())
+    return Launch(rt.lib.dpp_bn_eval_coeffs_multi, (table.ptr, len(jobs), block0), (table, list(jobs)), name,
+                  dict(kernel='bn_eval_coeffs', flops=0.0, bytes=24.0 * sum(int(j[3]) for j in jobs)))
+
+
+def bn_eval(mean, inv_std, gamma, beta):
+    """dpp_bn_eval: a BatchNorm in deterministic mode as the fused block kernel reads it (stored statistics + affine parameters)."""
+    b = BnEval(mean.ptr, inv_std.ptr, gamma.ptr, beta.ptr)
+    b._keep = (mean, inv_std, gamma, beta)
+    return b
+
+
+def resblock_eval(rt, X, N, H, W, Cin, stride, Cout, Nb, bn0, bn1, bn2, W1, b1, W2, b2, W3, b3, Y, Wsc=None, bsc=None, name='resblock_eval'):
+    """dpp_resblock_eval: one pre-activation bottleneck block of the deterministic forward pass in one launch (csrc/resblock.hip)."""
+    _f32_only('dpp_resblock_eval', X, Y)
+    d = ResblockDesc()
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    d.X, d.N, d.H, d.W, d.Cin = X.ptr, int(N), int(H), int(W), int(Cin)
+    d.stride, d.Ho, d.Wo, d.Cout, d.Nb = int(stride), Ho, Wo, int(Cout), int(Nb)
+    d.bn0, d.bn1, d.bn2 = bn0, bn1, bn2
+    d.W1, d.b1, d.W2, d.b2, d.W3, d.b3 = W1.ptr, b1.ptr, W2.ptr, b2.ptr, W3.ptr, b3.ptr
+    d.Wsc, d.bsc, d.Y = _p(Wsc), _p(bsc), Y.ptr
+    px = float(N) * Ho * Wo
+    flops = 2.0 * px * (Cin * Nb + 9.0 * Nb * Nb + Nb * Cout + (Cin * Cout if Wsc is not None else 0))
+    byts = 4.0 * (float(N) * H * W * Cin + px * Cout + (px * Cout if Wsc is None else 0) + Cin * Nb + 9.0 * Nb * Nb + Nb * Cout)
+    return Launch(rt.lib.dpp_resblock_eval, (C.byref(d),), (d, X, Y, bn0, bn1, bn2, W1, b1, W2, b2, W3, b3, Wsc, bsc), name,
+                  dict(kernel='resblock_eval_mfma_f32', flops=flops, bytes=byts))
 
 
 def bn_bwd_reduce(rt, dA, X, M, Cc, mean, inv_std, scale, beta, relu, G, rpb, partial, name='bn_bwd_reduce'):

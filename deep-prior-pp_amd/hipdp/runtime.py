@@ -131,6 +131,24 @@ class TorchHipRuntime(object):
     def copy(self, dst, src):
         self._tensor(dst).copy_(self._tensor(src))
 
+    def download_async(self, buf, host=None):
+        """Start a device -> page-locked host copy of `buf` on the COPY stream (behind the work queued so far on the current stream, but
+        not in front of what is queued afterwards: the copy engine moves it while later kernels run).  Returns (handle, host tensor);
+        handle.get() waits for that copy only.  `host`: a pinned tensor of a previous call to reuse.  The caller keeps `buf` unchanged
+        until get() returns (checkpoints copy the live parameters into a staging buffer first)."""
+        t = self.torch
+        if getattr(self, '_copy', None) is None:
+            self._copy = t.cuda.Stream(self.device)
+        src = self._tensor(buf)
+        if host is None or host.numel() != src.numel() or host.dtype != src.dtype:
+            host = t.empty(src.shape, dtype=src.dtype, pin_memory=True)
+        self._copy.wait_stream(t.cuda.current_stream(self.device))
+        with t.cuda.stream(self._copy):
+            host.copy_(src, non_blocking=True)
+            ev = t.cuda.Event()
+            ev.record(self._copy)
+        return _AsyncRead(host, ev, buf.shape), host
+
     def pinned_like(self, arr):
         """An uninitialised page-locked host array of arr's shape / dtype (source of asynchronous uploads)."""
         t = self.torch

@@ -556,10 +556,10 @@ class NetTrainer(object):
         while self.epoch < n_epochs:
             writer = self.dp is None or self.dp.rank == 0          # replicas hold the same weights: rank 0 writes the snapshots
             if self.epoch % self.cfgParams.snapshot_last == 0 and writer:
-                self.poseNet.save(self.subfolder + '/net_last.pkl')
+                self._snapshot(self.subfolder + '/net_last.pkl')
             if self.cfgParams.snapshot_freq is not None:
                 if self.epoch % self.cfgParams.snapshot_freq == 0 and writer:
-                    self.poseNet.save(self.subfolder + '/net_{}.pkl'.format(self.epoch))
+                    self._snapshot(self.subfolder + '/net_{}.pkl'.format(self.epoch))
             if self.cfgParams.pre_epoch_fn is not None:
                 getattr(self, self.cfgParams.pre_epoch_fn)()
             self.epoch += 1
@@ -609,6 +609,7 @@ class NetTrainer(object):
             if self.cfgParams.post_epoch_fn is not None:
                 getattr(self, self.cfgParams.post_epoch_fn)()
 
+        getattr(self.poseNet, 'joinSave', lambda: None)()          # the last epoch's snapshot is on disk when train() returns
         end_time = time.time()
         print('Optimization complete with best validation score of %f,' % best_validation_loss)
         print('The code run for %d epochs, with %f epochs/sec' % (self.epoch, self.epoch / max(1e-9, end_time - start_time)))
@@ -625,6 +626,17 @@ class NetTrainer(object):
         if self.cfgParams.augment_fun_params['fun'] is not None or self.cfgParams.load_fun_params['fun'] is not None:
             self.unsetDataLoading()
         return train_costs, wvals, validation_obs[0] if len(validation_obs) == 1 else validation_obs
+
+    def _snapshot(self, path):
+        """The per-epoch checkpoint (nettrainer.py:816-820) without stopping the epoch loop for the pickle: NetBase.saveAsync copies the
+        parameters on the device, moves them to the host on the copy stream and writes the file from a worker thread.  A net whose
+        save() was replaced (an instance attribute) or that has no saveAsync is saved the plain way."""
+        net = self.poseNet
+        fn = getattr(net, 'saveAsync', None)
+        if fn is None or 'save' in vars(net):
+            net.save(path)
+        else:
+            fn(path)
 
     def checkNaNs(self):
         for param_i in self.params:

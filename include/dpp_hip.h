@@ -34,7 +34,7 @@ typedef void* dpp_stream_t; /* a hipStream_t */
 #define DPP_E_BADARG 10001
 #define DPP_E_UNSUPPORTED 10002
 
-#define DPP_ABI_VERSION 9
+#define DPP_ABI_VERSION 10
 int dpp_abi_version(void);
 
 /* bf16 STORAGE of activation tensors (ABI v9; BASELINE config 5 "bf16 MFMA, 256x256 input stress").  The [pixels][channels] tensors the
@@ -285,6 +285,11 @@ int dpp_bn_finalize(const float* partial, int nb, int nseg, int M, int rows_per_
                     dpp_stream_t stream);
 int dpp_bn_eval_coeffs(const float* gamma, const float* run_mean, const float* run_inv_std, int C, float* mean,
                        float* inv_std, float* scale, dpp_stream_t stream);
+/* eval_coeffs for EVERY BatchNorm of a net in ONE launch (ABI v10): the test-time forward pass issued one 4.7 us launch per
+ * BatchNorm -- 61 of its 131 launches.  jobs (device): dpp_bn_eval_job_bytes() bytes each = { const float* gamma, * run_mean, * run_inv_std;
+ * float* mean, * inv_std, * scale; int C; int block0 } with block0 = the first 256-thread block of the job, total_blocks their sum. */
+size_t dpp_bn_eval_job_bytes(void);
+int dpp_bn_eval_coeffs_multi(const void* jobs, int njobs, int total_blocks, dpp_stream_t stream);
 int dpp_bn_bwd_reduce(const float* dA, const float* X, int M, int C, const float* mean, const float* inv_std,
                       const float* scale, const float* beta, int relu, float* G, int rows_per_block, float* partial,
                       int store /* DPP_ST_BNX: X, DPP_ST_A: the incoming gradient (dA / G), DPP_ST_C: the outgoing one (G / dX + add) hold bf16 */, dpp_stream_t stream);
@@ -440,6 +445,34 @@ size_t dpp_pca_workspace_bytes(long N, int D);
 int dpp_pca_fit(const float* X, long N, int D, void* workspace, double* mean, double* evals, double* components, dpp_stream_t stream);
 int dpp_pose_eval(const float* gt, const float* pred, int N, int J, const double* thresholds, int T, double* err, double* frame,
                   double* out, dpp_stream_t stream);
+
+/* ---- a whole bottleneck block of the deterministic forward pass as ONE launch (ABI v10) ----------------------------------------
+ * res_block of /root/reference/src/net/resnet.py:349-414 with every BatchNormLayer in deterministic mode
+ * (/root/reference/src/net/batchnormlayer.py:158-159: stored running mean / inv_std), as netbase.py:257-310 (computeOutput) runs it:
+ *     h = relu(bn0(x));  c1 = conv1x1_s(h) + b1;  c2 = conv3x3(relu(bn1(c1))) + b2;  c3 = conv1x1(relu(bn2(c2))) + b3
+ *     Y = x + c3  (identity block: Wsc == NULL, Cin == Cout, stride 1)     Y = c3 + conv1x1_s(h) + bsc  (projection block)
+ * bn(v) = (v - mean) * (gamma * inv_std) + beta.  X [N][H][W][Cin], Y [N][Ho][Wo][Cout] (Ho = ceil(H / stride)), weights in kernel
+ * layout: W1 [Nb][Cin], W2 [Nb][9][Nb], W3 [Cout][Nb], Wsc [Cout][Cin].  float32 tensors, f32 MFMA.  The 16- / 32- / 64-channel
+ * intermediates stay in LDS (csrc/resblock.hip).  dpp_resblock_eval_ok: 1 when the kernel takes the shape, else the caller issues the
+ * block layer by layer (dpp_gemm / dpp_conv3x3 with dpp_act prologues). */
+typedef struct {
+    const float* mean;
+    const float* inv_std;
+    const float* gamma;
+    const float* beta;
+} dpp_bn_eval;
+typedef struct {
+    const float* X; int N, H, W, Cin;
+    int stride, Ho, Wo, Cout, Nb;
+    dpp_bn_eval bn0, bn1, bn2;
+    const float* W1; const float* b1;
+    const float* W2; const float* b2;
+    const float* W3; const float* b3;
+    const float* Wsc; const float* bsc;
+    float* Y;
+} dpp_resblock_desc;
+int dpp_resblock_eval_ok(int Cin, int Cout, int Nb, int stride, int projection);
+int dpp_resblock_eval(const dpp_resblock_desc* d, dpp_stream_t stream);
 
 /* ---- launch plans: a whole train / inference step as ONE call --------------------------------------------------------
  * The reference runs `train_model(index, lr)` as one compiled device function (theano.function,

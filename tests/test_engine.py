@@ -530,6 +530,30 @@ def test_engines_of_a_rebuilt_parameter_store_refuse_to_run(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+def test_async_checkpoint_writes_the_bytes_save_writes(backend, tmp_path):
+    """NetBase.saveAsync (the epoch loop's snapshot off the training thread): the file is byte for byte what save()
+    writes for the parameters AT THE CALL -- training goes on while the worker thread pickles."""
+    from hipdp import runtime as R
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    net, onet, P = make_net(rt, 0, 4, 32, 1, 30)
+    eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
+    rng = np.random.RandomState(7)
+    x = nets.synthetic_crops(rng, 4, 32, 32, np.float32)
+    y = rng.normal(0, 0.3, (4, 30)).astype(np.float32)
+    eng.train_step(x, y, 1e-2)
+    net.save(str(tmp_path / 'sync.pkl'))
+    net.saveAsync(str(tmp_path / 'async.pkl'))
+    eng.train_step(x, y, 1e-2)                     # the live parameters move on while the snapshot is written
+    net.saveAsync(str(tmp_path / 'async2.pkl'))    # (joins the first one)
+    net.joinSave()
+    a, b, c = (open(str(tmp_path / f), 'rb').read() for f in ('sync.pkl', 'async.pkl', 'async2.pkl'))
+    assert a == b and len(a) > 1000 and c != a
+    net.save(str(tmp_path / 'sync2.pkl'))
+    assert open(str(tmp_path / 'sync2.pkl'), 'rb').read() == c
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_device_weight_snapshot_and_bulk_checkpoint_values(backend, tmp_path):
     """The epoch loop's "best weights so far" stay on the device (NetBase.deviceWeightSnapshot / restoreDeviceWeightSnapshot: two
     device-to-device copies instead of the reference's host copy of every array, nettrainer.py:871-876), and a checkpoint reads the

@@ -1,0 +1,123 @@
+"""The fused deterministic-mode bottleneck block (csrc/resblock.hip, dpp_resblock_eval) against the float64 oracle layers composed
+the way res_block composes them (/root/reference/src/net/resnet.py:349-414 with BatchNorm in deterministic mode,
+/root/reference/src/net/batchnormlayer.py:158-159).  Emulator in the CPU tier, the real kernel through the C ABI with `-m gpu`."""
+import numpy as np
+import pytest
+
+from hipdp import layout, ops
+from oracle import layers as L
+from tests.backends import BACKENDS, get_runtime
+
+
+def _bn_params(rng, C):
+    return dict(mean=rng.normal(size=C) * 0.3, inv_std=rng.uniform(0.5, 2.0, C), gamma=rng.uniform(0.5, 1.5, C), beta=rng.normal(size=C) * 0.3)
+
+
+def _bnrelu(x, p):
+    s = lambda v: v[None, :, None, None]          # noqa: E731
+    return np.maximum((x - s(p['mean'])) * s(p['gamma'] * p['inv_std']) + s(p['beta']), 0)
+
+
+def _block_ref(x, P, stride, proj):
+    h = _bnrelu(x, P['bn0'])
+    c1 = L.conv2d_fwd(h, P['W1'], P['b1'], (stride, stride), 'half')
+    c2 = L.conv2d_fwd(_bnrelu(c1, P['bn1']), P['W2'], P['b2'], (1, 1), 'half')
+    c3 = L.conv2d_fwd(_bnrelu(c2, P['bn2']), P['W3'], P['b3'], (1, 1), 'half')
+    if not proj:
+        return x + c3
+    return c3 + L.conv2d_fwd(h, P['Wsc'], P['bsc'], (stride, stride), 'half')
+
+
+def _run(rt, x, P, stride, proj, Nb, Cout):
+    N, Cin, H, W = x.shape
+    f = lambda a: rt.upload(np.ascontiguousarray(a, np.float32))          # noqa: E731
+    bns = []
+    for k in ('bn0', 'bn1', 'bn2'):
+        bns.append(ops.bn_eval(*(f(P[k][q]) for q in ('mean', 'inv_std', 'gamma', 'beta'))))
+    X = f(layout.nchw_to_nhwc(x))
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    Y = rt.alloc((N, Ho, Wo, Cout), zero=False)
+    kw = {}
+    if proj:
+        kw = dict(Wsc=f(layout.conv_w_to_kernel(P['Wsc'])), bsc=f(P['bsc']))
+    op = ops.resblock_eval(rt, X, N, H, W, Cin, stride, Cout, Nb, bns[0], bns[1], bns[2], f(layout.conv_w_to_kernel(P['W1'])), f(P['b1']),
+                           f(layout.conv_w_to_kernel(P['W2'])), f(P['b2']), f(layout.conv_w_to_kernel(P['W3'])), f(P['b3']), Y, **kw)
+    op(rt.stream)
+    rt.synchronize()
+    return layout.nhwc_to_nchw(Y.get())
+
+
+def _params(rng, Cin, Nb, Cout, proj):
+    P = dict(bn0=_bn_params(rng, Cin), bn1=_bn_params(rng, Nb), bn2=_bn_params(rng, Nb),
+             W1=rng.normal(size=(Nb, Cin, 1, 1)) * (2.0 / Cin) ** 0.5, b1=rng.normal(size=Nb) * 0.1,
+             W2=rng.normal(size=(Nb, Nb, 3, 3)) * (2.0 / (9 * Nb)) ** 0.5, b2=rng.normal(size=Nb) * 0.1,
+             W3=rng.normal(size=(Cout, Nb, 1, 1)) * (2.0 / Nb) ** 0.5, b3=rng.normal(size=Cout) * 0.1)
+    if proj:
+        P['Wsc'] = rng.normal(size=(Cout, Cin, 1, 1)) * (2.0 / Cin) ** 0.5
+        P['bsc'] = rng.normal(size=Cout) * 0.1
+    return P
+
+
+# (N, H, W, Nb): identity blocks of the three stage shapes -- whole tiles, ragged tiles (H, W no multiple of the tile), maps smaller
+# than one tile, several tiles per image in both directions
+IDENTITY = [(2, 8, 16, 16), (1, 19, 21, 16), (3, 4, 4, 16), (2, 8, 8, 32), (1, 11, 13, 32), (2, 2, 2, 32), (3, 8, 8, 64), (1, 9, 10, 64),
+            (2, 2, 2, 64), (1, 16, 16, 64)]
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', IDENTITY, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_identity_block_matches_the_oracle_layers(backend, cfg):
+    rt = get_runtime(backend)
+    N, H, W, Nb = cfg
+    C4 = 4 * Nb
+    assert rt.lib.dpp_resblock_eval_ok(C4, C4, Nb, 1, 0) == 1
+    rng = np.random.RandomState(3 + H * W + Nb)
+    x = rng.normal(size=(N, C4, H, W))
+    P = _params(rng, C4, Nb, C4, False)
+    ref = _block_ref(x, P, 1, False)
+    out = _run(rt, x, P, 1, False, Nb, C4)
+    # three chained f32 products of depth Cin, 9 Nb, Nb: round-off bound relative to the output scale
+    tol = 4e-6 * np.sqrt(C4 + 9 * Nb + Nb) * np.abs(ref).max()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=tol)
+
+
+# (N, H, W, Cin, Nb, stride): the three projection blocks of the ResNet (32 -> 64, 64 -> 128, 128 -> 256, stride 2), odd map sizes (the
+# strided output is ceil(H / 2)), a stride-1 projection
+PROJECTION = [(2, 16, 16, 32, 16, 2), (1, 13, 19, 32, 16, 2), (2, 16, 16, 64, 32, 2), (1, 9, 7, 64, 32, 2), (2, 16, 16, 128, 64, 2),
+              (3, 5, 6, 128, 64, 2), (1, 8, 8, 64, 32, 1)]
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', PROJECTION, ids=lambda c: 'x'.join(str(v) for v in c))
+def test_projection_block_matches_the_oracle_layers(backend, cfg):
+    rt = get_runtime(backend)
+    N, H, W, Cin, Nb, stride = cfg
+    Cout = 4 * Nb
+    assert rt.lib.dpp_resblock_eval_ok(Cin, Cout, Nb, stride, 1) == 1
+    rng = np.random.RandomState(5 + H * W + Nb)
+    x = rng.normal(size=(N, Cin, H, W))
+    P = _params(rng, Cin, Nb, Cout, True)
+    ref = _block_ref(x, P, stride, True)
+    out = _run(rt, x, P, stride, True, Nb, Cout)
+    tol = 4e-6 * np.sqrt(2 * Cin + 9 * Nb + Nb) * np.abs(ref).max()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+def test_a_pixel_does_not_depend_on_its_batch(backend):
+    """Same frame alone and as the last of a batch of 5: bit-identical rows (tile geometry and summation order follow from the layer
+    shape alone -- what lets computeOutput's padded last batch and tests/test_full_size.py's 8-vs-128 comparison hold)."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(77)
+    x = rng.normal(size=(5, 64, 10, 12))
+    P = _params(rng, 64, 16, 64, False)
+    full = _run(rt, x, P, 1, False, 16, 64)
+    one = _run(rt, x[4:5], P, 1, False, 16, 64)
+    assert np.array_equal(full[4:5], one)
+
+
+def test_unsupported_shapes_are_refused():
+    rt = get_runtime('emu')
+    assert rt.lib.dpp_resblock_eval_ok(64, 64, 24, 1, 0) == 0          # bottleneck width
+    assert rt.lib.dpp_resblock_eval_ok(32, 64, 16, 1, 0) == 0          # identity needs Cin == Cout
+    assert rt.lib.dpp_resblock_eval(None, None) == 10001
