@@ -35,9 +35,6 @@ struct RBArgs {
     dpp_resblock_desc d;
     int lth, ltw, tiles_x, tiles_y, ntiles;
     unsigned m_tw2;          // floor(2^32 / (TW+2)) + 1
-    int chunks, KC, lqa;     // phase-A K chunks, channels per chunk, log2(KC / 4)
-    int nbufA;               // LDS buffers of the input halo: 1, 2, or `chunks` (projection: the whole activated halo stays)
-    int r0_floats, wbuf_floats;
     int xcd_chunk;           // ntiles / 8 when the tile -> XCD swizzle applies, else 0
 };
 
@@ -47,35 +44,65 @@ __device__ __forceinline__ void rb_st4(float* p, float4 v) { *reinterpret_cast<f
 // v = relu((x - mean) * (gamma * inv_std) + beta), the arithmetic of dpp_act1 with dpp_bn_eval_coeffs' scale
 __device__ __forceinline__ float rb_bnrelu(float x, float mu, float sc, float be) { return fmaxf((x - mu) * sc + be, 0.0f); }
 
-// NB: bottleneck width (16 / 32 / 64); BM = TH * TW output pixels per workgroup; RT1: 16-row tiles of the halo per wave (halo padded to
-// RT1 * 64 rows); PROJ: projection block (strided input, shortcut convolution) instead of the identity block.
+template <int RT, int CT>
+__device__ __forceinline__ void rb_mfma16(f32x4 (&acc)[RT][CT], const float4 (&av)[RT], const float4 (&bv)[CT]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t), acc[rt][ct], 0, 0, 0);
+}
+
+// NB: bottleneck width (16 / 32 / 64); the block's output has 4 NB channels, its input 4 NB (identity block) or 2 NB (PROJ: the projection
+// blocks that open a stage, strided input + shortcut convolution).  BM = TH * TW output pixels per workgroup; RT1: 16-row tiles of the
+// halo per wave (halo padded to RT1 * 64 rows).
+//
+// Round-5 second version.  The first one streamed the weight slices through two LDS buffers with one barrier per slice (K chunk / tap /
+// column pass): a slice is 0.4-0.9 us of MFMA work per wave but a 1.5-2 us global -> register -> LDS round trip, so the kernel ran at the
+// round-trip rate (30.8 us per stage-3/4 block against 9 us of MFMA time; profiles/r05_forward_kernels_fused_v1.txt).  Now
+//   * the whole activated input halo goes to LDS in ONE round trip (all loads of the workgroup in flight at once), one barrier;
+//   * weights never touch LDS: every wave loads its B fragments straight from global memory / L2 in MFMA fragment order (the kernel
+//     layouts [out][k] are K-contiguous: lane (l15 = column, kq) reads 16 bytes of row `column` at k = 16 step + 4 kq) through a register
+//     ring several k-steps deep, requested before the barrier that precedes their phase -- no barrier inside a phase;
+//   * the output image of a column pass is private to the wave (wave-level ordering only).
+// Three workgroup barriers per block: input halo, A1, A2.
 template <int NB, int BM, int RT1, bool PROJ>
 __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     dpp_kernarg_warm<sizeof(RBArgs)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);
+    constexpr int CIN = PROJ ? 2 * NB : 4 * NB, COUT = 4 * NB;
     constexpr int CT1 = NB / 16;                     // column tiles of the bottleneck width
     constexpr int HPP = RT1 * 64;                    // padded halo rows
-    constexpr int LD1 = NB + 4;                      // row stride of A1 / A2 and of the W2 / W3 slices
+    constexpr int LDA = CIN + 4;                     // row stride of the activated input halo
+    constexpr int LD1 = NB + 4;                      // row stride of A1 / A2
     constexpr int RTB = BM / 16;                     // row tiles of the output tile
     constexpr int WM2 = RTB < 4 ? RTB : 4, RM2 = RTB / WM2, WN2 = 4 / WM2;
     constexpr int CN2 = CT1 / WN2;                   // phase B: column tiles per wave
     constexpr int CN3 = 4 / WN2;                     // phase C: column tiles per wave of a 64-column pass
-    constexpr int ASLOTS = HPP / 16;                 // halo float4 slots per thread and chunk (KC = 64; fewer rows per sweep for KC = 32)
-    constexpr int WSLOTS = CT1;                      // weight-slice float4 slots per thread
-    constexpr int LDI = 64 + 4;                      // row stride of the output image of a pass
-    static_assert(CN2 >= 1 && RM2 >= 1, "tile shape");
+    constexpr int QR = CIN / 4;                      // channel quads per halo row
+    constexpr int RS = DPP_THREADS / QR;             // halo rows per staging sweep
+    constexpr int ASLOTS = HPP / RS;                 // halo float4 slots per thread
+    constexpr int KSA = CIN / 16, RDA = KSA < 8 ? KSA : 8;             // phase A: k-steps, B-fragment ring depth
+    constexpr int KSB = 9 * (NB / 16), RDB = KSB < 8 ? KSB : 8;        // phase B
+    constexpr int KSC = NB / 16;                                       // phase C: k-steps of a pass
+    constexpr int NPASS = COUT / 64;
+    constexpr int WROWS = RM2 * 16, WCOLS = CN3 * 16, LDI = WCOLS + 4; // a wave's share of a pass and its private image
+    constexpr int QW = WCOLS / 4, RSW = 64 / QW, SWEEPS = WROWS / RSW; // the wave's 16-byte store sweep
+    static_assert(CN2 >= 1 && RM2 >= 1 && HPP % RS == 0 && WROWS % RSW == 0, "tile shape");
     const dpp_resblock_desc& d = a.d;
     const int TH = 1 << a.lth, TW = 1 << a.ltw, TW2 = TW + 2, HP = (TH + 2) * TW2;
-    const int KC = a.KC, LDA = KC + 4, Cin = d.Cin, Cout = d.Cout, S = d.stride;
+    const int S = d.stride;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const int wm = wave % WM2, wn = wave / WM2;
 
-    float* R0 = smem;                                 // input-halo buffers; later A1 [HPP][LD1] + the output image [BM][LDI]
-    float* Wb = smem + a.r0_floats;                   // two weight-slice buffers
-    float* A2 = Wb + 2 * a.wbuf_floats;               // [BM][LD1]
-    float* A1 = PROJ ? A2 + BM * LD1 : R0;            // (projection: the activated halo stays alive for the shortcut)
-    float* IMG = PROJ ? A1 + HPP * LD1 : R0 + HPP * LD1;
+    // LDS: A0 [HPP][LDA] | A2 [BM][LD1] | (PROJ: A1 [HPP][LD1] | images) ; identity: A1 and the images alias A0 (dead after phase A)
+    float* A0 = smem;
+    float* A2 = A0 + HPP * LDA;
+    float* A1 = PROJ ? A2 + BM * LD1 : A0;
+    float* IMG = (PROJ ? A1 + HPP * LD1 : A0 + HPP * LD1) + wave * (WROWS * LDI);
 
     int bid = blockIdx.x;
     if (a.xcd_chunk) bid = (bid & 7) * a.xcd_chunk + (bid >> 3);      // neighbouring tiles (shared halo rows) on one XCD's L2
@@ -84,123 +111,54 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     const int by = tq % a.tiles_y, n = tq / a.tiles_y;
     const int y0 = by << a.lth, x0 = bx << a.ltw;
     const int Ho = d.Ho, Wo = d.Wo;
-    const float* Xn = d.X + (size_t)n * d.H * d.W * Cin;
+    const float* Xn = d.X + (size_t)n * d.H * d.W * CIN;
 
-    // ---- per-lane column constants of the three epilogues (requested now, used after the first products) ----
+    // ---- phase A's first B fragments: requested before anything else ----
+    const float* w1p[CT1];
+#pragma unroll
+    for (int ct = 0; ct < CT1; ++ct) w1p[ct] = d.W1 + (size_t)(ct * 16 + l15) * CIN + kq * 4;
+    float4 bA[RDA][CT1];
+#pragma unroll
+    for (int s = 0; s < RDA; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CT1; ++ct) bA[s][ct] = rb_ld4(w1p[ct] + s * 16);
+
+    // ---- the activated input halo: slot u of a thread is halo position hp = tid / QR + u * RS, channel quad qa ----
+    {
+        const int qa = (tid % QR) * 4;
+        const float4 mu = rb_ld4(d.bn0.mean + qa), g0 = rb_ld4(d.bn0.gamma + qa), i0 = rb_ld4(d.bn0.inv_std + qa), be = rb_ld4(d.bn0.beta + qa);
+        float4 areg[ASLOTS];
+        bool ain[ASLOTS];
+#pragma unroll
+        for (int u = 0; u < ASLOTS; ++u) {
+            const int hp = tid / QR + u * RS;
+            const int hy = (int)__umulhi((unsigned)hp, a.m_tw2), hx = hp - hy * TW2;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            ain[u] = hp < HP && y >= 0 && y < Ho && x >= 0 && x < Wo;
+            areg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ain[u]) areg[u] = rb_ld4(Xn + ((size_t)(y * S) * d.W + x * S) * CIN + qa);
+        }
+        const float4 sc = make_float4(g0.x * i0.x, g0.y * i0.y, g0.z * i0.z, g0.w * i0.w);
+#pragma unroll
+        for (int u = 0; u < ASLOTS; ++u) {
+            const int hp = tid / QR + u * RS;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);              // zero padding is applied AFTER the activation
+            if (ain[u]) {
+                const float4 v = areg[u];
+                t = make_float4(rb_bnrelu(v.x, mu.x, sc.x, be.x), rb_bnrelu(v.y, mu.y, sc.y, be.y),
+                                rb_bnrelu(v.z, mu.z, sc.z, be.z), rb_bnrelu(v.w, mu.w, sc.w, be.w));
+            }
+            rb_st4(&A0[hp * LDA + qa], t);
+        }
+    }
+    // per-lane column constants of the first epilogue
     float e1b[CT1], e1m[CT1], e1s[CT1], e1t[CT1];
 #pragma unroll
     for (int ct = 0; ct < CT1; ++ct) {
         const int c = ct * 16 + l15;
         e1b[ct] = d.b1[c]; e1m[ct] = d.bn1.mean[c]; e1s[ct] = d.bn1.gamma[c] * d.bn1.inv_std[c]; e1t[ct] = d.bn1.beta[c];
     }
-    float e2b[CN2], e2m[CN2], e2s[CN2], e2t[CN2];
-#pragma unroll
-    for (int ct = 0; ct < CN2; ++ct) {
-        const int c = (wn * CN2 + ct) * 16 + l15;
-        e2b[ct] = d.b2[c]; e2m[ct] = d.bn2.mean[c]; e2s[ct] = d.bn2.gamma[c] * d.bn2.inv_std[c]; e2t[ct] = d.bn2.beta[c];
-    }
-
-    // ---- halo geometry of this thread's staging slots: slot u is halo position hp = (tid >> lqa) + u * hstep ----
-    const int qa = (tid & ((1 << a.lqa) - 1)) * 4;     // channel quad inside a chunk
-    const int hstep = DPP_THREADS >> a.lqa;
-    const int nslots = HPP / hstep;                     // <= ASLOTS (KC = 64), 2x fewer rows per sweep would exceed it: host keeps KC >= 32 with HPP * KC <= ASLOTS * 1024
-    int xoff[ASLOTS];                                   // element offset of the halo pixel in this image, -1 outside
-#pragma unroll
-    for (int u = 0; u < ASLOTS; ++u) {
-        xoff[u] = -1;
-        if (u < nslots) {
-            const int hp = (tid >> a.lqa) + u * hstep;
-            const int hy = (int)__umulhi((unsigned)hp, a.m_tw2), hx = hp - hy * TW2;
-            const int y = y0 + hy - 1, x = x0 + hx - 1;
-            if (hp < HP && y >= 0 && y < Ho && x >= 0 && x < Wo) xoff[u] = ((y * S) * d.W + x * S) * Cin;
-        }
-    }
-    float4 areg[ASLOTS];
-    float4 amu, asc, abe;
-    auto fetchA = [&](int chunk) {
-        const int c0 = chunk * KC + qa;
-        amu = rb_ld4(d.bn0.mean + c0);
-        const float4 g = rb_ld4(d.bn0.gamma + c0), is = rb_ld4(d.bn0.inv_std + c0);
-        asc = make_float4(g.x * is.x, g.y * is.y, g.z * is.z, g.w * is.w);
-        abe = rb_ld4(d.bn0.beta + c0);
-#pragma unroll
-        for (int u = 0; u < ASLOTS; ++u) {
-            areg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < nslots && xoff[u] >= 0) areg[u] = rb_ld4(Xn + xoff[u] + c0);
-        }
-    };
-    auto commitA = [&](float* buf) {
-#pragma unroll
-        for (int u = 0; u < ASLOTS; ++u) {
-            if (u < nslots) {
-                const int hp = (tid >> a.lqa) + u * hstep;
-                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);          // zero padding is applied AFTER the activation
-                if (xoff[u] >= 0) {
-                    const float4 v = areg[u];
-                    t = make_float4(rb_bnrelu(v.x, amu.x, asc.x, abe.x), rb_bnrelu(v.y, amu.y, asc.y, abe.y),
-                                    rb_bnrelu(v.z, amu.z, asc.z, abe.z), rb_bnrelu(v.w, amu.w, asc.w, abe.w));
-                }
-                rb_st4(&buf[hp * LDA + qa], t);
-            }
-        }
-    };
-
-    // ---- the weight-slice stream ----
-    float4 wreg[WSLOTS];
-    auto fetchW1 = [&](int chunk) {                     // [NB][KC] of W1 [NB][Cin]
-#pragma unroll
-        for (int s = 0; s < WSLOTS; ++s) {
-            const int slot = tid + s * DPP_THREADS, j = slot >> a.lqa;
-            wreg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < NB) wreg[s] = rb_ld4(d.W1 + (size_t)j * Cin + chunk * KC + qa);
-        }
-    };
-    auto commitW1 = [&](float* buf) {
-#pragma unroll
-        for (int s = 0; s < WSLOTS; ++s) {
-            const int slot = tid + s * DPP_THREADS, j = slot >> a.lqa;
-            if (j < NB) rb_st4(&buf[j * LDA + qa], wreg[s]);
-        }
-    };
-    constexpr int Q2 = NB / 4;                          // quads per row of the NB-deep slices
-    auto fetchW2 = [&](int tap) {                       // [NB][NB] of W2 [NB][9][NB]
-#pragma unroll
-        for (int s = 0; s < WSLOTS; ++s) {
-            const int slot = tid + s * DPP_THREADS, j = slot / Q2, c0 = (slot % Q2) * 4;
-            wreg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < NB) wreg[s] = rb_ld4(d.W2 + ((size_t)j * 9 + tap) * NB + c0);
-        }
-    };
-    auto fetchW3 = [&](int pass) {                      // [64][NB] of W3 [Cout][NB]
-#pragma unroll
-        for (int s = 0; s < WSLOTS; ++s) {
-            const int slot = tid + s * DPP_THREADS, j = slot / Q2, c0 = (slot % Q2) * 4;
-            wreg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < 64) wreg[s] = rb_ld4(d.W3 + ((size_t)pass * 64 + j) * NB + c0);
-        }
-    };
-    auto commitWn = [&](float* buf, int rows) {         // NB-deep slices (W2 taps: rows = NB, W3 passes: rows = 64)
-#pragma unroll
-        for (int s = 0; s < WSLOTS; ++s) {
-            const int slot = tid + s * DPP_THREADS, j = slot / Q2, c0 = (slot % Q2) * 4;
-            if (j < rows) rb_st4(&buf[j * LD1 + c0], wreg[s]);
-        }
-    };
-    auto fetchWsc = [&](int pass, int chunk) {          // projection shortcut: [64][KC] of Wsc [Cout][Cin]
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {                   // (64 rows x KC / 4 quads: up to 4 slots; uses the halo registers, free by then)
-            const int slot = tid + s * DPP_THREADS, j = slot >> a.lqa;
-            areg[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < 64) areg[s] = rb_ld4(d.Wsc + ((size_t)pass * 64 + j) * Cin + chunk * KC + qa);
-        }
-    };
-    auto commitWsc = [&](float* buf) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int slot = tid + s * DPP_THREADS, j = slot >> a.lqa;
-            if (j < 64) rb_st4(&buf[j * LDA + qa], areg[s]);
-        }
-    };
+    __syncthreads();
 
     // ================================ phase A: c1 over the halo ================================
     f32x4 acc1[RT1][CT1];
@@ -208,43 +166,34 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     for (int i = 0; i < RT1; ++i)
 #pragma unroll
         for (int j = 0; j < CT1; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int chunks = a.chunks;
-    fetchA(0);
-    fetchW1(0);
-    commitA(R0);
-    commitW1(Wb);
-    __syncthreads();
-    int ws = 0;                                         // index of the weight slice in Wb[ws & 1]
-    for (int c = 0; c < chunks; ++c, ++ws) {
-        const float* Ab = R0 + (a.nbufA == 1 ? 0 : (a.nbufA == 2 ? (c & 1) : c)) * HPP * LDA;
-        const float* Wc = Wb + (ws & 1) * a.wbuf_floats;
-        const bool more = c + 1 < chunks;
-        if (more) { fetchA(c + 1); fetchW1(c + 1); } else fetchW2(0);
-        for (int kc = 0; kc < KC; kc += 16) {
-            float4 av[RT1], bv[CT1];
 #pragma unroll
-            for (int rt = 0; rt < RT1; ++rt) av[rt] = rb_ld4(&Ab[((wave * RT1 + rt) * 16 + l15) * LDA + kc + kq * 4]);
+    for (int s = 0; s < KSA; ++s) {
+        float4 av[RT1];
 #pragma unroll
-            for (int ct = 0; ct < CT1; ++ct) bv[ct] = rb_ld4(&Wc[(ct * 16 + l15) * LDA + kc + kq * 4]);
+        for (int rt = 0; rt < RT1; ++rt) av[rt] = rb_ld4(&A0[((wave * RT1 + rt) * 16 + l15) * LDA + s * 16 + kq * 4]);
+        rb_mfma16<RT1, CT1>(acc1, av, bA[s % RDA]);
+        if (s + RDA < KSA) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int rt = 0; rt < RT1; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < CT1; ++ct)
-                        acc1[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t), acc1[rt][ct], 0, 0, 0);
+            for (int ct = 0; ct < CT1; ++ct) bA[s % RDA][ct] = rb_ld4(w1p[ct] + (s + RDA) * 16);
         }
-        float* Wn = Wb + ((ws + 1) & 1) * a.wbuf_floats;
-        if (more) {
-            if (a.nbufA == 1) __syncthreads();          // single halo buffer: everybody has read chunk c
-            float* An = R0 + (a.nbufA == 1 ? 0 : (a.nbufA == 2 ? ((c + 1) & 1) : (c + 1)) * HPP * LDA);
-            commitA(An);
-            commitW1(Wn);
-        } else {
-            commitWn(Wn, NB);
-        }
-        __syncthreads();
+        DPP_SCHED_FENCE();
     }
+    // phase B's first B fragments (W2 [NB][9][NB]: the (tap, channel) pairs of a row are contiguous, step s is offset 16 s)
+    const float* w2p[CN2];
+#pragma unroll
+    for (int ct = 0; ct < CN2; ++ct) w2p[ct] = d.W2 + (size_t)((wn * CN2 + ct) * 16 + l15) * 9 * NB + kq * 4;
+    float4 bB[RDB][CN2];
+#pragma unroll
+    for (int s = 0; s < RDB; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CN2; ++ct) bB[s][ct] = rb_ld4(w2p[ct] + s * 16);
+    float e2b[CN2], e2m[CN2], e2s[CN2], e2t[CN2];
+#pragma unroll
+    for (int ct = 0; ct < CN2; ++ct) {
+        const int c = (wn * CN2 + ct) * 16 + l15;
+        e2b[ct] = d.b2[c]; e2m[ct] = d.bn2.mean[c]; e2s[ct] = d.bn2.gamma[c] * d.bn2.inv_std[c]; e2t[ct] = d.bn2.beta[c];
+    }
+    if (!PROJ) __syncthreads();                         // identity: A1 overwrites the halo, which every wave has to be done reading
     // c1 + b1 -> bn1 -> ReLU -> A1 (zero outside the image: the 3x3 pads its ACTIVATED input)
 #pragma unroll
     for (int rt = 0; rt < RT1; ++rt)
@@ -274,27 +223,38 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     for (int i = 0; i < RM2; ++i)
 #pragma unroll
         for (int j = 0; j < CN2; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int tap = 0; tap < 9; ++tap, ++ws) {
-        const float* Wc = Wb + (ws & 1) * a.wbuf_floats;
-        if (tap + 1 < 9) fetchW2(tap + 1); else fetchW3(0);
+#pragma unroll
+    for (int s = 0; s < KSB; ++s) {
+        constexpr int KPT = NB / 16;                    // k-steps per tap
+        const int tap = s / KPT, kk = s % KPT;
         const int toff = (tap / 3 - 1) * TW2 + (tap % 3 - 1);
+        float4 av[RM2];
 #pragma unroll
-        for (int kc = 0; kc < NB; kc += 16) {
-            float4 av[RM2], bv[CN2];
+        for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&A1[(hbase[rt] + toff) * LD1 + kk * 16 + kq * 4]);
+        rb_mfma16<RM2, CN2>(acc2, av, bB[s % RDB]);
+        if (s + RDB < KSB) {
 #pragma unroll
-            for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&A1[(hbase[rt] + toff) * LD1 + kc + kq * 4]);
-#pragma unroll
-            for (int ct = 0; ct < CN2; ++ct) bv[ct] = rb_ld4(&Wc[((wn * CN2 + ct) * 16 + l15) * LD1 + kc + kq * 4]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int rt = 0; rt < RM2; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < CN2; ++ct)
-                        acc2[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t), acc2[rt][ct], 0, 0, 0);
+            for (int ct = 0; ct < CN2; ++ct) bB[s % RDB][ct] = rb_ld4(w2p[ct] + (s + RDB) * 16);
         }
-        commitWn(Wb + ((ws + 1) & 1) * a.wbuf_floats, tap + 1 < 9 ? NB : 64);
-        __syncthreads();
+        DPP_SCHED_FENCE();
+    }
+    // phase C's first B fragments and the sweep geometry of this wave's stores, requested before the A2 barrier
+    const float* w3p[CN3];
+#pragma unroll
+    for (int ct = 0; ct < CN3; ++ct) w3p[ct] = d.W3 + (size_t)((wn * CN3 + ct) * 16 + l15) * NB + kq * 4;
+    float4 bC[2][KSC][CN3];
+#pragma unroll
+    for (int s = 0; s < KSC; ++s)
+#pragma unroll
+        for (int ct = 0; ct < CN3; ++ct) bC[0][s][ct] = rb_ld4(w3p[ct] + s * 16);
+    const int cq = lane % QW, rq = lane / QW;           // column quad / first row of this lane in the wave's sweep
+    const int colw = wn * WCOLS + cq * 4;               // its first column inside a 64-column pass
+    int ooff[SWEEPS];                                   // pixel index of the row in Y (and, identity block, in X), -1 outside
+#pragma unroll
+    for (int it = 0; it < SWEEPS; ++it) {
+        const int row = wm * WROWS + rq + it * RSW;
+        const int y = y0 + (row >> a.ltw), x = x0 + (row & (TW - 1));
+        ooff[it] = (y < Ho && x < Wo) ? ((n * Ho + y) * Wo + x) : -1;
     }
 #pragma unroll
     for (int rt = 0; rt < RM2; ++rt)
@@ -308,127 +268,83 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     __syncthreads();
 
     // ================================ phase C: c3 (+ shortcut) in passes of 64 output channels ================================
-    // a thread of the store sweep owns one column quad of the pass and rows rb, rb + 16, ...
-    const int cq = tid & 15, rb = tid >> 4;
-    constexpr int RSW = BM / 16;                        // rows per thread in the sweep
-    int ooff[RSW];                                      // element offset of the row's pixel in Y (and, identity block, in X), -1 outside
+    int hc[RM2];                                        // (projection) halo row of this lane's A rows, centre tap
 #pragma unroll
-    for (int it = 0; it < RSW; ++it) {
-        const int row = rb + it * 16;
-        const int y = y0 + (row >> a.ltw), x = x0 + (row & (TW - 1));
-        ooff[it] = (y < Ho && x < Wo) ? ((n * Ho + y) * Wo + x) : -1;
+    for (int rt = 0; rt < RM2; ++rt) {
+        const int row = (wm * RM2 + rt) * 16 + l15;
+        hc[rt] = ((row >> a.ltw) + 1) * TW2 + (row & (TW - 1)) + 1;
     }
-    const int npass = Cout >> 6;
-    auto product_c3 = [&](f32x4 (&acc3)[RM2][CN3], const float* Wc) {
 #pragma unroll
-        for (int kc = 0; kc < NB; kc += 16) {
-            float4 av[RM2], bv[CN3];
+    for (int pass = 0; pass < NPASS; ++pass) {
+        // next pass's W3 fragments, this pass's bias / residual rows (identity block) / first shortcut fragments (projection)
+        if (pass + 1 < NPASS) {
 #pragma unroll
-            for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&A2[((wm * RM2 + rt) * 16 + l15) * LD1 + kc + kq * 4]);
+            for (int s = 0; s < KSC; ++s)
 #pragma unroll
-            for (int ct = 0; ct < CN3; ++ct) bv[ct] = rb_ld4(&Wc[((wn * CN3 + ct) * 16 + l15) * LD1 + kc + kq * 4]);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int rt = 0; rt < RM2; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < CN3; ++ct)
-                        acc3[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t), acc3[rt][ct], 0, 0, 0);
+                for (int ct = 0; ct < CN3; ++ct) bC[(pass + 1) & 1][s][ct] = rb_ld4(w3p[ct] + (size_t)(pass + 1) * 64 * NB + s * 16);
         }
-    };
-    auto store_pass = [&](f32x4 (&acc3)[RM2][CN3], int pass, const float4& bq, const float4 (&res)[RSW]) {
-        if (pass > 0) __syncthreads();                  // the previous pass's image has been read by everybody
+        float4 bq = rb_ld4(d.b3 + pass * 64 + colw);
+        float4 res[SWEEPS];
+#pragma unroll
+        for (int it = 0; it < SWEEPS; ++it) {
+            res[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!PROJ && ooff[it] >= 0) res[it] = rb_ld4(d.X + (size_t)ooff[it] * CIN + pass * 64 + colw);
+        }
+        const float* wsp[CN3];
+        float4 bS[RDA][CN3];
+        if (PROJ) {
+            const float4 t = rb_ld4(d.bsc + pass * 64 + colw);
+            bq.x += t.x; bq.y += t.y; bq.z += t.z; bq.w += t.w;
+#pragma unroll
+            for (int ct = 0; ct < CN3; ++ct) wsp[ct] = d.Wsc + (size_t)(pass * 64 + (wn * CN3 + ct) * 16 + l15) * CIN + kq * 4;
+#pragma unroll
+            for (int s = 0; s < RDA; ++s)
+#pragma unroll
+                for (int ct = 0; ct < CN3; ++ct) bS[s][ct] = rb_ld4(wsp[ct] + s * 16);
+        }
+        f32x4 acc3[RM2][CN3];
+#pragma unroll
+        for (int i = 0; i < RM2; ++i)
+#pragma unroll
+            for (int j = 0; j < CN3; ++j) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSC; ++s) {
+            float4 av[RM2];
+#pragma unroll
+            for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&A2[((wm * RM2 + rt) * 16 + l15) * LD1 + s * 16 + kq * 4]);
+            rb_mfma16<RM2, CN3>(acc3, av, bC[pass & 1][s]);
+        }
+        if (PROJ) {
+            // the shortcut's product on the centre pixels of the activated input (still whole in LDS)
+#pragma unroll
+            for (int s = 0; s < KSA; ++s) {
+                float4 av[RM2];
+#pragma unroll
+                for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&A0[hc[rt] * LDA + s * 16 + kq * 4]);
+                rb_mfma16<RM2, CN3>(acc3, av, bS[s % RDA]);
+                if (s + RDA < KSA) {
+#pragma unroll
+                    for (int ct = 0; ct < CN3; ++ct) bS[s % RDA][ct] = rb_ld4(wsp[ct] + (s + RDA) * 16);
+                }
+                DPP_SCHED_FENCE();
+            }
+        }
+        // the wave's [WROWS][WCOLS] share through its private image: 16-byte bias / residual / store
+        DPP_WAVE_SYNC();                                // (the previous pass's reads of the image are done)
 #pragma unroll
         for (int rt = 0; rt < RM2; ++rt)
 #pragma unroll
             for (int ct = 0; ct < CN3; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    IMG[((wm * RM2 + rt) * 16 + kq * 4 + r) * LDI + (wn * CN3 + ct) * 16 + l15] = acc3[rt][ct][r];
-        __syncthreads();
+                for (int r = 0; r < 4; ++r) IMG[(rt * 16 + kq * 4 + r) * LDI + ct * 16 + l15] = acc3[rt][ct][r];
+        DPP_WAVE_SYNC();
 #pragma unroll
-        for (int it = 0; it < RSW; ++it) {
+        for (int it = 0; it < SWEEPS; ++it) {
             if (ooff[it] >= 0) {
-                const float4 v = rb_ld4(&IMG[(rb + it * 16) * LDI + cq * 4]);
-                rb_st4(d.Y + (size_t)ooff[it] * Cout + pass * 64 + cq * 4,
+                const float4 v = rb_ld4(&IMG[(rq + it * RSW) * LDI + cq * 4]);
+                rb_st4(d.Y + (size_t)ooff[it] * COUT + pass * 64 + colw,
                        make_float4(v.x + bq.x + res[it].x, v.y + bq.y + res[it].y, v.z + bq.z + res[it].z, v.w + bq.w + res[it].w));
             }
-        }
-    };
-    if constexpr (!PROJ) {
-        for (int pass = 0; pass < npass; ++pass, ++ws) {
-            const float* Wc = Wb + (ws & 1) * a.wbuf_floats;
-            if (pass + 1 < npass) fetchW3(pass + 1);
-            // the residual rows of this pass, requested before the products
-            float4 res[RSW];
-            const float4 bq = rb_ld4(d.b3 + pass * 64 + cq * 4);
-#pragma unroll
-            for (int it = 0; it < RSW; ++it) {
-                res[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ooff[it] >= 0) res[it] = rb_ld4(d.X + (size_t)ooff[it] * Cin + pass * 64 + cq * 4);
-            }
-            f32x4 acc3[RM2][CN3];
-#pragma unroll
-            for (int i = 0; i < RM2; ++i)
-#pragma unroll
-                for (int j = 0; j < CN3; ++j) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            product_c3(acc3, Wc);
-            if (pass + 1 < npass) commitWn(Wb + ((ws + 1) & 1) * a.wbuf_floats, 64);
-            store_pass(acc3, pass, bq, res);
-        }
-    } else {
-        // Projection block: buffer U holds the W3 slice of the pass, buffer V the [64][KC] slices of the shortcut's weights, whose product
-        // runs on the centre pixels of the activated input (all K chunks are still alive in R0).  Three of the twenty blocks take this
-        // path: plain fetch / barrier / commit / barrier sequencing, no pipelining across slices.
-        float* U = Wb + (ws & 1) * a.wbuf_floats;
-        float* V = Wb + ((ws + 1) & 1) * a.wbuf_floats;
-        int hc[RM2];                                    // halo row of this lane's A rows (centre tap)
-#pragma unroll
-        for (int rt = 0; rt < RM2; ++rt) {
-            const int row = (wm * RM2 + rt) * 16 + l15;
-            hc[rt] = ((row >> a.ltw) + 1) * TW2 + (row & (TW - 1)) + 1;
-        }
-        float4 res[RSW];
-#pragma unroll
-        for (int it = 0; it < RSW; ++it) res[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int pass = 0; pass < npass; ++pass) {
-            if (pass > 0) {
-                fetchW3(pass);
-                __syncthreads();
-                commitWn(U, 64);
-                __syncthreads();
-            }
-            fetchWsc(pass, 0);
-            float4 bq = rb_ld4(d.b3 + pass * 64 + cq * 4);
-            { const float4 t = rb_ld4(d.bsc + pass * 64 + cq * 4); bq.x += t.x; bq.y += t.y; bq.z += t.z; bq.w += t.w; }
-            f32x4 acc3[RM2][CN3];
-#pragma unroll
-            for (int i = 0; i < RM2; ++i)
-#pragma unroll
-                for (int j = 0; j < CN3; ++j) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            product_c3(acc3, U);
-            for (int c = 0; c < chunks; ++c) {
-                if (c > 0) fetchWsc(pass, c);
-                __syncthreads();                         // V has been read by everybody
-                commitWsc(V);
-                __syncthreads();
-                const float* Ab = R0 + c * HPP * LDA;
-                for (int kc = 0; kc < KC; kc += 16) {
-                    float4 av[RM2], bv[CN3];
-#pragma unroll
-                    for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&Ab[hc[rt] * LDA + kc + kq * 4]);
-#pragma unroll
-                    for (int ct = 0; ct < CN3; ++ct) bv[ct] = rb_ld4(&V[((wn * CN3 + ct) * 16 + l15) * LDA + kc + kq * 4]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int rt = 0; rt < RM2; ++rt)
-#pragma unroll
-                            for (int ct = 0; ct < CN3; ++ct)
-                                acc3[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t), acc3[rt][ct], 0, 0, 0);
-                }
-            }
-            store_pass(acc3, pass, bq, res);
         }
     }
 }
@@ -441,9 +357,9 @@ bool rb_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 
 extern "C" int dpp_resblock_eval_ok(int Cin, int Cout, int Nb, int stride, int projection) {
     if (Nb != 16 && Nb != 32 && Nb != 64) return 0;
-    if (Cout < 64 || (Cout & 63)) return 0;
+    if (Cout != 4 * Nb) return 0;
     if (!projection) return stride == 1 && Cin == Cout;                    // identity block
-    return (stride == 1 || stride == 2) && (Cin == 32 || (Cin >= 64 && Cin % 64 == 0 && Cin <= 256));
+    return (stride == 1 || stride == 2) && Cin == 2 * Nb;                  // the block that opens a stage
 }
 
 extern "C" int dpp_resblock_eval(const dpp_resblock_desc* desc, dpp_stream_t stream) {
@@ -469,18 +385,12 @@ extern "C" int dpp_resblock_eval(const dpp_resblock_desc* desc, dpp_stream_t str
     a.tiles_x = dpp_cdiv(d.Wo, tw); a.tiles_y = dpp_cdiv(d.Ho, th);
     a.ntiles = a.tiles_x * a.tiles_y * d.N;
     a.m_tw2 = (unsigned)(0x100000000ull / (unsigned)(tw + 2)) + 1u;
-    a.KC = d.Cin < 64 ? d.Cin : 64;
-    if (a.KC != 32 && a.KC != 64) return DPP_E_UNSUPPORTED;
-    a.chunks = d.Cin / a.KC;
-    a.lqa = rb_ilog2(a.KC / 4);
-    const int HP = (th + 2) * (tw + 2), HPP = (HP + 63) / 64 * 64, BM = th * tw, LD1 = d.Nb + 4, LDA = a.KC + 4;
-    a.nbufA = proj ? a.chunks : (a.chunks == 1 ? 1 : (HPP == 64 ? 2 : 1));
-    const int r0a = a.nbufA * HPP * LDA, r0b = HPP * LD1 + BM * 68;
-    a.r0_floats = proj ? r0a : (r0a > r0b ? r0a : r0b);      // (projection: A1 and the output image live behind A2 instead)
-    const int w1 = d.Nb * LDA, w3 = 64 * LD1, wsc = proj ? 64 * LDA : 0;
-    a.wbuf_floats = w1 > w3 ? w1 : w3;
-    if (wsc > a.wbuf_floats) a.wbuf_floats = wsc;
-    const size_t lds = ((size_t)a.r0_floats + 2 * (size_t)a.wbuf_floats + (size_t)BM * LD1 + (proj ? (size_t)r0b : 0)) * sizeof(float);
+    const int HP = (th + 2) * (tw + 2), HPP = (HP + 63) / 64 * 64, BM = th * tw, LD1 = d.Nb + 4, LDA = d.Cin + 4;
+    // LDS: halo | A2 | (projection: A1 | images); identity: A1 + images alias the halo
+    const int wm2 = BM / 16 < 4 ? BM / 16 : 4, wrows = BM / wm2, wcols = 64 / (4 / wm2);      // a wave's share of a 64-column pass
+    const int img = 4 * wrows * (wcols + 4);                                                   // four wave-private images
+    const int r0a = HPP * LDA, r0b = HPP * LD1 + img;
+    const size_t lds = ((size_t)(proj ? r0a + r0b : (r0a > r0b ? r0a : r0b)) + (size_t)BM * LD1) * sizeof(float);
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     a.xcd_chunk = (a.ntiles % 8 == 0 && a.ntiles >= 64) ? a.ntiles / 8 : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);

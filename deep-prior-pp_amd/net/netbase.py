@@ -284,15 +284,22 @@ class NetBase(object):
         bulk = store.bulk_values() if store is not None else {}      # two device -> host copies for the whole net
         self._write_checkpoint(self._checkpoint_state(bulk), filename)
 
-    def saveAsync(self, filename):
+    def saveAsync(self, filename, skip_if_busy=False):
         """save() off the calling thread (the epoch loop's per-epoch `net_last.pkl`, /root/reference/src/trainer/nettrainer.py:816-820:
         a 75 MB protocol-2 pickle is 0.4 s of host time per epoch of the 128x128 ResNet).  The parameters are copied device-to-device
         into a staging buffer on the current stream (50 us; training may go on changing the live ones), that buffer goes to
         page-locked host memory on the copy stream, and a worker thread converts the layouts and writes the SAME bytes save() writes.
-        joinSave() -- called by the next saveAsync / save and at the end of train() -- waits for it."""
+        joinSave() -- called by the next saveAsync / save and at the end of train() -- waits for it.
+        skip_if_busy: for a file that is rewritten over and over (`net_last.pkl`): when the writer of the previous snapshot is still at
+        work -- epochs shorter than a checkpoint write -- this snapshot is dropped instead of stalling the epoch loop behind it; the
+        file then holds the state of the previous epoch until the next one lands.  Returns True when a snapshot was started / written."""
         store = self._live_store()
         if store is None or not hasattr(store.rt, 'download_async'):
-            return self.save(filename)
+            self.save(filename)
+            return True
+        pend = self.__dict__.get('_save_pending')
+        if skip_if_busy and pend is not None and pend[0].is_alive():
+            return False
         self.joinSave()
         import threading
         rt = store.rt
@@ -324,6 +331,7 @@ class NetBase(object):
         th = threading.Thread(target=work, name='dpp-checkpoint')
         th.start()
         self._save_pending = (th, err)
+        return True
 
     def joinSave(self):
         """Wait for the checkpoint a saveAsync() started (no-op otherwise); an error of the writer thread is raised here."""
