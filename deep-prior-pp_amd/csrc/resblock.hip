@@ -36,6 +36,7 @@ struct RBArgs {
     int lth, ltw, tiles_x, tiles_y, ntiles;
     unsigned m_tw2;          // floor(2^32 / (TW+2)) + 1
     int xcd_chunk;           // ntiles / 8 when the tile -> XCD swizzle applies, else 0
+    unsigned long long* prof;   // phase stamps (profiling build only, see dpp_stamp)
 };
 
 __device__ __forceinline__ float4 rb_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -79,14 +80,16 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     constexpr int LDA = CIN + 4;                     // row stride of the activated input halo
     constexpr int LD1 = NB + 4;                      // row stride of A1 / A2
     constexpr int RTB = BM / 16;                     // row tiles of the output tile
-    constexpr int WM2 = RTB < 4 ? RTB : 4, RM2 = RTB / WM2, WN2 = 4 / WM2;
+    // phases B / C: the waves split the COLUMNS first (a B fragment comes from global memory and feeds RM2 row tiles; an A fragment is an
+    // LDS read): 1 x 4 waves (64 channels), 2 x 2 (32), 4 x 1 (16) -- two row tiles and one column tile per wave in phase B everywhere
+    constexpr int WN2 = CT1 < 4 ? CT1 : 4, WM2 = 4 / WN2, RM2 = RTB / WM2;
     constexpr int CN2 = CT1 / WN2;                   // phase B: column tiles per wave
     constexpr int CN3 = 4 / WN2;                     // phase C: column tiles per wave of a 64-column pass
     constexpr int QR = CIN / 4;                      // channel quads per halo row
     constexpr int RS = DPP_THREADS / QR;             // halo rows per staging sweep
     constexpr int ASLOTS = HPP / RS;                 // halo float4 slots per thread
     constexpr int KSA = CIN / 16, RDA = KSA < 8 ? KSA : 8;             // phase A: k-steps, B-fragment ring depth
-    constexpr int KSB = 9 * (NB / 16), RDB = KSB < 8 ? KSB : 8;        // phase B
+    constexpr int KSB = 9 * (NB / 16), RDB = KSB < 12 ? KSB : 12;      // phase B
     constexpr int KSC = NB / 16;                                       // phase C: k-steps of a pass
     constexpr int NPASS = COUT / 64;
     constexpr int WROWS = RM2 * 16, WCOLS = CN3 * 16, LDI = WCOLS + 4; // a wave's share of a pass and its private image
@@ -113,7 +116,24 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     const int Ho = d.Ho, Wo = d.Wo;
     const float* Xn = d.X + (size_t)n * d.H * d.W * CIN;
 
-    // ---- phase A's first B fragments: requested before anything else ----
+    dpp_stamp(a.prof, 0);
+    // ---- the activated input halo: slot u of a thread is halo position hp = tid / QR + u * RS, channel quad qa.  Every load is
+    //      UNCONDITIONAL (a pixel outside the image reads the clamped one and is zeroed afterwards): a branch between a load and its use
+    //      makes the compiler drain all outstanding loads, and these are the longest pole of the kernel -- requested first ----
+    const int qa = (tid % QR) * 4;
+    float4 areg[ASLOTS];
+    bool ain[ASLOTS];
+#pragma unroll
+    for (int u = 0; u < ASLOTS; ++u) {
+        const int hp = tid / QR + u * RS;
+        const int hy = (int)__umulhi((unsigned)hp, a.m_tw2), hx = hp - hy * TW2;
+        const int y = y0 + hy - 1, x = x0 + hx - 1;
+        ain[u] = hp < HP && y >= 0 && y < Ho && x >= 0 && x < Wo;
+        const int yc = y < 0 ? 0 : (y >= Ho ? Ho - 1 : y), xc = x < 0 ? 0 : (x >= Wo ? Wo - 1 : x);
+        areg[u] = rb_ld4(Xn + ((size_t)(yc * S) * d.W + xc * S) * CIN + qa);
+    }
+    const float4 mu = rb_ld4(d.bn0.mean + qa), g0 = rb_ld4(d.bn0.gamma + qa), i0 = rb_ld4(d.bn0.inv_std + qa), be = rb_ld4(d.bn0.beta + qa);
+    // ---- phase A's first B fragments (in flight while the halo is committed) ----
     const float* w1p[CT1];
 #pragma unroll
     for (int ct = 0; ct < CT1; ++ct) w1p[ct] = d.W1 + (size_t)(ct * 16 + l15) * CIN + kq * 4;
@@ -122,35 +142,20 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     for (int s = 0; s < RDA; ++s)
 #pragma unroll
         for (int ct = 0; ct < CT1; ++ct) bA[s][ct] = rb_ld4(w1p[ct] + s * 16);
-
-    // ---- the activated input halo: slot u of a thread is halo position hp = tid / QR + u * RS, channel quad qa ----
+    DPP_SCHED_FENCE();
     {
-        const int qa = (tid % QR) * 4;
-        const float4 mu = rb_ld4(d.bn0.mean + qa), g0 = rb_ld4(d.bn0.gamma + qa), i0 = rb_ld4(d.bn0.inv_std + qa), be = rb_ld4(d.bn0.beta + qa);
-        float4 areg[ASLOTS];
-        bool ain[ASLOTS];
-#pragma unroll
-        for (int u = 0; u < ASLOTS; ++u) {
-            const int hp = tid / QR + u * RS;
-            const int hy = (int)__umulhi((unsigned)hp, a.m_tw2), hx = hp - hy * TW2;
-            const int y = y0 + hy - 1, x = x0 + hx - 1;
-            ain[u] = hp < HP && y >= 0 && y < Ho && x >= 0 && x < Wo;
-            areg[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ain[u]) areg[u] = rb_ld4(Xn + ((size_t)(y * S) * d.W + x * S) * CIN + qa);
-        }
         const float4 sc = make_float4(g0.x * i0.x, g0.y * i0.y, g0.z * i0.z, g0.w * i0.w);
 #pragma unroll
         for (int u = 0; u < ASLOTS; ++u) {
             const int hp = tid / QR + u * RS;
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);              // zero padding is applied AFTER the activation
-            if (ain[u]) {
-                const float4 v = areg[u];
-                t = make_float4(rb_bnrelu(v.x, mu.x, sc.x, be.x), rb_bnrelu(v.y, mu.y, sc.y, be.y),
-                                rb_bnrelu(v.z, mu.z, sc.z, be.z), rb_bnrelu(v.w, mu.w, sc.w, be.w));
-            }
+            const float4 v = areg[u];
+            float4 t = make_float4(rb_bnrelu(v.x, mu.x, sc.x, be.x), rb_bnrelu(v.y, mu.y, sc.y, be.y),
+                                   rb_bnrelu(v.z, mu.z, sc.z, be.z), rb_bnrelu(v.w, mu.w, sc.w, be.w));
+            if (!ain[u]) t = make_float4(0.f, 0.f, 0.f, 0.f);       // zero padding is applied AFTER the activation
             rb_st4(&A0[hp * LDA + qa], t);
         }
     }
+    dpp_stamp(a.prof, 1);
     // per-lane column constants of the first epilogue
     float e1b[CT1], e1m[CT1], e1s[CT1], e1t[CT1];
 #pragma unroll
@@ -159,6 +164,7 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
         e1b[ct] = d.b1[c]; e1m[ct] = d.bn1.mean[c]; e1s[ct] = d.bn1.gamma[c] * d.bn1.inv_std[c]; e1t[ct] = d.bn1.beta[c];
     }
     __syncthreads();
+    dpp_stamp(a.prof, 2);
 
     // ================================ phase A: c1 over the halo ================================
     f32x4 acc1[RT1][CT1];
@@ -166,18 +172,26 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     for (int i = 0; i < RT1; ++i)
 #pragma unroll
         for (int j = 0; j < CT1; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        // (the A fragment of step s + 1 is read from LDS before the products of step s: its latency hides under 16 MFMAs)
+        float4 av[2][RT1];
 #pragma unroll
-    for (int s = 0; s < KSA; ++s) {
-        float4 av[RT1];
+        for (int rt = 0; rt < RT1; ++rt) av[0][rt] = rb_ld4(&A0[((wave * RT1 + rt) * 16 + l15) * LDA + kq * 4]);
 #pragma unroll
-        for (int rt = 0; rt < RT1; ++rt) av[rt] = rb_ld4(&A0[((wave * RT1 + rt) * 16 + l15) * LDA + s * 16 + kq * 4]);
-        rb_mfma16<RT1, CT1>(acc1, av, bA[s % RDA]);
-        if (s + RDA < KSA) {
+        for (int s = 0; s < KSA; ++s) {
+            if (s + 1 < KSA) {
 #pragma unroll
-            for (int ct = 0; ct < CT1; ++ct) bA[s % RDA][ct] = rb_ld4(w1p[ct] + (s + RDA) * 16);
+                for (int rt = 0; rt < RT1; ++rt) av[(s + 1) & 1][rt] = rb_ld4(&A0[((wave * RT1 + rt) * 16 + l15) * LDA + (s + 1) * 16 + kq * 4]);
+            }
+            rb_mfma16<RT1, CT1>(acc1, av[s & 1], bA[s % RDA]);
+            if (s + RDA < KSA) {
+#pragma unroll
+                for (int ct = 0; ct < CT1; ++ct) bA[s % RDA][ct] = rb_ld4(w1p[ct] + (s + RDA) * 16);
+            }
+            DPP_SCHED_FENCE();
         }
-        DPP_SCHED_FENCE();
     }
+    dpp_stamp(a.prof, 3);
     // phase B's first B fragments (W2 [NB][9][NB]: the (tap, channel) pairs of a row are contiguous, step s is offset 16 s)
     const float* w2p[CN2];
 #pragma unroll
@@ -223,30 +237,31 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     for (int i = 0; i < RM2; ++i)
 #pragma unroll
         for (int j = 0; j < CN2; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < KSB; ++s) {
+    dpp_stamp(a.prof, 4);
+    {
         constexpr int KPT = NB / 16;                    // k-steps per tap
-        const int tap = s / KPT, kk = s % KPT;
-        const int toff = (tap / 3 - 1) * TW2 + (tap % 3 - 1);
-        float4 av[RM2];
+        auto afrag = [&](int s, float4 (&av)[RM2]) {
+            const int tap = s / KPT, kk = s % KPT;
+            const int toff = (tap / 3 - 1) * TW2 + (tap % 3 - 1);
 #pragma unroll
-        for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&A1[(hbase[rt] + toff) * LD1 + kk * 16 + kq * 4]);
-        rb_mfma16<RM2, CN2>(acc2, av, bB[s % RDB]);
-        if (s + RDB < KSB) {
+            for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&A1[(hbase[rt] + toff) * LD1 + kk * 16 + kq * 4]);
+        };
+        float4 av[2][RM2];
+        afrag(0, av[0]);
 #pragma unroll
-            for (int ct = 0; ct < CN2; ++ct) bB[s % RDB][ct] = rb_ld4(w2p[ct] + (s + RDB) * 16);
+        for (int s = 0; s < KSB; ++s) {
+            if (s + 1 < KSB) afrag(s + 1, av[(s + 1) & 1]);
+            rb_mfma16<RM2, CN2>(acc2, av[s & 1], bB[s % RDB]);
+            if (s + RDB < KSB) {
+#pragma unroll
+                for (int ct = 0; ct < CN2; ++ct) bB[s % RDB][ct] = rb_ld4(w2p[ct] + (s + RDB) * 16);
+            }
+            DPP_SCHED_FENCE();
         }
-        DPP_SCHED_FENCE();
     }
-    // phase C's first B fragments and the sweep geometry of this wave's stores, requested before the A2 barrier
-    const float* w3p[CN3];
-#pragma unroll
-    for (int ct = 0; ct < CN3; ++ct) w3p[ct] = d.W3 + (size_t)((wn * CN3 + ct) * 16 + l15) * NB + kq * 4;
-    float4 bC[2][KSC][CN3];
-#pragma unroll
-    for (int s = 0; s < KSC; ++s)
-#pragma unroll
-        for (int ct = 0; ct < CN3; ++ct) bC[0][s][ct] = rb_ld4(w3p[ct] + s * 16);
+    dpp_stamp(a.prof, 5);
+    // phase C: the sweep geometry of this wave's stores, and EVERYTHING the passes need from memory -- W3 fragments, bias, residual rows
+    // (identity block) -- requested here, before the A2 barrier: a pass is 0.4 us of products, a round trip 1-2 us
     const int cq = lane % QW, rq = lane / QW;           // column quad / first row of this lane in the wave's sweep
     const int colw = wn * WCOLS + cq * 4;               // its first column inside a 64-column pass
     int ooff[SWEEPS];                                   // pixel index of the row in Y (and, identity block, in X), -1 outside
@@ -256,6 +271,28 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
         const int y = y0 + (row >> a.ltw), x = x0 + (row & (TW - 1));
         ooff[it] = (y < Ho && x < Wo) ? ((n * Ho + y) * Wo + x) : -1;
     }
+    const float* w3p[CN3];
+#pragma unroll
+    for (int ct = 0; ct < CN3; ++ct) w3p[ct] = d.W3 + (size_t)((wn * CN3 + ct) * 16 + l15) * NB + kq * 4;
+    float4 bC[NPASS][KSC][CN3], bq[NPASS], res[NPASS][SWEEPS];
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+        for (int sk = 0; sk < KSC; ++sk)
+#pragma unroll
+            for (int ct = 0; ct < CN3; ++ct) bC[pass][sk][ct] = rb_ld4(w3p[ct] + (size_t)pass * 64 * NB + sk * 16);
+        bq[pass] = rb_ld4(d.b3 + pass * 64 + colw);
+#pragma unroll
+        for (int it = 0; it < SWEEPS; ++it) {
+            // (unconditional: a row outside the image reads pixel 0 of the tensor and is never stored)
+            res[pass][it] = PROJ ? make_float4(0.f, 0.f, 0.f, 0.f) : rb_ld4(d.X + (size_t)(ooff[it] >= 0 ? ooff[it] : 0) * CIN + pass * 64 + colw);
+        }
+        if (PROJ) {
+            const float4 t = rb_ld4(d.bsc + pass * 64 + colw);
+            bq[pass].x += t.x; bq[pass].y += t.y; bq[pass].z += t.z; bq[pass].w += t.w;
+        }
+    }
+    DPP_SCHED_FENCE();
 #pragma unroll
     for (int rt = 0; rt < RM2; ++rt)
 #pragma unroll
@@ -266,6 +303,7 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
                 A2[row * LD1 + (wn * CN2 + ct) * 16 + l15] = rb_bnrelu(acc2[rt][ct][r] + e2b[ct], e2m[ct], e2s[ct], e2t[ct]);
         }
     __syncthreads();
+    dpp_stamp(a.prof, 6);
 
     // ================================ phase C: c3 (+ shortcut) in passes of 64 output channels ================================
     int hc[RM2];                                        // (projection) halo row of this lane's A rows, centre tap
@@ -276,25 +314,9 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
-        // next pass's W3 fragments, this pass's bias / residual rows (identity block) / first shortcut fragments (projection)
-        if (pass + 1 < NPASS) {
-#pragma unroll
-            for (int s = 0; s < KSC; ++s)
-#pragma unroll
-                for (int ct = 0; ct < CN3; ++ct) bC[(pass + 1) & 1][s][ct] = rb_ld4(w3p[ct] + (size_t)(pass + 1) * 64 * NB + s * 16);
-        }
-        float4 bq = rb_ld4(d.b3 + pass * 64 + colw);
-        float4 res[SWEEPS];
-#pragma unroll
-        for (int it = 0; it < SWEEPS; ++it) {
-            res[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!PROJ && ooff[it] >= 0) res[it] = rb_ld4(d.X + (size_t)ooff[it] * CIN + pass * 64 + colw);
-        }
         const float* wsp[CN3];
         float4 bS[RDA][CN3];
         if (PROJ) {
-            const float4 t = rb_ld4(d.bsc + pass * 64 + colw);
-            bq.x += t.x; bq.y += t.y; bq.z += t.z; bq.w += t.w;
 #pragma unroll
             for (int ct = 0; ct < CN3; ++ct) wsp[ct] = d.Wsc + (size_t)(pass * 64 + (wn * CN3 + ct) * 16 + l15) * CIN + kq * 4;
 #pragma unroll
@@ -312,7 +334,7 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
             float4 av[RM2];
 #pragma unroll
             for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&A2[((wm * RM2 + rt) * 16 + l15) * LD1 + s * 16 + kq * 4]);
-            rb_mfma16<RM2, CN3>(acc3, av, bC[pass & 1][s]);
+            rb_mfma16<RM2, CN3>(acc3, av, bC[pass][s]);
         }
         if (PROJ) {
             // the shortcut's product on the centre pixels of the activated input (still whole in LDS)
@@ -342,11 +364,12 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
         for (int it = 0; it < SWEEPS; ++it) {
             if (ooff[it] >= 0) {
                 const float4 v = rb_ld4(&IMG[(rq + it * RSW) * LDI + cq * 4]);
-                rb_st4(d.Y + (size_t)ooff[it] * COUT + pass * 64 + colw,
-                       make_float4(v.x + bq.x + res[it].x, v.y + bq.y + res[it].y, v.z + bq.z + res[it].z, v.w + bq.w + res[it].w));
+                const float4 bb = bq[pass], rr = res[pass][it];
+                rb_st4(d.Y + (size_t)ooff[it] * COUT + pass * 64 + colw, make_float4(v.x + bb.x + rr.x, v.y + bb.y + rr.y, v.z + bb.z + rr.z, v.w + bb.w + rr.w));
             }
         }
     }
+    dpp_stamp(a.prof, 7);
 }
 
 int rb_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -379,6 +402,7 @@ extern "C" int dpp_resblock_eval(const dpp_resblock_desc* desc, dpp_stream_t str
     if ((long)d.N * d.H * d.W * (long)(d.Cin > d.Cout ? d.Cin : d.Cout) >= (1L << 31)) return DPP_E_UNSUPPORTED;     // 32-bit element offsets
     RBArgs a;
     a.d = d;
+    a.prof = dpp_prof_buffer;
     // the tile follows from the bottleneck width alone (never from the batch): 8 x 16 (16 channels), 8 x 8 (32), 4 x 8 (64)
     const int th = d.Nb == 64 ? 4 : 8, tw = d.Nb == 16 ? 16 : 8;
     a.lth = rb_ilog2(th); a.ltw = rb_ilog2(tw);
@@ -387,7 +411,7 @@ extern "C" int dpp_resblock_eval(const dpp_resblock_desc* desc, dpp_stream_t str
     a.m_tw2 = (unsigned)(0x100000000ull / (unsigned)(tw + 2)) + 1u;
     const int HP = (th + 2) * (tw + 2), HPP = (HP + 63) / 64 * 64, BM = th * tw, LD1 = d.Nb + 4, LDA = d.Cin + 4;
     // LDS: halo | A2 | (projection: A1 | images); identity: A1 + images alias the halo
-    const int wm2 = BM / 16 < 4 ? BM / 16 : 4, wrows = BM / wm2, wcols = 64 / (4 / wm2);      // a wave's share of a 64-column pass
+    const int wn2 = d.Nb / 16 < 4 ? d.Nb / 16 : 4, wm2 = 4 / wn2, wrows = BM / wm2, wcols = 64 / wn2;      // a wave's share of a 64-column pass
     const int img = 4 * wrows * (wcols + 4);                                                   // four wave-private images
     const int r0a = HPP * LDA, r0b = HPP * LD1 + img;
     const size_t lds = ((size_t)(proj ? r0a + r0b : (r0a > r0b ? r0a : r0b)) + (size_t)BM * LD1) * sizeof(float);

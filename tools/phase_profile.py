@@ -108,7 +108,42 @@ def fc_case(label, M, N, K, a_kc, b_kc, tile, splitk):
     profile('%s tile %dx%d splitk %d' % (label, tile[0], tile[1], splitk), L, -(-M // tile[0]) * -(-N // tile[1]) * splitk)
 
 
+def resblock_case(label, N, H, Nb, proj=False):
+    """The fused deterministic-mode bottleneck block (csrc/resblock.hip).  Phases: 0 entry -> 1 halo loads issued, activated, written to
+    LDS -> 2 barrier -> 3 phase A (c1 over the halo) -> 4 A1 written + barrier -> 5 phase B (3x3) -> 6 A2 written + barrier -> 7 phase C."""
+    Cin, Cout = (2 * Nb if proj else 4 * Nb), 4 * Nb
+    s = 2 if proj else 1
+    Hi = H * s
+    X = rt.alloc((N, Hi, Hi, Cin), zero=False)
+    rt.tensor(X).normal_()
+    Y = rt.alloc((N, H, H, Cout), zero=False)
+
+    def vec(n, lo=0.5, hi=1.5):
+        b = rt.alloc(n, zero=False)
+        rt.tensor(b).uniform_(lo, hi)
+        return b
+
+    def w(*shape):
+        b = rt.alloc(shape, zero=False)
+        rt.tensor(b).normal_(0, 0.05)
+        return b
+    bns = [ops.bn_eval(vec(c, -0.3, 0.3), vec(c), vec(c), vec(c, -0.3, 0.3)) for c in (Cin, Nb, Nb)]
+    kw = dict(Wsc=w(Cout, Cin), bsc=vec(Cout)) if proj else {}
+    L = ops.resblock_eval(rt, X, N, Hi, Hi, Cin, s, Cout, Nb, bns[0], bns[1], bns[2], w(Nb, Cin), vec(Nb), w(Nb, 9, Nb), vec(Nb), w(Cout, Nb), vec(Cout),
+                          Y, **kw)
+    th, tw = (4 if Nb == 64 else 8), (16 if Nb == 16 else 8)
+    profile(label, L, N * -(-H // th) * -(-H // tw), nphase=8)
+
+
 if __name__ == '__main__':
+    if 'resblock' in sys.argv[1:]:
+        resblock_case('block stage3/4 256 -> 64 -> 256, 8x8 maps', 128, 8, 64)
+        resblock_case('block stage2   128 -> 32 -> 128, 16x16 maps', 128, 16, 32)
+        resblock_case('block stage1    64 -> 16 ->  64, 32x32 maps', 128, 32, 16)
+        resblock_case('projection stage3 128 -> 64 -> 256 /2', 128, 8, 64, proj=True)
+        resblock_case('projection stage2  64 -> 32 -> 128 /2', 128, 16, 32, proj=True)
+        resblock_case('projection stage1  32 -> 16 ->  64 /2', 128, 32, 16, proj=True)
+        sys.exit(0)
     if 'fc' in sys.argv[1:]:
         fc_case('FC1 fwd   128 x 1024 x 16384', 128, 1024, 16384, 1, 0, (128, 64, 4), 32)
         fc_case('FC1 fwd   128 x 1024 x 16384', 128, 1024, 16384, 1, 0, (64, 64, 4), 32)
