@@ -1,7 +1,7 @@
 # Regenerate the rocprofv3 evidence of the current round on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
 # Outputs land in gpurun_out/<round>/ and are then copied to profiles/<round>_*.
 set -x
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
@@ -27,6 +27,13 @@ done
 DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA --kernel-trace -d /tmp/p5 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
 DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace -d /tmp/p6 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
 python $R/tools/inst_summary.py $(find /tmp/p5 -name '*_results.db' | head -1) $(find /tmp/p6 -name '*_results.db' | head -1) > $O/instruction_mix.txt 2>&1
+# matrix-core busy cycles (north_star: "rocprof MFMA utilisation"): one more SQ pass, counters only + kernel trace
+DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES --kernel-trace -d /tmp/p7 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
+python $R/tools/mfma_busy_summary.py $(find /tmp/p7 -name '*_results.db' | head -1) --json $O/mfma_busy.json > $O/mfma_busy.txt 2>&1
+# the deterministic forward (computeOutput's device function): kernel trace by grid + the fused block's phase stamps
+rocprofv3 --kernel-trace -d /tmp/p8 -o run -- python $R/tools/forward_profile.py 8 > /dev/null 2>&1
+python $R/tools/prof_summary.py $(find /tmp/p8 -name '*_results.db' | head -1) 11 --by-grid > $O/forward_kernels_by_grid.txt 2>&1
+python $R/tools/forward_profile.py 30 > $O/forward_only.txt 2>/dev/null
 python $R/tools/branch_probe.py > $O/branch_probe.txt 2>/dev/null
 python $R/tools/launch_rate.py > $O/launch_rate.txt 2>/dev/null
 # the other bench modes of BASELINE.json
