@@ -278,12 +278,36 @@ def forward_only_leg(rt, torch, net, B, S, x_host, steps=50, warmup=10):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     out = ev_eng.out.buf.get()
-    names = {}
+    names, groups = {}, {}
     for o in ev_eng.fwd.launches():
-        k = (o.meta or {}).get('kernel', o.name)
-        names[k] = names.get(k, 0) + 1
+        m = o.meta or dict(kernel=o.name, flops=0.0, bytes=0.0)
+        names[m['kernel']] = names.get(m['kernel'], 0) + 1
+        g = groups.setdefault(m['kernel'], dict(ops=[], flops=0.0, bytes=0.0))
+        g['ops'].append(o)
+        g['flops'] += m['flops']
+        g['bytes'] += m['bytes']
+    # the leg's own roofline: its dominant kernel family re-issued back to back between two HIP events (as the train step's families are)
+    from hipdp import ops
+    fam = {}
+    for kname, g in groups.items():
+        plan = ops.NativePlan(rt, [(o, False) for o in g['ops']], mode='native')
+        plan.run(rt)
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record(torch.cuda.current_stream())
+        for _ in range(5):
+            plan.run(rt)
+        f1.record(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        fam[kname] = f0.elapsed_time(f1) / 5
+    dom = max(fam, key=fam.get)
+    g = groups[dom]
+    t = fam[dom] * 1e-3
+    roof = dict(kernel=dom, launches_per_batch=len(g['ops']), avg_launch_us=round(t / len(g['ops']) * 1e6, 2), share_of_batch=round(fam[dom] / sum(fam.values()), 3),
+                mfma=dict(achieved=round(g['flops'] / t / 1e12, 2), peak=PEAK_MFMA_F32 / 1e12, unit='TFLOP/s', frac=round(g['flops'] / t / PEAK_MFMA_F32, 4)),
+                hbm=dict(achieved=round(g['bytes'] / t / 1e9, 1), peak=PEAK_HBM / 1e9, unit='GB/s', frac=round(g['bytes'] / t / PEAK_HBM, 4)))
     return dict(value=round(B / (ms * 1e-3), 1), unit='depth-crops/sec', ms_per_batch=round(ms, 4), batch=B, launches=len(ev_eng.fwd),
-                launches_by_family=names, finite=bool(np.isfinite(out).all()),
+                launches_by_family=names, finite=bool(np.isfinite(out).all()), roofline=roof,
                 mode='deterministic forward (stored BatchNorm statistics), inputs resident, HIP events over %d batches' % steps)
 
 

@@ -593,7 +593,13 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     a.sg.m_tw2 = c3_magic(TW + 2);
     a.sg.lqp = ilog2(((precision && Ci < 32) ? 32 : Ci) / 4);
     int bn = Co >= 64 ? 64 : (Co >= 32 ? 32 : 16);
-    while (bn > 16 && (long)nblk * dpp_cdiv(Co, bn) < 1024) bn >>= 1;     // ~4 workgroups per CU (measured: 256 -> 1024 is ~0.5 % of the step)
+    // The column tile is halved while the grid is below ~2 workgroups per CU.  Round 5, same-box A/B of the bs128 step over 200 steps
+    // (tools/ab_r05.sh, profiles/r05_ab.txt): 1024 (rounds 1-4) 3.463 / 3.462 ms, 512 3.440, 256 3.548 -- with 512 the 32-channel layers of
+    // stage 2 (512 pixel tiles) keep their 32 columns together (one halo staging + BatchNorm prologue per tile instead of two), the
+    // 64-channel layers of stages 3-4 (128 tiles) still go to four workgroups per tile; with 256 those serialise (the VERDICT r4 proposal:
+    // measured slower).  256x256 bf16: 8.214 -> 8.160 ms.  DPP_C3_MIN_WGS overrides (experiments).
+    static const long min_wgs = []() { const char* e = getenv("DPP_C3_MIN_WGS"); return (e && atol(e) > 0) ? atol(e) : 512L; }();
+    while (bn > 16 && (long)nblk * dpp_cdiv(Co, bn) < min_wgs) bn >>= 1;
     size_t halo = (size_t)a.img * (TH + 2) * (TW + 2);
     // bytes of one image row: f32 [Ci + 4], bf16 [max(Ci, 32) + 8]
     const size_t rowb = precision ? (size_t)((Ci < 32 ? 32 : Ci) + 8) * 2 : (size_t)(Ci + 4) * sizeof(float);

@@ -162,11 +162,7 @@ class ParamStore(object):
         return value.reshape(-1)
 
     def _from_kernel(self, s, flat):
-        if s['kind'] == 'conv_w':
-            return layout.conv_w_from_kernel(flat, s['shape'])
-        if s['kind'] == 'fc_w' and s['info'] is not None:
-            return _fc_rows(flat.reshape(s['shape']), s['info'], layout.fc_rows_nhwc_to_nchw)
-        return flat.reshape(s['shape']).copy()
+        return layout.from_kernel(s['kind'], s['info'], s['shape'], flat)
 
     def _write(self, i, value):
         s = self.slots[i]
@@ -225,18 +221,7 @@ class ParamStore(object):
                                "device parameter store was rebuilt): compile the net again")
 
 
-def _fc_rows(W, info, fn):
-    """Row permutation between the reference's NCHW flatten order and the NHWC order of the activations: one (C, H, W)
-    block, or several side by side when the FC input is a concatenation of flattened maps (ScaleNet)."""
-    if isinstance(info[0], int):
-        return fn(W, *info)
-    out, o = [], 0
-    for (Cc, H, Wd) in info:
-        n = Cc * H * Wd
-        out.append(fn(W[o:o + n], Cc, H, Wd) if H * Wd > 1 else W[o:o + n])
-        o += n
-    assert o == W.shape[0]
-    return np.concatenate(out, axis=0)
+_fc_rows = layout.fc_rows
 
 
 def _layer_kind(layer):

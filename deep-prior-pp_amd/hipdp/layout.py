@@ -36,3 +36,27 @@ def nchw_to_nhwc(x):
 
 def nhwc_to_nchw(x):
     return np.ascontiguousarray(np.asarray(x).transpose(0, 3, 1, 2))
+
+
+def fc_rows(W, info, fn):
+    """Row permutation between the reference's NCHW flatten order and the NHWC order of the activations: one (C, H, W) block, or
+    several side by side when the FC input is a concatenation of flattened maps (ScaleNet)."""
+    if isinstance(info[0], int):
+        return fn(W, *info)
+    out, o = [], 0
+    for (Cc, H, Wd) in info:
+        n = Cc * H * Wd
+        out.append(fn(W[o:o + n], Cc, H, Wd) if H * Wd > 1 else W[o:o + n])
+        o += n
+    assert o == W.shape[0]
+    return np.concatenate(out, axis=0)
+
+
+def from_kernel(kind, info, shape, flat):
+    """A parameter's value in the reference's layout from its kernel-layout slice of the flat device buffer (kind: 'conv_w' | 'fc_w' |
+    'vec'; info: the (C, H, W) block(s) of an FC behind a conv map, else None)."""
+    if kind == 'conv_w':
+        return conv_w_from_kernel(flat, shape)
+    if kind == 'fc_w' and info is not None:
+        return fc_rows(flat.reshape(shape), info, fc_rows_nhwc_to_nchw)
+    return flat.reshape(shape).copy()

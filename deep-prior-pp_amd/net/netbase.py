@@ -9,6 +9,7 @@ when it appends the PCA-prior layer).
 """
 import difflib
 import gzip
+import os
 import pickle
 import time
 
@@ -286,10 +287,12 @@ class NetBase(object):
 
     def saveAsync(self, filename, skip_if_busy=False):
         """save() off the calling thread (the epoch loop's per-epoch `net_last.pkl`, /root/reference/src/trainer/nettrainer.py:816-820:
-        a 75 MB protocol-2 pickle is 0.4 s of host time per epoch of the 128x128 ResNet).  The parameters are copied device-to-device
-        into a staging buffer on the current stream (50 us; training may go on changing the live ones), that buffer goes to
-        page-locked host memory on the copy stream, and a worker thread converts the layouts and writes the SAME bytes save() writes.
-        joinSave() -- called by the next saveAsync / save and at the end of train() -- waits for it.
+        a 75 MB protocol-2 pickle is 0.6 s of interpreter time per epoch of the 128x128 ResNet).  The parameters are copied
+        device-to-device into a staging buffer on the current stream (50 us; training may go on changing the live ones), that buffer goes
+        to page-locked host memory on the copy stream, a helper thread dumps it raw (GIL released) and a writer PROCESS
+        (hipdp/ckpt_writer.py: NumPy only) converts the layouts and writes the SAME bytes save() writes -- a writer thread would hold the
+        GIL for the pickle and stall the training thread with it.  joinSave() -- called by the next saveAsync / save and at the end of
+        train() -- waits for it.
         skip_if_busy: for a file that is rewritten over and over (`net_last.pkl`): when the writer of the previous snapshot is still at
         work -- epochs shorter than a checkpoint write -- this snapshot is dropped instead of stalling the epoch loop behind it; the
         file then holds the state of the previous epoch until the next one lands.  Returns True when a snapshot was started / written."""
@@ -297,10 +300,17 @@ class NetBase(object):
         if store is None or not hasattr(store.rt, 'download_async'):
             self.save(filename)
             return True
+        names = [[getattr(p, 'auto_name', None) for p in layer.params + layer.params_nontrained] for layer in self.layers]
+        if any(n not in store.by_param for ns in names for n in ns):
+            self.save(filename)                  # a parameter that does not live in the device store: the plain path reads it
+            return True
         pend = self.__dict__.get('_save_pending')
         if skip_if_busy and pend is not None and pend[0].is_alive():
             return False
         self.joinSave()
+        import subprocess
+        import sys
+        import tempfile
         import threading
         rt = store.rt
         st = self.__dict__.setdefault('_save_stage', {})
@@ -311,21 +321,30 @@ class NetBase(object):
         rt.copy(st['nt'], store.nt)
         rw, st['hw'] = rt.download_async(st['w'], st['hw'])
         rn, st['hnt'] = rt.download_async(st['nt'], st['hnt'])
-        # everything that reads the net object is done NOW, on the caller's thread: the worker only sees the copies
-        slots = [(s['param'].auto_name, s['trained'], s['off'], s['size'], dict(s)) for s in store.slots]
-        header_state = dict(cls=self.__class__.__name__, network=self.__str__(),
-                            layers=[(layer.layerNum, [getattr(p, 'auto_name', None) for p in layer.params + layer.params_nontrained],
-                                     [p for p in layer.params + layer.params_nontrained]) for layer in self.layers])
+        # everything that reads the net object is done NOW, on the caller's thread
+        meta = {'class': self.__class__.__name__, 'network': self.__str__(), 'n_w': int(store.n_w), 'n_nt': int(store.n_nt),
+                'layers': [(layer.layerNum, ns) for layer, ns in zip(self.layers, names)],
+                'slots': [(s['param'].auto_name, 'w' if s['trained'] else 'nt', s['off'], s['size'], s['kind'], s['info'], tuple(s['shape']))
+                          for s in store.slots]}
+        tmpdir = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
+        tag = 'dpp_ckpt_%d_%d' % (os.getpid(), id(self) & 0xffffff)
+        meta_path, raw_path = os.path.join(tmpdir, tag + '.meta'), os.path.join(tmpdir, tag + '.f32')
+        pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # the directory that holds hipdp/
         err = []
 
         def work():
             try:
-                flat = {True: rw.get(), False: rn.get()}
-                bulk = {name: store._from_kernel(sl, flat[tr][off:off + size]) for (name, tr, off, size, sl) in slots}
-                state = dict([('class', header_state['cls']), ('network', header_state['network'])])
-                for num, names, params in header_state['layers']:
-                    state['{}-values'.format(num)] = [numpy.array(bulk[n] if n in bulk else p.get_value()) for n, p in zip(names, params)]
-                self._write_checkpoint(state, filename)
+                with open(meta_path, 'wb') as fh:
+                    pickle.dump(meta, fh, 4)
+                with open(raw_path, 'wb') as fh:          # ndarray.tofile releases the GIL while it writes
+                    numpy.ascontiguousarray(rw.get(), numpy.float32).reshape(-1).tofile(fh)
+                    numpy.ascontiguousarray(rn.get(), numpy.float32).reshape(-1).tofile(fh)
+                env = dict(os.environ, PYTHONPATH=pkg + os.pathsep + os.environ.get('PYTHONPATH', ''))
+                r = subprocess.run([sys.executable, '-m', 'hipdp.ckpt_writer', meta_path, raw_path, filename], env=env,
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                if r.returncode != 0:
+                    raise RuntimeError("checkpoint writer failed for %s: %s" % (filename, r.stdout.decode(errors='replace')[-2000:]))
+                print('Saved model parameter to {}'.format(filename))
             except BaseException as e:           # noqa: BLE001  (re-raised by joinSave on the caller's thread)
                 err.append(e)
         th = threading.Thread(target=work, name='dpp-checkpoint')
