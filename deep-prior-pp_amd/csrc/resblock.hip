@@ -403,8 +403,10 @@ extern "C" int dpp_resblock_eval(const dpp_resblock_desc* desc, dpp_stream_t str
     RBArgs a;
     a.d = d;
     a.prof = dpp_prof_buffer;
-    // the tile follows from the bottleneck width alone (never from the batch): 8 x 16 (16 channels), 8 x 8 (32), 4 x 8 (64)
-    const int th = d.Nb == 64 ? 4 : 8, tw = d.Nb == 16 ? 16 : 8;
+    // the tile follows from the bottleneck width alone (never from the batch): 8 x 8 (16 and 32 channels), 4 x 8 (64).  (16 channels: 8 x 16
+    // tiles -- 1.4x instead of 1.56x halo recomputation, but 62 KB of LDS = two workgroups per CU -- measured 13 us per forward pass slower
+    // than 8 x 8 with four per CU: these blocks are bound by memory-level parallelism.  32 channels on 4 x 8 tiles: 30 us slower.)
+    const int th = d.Nb == 64 ? 4 : 8, tw = 8;
     a.lth = rb_ilog2(th); a.ltw = rb_ilog2(tw);
     a.tiles_x = dpp_cdiv(d.Wo, tw); a.tiles_y = dpp_cdiv(d.Ho, th);
     a.ntiles = a.tiles_x * a.tiles_y * d.N;
@@ -422,7 +424,7 @@ extern "C" int dpp_resblock_eval(const dpp_resblock_desc* desc, dpp_stream_t str
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_eval_kernel<NB_, BM_, RT_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         DPP_LAUNCH((resblock_eval_kernel<NB_, BM_, RT_, P_>), dim3(a.ntiles), dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
 #define DPP_RB(NB_, BM_, RT_) do { if (proj) DPP_RBK(NB_, BM_, RT_, true); else DPP_RBK(NB_, BM_, RT_, false); } while (0)
-    if (d.Nb == 16) DPP_RB(16, 128, 3);
+    if (d.Nb == 16) DPP_RB(16, 64, 2);
     if (d.Nb == 32) DPP_RB(32, 64, 2);
     if (d.Nb == 64) DPP_RB(64, 32, 1);
 #undef DPP_RB

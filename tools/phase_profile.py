@@ -131,7 +131,7 @@ def resblock_case(label, N, H, Nb, proj=False):
     kw = dict(Wsc=w(Cout, Cin), bsc=vec(Cout)) if proj else {}
     L = ops.resblock_eval(rt, X, N, Hi, Hi, Cin, s, Cout, Nb, bns[0], bns[1], bns[2], w(Nb, Cin), vec(Nb), w(Nb, 9, Nb), vec(Nb), w(Cout, Nb), vec(Cout),
                           Y, **kw)
-    th, tw = (4 if Nb == 64 else 8), (16 if Nb == 16 else 8)
+    th, tw = (4 if Nb == 64 else 8), 8
     profile(label, L, N * -(-H // th) * -(-H // tw), nphase=8)
 
 
