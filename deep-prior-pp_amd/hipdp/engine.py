@@ -19,32 +19,11 @@ from ctypes import c_int as C_int
 import numpy as np
 
 from . import evalfuse, layout, ops
+from . import heuristics as hz
 from .lib import Act, RowMap
 from .ops import Plan
 from .runtime import default_runtime
 
-
-
-def knob(name, default):
-    """Experiment knobs (tile / kernel-variant choices the measurements of DESIGN.md section 5 were made with, and the ablation
-    DPP_WHATIF_SKIP of tools/whatif.sh).  The product ignores them: they are read only when DPP_EXPERIMENT=1 is set as well, which
-    the tools/ scripts do and bench.py stamps into its output line (config.knobs)."""
-    if os.environ.get('DPP_EXPERIMENT', '0') != '1':
-        return default
-    return os.environ.get(name, default)
-
-
-BN_RPB_TARGET_BLOCKS = int(knob('DPP_BN_BLOCKS', '1024'))
-# BatchNorm backward of the small maps: when the per-block sums of a BatchNorm are at most this many blocks, the finalize is done by
-# every workgroup of the apply pass itself (dpp_bn_bwd_finalize_apply: one launch instead of two in the data-gradient chain; the
-# stand-alone finalize is a launch + one memory round trip, 4.8 us).  0 = always two launches (the default).
-# Measured on the MI355X (profiles/r04_whatif.txt): the fused launch takes 5.9 us against 5.5 + 4.6 and the single-stream kernel time of
-# a bs128 step falls by 25 us (<= 128 blocks: 11 BatchNorms) / 54 us (<= 256: 31) -- but the two-stream step does not move: 3.503-3.508
-# ms (128) and 3.531 (256) against 3.490 with two launches.  The backward pass is not a chain any more: the data-gradient stream and
-# the filter-gradient branch end together and share the machine (dropping ALL 61 bn_bwd_finalize launches buys 0.07 ms, the 61
-# forward bn_finalize launches 0.37 ms), so a launch saved on the chain is not time saved.
-BN_BWD_FUSE_MAX_BLOCKS = int(knob('DPP_BN_BWD_FUSE_NB', '0'))
-BN_BWD_FUSE_TARGET_WGS = int(knob('DPP_BN_BWD_FUSE_WGS', '512'))
 
 
 def _pad4(n):
@@ -87,11 +66,11 @@ class TensorV(object):
 class BNState(object):
     def __init__(self, layer, C, M, world=1):
         self.layer, self.C, self.M = layer, C, M
-        self.rpb = max(32, -(-M // BN_RPB_TARGET_BLOCKS))
+        self.rpb = max(32, -(-M // hz.BN_RPB_TARGET_BLOCKS))
         if world > 1:
             # sync-BN concatenates the partials of all ranks: every block must hold exactly rpb rows
             self.rpb = M if M < 32 else 32
-            while self.rpb * 2 <= max(32, M // BN_RPB_TARGET_BLOCKS) and M % (self.rpb * 2) == 0:
+            while self.rpb * 2 <= max(32, M // hz.BN_RPB_TARGET_BLOCKS) and M % (self.rpb * 2) == 0:
                 self.rpb *= 2
             if M % self.rpb:
                 raise NotImplementedError("sync-BN needs the per-rank pixel count to be a multiple of %d" % self.rpb)
@@ -314,252 +293,6 @@ def get_store(net, rt, layers):
     return store
 
 
-GEMM_TARGET_BLOCKS = int(knob('DPP_GEMM_TARGET_BLOCKS', '1024'))
-
-
-def gemm_plan(M, N, K, allow_split=True):
-    """(tile, splitk) heuristics.  These GEMMs are latency / HBM-bound (K and N of 16..256), so the tile is the LARGEST one
-    that still gives about GEMM_TARGET_BLOCKS workgroups (4 per CU: enough loads in flight to hide HBM latency); K is split
-    when even the smallest tile leaves the grid short."""
-    if M <= 16:
-        bm, bn, wm = 16, 64, 1
-    elif M <= 32:
-        bm, bn, wm = 32, 64, 1
-    else:
-        wm = 4
-        cands = [(128, 64), (64, 64), (128, 32), (64, 32), (128, 16), (64, 16)]
-        if knob('DPP_NO_128x64', '1') != '0':
-            cands = cands[1:]          # measured: 64x64 beats 128x64 on every conv shape of the net (gemm_micro.py)
-        cands = [(a, b) for (a, b) in cands if b <= max(16, 16 * (-(-N // 16))) or b == 16]
-        bm, bn = cands[-1]
-        for (a, b) in cands:
-            if (-(-M // a)) * (-(-N // b)) >= GEMM_TARGET_BLOCKS:
-                bm, bn = a, b
-                break
-    tiles = (-(-M // bm)) * (-(-N // bn))
-    splitk = 1
-    if allow_split and tiles < 512 and K >= 256:
-        # few output tiles, long K (the FC layers): split K until ~2048 workgroups with >= 128 of K each
-        splitk = int(min(max(1, 2048 // tiles), max(1, K // 128), 256))
-    return (bm, bn, wm), splitk
-
-
-# Deterministic-mode engines (computeOutput, validation, the cascade's refinement net): a whole bottleneck block as ONE launch
-# (hipdp/evalfuse.py, csrc/resblock.hip) and the stored-statistics coefficients of all remaining BatchNorms in one launch.
-# DPP_EVAL_FUSE=0: the layer-by-layer decomposition of rounds 1-4 (131 launches per forward pass of the 128x128 ResNet).
-EVAL_FUSE = knob('DPP_EVAL_FUSE', '1') != '0'
-OVERLAP_ALLREDUCE = knob('DPP_OVERLAP_ALLREDUCE', '1') != '0'
-EARLY_BUCKET_MIN = int(knob('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elements; FC1 of the 128x128 ResNet has 16.8 M
-# 1x1 convolutions can read the BatchNorm gradient as (G, x) instead of a materialised dX (see _resolve_view).
-#   1: data AND filter gradient take the two-tensor operand.  Takes 20 bn_bwd_apply launches (107 us) off the main chain but
-#      makes 40 GEMMs 3.5 us slower each, half of them on the gradient branch, which the end of the step waits for
-#      (4.87 vs 4.71 ms per step).
-#   2: only the data gradient does, and it leaves the dX it forms in memory for the filter gradient (dpp_act.out), which
-#      then starts after it instead of beside it.
-#   3 (round 4): as 2, but only where that data gradient runs on the wave-autonomous kernel (dpp_gemm variant 4: the bottleneck
-#      ENTRIES, whose data gradient expands K = 16 / 32 / 64 channels to 4 K).  There the operand is a few registers of a kernel that
-#      is bound by its OUTPUT: alone the launch costs +1.2 .. 2 us (tools/gemm_micro.py expand: 8.8 -> 10.3 us at stage 3/4) against
-#      the 6-9 us bn_bwd_apply launch it replaces.  In the step it still loses (3.60 vs 3.50 ms): the 16 filter gradients that read
-#      the kept dX start one launch later, the gradient branch -- which ends together with the chain -- costs 0.27 instead of 0.18 ms
-#      (tools/branch_probe.py), and the chain itself measures the same (3.26 vs 3.27 ms without the branch).  Off.
-LAZY_BN_BWD = int(knob('DPP_LAZY_BN_BWD', '0'))
-BF16_DEFAULT = os.environ.get('DPP_BF16', '0') == '1'
-# bf16 mode (BASELINE config 5) also STORES the activation tensors -- every [pixels][channels] tensor a convolution writes -- as
-# bfloat16 (ABI v9, DPP_ST_*): rounded by the producer's epilogue (statistics from the f32 values), widened by every reader.  At
-# 256x256 the step is bandwidth-bound and these tensors are read five to six times each.  DPP_BF16_STORE=0: f32 storage (rounds 2-3).
-BF16_STORE = knob('DPP_BF16_STORE', '1') != '0'
-# ... and the GRADIENTS of those tensors (the masked gradient G a data-gradient epilogue writes into a BatchNorm view, the dX that
-# bn_bwd_apply writes): the backward pass moves twice the bytes of the forward pass.  DPP_BF16_GRADS=0: float32 gradients.
-BF16_GRADS = knob('DPP_BF16_GRADS', '1') != '0'
-# ... and runs the channel-expanding 1x1 convolutions / the data gradients of the reducing ones (dpp_gemm variant 4, K = 32 / 64) on
-# bf16 MFMA operands (dpp_gemm_desc.precision).  DPP_BF16_GEMM=0: f32 MFMA there (rounds 2-3: only the 3x3 convolutions and FC1).
-BF16_GEMM = knob('DPP_BF16_GEMM', '1') != '0'
-# ADAM of the FC1 weight (90 % of the parameters, 470 MB of optimizer traffic) inside the backward pass: its gradient is final a few
-# kernels into the pass, so the update runs on the gradient branch under the latency-bound data-gradient chain instead of in the
-# serial tail of the step (step_plan only: cost_and_grads / allreduce paths keep backward and update apart).
-# Measured on the MI355X (tools/exp_tail.sh, profiles/r02_tail_experiments.txt): 4.19-4.20 vs 4.18 ms per step -- the gradient branch
-# finishes together with the data-gradient chain (tools/tail_probe.py: 2.51 vs 2.53 ms), so work moved onto it comes back as a longer
-# wait at the join.  Off by default; the plan surgery stays tested (tests/test_engine.py).
-EARLY_ADAM = knob('DPP_EARLY_ADAM', '0') != '0'
-# Filter / bias gradient partials are summed by dpp_reduce_multi.  One launch at the end of the pass reads all of them (224 MB) in the
-# serial tail of the step; with a threshold the jobs collected so far are reduced on the gradient branch as soon as they amount to
-# this many bytes (their producers are on that branch or already issued on the main stream), and the tail launch keeps the rest.
-# Measured: 4.21 (16 MB) / 4.19 (64 MB) vs 4.18 ms with the single launch, for the same reason as EARLY_ADAM.  0 = one launch (default).
-EARLY_REDUCE_BYTES = int(knob('DPP_EARLY_REDUCE_MB', '0')) << 20
-# the partials collected before the stem reduced on the branch beside the stem's filter gradient: 3.661-3.669 vs 3.673-3.680 ms over
-# 300-step runs -- the branch, not the main stream, is what the join waits for; off
-TAIL_REDUCE = knob('DPP_TAIL_REDUCE', '0') != '0'
-# FC1 (the HiddenLayer behind the last conv map) on the weight-streaming kernels of dpp_fc_gemm instead of the generic dpp_gemm.
-# f32: the three-stage kernel (fc_stream_kernel: 128 x 128 / 128 x 64 tiles, whole tiles only) runs the batch-128 FC1 forward /
-# data gradient in 53 / 70 us against dpp_gemm's 102 / 104 us; the older double-buffered kernel, which takes ragged shapes, only
-# ties with dpp_gemm in f32 (profiles/r02_fc1_kernels.txt), so f32 goes there only when the shape fits the three-stage kernel.
-# bf16 (config 5) always uses dpp_fc_gemm: dpp_gemm has no bf16 counterpart.
-#   DPP_FC1_STREAM=auto (default) | bf16: bf16 only | 1: always | 0: never (bf16 FC1 then falls back to f32 dpp_gemm)
-FC1_STREAM = knob('DPP_FC1_STREAM', 'auto')
-FC1_WGRAD_STREAM = knob('DPP_FC1_WGRAD_STREAM', '1') != '0'       # FC1's filter gradient on dpp_fc_wgrad_stream (f32)
-FC1_WGRAD_DEFER = int(knob('DPP_FC1_WGRAD_DEFER', '0'))          # see CompiledNet._defer_fc1_wgrad
-FC1_KCHUNK = int(knob('DPP_FC1_KCHUNK', '0'))
-FC1_SLICES = int(knob('DPP_FC1_SLICES', '32'))
-FC1_MIN_K = int(knob('DPP_FC1_MIN_K', '4096'))
-
-
-def is_fc1_shape(Nb, K, Nout):
-    """The weight-streaming shape: tens of MB of weights for at most a few hundred rows."""
-    return K >= FC1_MIN_K and Nout >= 64 and Nout % 4 == 0 and K % 4 == 0
-ROWSTREAM = knob('DPP_ROWSTREAM', '0') != '0'      # measured: no gain over the LDS-tiled kernel yet
-
-def rowstream_plan(M, N, K, b_kc):
-    """Tile of the barrier-free row-streaming GEMM variant for conv-shaped problems (M = pixels >> K, N), or None when it
-    does not apply: the whole K x bn weight slice must fit the 64 KB LDS window, and the grid should fill the chip."""
-    if not ROWSTREAM or M < 2048:
-        return None
-    K16 = (K + 15) // 16 * 16
-    for bn in (64, 32, 16):
-        if bn > 16 and bn >= 2 * N:
-            continue
-        lds = (bn * (K16 + 4) if b_kc else K16 * (bn + 4)) * 4
-        if lds > 48 * 1024:
-            continue
-        bm = 128 if (M // 128) * (-(-N // bn)) >= 1024 else 64
-        return (bm, bn, 4)
-    return None
-
-
-# dpp_gemm variant 2 (gemm_ksplit_kernel): 32 rows x all columns x the WHOLE K per workgroup, one memory round trip, the four waves
-# split K.  For the long-K / narrow-N 1x1 convolutions of the late stages, K-contiguous A, whole tiles only.
-#   DPP_KSPLIT = 0: off | 1: K = 256 (stage 3 / 4 bottleneck entries and the data gradients of their exits) | 2: K = 128 as well
-KSPLIT = int(knob('DPP_KSPLIT', '2'))
-KSPLIT_MAX_M = int(knob('DPP_KSPLIT_MAX_M', '16384'))
-
-
-def ksplit_plan(M, N, K):
-    if KSPLIT <= 0 or M % 32 or M > KSPLIT_MAX_M * (2 if K == 128 else 1):
-        return None
-    if K == 256 and N % 64 == 0:
-        return (32, 64, 4)
-    if K == 128 and N % 32 == 0 and KSPLIT >= 2:
-        return (32, 32, 4)
-    return None
-
-
-# dpp_gemm variant 3 (gemm_stream16_kernel): the stage-1 bottleneck entries and the data gradients of their exits (K = 64 -> 16
-# columns; 2 (default): also the K = 16 -> 64 columns data gradients; 3: and those forward convolutions) as a barrier-free row stream,
-# see csrc/gemm.hip.  DPP_STREAM16 = 0 | 1 | 2 | 3.  No lower bound on the row count by default:
-# the kernel sums k in another order than the LDS-tiled one, and a frame's joints must not depend on the batch it is evaluated in
-# (tests/test_full_size.py compares batches of 8 and 128 at 1e-4 mm), so the choice of kernel must not depend on the batch either.
-STREAM16 = int(knob('DPP_STREAM16', '2'))
-STREAM16_MIN_M = int(knob('DPP_STREAM16_MIN_M', '128'))
-
-
-def stream16_plan(M, N, K, forward):
-    """K = 64 -> 16 columns: 128 rows per workgroup; K = 16 -> 64 columns: 64 rows, data gradients only (DPP_STREAM16 >= 2; the
-    forward pass gains nothing there -- 22.8 vs 23.5 us: reading the residual and writing 256-byte rows 4 bytes per lane costs what the
-    LDS transposition did -- and its other summation order put the bs256 training-mode forward at 1.02e-5 of the output scale from
-    the float32 oracle, against the 1e-5 bar of tests/test_configs.py)."""
-    if STREAM16 <= 0 or M < STREAM16_MIN_M:
-        return None
-    if N == 16 and K == 64 and M % 128 == 0:
-        return (128, 16, 4)
-    if N == 64 and K == 16 and M % 64 == 0 and (STREAM16 >= 3 or (STREAM16 >= 2 and not forward)):
-        return (64, 64, 4)
-    return None
-
-
-# dpp_gemm variant 4 (gemm_expand_kernel): the channel-expanding 1x1 convolutions (K = 16 / 32 / 64 -> N = 64 / 128 / 256 columns: the
-# bottleneck exits, with bias + residual + statistics) and the data gradients of the reducing ones (same shapes, BatchNorm-backward
-# epilogue) as wave-autonomous 64-column strips -- no LDS, no barrier, 16-byte accesses straight from the MFMA D layout, see
-# csrc/gemm.hip.  DPP_EXPAND = 0 | 1 (forward) | 2 (data gradients) | 3 (both).  Rows per wave (= rows per statistics block) by stage.
-EXPAND = int(knob('DPP_EXPAND', '3'))
-EXPAND_RPW = tuple(int(v) for v in knob('DPP_EXPAND_RPW', '128,64,32').split(','))      # stage 1 | stage 2 | stages 3-4
-
-
-def expand_plan(M, N, K, forward):
-    if not (EXPAND & (1 if forward else 2)) or K not in (16, 32, 64) or N % 64 or N < 2 * K:
-        return None
-    rpw = EXPAND_RPW[0 if M >= 65536 else (1 if M >= 16384 else 2)]
-    while rpw > 32 and M % rpw:
-        rpw //= 2
-    if M % rpw:
-        return None
-    return (rpw, 64, 4)
-
-
-def conv3x3_bm(pixels, Co):
-    """Rows per workgroup of the 3x3 kernel (the choice dpp_conv3x3 makes for bm = 0, made explicit so that the host knows
-    the row-block count of the fused epilogue partials)."""
-    return 128 if (pixels // 128) * (-(-Co // 64)) >= 512 else 64
-
-
-# Projection shortcuts of the residual blocks on the second stream beside the bottleneck (see _emit_add).  DPP_SIDE_SHORTCUT=0: the
-# later convolution of a sum absorbs the add and everything stays on the main stream (rounds 1-3).
-SIDE_SHORTCUT = knob('DPP_SIDE_SHORTCUT', '1') != '0'
-
-
-# 3x3 convolutions of the narrow square layers (and their data gradients) on the barrier-free dpp_conv3x3_stream for these channel
-# counts.  OFF by default: measured on the MI355X (profiles/r04_conv3x3_stream.txt) the kernel is no faster than the LDS-tiled one on
-# the shapes it was written for -- stage 1 (131 072 px, 16 -> 16) 14.7 us plain / 17.4 us with prologue + statistics against 12.1 /
-# 13.4 us, insensitive to the tiles per wave (1 | 2 | 4), and the bs128 step is 3.55 ms with it against 3.49 ms; stage 2 (32 -> 32,
-# 144 filter registers, one wave per SIMD) 16-22 us against 11-12 us.  Every wave re-loads the 9 KB filter through the texture path
-# (twice the operand traffic) and redoes the BatchNorm prologue for each of the nine taps; the tiled kernel pays one barrier per tap
-# but stages and activates each pixel once.
-CONV3_STREAM_C = tuple(int(v) for v in knob('DPP_CONV3_STREAM_C', '').split(',') if v)
-
-
-WGRAD_TARGET_BLOCKS = int(knob('DPP_WGRAD_TARGET_BLOCKS', '256'))
-
-
-def wgrad_plan(Co, Ci, K):
-    """Filter gradients reduce over K = pixels (1e4..1e5) into a small [Co][Ci] matrix.  Measured (tools/gemm_micro.py wgrad):
-    the fewest, largest tiles that cover [Co][Ci] win, with the pixel reduction split until 512..1024 workgroups are in
-    flight but no slice shorter than ~128 pixels."""
-    if Co <= 16:
-        tile = (16, 64, 1)
-    elif Co <= 32:
-        tile = (32, 64, 1)
-    else:
-        tile = (64, 64 if Ci > 32 else (32 if Ci > 16 else 16), 4)
-    tiles = (-(-Co // tile[0])) * (-(-Ci // tile[1]))
-    splitk = int(max(1, min(WGRAD_TARGET_BLOCKS // tiles, max(K // 128, min(128, K // 64)))))
-    return tile, splitk
-
-
-# 1x1 filter gradients on the row-streaming kernel of csrc/wgrad.hip.  Measured on the MI355X (profiles/r03_wgrad_stream.txt): alone
-# (one stream) the kernel beats dpp_gemm's filter-gradient layout on every stage (stage 1: 14 vs 43 us per launch under the
-# profiler), but the gradient branch runs BESIDE the data-gradient chain, and there what counts is how little a launch takes
-# from the chain, not how fast it is: with 512 workgroups per launch the step got SLOWER (3.84 vs 3.77 ms), with 128 long-running
-# workgroups (256 rows per wave) on the stage-1 layers only it is 3.72 ms.  Stages 2-4 stay on dpp_gemm (3.76 / 3.84 ms with the
-# stream kernel there), as does the two-tensor dY operand of DPP_LAZY_BN_BWD.
-WGRAD_STREAM = knob('DPP_WGRAD_STREAM', '1') != '0'
-WGRAD_STREAM_RPW = tuple(int(v) for v in knob('DPP_WGRAD_STREAM_RPW', '256,128,128').split(','))      # stage 1 | stage 2 | stages 3-4
-WGRAD_STREAM_STAGES = knob('DPP_WGRAD_STREAM_STAGES', '1')            # which of them take the kernel
-
-
-# 3x3 filter gradients on dpp_wgrad3_stream for these channel counts (the rest stays on the LDS-tiled dpp_conv3x3_wgrad)
-WGRAD3_STREAM_C = tuple(int(v) for v in knob('DPP_WGRAD3_STREAM_C', '64').split(',') if v)
-
-
-WGRAD3_STREAM_SLICE_BUDGET = int(knob('DPP_WGRAD3_STREAM_SLICES', '1024'))       # slices of a 16-channel layer (9.2 KB each)
-
-
-def wgrad3_stream_rows(M, C):
-    """Pixel rows per wave of dpp_wgrad3_stream for a C -> C 3x3 layer over M pixels, or 0 (LDS-tiled kernel).  The partial slices of
-    a layer are held to ~9.4 MB (1 024 slices of 16 x 9 x 16, 256 of 32 x 9 x 32, 64 of 64 x 9 x 64): more slices is more waves but
-    the partials' write + re-read grows past the tensors themselves (tools/gemm_micro.py conv3, profiles/r03_wgrad3_stream.txt)."""
-    if C not in WGRAD3_STREAM_C:
-        return 0
-    slices = max(1, WGRAD3_STREAM_SLICE_BUDGET // max(1, (C // 16) ** 2))
-    return max(64, (M // slices) & ~3)
-
-
-def wgrad_stream_rows(M):
-    """Pixel rows per wave of dpp_wgrad_stream for a layer with M pixel rows, or 0: leave the layer on dpp_gemm."""
-    stage = 0 if M >= 65536 else (1 if M >= 16384 else 2)
-    if str(stage + 1) not in WGRAD_STREAM_STAGES:
-        return 0
-    r = WGRAD_STREAM_RPW[min(stage, len(WGRAD_STREAM_RPW) - 1)]
-    return r if M >= 1024 else 32
-
-
 class CompiledNet(object):
     def __init__(self, net, train=False, runtime=None, loss=None, weight_decay=0.0, dp=None, fuse_bn=True, bf16=None, optimizer=None,
                  fuse_blocks=None):
@@ -579,7 +312,7 @@ class CompiledNet(object):
         """
         self.rt = rt = runtime or default_runtime()
         self.optimizer = dict(optimizer) if optimizer else dict(name='ADAM')
-        self.prec = int(bool(BF16_DEFAULT if bf16 is None else bf16))
+        self.prec = int(bool(hz.BF16_DEFAULT if bf16 is None else bf16))
         self.store16 = self.grad16 = False                      # set below, once the layer list is known
         self.dp = dp                                  # hipdp.parallel.DataParallel or None
         # BatchNorm statistics / backward sums produced by the conv epilogues (off with sync-BN, whose partials are
@@ -595,8 +328,8 @@ class CompiledNet(object):
         resnet_like = all(_layer_kind(l) != 'ConvPoolLayer' or (tuple(l.cfgParams.filterDim) == (5, 5) and tuple(l.cfgParams.poolsize) == (2, 2)
                                                                  and l.cfgParams.nFilters <= 32 and l.cfgParams.activation is None)
                           for l in self.layers) and not any(v.kind == 'concat' for v in self.order)
-        self.store16 = bool(self.prec and BF16_STORE and resnet_like)         # conv outputs held as bf16 (see BF16_STORE)
-        self.grad16 = bool(self.store16 and BF16_GRADS)                        # ... and their gradients (see BF16_GRADS)
+        self.store16 = bool(self.prec and hz.BF16_STORE and resnet_like)         # conv outputs held as bf16 (see hz.BF16_STORE)
+        self.grad16 = bool(self.store16 and hz.BF16_GRADS)                        # ... and their gradients (see hz.BF16_GRADS)
         self.store = get_store(net, rt, self.layers)
         self.fwd, self.bwd, self.upd = Plan('forward'), Plan('backward'), Plan('update')
         self.views = {}
@@ -622,7 +355,7 @@ class CompiledNet(object):
             self.input_of[id(v)] = t
         self.x_in, self.in_shape = self.x_ins[0], self.x_ins[0].shape
         self._memo = {}
-        self.fuse_blocks = (EVAL_FUSE if fuse_blocks is None else bool(fuse_blocks)) and not train
+        self.fuse_blocks = (hz.EVAL_FUSE if fuse_blocks is None else bool(fuse_blocks)) and not train
         self.fused_blocks = []         # the blocks that became one launch (evalfuse.match_block dicts)
         self._bn_eval_jobs = []        # deterministic mode: (gamma, run_mean, run_inv_std, C, mean, inv_std, scale) of every BatchNorm
         self._beside = []           # (fork / join markers, launches) of the shortcuts moved beside the chain (see _emit_add)
@@ -767,18 +500,18 @@ class CompiledNet(object):
         return self._wseg
 
     def _fc1_stream(self, Nb, K, Nout):
-        if not is_fc1_shape(Nb, K, Nout) or FC1_STREAM == '0':
+        if not hz.is_fc1_shape(Nb, K, Nout) or hz.FC1_STREAM == '0':
             return False
-        if FC1_STREAM == '1' or self.prec == 1:
+        if hz.FC1_STREAM == '1' or self.prec == 1:
             return True
-        if FC1_STREAM != 'auto':
+        if hz.FC1_STREAM != 'auto':
             return False
         # f32: whole 128-row tiles in all three GEMMs (forward / data gradient rows = samples, filter gradient reduces over them),
-        # whole 32-deep chunks per K slice.  This is the one kernel choice that DOES depend on the batch (stream16_plan's rule, above,
+        # whole 32-deep chunks per K slice.  This is the one kernel choice that DOES depend on the batch (hz.stream16_plan's rule, above,
         # is about the convolutions): batches that are no multiple of 128 stay on dpp_gemm, whose K order differs.  The bar that
         # bounds the difference: tests/test_full_size.py evaluates the same frames in batches of 8 (dpp_gemm) and 128 (this kernel)
         # and holds the joints to 1e-4 mm.
-        splitk = max(1, min(FC1_SLICES, K // 512))
+        splitk = max(1, min(hz.FC1_SLICES, K // 512))
         return Nb % 128 == 0 and K % 128 == 0 and Nout % 64 == 0 and K % splitk == 0 and (K // splitk) % 32 == 0
 
     def _single_consumer(self, var):
@@ -869,9 +602,9 @@ class CompiledNet(object):
         # (resnet.py:117-123: c + sc) that is the bottleneck exit c, not the shortcut sc -- which then depends on nothing but the
         # block's input and runs on the second stream BESIDE the bottleneck's first two convolutions instead of behind them: the forward
         # pass is a pure dependent chain (profiles/r04_whatif.txt), and the three projection convolutions were 72 us of it.
-        q = max(cand, key=lambda x: (self._depth(x) if SIDE_SHORTCUT else 0, x.layer.layerNum))
+        q = max(cand, key=lambda x: (self._depth(x) if hz.SIDE_SHORTCUT else 0, x.layer.layerNum))
         p = b if q is a else a
-        beside = SIDE_SHORTCUT and self.train and p in cand and id(p) not in self._memo
+        beside = hz.SIDE_SHORTCUT and self.train and p in cand and id(p) not in self._memo
         if beside:
             self._emit(p.inputs[0])                          # its input chain belongs to the main stream (normally emitted already)
             n0 = len(self.fwd.ops)
@@ -942,7 +675,7 @@ class CompiledNet(object):
                     part = allp
                 self.fwd.add(ops.bn_finalize(rt, part, b.nb, M * W, b.rpb, C, b.gamma_buf, layer.cfgParams.epsilon, b.mean, b.inv_std,
                                              b.scale, b.run_mean, b.run_inv_std, layer.cfgParams.alpha, nseg=W))
-            elif EVAL_FUSE:
+            elif hz.EVAL_FUSE:
                 self._bn_eval_jobs.append((b.gamma_buf, b.run_mean, b.run_inv_std, C, b.mean, b.inv_std, b.scale))
             else:
                 self.fwd.add(ops.bn_eval_coeffs(rt, b.gamma_buf, b.run_mean, b.run_inv_std, C, b.mean, b.inv_std, b.scale))
@@ -1030,15 +763,15 @@ class CompiledNet(object):
         M = N * Ho * Wo
         epi = None
         if k == (1, 1):
-            tile, _ = gemm_plan(M, Co, Ci, allow_split=False)
-            rs = rowstream_plan(M, Co, Ci, True)
+            tile, _ = hz.gemm_plan(M, Co, Ci, allow_split=False)
+            rs = hz.rowstream_plan(M, Co, Ci, True)
             if rs is not None:
                 tile = rs
-            ks = ksplit_plan(M, Co, Ci) if (s[0] == 1 and rs is None) else None
+            ks = hz.ksplit_plan(M, Co, Ci) if (s[0] == 1 and rs is None) else None
             if ks is not None:
                 tile = ks
-            ex = expand_plan(M, Co, Ci, True) if (s[0] == 1 and rs is None and ks is None) else None
-            s16 = stream16_plan(M, Co, Ci, True) if (s[0] == 1 and rs is None and ks is None and ex is None) else None
+            ex = hz.expand_plan(M, Co, Ci, True) if (s[0] == 1 and rs is None and ks is None) else None
+            s16 = hz.stream16_plan(M, Co, Ci, True) if (s[0] == 1 and rs is None and ks is None and ex is None) else None
             if s16 is not None:
                 tile = s16
             if ex is not None:
@@ -1050,10 +783,10 @@ class CompiledNet(object):
                 # (bf16 mode: the wave-autonomous kernel multiplies on the bf16 matrix pipe where K is a whole 32-deep step)
                 return ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
                                 bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=variant,
-                                name='conv1x1_%d' % layer.layerNum, precision=self.prec if (variant == 4 and Ci >= 32 and BF16_GEMM) else 0)
+                                name='conv1x1_%d' % layer.layerNum, precision=self.prec if (variant == 4 and Ci >= 32 and hz.BF16_GEMM) else 0)
             if variant in (2, 3, 4) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
                 # the shape asks for the kernel, the buffers rule it out (alignment / prologue): the generic tile, not a failed build
-                variant, (tile, _) = 0, gemm_plan(M, Co, Ci, allow_split=False)
+                variant, (tile, _) = 0, hz.gemm_plan(M, Co, Ci, allow_split=False)
             if want_stats:
                 nblk = -(-M // tile[0])
                 out.stats = (rt.alloc((nblk, 2, Co), zero=False), nblk, tile[0])
@@ -1067,7 +800,7 @@ class CompiledNet(object):
             self.fwd.add(ops.conv3x3_stream(rt, src.base.buf, N, Hi, Wi, Ci, st.view(layer.W), out.buf, actX=act, bias=st.view(layer.b), epi=epi,
                                             name='conv3x3_%d' % layer.layerNum))
         else:
-            bm = conv3x3_bm(M, Co)
+            bm = hz.conv3x3_bm(M, Co)
             if want_stats:
                 th, tw, img = (C_int() for _ in range(3))
                 nblk = rt.lib.dpp_conv3x3_tiling(N, Hi, Wi, bm, th, tw, img)
@@ -1082,7 +815,7 @@ class CompiledNet(object):
     def _conv3_stream(self, N, H, W, Ci, Co, *bufs):
         """Whether a 3x3 layer (or its data gradient) runs on dpp_conv3x3_stream: a narrow square layer on float32 tensors in the
         float32 mode (the bf16 mode multiplies the 3x3 layers on the bf16 matrix pipe of the LDS-tiled kernel)."""
-        if Ci != Co or Ci not in CONV3_STREAM_C or self.prec:
+        if Ci != Co or Ci not in hz.CONV3_STREAM_C or self.prec:
             return False
         if any(b is not None and b.dtype == ops.BF16 for b in bufs):
             return False
@@ -1099,18 +832,18 @@ class CompiledNet(object):
         rt, st = self.rt, self.store
         act = self._act(src)
         if self._fc1_stream(Nb, K, Nout):
-            splitk = max(1, min(FC1_SLICES, K // 512))
+            splitk = max(1, min(hz.FC1_SLICES, K // 512))
             part = self.scratch(splitk * Nb * Nout)
             self.fwd.add(ops.fc_gemm(rt, src.base.buf, st.view(layer.W), None, Nb, Nout, K, 1, 0, K, Nout, Nout, actA=act, splitk=splitk,
-                                     partial=part, precision=self.prec, kchunk=FC1_KCHUNK, name='fc_%d' % layer.layerNum))
+                                     partial=part, precision=self.prec, kchunk=hz.FC1_KCHUNK, name='fc_%d' % layer.layerNum))
             self.fwd.add(ops.reduce_partials(rt, part, splitk, Nb * Nout, out.buf, bias=st.view(layer.b), nbias=Nout))
             self.layer_io[id(layer)] = dict(in_view=src, out=out)
             return View(out)
-        tile, splitk = gemm_plan(Nb, Nout, K)
+        tile, splitk = hz.gemm_plan(Nb, Nout, K)
         if K >= 4096 and Nb <= 128 and Nout >= 64:
             # weight-streaming shape (FC1: 67 MB of W for 128 rows): wide column tiles read W in 256 B rows, K split 512 deep
             # (tools/gemm_micro.py fc: all 128 rows in one tile halve the passes over W through L2, 96 -> 79 us)
-            tile, splitk = ((128, 64, 4) if Nb > 64 and knob('DPP_FC1_TILE128', '1') != '0' else (64, 64, 4)), max(1, K // 512)
+            tile, splitk = ((128, 64, 4) if Nb > 64 and hz.knob('DPP_FC1_TILE128', '1') != '0' else (64, 64, 4)), max(1, K // 512)
         act = self._act(src)
         if splitk > 1:
             part = self.scratch(splitk * Nb * Nout)
@@ -1217,17 +950,17 @@ class CompiledNet(object):
         # dX = scale*(G - c1 - xhat*c2) is never written: that convolution's data- and filter-gradient GEMMs form it from
         # (G, x) while they stage their operand (dpp_act mode 4), which removes a launch from the dependent chain and a pass
         # over the tensor.  The finalize then also writes the two per-channel constants that prologue needs.
-        lazy = LAZY_BN_BWD and not t.grad_written and not t.pending and self._produced_by_conv1x1(t)
-        if lazy and LAZY_BN_BWD == 3:
+        lazy = hz.LAZY_BN_BWD and not t.grad_written and not t.pending and self._produced_by_conv1x1(t)
+        if lazy and hz.LAZY_BN_BWD == 3:
             pl = self._producer(t)                       # conv Ci -> C; its data gradient is the GEMM  [M x C] . [C x Ci]
             src_t = self.layer_io[id(pl)]['in_view'].base
-            lazy = pl.cfgParams.stride[0] == 1 and src_t not in self.x_ins and expand_plan(M, src_t.C, C, False) is not None
+            lazy = pl.cfgParams.stride[0] == 1 and src_t not in self.x_ins and hz.expand_plan(M, src_t.C, C, False) is not None
         q, p = (rt.alloc(_pad4(C)), rt.alloc(_pad4(C))) if lazy else (None, None)
         fin = dict(bn=b, q=q, p=p) if lazy else {}
         fused = getattr(vg, 'fused_reduce', None)
         # few blocks of sums: the apply pass reduces them itself (one launch for finalize + apply)
         nbp = fused[1] if fused is not None else b.nb
-        one_launch = (not lazy and W <= 1 and 0 < nbp <= BN_BWD_FUSE_MAX_BLOCKS and rt.lib.dpp_bn_bwd_finalize_apply_ok(M, C, nbp))
+        one_launch = (not lazy and W <= 1 and 0 < nbp <= hz.BN_BWD_FUSE_MAX_BLOCKS and rt.lib.dpp_bn_bwd_finalize_apply_ok(M, C, nbp))
         if fused is not None:
             # the data-gradient kernel already masked vg.grad and wrote the per-block sums
             part, nbp = fused
@@ -1290,7 +1023,7 @@ class CompiledNet(object):
             t.grad = rt.alloc(t.shape, add.dtype if add is not None else self._grad_dtype(t), zero=False)
         # t.grad is the dY of the conv(s) that produced t: emit its column sums (their bias gradients) in the same pass
         if sums is not None:
-            rpb = max(32, -(-(M * (C // 32)) // BN_BWD_FUSE_TARGET_WGS))
+            rpb = max(32, -(-(M * (C // 32)) // hz.BN_BWD_FUSE_TARGET_WGS))
             rpb = -(-rpb // 32) * 32
             nbc = -(-M // rpb)
             cs = rt.alloc((nbc, C), zero=False)
@@ -1334,11 +1067,11 @@ class CompiledNet(object):
             out = io['out']
             lz = getattr(out, 'lazy', None)
             if lz is not None and kind == 'ConvLayer' and tuple(layer.cfgParams.filterDim) == (1, 1) and \
-                    (LAZY_BN_BWD == 1 or io['in_view'].base not in self.x_ins):
+                    (hz.LAZY_BN_BWD == 1 or io['in_view'].base not in self.x_ins):
                 out.lazy = None
                 b = lz['bn']
                 keep = None
-                if LAZY_BN_BWD >= 2:
+                if hz.LAZY_BN_BWD >= 2:
                     if out.grad is None:
                         out.grad = rt.alloc(out.shape, zero=False)
                     keep = out.grad
@@ -1354,7 +1087,7 @@ class CompiledNet(object):
             elif kind == 'HiddenLayer':
                 self._bwd_fc(layer, io, src, dY)
             elif kind == 'ConvPoolLayer':
-                if TAIL_REDUCE and self.reduce_jobs.jobs:
+                if hz.TAIL_REDUCE and self.reduce_jobs.jobs:
                     # the partials collected so far are reduced on the gradient branch BESIDE the stem's filter gradient (the last
                     # launch of the main stream, which otherwise idles at the join while reduce_multi waits behind it)
                     self.bwd.fork()
@@ -1369,7 +1102,7 @@ class CompiledNet(object):
                 tgt.grad_written = True
             else:
                 raise NotImplementedError(kind)
-            if EARLY_REDUCE_BYTES > 0 and self.reduce_jobs.pending_bytes() >= EARLY_REDUCE_BYTES:
+            if hz.EARLY_REDUCE_BYTES > 0 and self.reduce_jobs.pending_bytes() >= hz.EARLY_REDUCE_BYTES:
                 self.bwd.fork()
                 self.bwd.add(self.reduce_jobs.flush('reduce_multi_early'), side=True)
         self._defer_fc1_wgrad()
@@ -1384,7 +1117,7 @@ class CompiledNet(object):
         self._wd_ops, self._wd_of = [], {}
         if self.weight_decay and not self.net.hasDropout():
             seg = self._weight_segments()
-            if seg is not None and not EARLY_ADAM:       # (EARLY_ADAM moves FC1's share next to FC1's update: per-layer launches)
+            if seg is not None and not hz.EARLY_ADAM:       # (hz.EARLY_ADAM moves FC1's share next to FC1's update: per-layer launches)
                 self._wd_ops.append(ops.axpy_multi(rt, st.g, st.w, seg[0], seg[1], 2.0 * self.weight_decay))
             else:
                 for W in self._unique_weights():
@@ -1398,19 +1131,19 @@ class CompiledNet(object):
         """FC1's filter gradient (4.3 GFLOP, f32-MFMA-bound like FC1's data gradient) is the first big launch of the gradient branch
         and runs BESIDE FC1's data gradient: the two share the matrix cores and the main chain waits longer for its first link.  Nothing
         needs this gradient before the end of the pass, and a few launches later the chain is in the latency-bound stage-4 / 3
-        convolutions that leave the matrix cores idle -- so the launch moves FC1_WGRAD_DEFER side launches down the branch (it then
+        convolutions that leave the matrix cores idle -- so the launch moves hz.FC1_WGRAD_DEFER side launches down the branch (it then
         sits behind a later fork, i.e. waits for more of the chain than it needs).  Not under data parallelism (its all-reduce
-        bucket wants the gradient early) or EARLY_ADAM (its update sits right behind it).
+        bucket wants the gradient early) or hz.EARLY_ADAM (its update sits right behind it).
         Measured on the MI355X (tools/knob_sweep.sh, 300 steps each): 3.659 / 3.675 / 3.676 / 3.678 / 3.649 / 3.675 ms for 2 / 4 / 8 /
         16 / 30 / 60 launches against 3.680-3.682 without -- inside the run-to-run noise, so it stays off (DPP_FC1_WGRAD_DEFER = 0)."""
         op = self.__dict__.get('_fc1_wgrad_op')
-        if op is None or FC1_WGRAD_DEFER <= 0 or self.dp is not None or EARLY_ADAM:
+        if op is None or hz.FC1_WGRAD_DEFER <= 0 or self.dp is not None or hz.EARLY_ADAM:
             return
         ops_ = self.bwd.ops
         i = [k for k, (o, _) in enumerate(ops_) if o is op][0]
         entry = ops_.pop(i)
         seen, j = 0, i
-        while j < len(ops_) and seen < FC1_WGRAD_DEFER:
+        while j < len(ops_) and seen < hz.FC1_WGRAD_DEFER:
             if ops_[j][1] and isinstance(ops_[j][0], ops.Launch):
                 seen += 1
             j += 1
@@ -1483,8 +1216,8 @@ class CompiledNet(object):
                 return
             mp = RowMap.strided(s, Ho, Wo, Hi, Wi) if s != 1 else None
             # filter gradient dW[o][c] = sum_m dY[m][o] * act(X)[map(m)][c]
-            rpw = wgrad_stream_rows(M)
-            if dy_act is None and WGRAD_STREAM and rpw > 0 and rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rpw) > 0:
+            rpw = hz.wgrad_stream_rows(M)
+            if dy_act is None and hz.WGRAD_STREAM and rpw > 0 and rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rpw) > 0:
                 # the row-streaming kernel (csrc/wgrad.hip): operands straight from memory into MFMA fragments, one partial slice per
                 # (workgroup, row split), all of them summed by the pass's single reduction launch
                 nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rpw)
@@ -1493,7 +1226,7 @@ class CompiledNet(object):
                                               name='wgrad1x1_%d' % layer.layerNum), side=True)
                 self.reduce_jobs.add(part, nsl, Co * Ci, gW)
                 return
-            tile, splitk = wgrad_plan(Co, Ci, M)
+            tile, splitk = hz.wgrad_plan(Co, Ci, M)
             part = rt.alloc(splitk * Co * Ci, zero=False) if splitk > 1 else None     # persistent: reduced at the end of backward
             self.bwd.add(ops.gemm(rt, dy, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actA=dy_act,
                                   actB=act, splitk=splitk, partial=part, tile=tile, name='wgrad1x1_%d' % layer.layerNum), side=True)
@@ -1511,15 +1244,15 @@ class CompiledNet(object):
                     # the strided data gradient leaves the skipped pixels untouched: they are zeroed on the side stream while
                     # the forward pass runs (the buffer is only written in the backward pass), not in the data-gradient chain
                     self.early_side.append(ops.fill_zero(rt, dst))
-                tile, _ = gemm_plan(M, Ci, Co, allow_split=False)
-                rs = rowstream_plan(M, Ci, Co, False)
+                tile, _ = hz.gemm_plan(M, Ci, Co, allow_split=False)
+                rs = hz.rowstream_plan(M, Ci, Co, False)
                 if rs is not None:
                     tile = rs
-                ks = ksplit_plan(M, Ci, Co) if (s == 1 and rs is None and dY_act is None) else None
+                ks = hz.ksplit_plan(M, Ci, Co) if (s == 1 and rs is None and dY_act is None) else None
                 if ks is not None:
                     tile = ks
-                ex = expand_plan(M, Ci, Co, False) if (s == 1 and rs is None and ks is None) else None
-                s16 = stream16_plan(M, Ci, Co, False) if (s == 1 and rs is None and ks is None and dY_act is None and ex is None) else None
+                ex = hz.expand_plan(M, Ci, Co, False) if (s == 1 and rs is None and ks is None) else None
+                s16 = hz.stream16_plan(M, Ci, Co, False) if (s == 1 and rs is None and ks is None and dY_act is None and ex is None) else None
                 if s16 is not None:
                     tile = s16
                 if ex is not None:
@@ -1530,9 +1263,9 @@ class CompiledNet(object):
                     return ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
                                     residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
                                     name='dgrad1x1_%d' % layer.layerNum,
-                                    precision=self.prec if (variant == 4 and Co >= 32 and dY_act is None and BF16_GEMM) else 0)
+                                    precision=self.prec if (variant == 4 and Co >= 32 and dY_act is None and hz.BF16_GEMM) else 0)
                 if variant in (2, 3, 4) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
-                    variant, (tile, _) = 0, gemm_plan(M, Ci, Co, allow_split=False)       # see the forward twin
+                    variant, (tile, _) = 0, hz.gemm_plan(M, Ci, Co, allow_split=False)       # see the forward twin
                 epi = None
                 if (s == 1 and not acc and self._sole_consumer_bn_view(src)) or (acc and self._two_conv1x1_consumers(src)):
                     # ReLU mask + (sum G, sum G*xhat) of the BatchNorm backward in this kernel's epilogue.  A projection block
@@ -1549,7 +1282,7 @@ class CompiledNet(object):
                 emit_param_grads(dY_keep, None)               # after the data gradient, which wrote dY_keep
         else:
             bm = 64
-            rpw = wgrad3_stream_rows(N * Hi * Wi, Ci) if Ci == Co else 0
+            rpw = hz.wgrad3_stream_rows(N * Hi * Wi, Ci) if Ci == Co else 0
             nblk = rt.lib.dpp_wgrad3_stream_slices(Co, Ci, N, Hi, Wi, rpw) if rpw > 0 else 0
             if nblk > 0:
                 part = rt.alloc(nblk * Co * 9 * Ci, zero=False)
@@ -1566,7 +1299,7 @@ class CompiledNet(object):
                 # the mirrored weights only depend on the parameters: they are prepared on the side stream while the forward
                 # pass runs (the side stream is idle then) instead of sitting in the data-gradient chain
                 self._wtrans_jobs.append((st.view(layer.W), Co, Ci, Wd))       # one batched launch, see _emit_backward
-                bmd = conv3x3_bm(N * Hi * Wi, Ci)
+                bmd = hz.conv3x3_bm(N * Hi * Wi, Ci)
                 epi = None
                 fuse = not acc and self._sole_consumer_bn_view(src)
                 if not acc and self._conv3_stream(N, Hi, Wi, Ci, Co, dY, dst, src.base.buf if fuse else None):
@@ -1594,24 +1327,24 @@ class CompiledNet(object):
         self.bwd.fork()
         self._bias_grad(dY, Nb, Nout, gb)
         stream_kernel = self._fc1_stream(Nb, K, Nout)
-        if stream_kernel and self.prec == 0 and FC1_WGRAD_STREAM and (act is None or act.mode < 4) and rt.lib.dpp_fc_wgrad_stream_ok(Nb, K, Nout):
+        if stream_kernel and self.prec == 0 and hz.FC1_WGRAD_STREAM and (act is None or act.mode < 4) and rt.lib.dpp_fc_wgrad_stream_ok(Nb, K, Nout):
             # the reduction is only the batch: every 64 x 64 block of dW is owned by one wave of the row stream (csrc/wgrad.hip),
             # no LDS pipeline to fill and drain for four chunks, no partials
             op = self.bwd.add(ops.fc_wgrad_stream(rt, src.base.buf, dY, gW, Nb, K, Nout, actX=act, name='fc_wgrad_%d' % layer.layerNum), side=True)
-            if K * Nout >= EARLY_BUCKET_MIN:
+            if K * Nout >= hz.EARLY_BUCKET_MIN:
                 self._fc1_wgrad_op = op
         elif stream_kernel:
             op = self.bwd.add(ops.fc_gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, precision=self.prec,
-                                          kchunk=FC1_KCHUNK, name='fc_wgrad_%d' % layer.layerNum), side=True)
-            if K * Nout >= EARLY_BUCKET_MIN:
+                                          kchunk=hz.FC1_KCHUNK, name='fc_wgrad_%d' % layer.layerNum), side=True)
+            if K * Nout >= hz.EARLY_BUCKET_MIN:
                 self._fc1_wgrad_op = op
         else:
-            tile, _ = gemm_plan(K, Nout, Nb, allow_split=False)
-            if K >= 4096 and Nout >= 64 and knob('DPP_FC1_TILE128', '1') != '0':
+            tile, _ = hz.gemm_plan(K, Nout, Nb, allow_split=False)
+            if K >= 4096 and Nout >= 64 and hz.knob('DPP_FC1_TILE128', '1') != '0':
                 tile = (128, 64, 4)          # FC1: 67 MB of output, MFMA-bound (tools/gemm_micro.py fc: 107 -> 84 us)
             self.bwd.add(ops.gemm(rt, src.base.buf, dY, gW, K, Nout, Nb, 0, 0, K, Nout, Nout, actA=act, tile=tile,
                                   name='fc_wgrad_%d' % layer.layerNum), side=True)
-        if self.dp is not None and self._early_slice is None and K * Nout >= EARLY_BUCKET_MIN and OVERLAP_ALLREDUCE:
+        if self.dp is not None and self._early_slice is None and K * Nout >= hz.EARLY_BUCKET_MIN and hz.OVERLAP_ALLREDUCE:
             # data parallel: this gradient (FC1: 90 % of all parameter bytes) is final now -- start its all-reduce from the
             # side stream so that it overlaps the rest of the backward pass
             off = (gW.ptr - st.g.ptr) // 4
@@ -1620,10 +1353,10 @@ class CompiledNet(object):
         if src.base not in self.x_ins:
             tgt, dst = self._view_grad(src)
             acc = tgt.grad_written
-            tile, splitk = gemm_plan(Nb, K, Nout, allow_split=not acc)
+            tile, splitk = hz.gemm_plan(Nb, K, Nout, allow_split=not acc)
             if stream_kernel:
                 self.bwd.add(ops.fc_gemm(rt, dY, st.view(layer.W), dst, Nb, K, Nout, 1, 1, Nout, Nout, K, residual=dst if acc else None,
-                                         precision=self.prec, kchunk=FC1_KCHUNK, name='fc_dgrad_%d' % layer.layerNum))
+                                         precision=self.prec, kchunk=hz.FC1_KCHUNK, name='fc_dgrad_%d' % layer.layerNum))
             elif splitk > 1:
                 part = self.scratch(splitk * Nb * K)
                 self.bwd.add(ops.gemm(rt, dY, st.view(layer.W), None, Nb, K, Nout, 1, 1, Nout, Nout, K, splitk=splitk, partial=part,
@@ -1635,7 +1368,7 @@ class CompiledNet(object):
             tgt.grad_written = True
             if getattr(src.base, 'concat_parts', None) is not None:
                 self._split_concat_grad(src.base)
-        if self._early_adam is None and K * Nout >= EARLY_BUCKET_MIN and gW.ptr >= st.g.ptr and \
+        if self._early_adam is None and K * Nout >= hz.EARLY_BUCKET_MIN and gW.ptr >= st.g.ptr and \
                 gW.ptr + 4 * K * Nout <= st.g.ptr + 4 * st.n_w:
             # from here on nothing reads this weight or writes its gradient any more (filter gradient on the branch, data gradient
             # on the main stream, both issued above): the position where step_plan may put its ADAM update
@@ -1677,7 +1410,7 @@ class CompiledNet(object):
         # done -- and then the main stream has nothing left to do while the gradient branch still works off its backlog
         # (tools/tail_probe.py): it runs on the main stream.
         self.bwd.add(ops.stem_wgrad(rt, self.x_in.buf, N, H, W, dY, io['argmax'], Co, part, tpb),
-                     side=knob('DPP_STEM_WGRAD_SIDE', '0') == '1')
+                     side=hz.knob('DPP_STEM_WGRAD_SIDE', '0') == '1')
         self.reduce_jobs.add(part, nblk, Co * 25, self._grad_view(layer.W))
 
     # ------------------------------------------------------------------------------------------ execution
@@ -1771,7 +1504,7 @@ class CompiledNet(object):
                 at = 1 if prefetch is not None else 0          # behind the join that waits for the previous call's prefetch
                 parts = parts[:at] + [head] + parts[at:]
             plan = Plan.concat('step', parts + [upd])
-            skip = tuple(x for x in knob('DPP_WHATIF_SKIP', '').split(',') if x)
+            skip = tuple(x for x in hz.knob('DPP_WHATIF_SKIP', '').split(',') if x)
             if skip:
                 # ablation for tools/whatif.sh ONLY (results are wrong): the step without the launches whose name starts with one of
                 # the prefixes -- what the step would cost if those kernels were free
@@ -1780,11 +1513,11 @@ class CompiledNet(object):
         return cache[key][-1]
 
     def _early_adam_plans(self):
-        """(backward, update) plans of a whole step.  With EARLY_ADAM the FC1 weight is updated inside the backward pass, on the
+        """(backward, update) plans of a whole step.  With hz.EARLY_ADAM the FC1 weight is updated inside the backward pass, on the
         gradient branch, right after the two kernels that use it (its weight-decay term first), and the update plan covers the rest of
         the flat buffer.  Single process only: with data parallelism the gradient is not final before its all-reduce."""
         ea = self._early_adam
-        if not EARLY_ADAM or ea is None or self.dp is not None:
+        if not hz.EARLY_ADAM or ea is None or self.dp is not None:
             return self.bwd, self.upd
         if '_early_adam_cache' in self.__dict__:
             return self._early_adam_cache

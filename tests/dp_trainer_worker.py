@@ -16,13 +16,14 @@ import numpy as np  # noqa: E402
 from sklearn.decomposition import PCA  # noqa: E402
 
 from data.importers import ICVLImporter  # noqa: E402
+from hipdp import heuristics  # noqa: E402
 from hipdp import engine, parallel  # noqa: E402
 from hipdp import runtime as R  # noqa: E402
 from net.resnet import ResNet, ResNetParams  # noqa: E402
 from trainer.poseregnettrainer import PoseRegNetTrainer, PoseRegNetTrainerParams  # noqa: E402
 from util.handdetector import HandDetector  # noqa: E402
 
-engine.EARLY_BUCKET_MIN = 1 << 18      # the test net's FC1 (1 M weights) takes the overlapped early-bucket path
+heuristics.EARLY_BUCKET_MIN = 1 << 18      # the test net's FC1 (1 M weights) takes the overlapped early-bucket path
 
 
 def main():

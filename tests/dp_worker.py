@@ -14,9 +14,10 @@ for p in (ROOT, os.path.join(ROOT, 'deep-prior-pp_amd')):
 
 import numpy as np  # noqa: E402
 
+from hipdp import heuristics  # noqa: E402
 from hipdp import engine, parallel  # noqa: E402
 
-engine.EARLY_BUCKET_MIN = 1 << 18      # the test net's FC layers (1 M weights) take the overlapped early-bucket path
+heuristics.EARLY_BUCKET_MIN = 1 << 18      # the test net's FC layers (1 M weights) take the overlapped early-bucket path
 from net.resnet import ResNet, ResNetParams  # noqa: E402
 from oracle import nets  # noqa: E402
 

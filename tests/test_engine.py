@@ -7,6 +7,7 @@ Tolerances: the north-star bar is 1e-3 mm on the 3-D joint output, i.e. 1e-3 / 1
 import numpy as np
 import pytest
 
+from hipdp import heuristics  # noqa: E402
 from hipdp import engine, ops
 from net.resnet import ResNet, ResNetParams
 from oracle import layers as L
@@ -129,29 +130,29 @@ def test_resnet_forward_eval_matches_oracle(backend):
 @pytest.mark.parametrize('type_', [0, 1, 'lazy', 'lazy2', 'lazy3', 'fc1stream', 'early_reduce', 'no_variants', 'conv3stream', 'bn_fuse'])
 def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatch):
     """'lazy': type 0 with the opt-in plan in which the 1x1 convolutions form the gradient through a BatchNorm from (G, x) in
-    their operand prologue (engine.LAZY_BN_BWD) instead of reading a tensor written by bn_bwd_apply.
+    their operand prologue (heuristics.LAZY_BN_BWD) instead of reading a tensor written by bn_bwd_apply.
     'fc1stream': the HiddenLayer behind the last conv map on the weight-streaming kernel (dpp_fc_gemm: forward with split-K,
     data gradient, weight gradient with the BN+ReLU prologue) -- the full-size nets take that path for FC1, this 32x32 net
     (K = 1 024) only with the threshold lowered.
     'early_reduce': the filter / bias gradient partials reduced in several dpp_reduce_multi launches on the gradient branch while the
-    pass runs (engine.EARLY_REDUCE_BYTES; the bs128 net flushes every 16 MB) instead of one launch at its end.
-    'conv3stream': a 64x64 net, whose stage-1 maps are 16 pixels wide, with the opt-in engine.CONV3_STREAM_C: its 16 -> 16 3x3 layers
+    pass runs (heuristics.EARLY_REDUCE_BYTES; the bs128 net flushes every 16 MB) instead of one launch at its end.
+    'conv3stream': a 64x64 net, whose stage-1 maps are 16 pixels wide, with the opt-in heuristics.CONV3_STREAM_C: its 16 -> 16 3x3 layers
     and their data gradients run on the barrier-free dpp_conv3x3_stream (measured no faster than the tiled kernel: off by default)."""
     size = 32
-    if type_ == 'bn_fuse':          # finalize + apply of the BatchNorm backward in one launch (opt-in engine.BN_BWD_FUSE_MAX_BLOCKS)
-        monkeypatch.setattr(engine, 'BN_BWD_FUSE_MAX_BLOCKS', 128)
+    if type_ == 'bn_fuse':          # finalize + apply of the BatchNorm backward in one launch (opt-in heuristics.BN_BWD_FUSE_MAX_BLOCKS)
+        monkeypatch.setattr(heuristics, 'BN_BWD_FUSE_MAX_BLOCKS', 128)
         type_ = 0
     if type_ == 'conv3stream':
         size, type_ = 64, 0
-        monkeypatch.setattr(engine, 'CONV3_STREAM_C', (16, 32))
+        monkeypatch.setattr(heuristics, 'CONV3_STREAM_C', (16, 32))
     if type_ == 'lazy2' and backend == 'emu':
         pytest.skip("the opt-in lazy2 plan (measured slower, off by default) is exercised on the GPU tier only; 'lazy' covers the mode-4 operand here")
     if type_ in ('lazy', 'lazy2', 'lazy3'):       # lazy2: only the data gradient does, and leaves the tensor it forms for the filter gradient
         # (lazy3: lazy2 restricted to the data gradients that run on the wave-autonomous kernel, dpp_gemm variant 4)
-        monkeypatch.setattr(engine, 'LAZY_BN_BWD', {'lazy': 1, 'lazy2': 2, 'lazy3': 3}[type_])
+        monkeypatch.setattr(heuristics, 'LAZY_BN_BWD', {'lazy': 1, 'lazy2': 2, 'lazy3': 3}[type_])
         type_ = 0
     if type_ == 'early_reduce':
-        monkeypatch.setattr(engine, 'EARLY_REDUCE_BYTES', 1 << 14)
+        monkeypatch.setattr(heuristics, 'EARLY_REDUCE_BYTES', 1 << 14)
         type_ = 0
     no_variants = type_ == 'no_variants'
     if no_variants:
@@ -160,25 +161,25 @@ def test_resnet_train_forward_backward_matches_oracle(backend, type_, monkeypatc
         monkeypatch.setattr(ops, 'gemm_variant_rows', lambda rt, launch: 0)
         type_ = 0
     if type_ == 'fc1stream':
-        monkeypatch.setattr(engine, 'FC1_MIN_K', 512)
-        monkeypatch.setattr(engine, 'FC1_STREAM', '1')
+        monkeypatch.setattr(heuristics, 'FC1_MIN_K', 512)
+        monkeypatch.setattr(heuristics, 'FC1_STREAM', '1')
         type_ = 0
     rt = get_runtime(backend)
     nJ, nD = (1, 30) if type_ == 0 else (14, 3)
     net, onet, P = make_net(rt, type_, 4, size, nJ, nD, **(dict(calib_batch=4) if size != 32 else {}))
     eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
     nfa = sum(l.fn is rt.lib.dpp_bn_bwd_finalize_apply for _, l in eng.all_launches())
-    assert (nfa >= 20) if engine.BN_BWD_FUSE_MAX_BLOCKS else (nfa == 0), nfa
+    assert (nfa >= 20) if heuristics.BN_BWD_FUSE_MAX_BLOCKS else (nfa == 0), nfa
     n3s = sum(l.fn is rt.lib.dpp_conv3x3_stream for _, l in eng.all_launches())
     assert n3s == (10 if size == 64 else 0), n3s          # 5 stage-1 blocks: forward + data gradient each
     variants = [l.keep[0].variant for _, l in eng.all_launches() if l.fn is rt.lib.dpp_gemm]
     assert (not any(v in (2, 3, 4) for v in variants)) if no_variants else (any(v in (2, 3) for v in variants) and any(v == 4 for v in variants))
-    if engine.LAZY_BN_BWD:
+    if heuristics.LAZY_BN_BWD:
         assert any(l.name.startswith('dgrad1x1') and l.keep[0].actA.mode == 4 for l in eng.bwd.launches())
-    if engine.FC1_MIN_K == 512:
+    if heuristics.FC1_MIN_K == 512:
         assert sum(l.fn is rt.lib.dpp_fc_gemm for _, l in eng.all_launches()) >= 4            # forward (+ split-K), data gradient, ...
         assert sum(l.fn is rt.lib.dpp_fc_wgrad_stream for _, l in eng.all_launches()) >= 1    # ... and the filter gradients on the row stream
-    if engine.EARLY_REDUCE_BYTES == 1 << 14:
+    if heuristics.EARLY_REDUCE_BYTES == 1 << 14:
         assert sum(l.name == 'reduce_multi_early' for l in eng.bwd.launches()) >= 3
     P64 = nets.cast_params(P, np.float64)
 
@@ -342,7 +343,7 @@ def bf16_gradients_vs_pinned_oracle(rt, net, onet, P, x, y, bar=2e-4):
     assert any(q['fwd'] for q in quant.values()) and any(q['dgrad'] for q in quant.values())
     # bf16 STORAGE (the default of the bf16 mode): the device's own stored tensors are pinned like its rounded MFMA operands ...
     store = device_store(eng, net) if eng.store16 else None
-    assert (store is not None and len(store) >= 10) == bool(engine.BF16_STORE)
+    assert (store is not None and len(store) >= 10) == bool(heuristics.BF16_STORE)
     own, own_g = {}, {}
     gpins = device_grad_pins(eng, net) if eng.grad16 else None
     c_ref, G_ref, out_ref = torch_ref.cost_and_grads(onet, nets.cast_params(P, np.float64), x.astype(np.float64), y.astype(np.float64),
@@ -386,7 +387,7 @@ def test_bf16_step_matches_the_bf16_oracle(backend, monkeypatch):
     """CompiledNet(bf16=True) (BASELINE config 5) on a small net: every gradient at the 2e-4 bar against the oracle that rounds the
     same operands; the bf16 kernels really ran (the result differs from the fp32 engine's), and the UNROUNDED oracle is far outside
     the bar (the comparison has teeth)."""
-    monkeypatch.setattr(engine, 'FC1_MIN_K', 512)
+    monkeypatch.setattr(heuristics, 'FC1_MIN_K', 512)
     rt = get_runtime(backend)
     net, onet, P = make_net(rt, 0, 4, 32, 1, 30)
     rng = np.random.RandomState(6)
@@ -412,7 +413,7 @@ def test_bf16_gradient_storage_on_maps_large_enough_to_use_it(backend, monkeypat
     oracle on the device's own stored operands, the oracle's own roundings agree with the device's stored gradients, and with
     BF16_GRADS off the gradients come out float32 and different."""
     from tests.pinning import device_grad_pins
-    monkeypatch.setattr(engine, 'FC1_MIN_K', 512)
+    monkeypatch.setattr(heuristics, 'FC1_MIN_K', 512)
     rt = get_runtime(backend)
     net, onet, P = make_net(rt, 0, 4, 64, 1, 30, calib_batch=4)
     rng = np.random.RandomState(16)
@@ -422,7 +423,7 @@ def test_bf16_gradient_storage_on_maps_large_enough_to_use_it(backend, monkeypat
     assert eng.grad16
     gp, dv = device_grad_pins(eng, net)
     assert len(gp) >= 6 and len(dv) >= 6, (len(gp), len(dv))
-    monkeypatch.setattr(engine, 'BF16_GRADS', False)
+    monkeypatch.setattr(heuristics, 'BF16_GRADS', False)
     e2 = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), bf16=True)
     assert e2.store16 and not e2.grad16
     e2.cost_and_grads(x, y)
@@ -437,11 +438,11 @@ def test_early_fc1_adam_step_equals_plain_step(backend, monkeypatch):
     first) and the rest of the flat buffer at the end: two whole steps must leave EVERY parameter, both ADAM moments and the cost
     bit-identical to backward-then-one-ADAM."""
     rt = get_runtime(backend)
-    monkeypatch.setattr(engine, 'EARLY_BUCKET_MIN', 1 << 18)           # the 32x32 test net's FC1 (1 M weights) qualifies
+    monkeypatch.setattr(heuristics, 'EARLY_BUCKET_MIN', 1 << 18)           # the 32x32 test net's FC1 (1 M weights) qualifies
     wd = 1e-3
     state = {}
     for early in (True, False):
-        monkeypatch.setattr(engine, 'EARLY_ADAM', early)
+        monkeypatch.setattr(heuristics, 'EARLY_ADAM', early)
         net, _, _ = make_net(rt, 0, 4, 32, 1, 30)
         eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'), weight_decay=wd)
         assert eng._early_adam is not None
@@ -470,7 +471,7 @@ def test_projection_shortcuts_beside_the_chain_and_in_it(backend, monkeypatch):
     rt = get_runtime(backend)
     state = {}
     for mode in ('beside', 'early', 'off'):
-        monkeypatch.setattr(engine, 'SIDE_SHORTCUT', mode != 'off')
+        monkeypatch.setattr(heuristics, 'SIDE_SHORTCUT', mode != 'off')
         net, _, _ = make_net(rt, 0, 4, 32, 1, 30)
         eng = engine.CompiledNet(net, train=True, runtime=rt, loss=dict(kind='embedding'))
         side_convs = [o.name for (o, side) in eng.fwd.ops if side and getattr(o, 'name', '').startswith('conv1x1')]

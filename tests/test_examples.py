@@ -10,6 +10,7 @@ import scipy.io
 from PIL import Image
 
 from data.importers import NYUImporter
+from hipdp import heuristics  # noqa: E402
 from hipdp import runtime as R
 from oracle import augment as A
 from tests.backends import BACKENDS, get_runtime
@@ -174,7 +175,7 @@ def test_resnet_learns_the_synthetic_pose_manifold(tmp_path):
 def test_resnet_learns_with_bf16_operands_too(tmp_path, monkeypatch):
     """The same run with bf16 MFMA operands in the 3x3 convolutions and FC1 (BASELINE config 5's arithmetic) learns as well."""
     from hipdp import engine
-    monkeypatch.setattr(engine, 'BF16_DEFAULT', True)
+    monkeypatch.setattr(heuristics, 'BF16_DEFAULT', True)
     R.set_default_runtime(get_runtime('hip'))
     costs, (mean_err, max_err, mean_pose_err) = _load_driver('main_synthetic_posereg_embedding').main(
         ['--net', 'resnet', '--frames', '4096', '--epochs', '6', '--out', str(tmp_path / 'eval')])
