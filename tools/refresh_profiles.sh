@@ -6,7 +6,6 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $R/bench.py > $O/bench.json 2> $O/bench.err
 # kernel trace of the measured configuration (bench defaults: native plan, two streams) -- kernel-trace only, no counters
 rocprofv3 --kernel-trace -d /tmp/p1 -o run -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
 python $R/tools/prof_summary.py $(find /tmp/p1 -name '*_results.db' | head -1) 28 > $O/kernel_stats_bench.txt 2>&1
@@ -46,4 +45,9 @@ python $R/bench.py --no-cpu-baseline --workload cascade --size 256 --steps 20 --
 python $R/tools/trainer_throughput.py 2>/dev/null | tail -1 > $O/trainer_throughput.txt
 python $R/tools/augment_bench.py > $O/augment_bench.json 2> $O/augment_bench.err
 python $R/tools/augment_bench.py --batch 4096 --iters 50 >> $O/augment_bench.json 2>> $O/augment_bench.err
+# the bench line LAST, with this run's counter files in place (bench.py quotes roofline.traffic / roofline.mfma_busy only from files under
+# profiles/ whose recorded kernel-source fingerprint is the one it runs on)
+cp $O/hbm_traffic.json $R/profiles/${ROUND}_hbm_traffic.json
+cp $O/mfma_busy.json $R/profiles/${ROUND}_mfma_busy.json
+python $R/bench.py > $O/bench.json 2> $O/bench.err
 ls -la $O
