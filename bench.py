@@ -176,9 +176,15 @@ def cpu_baseline(batch, size, budget_s=45.0):
         left = max(10.0, budget_s - 4.0 * sum(probes.values()))
         mean_s, med_s, n = _time_cpu_steps(batch, size, 5, 12, left)
         cand = {str(t): round(batch / v, 2) for t, v in sorted(probes.items())}
-        out = dict(value=round(batch / med_s, 2), unit='depth-crops/sec', cores=best, kind='port', candidates_crops_per_s=cand,
+        # The host of a GPU box is a noisy place (128 hardware threads, placement decided per run: the same thread count measured 2.7x apart
+        # within one process in round 5): the baseline is the BEST sustained rate seen at the chosen count -- the better of the probe's
+        # median and the longer run's median -- so that noise can only make the CPU look faster, never the comparison kinder to the GPU.
+        best_s = min(med_s, probes[best])
+        out = dict(value=round(batch / best_s, 2), unit='depth-crops/sec', cores=best, kind='port', candidates_crops_per_s=cand,
+                   medians_s_per_step=dict(probe=round(probes[best], 3), run=round(med_s, 3)),
                    sample='%d train steps of batch %d (PyTorch-CPU fp32 restatement, not Theano) on %d of %d threads (the fastest of %s, each '
-                          'on the median of 2-3 probe steps): median %.2f s/step, mean %.2f' % (n, batch, best, threads, sorted(probes), med_s, mean_s))
+                          'on the median of 2-3 probe steps): median %.2f s/step, mean %.2f; value = the better of that median and the '
+                          "probe's" % (n, batch, best, threads, sorted(probes), med_s, mean_s))
         extra['cpu_baseline_all_threads'] = dict(value=round(batch / probes[threads], 2), unit='depth-crops/sec', cores=threads, kind='port',
                                                  sample='median of 2-3 train steps of batch %d after a warm-up step: %.2f s' % (batch, probes[threads]))
         torch.set_num_threads(1)
