@@ -312,9 +312,26 @@ def forward_only_leg(rt, torch, net, B, S, x_host, steps=50, warmup=10):
     roof = dict(kernel=dom, launches_per_batch=len(g['ops']), avg_launch_us=round(t / len(g['ops']) * 1e6, 2), share_of_batch=round(fam[dom] / sum(fam.values()), 3),
                 mfma=dict(achieved=round(g['flops'] / t / 1e12, 2), peak=PEAK_MFMA_F32 / 1e12, unit='TFLOP/s', frac=round(g['flops'] / t / PEAK_MFMA_F32, 4)),
                 hbm=dict(achieved=round(g['bytes'] / t / 1e9, 1), peak=PEAK_HBM / 1e9, unit='GB/s', frac=round(g['bytes'] / t / PEAK_HBM, 4)))
+    # one frame at a time (the reference's realtime use, netbase.py:286-310 with a batch of one; the paper quotes 30 fps): the same
+    # architecture compiled for batch 1, latency per frame with the frame resident
+    from net.resnet import ResNet, ResNetParams
+    net1 = ResNet(np.random.RandomState(23455), cfgParams=ResNetParams(type=0, nChan=1, wIn=S, hIn=S, batchSize=1, numJoints=1, nDims=30))
+    e1 = engine.CompiledNet(net1, train=False, runtime=rt)
+    e1.set_input(x_host[:1])
+    for _ in range(warmup):
+        e1.fwd.run(rt)
+    torch.cuda.synchronize()
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g0.record(torch.cuda.current_stream())
+    for _ in range(steps):
+        e1.fwd.run(rt)
+    g1.record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
     return dict(value=round(B / (ms * 1e-3), 1), unit='depth-crops/sec', ms_per_batch=round(ms, 4), batch=B, launches=len(ev_eng.fwd),
                 launches_by_family=names, finite=bool(np.isfinite(out).all()), roofline=roof,
-                mode='deterministic forward (stored BatchNorm statistics), inputs resident, HIP events over %d batches' % steps)
+                single_frame_ms=round(g0.elapsed_time(g1) / steps, 4),
+                mode='deterministic forward (stored BatchNorm statistics), inputs resident, HIP events over %d batches; single_frame_ms: the '
+                     'same net compiled for a batch of one' % steps)
 
 
 def _mfma_busy_from_profiles(kernel_family, B, S, args):
