@@ -121,3 +121,35 @@ def test_unsupported_shapes_are_refused():
     assert rt.lib.dpp_resblock_eval_ok(64, 64, 24, 1, 0) == 0          # bottleneck width
     assert rt.lib.dpp_resblock_eval_ok(32, 64, 16, 1, 0) == 0          # identity needs Cin == Cout
     assert rt.lib.dpp_resblock_eval(None, None) == 10001
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('type_', [0, 1, 2, 3, 4])
+def test_every_resnet_type_lowers_its_twenty_blocks_to_one_launch_each(backend, type_):
+    """hipdp/evalfuse.py on the graphs the reference's ResNet builds (/root/reference/src/net/resnet.py:120-336): types 0-4 (30-D bottleneck,
+    dropout variants, the narrowed stages of type 3 whose stage-3 / 4 openers are IDENTITY blocks because the width does not change).  The
+    deterministic engine must recognise all twenty blocks, and its output must equal the layer-by-layer engine's to float32 round-off."""
+    from hipdp import engine
+    from hipdp import runtime as R
+    from net.resnet import ResNet, ResNetParams
+    from oracle import nets
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    nJ, nD = (14, 3) if type_ in (1, 4) else (1, 30)
+    net = ResNet(np.random.RandomState(23455 + type_), cfgParams=ResNetParams(type=type_, wIn=32, hIn=32, batchSize=2, numJoints=nJ, nDims=nD))
+    rng = np.random.RandomState(9)
+    for l in net.layers:                      # running statistics / affine parameters away from their (0, 1) initial values
+        for p_ in getattr(l, 'params_nontrained', []):
+            v = p_.get_value()
+            p_.set_value((v + rng.normal(0, 0.1, v.shape) * (1.0 if 'mean' in p_.name else 0.2)).astype(np.float32))
+    net.setDeterministic()
+    x = nets.synthetic_crops(np.random.RandomState(5), 2, 32, 32, np.float32)
+    fused = engine.CompiledNet(net, train=False, runtime=rt)
+    plain = engine.CompiledNet(net, train=False, runtime=rt, fuse_blocks=False)
+    assert len(fused.fused_blocks) == 20 and len(plain.fused_blocks) == 0
+    n_proj = sum(m['shortcut'] is not None for m in fused.fused_blocks)
+    assert n_proj == (3 if type_ != 3 else 2)              # type 3: stages 3 and 4 keep the width of stage 2 (128), so only stages 1 and 2 open with a projection
+    a, b = fused.forward(x), plain.forward(x)
+    assert np.isfinite(a).all() and np.abs(b).max() > 0
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-5 * np.abs(b).max())
+    assert len(fused.fwd) < len(plain.fwd) - 30
