@@ -31,8 +31,19 @@ run bf16_256_lazy3 DPP_LAZY_BN_BWD=3 -- --size 256 --dtype bf16 --steps 60 --war
 run bf16_256_lazy1 DPP_LAZY_BN_BWD=1 -- --size 256 --dtype bf16 --steps 60 --warmup 10
 run bf16_256_slices DPP_WGRAD3_STREAM_SLICES=512 DPP_WGRAD_TARGET_BLOCKS=128 -- --size 256 --dtype bf16 --steps 60 --warmup 10
 run bf16_256_c3_512 DPP_C3_MIN_WGS=512 -- --size 256 --dtype bf16 --steps 60 --warmup 10
+elif [ "${AB_SET}" = "4" ]; then
+# fourth set: BASELINE config 5 (256x256 bf16) with the row-stream filter-gradient kernels on more layers (existing knobs)
+run s4_bf16_256_base -- --size 256 --dtype bf16 --steps 60 --warmup 10
+run s4_bf16_256_w3_all DPP_WGRAD3_STREAM_C=16,32,64 -- --size 256 --dtype bf16 --steps 60 --warmup 10
+run s4_bf16_256_w3_32 DPP_WGRAD3_STREAM_C=32,64 -- --size 256 --dtype bf16 --steps 60 --warmup 10
+run s4_bf16_256_w1_12 DPP_WGRAD_STREAM_STAGES=12 -- --size 256 --dtype bf16 --steps 60 --warmup 10
+run s4_bf16_256_w1_123 DPP_WGRAD_STREAM_STAGES=123 -- --size 256 --dtype bf16 --steps 60 --warmup 10
+run s4_bf16_256_w3_all_w1_123 DPP_WGRAD3_STREAM_C=16,32,64 DPP_WGRAD_STREAM_STAGES=123 -- --size 256 --dtype bf16 --steps 60 --warmup 10
+run s4_128_w3_all DPP_WGRAD3_STREAM_C=16,32,64 --
+run s4_128_base --
 else
-# second set: the new defaults (column-tile rule 512), MORE partial slices, the lazy BatchNorm-backward operand at 256x256 (float32: the
+# second set (AB_SET=2; the third and fifth sets of profiles/r05_ab.txt measured kernels / plans that were removed again: conv3x3_db_kernel,
+# the late FC1 update): the new defaults (column-tile rule 512), MORE partial slices, the lazy BatchNorm-backward operand at 256x256 (float32: the
 # two-tensor operand is not built for bf16-stored tensors)
 run s2_base --
 run s2_wgrad_blocks512 DPP_WGRAD_TARGET_BLOCKS=512 --
