@@ -183,6 +183,33 @@ class TorchHipRuntime(object):
                 self_inner.ev.synchronize()
         return _Copy(ev, src)
 
+    def staged_upload(self, buf, host, free_event=None):
+        """Host array -> device buffer `buf` on the COPY stream, ordered only behind `free_event` (the point on the main stream after which
+        `buf` may be overwritten: the caller recorded it behind the last reader) -- not behind everything queued on the main stream, as
+        upload_async orders it.  Returns the event to make the main stream wait for before it reads `buf`.  What lets computeOutput move
+        batch i + 1 over PCIe while batch i is being evaluated."""
+        t = self.torch
+        if getattr(self, '_copy', None) is None:
+            self._copy = t.cuda.Stream(self.device)
+        src = t.from_numpy(np.ascontiguousarray(host, dtype=buf.dtype).reshape(-1))
+        dst = self._tensor(buf)[:src.numel()]
+        if free_event is not None:
+            self._copy.wait_event(free_event)
+        with t.cuda.stream(self._copy):
+            dst.copy_(src, non_blocking=True)
+            ev = t.cuda.Event()
+            ev.record(self._copy)
+        return ev
+
+    def record_event(self):
+        """An event at the current end of the main stream."""
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        return ev
+
+    def wait_event(self, ev):
+        self.torch.cuda.current_stream(self.device).wait_event(ev)
+
     @property
     def stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
