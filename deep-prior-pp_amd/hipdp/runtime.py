@@ -199,6 +199,7 @@ class TorchHipRuntime(object):
             dst.copy_(src, non_blocking=True)
             ev = t.cuda.Event()
             ev.record(self._copy)
+        ev.keep = src                      # the host tensor outlives the copy: the caller holds the event until it has been waited for
         return ev
 
     def record_event(self):

@@ -212,6 +212,7 @@ class NetBase(object):
         eng.store.check_live()
         stages = [[rt.alloc(t.shape, zero=False) for t in eng.x_ins] for _ in range(2)]
         free = [None, None]
+        held = [None, None]              # the upload events (and through them the host source arrays) of the batch in each staging slot
         pending = None
 
         def to_device_layout(a, t):
@@ -226,6 +227,7 @@ class NetBase(object):
             for j, t in enumerate(eng.x_ins):
                 rt.wait_event(ups[j])
                 rt.copy(t.buf, stages[k][j])
+            held[k] = ups
             free[k] = rt.record_event()
             eng.fwd.run(rt)
             handle = rt.read_async(eng.out.buf)
