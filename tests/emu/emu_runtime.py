@@ -84,5 +84,17 @@ class EmuRuntime(object):
     def download_async(self, buf, host=None):
         return self.read_async(buf), None
 
+    # the stream-ordered upload interface of NetBase._compute_output_pipelined: everything executes in issue order here, so the events
+    # are placeholders -- what the CPU tier exercises is the control flow (staging slots, padding of the last batch, late output reads)
+    def staged_upload(self, buf, host, free_event=None):
+        self.copy_in(buf, np.asarray(host).reshape(buf.shape) if np.asarray(host).size == buf.size else host)
+        return object()
+
+    def record_event(self):
+        return object()
+
+    def wait_event(self, ev):
+        pass
+
     def synchronize(self):
         pass
