@@ -39,6 +39,8 @@ net = ResNet(rng, cfgParams=ResNetParams(type=0, nChan=1, wIn=S, hIn=S, batchSiz
 p = PoseRegNetTrainerParams()
 p.batch_size = B
 p.learning_rate = 1e-3
+p.weightreg_factor = 0.0        # as the pose-regression mains set it (/root/reference/src/main_nyu_posereg_embedding.py:104); the default 0.001 adds two
+                                # launches over all parameters (0.17 ms per step)
 p.force_macrobatch_reload = True
 p.para_augment = True
 p.augment_fun_params = {'fun': 'augment_poses', 'args': {'normZeroOne': False, 'di': di, 'aug_modes': ['com', 'rot', 'none'], 'proj': Proj,
