@@ -352,7 +352,13 @@ class NetBase(object):
             return True
         pend = self.__dict__.get('_save_pending')
         if skip_if_busy and pend is not None and pend[0].is_alive():
+            # remembered: joinSave() writes the LATEST dropped snapshot request once the running writer is done (the reference's
+            # net_last.pkl holds the state at the start of the last epoch, nettrainer.py:816-820; without this the file could end up
+            # several epochs stale)
+            self._save_dropped = filename
+            print('Snapshot {} skipped (previous checkpoint write still running); it is written when that one finishes'.format(filename))
             return False
+        self.__dict__.pop('_save_dropped', None)          # superseded by the snapshot taken now
         self.joinSave()
         import subprocess
         import sys
@@ -372,39 +378,88 @@ class NetBase(object):
                 'layers': [(layer.layerNum, ns) for layer, ns in zip(self.layers, names)],
                 'slots': [(s['param'].auto_name, 'w' if s['trained'] else 'nt', s['off'], s['size'], s['kind'], s['info'], tuple(s['shape']))
                           for s in store.slots]}
-        tmpdir = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
+        tmpdir = self._scratch_dir(4 * (int(store.n_w) + int(store.n_nt)) + (1 << 20))
         tag = 'dpp_ckpt_%d_%d' % (os.getpid(), id(self) & 0xffffff)
-        meta_path, raw_path = os.path.join(tmpdir, tag + '.meta'), os.path.join(tmpdir, tag + '.f32')
         pkg = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # the directory that holds hipdp/
         err = []
 
         def work():
+            # A per-epoch snapshot is best effort and must never end a training run that a plain save() would have survived: when the
+            # hand-over to the writer process fails (scratch directory full -- Docker's default /dev/shm is 64 MB, the 128x128 net dumps
+            # 75 MB --, no process to be had, the writer itself dying) the scratch files are removed and the SAME state is written the
+            # synchronous way, in this thread, from the host copies already made.  Only if that fails too is the error kept for joinSave().
+            host = {}
+            meta_path = raw_path = None
             try:
+                host['w'] = numpy.ascontiguousarray(rw.get(), numpy.float32).reshape(-1)
+                host['nt'] = numpy.ascontiguousarray(rn.get(), numpy.float32).reshape(-1)
+                if tmpdir is None:
+                    raise OSError("no scratch directory with room for the parameter dump")
+                meta_path, raw_path = os.path.join(tmpdir, tag + '.meta'), os.path.join(tmpdir, tag + '.f32')
                 with open(meta_path, 'wb') as fh:
                     pickle.dump(meta, fh, 4)
                 with open(raw_path, 'wb') as fh:          # ndarray.tofile releases the GIL while it writes
-                    numpy.ascontiguousarray(rw.get(), numpy.float32).reshape(-1).tofile(fh)
-                    numpy.ascontiguousarray(rn.get(), numpy.float32).reshape(-1).tofile(fh)
+                    host['w'].tofile(fh)
+                    host['nt'].tofile(fh)
                 env = dict(os.environ, PYTHONPATH=pkg + os.pathsep + os.environ.get('PYTHONPATH', ''))
                 r = subprocess.run([sys.executable, '-m', 'hipdp.ckpt_writer', meta_path, raw_path, filename], env=env,
                                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
                 if r.returncode != 0:
                     raise RuntimeError("checkpoint writer failed for %s: %s" % (filename, r.stdout.decode(errors='replace')[-2000:]))
                 print('Saved model parameter to {}'.format(filename))
-            except BaseException as e:           # noqa: BLE001  (re-raised by joinSave on the caller's thread)
-                err.append(e)
+            except BaseException as e:           # noqa: BLE001
+                for f in (meta_path, raw_path, filename + '.part'):
+                    try:
+                        if f is not None:
+                            os.remove(f)
+                    except OSError:
+                        pass
+                try:
+                    if 'nt' not in host:
+                        raise e
+                    from hipdp import ckpt_writer
+                    print('WARNING: asynchronous checkpoint of {} failed ({}: {}); writing it synchronously'.format(filename, type(e).__name__, e))
+                    ckpt_writer.write(ckpt_writer.build_state(meta, host), filename)
+                    print('Saved model parameter to {}'.format(filename))
+                except BaseException as e2:      # noqa: BLE001  (raised by joinSave(strict=True); reported otherwise)
+                    err.append(e2)
         th = threading.Thread(target=work, name='dpp-checkpoint')
         th.start()
-        self._save_pending = (th, err)
+        self._save_pending = (th, err, filename)
         return True
 
-    def joinSave(self):
-        """Wait for the checkpoint a saveAsync() started (no-op otherwise); an error of the writer thread is raised here."""
+    @staticmethod
+    def _scratch_dir(need_bytes):
+        """A directory with room for the raw parameter dump: /dev/shm when it has the space, else the temporary directory, else None."""
+        import shutil
+        import tempfile
+        for d in ('/dev/shm', tempfile.gettempdir()):
+            try:
+                if os.path.isdir(d) and os.access(d, os.W_OK) and shutil.disk_usage(d).free > need_bytes:
+                    return d
+            except OSError:
+                pass
+        return None
+
+    def joinSave(self, strict=False):
+        """Wait for the checkpoint a saveAsync() started (no-op otherwise), then write the snapshot request that was dropped while it ran
+        (skip_if_busy), if any.  A snapshot whose asynchronous AND synchronous write both failed is reported, not raised (the epoch loop's
+        `net_last.pkl` is best effort: a full disk must not end the run) -- unless strict."""
         pend = self.__dict__.pop('_save_pending', None)
         if pend is not None:
             pend[0].join()
             if pend[1]:
-                raise pend[1][0]
+                if strict:
+                    raise pend[1][0]
+                print('WARNING: checkpoint {} was NOT written: {}: {}'.format(pend[2], type(pend[1][0]).__name__, pend[1][0]))
+        dropped = self.__dict__.pop('_save_dropped', None)
+        if dropped is not None:
+            try:
+                self.save(dropped)
+            except (OSError, RuntimeError) as e:
+                if strict:
+                    raise
+                print('WARNING: checkpoint {} was NOT written: {}: {}'.format(dropped, type(e).__name__, e))
 
     def load(self, filename, raise_on_error=True):
         if filename is None:
