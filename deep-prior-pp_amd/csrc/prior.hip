@@ -40,7 +40,8 @@ constexpr int PM_NONE = 0, PM_COM = 1, PM_ROT = 2, PM_SC = 3, PM_ROTCOM = 4, PM_
 __global__ __launch_bounds__(DPP_THREADS) void pose_sample_kernel(const float* __restrict__ base_poses, const float* __restrict__ base_com,
                                                                   const float* __restrict__ base_cube, int J, const int* __restrict__ mode,
                                                                   const int* __restrict__ ridx, const double* __restrict__ off,
-                                                                  const double* __restrict__ sc, const double* __restrict__ rot, long n,
+                                                                  const double* __restrict__ sc, const double* __restrict__ rot,
+                                                                  const double* __restrict__ rot3, long n,
                                                                   PoseCam cam, float* __restrict__ out_poses, float* __restrict__ out_com,
                                                                   float* __restrict__ out_cube) {
     const long t = (long)blockIdx.x * DPP_THREADS + threadIdx.x;
@@ -71,6 +72,32 @@ __global__ __launch_bounds__(DPP_THREADS) void pose_sample_kernel(const float* _
     } else if (m == PM_COM) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) o[d] = ((p[d] + com[d]) - ncom[d]) / half;
+    } else if (rot3 != nullptr) {
+        // rot3D=True (handdetector.py:870, 891, 903): rotatePoints3D about the (new) centre with the sample's 3x3 matrix R = rot3[i]
+        // (row-major; getRotationMatrix of the three drawn angles, formed on the host), re-centred on the same centre.  As the
+        // reference: the offset from the centre in float32, product and re-centring in float64, stored float32.
+        float q[3];
+        if (m == PM_ROT) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) q[d] = p[d] + ncom[d];
+        } else {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) q[d] = (p[d] + com[d]) - ncom[d];
+            if (m == PM_ROTCOMSC) {
+                const float s = (float)sc[i];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) q[d] = q[d] * s;
+            }
+#pragma unroll
+            for (int d = 0; d < 3; ++d) q[d] = q[d] + ncom[d];
+        }
+        const double* R = rot3 + i * 9;
+        const double r0 = (double)(q[0] - ncom[0]), r1 = (double)(q[1] - ncom[1]), r2 = (double)(q[2] - ncom[2]);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float b = (float)(((R[d * 3] * r0 + R[d * 3 + 1] * r1) + R[d * 3 + 2] * r2) + (double)ncom[d]);
+            o[d] = (b - ncom[d]) / half;
+        }
     } else {
         // rotation in the image plane about the projected centre: 'rot' about com3D with the pose re-centred on new_com = com3D;
         // the combined modes shift (and scale) the pose first and rotate about the NEW centre, re-centring on the OLD one
@@ -362,16 +389,34 @@ __global__ __launch_bounds__(DPP_THREADS) void eval_reduce_kernel(const double* 
 
 }  // namespace
 
-extern "C" int dpp_pose_sample(const float* base_poses, const float* base_com, const float* base_cube, int n_base, int J, const int* mode,
-                               const int* ridx, const double* off, const double* sc, const double* rot, long n, double fx, double fy,
-                               double ux, double uy, int flip_y, float* out_poses, float* out_com, float* out_cube, dpp_stream_t stream) {
-    if (!base_poses || !base_com || !base_cube || !mode || !ridx || !off || !sc || !rot || !out_poses || n_base < 1 || J < 1 || n < 1)
+static int pose_sample_launch(const float* base_poses, const float* base_com, const float* base_cube, int n_base, int J, const int* mode,
+                              const int* ridx, const double* off, const double* sc, const double* rot, const double* rot3, long n, double fx,
+                              double fy, double ux, double uy, int flip_y, float* out_poses, float* out_com, float* out_cube,
+                              dpp_stream_t stream) {
+    if (!base_poses || !base_com || !base_cube || !mode || !ridx || !off || !sc || (!rot && !rot3) || !out_poses || n_base < 1 || J < 1 || n < 1)
         return DPP_E_BADARG;
     PoseCam cam = {fx, fy, ux, uy, flip_y};
     const long total = n * J;
     DPP_LAUNCH(pose_sample_kernel, dim3((unsigned)((total + DPP_THREADS - 1) / DPP_THREADS)), dim3(DPP_THREADS), 0,
-               static_cast<hipStream_t>(stream), base_poses, base_com, base_cube, J, mode, ridx, off, sc, rot, n, cam, out_poses, out_com, out_cube);
+               static_cast<hipStream_t>(stream), base_poses, base_com, base_cube, J, mode, ridx, off, sc, rot, rot3, n, cam, out_poses, out_com,
+               out_cube);
     return dpp_launch_status();
+}
+
+extern "C" int dpp_pose_sample(const float* base_poses, const float* base_com, const float* base_cube, int n_base, int J, const int* mode,
+                               const int* ridx, const double* off, const double* sc, const double* rot, long n, double fx, double fy,
+                               double ux, double uy, int flip_y, float* out_poses, float* out_com, float* out_cube, dpp_stream_t stream) {
+    if (!rot) return DPP_E_BADARG;
+    return pose_sample_launch(base_poses, base_com, base_cube, n_base, J, mode, ridx, off, sc, rot, nullptr, n, fx, fy, ux, uy, flip_y, out_poses,
+                              out_com, out_cube, stream);
+}
+
+extern "C" int dpp_pose_sample_rot3d(const float* base_poses, const float* base_com, const float* base_cube, int n_base, int J, const int* mode,
+                                     const int* ridx, const double* off, const double* sc, const double* rot3, long n, double fx, double fy,
+                                     double ux, double uy, int flip_y, float* out_poses, float* out_com, float* out_cube, dpp_stream_t stream) {
+    if (!rot3) return DPP_E_BADARG;
+    return pose_sample_launch(base_poses, base_com, base_cube, n_base, J, mode, ridx, off, sc, nullptr, rot3, n, fx, fy, ux, uy, flip_y, out_poses,
+                              out_com, out_cube, stream);
 }
 
 extern "C" size_t dpp_pca_workspace_bytes(long N, int D) {

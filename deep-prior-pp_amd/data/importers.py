@@ -227,6 +227,24 @@ class ICVLImporter(DepthImporter):
         assert len(img.getbands()) == 1                     # ensure depth image
         return np.asarray(img, np.float32)
 
+    def _baseline_rows(self, filename, firstName):
+        """The non-blank lines of a result file as a (frames, numJoints, 3) float32 array of (u, v, d) triples; with firstName the
+        leading file-name token of every line is skipped."""
+        off = 1 if firstName else 0
+        with open(filename) as fh:
+            rows = [ln.strip().split(' ') for ln in fh if ln.rstrip()]
+        n = self.numJoints * 3
+        return np.asarray([[float(v) for v in r[off:off + n]] for r in rows], np.float32).reshape(len(rows), self.numJoints, 3)
+
+    def loadBaseline(self, filename, firstName=False):
+        """Results of a baseline method (e.g. LRF_Results_seq_1.txt: one line of u v d triples per frame) as a list of metric (numJoints, 3)
+        arrays (importers.py:422-456)."""
+        return [self.jointsImgTo3D(ev) for ev in self._baseline_rows(filename, firstName)]
+
+    def loadBaseline2D(self, filename, firstName=False):
+        """The same file as image-plane (numJoints, 2) arrays (importers.py:458-484)."""
+        return [np.array(ev[:, :2]) for ev in self._baseline_rows(filename, firstName)]
+
     def loadSequence(self, seqName, subSeq=None, Nmax=float('inf'), shuffle=False, rng=None, docom=False, cube=None):
         """<basepath>/<seqName>.txt: one line per frame, `relative/path.png u v d` x 16 joints; frames under <basepath>/Depth/
         (importers.py:232-420)."""
@@ -386,6 +404,52 @@ class NYUImporter(DepthImporter):
         _, g, b = img.split()
         g, b = np.asarray(g, np.int32), np.asarray(b, np.int32)
         return np.asarray(np.bitwise_or(np.left_shift(g, 8), b), np.float32)
+
+    @staticmethod
+    def _predicted_uv(filename):
+        """`pred_joint_uvconf` of camera 0 from Tompson et al.'s test_predictions.mat, with the all-zero (unused) joint slots of every frame
+        dropped: (frames, numJoints, 3) of (u, v, confidence); numJoints = the length of `conv_joint_names`."""
+        import scipy.io
+        mat = scipy.io.loadmat(filename)
+        numJoints = mat['conv_joint_names'][0].shape[0]
+        joints = np.asarray(mat['pred_joint_uvconf'][0])
+        out = np.zeros((joints.shape[0], numJoints, 3), np.float64)
+        for f in range(joints.shape[0]):
+            used = joints[f][np.count_nonzero(joints[f], axis=1) != 0]
+            out[f, :used.shape[0]] = used[:numJoints]
+        return numJoints, out
+
+    def loadBaseline(self, filename, gt=None):
+        """Baseline predictions as a list of metric (numJoints, 3) arrays (importers.py:1079-1145).  With `gt` (frames, >= 14 joints, 3:
+        the ground truth in image coordinates) the file is the .mat of 2-D predictions: depth is read off the frame `depth_1_NNNNNNN.png`
+        beside it at the predicted pixel and replaced by the ground-truth depth where it is more than 150 mm from that of joint 13 (the
+        palm: a prediction that fell onto the background); frames whose image is missing are skipped.  Without `gt` the file is text, one
+        line of u v d triples per frame."""
+        if gt is None:
+            with open(filename) as fh:
+                rows = [ln.rstrip().split(' ') for ln in fh if ln.rstrip()]
+            self.numJoints = len(rows[0]) // 3
+            n = self.numJoints * 3
+            return [self.jointsImgTo3D(np.asarray([float(v) for v in r[:n]], np.float32).reshape(self.numJoints, 3)) for r in rows]
+        self.numJoints, pred = self._predicted_uv(filename)
+        data = []
+        for dat in range(min(pred.shape[0], gt.shape[0])):
+            fname = '{0:s}/depth_1_{1:07d}.png'.format(os.path.split(filename)[0], dat + 1)
+            if not os.path.isfile(fname):
+                continue
+            dm = self.loadDepthMap(fname)
+            ev = np.zeros((self.numJoints, 3), np.float32)
+            ev[:, :2] = pred[dat, :, :2]
+            ev[:, 2] = dm[ev[:, 1].astype(int), ev[:, 0].astype(int)]
+            far = np.abs(ev[:, 2] - gt[dat, 13, 2]) > 150.
+            ev[far, 2] = np.asarray(gt[dat, :self.numJoints, 2])[far]
+            data.append(self.jointsImgTo3D(ev))
+        return data
+
+    def loadBaseline2D(self, filename):
+        """The .mat predictions as image-plane (numJoints, 2) arrays (importers.py:1147-1175)."""
+        self.numJoints, pred = self._predicted_uv(filename)
+        return [np.asarray(p[:, :2], np.float32) for p in pred]
 
     def loadSequence(self, seqName, Nmax=float('inf'), shuffle=False, rng=None, docom=False, cube=None):
         """<basepath>/<seqName>/joint_data.mat (joint_xyz, joint_uvd of camera 1) and depth_1_NNNNNNN.png

@@ -46,3 +46,68 @@ def rotatePoints2D(pts, center, angle):
 def rotatePoint2D(p1, center, angle):
     """One (u, v, d) point; see rotatePoints2D."""
     return rotatePoints2D(numpy.asarray(p1)[None, :], center, angle)[0]
+
+
+# ---- 3-D rotations about a centre (/root/reference/src/data/transformations.py:105-166) ------------------------------------------------
+def euler_rxyz_matrix(ax, ay, az):
+    """3x3 matrix of `transforms3d.euler.euler2mat(ax, ay, az, 'rxyz')` (radians; scalars or equal-shaped arrays -> (..., 3, 3)), the call
+    getRotationMatrix makes (transformations.py:118-119).  transforms3d (0.3, a dependency the reference does not vendor and this image
+    does not have) is restated from its published algorithm: axes 'rxyz' = (first axis 2, parity 1, no repetition, rotating frame), i.e.
+    i, j, k = z, y, x, the first and last angles swapped, all three negated, then Shoemake's products.  The result equals
+    Rx(ax) @ Ry(ay) @ Rz(az) -- intrinsic rotations about x, then the new y, then the new z (checked in tests/test_oracle.py)."""
+    ai, aj, ak = -numpy.asarray(az, numpy.float64), -numpy.asarray(ay, numpy.float64), -numpy.asarray(ax, numpy.float64)
+    si, sj, sk = numpy.sin(ai), numpy.sin(aj), numpy.sin(ak)
+    ci, cj, ck = numpy.cos(ai), numpy.cos(aj), numpy.cos(ak)
+    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
+    i, j, k = 2, 1, 0
+    M = numpy.zeros(numpy.shape(ai) + (3, 3), numpy.float64)
+    M[..., i, i] = cj * ck
+    M[..., i, j] = sj * sc - cs
+    M[..., i, k] = sj * cc + ss
+    M[..., j, i] = cj * sk
+    M[..., j, j] = sj * ss + cc
+    M[..., j, k] = sj * cs - sc
+    M[..., k, i] = -sj
+    M[..., k, j] = cj * si
+    M[..., k, k] = cj * ci
+    return M
+
+
+def getRotationMatrix(angle_x, angle_y, angle_z):
+    """4x4 homogeneous rotation for angles in degrees about x, y, z (rotating frame)."""
+    R = numpy.eye(4)
+    R[:3, :3] = euler_rxyz_matrix(angle_x * numpy.pi / 180., angle_y * numpy.pi / 180., angle_z * numpy.pi / 180.)
+    return R
+
+
+def rotatePoints3D(pts, center, angle_x, angle_y, angle_z):
+    """Rotate the (n, 3) points about `center`; dtype of `pts`.  The offset from the centre is formed in the points' own precision (the
+    reference subtracts in place on a copy of the point), the product and the re-centring are float64, the result is stored in the
+    points' dtype."""
+    out = numpy.array(pts, copy=True)
+    R = getRotationMatrix(angle_x, angle_y, angle_z)[:3, :3]
+    ctr = numpy.asarray(center)
+    rel = out - ctr.astype(out.dtype)
+    out[:] = rel.astype(numpy.float64) @ R.T + ctr.astype(numpy.float64)
+    return out
+
+
+def rotatePoint3D(p1, center, angle_x, angle_y, angle_z):
+    """One point; a float64 triple like the reference's (its `ps` is the float64 product)."""
+    p = numpy.asarray(p1)
+    rel = p - numpy.asarray(center).astype(p.dtype)
+    return rel.astype(numpy.float64) @ getRotationMatrix(angle_x, angle_y, angle_z)[:3, :3].T + numpy.asarray(center, numpy.float64)
+
+
+def transformPoint3D(pt, M):
+    """One (x, y, z) point through the 4x4 homogeneous matrix M."""
+    q = numpy.asarray(M, numpy.float64).reshape(4, 4) @ numpy.array([pt[0], pt[1], pt[2], 1.], numpy.float64)
+    return q[:3] / q[3]
+
+
+def getTransformationMatrix(center, rot, trans, scale):
+    """The six coefficients (row-major 2x3) of: translate by -trans - center, rotate by `rot` (radians), scale, move back to center."""
+    c, s = numpy.cos(rot), numpy.sin(rot)
+    dx, dy = -trans[0] - center[0], -trans[1] - center[1]
+    return numpy.array([c * scale, -s * scale, scale * (c * dx - s * dy) + center[0],
+                        s * scale, c * scale, scale * (c * dy + s * dx) + center[1]])

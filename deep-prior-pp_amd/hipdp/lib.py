@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), 'lib', 'libdpp_hip.so')
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 ST_A, ST_B, ST_C, ST_BNX = 1, 2, 4, 8      # DPP_ST_*: which pointers of a call address bf16-stored activation tensors
 c_float_p = C.c_void_p      # device pointers travel as integers
 stream_t = C.c_void_p
@@ -170,6 +170,9 @@ SIGNATURES = {
     'dpp_pose_sample': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, stream_t]),
+    'dpp_pose_sample_rot3d': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_long, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, stream_t]),
     'dpp_pca_workspace_bytes': (C.c_size_t, [C.c_long, C.c_int]),
     'dpp_pca_fit': (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_pose_eval': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),

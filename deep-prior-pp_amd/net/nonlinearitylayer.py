@@ -21,10 +21,8 @@ class NonlinearityLayer(Layer):
         assert isinstance(cfgParams, NonlinearityLayerParams)
         self.inputVar, self.cfgParams, self.layerNum = inputVar, cfgParams, layerNum
         self.output_pre_act = inputVar
-        if cfgParams.activation is None:
-            self.output = Var('layer', (inputVar,), layer=self, shape=cfgParams.outputDim)
-        else:
-            self.output = Var('layer', (inputVar,), layer=self, shape=cfgParams.outputDim)
+        # (activation None = the identity: the engine reads the function off cfgParams when it folds the node into its consumer)
+        self.output = Var('layer', (inputVar,), layer=self, shape=cfgParams.outputDim)
         self.output.name = 'output_layer_{}'.format(self.layerNum)
         self.params = []
         self.weights = []

@@ -140,8 +140,6 @@ class HandDetector(object):
         sigma_com = 5. if sigma_com is None else sigma_com
         sigma_sc = 0.02 if sigma_sc is None else sigma_sc
         rot_range = 180. if rot_range is None else rot_range
-        if rot3D:
-            raise NotImplementedError("3-D rotation sampling needs transforms3d and is not used by the embedding scripts")
         simple = ('none', 'rot', 'sc', 'com')
         combo = ('rot+com', 'com+rot')
         combo_sc = ('rot+com+sc', 'rot+sc+com')
@@ -190,6 +188,13 @@ class HandDetector(object):
             out[..., 1] = r1 + center[:, None, 1]
             return out
 
+        def rot_3d(pts, center, angles):    # rotatePoints3D about per-sample centres with per-sample angles, transformations.py:105-155
+            from data.transformations import euler_rxyz_matrix
+            a = numpy.asarray(angles, numpy.float64) * numpy.pi / 180.
+            R = euler_rxyz_matrix(a[:, 0], a[:, 1], a[:, 2])
+            rel = (pts - center[:, None]).astype(numpy.float64)             # the offset is formed in the points' precision
+            return (numpy.einsum('nab,njb->nja', R, rel) + center[:, None].astype(numpy.float64)).astype(pts.dtype)
+
         dt = base_poses.dtype
         mode_of = numpy.asarray([aug_modes[m] for m in range(len(aug_modes))])
         mname = mode_of[modes]
@@ -204,6 +209,9 @@ class HandDetector(object):
             elif mode == 'rot':
                 new_com[I], new_cube[I] = com3D, cube
                 nc = new_com[I]
+                if rot3D:
+                    new_poses[I] = (rot_3d(pose + nc[:, None], nc, rot[I]) - nc[:, None]) / (new_cube[I][:, 2] / 2.)[:, None, None]
+                    continue
                 joint_2D = to_img(pose + nc[:, None])
                 data_2D = rot_2d(joint_2D, to_img(com3D), rot[I, 0])
                 new_poses[I] = (to_3d(data_2D) - nc[:, None]) / (new_cube[I][:, 2] / 2.)[:, None, None]
@@ -220,6 +228,10 @@ class HandDetector(object):
                 p = pose + com3D[:, None] - new_com[I][:, None]
                 if mode in combo_sc:
                     p = p * sc[I].astype(f32)[:, None, None]
+                if rot3D:                    # handdetector.py:891, 903: about the NEW centre, re-centred on it
+                    nc = new_com[I]
+                    new_poses[I] = (rot_3d(p + nc[:, None], nc, rot[I]) - nc[:, None]) / (new_cube[I][:, 2] / 2.)[:, None, None]
+                    continue
                 joint_2D = to_img(p + com3D[:, None])
                 data_2D = rot_2d(joint_2D, to_img(new_com[I]), rot[I, 0])
                 new_poses[I] = (to_3d(data_2D) - com3D[:, None]) / (new_cube[I][:, 2] / 2.)[:, None, None]

@@ -19,8 +19,9 @@ MODE_CODE = {'none': 0, 'com': 1, 'rot': 2, 'sc': 3, 'rot+com': 4, 'com+rot': 4,
 
 
 def sample_random_poses_device(importer, rng, base_poses, base_com, base_cube, num_poses, aug_modes, sigma_com=None, sigma_sc=None,
-                               rot_range=None, runtime=None, keep_on_device=False):
-    """HandDetector.sampleRandomPoses(..., rot3D=False) with the per-sample arithmetic on the device.  Returns the (n, J, 3) float32
+                               rot_range=None, runtime=None, keep_on_device=False, rot3D=False):
+    """HandDetector.sampleRandomPoses(...) with the per-sample arithmetic on the device (rot3D: the rotation modes turn the pose in 3-D
+    about its centre, /root/reference/src/util/handdetector.py:870, 891, 903; the per-sample rotation matrices are formed on the host).  Returns the (n, J, 3) float32
     poses (a device Buffer when keep_on_device, else a NumPy array).  Draws: exactly the reference's five rng calls."""
     rt = runtime or default_runtime()
     sigma_com = 5. if sigma_com is None else sigma_com
@@ -44,13 +45,20 @@ def sample_random_poses_device(importer, rng, base_poses, base_com, base_cube, n
     up = rt.upload
     d_poses, d_com, d_cube = up(base_poses), up(numpy.ascontiguousarray(base_com, numpy.float32)), up(numpy.ascontiguousarray(base_cube, numpy.float32))
     d_mode, d_ridx = up(code.astype(numpy.int32)), up(ridxs.astype(numpy.int32))
+    if rot3D:
+        from data.transformations import euler_rxyz_matrix
+        a = rot * numpy.pi / 180.
+        rot_arg = euler_rxyz_matrix(a[:, 0], a[:, 1], a[:, 2]).reshape(n, 9)
+    else:
+        rot_arg = rot[:, 0]
     d_off, d_sc, d_rot = up(numpy.ascontiguousarray(off, numpy.float64)), up(numpy.ascontiguousarray(sc, numpy.float64)), \
-        up(numpy.ascontiguousarray(rot[:, 0], numpy.float64))
+        up(numpy.ascontiguousarray(rot_arg, numpy.float64))
     out = rt.alloc((n, J, 3), zero=False)
     flip = bool(getattr(importer, 'flip_y', importer.__class__.__name__ in ('NYUImporter', 'MSRA15Importer')))
-    check(rt.lib.dpp_pose_sample(d_poses.ptr, d_com.ptr, d_cube.ptr, base_poses.shape[0], J, d_mode.ptr, d_ridx.ptr, d_off.ptr, d_sc.ptr,
-                                 d_rot.ptr, n, float(importer.fx), float(importer.fy), float(importer.ux), float(importer.uy), int(flip),
-                                 out.ptr, None, None, rt.stream), 'dpp_pose_sample')
+    fn = rt.lib.dpp_pose_sample_rot3d if rot3D else rt.lib.dpp_pose_sample
+    check(fn(d_poses.ptr, d_com.ptr, d_cube.ptr, base_poses.shape[0], J, d_mode.ptr, d_ridx.ptr, d_off.ptr, d_sc.ptr,
+             d_rot.ptr, n, float(importer.fx), float(importer.fy), float(importer.ux), float(importer.uy), int(flip),
+             out.ptr, None, None, rt.stream), 'dpp_pose_sample')
     if keep_on_device:
         out.keep = (d_poses, d_com, d_cube, d_mode, d_ridx, d_off, d_sc, d_rot)      # inputs alive until the kernel has run
         return out

@@ -34,7 +34,7 @@ typedef void* dpp_stream_t; /* a hipStream_t */
 #define DPP_E_BADARG 10001
 #define DPP_E_UNSUPPORTED 10002
 
-#define DPP_ABI_VERSION 10
+#define DPP_ABI_VERSION 11
 int dpp_abi_version(void);
 
 /* bf16 STORAGE of activation tensors (ABI v9; BASELINE config 5 "bf16 MFMA, 256x256 input stress").  The [pixels][channels] tensors the
@@ -441,6 +441,12 @@ int dpp_crop_refine(const float* frames, const void* records, int B, int H, int 
 int dpp_pose_sample(const float* base_poses, const float* base_com, const float* base_cube, int n_base, int J, const int* mode,
                     const int* ridx, const double* off, const double* sc, const double* rot, long n, double fx, double fy,
                     double ux, double uy, int flip_y, float* out_poses, float* out_com, float* out_cube, dpp_stream_t stream);
+/* (ABI v11) the same with rot3D=True (handdetector.py:870, 891, 903): the rotation modes turn the pose in 3-D about the (new) centre --
+ * rotatePoints3D, /root/reference/src/data/transformations.py:105-155 -- by the sample's matrix rot3[i] (3x3 row-major f64: getRotationMatrix of
+ * the three drawn angles, formed on the host like the draws themselves) instead of in the image plane. */
+int dpp_pose_sample_rot3d(const float* base_poses, const float* base_com, const float* base_cube, int n_base, int J, const int* mode,
+                          const int* ridx, const double* off, const double* sc, const double* rot3, long n, double fx, double fy,
+                          double ux, double uy, int flip_y, float* out_poses, float* out_com, float* out_cube, dpp_stream_t stream);
 size_t dpp_pca_workspace_bytes(long N, int D);
 int dpp_pca_fit(const float* X, long N, int D, void* workspace, double* mean, double* evals, double* components, dpp_stream_t stream);
 int dpp_pose_eval(const float* gt, const float* pred, int N, int J, const double* thresholds, int T, double* err, double* frame,

@@ -189,3 +189,47 @@ def test_msra_reader(backend, tmp_path):
     seq = imp.loadSequence('P0')
     _check(seq, imp, cam, frames, gtuvd, gt3D, cube)
     assert [f.subSeqName for f in imp.loadSequence('P0', subSeq=['IP']).data] == ['IP', 'IP']
+
+
+def test_load_baseline_readers_against_reference_outputs(tmp_path):
+    """tests/golden/baseline.npz (make_golden_r6.py): ICVLImporter / NYUImporter.loadBaseline and loadBaseline2D
+    (/root/reference/src/data/importers.py:422-484, 1079-1175) run by the reference on small result files; the files are rebuilt here from
+    the numbers the fixture keeps (text rows, the .mat arrays, the depth frames)."""
+    import scipy.io
+    from PIL import Image
+    from data.importers import ICVLImporter, NYUImporter
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'baseline.npz'))
+    icvl = ICVLImporter('x')
+    for first in (0, 1):
+        fn = str(tmp_path / ('lrf_%d.txt' % first))
+        with open(fn, 'w') as fh:
+            for k, r in enumerate(g['icvl_rows']):
+                fh.write((('image_%04d.png ' % k) if first else '') + ' '.join('%.4f' % v for v in r.reshape(-1)) + '\n')
+                if k == 2:
+                    fh.write('\n')
+        got = icvl.loadBaseline(fn, firstName=bool(first))
+        assert isinstance(got, list) and got[0].dtype == np.float32
+        np.testing.assert_allclose(np.stack(got), g['icvl_3d_%d' % first], rtol=2e-7, atol=0)
+        np.testing.assert_array_equal(np.stack(icvl.loadBaseline2D(fn, firstName=bool(first))), g['icvl_2d_%d' % first])
+    nyu = NYUImporter('x')
+    fn = str(tmp_path / 'pred.txt')
+    with open(fn, 'w') as fh:
+        for r in g['nyu_rows']:
+            fh.write(' '.join('%.4f' % v for v in r.reshape(-1)) + '\n')
+    np.testing.assert_allclose(np.stack(nyu.loadBaseline(fn)), g['nyu_text_3d'], rtol=2e-7, atol=0)
+    assert nyu.numJoints == 14
+    uvc, depth, gt = g['nyu_uvc'], g['nyu_depth'], g['nyu_gt']
+    names = np.empty((1, 14), dtype=object)
+    for j in range(14):
+        names[0, j] = 'J%d' % j
+    scipy.io.savemat(str(tmp_path / 'test_predictions.mat'), {'conv_joint_names': names, 'pred_joint_uvconf': uvc[None]})
+    for f in range(depth.shape[0]):
+        if f == 2:
+            continue                                                # a missing frame is skipped
+        rgb = np.zeros(depth.shape[1:] + (3,), np.uint8)
+        rgb[..., 1], rgb[..., 2] = depth[f] >> 8, depth[f] & 255
+        Image.fromarray(rgb).save(str(tmp_path / ('depth_1_%07d.png' % (f + 1))))
+    got = nyu.loadBaseline(str(tmp_path / 'test_predictions.mat'), gt)
+    assert len(got) == 3
+    np.testing.assert_allclose(np.stack(got), g['nyu_mat_3d'], rtol=2e-7, atol=0)
+    np.testing.assert_array_equal(np.stack(nyu.loadBaseline2D(str(tmp_path / 'test_predictions.mat'))), g['nyu_mat_2d'])

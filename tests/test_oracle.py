@@ -352,6 +352,39 @@ def test_sample_random_poses_against_reference_outputs():
             np.testing.assert_allclose(got, g['%s_%s' % (nm, tag)], rtol=0, atol=2e-6)       # poses are O(1) normalised coordinates
 
 
+def test_rotate_points_3d_and_rot3d_pose_sampling_against_reference_outputs():
+    """tests/golden/rot3d.npz (make_golden_r6.py): the reference's rotatePoints3D / rotatePoint3D / getRotationMatrix / transformPoint3D /
+    getTransformationMatrix (data/transformations.py:34-45, 105-166) and HandDetector.sampleRandomPoses(rot3D=True)
+    (util/handdetector.py:870, 891, 903) run here, with a documented stand-in for the one transforms3d function they import."""
+    from data import transformations as T
+    from data.importers import ICVLImporter, NYUImporter
+    from util.handdetector import HandDetector
+    g = _golden('rot3d.npz')
+    for i in range(g['pts'].shape[0]):
+        np.testing.assert_allclose(T.getRotationMatrix(*g['ang'][i]), g['R'][i], rtol=0, atol=1e-15)
+        got = T.rotatePoints3D(g['pts'][i], g['ctr'][i], *g['ang'][i])
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, g['out'][i], rtol=0, atol=1e-4)        # coordinates are O(600) mm: a float32 ulp is 6e-5
+        np.testing.assert_allclose(T.rotatePoint3D(g['pts'][i, 0].astype(np.float64), g['ctr'][i].astype(np.float64), *g['ang'][i]),
+                                   g['out_point64'][i], rtol=0, atol=1e-10)
+    for i in range(g['tp3_M'].shape[0]):
+        np.testing.assert_allclose(T.transformPoint3D(g['pts'][i, 0], g['tp3_M'][i]), g['tp3_out'][i], rtol=1e-12, atol=1e-9)
+    for a, want in zip(g['gtm_args'], g['gtm_out']):
+        np.testing.assert_allclose(T.getTransformationMatrix(a[0:2], a[2], a[3:5], a[5]), want, rtol=1e-14, atol=1e-12)
+    a = np.deg2rad(g['ang'][:, 0]), np.deg2rad(g['ang'][:, 1]), np.deg2rad(g['ang'][:, 2])
+    np.testing.assert_allclose(T.euler_rxyz_matrix(*a), g['R'][:, :3, :3], rtol=0, atol=1e-15)           # the array form
+    for nm, di in (('icvl', ICVLImporter('x')), ('nyu', NYUImporter('x'))):
+        args = (g['%s_gt' % nm], g['%s_com' % nm], g['%s_cube' % nm], 300)
+        for tag, modes in (('main', ['com', 'rot', 'none']), ('all', ['com', 'rot', 'sc', 'none', 'rot+com', 'rot+com+sc'])):
+            got, ncom, ncube, _ = HandDetector.sampleRandomPoses(di, np.random.RandomState(9), *args, modes, retall=True, rot3D=True)
+            assert got.shape == g['%s_%s' % (nm, tag)].shape and got.dtype == np.float32
+            np.testing.assert_allclose(got, g['%s_%s' % (nm, tag)], rtol=0, atol=2e-6)
+            np.testing.assert_array_equal(ncom, g['%s_%s_com' % (nm, tag)])
+            # ('sc': float32 cube x float64 draw -- a float32 product under the reference's 2017 NumPy and here, a rounded float64 one under
+            #  the NumPy 2 that generated the fixture: one float32 ulp)
+            np.testing.assert_allclose(ncube, g['%s_%s_cube' % (nm, tag)], rtol=1.3e-7, atol=0)
+
+
 def test_pca_projection_is_sklearns():
     """proj.transform(label) of poseregnettrainer.py:262 is scikit-learn's PCA.transform: (x - mean_) . components_^T."""
     from oracle import augment as A

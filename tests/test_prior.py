@@ -56,6 +56,27 @@ def test_device_pose_sampling_matches_the_reference_fixture(backend):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+def test_device_pose_sampling_rot3d_matches_host_and_reference_fixture(backend):
+    """rot3D=True (/root/reference/src/util/handdetector.py:870, 891, 903): the device path against the host
+    restatement (bit for bit: the rotation matrices are the host's, the arithmetic is IEEE without contraction) and against rot3d.npz,
+    the reference's own output (tests/golden/make_golden_r6.py)."""
+    rt = get_runtime(backend)
+    R.set_default_runtime(rt)
+    g = np.load(os.path.join(GOLD, 'rot3d.npz'))
+    for nm, di in (('icvl', ICVLImporter('x')), ('nyu', NYUImporter('x'))):
+        args = (g['%s_gt' % nm], g['%s_com' % nm], g['%s_cube' % nm], 300)
+        for tag, modes in (('main', ['com', 'rot', 'none']), ('all', ['com', 'rot', 'sc', 'none', 'rot+com', 'rot+com+sc'])):
+            got = sample_random_poses_device(di, np.random.RandomState(9), *args, modes, runtime=rt, rot3D=True)
+            host = HandDetector.sampleRandomPoses(di, np.random.RandomState(9), *args, modes, rot3D=True)
+            want = g['%s_%s' % (nm, tag)]
+            assert got.shape == want.shape and got.dtype == np.float32
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+            assert np.array_equal(got, host)
+            flat = sample_random_poses_device(di, np.random.RandomState(9), *args, modes, runtime=rt)
+            assert not np.array_equal(flat, got)          # the in-plane rotation is a different sample
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('J', [14, 21])
 def test_device_pca_matches_sklearn(backend, J):
     rt = get_runtime(backend)
