@@ -78,7 +78,7 @@ def _time_cpu_steps(batch, size, min_steps, max_steps, budget_s):
         t0 = time.time()
         tr.step(x, y, 1e-3)
         times.append(time.time() - t0)
-    return sum(times) / len(times), float(np.median(times)), len(times)
+    return sum(times) / len(times), float(np.median(times)), len(times), times
 
 
 def _augment_worker(job):
@@ -153,47 +153,65 @@ def forward_parity_mm(rt, size, frames=8):
                 against='float64 NumPy oracle (oracle/nets.py), 14 joints through the PCA-prior layer, 300 mm cube')
 
 
+def _cpu_leg_child(argv):
+    """`bench.py --cpu-leg batch size threads min_steps max_steps budget_s`: the child process of cpu_baseline -- started with
+    OMP_NUM_THREADS / OMP_PROC_BIND / OMP_PLACES in its environment (they are read when the OpenMP runtime starts, so they cannot be set
+    inside the parent) -- times the oracle's PyTorch-CPU train step and prints the per-step seconds as one JSON line."""
+    batch, size, threads, min_steps, max_steps = (int(v) for v in argv[:5])
+    budget = float(argv[5])
+    import torch
+    torch.set_num_threads(threads)
+    import torch.nn.functional  # noqa: F401
+    times = _time_cpu_steps(batch, size, min_steps, max_steps, budget)[3]
+    print(json.dumps(dict(times=times, threads=int(torch.get_num_threads()))))
+
+
+def _cpu_leg(batch, size, threads, min_steps, max_steps, budget_s):
+    """Per-step seconds of the CPU train step on `threads` OpenMP threads pinned to neighbouring cores, measured in a child process."""
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_PROC_BIND='close', OMP_PLACES='cores',
+               OMP_WAIT_POLICY='active')
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-leg', str(batch), str(size), str(threads), str(min_steps),
+                        str(max_steps), str(budget_s)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError('cpu leg failed: ' + r.stderr.decode(errors='replace')[-1500:])
+    return json.loads(r.stdout.decode().strip().splitlines()[-1])['times']
+
+
 def cpu_baseline(batch, size, budget_s=45.0):
     """The oracle's PyTorch-CPU restatement of the identical fp32 train step on bounded samples, as legs of
     the SAME JSON line.  PyTorch-CPU does NOT get faster with every core on these small convolutions (round 4 measured 19.8 crops/s
     on 128 threads against 38.3 on ONE thread at batch 16), so the headline leg is the best of {all threads, 32, 16, 8} at the
     benchmarked batch -- chosen on the median of 2-3 probe steps each (all candidates are printed), then timed for the rest of the
-    budget (median step) -- and the all-thread and one-thread figures are reported beside it, plus the NumPy augmentation in 1 and 8
-    processes (the reference's para_num_proc = 8, nettrainer.py:59).  With forward_parity_mm the only place this script touches
-    oracle/."""
+    budget -- and the all-thread and one-thread figures are reported beside it, plus the NumPy augmentation in 1 and 8 processes (the
+    reference's para_num_proc = 8, nettrainer.py:59).  With forward_parity_mm the only place this script touches oracle/.
+    Round 6: every timing runs in a CHILD process started with OMP_NUM_THREADS = the candidate count,
+    OMP_PROC_BIND=close and OMP_PLACES=cores -- the threads of a candidate sit on neighbouring cores and stay there.  Unpinned, the same
+    16 threads measured 72 and 383 crops/s inside one process (round 5: placement decided per parallel region).  `value` is the median of
+    the longer run; the probe's median at the chosen count is reported beside it."""
     import torch
     threads = int(torch.get_num_threads())
     extra = {}
-    try:
-        # Candidate thread counts, each timed on the MEDIAN of 3 steps after a warm-up step (round 4 chose on ONE probe step and two
-        # boxes then disagreed 2.8x on the headline figure: a single step of a 128-thread OpenMP region is mostly scheduling noise).
-        probes = {}
-        for t in sorted(set([threads, min(threads, 32), min(threads, 16), min(threads, 8)]), reverse=True):
-            torch.set_num_threads(t)
-            probes[t] = _time_cpu_steps(batch, size, 2, 3, 6.0)[1]       # 3 steps (2 where a step takes > 3 s: the oversubscribed counts)
-        best = min(probes, key=probes.get)
-        torch.set_num_threads(best)
-        left = max(10.0, budget_s - 4.0 * sum(probes.values()))
-        mean_s, med_s, n = _time_cpu_steps(batch, size, 5, 12, left)
-        cand = {str(t): round(batch / v, 2) for t, v in sorted(probes.items())}
-        # The host of a GPU box is a noisy place (128 hardware threads, placement decided per run: the same thread count measured 2.7x apart
-        # within one process in round 5): the baseline is the BEST sustained rate seen at the chosen count -- the better of the probe's
-        # median and the longer run's median -- so that noise can only make the CPU look faster, never the comparison kinder to the GPU.
-        best_s = min(med_s, probes[best])
-        out = dict(value=round(batch / best_s, 2), unit='depth-crops/sec', cores=best, kind='port', candidates_crops_per_s=cand,
-                   medians_s_per_step=dict(probe=round(probes[best], 3), run=round(med_s, 3)),
-                   sample='%d train steps of batch %d (PyTorch-CPU fp32 restatement, not Theano) on %d of %d threads (the fastest of %s, each '
-                          'on the median of 2-3 probe steps): median %.2f s/step, mean %.2f; value = the better of that median and the '
-                          "probe's" % (n, batch, best, threads, sorted(probes), med_s, mean_s))
-        extra['cpu_baseline_all_threads'] = dict(value=round(batch / probes[threads], 2), unit='depth-crops/sec', cores=threads, kind='port',
-                                                 sample='median of 2-3 train steps of batch %d after a warm-up step: %.2f s' % (batch, probes[threads]))
-        torch.set_num_threads(1)
-        b1 = min(16, batch)
-        mean1, med1, n1 = _time_cpu_steps(b1, size, 2, 6, 15.0)
-        extra['cpu_baseline_1thread'] = dict(value=round(b1 / med1, 3), unit='depth-crops/sec', cores=1, kind='port',
-                                             sample='%d train steps of batch %d of the same graph on ONE thread: median %.2f s/step' % (n1, b1, med1))
-    finally:
-        torch.set_num_threads(threads)
+    probes = {}
+    for t in sorted(set([threads, min(threads, 32), min(threads, 16), min(threads, 8)]), reverse=True):
+        probes[t] = float(np.median(_cpu_leg(batch, size, t, 2, 3, 6.0)))       # 3 steps (2 where a step takes > 3 s: the oversubscribed counts)
+    best = min(probes, key=probes.get)
+    left = max(10.0, budget_s - 4.0 * sum(probes.values()))
+    times = _cpu_leg(batch, size, best, 5, 12, left)
+    med_s, mean_s, n = float(np.median(times)), float(np.mean(times)), len(times)
+    cand = {str(t): round(batch / v, 2) for t, v in sorted(probes.items())}
+    out = dict(value=round(batch / med_s, 2), unit='depth-crops/sec', cores=best, kind='port', candidates_crops_per_s=cand,
+               medians_s_per_step=dict(probe=round(probes[best], 3), run=round(med_s, 3)),
+               pinning='child process per timing: OMP_NUM_THREADS=<cores>, OMP_PROC_BIND=close, OMP_PLACES=cores',
+               sample='%d train steps of batch %d (PyTorch-CPU fp32 restatement, not Theano) on %d of %d threads pinned to neighbouring cores '
+                      '(the fastest of %s, each on the median of 2-3 probe steps in a process of its own): median %.2f s/step, mean %.2f; '
+                      'value = that median' % (n, batch, best, threads, sorted(probes), med_s, mean_s))
+    extra['cpu_baseline_all_threads'] = dict(value=round(batch / probes[threads], 2), unit='depth-crops/sec', cores=threads, kind='port',
+                                             sample='median of 2-3 train steps of batch %d after a warm-up step: %.2f s' % (batch, probes[threads]))
+    b1 = min(16, batch)
+    t1 = _cpu_leg(b1, size, 1, 2, 6, 15.0)
+    extra['cpu_baseline_1thread'] = dict(value=round(b1 / float(np.median(t1)), 3), unit='depth-crops/sec', cores=1, kind='port',
+                                         sample='%d train steps of batch %d of the same graph on ONE thread: median %.2f s/step' % (
+                                             len(t1), b1, float(np.median(t1))))
     if size == 128:
         extra['cpu_augment_baseline'] = [cpu_augment_baseline(1), cpu_augment_baseline(8)]
     return out, extra
@@ -358,6 +376,89 @@ def _mfma_busy_from_profiles(kernel_family, B, S, args):
     return dict(mfma_busy=None)
 
 
+def _sub_bench(extra_args, timeout=900):
+    """One more configuration of this script in a process of its own (own device allocations, own DPP_BF16): its JSON line."""
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--headline-only', '--no-cpu-baseline', '--no-trainer'] + extra_args,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    if r.returncode != 0:
+        return dict(error=r.stderr.decode(errors='replace')[-800:])
+    return json.loads(r.stdout.decode().strip().splitlines()[-1])
+
+
+def _pmc_step_bytes(tag, sha):
+    """HBM bytes per step of a non-headline configuration from the rocprofv3 --pmc passes of tools/refresh_profiles.sh
+    (profiles/r*_hbm_traffic_<tag>.json), only from a file measured on THESE kernel sources."""
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic_%s.json' % tag)), reverse=True):
+        try:
+            with open(fn) as fh:
+                pj = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if pj.get('_csrc_sha16') == sha and pj.get('_total_bytes_per_step'):
+            return float(pj['_total_bytes_per_step']), 'profiles/' + os.path.basename(fn)
+    return None, None
+
+
+def config5_leg(steps=10, warmup=3):
+    """BASELINE.json configs[4] on this GPU, driver-timed: the 256x256 bf16 train step, bs128 -- bf16-stored
+    activations / gradients, bf16 MFMA operands wherever the plan has them.  `bf16_mfma_flop_share` = the share of the step's MFMA FLOPs
+    issued as v_mfma_f32_16x16x32_bf16; `hbm_frac` = PMC bytes per step / step time / 8 TB/s (null without a fingerprint-matching
+    counter file)."""
+    j = _sub_bench(['--size', '256', '--dtype', 'bf16', '--steps', str(steps), '--warmup', str(warmup)])
+    if 'error' in j:
+        return j
+    nbytes, src = _pmc_step_bytes('256_bf16', j['config']['kernel_sources'])
+    out = dict(ms_per_step=j['ms_per_step'], value=j['value'], unit=j['unit'], steps=steps, warmup=warmup, dtype='bf16',
+               workload=j['config']['workload'], launches=j['config']['launches'], final_cost=j['config']['final_cost'],
+               hip_event_ms_per_step=j['config']['hip_event_ms_per_step'],
+               bf16_mfma_flop_share=j['config'].get('bf16_mfma_flop_share'),
+               step_flop_rate_tflops=round(j['value'] * FLOP_PER_CROP[256] / 1e12, 1),
+               step_bf16_mfma_frac=round(j['value'] * FLOP_PER_CROP[256] / PEAK_MFMA_BF16, 4),
+               hbm_bytes_per_step=nbytes, hbm_source=src,
+               hbm_frac=round(nbytes / (j['ms_per_step'] * 1e-3) / PEAK_HBM, 4) if nbytes else None,
+               roofline=j.get('roofline'))
+    return out
+
+
+def config3_leg(rt, torch, iters=200):
+    """BASELINE.json configs[2]: ICVL geometry (16 joints, 250 mm cube), the fused online augmentation (rot / scale / trans / CoM jitter +
+    labels + PCA projection) as ONE launch over 256 crops, timed alone -- replayed `iters` times as one hipGraph chain between two HIP
+    events (includes the kernel boundary) -- and the bs256 train step with that augmentation in it (a process of its own)."""
+    from hipdp import ops
+    from hipdp.augmenter import MODE_CODE, camera_tuple
+    from tools import synth
+    B, J, E, S = 256, 16, 30, 128
+    di, imgs, coms, cubes, Ms, gts, pca_mean, pca_comp = synth.crop_db(B, S, J, dataset='icvl', cube=(250., 250., 250.))
+    f32 = lambda a: rt.upload(np.ascontiguousarray(a, np.float32))       # noqa: E731
+    modes = ['com', 'rot', 'sc', 'none']
+    table = rt.upload(np.array([MODE_CODE[m] for m in modes], np.int32))
+    x_out, y_out = rt.alloc((B, S, S)), rt.alloc((B, E))
+    st = ops.AugmentState(rt, B, seed=1234)
+    (launch,) = st.ops(f32(imgs), f32(coms), f32(cubes), f32(Ms.reshape(B, 9)), f32(gts), J, S, camera_tuple(di), x_out, y_out, mode_table=table,
+                       n_modes=len(modes), pca_mean=f32(pca_mean), pca_comp=f32(pca_comp), E=E)
+    plan = ops.NativePlan(rt, [(launch, False)] * iters, mode='graph1')
+    plan.run(rt)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream())
+    for _ in range(3):
+        plan.run(rt)
+    e1.record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (3 * iters)
+    out = dict(augment_us_bs256=round(us, 2), augment_crops_per_s=round(B / (us * 1e-6), 0),
+               augment_hbm_frac=round(B * 2.0 * S * S * 4 / (us * 1e-6) / PEAK_HBM, 4), modes=modes, joints=J,
+               finite=bool(np.isfinite(x_out.get()).all() and np.isfinite(y_out.get()).all()),
+               algorithmic_bytes_per_crop=2 * S * S * 4)
+    j = _sub_bench(['--batch', '256', '--steps', '20', '--warmup', '5'])
+    if 'error' in j:
+        out['train_step'] = j
+    else:
+        out.update(ms_per_step_bs256=j['ms_per_step'], value_bs256=j['value'], unit=j['unit'])
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks with torch.distributed.run (one per GPU, RCCL)."""
     import torch
@@ -391,6 +492,8 @@ def main():
                     help='augment the minibatch at the start of its own step on the main stream (default: the previous step does it '
                          'on the gradient-branch stream while ADAM runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--headline-only', action='store_true', help='the timed steps and the roofline only: none of the extra legs (forward_only, '
+                    'no_augment, config3, config5); what the extra legs themselves run')
     ap.add_argument('--no-trainer', action='store_true', help="skip config.trainer_ms_per_minibatch (a short PoseRegNetTrainer.train() run)")
     ap.add_argument('--sync-bn', action='store_true', help='all-gather BatchNorm partial statistics across ranks (parity mode)')
     ap.add_argument('--launch', choices=['native', 'python', 'graph', 'graph1'], default=None,
@@ -694,7 +797,11 @@ def main():
                    roofline=roof)
         if roof is not None:
             roof.update(_mfma_busy_from_profiles(roof.get('kernel'), B, S, args))
-        if world == 1 and not emu and args.workload == 'train':
+        if not emu:
+            fl = [((o.meta or {}).get('kernel', ''), (o.meta or {}).get('flops', 0.0)) for _, o in eng.all_launches()]
+            mf = sum(f for k, f in fl if 'mfma' in k)
+            res['config']['bf16_mfma_flop_share'] = round(sum(f for k, f in fl if 'mfma_bf16' in k) / mf, 4) if mf else None
+        if world == 1 and not emu and args.workload == 'train' and not args.headline_only:
             # the other legs BASELINE.md section 3 lists, after the timed region: the train step WITHOUT the augmentation launch, and the
             # deterministic forward alone (computeOutput's device function)
             plain = eng.step_plan()
@@ -732,6 +839,10 @@ def main():
         if world == 1 and not emu and args.workload == 'train' and S == 128 and args.dtype == 'f32' and not args.no_trainer:
             # the drop-in class API next to the engine's number (same GPU, same build, right after the timed region)
             res['config']['trainer_ms_per_minibatch'] = trainer_ms_per_minibatch(rt, B, S)
+        if world == 1 and not emu and args.workload == 'train' and S == 128 and B == 128 and args.dtype == 'f32' and not args.headline_only:
+            # the other single-GPU configurations of BASELINE.json, timed by whoever runs this script
+            res['config3'] = config3_leg(rt, torch)
+            res['config5'] = config5_leg()
         if world == 1 and not args.no_cpu_baseline and not emu and args.workload == 'train':
             res['cpu_baseline'], extra = cpu_baseline(B, S)
             res.update(extra)
@@ -744,4 +855,7 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == '--cpu-leg':
+        _cpu_leg_child(sys.argv[2:])
+    else:
+        main()

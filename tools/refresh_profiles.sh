@@ -1,7 +1,7 @@
 # Regenerate the rocprofv3 evidence of the current round on the GPU box:  gpurun -- 'bash tools/refresh_profiles.sh r02'
 # Outputs land in gpurun_out/<round>/ and are then copied to profiles/<round>_*.
 set -x
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$ROUND
 mkdir -p $O
@@ -20,7 +20,7 @@ python $R/tools/pmc_summary.py $(find /tmp/p3 -name '*_results.db' | head -1) $(
 for dt in f32 bf16; do
   DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p3_$dt -o run -- python $R/tools/step_profile.py 2 256 $dt > /dev/null 2>&1
   DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p4_$dt -o run -- python $R/tools/step_profile.py 2 256 $dt > /dev/null 2>&1
-  python $R/tools/pmc_summary.py $(find /tmp/p3_$dt -name '*_results.db' | head -1) $(find /tmp/p4_$dt -name '*_results.db' | head -1) 2 --params 69046100 > $O/hbm_traffic_256_$dt.txt 2>&1
+  python $R/tools/pmc_summary.py $(find /tmp/p3_$dt -name '*_results.db' | head -1) $(find /tmp/p4_$dt -name '*_results.db' | head -1) 2 --params 69046100 --json $O/hbm_traffic_256_$dt.json > $O/hbm_traffic_256_$dt.txt 2>&1
 done
 # dynamic instruction mix per wave (SQ counters, two passes of 8; counters only + kernel trace)
 DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA --kernel-trace -d /tmp/p5 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
@@ -49,5 +49,6 @@ python $R/tools/augment_bench.py --batch 4096 --iters 50 >> $O/augment_bench.jso
 # profiles/ whose recorded kernel-source fingerprint is the one it runs on)
 cp $O/hbm_traffic.json $R/profiles/${ROUND}_hbm_traffic.json
 cp $O/mfma_busy.json $R/profiles/${ROUND}_mfma_busy.json
+cp $O/hbm_traffic_256_bf16.json $R/profiles/${ROUND}_hbm_traffic_256_bf16.json
 python $R/bench.py > $O/bench.json 2> $O/bench.err
 ls -la $O
