@@ -71,7 +71,8 @@ def _time_cpu_steps(batch, size, min_steps, max_steps, budget_s):
     rng = np.random.RandomState(3)
     x = torch.tensor(nets.synthetic_crops(rng, batch, size, size, np.float32))
     y = torch.tensor(rng.normal(0, 0.3, (batch, 30)).astype(np.float32))
-    tr.step(x, y, 1e-3)                      # warm-up (thread pools, allocator)
+    for _ in range(2):
+        tr.step(x, y, 1e-3)                  # warm-up (thread pools, allocator, oneDNN primitive caches: the first TWO steps are slow)
     times = []
     t_start = time.time()
     while len(times) < min_steps or (time.time() - t_start < budget_s and len(times) < max_steps):

@@ -18,6 +18,7 @@
 // waves; per-workgroup partials are summed by dpp_reduce_partials in a fixed order.
 #include <stdlib.h>
 #include "dpp_common.h"
+#include "conv3x3_wgrad_t.h"
 
 namespace {
 
@@ -683,8 +684,23 @@ extern "C" int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int Ci, int Co, int
     return nblk;
 }
 
+static int conv3x3_wgrad_launch(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
+                                float* partial, int bm, int store, int precision, dpp_stream_t stream);
+
 extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
                                  float* partial, int bm, int store, dpp_stream_t stream) {
+    return conv3x3_wgrad_launch(X, N, H, W, Ci, act, dY, Co, partial, bm, store, 0, stream);
+}
+
+extern "C" int dpp_conv3x3_wgrad_bf16_ok(int N, int H, int W, int Ci, int Co) { return dpp_conv3x3_wgrad_t_ok(N, H, W, Ci, Co, nullptr) ? 1 : 0; }
+
+extern "C" int dpp_conv3x3_wgrad_bf16(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
+                                      float* partial, int bm, int store, dpp_stream_t stream) {
+    return conv3x3_wgrad_launch(X, N, H, W, Ci, act, dY, Co, partial, bm, store, 1, stream);
+}
+
+static int conv3x3_wgrad_launch(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
+                                float* partial, int bm, int store, int precision, dpp_stream_t stream) {
     if (!X || !dY || !partial || N < 1 || Ci < 16 || (Ci & 15) || Co < 16 || (Co & 15) || (bm != 64 && bm != 128) || (store & ~(DPP_ST_A | DPP_ST_B))) return DPP_E_BADARG;
     const int y16 = (store & DPP_ST_B) ? 1 : 0;
     Wgrad3Args a;
@@ -697,6 +713,10 @@ extern "C" int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, co
     a.ntiles = a.tiles_x * a.tiles_y * dpp_cdiv(N, a.img);
     int nblk, taps_pb;
     wgrad_geometry(N, H, W, Ci, Co, bm, nblk, taps_pb);
+    // the 16- / 32-channel layers: channel-major LDS images, 16-byte operand reads (conv3x3_wgrad_t.hip, round 6)
+    if (dpp_conv3x3_wgrad_t_ok(N, H, W, Ci, Co, act))
+        return dpp_conv3x3_wgrad_t_launch(X, N, H, W, Ci, act, dY, partial, nblk, taps_pb, store, precision, static_cast<hipStream_t>(stream));
+    if (precision) return DPP_E_UNSUPPORTED;          // bf16 MFMA operands: the transposed-image kernel only
     int NT = (Co >> 4) * (Ci >> 4);
     int pairs = taps_pb * NT;
     int maxacc = dpp_cdiv(pairs, 4);

@@ -87,6 +87,9 @@ SIGNATURES = {
     'dpp_conv3x3_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'dpp_conv3x3_wgrad': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_int, stream_t]),
+    'dpp_conv3x3_wgrad_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Act), C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_int, stream_t]),
+    'dpp_conv3x3_wgrad_bf16_ok': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     'dpp_stem_fwd': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_int, stream_t]),
     'dpp_stem_wgrad_blocks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -388,11 +388,14 @@ def conv3x3_wtrans_multi(rt, jobs, name='conv3x3_wtrans'):
     return Launch(rt.lib.dpp_conv3x3_wtrans_multi, (table.ptr, len(jobs), block0), (table, list(jobs)), name)
 
 
-def conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, partial, actX=None, bm=64, name='conv3x3_wgrad'):
+def conv3x3_wgrad(rt, X, N, H, W, Ci, dY, Co, partial, actX=None, bm=64, name='conv3x3_wgrad', precision=0):
+    """precision 1: bf16 MFMA operands (dpp_conv3x3_wgrad_bf16; layers dpp_conv3x3_wgrad_bf16_ok accepts)."""
     px = float(N) * H * W
     nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, Ci, Co, bm)
-    meta = dict(kernel='conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co, bytes=4.0 * (px * Co + nblk * 9.0 * Ci * Co) + _esz(X) * px * Ci)
-    return Launch(rt.lib.dpp_conv3x3_wgrad, (X.ptr, N, H, W, Ci, _actp(actX), dY.ptr, Co, partial.ptr, bm, _store(a=X, b=dY)),
+    meta = dict(kernel='conv3x3_wgrad_mfma_bf16' if precision else 'conv3x3_wgrad_mfma_f32', flops=2.0 * px * 9 * Ci * Co,
+                bytes=_esz(dY) * px * Co + 4.0 * nblk * 9.0 * Ci * Co + _esz(X) * px * Ci)
+    fn = rt.lib.dpp_conv3x3_wgrad_bf16 if precision else rt.lib.dpp_conv3x3_wgrad
+    return Launch(fn, (X.ptr, N, H, W, Ci, _actp(actX), dY.ptr, Co, partial.ptr, bm, _store(a=X, b=dY)),
                   (X, dY, partial, actX), name, meta)
 
 

@@ -235,6 +235,13 @@ int dpp_conv3x3_wtrans_multi(const void* jobs_dev, int njobs, int total_blocks, 
 int dpp_conv3x3_wgrad_blocks(int N, int H, int W, int Ci, int Co, int bm);
 int dpp_conv3x3_wgrad(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
                       float* partial, int bm, int store /* DPP_ST_A: X, DPP_ST_B: dY hold bf16 */, dpp_stream_t stream);
+/* (ABI v11) the same with bf16 MFMA operands (BASELINE config 5; `T.grad` of /root/reference/src/net/convlayer.py:230-240 evaluated with
+ * both operands rounded to bfloat16, f32 accumulation): act(X) is rounded to nearest-even AFTER the prologue, dY is rounded likewise (exact
+ * when it is bf16-stored).  Layers dpp_conv3x3_wgrad_bf16_ok() accepts only (16 or 32 channels in and out, maps >= 12 wide);
+ * DPP_E_UNSUPPORTED otherwise.  Same partial layout and slice count as dpp_conv3x3_wgrad. */
+int dpp_conv3x3_wgrad_bf16_ok(int N, int H, int W, int Ci, int Co);
+int dpp_conv3x3_wgrad_bf16(const float* X, int N, int H, int W, int Ci, const dpp_act* act, const float* dY, int Co,
+                           float* partial, int bm, int store /* DPP_ST_A: X, DPP_ST_B: dY hold bf16 */, dpp_stream_t stream);
 
 /* ---- ResNet stem: ConvPoolLayer 5x5 'half' 1 -> Co (<= 32), 2x2 max-pool, bias AFTER the pool ----------------
  * /root/reference/src/net/convpoollayer.py:251-282 as built at /root/reference/src/net/resnet.py:128-133.

@@ -71,6 +71,69 @@ def test_conv3x3_fwd_dgrad_wgrad(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(1, 8, 16, 16), (3, 20, 28, 16), (2, 9, 13, 32), (12, 32, 32, 16), (6, 16, 32, 32), (36, 32, 32, 16)])
+def test_conv3x3_filter_gradient_on_transposed_images(backend, cfg):
+    """conv3x3_wgrad_t_kernel (round 6: channel-major LDS images, 16-byte operand reads) on the 16- / 32-channel layers: one, three and
+    nine taps per workgroup (the grid wgrad_geometry picks from the tile count), ragged maps (zero padding after the activation, tiles
+    that hang over the image), workgroups that walk several tiles with the next tile in flight, more workgroups than tiles; float32
+    and bf16-stored operands (widened exactly: equal bits).  Against the float64 oracle (T.grad of conv2d,
+    /root/reference/src/net/convlayer.py:230-240)."""
+    rt = get_runtime(backend)
+    N, H, W, Cc = cfg
+    rng = np.random.RandomState(19)
+    x = rng.normal(size=(N, Cc, H, W)) + 0.2
+    mean, scale, beta = rng.normal(size=Cc) * 0.3, rng.uniform(0.5, 1.5, Cc), rng.normal(size=Cc) * 0.3
+    a = np.maximum((x - mean[None, :, None, None]) * scale[None, :, None, None] + beta[None, :, None, None], 0)
+    dy = rng.normal(size=(N, Cc, H, W))
+    d = up(rt, X=layout.nchw_to_nhwc(x), dY=layout.nchw_to_nhwc(dy), mean=mean, scale=scale, beta=beta)
+    for use_act in (True, False):
+        _, dW_ref, _ = L.conv2d_bwd(a if use_act else x, np.zeros((Cc, Cc, 3, 3)), dy, (1, 1), 'half')
+        act = ops.act(Act.BN_RELU, d['mean'], d['scale'], d['beta'], Cc) if use_act else None
+        for bm in (64, 128):
+            nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, Cc, Cc, bm)
+            part = rt.alloc((nblk, Cc, 9, Cc), zero=False)
+            part.set(np.full((nblk, Cc, 9, Cc), np.nan, np.float32))          # every slice element must be written
+            dWk = rt.alloc((Cc, 9, Cc), zero=False)
+            ops.conv3x3_wgrad(rt, d['X'], N, H, W, Cc, d['dY'], Cc, part, actX=act, bm=bm)(rt.stream)
+            ops.reduce_partials(rt, part, nblk, Cc * 9 * Cc, dWk)(rt.stream)
+            rt.synchronize()
+            dW = layout.conv_w_from_kernel(dWk.get(), (Cc, Cc, 3, 3))
+            np.testing.assert_allclose(dW, dW_ref, rtol=0, atol=3e-6 * np.sqrt(N * H * W) * np.abs(dW_ref).max())
+            again = rt.alloc((nblk, Cc, 9, Cc), zero=False)
+            ops.conv3x3_wgrad(rt, d['X'], N, H, W, Cc, d['dY'], Cc, again, actX=act, bm=bm)(rt.stream)
+            rt.synchronize()
+            assert np.array_equal(again.get(), part.get())                      # fixed summation order
+    # bf16 MFMA operands (BASELINE config 5, dpp_conv3x3_wgrad_bf16): both operands rounded to bfloat16 -- act(X) AFTER the prologue --,
+    # float32 accumulation: against the float64 oracle on the rounded operands; a bf16-stored dY gives the same bits as its widened twin
+    assert rt.lib.dpp_conv3x3_wgrad_bf16_ok(N, H, W, Cc, Cc) == 1
+    rne = lambda v: ((np.ascontiguousarray(v, np.float32).view(np.uint32).astype(np.uint64) + 0x7FFF +          # noqa: E731
+                      ((np.ascontiguousarray(v, np.float32).view(np.uint32).astype(np.uint64) >> 16) & 1)) >> 16).astype(np.uint16)
+    wid = lambda b: (b.astype(np.uint32) << 16).view(np.float32)                                                   # noqa: E731
+    xf = layout.nchw_to_nhwc(x).astype(np.float32)
+    af = np.maximum((xf - mean.astype(np.float32)) * scale.astype(np.float32) + beta.astype(np.float32), np.float32(0))      # the kernel's f32 prologue
+    a_q = layout.nhwc_to_nchw(wid(rne(af)).astype(np.float64))
+    dy_bits = rne(layout.nchw_to_nhwc(dy))
+    dy_q = layout.nhwc_to_nchw(wid(dy_bits).astype(np.float64))
+    _, dW_ref, _ = L.conv2d_bwd(a_q, np.zeros((Cc, Cc, 3, 3)), dy_q, (1, 1), 'half')
+    act = ops.act(Act.BN_RELU, d['mean'], d['scale'], d['beta'], Cc)
+    nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, H, W, Cc, Cc, 128)
+    got = []
+    for dYbuf in (rt.upload(dy_bits), rt.upload(wid(dy_bits))):
+        part = rt.alloc((nblk, Cc, 9, Cc), zero=False)
+        part.set(np.full((nblk, Cc, 9, Cc), np.nan, np.float32))
+        dWk = rt.alloc((Cc, 9, Cc), zero=False)
+        ops.conv3x3_wgrad(rt, d['X'], N, H, W, Cc, dYbuf, Cc, part, actX=act, bm=128, precision=1)(rt.stream)
+        ops.reduce_partials(rt, part, nblk, Cc * 9 * Cc, dWk)(rt.stream)
+        rt.synchronize()
+        got.append(part.get())
+        dW = layout.conv_w_from_kernel(dWk.get(), (Cc, Cc, 3, 3))
+        # an activation within float32 round-off of a bf16 rounding boundary may round the other way than the float32 prologue here
+        # (FMA contraction on the device): allow a few bf16 steps of one product among the N*H*W of a sum
+        np.testing.assert_allclose(dW, dW_ref, rtol=0, atol=(3e-6 * np.sqrt(N * H * W) + 2e-4) * np.abs(dW_ref).max())
+    assert np.array_equal(got[0], got[1])
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('cfg', [(2, 32, 32, 32), (3, 16, 48, 32), (1, 36, 20, 16), (1, 32, 16, 30), (2, 16, 16, 24)])
 def test_stem_fwd_and_wgrad(backend, cfg):
     rt = get_runtime(backend)
