@@ -1290,7 +1290,10 @@ class CompiledNet(object):
             else:
                 nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, Hi, Wi, Ci, Co, bm)
                 part = rt.alloc(nblk * Co * 9 * Ci, zero=False)
-                self.bwd.add(ops.conv3x3_wgrad(rt, src.base.buf, N, Hi, Wi, Ci, dY, Co, part, actX=act, bm=bm), side=True)
+                # bf16 mode: both operands on the bf16 matrix pipe where the transposed-image kernel takes the layer (16 / 32 channels)
+                p16 = int(bool(self.prec and hz.BF16_WGRAD3 and rt.lib.dpp_conv3x3_wgrad_bf16_ok(N, Hi, Wi, Ci, Co)))
+                self.bwd.add(ops.conv3x3_wgrad(rt, src.base.buf, N, Hi, Wi, Ci, dY, Co, part, actX=act, bm=bm, precision=p16,
+                                               name='wgrad3x3_%d' % layer.layerNum), side=True)
             self.reduce_jobs.add(part, nblk, Co * 9 * Ci, gW)
             if need_dx:
                 tgt, dst = self._view_grad(src)

@@ -92,6 +92,8 @@ BF16_GRADS = knob('DPP_BF16_GRADS', '1') != '0'
 # ... and runs the channel-expanding 1x1 convolutions / the data gradients of the reducing ones (dpp_gemm variant 4, K = 32 / 64) on
 # bf16 MFMA operands (dpp_gemm_desc.precision).  DPP_BF16_GEMM=0: f32 MFMA there (rounds 2-3: only the 3x3 convolutions and FC1).
 BF16_GEMM = knob('DPP_BF16_GEMM', '1') != '0'
+# round 6: the 3x3 filter gradients of the 16- / 32-channel layers on bf16 MFMA operands (dpp_conv3x3_wgrad_bf16).  DPP_BF16_WGRAD3=0: f32 MFMA.
+BF16_WGRAD3 = knob('DPP_BF16_WGRAD3', '1') != '0'
 # ADAM of the FC1 weight (90 % of the parameters, 470 MB of optimizer traffic) inside the backward pass: its gradient is final a few
 # kernels into the pass, so the update runs on the gradient branch under the latency-bound data-gradient chain instead of in the
 # serial tail of the step (step_plan only: cost_and_grads / allreduce paths keep backward and update apart).
