@@ -119,8 +119,8 @@ __device__ __forceinline__ void stage_halo(const TX* __restrict__ X, int N, int 
                 float4 t = v[u];
                 if (in[u]) {                         // zero padding is applied AFTER the activation
                     if (act.mode & 2) {
-                        t.x = (t.x - mu.x) * sc.x + be.x; t.y = (t.y - mu.y) * sc.y + be.y;
-                        t.z = (t.z - mu.z) * sc.z + be.z; t.w = (t.w - mu.w) * sc.w + be.w;
+                        t.x = dpp_fma(t.x - mu.x, sc.x, be.x); t.y = dpp_fma(t.y - mu.y, sc.y, be.y);
+                        t.z = dpp_fma(t.z - mu.z, sc.z, be.z); t.w = dpp_fma(t.w - mu.w, sc.w, be.w);
                     }
                     if (act.mode & 1) { t.x = fmaxf(t.x, 0.0f); t.y = fmaxf(t.y, 0.0f); t.z = fmaxf(t.z, 0.0f); t.w = fmaxf(t.w, 0.0f); }
                 }

@@ -115,8 +115,8 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_stream_kernel(C3sArgs a) 
             for (int g = 0; g < CN; ++g) {
                 float4 v = xa[tl][t][g];
                 if (mode & 2) {
-                    v.x = (v.x - mu[g].x) * sc[g].x + be[g].x; v.y = (v.y - mu[g].y) * sc[g].y + be[g].y;
-                    v.z = (v.z - mu[g].z) * sc[g].z + be[g].z; v.w = (v.w - mu[g].w) * sc[g].w + be[g].w;
+                    v.x = dpp_fma(v.x - mu[g].x, sc[g].x, be[g].x); v.y = dpp_fma(v.y - mu[g].y, sc[g].y, be[g].y);
+                    v.z = dpp_fma(v.z - mu[g].z, sc[g].z, be[g].z); v.w = dpp_fma(v.w - mu[g].w, sc[g].w, be[g].w);
                 }
                 if (mode & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 v.x = in ? v.x : 0.0f; v.y = in ? v.y : 0.0f; v.z = in ? v.z : 0.0f; v.w = in ? v.w : 0.0f;      // zero padding AFTER the activation

@@ -182,8 +182,8 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
         for (int s = 0; s < SX; ++s) {
             float4 v = W3Raw<TX>::widen(rx[s]);
             if (mode & 2) {
-                v.x = (v.x - mu.x) * sc.x + be.x; v.y = (v.y - mu.y) * sc.y + be.y;
-                v.z = (v.z - mu.z) * sc.z + be.z; v.w = (v.w - mu.w) * sc.w + be.w;
+                v.x = dpp_fma(v.x - mu.x, sc.x, be.x); v.y = dpp_fma(v.y - mu.y, sc.y, be.y);
+                v.z = dpp_fma(v.z - mu.z, sc.z, be.z); v.w = dpp_fma(v.w - mu.w, sc.w, be.w);
             }
             if (mode & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (!((inx >> s) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);        // zero padding AFTER the activation

@@ -191,11 +191,16 @@ __device__ __forceinline__ int dpp_map_row(const dpp_rowmap& m, int r) {
     return n * m.HiWi + (y * m.s) * m.Wi + x * m.s;
 }
 
+// (x - mean) * scale + beta of the operand prologues as ONE fused multiply-add, spelled out: the device compiler contracts the expression
+// anyway (so this changes nothing there), the host build against the SIMT emulator does not -- and tests/pinning.py rebuilds the kernels'
+// bf16-rounded operands with exactly this arithmetic (an unfused evaluation flips the bfloat16 rounding of an element in 1e4).
+__device__ __forceinline__ float dpp_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // The fused BatchNorm(+ReLU) operand prologue: v = (x - mean) * scale + beta ; relu.
 // Written as (x - mean) * scale + beta (not x*s + t) so that no bits are lost when |mean| >> std.
 __device__ __forceinline__ float dpp_act1(float x, const dpp_act& a, int c) {
     float v = x;
-    if (a.mode & 2) v = (x - a.mean[c]) * a.scale[c] + a.beta[c];
+    if (a.mode & 2) v = dpp_fma(x - a.mean[c], a.scale[c], a.beta[c]);
     if (a.mode & 1) v = fmaxf(v, 0.0f);
     return v;
 }
@@ -206,10 +211,10 @@ __device__ __forceinline__ float4 dpp_act4(float4 x, const dpp_act& a, int c) {
         const float4 mu = *reinterpret_cast<const float4*>(a.mean + c);
         const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
         const float4 be = *reinterpret_cast<const float4*>(a.beta + c);
-        v.x = (x.x - mu.x) * sc.x + be.x;
-        v.y = (x.y - mu.y) * sc.y + be.y;
-        v.z = (x.z - mu.z) * sc.z + be.z;
-        v.w = (x.w - mu.w) * sc.w + be.w;
+        v.x = dpp_fma(x.x - mu.x, sc.x, be.x);
+        v.y = dpp_fma(x.y - mu.y, sc.y, be.y);
+        v.z = dpp_fma(x.z - mu.z, sc.z, be.z);
+        v.w = dpp_fma(x.w - mu.w, sc.w, be.w);
     }
     if (a.mode & 1) {
         v.x = fmaxf(v.x, 0.0f);

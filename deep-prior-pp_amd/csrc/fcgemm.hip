@@ -377,8 +377,8 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void fc_stream_
     };
     auto act = [&](float4 v) __attribute__((always_inline)) {
         if (modeA & 2) {
-            v.x = (v.x - mu.x) * sc.x + be.x; v.y = (v.y - mu.y) * sc.y + be.y;
-            v.z = (v.z - mu.z) * sc.z + be.z; v.w = (v.w - mu.w) * sc.w + be.w;
+            v.x = dpp_fma(v.x - mu.x, sc.x, be.x); v.y = dpp_fma(v.y - mu.y, sc.y, be.y);
+            v.z = dpp_fma(v.z - mu.z, sc.z, be.z); v.w = dpp_fma(v.w - mu.w, sc.w, be.w);
         }
         if (modeA & 1) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
         return v;

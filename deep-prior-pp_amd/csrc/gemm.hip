@@ -156,7 +156,9 @@ static int gemm_prepare(const dpp_gemm_desc* dp, GemmArgs& ga) {
     // and through the 16-byte epilogue; the mode-4 operand (two f32 tensors) does not combine with them
     if (d.store & ~(DPP_ST_A | DPP_ST_B | DPP_ST_C | DPP_ST_BNX)) return DPP_E_BADARG;
     if (d.precision != 0 && d.precision != 1) return DPP_E_BADARG;
-    if (d.precision == 1 && d.variant != 4) return DPP_E_UNSUPPORTED;          // bf16 MFMA operands: the wave-autonomous kernel only
+    // bf16 MFMA operands (round 6: every variant but the row-stream kernel; not with the two-tensor operand, not split over K slices whose
+    // partials would each be rounded differently -- they are not: partials are f32 sums, so split-K is fine)
+    if (d.precision == 1 && (d.variant == 1 || (d.actA.mode & 4))) return DPP_E_UNSUPPORTED;
     if ((d.store & DPP_ST_A) && (!ga.vecA || (d.actA.mode & 4))) return DPP_E_UNSUPPORTED;
     if ((d.store & DPP_ST_B) && !ga.vecB) return DPP_E_UNSUPPORTED;
     if ((d.store & (DPP_ST_C | DPP_ST_BNX)) && d.splitk != 1) return DPP_E_UNSUPPORTED;
@@ -214,6 +216,11 @@ extern "C" int dpp_gemm(const dpp_gemm_desc* dp, dpp_stream_t stream) {
         const int rpw = dpp_gemm_expand_rows(d, ga);
         if (!rpw) return DPP_E_UNSUPPORTED;
         return dpp_gemm_expand_launch(ga, rpw, st);
+    }
+    if (d.precision == 1) {
+        // 8 k-values per lane and chunk: chunks of 32 / 64 (K > 16), or the K = 16 stream kernel (zero upper half)
+        if (d.variant == 0 && !red_layout && ga.bk < 32) return DPP_E_UNSUPPORTED;
+        return dpp_gemm_dispatch_pb(ga, bm, bn, wm, st);
     }
     return d.store ? dpp_gemm_dispatch_st(ga, bm, bn, wm, st) : gemm_dispatch<false>(ga, bm, bn, wm, st);
 }

@@ -18,3 +18,5 @@ int dpp_gemm_expand_rows(const dpp_gemm_desc& d, const GemmArgs& ga);
 int dpp_gemm_expand_launch(const GemmArgs& ga, int rpw, hipStream_t st);
 // variants 0-3 on bf16-stored tensors (gemm_st.hip)
 int dpp_gemm_dispatch_st(GemmArgs& ga, int bm, int bn, int wm, hipStream_t st);
+// variants 0, 2, 3 with bf16 MFMA operands, float32 or bf16-stored tensors (gemm_pb.hip)
+int dpp_gemm_dispatch_pb(GemmArgs& ga, int bm, int bn, int wm, hipStream_t st);

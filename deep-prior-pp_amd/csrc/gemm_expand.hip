@@ -155,8 +155,8 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
                     if (lz_store) *reinterpret_cast<float4*>(d.actA.out + (size_t)(r0 + rt * 16 + l15) * d.lda + kq * KL + 4 * j) = v;
                 }
                 if (modeA & 2) {
-                    v.x = (v.x - mu[j].x) * sc[j].x + be[j].x; v.y = (v.y - mu[j].y) * sc[j].y + be[j].y;
-                    v.z = (v.z - mu[j].z) * sc[j].z + be[j].z; v.w = (v.w - mu[j].w) * sc[j].w + be[j].w;
+                    v.x = dpp_fma(v.x - mu[j].x, sc[j].x, be[j].x); v.y = dpp_fma(v.y - mu[j].y, sc[j].y, be[j].y);
+                    v.z = dpp_fma(v.z - mu[j].z, sc[j].z, be[j].z); v.w = dpp_fma(v.w - mu[j].w, sc[j].w, be[j].w);
                 }
                 if (modeA & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 av[rt][0] = v.x; av[rt][1] = v.y; av[rt][2] = v.z; av[rt][3] = v.w;

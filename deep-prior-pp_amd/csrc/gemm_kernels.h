@@ -201,8 +201,12 @@ struct Stager {
 };
 
 // ST: the instantiation may meet bf16-stored operands / outputs (DPP_ST_*); the float32 instantiations carry none of that code
-template <int BM, int BN, int WM, int BKT, bool AKC, bool BKC, int DEPTH, bool LAZY = false, bool WIDE = true, bool ST = false>
+// PB (dpp_gemm_desc.precision = 1, BASELINE config 5, round 6): both operands are rounded to bfloat16 (RNE; the activation after its
+// prologue) when the fragments are read from the float32 LDS images, eight k-values of a lane become ONE v_mfma_f32_16x16x32_bf16
+// operand (lane (i, kq) owns k = kq * KL + e .. + 7 on both sides), accumulation stays float32.  Chunks of 32 / 64 only (KL >= 8).
+template <int BM, int BN, int WM, int BKT, bool AKC, bool BKC, int DEPTH, bool LAZY = false, bool WIDE = true, bool ST = false, bool PB = false>
 __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
+    static_assert(!PB || (BKT % 32 == 0 && !LAZY), "bf16 MFMA operands: 8 k-values per lane and chunk");
     dpp_kernarg_warm<sizeof(GemmArgs)>();
     const dpp_gemm_desc& d = ga.d;
     constexpr int WN = 4 / WM;
@@ -288,10 +292,10 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
     };
     auto apply_co = [](float4 v, const Co4& co, int mode) {
         if (mode & 2) {
-            v.x = (v.x - co.mu.x) * co.sc.x + co.be.x;
-            v.y = (v.y - co.mu.y) * co.sc.y + co.be.y;
-            v.z = (v.z - co.mu.z) * co.sc.z + co.be.z;
-            v.w = (v.w - co.mu.w) * co.sc.w + co.be.w;
+            v.x = dpp_fma(v.x - co.mu.x, co.sc.x, co.be.x);
+            v.y = dpp_fma(v.y - co.mu.y, co.sc.y, co.be.y);
+            v.z = dpp_fma(v.z - co.mu.z, co.sc.z, co.be.z);
+            v.w = dpp_fma(v.w - co.mu.w, co.sc.w, co.be.w);
         }
         if (mode & 1) {
             v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
@@ -479,6 +483,47 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_kernel(GemmArgs ga) {
                 __syncthreads();
                 if (c == 0) dpp_stamp(ga.prof, 2);
                 if (c + DEPTH < nchunks) fetch(dd, k_begin + (c + DEPTH) * BKT);
+                if constexpr (PB) {
+#pragma unroll
+                    for (int e8 = 0; e8 < KL; e8 += 8) {
+                        dpp_bf16x8 af[RM], bf[CN];
+#pragma unroll
+                        for (int rt = 0; rt < RM; ++rt) {
+                            const int r = wm * (BM / WM) + rt * 16 + l15;
+                            float f[8];
+                            if (AKC) {
+                                const float4 v0 = *reinterpret_cast<const float4*>(&As[r * LDA_ + kq * KL + e8]);
+                                const float4 v1 = *reinterpret_cast<const float4*>(&As[r * LDA_ + kq * KL + e8 + 4]);
+                                f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+                            } else {
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) f[t] = As[(kq * KL + e8 + t) * LDA_ + r];
+                            }
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) af[rt][t] = (dpp_bf16)f[t];
+                        }
+#pragma unroll
+                        for (int ct = 0; ct < CN; ++ct) {
+                            const int cc = wn * (BN / WN) + ct * 16 + l15;
+                            float f[8];
+                            if (BKC) {
+                                const float4 v0 = *reinterpret_cast<const float4*>(&Bs[cc * LDB_ + kq * KL + e8]);
+                                const float4 v1 = *reinterpret_cast<const float4*>(&Bs[cc * LDB_ + kq * KL + e8 + 4]);
+                                f[0] = v0.x; f[1] = v0.y; f[2] = v0.z; f[3] = v0.w; f[4] = v1.x; f[5] = v1.y; f[6] = v1.z; f[7] = v1.w;
+                            } else {
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) f[t] = Bs[(kq * KL + e8 + t) * LDB_ + cc];
+                            }
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) bf[ct][t] = (dpp_bf16)f[t];
+                        }
+#pragma unroll
+                        for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                            for (int ct = 0; ct < CN; ++ct)
+                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
+                    }
+                } else
 #pragma unroll
                 for (int e4 = 0; e4 < KL; e4 += 4) {
                     float af[RM][4], bf[CN][4];
@@ -622,7 +667,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_rowstream_kernel(GemmArgs ga
 // changed nothing (3.84-3.86 ms either way): not kept.
 // (amdgpu_waves_per_eu: with the default occupancy goal the scheduler sinks every load down to its LDS write to save registers --
 // "load, wait, write" twenty-four times over; one workgroup per CU is all the 100 KB LDS footprint allows anyway)
-template <int KT, int BN, bool BKC, bool ST = false>
+template <int KT, int BN, bool BKC, bool ST = false, bool PB = false>
 __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4) void gemm_ksplit_kernel(GemmArgs ga) {
     dpp_kernarg_warm<sizeof(GemmArgs)>();
     const dpp_gemm_desc& d = ga.d;
@@ -692,8 +737,8 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
         for (int s = 0; s < SA; ++s) {
             float4 v = (ST && ga.shA) ? dpp_widen4(ra[s]) : ra[s];
             if (modeA & 2) {
-                v.x = (v.x - mu.x) * sc.x + be.x; v.y = (v.y - mu.y) * sc.y + be.y;
-                v.z = (v.z - mu.z) * sc.z + be.z; v.w = (v.w - mu.w) * sc.w + be.w;
+                v.x = dpp_fma(v.x - mu.x, sc.x, be.x); v.y = dpp_fma(v.y - mu.y, sc.y, be.y);
+                v.z = dpp_fma(v.z - mu.z, sc.z, be.z); v.w = dpp_fma(v.w - mu.w, sc.w, be.w);
             }
             if (modeA & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             *reinterpret_cast<float4*>(la + s * (DPP_THREADS / QK) * LDA_) = v;
@@ -710,6 +755,41 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
         for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* arow = As + l15 * LDA_ + wave * KS + kq * 4;
     const float* brow = BKC ? Bs + l15 * LDB_ + wave * KS + kq * 4 : Bs + (wave * KS + kq * 4) * LDB_ + l15;
+    if constexpr (PB) {
+        // bf16 operands: the lane's k-values of two 16-deep groups (k = base + 16 g + 4 kq + t, g = 2 h, 2 h + 1) form one 32-deep step
+        static_assert(KS % 32 == 0, "whole 32-deep steps per wave");
+#pragma unroll
+        for (int h = 0; h < KS / 32; ++h) {
+            dpp_bf16x8 af[RM], bf[CN];
+#pragma unroll
+            for (int rt = 0; rt < RM; ++rt) {
+                const float4 v0 = *reinterpret_cast<const float4*>(arow + rt * 16 * LDA_ + h * 32);
+                const float4 v1 = *reinterpret_cast<const float4*>(arow + rt * 16 * LDA_ + h * 32 + 16);
+                af[rt][0] = (dpp_bf16)v0.x; af[rt][1] = (dpp_bf16)v0.y; af[rt][2] = (dpp_bf16)v0.z; af[rt][3] = (dpp_bf16)v0.w;
+                af[rt][4] = (dpp_bf16)v1.x; af[rt][5] = (dpp_bf16)v1.y; af[rt][6] = (dpp_bf16)v1.z; af[rt][7] = (dpp_bf16)v1.w;
+            }
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                if (BKC) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(brow + ct * 16 * LDB_ + h * 32);
+                    const float4 v1 = *reinterpret_cast<const float4*>(brow + ct * 16 * LDB_ + h * 32 + 16);
+                    bf[ct][0] = (dpp_bf16)v0.x; bf[ct][1] = (dpp_bf16)v0.y; bf[ct][2] = (dpp_bf16)v0.z; bf[ct][3] = (dpp_bf16)v0.w;
+                    bf[ct][4] = (dpp_bf16)v1.x; bf[ct][5] = (dpp_bf16)v1.y; bf[ct][6] = (dpp_bf16)v1.z; bf[ct][7] = (dpp_bf16)v1.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        bf[ct][t] = (dpp_bf16)brow[(h * 32 + t) * LDB_ + ct * 16];
+                        bf[ct][4 + t] = (dpp_bf16)brow[(h * 32 + 16 + t) * LDB_ + ct * 16];
+                    }
+                }
+            }
+#pragma unroll
+            for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct)
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[rt], bf[ct], acc[rt][ct], 0, 0, 0);
+        }
+    } else
 #pragma unroll
     for (int g = 0; g < KS / 16; ++g) {
         float af[RM][4], bf[CN][4];
@@ -753,7 +833,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
 // (256 contiguous bytes); no LDS, no barrier until the column reductions at the very end.
 // ACT: operand prologue present (forward); EPI: residual / BatchNorm-backward epilogue present -- register diets.  KT = K (16 or 64),
 // CN = column tiles of 16 (N = 16 or 64), TPW = 16-row tiles per wave (rows per workgroup = 64 * TPW = one BatchNorm partial block).
-template <int KT, int CN, bool BKC, int TPW, bool ACT, bool EPI, bool ST = false>
+template <int KT, int CN, bool BKC, int TPW, bool ACT, bool EPI, bool ST = false, bool PB = false>
 __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga) {
     dpp_kernarg_warm<sizeof(GemmArgs)>();
     const dpp_gemm_desc& d = ga.d;
@@ -832,14 +912,39 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga)
         f32x4 acc[CN];
 #pragma unroll
         for (int ct = 0; ct < CN; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 va[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             float4 v = (ST && ga.shA) ? dpp_widen4(ra[t][g]) : ra[t][g];
             if (modeA & 2) {
-                v.x = (v.x - mu[g].x) * sc[g].x + be[g].x; v.y = (v.y - mu[g].y) * sc[g].y + be[g].y;
-                v.z = (v.z - mu[g].z) * sc[g].z + be[g].z; v.w = (v.w - mu[g].w) * sc[g].w + be[g].w;
+                v.x = dpp_fma(v.x - mu[g].x, sc[g].x, be[g].x); v.y = dpp_fma(v.y - mu[g].y, sc[g].y, be[g].y);
+                v.z = dpp_fma(v.z - mu[g].z, sc[g].z, be[g].z); v.w = dpp_fma(v.w - mu[g].w, sc[g].w, be[g].w);
             }
             if (modeA & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            va[g] = v;
+        }
+        if constexpr (PB) {
+            // bf16 operands: the lane's k-quads of two 16-deep groups make one 32-deep step (K = 16: the upper half is zero)
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int h = 0; h < (G + 1) / 2; ++h) {
+                const float4 a0 = va[2 * h], a1 = (2 * h + 1 < G) ? va[2 * h + 1] : z4;
+                dpp_bf16x8 af;
+                af[0] = (dpp_bf16)a0.x; af[1] = (dpp_bf16)a0.y; af[2] = (dpp_bf16)a0.z; af[3] = (dpp_bf16)a0.w;
+                af[4] = (dpp_bf16)a1.x; af[5] = (dpp_bf16)a1.y; af[6] = (dpp_bf16)a1.z; af[7] = (dpp_bf16)a1.w;
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    const float4 b0 = bw[2 * h][ct], b1 = (2 * h + 1 < G) ? bw[(2 * h + 1 < G) ? 2 * h + 1 : 0][ct] : z4;
+                    dpp_bf16x8 bf;
+                    bf[0] = (dpp_bf16)b0.x; bf[1] = (dpp_bf16)b0.y; bf[2] = (dpp_bf16)b0.z; bf[3] = (dpp_bf16)b0.w;
+                    bf[4] = (dpp_bf16)b1.x; bf[5] = (dpp_bf16)b1.y; bf[6] = (dpp_bf16)b1.z; bf[7] = (dpp_bf16)b1.w;
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[ct], 0, 0, 0);
+                }
+            }
+        } else
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 v = va[g];
 #pragma unroll
             for (int ct = 0; ct < CN; ++ct) {
                 acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, bw[g][ct].x, acc[ct], 0, 0, 0);
@@ -932,24 +1037,25 @@ static int ksplit_bn(const dpp_gemm_desc& d, const GemmArgs& ga) {
     return d.N % bn == 0 ? bn : 0;
 }
 
-template <int KT, int BN, bool BKC, bool ST>
+template <int KT, int BN, bool BKC, bool ST, bool PB = false>
 static int launch_ksplit(const GemmArgs& ga, hipStream_t st) {
     const dpp_gemm_desc& d = ga.d;
     constexpr int opnd = 32 * (KT + 4) + (BKC ? BN * (KT + 4) : KT * (BN + 4));
     constexpr int epil = 4 * 32 * (BN + 4) + 16 * BN;
     constexpr size_t lds = sizeof(float) * (opnd > epil ? opnd : epil);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ksplit_kernel<KT, BN, BKC, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    DPP_LAUNCH((gemm_ksplit_kernel<KT, BN, BKC, ST>), dim3(d.M / 32, d.N / BN), dim3(DPP_THREADS), lds, st, ga);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ksplit_kernel<KT, BN, BKC, ST, PB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    DPP_LAUNCH((gemm_ksplit_kernel<KT, BN, BKC, ST, PB>), dim3(d.M / 32, d.N / BN), dim3(DPP_THREADS), lds, st, ga);
     return dpp_launch_status();
 }
 
 
-template <int BM, int BN, int WM, bool ST>
+template <int BM, int BN, int WM, bool ST, bool PB = false>
 int launch_layout(const GemmArgs& ga, hipStream_t st) {
     const dpp_gemm_desc& d = ga.d;
     dim3 grid(dpp_cdiv(d.M, BM), dpp_cdiv(d.N, BN), d.splitk);
     const bool k32 = ga.bk == 32;
+    if (PB && (d.actA.mode == 4 || ga.bk < 32)) return DPP_E_UNSUPPORTED;       // (dpp_gemm refuses these before it gets here)
     if (d.actA.mode == 4) {
         if (ST) return DPP_E_UNSUPPORTED;            // (gemm_prepare refuses the combination; keeps the LAZY kernels float32-only)
         // data gradient (A [pixels][C] with B = W [K][N]) and filter gradient (both operands [k][mn]) of a 1x1 convolution
@@ -965,18 +1071,18 @@ int launch_layout(const GemmArgs& ga, hipStream_t st) {
     }
     if (ga.bk == 64 && d.a_kc) {
         // long K-contiguous reductions (stage-2..4 1x1 convolutions and FC layers, K >= 128; measured 4.80 -> 4.74 ms per step): half as many global -> LDS round trips
-        if (d.b_kc) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, true, 1, false, true, ST>), grid, dim3(DPP_THREADS), 0, st, ga);
-        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, false, 1, false, true, ST>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (d.b_kc) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, true, 1, false, true, ST, PB>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, true, false, 1, false, true, ST, PB>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else if (d.a_kc && d.b_kc) {
-        if (k32) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 32, true, true, 1, false, true, ST>), grid, dim3(DPP_THREADS), 0, st, ga);
-        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 16, true, true, 1, false, true, ST>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (k32) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 32, true, true, 1, false, true, ST, PB>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 16, true, true, 1, false, true, ST, false>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else if (d.a_kc && !d.b_kc) {
-        if (k32) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 32, true, false, 1, false, true, ST>), grid, dim3(DPP_THREADS), 0, st, ga);
-        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 16, true, false, 1, false, true, ST>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (k32) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 32, true, false, 1, false, true, ST, PB>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 16, true, false, 1, false, true, ST, false>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else if (!d.a_kc && !d.b_kc) {
         // reduction over pixels / samples: long K, both operands [k][mn] -> 64-deep chunks keep 20+ KB per workgroup in flight
-        if (ga.wide) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, false, false, 1, false, true, ST>), grid, dim3(DPP_THREADS), 0, st, ga);
-        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, false, false, 1, false, false, ST>), grid, dim3(DPP_THREADS), 0, st, ga);
+        if (ga.wide) DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, false, false, 1, false, true, ST, PB>), grid, dim3(DPP_THREADS), 0, st, ga);
+        else DPP_LAUNCH((gemm_kernel<BM, BN, WM, 64, false, false, 1, false, false, ST, PB>), grid, dim3(DPP_THREADS), 0, st, ga);
     } else
         return DPP_E_UNSUPPORTED;
     return dpp_launch_status();
@@ -985,14 +1091,14 @@ int launch_layout(const GemmArgs& ga, hipStream_t st) {
 
 // variants 3 / 2 / 1 / 0 of dpp_gemm for a prepared problem.  ST = false: every tensor float32 (gemm.hip); ST = true: some operand /
 // output is bf16-stored (gemm_st.hip, its own translation unit: the two sets of instantiations compile side by side)
-template <bool ST>
+template <bool ST, bool PB = false>
 int gemm_dispatch(GemmArgs& ga, int bm, int bn, int wm, hipStream_t st) {
     dpp_gemm_desc& d = ga.d;
     if (d.variant == 3) {
         const int rows = stream16_rows(d, ga);
         if (!rows) return DPP_E_UNSUPPORTED;
         const bool act = d.actA.mode != 0, epi = d.residual != nullptr || d.epi.bn_x != nullptr;
-#define DPP_S16(K_, CN_, T_, B_, A_, E_) DPP_LAUNCH((gemm_stream16_kernel<K_, CN_, B_, T_, A_, E_, ST>), dim3(d.M / rows), dim3(DPP_THREADS), 0, st, ga)
+#define DPP_S16(K_, CN_, T_, B_, A_, E_) DPP_LAUNCH((gemm_stream16_kernel<K_, CN_, B_, T_, A_, E_, ST, PB>), dim3(d.M / rows), dim3(DPP_THREADS), 0, st, ga)
 #define DPP_S16_ALL(K_, CN_, T_) \
         if (d.b_kc) { if (act) { if (epi) DPP_S16(K_, CN_, T_, true, true, true); else DPP_S16(K_, CN_, T_, true, true, false); } \
                       else { if (epi) DPP_S16(K_, CN_, T_, true, false, true); else DPP_S16(K_, CN_, T_, true, false, false); } } \
@@ -1006,12 +1112,12 @@ int gemm_dispatch(GemmArgs& ga, int bm, int bn, int wm, hipStream_t st) {
     if (d.variant == 2) {
         const int kbn = ksplit_bn(d, ga);
         if (!kbn) return DPP_E_UNSUPPORTED;
-        if (d.K == 256) return d.b_kc ? launch_ksplit<256, 64, true, ST>(ga, st) : launch_ksplit<256, 64, false, ST>(ga, st);
-        return d.b_kc ? launch_ksplit<128, 32, true, ST>(ga, st) : launch_ksplit<128, 32, false, ST>(ga, st);
+        if (d.K == 256) return d.b_kc ? launch_ksplit<256, 64, true, ST, PB>(ga, st) : launch_ksplit<256, 64, false, ST, PB>(ga, st);
+        return d.b_kc ? launch_ksplit<128, 32, true, ST, PB>(ga, st) : launch_ksplit<128, 32, false, ST, PB>(ga, st);
     }
     if (d.variant == 1) {
         // row-streaming kernel: bm in {64, 128} rows per workgroup, bn in {16, 32, 64} columns, whole K staged for B
-        if (!d.a_kc || d.splitk != 1 || ST) return DPP_E_UNSUPPORTED;
+        if (!d.a_kc || d.splitk != 1 || ST || PB) return DPP_E_UNSUPPORTED;
         if (bm != 64 && bm != 128) bm = 64;
         if (bn != 16 && bn != 32 && bn != 64) bn = d.N > 32 ? 64 : (d.N > 16 ? 32 : 16);
         const int K16 = (d.K + 15) & ~15;
@@ -1027,7 +1133,7 @@ int gemm_dispatch(GemmArgs& ga, int bm, int bn, int wm, hipStream_t st) {
 #undef DPP_RS
         return DPP_E_UNSUPPORTED;
     }
-#define DPP_TILE(BM_, BN_, WM_) if (bm == BM_ && bn == BN_ && wm == WM_) return launch_layout<BM_, BN_, WM_, ST>(ga, st);
+#define DPP_TILE(BM_, BN_, WM_) if (bm == BM_ && bn == BN_ && wm == WM_) return launch_layout<BM_, BN_, WM_, ST, PB>(ga, st);
     DPP_TILE(128, 64, 4)
     DPP_TILE(128, 32, 4)
     DPP_TILE(128, 16, 4)

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(DPP_THREADS) void wgrad_stream_kernel(WgradArgs a) 
 #pragma unroll
                 for (int f = 0; f < VB; ++f) {
                     float v = bv[u][f];
-                    if (mode & 2) v = (v - mu[f]) * sc[f] + be[f];
+                    if (mode & 2) v = dpp_fma(v - mu[f], sc[f], be[f]);
                     if (mode & 1) v = fmaxf(v, 0.0f);
                     bq[f] = v;
                 }
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(DPP_THREADS) void wgrad3_stream_kernel(Wgrad3sArgs 
                 for (int j = 0; j < TG; ++j) {
                     const bool in = (mask >> j) & 1u;
 #pragma unroll
-                    for (int f = 0; f < VB; ++f) bq[j][f] = in ? fmaxf((bv[u][j][f] - mu[f]) * sc[f] + be[f], lo) : 0.0f;
+                    for (int f = 0; f < VB; ++f) bq[j][f] = in ? fmaxf(dpp_fma(bv[u][j][f] - mu[f], sc[f], be[f]), lo) : 0.0f;
                 }
 #pragma unroll
                 for (int e = 0; e < VA; ++e) aq[e] = (mask & 0x10000u) ? av[u][e] : 0.0f;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(DPP_THREADS) void fc_wgrad_stream_kernel(FcWgradArg
             float aq[V], bq[V];
             const bool ok = b0 + 4 * u + kq < a.Nb;
 #pragma unroll
-            for (int e = 0; e < V; ++e) aq[e] = ok ? fmaxf((av[u][e] - mu[e]) * sc[e] + be[e], lo) : 0.0f;
+            for (int e = 0; e < V; ++e) aq[e] = ok ? fmaxf(dpp_fma(av[u][e] - mu[e], sc[e], be[e]), lo) : 0.0f;
 #pragma unroll
             for (int f = 0; f < V; ++f) bq[f] = bv[u][f];
             DPP_SCHED_FENCE();

@@ -458,6 +458,19 @@ class CompiledNet(object):
         self.tensors.append(t)
         return t
 
+    def _gemm_prec(self, variant, K, lazy=False):
+        """dpp_gemm_desc.precision of a 1x1-convolution product in this net: 1 (bf16 MFMA operands, f32 accumulation) in the bf16 mode
+        wherever the kernel of `variant` has the path -- round 4: the wave-autonomous kernel (variant 4) with whole 32-deep steps; round 6:
+        the LDS-tiled kernel with chunks of 32 / 64 (K > 16), the K-split kernel, the 16-column stream (K = 16 with a zero upper half) --
+        never with the two-tensor BatchNorm-backward operand (`lazy`) or on the row-stream kernel (variant 1)."""
+        if not (self.prec and hz.BF16_GEMM) or lazy or variant == 1:
+            return 0
+        if variant == 4:
+            return int(K >= 32)
+        if not hz.BF16_GEMM_ALL:
+            return 0
+        return int(variant in (2, 3) or K > 16)
+
     def _act(self, view):
         mode = (Act.BN if view.bn is not None else 0) | (Act.RELU if view.relu else 0)
         if mode == 0:
@@ -780,10 +793,10 @@ class CompiledNet(object):
             variant = 1 if rs is not None else (2 if ks is not None else (4 if ex is not None else (3 if s16 is not None else 0)))
 
             def build(tile, variant, epi):
-                # (bf16 mode: the wave-autonomous kernel multiplies on the bf16 matrix pipe where K is a whole 32-deep step)
+                # (bf16 mode: bf16 MFMA operands wherever the kernel of the variant has them, _gemm_prec)
                 return ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, M, Co, Ci, 1, 1, Ci, Ci, Co, mapA=mp, actA=act,
                                 bias=st.view(layer.b), residual=res, tile=tile, epi=epi, variant=variant,
-                                name='conv1x1_%d' % layer.layerNum, precision=self.prec if (variant == 4 and Ci >= 32 and hz.BF16_GEMM) else 0)
+                                name='conv1x1_%d' % layer.layerNum, precision=self._gemm_prec(variant, Ci))
             if variant in (2, 3, 4) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
                 # the shape asks for the kernel, the buffers rule it out (alignment / prologue): the generic tile, not a failed build
                 variant, (tile, _) = 0, hz.gemm_plan(M, Co, Ci, allow_split=False)
@@ -1229,7 +1242,8 @@ class CompiledNet(object):
             tile, splitk = hz.wgrad_plan(Co, Ci, M)
             part = rt.alloc(splitk * Co * Ci, zero=False) if splitk > 1 else None     # persistent: reduced at the end of backward
             self.bwd.add(ops.gemm(rt, dy, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actA=dy_act,
-                                  actB=act, splitk=splitk, partial=part, tile=tile, name='wgrad1x1_%d' % layer.layerNum), side=True)
+                                  actB=act, splitk=splitk, partial=part, tile=tile, name='wgrad1x1_%d' % layer.layerNum,
+                                  precision=self._gemm_prec(0, M, lazy=dy_act is not None)), side=True)
             if splitk > 1:
                 self.reduce_jobs.add(part, splitk, Co * Ci, gW)
 
@@ -1263,7 +1277,7 @@ class CompiledNet(object):
                     return ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
                                     residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
                                     name='dgrad1x1_%d' % layer.layerNum,
-                                    precision=self.prec if (variant == 4 and Co >= 32 and dY_act is None and hz.BF16_GEMM) else 0)
+                                    precision=self._gemm_prec(variant, Co, lazy=dY_act is not None))
                 if variant in (2, 3, 4) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
                     variant, (tile, _) = 0, hz.gemm_plan(M, Ci, Co, allow_split=False)       # see the forward twin
                 epi = None

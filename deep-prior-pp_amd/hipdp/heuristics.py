@@ -92,6 +92,9 @@ BF16_GRADS = knob('DPP_BF16_GRADS', '1') != '0'
 # ... and runs the channel-expanding 1x1 convolutions / the data gradients of the reducing ones (dpp_gemm variant 4, K = 32 / 64) on
 # bf16 MFMA operands (dpp_gemm_desc.precision).  DPP_BF16_GEMM=0: f32 MFMA there (rounds 2-3: only the 3x3 convolutions and FC1).
 BF16_GEMM = knob('DPP_BF16_GEMM', '1') != '0'
+# round 6: also on the LDS-tiled, K-split and 16-column-stream kernels (reducing 1x1 convolutions, their twins' data gradients, the 1x1
+# filter gradients of stages 2-4).  DPP_BF16_GEMM_ALL=0: the round-4/5 set (wave-autonomous kernel only).
+BF16_GEMM_ALL = knob('DPP_BF16_GEMM_ALL', '1') != '0'
 # round 6: the 3x3 filter gradients of the 16- / 32-channel layers on bf16 MFMA operands (dpp_conv3x3_wgrad_bf16).  DPP_BF16_WGRAD3=0: f32 MFMA.
 BF16_WGRAD3 = knob('DPP_BF16_WGRAD3', '1') != '0'
 # ADAM of the FC1 weight (90 % of the parameters, 470 MB of optimizer traffic) inside the backward pass: its gradient is final a few

@@ -83,10 +83,13 @@ class _QBilinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, W, fn, q):
-        aq = q['pin'].to(a.dtype) if q.get('pin') is not None else (bf16r(a) if q.get('fwd') else a.detach())
+        # the rounded activation: the forward product's operand if 'fwd', the filter gradient's if 'wgrad' (round 6: a layer's filter
+        # gradient may run on bf16 operands while its forward product does not -- K = 16 layers -- and the other way round)
+        ar = q['pin'].to(a.dtype) if q.get('pin') is not None else bf16r(a)
+        aq = ar if q.get('fwd') else a.detach()
         Wq = bf16r(W) if q.get('fwd') else W.detach()
         ctx.fn, ctx.q = fn, q
-        ctx.save_for_backward(a.detach(), W.detach(), aq)
+        ctx.save_for_backward(a.detach(), W.detach(), ar if q.get('wgrad') else a.detach())
         return fn(aq, Wq)
 
     @staticmethod
@@ -98,7 +101,7 @@ class _QBilinear(torch.autograd.Function):
             av = a.clone().requires_grad_(True)
             (da,) = torch.autograd.grad(fn(av, bf16r(W) if q.get('dgrad') else W), av, gq if q.get('dgrad') else gy)
             Wv = W.clone().requires_grad_(True)
-            (dW,) = torch.autograd.grad(fn(aq if q.get('wgrad') else a, Wv), Wv, gq if q.get('wgrad') else gy)
+            (dW,) = torch.autograd.grad(fn(aq, Wv), Wv, gq if q.get('wgrad') else gy)          # aq: rounded iff 'wgrad' (see forward)
         return da, dW, None, None
 
 

@@ -102,7 +102,7 @@ def device_quant(eng, net):
             raise AssertionError("a bf16 launch the oracle cannot place: %r" % (l.name,))
     for i, q in quant.items():
         io = eng.layer_io[id(net.layers[i])]
-        if q['fwd']:
+        if q['fwd'] or q['wgrad']:
             q['pin'] = L.bf16_round(_activated_operand(io['in_view']))
         if (q['dgrad'] or q['wgrad']) and io['out'].grad is not None and getattr(eng, 'train', False):
             # the gradient w.r.t. the layer's output as the backward kernels read it (call after the backward pass has run)

@@ -462,7 +462,8 @@ def test_expand_kernel_on_bf16_mfma_operands(backend, cfg, stored):
     """dpp_gemm variant 4 with precision = 1: both operands rounded to bfloat16 (the activation AFTER its BatchNorm + ReLU prologue),
     f32 accumulation on v_mfma_f32_16x16x32_bf16 -- forward and data gradient against the float64 product of the ROUNDED operands
     (the rounding is the whole difference to the f32 kernel, so the f32 tolerance applies), on float32 and on bf16-stored tensors;
-    K = 16 and the other dpp_gemm kernels refuse the precision."""
+    K = 16 is refused by this kernel (the other dpp_gemm kernels take the precision since round 6:
+    test_gemm_tile_ksplit_and_stream_kernels_on_bf16_mfma_operands)."""
     rt = get_runtime(backend)
     K, N, M, rpw = cfg
     rng = np.random.RandomState(81)
@@ -512,5 +513,66 @@ def test_expand_kernel_on_bf16_mfma_operands(backend, cfg, stored):
     A16k = rt.alloc((M, 16))
     assert ops.gemm_variant_rows(rt, ops.gemm(rt, A16k, rt.alloc((64, 16)), rt.alloc((M, 64)), M, 64, 16, 1, 1, 16, 16, 64, tile=(32, 64, 4), variant=4,
                                               precision=1)) == 0
-    with pytest.raises(Exception):
-        ops.gemm(rt, X32, rt.upload(Wk), rt.alloc((M, N)), M, N, K, 1, 1, K, K, N, precision=1)(rt.stream)
+    with pytest.raises(Exception):          # the row-stream kernel (variant 1) has no bf16 path
+        ops.gemm(rt, X32, rt.upload(Wk), rt.alloc((M, N)), M, N, K, 1, 1, K, K, N, precision=1, variant=1, tile=(64, 64, 4))(rt.stream)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('stored', [False, True])
+@pytest.mark.parametrize('case', ['tile_k64_n32', 'tile_k128_n32', 'tile_k40_ragged', 'ksplit256', 'ksplit128', 'stream_64_16', 'stream_16_64'])
+def test_gemm_tile_ksplit_and_stream_kernels_on_bf16_mfma_operands(backend, stored, case):
+    """dpp_gemm variants 0, 2 and 3 with precision = 1 (round 6, VERDICT r5 item 1(a): bf16 MFMA operands for gemm_kernel, gemm_ksplit_kernel
+    and gemm_stream16_kernel): forward (K-contiguous activations with the BatchNorm + ReLU prologue x K-contiguous filters), data gradient
+    (dY x W[K][N]) and filter gradient (both operands pixel-major, reduction over pixels, split K) against the float64 product of the
+    operands ROUNDED to bfloat16 -- the activation after its prologue -- on float32 and on bf16-stored tensors.
+    /root/reference/src/net/convlayer.py:230-240, T.grad at /root/reference/src/trainer/poseregnettrainer.py:110-111."""
+    rt = get_runtime(backend)
+    K, N, M, variant, tile = {'tile_k64_n32': (64, 32, 192, 0, (64, 32, 4)), 'tile_k128_n32': (128, 32, 128, 0, (64, 16, 4)),
+                              'tile_k40_ragged': (40, 24, 100, 0, (0, 0, 0)), 'ksplit256': (256, 64, 64, 2, (32, 64, 4)),
+                              'ksplit128': (128, 32, 96, 2, (32, 32, 4)), 'stream_64_16': (64, 16, 256, 3, (128, 16, 4)),
+                              'stream_16_64': (16, 64, 128, 3, (64, 64, 4))}[case]
+    rng = np.random.RandomState(83)
+    q = lambda v: widen(bf16_bits(np.asarray(v, np.float32))).astype('f8')                  # noqa: E731
+    X16, X32 = both(rt, rng.normal(size=(M, K)) * 2 + 1)
+    X = X16 if stored else X32
+    xv = widen(X16.get()).reshape(M, K)
+    Wk = (rng.normal(size=(N, K)) * 0.3).astype(np.float32)
+    mean, scale, beta = (rng.normal(size=K).astype(np.float32) for _ in range(3))
+    bias = rng.normal(size=N).astype(np.float32)
+    act = ops.act(Act.BN_RELU, rt.upload(mean), rt.upload(scale), rt.upload(beta), K)
+    a = np.maximum(((xv - mean).astype(np.float32).astype('f8') * scale.astype('f8') + beta.astype('f8')).astype(np.float32), 0)
+    # forward
+    Y = rt.alloc((M, N), zero=False)
+    L = ops.gemm(rt, X, rt.upload(Wk), Y, M, N, K, 1, 1, K, K, N, actA=act, bias=rt.upload(bias), tile=tile, variant=variant, precision=1)
+    if variant:
+        assert ops.gemm_variant_rows(rt, L) > 0
+    L(rt.stream)
+    rt.synchronize()
+    ref = q(a) @ q(Wk).T + bias
+    np.testing.assert_allclose(Y.get(), ref, rtol=0, atol=3e-6 * np.sqrt(K) * np.abs(ref).max())
+    # the float32 kernel on the same problem differs by the rounding of the operands (a guard that the bf16 path really ran)
+    Y0 = rt.alloc((M, N), zero=False)
+    ops.gemm(rt, X, rt.upload(Wk), Y0, M, N, K, 1, 1, K, K, N, actA=act, bias=rt.upload(bias), tile=tile, variant=variant)(rt.stream)
+    rt.synchronize()
+    assert np.abs(Y0.get() - ref).max() > 20 * 3e-6 * np.sqrt(K) * np.abs(ref).max()
+    # data gradient of the twin layer: dX[M][N] = dY[M][K] . W2[K][N]
+    W2 = (rng.normal(size=(K, N)) * 0.3).astype(np.float32)
+    dY16, dY32 = both(rt, rng.normal(size=(M, K)))
+    dH = rt.alloc((M, N), zero=False)
+    L = ops.gemm(rt, dY16 if stored else dY32, rt.upload(W2), dH, M, N, K, 1, 0, K, N, N, tile=tile, variant=variant, precision=1)
+    if variant:
+        assert ops.gemm_variant_rows(rt, L) > 0
+    L(rt.stream)
+    rt.synchronize()
+    g = widen(dY16.get()).reshape(M, K).astype('f8') @ q(W2)
+    np.testing.assert_allclose(dH.get(), g, rtol=0, atol=3e-6 * np.sqrt(K) * np.abs(g).max())
+    if variant == 0:
+        # filter gradient dW[N][K] = sum_m G[m][N] * act(X)[m][K], reduction over the M pixel rows in 2 K-slices
+        G16, G32 = both(rt, rng.normal(size=(M, N)))
+        part = rt.alloc((2, N, K), zero=False)
+        dW = rt.alloc((N, K), zero=False)
+        ops.gemm(rt, G16 if stored else G32, X, None, N, K, M, 0, 0, N, K, K, actB=act, splitk=2, partial=part, precision=1)(rt.stream)
+        ops.reduce_partials(rt, part, 2, N * K, dW)(rt.stream)
+        rt.synchronize()
+        want = widen(G16.get()).reshape(M, N).astype('f8').T @ q(a)
+        np.testing.assert_allclose(dW.get(), want, rtol=0, atol=3e-6 * np.sqrt(M) * np.abs(want).max())
