@@ -51,6 +51,34 @@ __global__ __launch_bounds__(DPP_THREADS) void loss_sse_kernel(const float* __re
     if (threadIdx.x == 0) cost[0] = (float)(s[0] * (double)inv_denom);
 }
 
+// The last HiddenLayer's split-K reduction and the cost in ONE launch (round 6: the loss was a 5 us launch of its own between the forward
+// and the backward chain): out[i] = sum_z partial[z][i] + bias[i % nbias] in the slice order of reduce_partials_kernel's one-lane form,
+// then loss_sse_kernel's arithmetic on the values just written.  One workgroup; n = batch x output dimension (3 840 for the 30-D
+// embedding at batch 128).
+__global__ __launch_bounds__(DPP_THREADS) void reduce_partials_loss_kernel(const float* __restrict__ partial, int nz, int n,
+                                                                           const float* __restrict__ bias, int nbias, float* __restrict__ out,
+                                                                           const float* __restrict__ y, float inv_denom,
+                                                                           float* __restrict__ cost, float* __restrict__ dout) {
+    __shared__ double s[DPP_THREADS];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += DPP_THREADS) {
+        float v = 0.0f;
+        for (int z = 0; z < nz; ++z) v += partial[(size_t)z * n + i];
+        if (bias) v += bias[i % nbias];
+        out[i] = v;
+        const float d = v - y[i];
+        acc += (double)d * (double)d;
+        if (dout) dout[i] = 2.0f * inv_denom * d;
+    }
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = DPP_THREADS / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cost[0] = (float)(s[0] * (double)inv_denom);
+}
+
 // The scalar-target cost of poseregnettrainer.py:84-85, 92-93 (numJoints == nDims == 1): the net output reshaped to (B, 1) -- a
 // broadcastable column in Theano -- minus the VECTOR y (B,) is the (B, B) matrix o_i - y_j, so
 //   cost = mean_i mean_j (o_i - y_j)^2 ,   d cost / d o_i = (2 / B) (o_i - mean(y)).
@@ -130,8 +158,19 @@ __global__ __launch_bounds__(DPP_THREADS) void error_l2_kernel(const float* __re
 // state (device, 8 floats): lr, t, beta1, beta2, epsilon, gamma, -, -.  The scalar terms of optimizer.py:69-84 are evaluated
 // here in float32 (beta1_t = beta1*gamma^(t-1), 1-beta1^t, 1-beta2^t) so that a captured step can be replayed without
 // any host upload; adam_tick_kernel advances t after the update (the reference's `t <- t + 1`).
+// tick (round 6, dpp_adam_ticked): the launch advances t itself -- every workgroup takes a ticket (state[7], an unsigned counter) when it
+// is done, the LAST one resets the counter and bumps t: all the others have read t by then (a workgroup reads the state before its
+// first element), so the 5 us adam_tick launch at the end of every step is gone.
+__device__ __forceinline__ void adam_take_ticket(float* state) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* ctr = reinterpret_cast<unsigned*>(state + 7);
+        if (atomicAdd(ctr, 1u) == gridDim.x - 1) { *ctr = 0u; state[1] += 1.0f; }
+    }
+}
+
 __global__ __launch_bounds__(DPP_THREADS) void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
-                                                           float* __restrict__ v, size_t n, const float* __restrict__ state) {
+                                                           float* __restrict__ v, size_t n, float* state, int tick) {
     const float lr = state[0], t = state[1], beta1 = state[2], b2 = state[3], eps = state[4], gamma = state[5];
     if (state[6] != 0.0f) {
         // RMSProp (optimizer.py:92-116): msg = decay * msg + (1 - decay) * g^2;  w += -lr * g / max(sqrt(msg), epsilon).
@@ -143,6 +182,7 @@ __global__ __launch_bounds__(DPP_THREADS) void adam_kernel(float* __restrict__ w
             w[i] = w[i] + (-lr * gg) / fmaxf(sqrtf(ms), eps);
             v[i] = ms;
         }
+        if (tick) adam_take_ticket(state);
         return;
     }
     const float b1 = beta1 * powf(gamma, t - 1.0f);
@@ -170,6 +210,7 @@ __global__ __launch_bounds__(DPP_THREADS) void adam_kernel(float* __restrict__ w
         v[i] = vv;
     }
 #undef DPP_ADAM1
+    if (tick) adam_take_ticket(state);
 }
 
 __global__ void adam_tick_kernel(float* state) {
@@ -339,6 +380,14 @@ extern "C" int dpp_loss_sse(const float* out, const float* y, int rows, int d, i
     return dpp_launch_status();
 }
 
+extern "C" int dpp_reduce_partials_loss(const float* partial, int nz, int rows, int d, const float* bias, float* out, const float* y, int denom,
+                                        float* cost, float* dout, dpp_stream_t stream) {
+    if (!partial || !out || !y || !cost || nz < 1 || rows < 1 || d < 1 || denom < 1 || (long)rows * d > 65536) return DPP_E_BADARG;
+    DPP_LAUNCH(reduce_partials_loss_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), partial, nz, rows * d, bias, d, out, y,
+               1.0f / (float)denom, cost, dout);
+    return dpp_launch_status();
+}
+
 extern "C" int dpp_loss_sse_bcast(const float* out, const float* y, int n, float* cost, float* dout, float* err, dpp_stream_t stream) {
     if (!out || !y || !cost || n < 1 || n > 32768) return DPP_E_BADARG;
     DPP_LAUNCH(loss_sse_bcast_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), out, y, n, cost, dout, err);
@@ -357,12 +406,20 @@ extern "C" int dpp_adam_tick(float* state, dpp_stream_t stream) {
     return dpp_launch_status();
 }
 
-extern "C" int dpp_adam(float* w, const float* g, float* m, float* v, size_t n, const float* hyper, dpp_stream_t stream) {
+static int adam_launch(float* w, const float* g, float* m, float* v, size_t n, float* hyper, int tick, dpp_stream_t stream) {
     if (!w || !g || !m || !v || !hyper || n < 1) return DPP_E_BADARG;
     if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15)
         return DPP_E_BADARG;
-    DPP_LAUNCH(adam_kernel, dim3(grid_for(n >> 2)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), w, g, m, v, n, hyper);
+    DPP_LAUNCH(adam_kernel, dim3(grid_for(n >> 2)), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), w, g, m, v, n, hyper, tick);
     return dpp_launch_status();
+}
+
+extern "C" int dpp_adam(float* w, const float* g, float* m, float* v, size_t n, const float* hyper, dpp_stream_t stream) {
+    return adam_launch(w, g, m, v, n, const_cast<float*>(hyper), 0, stream);
+}
+
+extern "C" int dpp_adam_ticked(float* w, const float* g, float* m, float* v, size_t n, float* hyper, dpp_stream_t stream) {
+    return adam_launch(w, g, m, v, n, hyper, 1, stream);
 }
 
 extern "C" int dpp_axpy(float* y, const float* x, float alpha, size_t n, dpp_stream_t stream) {

@@ -386,8 +386,19 @@ class CompiledNet(object):
                 self.lossplan.add(ops.loss_sse_bcast(rt, self.out.buf, self.y_in, self.N, self.cost, self.out.grad if train else None,
                                                      err=None if train else self.err))
             else:
-                self.lossplan.add(ops.loss_sse(rt, self.out.buf, self.y_in, self.N, self.out_dim, denom, self.cost,
-                                               self.out.grad if train else None))
+                last = self.fwd.ops[-1][0] if self.fwd.ops else None
+                fus = getattr(self, '_loss_fusable', None)
+                if (train and hz.FUSE_LOSS and fus is not None and fus[0] is last and fus[1]['out'] is self.out.buf
+                        and self.N * self.out_dim <= 65536):
+                    # the split-K reduction of the last HiddenLayer is the forward plan's last launch: it computes the cost and its
+                    # gradient as well (one launch less between the forward and the backward chain; running the forward plan alone
+                    # still leaves `out`)
+                    f = fus[1]
+                    self.fwd.ops[-1] = (ops.reduce_partials_loss(rt, f['partial'], f['nz'], self.N, self.out_dim, self.out.buf, f['bias'], self.y_in,
+                                                                 denom, self.cost, self.out.grad), False)
+                else:
+                    self.lossplan.add(ops.loss_sse(rt, self.out.buf, self.y_in, self.N, self.out_dim, denom, self.cost,
+                                                   self.out.grad if train else None))
             if self.weight_decay and not net.hasDropout():
                 # cost += weightreg_factor * sum(W^2) over the conv / FC weights, only for nets without dropout
                 # (poseregnettrainer.py:101-107); the kernel-layout W holds the same values in another order
@@ -433,8 +444,9 @@ class CompiledNet(object):
                 self._grad_allreduce += self._wd_ops       # once, on the all-reduced gradient (see _emit_backward)
                 for op in self._grad_allreduce:
                     self.upd.add(op)
-            self.upd.add(ops.adam(rt, self.store.w, self.store.g, self.store.m, self.store.v, self.store.n_w, self.hyper))
-            self.upd.add(ops.adam_tick(rt, self.hyper))
+            # ONE launch: the update over the whole flat buffer, whose last workgroup advances t (round 6: the adam_tick launch behind
+            # it was 5 us at the end of every step)
+            self.upd.add(ops.adam(rt, self.store.w, self.store.g, self.store.m, self.store.v, self.store.n_w, self.hyper, tick=True))
             if self.dropout_masks:
                 self.upd.add(ops.counter_add(rt, self.step_ctr, 1))
             self._lr = None
@@ -458,7 +470,7 @@ class CompiledNet(object):
         self.tensors.append(t)
         return t
 
-    def _gemm_prec(self, variant, K, lazy=False):
+    def _gemm_prec(self, variant, K, lazy=False, role='fwd'):
         """dpp_gemm_desc.precision of a 1x1-convolution product in this net: 1 (bf16 MFMA operands, f32 accumulation) in the bf16 mode
         wherever the kernel of `variant` has the path -- round 4: the wave-autonomous kernel (variant 4) with whole 32-deep steps; round 6:
         the LDS-tiled kernel with chunks of 32 / 64 (K > 16), the K-split kernel, the 16-column stream (K = 16 with a zero upper half) --
@@ -467,7 +479,7 @@ class CompiledNet(object):
             return 0
         if variant == 4:
             return int(K >= 32)
-        if not hz.BF16_GEMM_ALL:
+        if not hz.BF16_GEMM_ALL or role not in hz.BF16_GEMM_ROLES or str(variant) not in hz.BF16_GEMM_VARIANTS:
             return 0
         return int(variant in (2, 3) or K > 16)
 
@@ -862,7 +874,8 @@ class CompiledNet(object):
             part = self.scratch(splitk * Nb * Nout)
             self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), None, Nb, Nout, K, 1, 0, K, Nout, Nout, actA=act, splitk=splitk,
                                   partial=part, tile=tile, name='fc_%d' % layer.layerNum))
-            self.fwd.add(ops.reduce_partials(rt, part, splitk, Nb * Nout, out.buf, bias=st.view(layer.b), nbias=Nout))
+            red = self.fwd.add(ops.reduce_partials(rt, part, splitk, Nb * Nout, out.buf, bias=st.view(layer.b), nbias=Nout))
+            self._loss_fusable = (red, dict(partial=part, nz=splitk, bias=st.view(layer.b), out=out.buf))       # see the loss plan (__init__)
         else:
             self.fwd.add(ops.gemm(rt, src.base.buf, st.view(layer.W), out.buf, Nb, Nout, K, 1, 0, K, Nout, Nout, actA=act,
                                   bias=st.view(layer.b), tile=tile, name='fc_%d' % layer.layerNum))
@@ -1243,7 +1256,7 @@ class CompiledNet(object):
             part = rt.alloc(splitk * Co * Ci, zero=False) if splitk > 1 else None     # persistent: reduced at the end of backward
             self.bwd.add(ops.gemm(rt, dy, src.base.buf, None if splitk > 1 else gW, Co, Ci, M, 0, 0, Co, Ci, Ci, mapB=mp, actA=dy_act,
                                   actB=act, splitk=splitk, partial=part, tile=tile, name='wgrad1x1_%d' % layer.layerNum,
-                                  precision=self._gemm_prec(0, M, lazy=dy_act is not None)), side=True)
+                                  precision=self._gemm_prec(0, M, lazy=dy_act is not None, role='wgrad')), side=True)
             if splitk > 1:
                 self.reduce_jobs.add(part, splitk, Co * Ci, gW)
 
@@ -1277,7 +1290,7 @@ class CompiledNet(object):
                     return ops.gemm(rt, dY, st.view(layer.W), dst, M, Ci, Co, 1, 0, Co, Ci, Ci, mapC=mp, actA=dY_act,
                                     residual=dst if acc else None, tile=tile, epi=epi, variant=variant,
                                     name='dgrad1x1_%d' % layer.layerNum,
-                                    precision=self._gemm_prec(variant, Co, lazy=dY_act is not None))
+                                    precision=self._gemm_prec(variant, Co, lazy=dY_act is not None, role='dgrad'))
                 if variant in (2, 3, 4) and ops.gemm_variant_rows(rt, build(tile, variant, None)) != tile[0]:
                     variant, (tile, _) = 0, hz.gemm_plan(M, Ci, Co, allow_split=False)       # see the forward twin
                 epi = None
@@ -1553,6 +1566,7 @@ class CompiledNet(object):
         for a, z in ((0, lo), (hi, n)):
             if z > a:
                 upd.add(ops.adam(rt, sl(st.w, a, z), sl(st.g, a, z), sl(st.m, a, z), sl(st.v, a, z), z - a, self.hyper))
+        upd.add(ops.adam_tick(rt, self.hyper))              # the update is several launches here: t advances behind the last of them
         for (op, side) in self.upd.ops:
             if getattr(op, 'name', '') != 'adam':
                 upd.add(op, side)

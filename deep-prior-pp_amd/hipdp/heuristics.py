@@ -66,6 +66,8 @@ def gemm_plan(M, N, K, allow_split=True):
 # (hipdp/evalfuse.py, csrc/resblock.hip) and the stored-statistics coefficients of all remaining BatchNorms in one launch.
 # DPP_EVAL_FUSE=0: the layer-by-layer decomposition of rounds 1-4 (131 launches per forward pass of the 128x128 ResNet).
 EVAL_FUSE = knob('DPP_EVAL_FUSE', '1') != '0'
+# round 6: the cost and its gradient computed by the split-K reduction of the last HiddenLayer (dpp_reduce_partials_loss).  DPP_FUSE_LOSS=0: own launch.
+FUSE_LOSS = knob('DPP_FUSE_LOSS', '1') != '0'
 OVERLAP_ALLREDUCE = knob('DPP_OVERLAP_ALLREDUCE', '1') != '0'
 EARLY_BUCKET_MIN = int(knob('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elements; FC1 of the 128x128 ResNet has 16.8 M
 # 1x1 convolutions can read the BatchNorm gradient as (G, x) instead of a materialised dX (see _resolve_view).
@@ -95,6 +97,8 @@ BF16_GEMM = knob('DPP_BF16_GEMM', '1') != '0'
 # round 6: also on the LDS-tiled, K-split and 16-column-stream kernels (reducing 1x1 convolutions, their twins' data gradients, the 1x1
 # filter gradients of stages 2-4).  DPP_BF16_GEMM_ALL=0: the round-4/5 set (wave-autonomous kernel only).
 BF16_GEMM_ALL = knob('DPP_BF16_GEMM_ALL', '1') != '0'
+BF16_GEMM_ROLES = tuple(knob('DPP_BF16_GEMM_ROLES', 'fwd,dgrad,wgrad').split(','))       # (bisecting: which products of the round-6 set)
+BF16_GEMM_VARIANTS = tuple(knob('DPP_BF16_GEMM_VARIANTS', '0,2,3').split(','))            # (bisecting: on which dpp_gemm variants)
 # round 6: the 3x3 filter gradients of the 16- / 32-channel layers on bf16 MFMA operands (dpp_conv3x3_wgrad_bf16).  DPP_BF16_WGRAD3=0: f32 MFMA.
 BF16_WGRAD3 = knob('DPP_BF16_WGRAD3', '1') != '0'
 # ADAM of the FC1 weight (90 % of the parameters, 470 MB of optimizer traffic) inside the backward pass: its gradient is final a few

@@ -133,9 +133,11 @@ SIGNATURES = {
     'dpp_wtrans_job_bytes': (C.c_size_t, []),
     'dpp_conv3x3_wtrans_multi': (C.c_int, [C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_loss_sse': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, stream_t]),
+    'dpp_reduce_partials_loss': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_loss_sse_bcast': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, stream_t]),
     'dpp_error_l2': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, stream_t]),
     'dpp_adam': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, stream_t]),
+    'dpp_adam_ticked': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, stream_t]),
     'dpp_adam_tick': (C.c_int, [C.c_void_p, stream_t]),
     'dpp_counter_add': (C.c_int, [C.c_void_p, C.c_ulonglong, stream_t]),
     'dpp_axpy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_size_t, stream_t]),

@@ -533,6 +533,13 @@ def loss_sse(rt, out, y, rows, d, denom, cost, dout=None, name='loss_sse'):
     return Launch(rt.lib.dpp_loss_sse, (out.ptr, y.ptr, rows, d, denom, cost.ptr, _p(dout)), (out, y, cost, dout), name)
 
 
+def reduce_partials_loss(rt, partial, nz, rows, d, out, bias, y, denom, cost, dout=None, name='reduce_partials_loss'):
+    """reduce_partials (+ bias) of the net's last HiddenLayer and loss_sse on its output in one launch."""
+    n = rows * d
+    return Launch(rt.lib.dpp_reduce_partials_loss, (partial.ptr, nz, rows, d, _p(bias), out.ptr, y.ptr, denom, cost.ptr, _p(dout)),
+                  (partial, out, bias, y, cost, dout), name, dict(kernel='reduce_partials', flops=float(nz) * n, bytes=4.0 * (nz + 3) * n))
+
+
 def loss_sse_bcast(rt, out, y, n, cost, dout=None, err=None, name='loss_sse_bcast'):
     return Launch(rt.lib.dpp_loss_sse_bcast, (out.ptr, y.ptr, n, cost.ptr, _p(dout), _p(err)), (out, y, cost, dout, err), name)
 
@@ -541,8 +548,9 @@ def error_l2(rt, out, y, rows, d, err, name='error_l2'):
     return Launch(rt.lib.dpp_error_l2, (out.ptr, y.ptr, rows, d, err.ptr), (out, y, err), name)
 
 
-def adam(rt, w, g, m, v, n, hyper, name='adam'):
-    return Launch(rt.lib.dpp_adam, (w.ptr, g.ptr, m.ptr, v.ptr, n, hyper.ptr), (w, g, m, v, hyper), name,
+def adam(rt, w, g, m, v, n, hyper, name='adam', tick=False):
+    """tick: the launch also advances the step count t (dpp_adam_ticked) -- no dpp_adam_tick launch behind it."""
+    return Launch(rt.lib.dpp_adam_ticked if tick else rt.lib.dpp_adam, (w.ptr, g.ptr, m.ptr, v.ptr, n, hyper.ptr), (w, g, m, v, hyper), name,
                   dict(kernel='adam', flops=12.0 * n, bytes=28.0 * n))
 
 

@@ -322,6 +322,10 @@ int dpp_colsum_partial(const float* X, int M, int C, int rows_per_block, float* 
 /* cost = (1/denom) sum (out-y)^2, dout = (2/denom)(out-y): /root/reference/src/trainer/poseregnettrainer.py:92-99
  * (denom = batch for the embedding loss, batch*numJoints for the joint loss); dout may be NULL */
 int dpp_loss_sse(const float* out, const float* y, int rows, int d, int denom, float* cost, float* dout, dpp_stream_t stream);
+/* (ABI v11) dpp_reduce_partials (out[rows][d] = sum of nz split-K slices + bias[d], the last HiddenLayer of the net,
+ * /root/reference/src/net/hiddenlayer.py:136-139) and dpp_loss_sse on that output in ONE launch; rows * d <= 65536. */
+int dpp_reduce_partials_loss(const float* partial, int nz, int rows, int d, const float* bias, float* out, const float* y, int denom,
+                             float* cost, float* dout, dpp_stream_t stream);
 /* The scalar-target case (numJoints == nDims == 1, poseregnettrainer.py:84-85, 92-93): Theano broadcasts the (B, 1) output against
  * the VECTOR y, so the cost is mean_i mean_j (out_i - y_j)^2 and dout_i = (2 / B)(out_i - mean(y)); n = B.  err (may be NULL):
  * the monitor of :115 under the same broadcast, err[0] = mean, err[1] = max over all pairs of |out_i - y_j|. */
@@ -332,6 +336,9 @@ int dpp_error_l2(const float* out, const float* y, int rows, int d, float* err, 
  * state (device, 8 floats): lr, t, beta1, beta2, epsilon, gamma, 0, 0 -- the bias-correction terms are evaluated on the
  * device in float32; dpp_adam_tick performs `t <- t + 1` (optimizer.py:88) after the update. */
 int dpp_adam(float* w, const float* g, float* m, float* v, size_t n, const float* state, dpp_stream_t stream);
+/* (ABI v11) dpp_adam followed by dpp_adam_tick in ONE launch: the last workgroup to finish advances t (hyper[1]); hyper[7] is the
+ * launch's ticket counter (an unsigned, zero between launches).  For an update that is a single launch over the whole flat buffer. */
+int dpp_adam_ticked(float* w, const float* g, float* m, float* v, size_t n, float* hyper, dpp_stream_t stream);
 int dpp_adam_tick(float* state, dpp_stream_t stream);
 int dpp_axpy(float* y, const float* x, float alpha, size_t n, dpp_stream_t stream);              /* y += alpha x */
 int dpp_sumsq(const float* x, size_t n, float alpha, float* out, int accumulate, dpp_stream_t stream);

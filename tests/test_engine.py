@@ -357,7 +357,10 @@ def bf16_gradients_vs_pinned_oracle(rt, net, onet, P, x, y, bar=2e-4):
         for (kind, i), mine in own_g.items():
             pin = gpins[0][i] if kind == 'g' else gpins[1][i]
             mine = np.asarray(mine, np.float32)
-            same = mine == pin
+            # (as tests/pinning.py:store_agreement: an element that is noise against its tensor -- a channel whose gradients are all masked
+            # has c1 = c2 = rounding noise, its dX values are 1e-12 on a tensor of 1e-2 and their bfloat16 neighbours are arbitrary --
+            # counts as agreeing; round 6 met one on the MI355X once the data gradients ran on bf16 MFMA, tools/bf16_agreement.py)
+            same = (mine == pin) | (np.abs(mine - pin) <= np.float32(2e-6) * np.abs(pin).max())
             bound = np.maximum(np.abs(pin) * np.float32(2.0 ** -7), np.float32(2e-5) * np.abs(pin).max())
             assert same.mean() >= 0.995 and (np.abs(mine - pin)[~same] <= bound[~same]).all(), (kind, i, float(same.mean()))
     if store is not None:
