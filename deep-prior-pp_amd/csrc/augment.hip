@@ -599,6 +599,66 @@ __device__ __forceinline__ float4 aug_warp_quad(const AugRec& r, const float* __
     return make_float4(out[0], out[1], out[2], out[3]);
 }
 
+// aug_warp_quad in two halves, for a pixel pass that keeps MANY gathers in flight (round 6): the source element index of each of the
+// four pixels (-1: outside the crop, BORDER_CONSTANT 0) -- the same integer / float64 expressions as aug_warp_quad --, and the value
+// rules applied to the gathered elements.  Bit-identical to aug_warp_quad by construction (tests: nbad == 0 in every mode).
+__device__ __forceinline__ void aug_quad_index(const AugRec& r, int dsz, int x, int y, int (&idx)[4]) {
+    long long X[4], Y[4];
+    if (r.warp == WARP_AFFINE) {
+        const long long X0 = cv_round((r.m[1] * (double)y + r.m[2]) * 1024.) + 512;
+        const long long Y0 = cv_round((r.m[4] * (double)y + r.m[5]) * 1024.) + 512;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long ad = cv_round(r.m[0] * (double)(x + j) * 1024.), bd = cv_round(r.m[3] * (double)(x + j) * 1024.);
+            X[j] = (X0 + ad) >> 10; Y[j] = (Y0 + bd) >> 10;
+        }
+    } else {
+        const int bx = (x >> 6) << 6;
+        const double fbx = (double)bx, fy_ = (double)y;
+        const double X0 = r.m[0] * fbx + r.m[1] * fy_ + r.m[2];
+        const double Y0 = r.m[3] * fbx + r.m[4] * fy_ + r.m[5];
+        const double W0 = r.m[6] * fbx + r.m[7] * fy_ + r.m[8];
+        const bool unit_w = r.m[6] == 0.0 && r.m[7] == 0.0 && r.m[8] == 1.0;          // see aug_warp_quad
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double x1 = (double)(x + j - bx);
+            double Wv = 1.0;
+            if (!unit_w) {
+                Wv = W0 + r.m[6] * x1;
+                Wv = (Wv != 0.0) ? 1. / Wv : 0.;
+            }
+            const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + r.m[0] * x1) * Wv));
+            const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + r.m[3] * x1) * Wv));
+            long long Xj = cv_round(fX), Yj = cv_round(fY);
+            X[j] = Xj < -32768 ? -32768 : (Xj > 32767 ? 32767 : Xj);
+            Y[j] = Yj < -32768 ? -32768 : (Yj > 32767 ? 32767 : Yj);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) idx[j] = (X[j] >= 0 && X[j] < dsz && Y[j] >= 0 && Y[j] < dsz) ? (int)Y[j] * dsz + (int)X[j] : -1;
+}
+
+__device__ __forceinline__ float4 aug_quad_value(const AugRec& r, const float (&raw)[4], const int (&idx)[4]) {
+    float out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = idx[j] >= 0 ? raw[j] * r.den_scale + r.den_off : 0.0f;
+        if (r.thresh) {
+            if (fabs((double)v - 32000.0) <= 1e-8 + 1e-5 * 32000.0) v = 0.0f;     // numpy.isclose(warped, nv_val)
+            if (v < r.zlo && v != 0.0f) v = r.zlo;
+            else if (v > r.zhi && v != 0.0f) v = 0.0f;
+        }
+        if (v == r.premax) v = r.far_v;
+        if (v == 0.0f) v = r.far_v;
+        if (v >= r.far_v) v = r.far_v;
+        if (v <= r.near_v) v = r.near_v;
+        v = (v - r.norm_off) / r.norm_div;
+        if (r.binarize) v = v < 0.5f ? 0.0f : 1.0f;
+        out[j] = v;
+    }
+    return make_float4(out[0], out[1], out[2], out[3]);
+}
+
 __global__ __launch_bounds__(DPP_THREADS) void augment_warp_kernel(const float* __restrict__ img, const AugRec* __restrict__ rec, int dsz,
                                                                    float* __restrict__ out) {
     const int b = blockIdx.y;
@@ -716,10 +776,39 @@ __global__ __launch_bounds__(DPP_THREADS) void augment_fused_kernel(PrepArgs a, 
     dpp_stamp(a.prof, 3);                              // labels + projection (split 0, wave 0)
     const AugRec r = s_rec;
     float* o = out_x + (size_t)b * npix;
-    for (int q = q0 + t; q < q1; q += nt) {
-        const int p = split * chunk + q * 4;
-        const int y = p / a.dsz, x = p - y * a.dsz;
-        *reinterpret_cast<float4*>(o + p) = aug_warp_quad(r, im, a.dsz, x, y);        // p, dsz multiples of 4: x % 4 == 0
+    if (r.warp == WARP_NONE) {
+        for (int q = q0 + t; q < q1; q += nt) {
+            const int p = split * chunk + q * 4;
+            const int y = p / a.dsz, x = p - y * a.dsz;
+            *reinterpret_cast<float4*>(o + p) = aug_warp_quad(r, im, a.dsz, x, y);        // p, dsz multiples of 4: x % 4 == 0
+        }
+    } else {
+        // Round 6: the gathers of AUG_NB quads (24 pixels) of a thread are all issued before the first is used.  One quad per iteration
+        // made the pass 5-6 dependent round trips to the L2 per thread (the indices of an iteration need the float64 map, its four
+        // gathers were consumed on the spot): 12-15 us per workgroup (tools/augment_phase.py) for 64 KB of pixels.  Unconditional
+        // loads (pixels outside the source crop and the lanes past the end read element 0 and are masked afterwards): a branch
+        // between a load and its use would drain the queue again.
+        constexpr int AUG_NB = 6;
+        for (int q = q0 + t; q < q1; q += AUG_NB * nt) {
+            int idx[AUG_NB][4];
+            float raw[AUG_NB][4];
+#pragma unroll
+            for (int u = 0; u < AUG_NB; ++u) {
+                const int qq = q + u * nt;
+                const int p = split * chunk + (qq < q1 ? qq : q) * 4;
+                const int y = p / a.dsz, x = p - y * a.dsz;
+                aug_quad_index(r, a.dsz, x, y, idx[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < AUG_NB; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw[u][j] = im[idx[u][j] >= 0 ? idx[u][j] : 0];
+#pragma unroll
+            for (int u = 0; u < AUG_NB; ++u) {
+                const int qq = q + u * nt;
+                if (qq < q1) *reinterpret_cast<float4*>(o + split * chunk + qq * 4) = aug_quad_value(r, raw[u], idx[u]);
+            }
+        }
     }
     dpp_stamp(a.prof, 4);
     aug_take_ticket(counter_rw, ticket);

@@ -1014,6 +1014,232 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16_kernel(GemmArgs ga)
     }
 }
 
+// ---- the same stream with the product TRANSPOSED in the accumulators (round 6) ----------------------------------------------------
+// gemm_stream16_kernel keeps the MFMA D layout of a [pixels][channels] product: a lane holds ONE channel of four pixel rows, so its
+// epilogue touches memory 4 bytes per lane -- 2 bytes on bf16-stored tensors: a store instruction of the wave moves 128 bytes.  At
+// 128 x 128 input the tensors sit in the Infinity Cache and that is hidden (5 TB/s); at 256 x 256 (BASELINE config 5) the kernel runs at
+// 2.1 TB/s of its algorithmic bytes, bound by the number of memory instructions, not by bytes.
+// Here the operands swap places: D^T[channel][pixel] = sum_k W[channel][k] * act(X)[pixel][k] -- the filter fragment is the A operand,
+// the pixel fragment (the same 16-byte load of row `l15`) the B operand -- and the D layout gives lane (pixel l15, kq) the FOUR
+// CONSECUTIVE channels 4 kq .. 4 kq + 3 of its pixel: bias, residual, BatchNorm input and output are 16-byte (f32) / 8-byte (bf16)
+// accesses, 16 pixels x 64 (32) bytes contiguous per instruction, with no LDS image and no 4 x 4 feeding order.  Column sums: over
+// the tiles in registers, over the 16 pixel lanes by xor shuffles, over the waves through LDS (fixed order).
+template <int KT, int CN, bool BKC, int TPW, bool ACT, bool EPI, bool ST = false, bool PB = false>
+__global__ __launch_bounds__(DPP_THREADS) void gemm_stream16t_kernel(GemmArgs ga) {
+    dpp_kernarg_warm<sizeof(GemmArgs)>();
+    const dpp_gemm_desc& d = ga.d;
+    constexpr int G = KT / 16, N = 16 * CN;
+    __shared__ __attribute__((aligned(16))) float red[4 * N];
+    constexpr int ROWS = 64 * TPW;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int wrow0 = blockIdx.x * ROWS + wave * 16 * TPW;
+    const dpp_epilogue& ep = d.epi;
+    const bool bn = EPI && ep.bn_x != nullptr;
+    const int modeA = ACT ? d.actA.mode : 0;
+    const bool c16 = ST && (d.store & DPP_ST_C) != 0, x16 = ST && (d.store & DPP_ST_BNX) != 0;
+
+    // ---- every load up front: filter fragments (lane (i, kq): filter row = output channel ct * 16 + i, k = 16 g + 4 kq ..), pixel rows ----
+    float4 bw[G][CN];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            if (BKC) bw[g][ct] = *reinterpret_cast<const float4*>(d.B + (size_t)(ct * 16 + l15) * d.ldb + g * 16 + kq * 4);
+            else {
+                const float* pb = d.B + (size_t)(g * 16 + kq * 4) * d.ldb + ct * 16 + l15;
+                bw[g][ct] = make_float4(pb[0], pb[d.ldb], pb[2 * (size_t)d.ldb], pb[3 * (size_t)d.ldb]);
+            }
+        }
+    float4 ra[TPW][G];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        if (ST && ga.shA) {
+            const float* pa = d.A + (((size_t)(wrow0 + t * 16 + l15) * d.lda + kq * 4) >> 1);
+#pragma unroll
+            for (int g = 0; g < G; ++g) ra[t][g] = dpp_raw8(pa + g * 8);
+        } else {
+            const float* pa = d.A + (size_t)(wrow0 + t * 16 + l15) * d.lda + kq * 4;
+#pragma unroll
+            for (int g = 0; g < G; ++g) ra[t][g] = *reinterpret_cast<const float4*>(pa + g * 16);
+        }
+    }
+    float4 mu[G], sc[G], be[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        mu[g] = sc[g] = be[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (modeA & 2) {
+            mu[g] = *reinterpret_cast<const float4*>(d.actA.mean + g * 16 + kq * 4);
+            sc[g] = *reinterpret_cast<const float4*>(d.actA.scale + g * 16 + kq * 4);
+            be[g] = *reinterpret_cast<const float4*>(d.actA.beta + g * 16 + kq * 4);
+        }
+    }
+    // per-channel vectors of this lane's quad (channels ct * 16 + 4 kq ..), residual / BatchNorm input of its output elements
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cb[CN], cmean[CN], cscale[CN], cbeta[CN], cistd[CN];
+#pragma unroll
+    for (int ct = 0; ct < CN; ++ct) {
+        const int c0 = ct * 16 + kq * 4;
+        cb[ct] = d.bias ? *reinterpret_cast<const float4*>(d.bias + c0) : z4;
+        cmean[ct] = bn ? *reinterpret_cast<const float4*>(ep.bn_mean + c0) : z4;
+        cscale[ct] = bn ? *reinterpret_cast<const float4*>(ep.bn_scale + c0) : z4;
+        cbeta[ct] = bn ? *reinterpret_cast<const float4*>(ep.bn_beta + c0) : z4;
+        cistd[ct] = bn ? *reinterpret_cast<const float4*>(ep.bn_inv_std + c0) : z4;
+    }
+    float4 xr[TPW][CN], rr[TPW][CN];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            const size_t o = (size_t)(wrow0 + t * 16 + l15) * d.ldc + ct * 16 + kq * 4;
+            xr[t][ct] = bn ? dpp_ld4_rt(ep.bn_x, o, x16) : z4;
+            rr[t][ct] = (EPI && d.residual) ? dpp_ld4_rt(d.residual, o, c16) : z4;
+        }
+
+    float4 vals[TPW][CN];
+    float4 sx[CN], sy[CN];
+#pragma unroll
+    for (int ct = 0; ct < CN; ++ct) { sx[ct] = z4; sy[ct] = z4; }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        f32x4 acc[CN];
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 va[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float4 v = (ST && ga.shA) ? dpp_widen4(ra[t][g]) : ra[t][g];
+            if (modeA & 2) {
+                v.x = dpp_fma(v.x - mu[g].x, sc[g].x, be[g].x); v.y = dpp_fma(v.y - mu[g].y, sc[g].y, be[g].y);
+                v.z = dpp_fma(v.z - mu[g].z, sc[g].z, be[g].z); v.w = dpp_fma(v.w - mu[g].w, sc[g].w, be[g].w);
+            }
+            if (modeA & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            va[g] = v;
+        }
+        if constexpr (PB) {
+#pragma unroll
+            for (int h = 0; h < (G + 1) / 2; ++h) {
+                const float4 a0 = va[2 * h], a1 = (2 * h + 1 < G) ? va[(2 * h + 1 < G) ? 2 * h + 1 : 0] : z4;
+                dpp_bf16x8 af;
+                af[0] = (dpp_bf16)a0.x; af[1] = (dpp_bf16)a0.y; af[2] = (dpp_bf16)a0.z; af[3] = (dpp_bf16)a0.w;
+                af[4] = (dpp_bf16)a1.x; af[5] = (dpp_bf16)a1.y; af[6] = (dpp_bf16)a1.z; af[7] = (dpp_bf16)a1.w;
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    const float4 b0 = bw[2 * h][ct], b1 = (2 * h + 1 < G) ? bw[(2 * h + 1 < G) ? 2 * h + 1 : 0][ct] : z4;
+                    dpp_bf16x8 bf;
+                    bf[0] = (dpp_bf16)b0.x; bf[1] = (dpp_bf16)b0.y; bf[2] = (dpp_bf16)b0.z; bf[3] = (dpp_bf16)b0.w;
+                    bf[4] = (dpp_bf16)b1.x; bf[5] = (dpp_bf16)b1.y; bf[6] = (dpp_bf16)b1.z; bf[7] = (dpp_bf16)b1.w;
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af, acc[ct], 0, 0, 0);      // filter rows x pixel columns
+                }
+            }
+        } else
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const float4 v = va[g];
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].x, v.x, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].y, v.y, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].z, v.z, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].w, v.w, acc[ct], 0, 0, 0);
+            }
+        }
+        // D^T layout: this lane holds channels ct * 16 + 4 kq + r (r = 0 .. 3) of pixel row wrow0 + 16 t + l15
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            const size_t o = (size_t)(wrow0 + t * 16 + l15) * d.ldc + ct * 16 + kq * 4;
+            float v[4] = {acc[ct][0] + cb[ct].x + rr[t][ct].x, acc[ct][1] + cb[ct].y + rr[t][ct].y, acc[ct][2] + cb[ct].z + rr[t][ct].z,
+                          acc[ct][3] + cb[ct].w + rr[t][ct].w};
+            if (bn) {
+                const float dx[4] = {xr[t][ct].x - cmean[ct].x, xr[t][ct].y - cmean[ct].y, xr[t][ct].z - cmean[ct].z, xr[t][ct].w - cmean[ct].w};
+                const float cs[4] = {cscale[ct].x, cscale[ct].y, cscale[ct].z, cscale[ct].w}, cbt[4] = {cbeta[ct].x, cbeta[ct].y, cbeta[ct].z, cbeta[ct].w};
+                const float ci[4] = {cistd[ct].x, cistd[ct].y, cistd[ct].z, cistd[ct].w};
+                float sxa[4] = {sx[ct].x, sx[ct].y, sx[ct].z, sx[ct].w}, sya[4] = {sy[ct].x, sy[ct].y, sy[ct].z, sy[ct].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (ep.bn_relu && dx[r] * cs[r] + cbt[r] < 0.0f) v[r] = 0.0f;
+                    if (c16) v[r] = dpp_bf16_round(v[r]);            // bf16-stored gradient: sums of the values as stored
+                    sxa[r] += v[r];
+                    sya[r] += v[r] * (dx[r] * ci[r]);
+                }
+                sx[ct] = make_float4(sxa[0], sxa[1], sxa[2], sxa[3]);
+                sy[ct] = make_float4(sya[0], sya[1], sya[2], sya[3]);
+            }
+            const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
+            if (c16) dpp_st4(reinterpret_cast<dpp_bf16*>(d.C) + o, v4); else *reinterpret_cast<float4*>(d.C + o) = v4;
+            vals[t][ct] = v4;
+        }
+    }
+    // ---- column sums: the 16 pixel lanes of a quad by xor shuffles, the four waves through LDS in wave order ----
+    auto colsum = [&](float4 (&s)[CN]) {
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s[ct].x += __shfl_xor(s[ct].x, o); s[ct].y += __shfl_xor(s[ct].y, o);
+                s[ct].z += __shfl_xor(s[ct].z, o); s[ct].w += __shfl_xor(s[ct].w, o);
+            }
+        }
+        __syncthreads();
+        if (l15 == 0) {
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) *reinterpret_cast<float4*>(&red[wave * N + ct * 16 + kq * 4]) = s[ct];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            float4 t = *reinterpret_cast<const float4*>(&red[ct * 16 + kq * 4]);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const float4 u = *reinterpret_cast<const float4*>(&red[w * N + ct * 16 + kq * 4]);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            s[ct] = t;
+        }
+    };
+    auto put = [&](float* dst, int which, const float4 (&s)[CN]) {
+        if (wave == 0 && l15 == 0) {
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                const int c0 = ct * 16 + kq * 4;
+                dst[dpp_partial_index(which, c0 + 0, blockIdx.x, N, gridDim.x)] = s[ct].x;
+                dst[dpp_partial_index(which, c0 + 1, blockIdx.x, N, gridDim.x)] = s[ct].y;
+                dst[dpp_partial_index(which, c0 + 2, blockIdx.x, N, gridDim.x)] = s[ct].z;
+                dst[dpp_partial_index(which, c0 + 3, blockIdx.x, N, gridDim.x)] = s[ct].w;
+            }
+        }
+    };
+    if (bn && ep.bn_partial != nullptr) {
+        colsum(sx);
+        colsum(sy);
+        put(ep.bn_partial, 0, sx);
+        put(ep.bn_partial, 1, sy);
+    }
+    if (ep.stats != nullptr) {
+        float4 sm[CN], m2[CN];
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            sm[ct] = z4;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) { sm[ct].x += vals[t][ct].x; sm[ct].y += vals[t][ct].y; sm[ct].z += vals[t][ct].z; sm[ct].w += vals[t][ct].w; }
+        }
+        colsum(sm);
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            const float inv = 1.0f / (float)ROWS;
+            sm[ct].x *= inv; sm[ct].y *= inv; sm[ct].z *= inv; sm[ct].w *= inv;
+            m2[ct] = z4;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const float a0 = vals[t][ct].x - sm[ct].x, a1 = vals[t][ct].y - sm[ct].y, a2 = vals[t][ct].z - sm[ct].z, a3 = vals[t][ct].w - sm[ct].w;
+                m2[ct].x += a0 * a0; m2[ct].y += a1 * a1; m2[ct].z += a2 * a2; m2[ct].w += a3 * a3;
+            }
+        }
+        colsum(m2);
+        put(ep.stats, 0, sm);
+        put(ep.stats, 1, m2);
+    }
+}
+
 // dpp_gemm variant 3: rows per workgroup of gemm_stream16_kernel for this problem (K = 64 -> 16 columns: 128; K = 16 -> 64 columns:
 // 64), or 0 when the kernel does not take it
 static int stream16_rows(const dpp_gemm_desc& d, const GemmArgs& ga) {
@@ -1098,7 +1324,13 @@ int gemm_dispatch(GemmArgs& ga, int bm, int bn, int wm, hipStream_t st) {
         const int rows = stream16_rows(d, ga);
         if (!rows) return DPP_E_UNSUPPORTED;
         const bool act = d.actA.mode != 0, epi = d.residual != nullptr || d.epi.bn_x != nullptr;
-#define DPP_S16(K_, CN_, T_, B_, A_, E_) DPP_LAUNCH((gemm_stream16_kernel<K_, CN_, B_, T_, A_, E_, ST, PB>), dim3(d.M / rows), dim3(DPP_THREADS), 0, st, ga)
+        // the transposed-accumulator form (16- / 8-byte epilogue accesses) needs aligned quads everywhere; DPP_STREAM16T=0: the round-2 kernel
+        static const bool s16t_on = []() { const char* e = getenv("DPP_STREAM16T"); return !(e && e[0] == '0'); }();
+        auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        const bool s16t = s16t_on && d.ldc % 4 == 0 && al16(d.C) && al16(d.residual) && al16(d.bias) && al16(d.epi.bn_x) && al16(d.epi.bn_mean) &&
+                          al16(d.epi.bn_scale) && al16(d.epi.bn_beta) && al16(d.epi.bn_inv_std);
+#define DPP_S16(K_, CN_, T_, B_, A_, E_) do { if (s16t) DPP_LAUNCH((gemm_stream16t_kernel<K_, CN_, B_, T_, A_, E_, ST, PB>), dim3(d.M / rows), dim3(DPP_THREADS), 0, st, ga); \
+            else DPP_LAUNCH((gemm_stream16_kernel<K_, CN_, B_, T_, A_, E_, ST, PB>), dim3(d.M / rows), dim3(DPP_THREADS), 0, st, ga); } while (0)
 #define DPP_S16_ALL(K_, CN_, T_) \
         if (d.b_kc) { if (act) { if (epi) DPP_S16(K_, CN_, T_, true, true, true); else DPP_S16(K_, CN_, T_, true, true, false); } \
                       else { if (epi) DPP_S16(K_, CN_, T_, true, false, true); else DPP_S16(K_, CN_, T_, true, false, false); } } \
