@@ -57,7 +57,7 @@ def csrc_sha16():
 
 # environment variables that select a measured configuration through a command-line flag of this script (recorded in `config` by
 # that flag) or plumbing; every other DPP_* variable is an experiment / opt-in knob and is stamped into config.knobs
-PLUMBING_ENV = ('DPP_LAUNCH_MODE', 'DPP_BF16', 'DPP_DIST_BACKEND', 'DPP_BENCH_EMU', 'DPP_TEST_WORKERS')
+PLUMBING_ENV = ('DPP_LAUNCH_MODE', 'DPP_BF16', 'DPP_DIST_BACKEND', 'DPP_BENCH_EMU', 'DPP_TEST_WORKERS', 'DPP_ALLREDUCE')
 ABLATION_ENV = ('DPP_WHATIF_SKIP',)            # drops launches from the timed plan: results are wrong on purpose
 
 
@@ -687,6 +687,23 @@ def main():
         if dist.get_backend() == 'nccl' and len(set(dist_info['devices'])) != world:
             raise SystemExit('bench.py: %d RCCL ranks on %d distinct GPUs (%s): one rank per GPU is the contract' % (
                 world, len(set(dist_info['devices'])), dist_info['devices']))
+    # how much of the step the main stream stood still for the gradient exchange (round 6): ten MORE steps, after the timed region,
+    # with an event pair around every join with a collective (an event is a marker packet: not something the timed steps carry)
+    exposed_ms = 0.0
+    if dp is not None and not emu:
+        dp.measure_exposed = True
+        for _ in range(10):
+            step()
+        sync_dev()
+        exposed_ms = dp.exposed_ms() / 10.0
+        dp.measure_exposed = False
+    seg = step_plans[0][1].segment_counts() if hasattr(step_plans[0][1], 'segment_counts') else (1, 0)
+    dist_info.update(allreduce_ms_exposed=[round(exposed_ms, 4)], launch_segments_per_step=seg[0], host_issued_collectives_per_step=seg[1],
+                     allreduce_schedule=getattr(dp, 'schedule', None))
+    if dist is not None:
+        rows = [None] * world
+        dist.all_gather_object(rows, round(exposed_ms, 4))
+        dist_info['allreduce_ms_exposed'] = rows
     cost = float(eng.cost.get()[0])
     ms = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed

@@ -1327,7 +1327,9 @@ int gemm_dispatch(GemmArgs& ga, int bm, int bn, int wm, hipStream_t st) {
         // the transposed-accumulator form (16- / 8-byte epilogue accesses) needs aligned quads everywhere; DPP_STREAM16T=0: the round-2 kernel
         static const bool s16t_on = []() { const char* e = getenv("DPP_STREAM16T"); return !(e && e[0] == '0'); }();
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        const bool s16t = s16t_on && d.ldc % 4 == 0 && al16(d.C) && al16(d.residual) && al16(d.bias) && al16(d.epi.bn_x) && al16(d.epi.bn_mean) &&
+        // ... and pays on bf16-stored tensors only: same-box A/B of the float32 128 x 128 step 3.462 / 3.465 (transposed) against 3.449 /
+        // 3.452 ms (its 4-byte accesses were not the bound there), bf16 256 x 256 7.452 / 7.535 against 7.550 / 7.561 (profiles/r06_ab.txt)
+        const bool s16t = s16t_on && ST && (d.store & (DPP_ST_A | DPP_ST_C | DPP_ST_BNX)) != 0 && d.ldc % 4 == 0 && al16(d.C) && al16(d.residual) && al16(d.bias) && al16(d.epi.bn_x) && al16(d.epi.bn_mean) &&
                           al16(d.epi.bn_scale) && al16(d.epi.bn_beta) && al16(d.epi.bn_inv_std);
 #define DPP_S16(K_, CN_, T_, B_, A_, E_) do { if (s16t) DPP_LAUNCH((gemm_stream16t_kernel<K_, CN_, B_, T_, A_, E_, ST, PB>), dim3(d.M / rows), dim3(DPP_THREADS), 0, st, ga); \
             else DPP_LAUNCH((gemm_stream16_kernel<K_, CN_, B_, T_, A_, E_, ST, PB>), dim3(d.M / rows), dim3(DPP_THREADS), 0, st, ga); } while (0)

@@ -188,6 +188,18 @@ class Plan(object):
         self._compiled = (key, segs)
         return segs
 
+    def segment_counts(self):
+        """(native launch segments, host-issued steps) of this plan: a step that is not a kernel launch -- an RCCL collective -- ends the
+        native segment in front of it and is issued from Python between two dpp_plan_run calls."""
+        native, host, open_ = 0, 0, False
+        for op, _ in self.ops:
+            if isinstance(op, (Launch, Fork, Join)):
+                if not open_:
+                    native, open_ = native + 1, True
+            else:
+                host, open_ = host + 1, False
+        return native, host
+
     def run(self, rt_or_stream):
         """rt_or_stream: a runtime (multi-stream aware) or a raw stream handle (single stream, side ops inline)."""
         rt = rt_or_stream if hasattr(rt_or_stream, 'stream') else None

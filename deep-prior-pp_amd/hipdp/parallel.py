@@ -26,6 +26,17 @@ class CollectiveOp(object):
         self.fn()
 
 
+class _Works(object):
+    """Several asynchronous collectives as one work object."""
+
+    def __init__(self, works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class _SideJoin(object):
     """Stand-in for the work object of an asynchronous collective whose result was written on the side stream: wait() makes the
     current (main) stream wait for that stream."""
@@ -51,6 +62,20 @@ class DataParallel(object):
         # DPP_DIST_BACKEND=gloo): the collectives run on host copies.  Blocking, correct against the HIP streams (the device -> host
         # copy waits for the stream it is issued on), and nothing a measured run ever takes: bench.py insists on RCCL.
         self.host_staged = dist.get_backend() == 'gloo' and not getattr(rt, 'is_emulator', False)
+        # How a gradient bucket is summed (round 6: an A/B switch for the 8-GPU box, which this build never met):
+        #   DPP_ALLREDUCE=allreduce (default)  one all_reduce of the bucket -- RCCL picks ring / tree;
+        #   DPP_ALLREDUCE=rs_ag                reduce_scatter + all_gather on the flat buffer: every rank sums ONE 1/world slice of the
+        #                                      bucket (in place: its slice of the buffer is the output) and the slices are gathered
+        #                                      back -- the "direct" schedule of SURVEY.md section 5 (xGMI is point-to-point: 7 links per
+        #                                      GPU, a ring is bound by one link), the tail that does not divide by world goes through a
+        #                                      small all_reduce.  Same sums in another order of additions (float32: last bits).
+        self.schedule = os.environ.get('DPP_ALLREDUCE', 'allreduce')
+        if self.schedule not in ('allreduce', 'rs_ag'):
+            raise ValueError("DPP_ALLREDUCE must be 'allreduce' or 'rs_ag', got %r" % self.schedule)
+        # bench.py --gpus N: with measure_exposed set, every join with a collective is bracketed by two events on the main stream
+        # (exposed_events); their distance is the time the main stream stood still for the exchange
+        self.measure_exposed = False
+        self.exposed_events = []
 
     def _collective(self, fn, *bufs):
         """fn(*tensors) on the buffers -- directly (RCCL on device memory; gloo on the emulator's host memory) or on host copies that
@@ -64,8 +89,48 @@ class DataParallel(object):
             t.copy_(h)
         return out
 
+    def _sum_tensor(self, t, async_op=False):
+        """Sum tensor t (flat, float32) over the ranks in place by the configured schedule; returns a work object when async_op."""
+        dist = self.dist
+        if self.schedule == 'allreduce':
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+        flat = t.view(-1)
+        n, G = flat.numel(), self.world
+        per = n // G
+        m = per * G
+        rccl = dist.get_backend() == 'nccl'
+        # RCCL orders the collectives of a communicator on its stream, so the three may be queued back to back (and reduce in place: a
+        # rank's output is its own slice of the input).  The host backend of the tests has no such order: blocking calls on copies.
+        queued = async_op and rccl
+        works = []
+        if per:
+            mine = flat[self.rank * per:(self.rank + 1) * per]
+            works.append(dist.reduce_scatter_tensor(mine, flat[:m] if rccl else flat[:m].clone(), op=dist.ReduceOp.SUM, async_op=queued))
+            works.append(dist.all_gather_into_tensor(flat[:m], mine if rccl else mine.clone(), async_op=queued))
+        if n > m:
+            works.append(dist.all_reduce(flat[m:], op=dist.ReduceOp.SUM, async_op=queued))
+        return _Works(works if queued else []) if async_op else None
+
+    def _bracket(self, fn):
+        """fn() between two events on the main stream when the exposed time of the exchanges is being measured."""
+        if not self.measure_exposed or not hasattr(self.rt, 'torch'):
+            return fn()
+        tc = self.rt.torch.cuda
+        e0, e1 = tc.Event(enable_timing=True), tc.Event(enable_timing=True)
+        e0.record(tc.current_stream())
+        out = fn()
+        e1.record(tc.current_stream())
+        self.exposed_events.append((e0, e1))
+        return out
+
+    def exposed_ms(self):
+        """Sum of the bracketed intervals since the last call (synchronise the device first)."""
+        ms = sum(a.elapsed_time(b) for a, b in self.exposed_events)
+        self.exposed_events = []
+        return ms
+
     def allreduce_sum_op(self, buf, name='allreduce_sum'):
-        return CollectiveOp(lambda: self._collective(lambda t: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM), buf), name)
+        return CollectiveOp(lambda: self._bracket(lambda: self._collective(lambda t: self._sum_tensor(t), buf)), name)
 
     def allreduce_sum_async_op(self, buf, handle, name='allreduce_sum_async'):
         """Start summing `buf` over the ranks WITHOUT blocking the stream the step continues on: issued from the side
@@ -79,23 +144,23 @@ class DataParallel(object):
             if self.host_staged:
                 if two:
                     with self.rt.torch.cuda.stream(side):
-                        self._collective(lambda h: self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM), buf)
+                        self._collective(lambda h: self._sum_tensor(h), buf)
                     handle[0] = _SideJoin(self.rt)
                 else:
-                    self._collective(lambda h: self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM), buf)
+                    self._collective(lambda h: self._sum_tensor(h), buf)
                     handle[0] = None
             elif two:
                 with self.rt.torch.cuda.stream(side):
-                    handle[0] = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
+                    handle[0] = self._sum_tensor(t, async_op=True)
             else:
-                handle[0] = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
+                handle[0] = self._sum_tensor(t, async_op=True)
         return CollectiveOp(start, name)
 
     def wait_op(self, handle, name='allreduce_wait'):
         """The current (main) stream waits for the collective started by allreduce_sum_async_op."""
         def wait():
             if handle[0] is not None:
-                handle[0].wait()
+                self._bracket(handle[0].wait)
                 handle[0] = None
         return CollectiveOp(wait, name)
 

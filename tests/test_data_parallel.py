@@ -80,6 +80,36 @@ def test_local_bn_replicas_stay_identical(tmp_path):
     assert not np.array_equal(r0['bn_mean'], r1['bn_mean'])            # per-GPU running statistics differ by design
 
 
+def test_reduce_scatter_all_gather_schedule_equals_the_all_reduce(tmp_path):
+    """DPP_ALLREDUCE=rs_ag (round 6): the gradient buckets summed by reduce_scatter + all_gather on the flat
+    buffer (+ an all_reduce of the tail that does not divide by the world size) -- two gloo ranks on the emulator: both ranks hold the
+    same gradient, and it is the all_reduce schedule's gradient up to the order of two additions (with two ranks: the same bits)."""
+    a0, a1 = _run_ranks(tmp_path, sync=False)
+    sub = tmp_path / 'rs_ag'
+    sub.mkdir()
+    b0, b1 = _run_ranks(sub, sync=False, DPP_ALLREDUCE='rs_ag')
+    n = 0
+    for k in a0.files:
+        if k.startswith('g_') or k == 'w_last':
+            assert np.array_equal(b0[k], b1[k]), k
+            assert np.array_equal(a0[k], b0[k]), k            # two ranks: a + b in either schedule
+            n += 1
+    assert n > 50 and float(a0['cost'][0]) == float(b0['cost'][0])
+
+
+@pytest.mark.gpu
+def test_rccl_world_of_one_reduce_scatter_all_gather_schedule(tmp_path):
+    """The same switch through RCCL on the MI355X with a world of one: in-place reduce_scatter / all_gather of the early FC1 bucket
+    started from the side stream, their wait, the second bucket -- identities that must leave gradients and weights bit-identical to the
+    all_reduce schedule (what is tested is their ordering against the engine's two HIP streams)."""
+    (a,) = _run_ranks(tmp_path, sync=False, world=1, wd=1e-3, DPP_WORKER_BACKEND='nccl', DPP_WORKER_BATCH='8')
+    sub = tmp_path / 'rs_ag'
+    sub.mkdir()
+    (b,) = _run_ranks(sub, sync=False, world=1, wd=1e-3, DPP_WORKER_BACKEND='nccl', DPP_WORKER_BATCH='8', DPP_ALLREDUCE='rs_ag')
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('sync', [False, True])
 def test_rccl_world_of_one_equals_single_process(tmp_path, sync):
