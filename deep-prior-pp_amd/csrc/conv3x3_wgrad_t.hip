@@ -211,11 +211,15 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
         }
     };
 
-    f32x4 acc[TPB];
+    // 16 channels: the waves split the row groups of a tile (and meet at the end); 32 channels: a wave owns one (o, c) tile; 64 channels
+    // (the 16-wide maps of stages 3-4 at 256 x 256 input): a wave owns the four (o = wave, c) tiles
+    constexpr int NTC = C == 64 ? 4 : 1;
+    f32x4 acc[TPB][NTC];
 #pragma unroll
-    for (int t = 0; t < TPB; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // 16 channels: the waves split the row groups of a tile (and meet at the end); 32 channels: a wave owns one (o, c) tile
-    const int to = C == 16 ? 0 : (wave >> 1), tc = C == 16 ? 0 : (wave & 1);
+    for (int t = 0; t < TPB; ++t)
+#pragma unroll
+        for (int n = 0; n < NTC; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int to = C == 16 ? 0 : (C == 32 ? (wave >> 1) : wave), tc0 = C == 32 ? (wave & 1) : 0;
     const int tap0 = blockIdx.y * TPB;
     const int dy0 = TPB == 9 ? 0 : tap0 / 3;                  // first halo row offset of the taps this workgroup owns
     const int dx0 = TPB == 1 ? tap0 % 3 : 0;
@@ -233,7 +237,9 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
             for (int g = 0; g < NG; ++g) {
                 const int r = C == 16 ? wave + 4 * g : g;     // tile row of this group
                 const float4 av = *reinterpret_cast<const float4*>(Yt + (to * 16 + l15) * W3_CPY + r * W3_TW + 4 * kq);
-                const float* xb = Xt + (tc * 16 + l15) * W3_CPX + (r + dy0) * W3_RP + 4 + 4 * kq;
+#pragma unroll
+                for (int n = 0; n < NTC; ++n) {
+                const float* xb = Xt + ((tc0 + n) * 16 + l15) * W3_CPX + (r + dy0) * W3_RP + 4 + 4 * kq;
 #pragma unroll
                 for (int dyi = 0; dyi < (TPB == 9 ? 3 : 1); ++dyi) {
                     const float* b = xb + dyi * W3_RP;
@@ -243,16 +249,17 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float bv = dx0 == 1 ? w3_get(b0, e) : (dx0 == 0 ? w3_tapval(b0, bm1, bp4, 0, e) : w3_tapval(b0, bm1, bp4, 2, e));
-                            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3_get(av, e), bv, acc[0], 0, 0, 0);
+                            acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3_get(av, e), bv, acc[0][n], 0, 0, 0);
                         }
                     } else {
 #pragma unroll
                         for (int dxi = 0; dxi < 3; ++dxi)
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
-                                acc[dyi * 3 + dxi] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3_get(av, e), w3_tapval(b0, bm1, bp4, dxi, e),
-                                                                                          acc[dyi * 3 + dxi], 0, 0, 0);
+                                acc[dyi * 3 + dxi][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3_get(av, e), w3_tapval(b0, bm1, bp4, dxi, e),
+                                                                                             acc[dyi * 3 + dxi][n], 0, 0, 0);
                     }
+                }
                 }
             }
         } else {
@@ -262,7 +269,9 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
             for (int g = 0; g < NG; ++g) {
                 const int r = (C == 16 ? 2 * wave : 2 * g) + (kq >> 1), xo = 8 * (kq & 1);
                 const w3_u32x4 av = *reinterpret_cast<const w3_u32x4*>(Yb + (to * 16 + l15) * W3_CPYB + r * W3_TW + xo);
-                const unsigned short* xb = Xb + (tc * 16 + l15) * W3_CPXB + (r + dy0) * W3_RPB + 8 + xo;
+#pragma unroll
+                for (int n = 0; n < NTC; ++n) {
+                const unsigned short* xb = Xb + ((tc0 + n) * 16 + l15) * W3_CPXB + (r + dy0) * W3_RPB + 8 + xo;
 #pragma unroll
                 for (int dyi = 0; dyi < (TPB == 9 ? 3 : 1); ++dyi) {
                     const unsigned short* b = xb + dyi * W3_RPB;
@@ -270,15 +279,16 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
                     const unsigned lo = b[-1], hi = b[8];
                     if (TPB == 1) {
                         const w3_u32x4 bv = dx0 == 1 ? b0 : (dx0 == 0 ? w3_shift8(b0, lo, hi, 0) : w3_shift8(b0, lo, hi, 2));
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dpp_bf16x8, av), __builtin_bit_cast(dpp_bf16x8, bv), acc[0], 0, 0, 0);
+                        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dpp_bf16x8, av), __builtin_bit_cast(dpp_bf16x8, bv), acc[0][n], 0, 0, 0);
                     } else {
 #pragma unroll
                         for (int dxi = 0; dxi < 3; ++dxi) {
                             const w3_u32x4 bv = w3_shift8(b0, lo, hi, dxi);
-                            acc[dyi * 3 + dxi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dpp_bf16x8, av), __builtin_bit_cast(dpp_bf16x8, bv),
-                                                                                         acc[dyi * 3 + dxi], 0, 0, 0);
+                            acc[dyi * 3 + dxi][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dpp_bf16x8, av), __builtin_bit_cast(dpp_bf16x8, bv),
+                                                                                            acc[dyi * 3 + dxi][n], 0, 0, 0);
                         }
                     }
+                }
                 }
             }
         }
@@ -290,34 +300,36 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
         __syncthreads();
         if (wave >= 2) {
 #pragma unroll
-            for (int t = 0; t < TPB; ++t) red[((wave - 2) * TPB + t) * 64 + lane] = acc[t];
+            for (int t = 0; t < TPB; ++t) red[((wave - 2) * TPB + t) * 64 + lane] = acc[t][0];
         }
         __syncthreads();
         if (wave < 2) {
 #pragma unroll
-            for (int t = 0; t < TPB; ++t) acc[t] += red[(wave * TPB + t) * 64 + lane];
+            for (int t = 0; t < TPB; ++t) acc[t][0] += red[(wave * TPB + t) * 64 + lane];
         }
         __syncthreads();
         if (wave == 1) {
 #pragma unroll
-            for (int t = 0; t < TPB; ++t) red[t * 64 + lane] = acc[t];
+            for (int t = 0; t < TPB; ++t) red[t * 64 + lane] = acc[t][0];
         }
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
-            for (int t = 0; t < TPB; ++t) acc[t] += red[t * 64 + lane];
+            for (int t = 0; t < TPB; ++t) acc[t][0] += red[t * 64 + lane];
         }
     }
-    if (C == 32 || wave == 0) {
+    if (C != 16 || wave == 0) {
         float* out = a.partial + (size_t)blockIdx.x * C * 9 * C;
 #pragma unroll
         for (int t = 0; t < TPB; ++t) {
             const int tap = tap0 + t;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = to * 16 + kq * 4 + r, c = tc * 16 + l15;
-                out[((size_t)o * 9 + tap) * C + c] = acc[t][r];
-            }
+            for (int n = 0; n < NTC; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = to * 16 + kq * 4 + r, c = (tc0 + n) * 16 + l15;
+                    out[((size_t)o * 9 + tap) * C + c] = acc[t][n][r];
+                }
         }
     }
 }
@@ -338,11 +350,23 @@ int w3t_launch_taps(const Wgrad3TArgs& a, int taps_pb, dim3 grid, size_t lds, bo
     return w3t_launch_typed<C, 1, PB>(a, grid, lds, x16, y16, st);
 }
 
+// 64 channels: one tap per workgroup; the float32 images are 96 KB (above the default 64 KB window: opt in per instantiation)
+template <bool PB>
+int w3t_launch_c64(const Wgrad3TArgs& a, dim3 grid, size_t lds, bool x16, bool y16, hipStream_t st) {
+#define DPP_W3T64(TX_, TY_) do { \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_t_kernel<64, 1, TX_, TY_, PB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        DPP_LAUNCH((conv3x3_wgrad_t_kernel<64, 1, TX_, TY_, PB>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
+    if (x16) { if (y16) DPP_W3T64(dpp_bf16, dpp_bf16); else DPP_W3T64(dpp_bf16, float); }
+    if (y16) DPP_W3T64(float, dpp_bf16);
+    DPP_W3T64(float, float);
+#undef DPP_W3T64
+}
+
 }  // namespace
 
 bool dpp_conv3x3_wgrad_t_ok(int N, int H, int W, int Ci, int Co, const dpp_act* act) {
     static const bool on = []() { const char* e = getenv("DPP_WGRAD3_T"); return !(e && e[0] == '0'); }();
-    if (!on || Ci != Co || (Ci != 16 && Ci != 32) || W < 12 || H < 4) return false;
+    if (!on || Ci != Co || (Ci != 16 && Ci != 32 && Ci != 64) || W < 12 || H < 4) return false;
     if ((long)N * H * W * Ci >= (1L << 31)) return false;                      // 32-bit element offsets inside the kernel
     if (act && ((act->mode & 4) || (act->mode && (act->cmod & 3)))) return false;
     return true;
@@ -360,6 +384,11 @@ int dpp_conv3x3_wgrad_t_launch(const float* X, int N, int H, int W, int C, const
     size_t lds = precision ? (size_t)C * (W3_CPXB + W3_CPYB) * 2 : (size_t)C * (W3_CPX + W3_CPY) * sizeof(float);
     const size_t red = C == 16 ? (size_t)2 * taps_pb * 64 * 16 : 0;
     if (lds < red) lds = red;
+    if (C == 64) {
+        // 4 x 4 (o, c) tiles of 9 taps: one tap per workgroup keeps the accumulators at four tiles per wave (and the grid at nblk x 9)
+        if (taps_pb != 1) return DPP_E_UNSUPPORTED;
+        return precision ? w3t_launch_c64<true>(a, grid, lds, x16, y16, st) : w3t_launch_c64<false>(a, grid, lds, x16, y16, st);
+    }
     if (precision) return C == 16 ? w3t_launch_taps<16, true>(a, taps_pb, grid, lds, x16, y16, st) : w3t_launch_taps<32, true>(a, taps_pb, grid, lds, x16, y16, st);
     return C == 16 ? w3t_launch_taps<16, false>(a, taps_pb, grid, lds, x16, y16, st) : w3t_launch_taps<32, false>(a, taps_pb, grid, lds, x16, y16, st);
 }

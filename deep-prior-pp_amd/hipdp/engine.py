@@ -1309,7 +1309,10 @@ class CompiledNet(object):
                 emit_param_grads(dY_keep, None)               # after the data gradient, which wrote dY_keep
         else:
             bm = 64
-            rpw = hz.wgrad3_stream_rows(N * Hi * Wi, Ci) if Ci == Co else 0
+            # bf16 mode: both operands on the bf16 matrix pipe where the transposed-image kernel takes the layer (16 / 32 / 64 channels, maps
+            # at least 12 wide: at 256 x 256 input that includes the 64-channel layers of stages 3-4, which otherwise go to the row stream)
+            p16 = int(bool(self.prec and hz.BF16_WGRAD3 and Ci == Co and rt.lib.dpp_conv3x3_wgrad_bf16_ok(N, Hi, Wi, Ci, Co)))
+            rpw = hz.wgrad3_stream_rows(N * Hi * Wi, Ci) if (Ci == Co and not p16) else 0
             nblk = rt.lib.dpp_wgrad3_stream_slices(Co, Ci, N, Hi, Wi, rpw) if rpw > 0 else 0
             if nblk > 0:
                 part = rt.alloc(nblk * Co * 9 * Ci, zero=False)
@@ -1317,8 +1320,6 @@ class CompiledNet(object):
             else:
                 nblk = rt.lib.dpp_conv3x3_wgrad_blocks(N, Hi, Wi, Ci, Co, bm)
                 part = rt.alloc(nblk * Co * 9 * Ci, zero=False)
-                # bf16 mode: both operands on the bf16 matrix pipe where the transposed-image kernel takes the layer (16 / 32 channels)
-                p16 = int(bool(self.prec and hz.BF16_WGRAD3 and rt.lib.dpp_conv3x3_wgrad_bf16_ok(N, Hi, Wi, Ci, Co)))
                 self.bwd.add(ops.conv3x3_wgrad(rt, src.base.buf, N, Hi, Wi, Ci, dY, Co, part, actX=act, bm=bm, precision=p16,
                                                name='wgrad3x3_%d' % layer.layerNum), side=True)
             self.reduce_jobs.add(part, nblk, Co * 9 * Ci, gW)

@@ -71,7 +71,7 @@ def test_conv3x3_fwd_dgrad_wgrad(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('cfg', [(1, 8, 16, 16), (3, 20, 28, 16), (2, 9, 13, 32), (12, 32, 32, 16), (6, 16, 32, 32), (36, 32, 32, 16)])
+@pytest.mark.parametrize('cfg', [(1, 8, 16, 16), (3, 20, 28, 16), (2, 9, 13, 32), (12, 32, 32, 16), (6, 16, 32, 32), (34, 32, 32, 16), (3, 16, 16, 64), (2, 7, 19, 64)])
 def test_conv3x3_filter_gradient_on_transposed_images(backend, cfg):
     """conv3x3_wgrad_t_kernel (round 6: channel-major LDS images, 16-byte operand reads) on the 16- / 32-channel layers: one, three and
     nine taps per workgroup (the grid wgrad_geometry picks from the tile count), ragged maps (zero padding after the activation, tiles
