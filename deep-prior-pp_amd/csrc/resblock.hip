@@ -39,14 +39,42 @@ struct RBArgs {
     unsigned long long* prof;   // phase stamps (profiling build only, see dpp_stamp)
 };
 
+// Raw loads of four consecutive elements of a float32 or bf16-stored tensor (16 / 8 bytes): kept UNCONVERTED in registers and widened
+// where they are consumed -- a conversion at the load would make the wave wait for the data right there.
+template <class T> struct RBRaw;
+template <> struct RBRaw<float> {
+    typedef float4 type;
+    __device__ static __forceinline__ type ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    __device__ static __forceinline__ float4 widen(const type& r) { return r; }
+    __device__ static __forceinline__ type zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+template <> struct RBRaw<dpp_bf16> {
+    typedef uint2 type;
+    __device__ static __forceinline__ type ld(const dpp_bf16* p) { return *reinterpret_cast<const uint2*>(p); }
+    __device__ static __forceinline__ float4 widen(const type& r) {
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+    }
+    __device__ static __forceinline__ type zero() { type z; z.x = 0u; z.y = 0u; return z; }
+};
+// bf16 mode (Q): a value as a bf16 MFMA operand / a bf16-stored tensor element sees it (round to nearest even, back in float32)
+template <bool Q> __device__ __forceinline__ float rb_q(float v) { return Q ? dpp_bf16_round(v) : v; }
+template <bool Q> __device__ __forceinline__ float4 rb_q4(const float4& v) {
+    return Q ? make_float4(dpp_bf16_round(v.x), dpp_bf16_round(v.y), dpp_bf16_round(v.z), dpp_bf16_round(v.w)) : v;
+}
+
 __device__ __forceinline__ float4 rb_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void rb_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 // v = relu((x - mean) * (gamma * inv_std) + beta), the arithmetic of dpp_act1 with dpp_bn_eval_coeffs' scale
 __device__ __forceinline__ float rb_bnrelu(float x, float mu, float sc, float be) { return fmaxf((x - mu) * sc + be, 0.0f); }
 
-template <int RT, int CT>
-__device__ __forceinline__ void rb_mfma16(f32x4 (&acc)[RT][CT], const float4 (&av)[RT], const float4 (&bv)[CT]) {
+// QW: the weight fragments are rounded to bfloat16 first (bf16 mode: the operand of a bf16 MFMA product; the activations were rounded
+// when they were written to LDS)
+template <int RT, int CT, bool QW = false>
+__device__ __forceinline__ void rb_mfma16(f32x4 (&acc)[RT][CT], const float4 (&av)[RT], const float4 (&bw)[CT]) {
+    float4 bv[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bv[ct] = rb_q4<QW>(bw[ct]);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -69,8 +97,17 @@ __device__ __forceinline__ void rb_mfma16(f32x4 (&acc)[RT][CT], const float4 (&a
 //     ring several k-steps deep, requested before the barrier that precedes their phase -- no barrier inside a phase;
 //   * the output image of a column pass is private to the wave (wave-level ordering only).
 // Three workgroup barriers per block: input halo, A1, A2.
-template <int NB, int BM, int RT1, bool PROJ>
+//
+// bf16 mode (round 6; XT / YT = the storage of the block's input / output, Q = YT is bfloat16: BASELINE config 5's deterministic forward,
+// which fell back to ~6 launches per block): the block computes what the layer-by-layer bf16 path computes -- every tensor that path
+// MATERIALISES is rounded to bfloat16 where it would have been stored (c1, c2, the shortcut's output, the block's output), every operand
+// of a product that path runs on bf16 MFMA is rounded as its kernel rounds it (the activated operands after their prologue, the filters;
+// the 16-channel exit convolution multiplies in float32 there and here) -- with float32 MFMA on the rounded values (bf16 x bf16 products
+// are exact in float32: the same sums in another order of additions).
+template <int NB, int BM, int RT1, bool PROJ, class XT = float, class YT = float>
 __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
+    constexpr bool Q = !std::is_same<YT, float>::value;
+    constexpr bool Q3 = Q && NB >= 32;                 // the exit convolution (K = NB) runs on bf16 operands from 32 channels up
     dpp_kernarg_warm<sizeof(RBArgs)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);
@@ -114,14 +151,14 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     const int by = tq % a.tiles_y, n = tq / a.tiles_y;
     const int y0 = by << a.lth, x0 = bx << a.ltw;
     const int Ho = d.Ho, Wo = d.Wo;
-    const float* Xn = d.X + (size_t)n * d.H * d.W * CIN;
+    const XT* Xn = reinterpret_cast<const XT*>(d.X) + (size_t)n * d.H * d.W * CIN;
 
     dpp_stamp(a.prof, 0);
     // ---- the activated input halo: slot u of a thread is halo position hp = tid / QR + u * RS, channel quad qa.  Every load is
     //      UNCONDITIONAL (a pixel outside the image reads the clamped one and is zeroed afterwards): a branch between a load and its use
     //      makes the compiler drain all outstanding loads, and these are the longest pole of the kernel -- requested first ----
     const int qa = (tid % QR) * 4;
-    float4 areg[ASLOTS];
+    typename RBRaw<XT>::type areg[ASLOTS];
     bool ain[ASLOTS];
 #pragma unroll
     for (int u = 0; u < ASLOTS; ++u) {
@@ -130,7 +167,7 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
         const int y = y0 + hy - 1, x = x0 + hx - 1;
         ain[u] = hp < HP && y >= 0 && y < Ho && x >= 0 && x < Wo;
         const int yc = y < 0 ? 0 : (y >= Ho ? Ho - 1 : y), xc = x < 0 ? 0 : (x >= Wo ? Wo - 1 : x);
-        areg[u] = rb_ld4(Xn + ((size_t)(yc * S) * d.W + xc * S) * CIN + qa);
+        areg[u] = RBRaw<XT>::ld(Xn + ((size_t)(yc * S) * d.W + xc * S) * CIN + qa);
     }
     const float4 mu = rb_ld4(d.bn0.mean + qa), g0 = rb_ld4(d.bn0.gamma + qa), i0 = rb_ld4(d.bn0.inv_std + qa), be = rb_ld4(d.bn0.beta + qa);
     // ---- phase A's first B fragments (in flight while the halo is committed) ----
@@ -148,9 +185,9 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
 #pragma unroll
         for (int u = 0; u < ASLOTS; ++u) {
             const int hp = tid / QR + u * RS;
-            const float4 v = areg[u];
-            float4 t = make_float4(rb_bnrelu(v.x, mu.x, sc.x, be.x), rb_bnrelu(v.y, mu.y, sc.y, be.y),
-                                   rb_bnrelu(v.z, mu.z, sc.z, be.z), rb_bnrelu(v.w, mu.w, sc.w, be.w));
+            const float4 v = RBRaw<XT>::widen(areg[u]);
+            float4 t = rb_q4<Q>(make_float4(rb_bnrelu(v.x, mu.x, sc.x, be.x), rb_bnrelu(v.y, mu.y, sc.y, be.y),
+                                            rb_bnrelu(v.z, mu.z, sc.z, be.z), rb_bnrelu(v.w, mu.w, sc.w, be.w)));
             if (!ain[u]) t = make_float4(0.f, 0.f, 0.f, 0.f);       // zero padding is applied AFTER the activation
             rb_st4(&A0[hp * LDA + qa], t);
         }
@@ -183,7 +220,7 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
 #pragma unroll
                 for (int rt = 0; rt < RT1; ++rt) av[(s + 1) & 1][rt] = rb_ld4(&A0[((wave * RT1 + rt) * 16 + l15) * LDA + (s + 1) * 16 + kq * 4]);
             }
-            rb_mfma16<RT1, CT1>(acc1, av[s & 1], bA[s % RDA]);
+            rb_mfma16<RT1, CT1, Q>(acc1, av[s & 1], bA[s % RDA]);
             if (s + RDA < KSA) {
 #pragma unroll
                 for (int ct = 0; ct < CT1; ++ct) bA[s % RDA][ct] = rb_ld4(w1p[ct] + (s + RDA) * 16);
@@ -219,7 +256,8 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
             const bool in = hp < HP && y >= 0 && y < Ho && x >= 0 && x < Wo;
 #pragma unroll
             for (int ct = 0; ct < CT1; ++ct) {
-                const float v = rb_bnrelu(acc1[rt][ct][r] + e1b[ct], e1m[ct], e1s[ct], e1t[ct]);
+                // (bf16 mode: c1 as stored, then the 3x3's operand as its kernel rounds it)
+                const float v = rb_q<Q>(rb_bnrelu(rb_q<Q>(acc1[rt][ct][r] + e1b[ct]), e1m[ct], e1s[ct], e1t[ct]));
                 A1[hp * LD1 + ct * 16 + l15] = in ? v : 0.0f;
             }
         }
@@ -251,7 +289,7 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
 #pragma unroll
         for (int s = 0; s < KSB; ++s) {
             if (s + 1 < KSB) afrag(s + 1, av[(s + 1) & 1]);
-            rb_mfma16<RM2, CN2>(acc2, av[s & 1], bB[s % RDB]);
+            rb_mfma16<RM2, CN2, Q>(acc2, av[s & 1], bB[s % RDB]);
             if (s + RDB < KSB) {
 #pragma unroll
                 for (int ct = 0; ct < CN2; ++ct) bB[s % RDB][ct] = rb_ld4(w2p[ct] + (s + RDB) * 16);
@@ -274,7 +312,9 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     const float* w3p[CN3];
 #pragma unroll
     for (int ct = 0; ct < CN3; ++ct) w3p[ct] = d.W3 + (size_t)((wn * CN3 + ct) * 16 + l15) * NB + kq * 4;
-    float4 bC[NPASS][KSC][CN3], bq[NPASS], res[NPASS][SWEEPS];
+    float4 bC[NPASS][KSC][CN3], bq[NPASS], bs[NPASS];
+    typename RBRaw<XT>::type res[NPASS][SWEEPS];
+    const XT* const Xr = reinterpret_cast<const XT*>(d.X);
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
@@ -285,11 +325,13 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
 #pragma unroll
         for (int it = 0; it < SWEEPS; ++it) {
             // (unconditional: a row outside the image reads pixel 0 of the tensor and is never stored)
-            res[pass][it] = PROJ ? make_float4(0.f, 0.f, 0.f, 0.f) : rb_ld4(d.X + (size_t)(ooff[it] >= 0 ? ooff[it] : 0) * CIN + pass * 64 + colw);
+            res[pass][it] = PROJ ? RBRaw<XT>::zero() : RBRaw<XT>::ld(Xr + (size_t)(ooff[it] >= 0 ? ooff[it] : 0) * CIN + pass * 64 + colw);
         }
+        bs[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (PROJ) {
             const float4 t = rb_ld4(d.bsc + pass * 64 + colw);
-            bq[pass].x += t.x; bq[pass].y += t.y; bq[pass].z += t.z; bq[pass].w += t.w;
+            if (Q) bs[pass] = t;                             // bf16 mode: the shortcut's output is a stored tensor of its own (rounded first)
+            else { bq[pass].x += t.x; bq[pass].y += t.y; bq[pass].z += t.z; bq[pass].w += t.w; }
         }
     }
     DPP_SCHED_FENCE();
@@ -300,7 +342,7 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
             const int row = (wm * RM2 + rt) * 16 + kq * 4 + r;
 #pragma unroll
             for (int ct = 0; ct < CN2; ++ct)
-                A2[row * LD1 + (wn * CN2 + ct) * 16 + l15] = rb_bnrelu(acc2[rt][ct][r] + e2b[ct], e2m[ct], e2s[ct], e2t[ct]);
+                A2[row * LD1 + (wn * CN2 + ct) * 16 + l15] = rb_q<Q3>(rb_bnrelu(rb_q<Q>(acc2[rt][ct][r] + e2b[ct]), e2m[ct], e2s[ct], e2t[ct]));
         }
     __syncthreads();
     dpp_stamp(a.prof, 6);
@@ -324,26 +366,27 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
 #pragma unroll
                 for (int ct = 0; ct < CN3; ++ct) bS[s][ct] = rb_ld4(wsp[ct] + s * 16);
         }
-        f32x4 acc3[RM2][CN3];
+        f32x4 acc3[RM2][CN3], accS[RM2][CN3];
 #pragma unroll
         for (int i = 0; i < RM2; ++i)
 #pragma unroll
-            for (int j = 0; j < CN3; ++j) acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < CN3; ++j) { acc3[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; accS[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int s = 0; s < KSC; ++s) {
             float4 av[RM2];
 #pragma unroll
             for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&A2[((wm * RM2 + rt) * 16 + l15) * LD1 + s * 16 + kq * 4]);
-            rb_mfma16<RM2, CN3>(acc3, av, bC[pass][s]);
+            rb_mfma16<RM2, CN3, Q3>(acc3, av, bC[pass][s]);
         }
         if (PROJ) {
-            // the shortcut's product on the centre pixels of the activated input (still whole in LDS)
+            // the shortcut's product on the centre pixels of the activated input (still whole in LDS); bf16 mode: its own accumulators
 #pragma unroll
             for (int s = 0; s < KSA; ++s) {
                 float4 av[RM2];
 #pragma unroll
                 for (int rt = 0; rt < RM2; ++rt) av[rt] = rb_ld4(&A0[hc[rt] * LDA + s * 16 + kq * 4]);
-                rb_mfma16<RM2, CN3>(acc3, av, bS[s % RDA]);
+                if (Q) rb_mfma16<RM2, CN3, true>(accS, av, bS[s % RDA]);
+                else rb_mfma16<RM2, CN3, false>(acc3, av, bS[s % RDA]);
                 if (s + RDA < KSA) {
 #pragma unroll
                     for (int ct = 0; ct < CN3; ++ct) bS[s % RDA][ct] = rb_ld4(wsp[ct] + (s + RDA) * 16);
@@ -352,7 +395,24 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
             }
         }
         // the wave's [WROWS][WCOLS] share through its private image: 16-byte bias / residual / store
-        DPP_WAVE_SYNC();                                // (the previous pass's reads of the image are done)
+        float4 scv[SWEEPS];
+        if (PROJ && Q) {
+            // bf16 mode: the shortcut's output as the tensor the layer-by-layer path stores (rounded), one more trip through the image
+            DPP_WAVE_SYNC();
+#pragma unroll
+            for (int rt = 0; rt < RM2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < CN3; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) IMG[(rt * 16 + kq * 4 + r) * LDI + ct * 16 + l15] = accS[rt][ct][r];
+            DPP_WAVE_SYNC();
+#pragma unroll
+            for (int it = 0; it < SWEEPS; ++it) {
+                const float4 v = rb_ld4(&IMG[(rq + it * RSW) * LDI + cq * 4]);
+                scv[it] = rb_q4<true>(make_float4(v.x + bs[pass].x, v.y + bs[pass].y, v.z + bs[pass].z, v.w + bs[pass].w));
+            }
+        }
+        DPP_WAVE_SYNC();                                // (the previous reads of the image are done)
 #pragma unroll
         for (int rt = 0; rt < RM2; ++rt)
 #pragma unroll
@@ -364,8 +424,10 @@ __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
         for (int it = 0; it < SWEEPS; ++it) {
             if (ooff[it] >= 0) {
                 const float4 v = rb_ld4(&IMG[(rq + it * RSW) * LDI + cq * 4]);
-                const float4 bb = bq[pass], rr = res[pass][it];
-                rb_st4(d.Y + (size_t)ooff[it] * COUT + pass * 64 + colw, make_float4(v.x + bb.x + rr.x, v.y + bb.y + rr.y, v.z + bb.z + rr.z, v.w + bb.w + rr.w));
+                const float4 bb = bq[pass];
+                const float4 rr = (PROJ && Q) ? scv[it] : RBRaw<XT>::widen(res[pass][it]);
+                dpp_st4(reinterpret_cast<YT*>(d.Y) + (size_t)ooff[it] * COUT + pass * 64 + colw,
+                        make_float4(v.x + bb.x + rr.x, v.y + bb.y + rr.y, v.z + bb.z + rr.z, v.w + bb.w + rr.w));
             }
         }
     }
@@ -385,14 +447,15 @@ extern "C" int dpp_resblock_eval_ok(int Cin, int Cout, int Nb, int stride, int p
     return (stride == 1 || stride == 2) && Cin == 2 * Nb;                  // the block that opens a stage
 }
 
-extern "C" int dpp_resblock_eval(const dpp_resblock_desc* desc, dpp_stream_t stream) {
+// argument checks, tile geometry and LDS size of a block (shared by the launch and by dpp_resblock_eval_check)
+static int rb_prepare(const dpp_resblock_desc* desc, RBArgs& a, size_t& lds, bool& proj) {
     if (!desc) return DPP_E_BADARG;
     const dpp_resblock_desc& d = *desc;
     if (!d.X || !d.Y || !d.W1 || !d.b1 || !d.W2 || !d.b2 || !d.W3 || !d.b3 || d.N < 1 || d.H < 1 || d.W < 1) return DPP_E_BADARG;
     const dpp_bn_eval* bns[3] = {&d.bn0, &d.bn1, &d.bn2};
     for (const dpp_bn_eval* b : bns)
         if (!b->mean || !b->inv_std || !b->gamma || !b->beta) return DPP_E_BADARG;
-    const bool proj = d.Wsc != nullptr;
+    proj = d.Wsc != nullptr;
     if (proj && !d.bsc) return DPP_E_BADARG;
     if (!dpp_resblock_eval_ok(d.Cin, d.Cout, d.Nb, d.stride, proj ? 1 : 0)) return DPP_E_UNSUPPORTED;
     if (d.Ho != (d.H + d.stride - 1) / d.stride || d.Wo != (d.W + d.stride - 1) / d.stride) return DPP_E_BADARG;
@@ -400,7 +463,8 @@ extern "C" int dpp_resblock_eval(const dpp_resblock_desc* desc, dpp_stream_t str
     for (const void* p : al)
         if (!rb_al16(p)) return DPP_E_UNSUPPORTED;
     if ((long)d.N * d.H * d.W * (long)(d.Cin > d.Cout ? d.Cin : d.Cout) >= (1L << 31)) return DPP_E_UNSUPPORTED;     // 32-bit element offsets
-    RBArgs a;
+    if (d.store & ~(DPP_ST_A | DPP_ST_C)) return DPP_E_BADARG;
+    if ((d.store & DPP_ST_A) && !(d.store & DPP_ST_C)) return DPP_E_UNSUPPORTED;
     a.d = d;
     a.prof = dpp_prof_buffer;
     // the tile follows from the bottleneck width alone (never from the batch): 8 x 8 (16 and 32 channels), 4 x 8 (64).  (16 channels: 8 x 16
@@ -416,18 +480,41 @@ extern "C" int dpp_resblock_eval(const dpp_resblock_desc* desc, dpp_stream_t str
     const int wn2 = d.Nb / 16 < 4 ? d.Nb / 16 : 4, wm2 = 4 / wn2, wrows = BM / wm2, wcols = 64 / wn2;      // a wave's share of a 64-column pass
     const int img = 4 * wrows * (wcols + 4);                                                   // four wave-private images
     const int r0a = HPP * LDA, r0b = HPP * LD1 + img;
-    const size_t lds = ((size_t)(proj ? r0a + r0b : (r0a > r0b ? r0a : r0b)) + (size_t)BM * LD1) * sizeof(float);
+    lds = ((size_t)(proj ? r0a + r0b : (r0a > r0b ? r0a : r0b)) + (size_t)BM * LD1) * sizeof(float);
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     a.xcd_chunk = (a.ntiles % 8 == 0 && a.ntiles >= 64) ? a.ntiles / 8 : 0;
+    return DPP_OK;
+}
+
+// would dpp_resblock_eval take this descriptor?  (DPP_OK, or the status it would return: alignment, LDS size, 32-bit offsets, storage
+// combination -- the engine asks while it COMPILES a net, so that a block the kernel refuses is lowered layer by layer, not a failed run)
+extern "C" int dpp_resblock_eval_check(const dpp_resblock_desc* desc) {
+    RBArgs a;
+    size_t lds;
+    bool proj;
+    return rb_prepare(desc, a, lds, proj);
+}
+
+extern "C" int dpp_resblock_eval(const dpp_resblock_desc* desc, dpp_stream_t stream) {
+    RBArgs a;
+    size_t lds;
+    bool proj;
+    const int prep = rb_prepare(desc, a, lds, proj);
+    if (prep != DPP_OK) return prep;
+    const dpp_resblock_desc& d = a.d;
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define DPP_RBK(NB_, BM_, RT_, P_) do { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_eval_kernel<NB_, BM_, RT_, P_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        DPP_LAUNCH((resblock_eval_kernel<NB_, BM_, RT_, P_>), dim3(a.ntiles), dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
+    // storage: float32 in and out; bf16 mode: bf16 out with float32 in (the block behind the stem, whose pooled map stays float32) or bf16 in
+    const bool x16 = (d.store & DPP_ST_A) != 0, y16 = (d.store & DPP_ST_C) != 0;
+#define DPP_RBT(NB_, BM_, RT_, P_, XT_, YT_) do { \
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&resblock_eval_kernel<NB_, BM_, RT_, P_, XT_, YT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return DPP_E_UNSUPPORTED; \
+        DPP_LAUNCH((resblock_eval_kernel<NB_, BM_, RT_, P_, XT_, YT_>), dim3(a.ntiles), dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
+#define DPP_RBK(NB_, BM_, RT_, P_) do { if (x16) DPP_RBT(NB_, BM_, RT_, P_, dpp_bf16, dpp_bf16); else if (y16) DPP_RBT(NB_, BM_, RT_, P_, float, dpp_bf16); else DPP_RBT(NB_, BM_, RT_, P_, float, float); } while (0)
 #define DPP_RB(NB_, BM_, RT_) do { if (proj) DPP_RBK(NB_, BM_, RT_, true); else DPP_RBK(NB_, BM_, RT_, false); } while (0)
     if (d.Nb == 16) DPP_RB(16, 64, 2);
     if (d.Nb == 32) DPP_RB(32, 64, 2);
     if (d.Nb == 64) DPP_RB(64, 32, 1);
 #undef DPP_RB
 #undef DPP_RBK
+#undef DPP_RBT
     return DPP_E_UNSUPPORTED;
 }

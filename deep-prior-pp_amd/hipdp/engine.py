@@ -470,6 +470,10 @@ class CompiledNet(object):
         self.tensors.append(t)
         return t
 
+    def _drop_tensor(self, t):
+        """Forget a tensor that was allocated for a launch that is not emitted after all."""
+        self.tensors = [u for u in self.tensors if u is not t]
+
     def _gemm_prec(self, variant, K, lazy=False, role='fwd'):
         """dpp_gemm_desc.precision of a 1x1-convolution product in this net: 1 (bf16 MFMA operands, f32 accumulation) in the bf16 mode
         wherever the kernel of `variant` has the path -- round 4: the wave-autonomous kernel (variant 4) with whole 32-deep steps; round 6:

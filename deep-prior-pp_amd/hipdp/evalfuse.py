@@ -10,8 +10,8 @@ engine used to issue that same decomposition (~6 launches per block).  Here the 
     conv1x1(relu(bn(conv3x3(relu(bn(conv1x1_s(h))))))) + conv1x1_s(h),   h = relu(bn(inputVar))      projection block
 
 is recognised on the `add` node and handed to dpp_resblock_eval (csrc/resblock.hip), which keeps the 16- / 32- / 64-channel
-intermediates in LDS.  Anything that does not match (other widths, dropout in between, a consumer of an intermediate value, bf16
-storage) stays on the layer-by-layer path.
+intermediates in LDS.  Anything that does not match (other widths, dropout in between, a consumer of an intermediate value) stays on
+the layer-by-layer path.  Round 6: the bf16 mode of BASELINE config 5 (bf16-stored tensors, bf16 MFMA operands) has its form of the kernel.
 """
 from . import ops
 
@@ -39,7 +39,7 @@ def _bn_relu_under(eng, var, sole=True):
     return bn, bv.inputs[0]
 
 
-def _conv(var, k, plain_output=True):
+def _conv(var, k):
     l = _layer_of(var, 'ConvLayer')
     if l is None:
         return None
@@ -95,8 +95,14 @@ def match_block(eng, add_var):
 def emit_block(eng, add_var):
     """Lower the block ending in `add_var` to one dpp_resblock_eval launch and return the View of its output, or None (not this shape:
     the caller emits the block layer by layer)."""
-    if eng.train or eng.prec or eng.store16:
+    if eng.train:
         return None
+    if eng.prec or eng.store16:
+        # bf16 mode (round 6): the fused block models the DEFAULT bf16 path -- bf16-stored conv outputs and bf16 MFMA operands in every
+        # product of the block but the 16-channel exit convolution; any other combination of the bf16 knobs stays layer by layer
+        from . import heuristics as hz
+        if not (eng.prec and eng.store16 and hz.BF16_GEMM and hz.BF16_GEMM_ALL and hz.EVAL_FUSE_BF16):
+            return None
     m = match_block(eng, add_var)
     if m is None:
         return None
@@ -108,13 +114,14 @@ def emit_block(eng, add_var):
     if not rt.lib.dpp_resblock_eval_ok(Cin, Cout, Nb, s, 1 if m['shortcut'] is not None else 0):
         return None
     src = eng._emit(m['root'])
-    if not src.plain or len(src.shape) != 4 or src.base.is16:
+    if not src.plain or len(src.shape) != 4 or (src.base.is16 and not eng.store16):
         return None
     N, H, W, Ci = src.base.shape
     if Ci != Cin:
         return None
     _, Co_, Ho, Wo = c3.outputDim
-    assert Co_ == Cout and Ho == -(-H // s) and Wo == -(-W // s), (c3.outputDim, (N, H, W, Ci), s)
+    if not (Co_ == Cout and Ho == -(-H // s) and Wo == -(-W // s)):
+        return None
 
     def bn(layer):
         return ops.bn_eval(st.view(layer.mean), st.view(layer.inv_std), st.view(layer.gamma), st.view(layer.beta))
@@ -122,9 +129,15 @@ def emit_block(eng, add_var):
     kw = {}
     if m['shortcut'] is not None:
         kw = dict(Wsc=st.view(m['shortcut'].W), bsc=st.view(m['shortcut'].b))
-    eng.fwd.add(ops.resblock_eval(rt, src.base.buf, N, H, W, Cin, s, Cout, Nb, bn(m['bn0']), bn(m['bn1']), bn(m['bn2']),
-                                  st.view(m['conv1'].W), st.view(m['conv1'].b), st.view(m['conv2'].W), st.view(m['conv2'].b),
-                                  st.view(m['conv3'].W), st.view(m['conv3'].b), out.buf, name='resblock_%d' % m['conv3'].layerNum, **kw))
+    launch = ops.resblock_eval(rt, src.base.buf, N, H, W, Cin, s, Cout, Nb, bn(m['bn0']), bn(m['bn1']), bn(m['bn2']),
+                               st.view(m['conv1'].W), st.view(m['conv1'].b), st.view(m['conv2'].W), st.view(m['conv2'].b),
+                               st.view(m['conv3'].W), st.view(m['conv3'].b), out.buf, name='resblock_%d' % m['conv3'].layerNum, **kw)
+    if rt.lib.dpp_resblock_eval_check(launch.args[0]) != 0:
+        # the kernel refuses THIS descriptor (pointer alignment, LDS size, 32-bit offsets, storage combination): layer by layer, decided
+        # while the net is compiled -- not a failed forward pass later
+        eng._drop_tensor(out)
+        return None
+    eng.fwd.add(launch)
     eng.fused_blocks.append(m)
     from .engine import View
     return View(out)

@@ -68,6 +68,9 @@ def gemm_plan(M, N, K, allow_split=True):
 EVAL_FUSE = knob('DPP_EVAL_FUSE', '1') != '0'
 # round 6: the cost and its gradient computed by the split-K reduction of the last HiddenLayer (dpp_reduce_partials_loss).  DPP_FUSE_LOSS=0: own launch.
 FUSE_LOSS = knob('DPP_FUSE_LOSS', '1') != '0'
+# round 6: the fused block in the bf16 mode (bf16-stored input / output).  DPP_EVAL_FUSE_BF16=0: the layer-by-layer bf16 forward (the path
+# whose every product can be pinned against the oracle: tests/test_configs.py).
+EVAL_FUSE_BF16 = knob('DPP_EVAL_FUSE_BF16', '1') != '0'
 OVERLAP_ALLREDUCE = knob('DPP_OVERLAP_ALLREDUCE', '1') != '0'
 EARLY_BUCKET_MIN = int(knob('DPP_EARLY_BUCKET_MIN', str(1 << 22)))      # elements; FC1 of the 128x128 ResNet has 16.8 M
 # 1x1 convolutions can read the BatchNorm gradient as (G, x) instead of a materialised dX (see _resolve_view).

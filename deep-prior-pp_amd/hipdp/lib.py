@@ -65,7 +65,7 @@ class ResblockDesc(C.Structure):
                 ('stride', C.c_int), ('Ho', C.c_int), ('Wo', C.c_int), ('Cout', C.c_int), ('Nb', C.c_int),
                 ('bn0', BnEval), ('bn1', BnEval), ('bn2', BnEval),
                 ('W1', C.c_void_p), ('b1', C.c_void_p), ('W2', C.c_void_p), ('b2', C.c_void_p), ('W3', C.c_void_p), ('b3', C.c_void_p),
-                ('Wsc', C.c_void_p), ('bsc', C.c_void_p), ('Y', C.c_void_p)]
+                ('Wsc', C.c_void_p), ('bsc', C.c_void_p), ('Y', C.c_void_p), ('store', C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/dpp_hip.h declares must be listed here
@@ -111,6 +111,7 @@ SIGNATURES = {
     'dpp_bn_eval_coeffs_multi': (C.c_int, [C.c_void_p, C.c_int, C.c_int, stream_t]),
     'dpp_resblock_eval_ok': (C.c_int, [C.c_int] * 5),
     'dpp_resblock_eval': (C.c_int, [C.POINTER(ResblockDesc), stream_t]),
+    'dpp_resblock_eval_check': (C.c_int, [C.POINTER(ResblockDesc)]),
     'dpp_bn_bwd_reduce': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_bn_bwd_finalize': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -484,8 +484,8 @@ def bn_eval(mean, inv_std, gamma, beta):
 
 def resblock_eval(rt, X, N, H, W, Cin, stride, Cout, Nb, bn0, bn1, bn2, W1, b1, W2, b2, W3, b3, Y, Wsc=None, bsc=None, name='resblock_eval'):
     """dpp_resblock_eval: one pre-activation bottleneck block of the deterministic forward pass in one launch (csrc/resblock.hip)."""
-    _f32_only('dpp_resblock_eval', X, Y)
     d = ResblockDesc()
+    d.store = _store(a=X, c=Y)
     Ho, Wo = -(-H // stride), -(-W // stride)
     d.X, d.N, d.H, d.W, d.Cin = X.ptr, int(N), int(H), int(W), int(Cin)
     d.stride, d.Ho, d.Wo, d.Cout, d.Nb = int(stride), Ho, Wo, int(Cout), int(Nb)
@@ -494,7 +494,7 @@ def resblock_eval(rt, X, N, H, W, Cin, stride, Cout, Nb, bn0, bn1, bn2, W1, b1, 
     d.Wsc, d.bsc, d.Y = _p(Wsc), _p(bsc), Y.ptr
     px = float(N) * Ho * Wo
     flops = 2.0 * px * (Cin * Nb + 9.0 * Nb * Nb + Nb * Cout + (Cin * Cout if Wsc is not None else 0))
-    byts = 4.0 * (float(N) * H * W * Cin + px * Cout + (px * Cout if Wsc is None else 0) + Cin * Nb + 9.0 * Nb * Nb + Nb * Cout)
+    byts = _esz(X) * (float(N) * H * W * Cin + (px * Cout if Wsc is None else 0)) + _esz(Y) * px * Cout + 4.0 * (Cin * Nb + 9.0 * Nb * Nb + Nb * Cout)
     return Launch(rt.lib.dpp_resblock_eval, (C.byref(d),), (d, X, Y, bn0, bn1, bn2, W1, b1, W2, b2, W3, b3, Wsc, bsc), name,
                   dict(kernel='resblock_eval_mfma_f32', flops=flops, bytes=byts))
 

@@ -490,9 +490,14 @@ typedef struct {
     const float* W3; const float* b3;
     const float* Wsc; const float* bsc;
     float* Y;
+    int store;      /* (ABI v11) DPP_ST_A: X holds bf16 elements, DPP_ST_C: Y does.  DPP_ST_C selects the bf16 MODE of the block (BASELINE config 5):
+                     * what the layer-by-layer bf16 path stores is rounded to bfloat16 where it would have been stored, what it multiplies on bf16
+                     * MFMA operands is rounded as its kernels round it.  DPP_ST_A alone is refused. */
 } dpp_resblock_desc;
 int dpp_resblock_eval_ok(int Cin, int Cout, int Nb, int stride, int projection);
 int dpp_resblock_eval(const dpp_resblock_desc* d, dpp_stream_t stream);
+/* (ABI v11) the status dpp_resblock_eval would return for this descriptor, without launching (alignment, LDS size, offsets, storage) */
+int dpp_resblock_eval_check(const dpp_resblock_desc* d);
 
 /* ---- launch plans: a whole train / inference step as ONE call --------------------------------------------------------
  * The reference runs `train_model(index, lr)` as one compiled device function (theano.function,
