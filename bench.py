@@ -332,7 +332,23 @@ def forward_only_leg(rt, torch, net, B, S, x_host, steps=50, warmup=10):
     dom = max(fam, key=fam.get)
     g = groups[dom]
     t = fam[dom] * 1e-3
+    # HBM bytes per launch of that family from the counter passes over the deterministic forward (tools/refresh_profiles.sh), from a
+    # file measured on THESE kernel sources only
+    traffic, traffic_src = None, None
+    import glob
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_hbm_traffic_forward.json')), reverse=True):
+        try:
+            with open(fn) as fh:
+                pj = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        kk = [k for k in pj if not k.startswith('_') and dom.split('_mfma')[0] in k]
+        if pj.get('_csrc_sha16') == csrc_sha16() and kk and B == 128 and S == 128:
+            traffic = round(sum(pj[k]['bytes_per_launch'] * pj[k]['launches_per_step'] for k in kk) / sum(pj[k]['launches_per_step'] for k in kk))
+            traffic_src = 'profiles/' + os.path.basename(fn).replace('.json', '.txt')
+            break
     roof = dict(kernel=dom, launches_per_batch=len(g['ops']), avg_launch_us=round(t / len(g['ops']) * 1e6, 2), share_of_batch=round(fam[dom] / sum(fam.values()), 3),
+                traffic=traffic, traffic_source=traffic_src, algorithmic_bytes=round(g['bytes'] / len(g['ops'])),
                 mfma=dict(achieved=round(g['flops'] / t / 1e12, 2), peak=PEAK_MFMA_F32 / 1e12, unit='TFLOP/s', frac=round(g['flops'] / t / PEAK_MFMA_F32, 4)),
                 hbm=dict(achieved=round(g['bytes'] / t / 1e9, 1), peak=PEAK_HBM / 1e9, unit='GB/s', frac=round(g['bytes'] / t / PEAK_HBM, 4)))
     # one frame at a time (the reference's realtime use, netbase.py:286-310 with a batch of one; the paper quotes 30 fps): the same

@@ -66,12 +66,16 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_stats_partial_kernel(const TX*
 }
 
 // One wave per channel, lane l owns partial blocks l, l+64, ... (contiguous in memory, see dpp_partial_index).  The per-block
-// (mean, M2) pairs are combined in two passes over the partials (the second one re-reads them from L2) instead of a chain of
-// pairwise Chan updates:
-//     mean = sum_b n_b mean_b / sum_b n_b ,   M2 = sum_b [ M2_b + n_b (mean_b - mean)^2 ]
-// -- the same quantity, no cancellation (deviations from the final mean), and no dependent f64 division per partial, which is
-// what the finalize of a stage-1 layer (2048 partial blocks, 8192 for the stem) spent its time on once the loads were
-// coalesced.  All sums are f64 in a fixed order; lanes meet in an xor butterfly (every lane ends with the same value).
+// (mean, M2) pairs are combined instead of chained through pairwise Chan updates (a dependent f64 division per partial is what the
+// finalize of a stage-1 layer -- 2048 partial blocks, 8192 for the stem -- spent its time on once the loads were coalesced):
+//   * single rank, all blocks in one sweep (every training launch of the nets here): ONE pass about a pivot K = block 0's mean,
+//         mean = K + S1 / M,   M2 = S2 - S1^2 / M,   S1 = sum_b n_b (mean_b - K),   S2 = sum_b [M2_b + n_b (mean_b - K)^2]
+//     The subtraction S2 - S1^2 / M is there again (round 5), but what cancels is the spread of the BLOCK means about K -- not
+//     |mean| >> std --, in f64: relative loss ~1e-16 (spread / std)^2, i.e. nothing until block 0 lies ~1e4 standard deviations away
+//     from the others (tests/test_kernels.py: an outlier block 0);
+//   * otherwise (sync-BN segments, more blocks than one sweep): two passes, mean = sum_b n_b mean_b / M first, then
+//         M2 = sum_b [M2_b + n_b (mean_b - mean)^2]  -- deviations from the final mean, no cancellation at all.
+// All sums are f64 in a fixed order; lanes meet in an xor butterfly (every lane ends with the same value).
 __device__ __forceinline__ double wave_allsum(double v) {
     for (int o = 1; o < DPP_WAVE; o <<= 1) v += __shfl_xor(v, o);
     return v;
@@ -172,28 +176,17 @@ __global__ __launch_bounds__(DPP_THREADS) void bn_finalize_kernel(const float* _
                 const int b = b0 + u * GT;
                 const int bb = b < nbs ? b : nbs - 1;
                 pm[u] = pm_row[bb];
-                if (one_sweep) pq0[u] = pq_row[bb];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int b = b0 + u * GT;
                 if (b < nbs) snm += (double)rows_of(b) * (double)pm[u];
-                pm0[u] = pm[u];
             }
         }
     }
     const double mean = group_allsum<WPC>(snm, slot_a) / (double)M;  // sum_b n_b = M
     double q = 0.0;
-    if (one_sweep) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int b = lane + u * GT;
-            if (b < nbs) {
-                const double d = (double)pm0[u] - mean;
-                q += (double)pq0[u] + (double)rows_of(b) * d * d;
-            }
-        }
-    } else {
+    {
         for (int seg = 0; seg < nseg; ++seg) {
             const float* pm_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(0, cc, 0, C, nbs);
             const float* pq_row = partial + (size_t)seg * 2 * C * nbs + dpp_partial_index(1, cc, 0, C, nbs);

@@ -141,7 +141,8 @@ class NetBase(object):
         statistics are not: with per-GPU batch statistics (DataParallel(sync_bn=False), the default) every rank's EMA follows its own
         shards.  Rank 0's statistics -- the ones in the checkpoint rank 0 writes -- are therefore broadcast before the batches are
         dealt out, so a batch goes through the same numbers and the same kernels whichever rank runs it and the result equals the
-        single-process evaluation of rank 0's checkpoint bit for bit."""
+        single-process evaluation of rank 0's checkpoint bit for bit.  The rank's OWN statistics are restored when the call returns
+        (round 6, ADVICE r5: the broadcast used to overwrite them for good)."""
         if not isinstance(inputs, list):
             inputs = [inputs]
         assert all(i.shape[0] == inputs[0].shape[0] for i in inputs[1:])
@@ -162,7 +163,18 @@ class NetBase(object):
         outSize[0] = padSize
         out = numpy.zeros(tuple(outSize), dtype='float32')
         eng = self._engine()
+        local_nt = None
         if G > 1:
+            # rank 0's running statistics for the evaluation only: the rank's own are put back afterwards (an inference call in the
+            # middle of training must not rewrite the state of the replicas -- train()'s epilogue is where they are made one model)
+            store = self._live_store()
+            if store is not None:
+                st = self.__dict__.setdefault('_nt_stage', {})
+                if st.get('store') is not store:
+                    st.clear()
+                    st.update(store=store, buf=store.rt.alloc(store.n_nt, zero=False))
+                local_nt = st['buf']
+                store.rt.copy(local_nt, store.nt)
             self.syncRunningStatistics(dp)
         n_test_batches = padSize // batch_size
         start = time.time()
@@ -195,6 +207,9 @@ class NetBase(object):
             for r, rows in enumerate(dp.all_gather_host(mine)):
                 for k, i in enumerate(range(r, n_test_batches, G)):
                     out[i * batch_size:(i + 1) * batch_size] = rows[k * batch_size:(k + 1) * batch_size]
+        if local_nt is not None:
+            store = self._live_store()
+            store.rt.copy(store.nt, local_nt)
         end = time.time()
         if timeit:
             print("{} in {}s, {}ms per frame".format(padSize, end - start, (end - start) * 1000. / padSize))

@@ -40,7 +40,12 @@ def main():
             for p_ in l.params_nontrained:
                 v = p_.get_value()
                 p_.set_value((v + prng.normal(0, 0.05, v.shape) * (1.0 if 'mean' in p_.name else 0.2)).astype(np.float32))
+    bn0 = [l for l in net.layers if l.__class__.__name__ == 'BatchNormLayer'][0]
+    before = bn0.mean.get_value().copy() if os.environ.get('DPP_WORKER_DIVERGE') == '1' else None
     res = dict(out=net.computeOutput(x, dp=dp))
+    if before is not None:
+        # the sharded call evaluated with rank 0's statistics and put this rank's own back (round 6)
+        res['bn_mean_before'], res['bn_mean_after'] = before, bn0.mean.get_value().copy()
     if dp is not None:
         net.dp = dp                                   # what a data-parallel trainer attaches: the plain call shards as well
         res['out_attr'] = net.computeOutput(x)

@@ -308,6 +308,11 @@ def test_compute_output_uses_rank0_running_statistics_after_local_bn_training(tm
     plain = _run_output_ranks(tmp_path, 1)[0]
     assert not np.array_equal(one['out'], plain['out'])           # the perturbed statistics matter
     _check_sharded_outputs(two, one)
+    # ... and a sharded evaluation leaves every rank's own running statistics as they were (an inference call in the middle
+    # of training must not rewrite the replicas' state)
+    for r in two:
+        assert np.array_equal(r['bn_mean_before'], r['bn_mean_after'])
+    assert not np.array_equal(two[0]['bn_mean_after'], two[1]['bn_mean_after'])
 
 
 @pytest.mark.gpu

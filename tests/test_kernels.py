@@ -134,6 +134,30 @@ def test_conv3x3_filter_gradient_on_transposed_images(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+def test_batchnorm_finalize_with_an_outlier_first_block(backend):
+    """the one-pass finalize takes the block means about a PIVOT (block 0's mean) and subtracts S1^2 / M -- what cancels is the
+    spread of the block means about that pivot.  Block 0 a constant far-plane background block (mean 1.0, no variance) in front of blocks of
+    hand pixels around -0.3 +- 0.2, and an extreme case (block 0 at +300, the rest ~N(0, 0.01)): mean and inv_std against float64."""
+    rt = get_runtime(backend)
+    rng = np.random.RandomState(5)
+    M, Cc, rpb = 64 * 40, 16, 64
+    for first, loc, sd in ((1.0, -0.3, 0.2), (300.0, 0.0, 0.01)):
+        x = (rng.normal(size=(M, Cc)) * sd + loc).astype(np.float32)
+        x[:rpb] = np.float32(first)
+        gamma = np.ones(Cc, np.float32)
+        nb = M // rpb
+        d = up(rt, x=x, gamma=gamma)
+        part = rt.alloc((nb, 2, Cc), zero=False)
+        mean, istd, scale = (rt.alloc(Cc, zero=False) for _ in range(3))
+        ops.bn_stats_partial(rt, d['x'], M, Cc, rpb, part)(rt.stream)
+        ops.bn_finalize(rt, part, nb, M, rpb, Cc, d['gamma'], 1e-4, mean, istd, scale, None, None, 0.0)(rt.stream)
+        rt.synchronize()
+        x64 = x.astype('f8')
+        np.testing.assert_allclose(mean.get(), x64.mean(0), rtol=3e-7, atol=1e-7)
+        np.testing.assert_allclose(istd.get(), 1.0 / np.sqrt(x64.var(0) + 1e-4), rtol=3e-6)
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('cfg', [(2, 32, 32, 32), (3, 16, 48, 32), (1, 36, 20, 16), (1, 32, 16, 30), (2, 16, 16, 24)])
 def test_stem_fwd_and_wgrad(backend, cfg):
     rt = get_runtime(backend)

@@ -35,6 +35,13 @@ def main():
         n_adam = float(sys.argv[sys.argv.index('--params') + 1])
     adam = [k for k in fetch if 'adam_kernel' in k]
     fcal = wcal = 1.0
+    if '--cal-from' in sys.argv:
+        # a pass without the ADAM update (the deterministic forward): the calibration factors of the train-step pass of the same run
+        import json as _json
+        with open(sys.argv[sys.argv.index('--cal-from') + 1]) as fh:
+            cj = _json.load(fh)
+        fcal, wcal = float(cj['_fetch_cal']), float(cj['_write_cal'])
+        adam = []
     if adam:
         fcal = 16.0 * n_adam / (fetch[adam[0]][1] * 1024.0)
         wcal = 12.0 * n_adam / (write[adam[0]][1] * 1024.0)
@@ -68,6 +75,7 @@ def main():
         import json
         js = {key: dict(launches_per_step=calls / steps, bytes_per_launch=t / calls * 1e6) for key, (calls, t) in fam.items()}
         js['_total_bytes_per_step'] = tot / steps * 1e6
+        js['_fetch_cal'], js['_write_cal'] = fcal, wcal
         js['_source'] = 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), calibrated on adam_kernel'
         # fingerprint of the kernel sources of the tree this ran in (= the tree that was profiled): bench.py only quotes the file for
         # a build of the same sources

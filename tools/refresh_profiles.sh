@@ -7,7 +7,7 @@ O=$R/gpurun_out/$ROUND
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # kernel trace of the measured configuration (bench defaults: native plan, two streams) -- kernel-trace only, no counters
-rocprofv3 --kernel-trace -d /tmp/p1 -o run -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace -d /tmp/p1 -o run -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --headline-only --no-trainer > /dev/null 2>&1
 python $R/tools/prof_summary.py $(find /tmp/p1 -name '*_results.db' | head -1) 28 > $O/kernel_stats_bench.txt 2>&1
 # un-overlapped kernel durations, one line per (kernel, grid)
 DPP_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace -d /tmp/p2 -o run -- python $R/tools/step_profile.py 8 > /dev/null 2>&1
@@ -29,10 +29,23 @@ python $R/tools/inst_summary.py $(find /tmp/p5 -name '*_results.db' | head -1) $
 # matrix-core busy cycles (north_star: "rocprof MFMA utilisation"): one more SQ pass, counters only + kernel trace
 DPP_NO_SIDE_STREAM=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES --kernel-trace -d /tmp/p7 -o run -- python $R/tools/step_profile.py 3 > /dev/null 2>&1
 python $R/tools/mfma_busy_summary.py $(find /tmp/p7 -name '*_results.db' | head -1) --json $O/mfma_busy.json > $O/mfma_busy.txt 2>&1
+# HBM traffic of the deterministic forward: the same two counter passes over tools/forward_profile.py, calibrated with
+# the factors of the train-step pass above (the forward has no adam_kernel to calibrate on)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p3_fwd -o run -- python $R/tools/forward_profile.py 3 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/p4_fwd -o run -- python $R/tools/forward_profile.py 3 > /dev/null 2>&1
+python $R/tools/pmc_summary.py $(find /tmp/p3_fwd -name '*_results.db' | head -1) $(find /tmp/p4_fwd -name '*_results.db' | head -1) 6 --cal-from $O/hbm_traffic.json --json $O/hbm_traffic_forward.json > $O/hbm_traffic_forward.txt 2>&1
 # the deterministic forward (computeOutput's device function): kernel trace by grid + the fused block's phase stamps
 rocprofv3 --kernel-trace -d /tmp/p8 -o run -- python $R/tools/forward_profile.py 8 > /dev/null 2>&1
 python $R/tools/prof_summary.py $(find /tmp/p8 -name '*_results.db' | head -1) 11 --by-grid > $O/forward_kernels_by_grid.txt 2>&1
 python $R/tools/forward_profile.py 30 > $O/forward_only.txt 2>/dev/null
+python $R/tools/forward_profile.py 30 256 >> $O/forward_only.txt 2>/dev/null
+python $R/tools/forward_profile.py 30 256 bf16 >> $O/forward_only.txt 2>/dev/null
+python $R/tools/wgrad3_micro.py > $O/wgrad3_micro.txt 2>/dev/null
+python $R/tools/wgrad3_micro.py --precision 1 >> $O/wgrad3_micro.txt 2>/dev/null
+DPP_WGRAD3_T=0 python $R/tools/wgrad3_micro.py >> $O/wgrad3_micro.txt 2>/dev/null
+# the 256 x 256 bf16 step: un-overlapped kernel durations by grid
+DPP_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace -d /tmp/p9 -o run -- python $R/tools/step_profile.py 3 256 bf16 > /dev/null 2>&1
+python $R/tools/prof_summary.py $(find /tmp/p9 -name '*_results.db' | head -1) 3 --by-grid > $O/kernels_256_bf16_by_grid.txt 2>&1
 python $R/tools/branch_probe.py > $O/branch_probe.txt 2>/dev/null
 python $R/tools/launch_rate.py > $O/launch_rate.txt 2>/dev/null
 # the other bench modes of BASELINE.json
@@ -50,5 +63,6 @@ python $R/tools/augment_bench.py --batch 4096 --iters 50 >> $O/augment_bench.jso
 cp $O/hbm_traffic.json $R/profiles/${ROUND}_hbm_traffic.json
 cp $O/mfma_busy.json $R/profiles/${ROUND}_mfma_busy.json
 cp $O/hbm_traffic_256_bf16.json $R/profiles/${ROUND}_hbm_traffic_256_bf16.json
+cp $O/hbm_traffic_forward.json $R/profiles/${ROUND}_hbm_traffic_forward.json
 python $R/bench.py > $O/bench.json 2> $O/bench.err
 ls -la $O
