@@ -55,28 +55,63 @@ __global__ __launch_bounds__(DPP_THREADS) void loss_sse_kernel(const float* __re
 // and the backward chain): out[i] = sum_z partial[z][i] + bias[i % nbias] in the slice order of reduce_partials_kernel's one-lane form,
 // then loss_sse_kernel's arithmetic on the values just written.  One workgroup; n = batch x output dimension (3 840 for the 30-D
 // embedding at batch 128).
-__global__ __launch_bounds__(DPP_THREADS) void reduce_partials_loss_kernel(const float* __restrict__ partial, int nz, int n,
+constexpr int RPL_THREADS = 1024;
+__global__ __launch_bounds__(RPL_THREADS) void reduce_partials_loss_kernel(const float* __restrict__ partial, int nz, int n,
                                                                            const float* __restrict__ bias, int nbias, float* __restrict__ out,
                                                                            const float* __restrict__ y, float inv_denom,
                                                                            float* __restrict__ cost, float* __restrict__ dout) {
-    __shared__ double s[DPP_THREADS];
+    // 1024 threads, one element quad each (3 840 outputs = 960 quads): every slice's load of a thread is issued before the first is
+    // used -- ONE memory round trip for the whole reduction (the first version walked 15 elements x 8 slices per thread of a 256-thread
+    // block, a dependent round trip per element: 0.02 ms slower per step than the two launches it replaced, profiles/r06_ab.txt)
+    __shared__ double s[RPL_THREADS / DPP_WAVE];
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += DPP_THREADS) {
-        float v = 0.0f;
-        for (int z = 0; z < nz; ++z) v += partial[(size_t)z * n + i];
-        if (bias) v += bias[i % nbias];
-        out[i] = v;
-        const float d = v - y[i];
-        acc += (double)d * (double)d;
-        if (dout) dout[i] = 2.0f * inv_denom * d;
+    const bool vec = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(y) |
+                                       reinterpret_cast<uintptr_t>(dout)) & 15) == 0;
+    if (vec) {
+        const int n4 = n >> 2;
+        for (int q = threadIdx.x; q < n4; q += RPL_THREADS) {
+            float4 v[16];
+            const int nzc = nz < 16 ? nz : 16;
+#pragma unroll
+            for (int z = 0; z < 16; ++z) v[z] = reinterpret_cast<const float4*>(partial + (size_t)(z < nzc ? z : 0) * n)[q];
+            const float4 yv = reinterpret_cast<const float4*>(y)[q];
+            // (the output dimension -- 30 for the embedding -- need not be a multiple of four: the bias element by element)
+            const int i0 = q << 2;
+            const float4 bv = bias ? make_float4(bias[i0 % nbias], bias[(i0 + 1) % nbias], bias[(i0 + 2) % nbias], bias[(i0 + 3) % nbias])
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 t = v[0];
+#pragma unroll
+            for (int z = 1; z < 16; ++z)
+                if (z < nzc) { t.x += v[z].x; t.y += v[z].y; t.z += v[z].z; t.w += v[z].w; }
+            for (int z = 16; z < nz; ++z) {
+                const float4 u = reinterpret_cast<const float4*>(partial + (size_t)z * n)[q];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            t.x += bv.x; t.y += bv.y; t.z += bv.z; t.w += bv.w;
+            reinterpret_cast<float4*>(out)[q] = t;
+            const float d0 = t.x - yv.x, d1 = t.y - yv.y, d2 = t.z - yv.z, d3 = t.w - yv.w;
+            acc += (double)d0 * (double)d0 + (double)d1 * (double)d1 + (double)d2 * (double)d2 + (double)d3 * (double)d3;
+            if (dout) reinterpret_cast<float4*>(dout)[q] = make_float4(2.0f * inv_denom * d0, 2.0f * inv_denom * d1, 2.0f * inv_denom * d2, 2.0f * inv_denom * d3);
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += RPL_THREADS) {
+            float v = 0.0f;
+            for (int z = 0; z < nz; ++z) v += partial[(size_t)z * n + i];
+            if (bias) v += bias[i % nbias];
+            out[i] = v;
+            const float d = v - y[i];
+            acc += (double)d * (double)d;
+            if (dout) dout[i] = 2.0f * inv_denom * d;
+        }
     }
-    s[threadIdx.x] = acc;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
-    for (int w = DPP_THREADS / 2; w > 0; w >>= 1) {
-        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+        for (int w = 0; w < RPL_THREADS / DPP_WAVE; ++w) tsum += s[w];
+        cost[0] = (float)(tsum * (double)inv_denom);
     }
-    if (threadIdx.x == 0) cost[0] = (float)(s[0] * (double)inv_denom);
 }
 
 // The scalar-target cost of poseregnettrainer.py:84-85, 92-93 (numJoints == nDims == 1): the net output reshaped to (B, 1) -- a
@@ -383,7 +418,7 @@ extern "C" int dpp_loss_sse(const float* out, const float* y, int rows, int d, i
 extern "C" int dpp_reduce_partials_loss(const float* partial, int nz, int rows, int d, const float* bias, float* out, const float* y, int denom,
                                         float* cost, float* dout, dpp_stream_t stream) {
     if (!partial || !out || !y || !cost || nz < 1 || rows < 1 || d < 1 || denom < 1 || (long)rows * d > 65536) return DPP_E_BADARG;
-    DPP_LAUNCH(reduce_partials_loss_kernel, dim3(1), dim3(DPP_THREADS), 0, static_cast<hipStream_t>(stream), partial, nz, rows * d, bias, d, out, y,
+    DPP_LAUNCH(reduce_partials_loss_kernel, dim3(1), dim3(RPL_THREADS), 0, static_cast<hipStream_t>(stream), partial, nz, rows * d, bias, d, out, y,
                1.0f / (float)denom, cost, dout);
     return dpp_launch_status();
 }

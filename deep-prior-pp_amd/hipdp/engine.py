@@ -446,7 +446,9 @@ class CompiledNet(object):
                     self.upd.add(op)
             # ONE launch: the update over the whole flat buffer, whose last workgroup advances t (round 6: the adam_tick launch behind
             # it was 5 us at the end of every step)
-            self.upd.add(ops.adam(rt, self.store.w, self.store.g, self.store.m, self.store.v, self.store.n_w, self.hyper, tick=True))
+            self.upd.add(ops.adam(rt, self.store.w, self.store.g, self.store.m, self.store.v, self.store.n_w, self.hyper, tick=hz.ADAM_TICKED))
+            if not hz.ADAM_TICKED:
+                self.upd.add(ops.adam_tick(rt, self.hyper))
             if self.dropout_masks:
                 self.upd.add(ops.counter_add(rt, self.step_ctr, 1))
             self._lr = None
@@ -1571,7 +1573,8 @@ class CompiledNet(object):
         for a, z in ((0, lo), (hi, n)):
             if z > a:
                 upd.add(ops.adam(rt, sl(st.w, a, z), sl(st.g, a, z), sl(st.m, a, z), sl(st.v, a, z), z - a, self.hyper))
-        upd.add(ops.adam_tick(rt, self.hyper))              # the update is several launches here: t advances behind the last of them
+        if hz.ADAM_TICKED:
+            upd.add(ops.adam_tick(rt, self.hyper))          # the update is several launches here: t advances behind the last of them
         for (op, side) in self.upd.ops:
             if getattr(op, 'name', '') != 'adam':
                 upd.add(op, side)

@@ -68,6 +68,8 @@ def gemm_plan(M, N, K, allow_split=True):
 EVAL_FUSE = knob('DPP_EVAL_FUSE', '1') != '0'
 # round 6: the cost and its gradient computed by the split-K reduction of the last HiddenLayer (dpp_reduce_partials_loss).  DPP_FUSE_LOSS=0: own launch.
 FUSE_LOSS = knob('DPP_FUSE_LOSS', '1') != '0'
+# round 6: the ADAM launch advances t itself (dpp_adam_ticked).  DPP_ADAM_TICKED=0: the adam_tick launch behind it.
+ADAM_TICKED = knob('DPP_ADAM_TICKED', '1') != '0'
 # round 6: the fused block in the bf16 mode (bf16-stored input / output).  DPP_EVAL_FUSE_BF16=0: the layer-by-layer bf16 forward (the path
 # whose every product can be pinned against the oracle: tests/test_configs.py).
 EVAL_FUSE_BF16 = knob('DPP_EVAL_FUSE_BF16', '1') != '0'
