@@ -16,6 +16,7 @@
 // Filter gradient (conv3x3_wgrad_kernel): same halo tile + the dY tile in LDS; the reduction runs over the
 // tile's pixels, out tile = [Cout][Cin] per tap, (tap, 16x16 tile) pairs are dealt round-robin to the 4
 // waves; per-workgroup partials are summed by dpp_reduce_partials in a fixed order.
+#include <stdio.h>
 #include <stdlib.h>
 #include "dpp_common.h"
 #include "conv3x3_wgrad_t.h"
@@ -50,6 +51,7 @@ struct Conv3Args {
     int tiles_x, tiles_y;
     C3Stage sg;           // staging geometry (host-computed division constants)
     unsigned long long* prof;   // phase stamps (profiling build only, see dpp_stamp)
+    int ntiles, woff;     // conv3x3_p_kernel: tiles in total (a workgroup walks several), byte offset of the weight images in LDS
 };
 
 typedef __bf16 c3_bf16x8 __attribute__((ext_vector_type(8)));
@@ -405,6 +407,186 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
     }
 }
 
+// ---- the narrow layers as a tile-WALKING kernel (round 6) -------------------------------------------------------------------------
+// conv3x3_kernel gives every 128-pixel tile a workgroup of its own: entry code, the halo's round trip to memory, the nine weight
+// slices' round trip, 18-72 MFMAs per wave, the epilogue's round trip for residual / BatchNorm input -- three dependent memory
+// latencies around a microsecond of arithmetic, hidden only by how many such workgroups a CU holds (16-channel layers at 256 x 256
+// input: 4 096 workgroups, 48 us for 58 MB = 1.2 TB/s).  Here a workgroup stages the nine weight slices ONCE and
+// walks tiles blockIdx.x, + gridDim.x, ...: the next tile's halo is requested (unconditional, clamped loads) right after the barrier that
+// publishes the current one and travels under the current tile's products and epilogue; it is committed to LDS -- prologue applied
+// there -- at the top of the next round.  Everything else is conv3x3_kernel's: same images, same tap loop, same 16-byte epilogue
+// through the LDS tile image, and the statistics partials keep ONE block per tile (dpp_epilogue_wide(blk = tile)), so callers size and
+// finalize them exactly as before.  Narrow layers only (all nine weight slices resident), the wide epilogue only.
+template <int BM, int BN, int PREC, class TX, bool EST, int SLOTS>
+__global__ __launch_bounds__(DPP_THREADS) void conv3x3_p_kernel(Conv3Args a) {
+    dpp_kernarg_warm<sizeof(Conv3Args)>();
+    HIP_DYNAMIC_SHARED(float4, smem4)
+    float* smem = reinterpret_cast<float*>(smem4);
+    typedef typename C3Prec<PREC>::elem elem;
+    constexpr int RM = BM / 64;
+    constexpr int CN = BN / 16;
+    constexpr int KSTEP = PREC ? 32 : 16;
+    const int TH = 1 << a.lth, TW = 1 << a.ltw;
+    const int Ci = a.Ci, KP = C3Prec<PREC>::kp(Ci), LDA = KP + C3Prec<PREC>::PAD;
+    const int HW2 = (TH + 2) * (TW + 2), TW2 = TW + 2;
+    const int HP = a.img * HW2;
+    elem* Ah = reinterpret_cast<elem*>(smem);
+    elem* Bs = reinterpret_cast<elem*>(reinterpret_cast<char*>(smem) + a.woff);          // [9][BN][KP+pad], behind the halo / epilogue image
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+    const int col0 = blockIdx.y * BN;
+    const TX* const Xg = reinterpret_cast<const TX*>(a.X);
+
+    dpp_wide_coef wco;
+    wco.load<BN>(col0, a.Co, a.bias, a.epi, a.Y);
+
+    // ---- halo slots of this thread: (position, channel quad), independent of the tile ----
+    const int c0 = (tid & ((1 << a.sg.lqp) - 1)) * 4;
+    const int hstep = DPP_THREADS >> a.sg.lqp;
+    const bool cld = c0 < Ci, cst = c0 < KP;           // loads / stores at all (bf16 images pad narrow layers to 32 channels with zeros)
+    int hq[SLOTS];                                     // packed (im, hy, hx) of the slot, -1 past the halo
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+        const int hp = (tid >> a.sg.lqp) + u * hstep;
+        const int im = (int)__umulhi((unsigned)hp, a.sg.m_hw2), rem = hp - im * HW2;
+        const int hy = (int)__umulhi((unsigned)rem, a.sg.m_tw2), hx = rem - hy * TW2;
+        hq[u] = hp < HP ? ((im << 16) | (hy << 8) | hx) : -1;
+    }
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
+    if (cld && (a.act.mode & 2)) {
+        mu = *reinterpret_cast<const float4*>(a.act.mean + c0);
+        sc = *reinterpret_cast<const float4*>(a.act.scale + c0);
+        be = *reinterpret_cast<const float4*>(a.act.beta + c0);
+    }
+    typedef typename std::conditional<std::is_same<TX, float>::value, float4, uint2>::type raw_t;
+    raw_t hr[SLOTS];
+    unsigned hin = 0;
+    auto fetch = [&](int tile) {
+        int n0, y0, x0;
+        tile_origin(a, tile, n0, y0, x0);
+        hin = 0;
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            const int n = n0 + (hq[u] >> 16), y = y0 + ((hq[u] >> 8) & 255) - 1, x = x0 + (hq[u] & 255) - 1;
+            const bool in = hq[u] >= 0 && cld && n < a.N && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            hin |= in ? (1u << u) : 0u;
+            const TX* p = Xg + (in ? (((size_t)n * a.H + y) * a.W + x) * Ci + c0 : (size_t)0);
+            hr[u] = *reinterpret_cast<const raw_t*>(p);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < SLOTS; ++u) {
+            if (hq[u] < 0 || !cst) continue;
+            float4 t;
+            if constexpr (std::is_same<TX, float>::value) t = hr[u];
+            else t = make_float4(__uint_as_float(hr[u].x << 16), __uint_as_float(hr[u].x & 0xffff0000u), __uint_as_float(hr[u].y << 16),
+                                 __uint_as_float(hr[u].y & 0xffff0000u));
+            if ((hin >> u) & 1u) {                       // zero padding is applied AFTER the activation
+                if (a.act.mode & 2) {
+                    t.x = dpp_fma(t.x - mu.x, sc.x, be.x); t.y = dpp_fma(t.y - mu.y, sc.y, be.y);
+                    t.z = dpp_fma(t.z - mu.z, sc.z, be.z); t.w = dpp_fma(t.w - mu.w, sc.w, be.w);
+                }
+                if (a.act.mode & 1) { t.x = fmaxf(t.x, 0.0f); t.y = fmaxf(t.y, 0.0f); t.z = fmaxf(t.z, 0.0f); t.w = fmaxf(t.w, 0.0f); }
+            } else t = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int hp = (tid >> a.sg.lqp) + u * hstep;
+            c3_store4(&Ah[hp * LDA + c0], t);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) fetch(tile);
+    // ---- all nine weight slices, once ----
+    {
+        constexpr int WSLOTS = (BN * 16 + DPP_THREADS - 1) / DPP_THREADS;
+#pragma unroll
+        for (int t3 = 0; t3 < 9; t3 += 3) {
+            float4 w3[3][WSLOTS];
+            int wo[WSLOTS];
+#pragma unroll
+            for (int s = 0; s < WSLOTS; ++s) {
+                const int slot = tid + s * DPP_THREADS;
+                const int j = slot >> a.sg.lqp, cc = (slot & ((1 << a.sg.lqp) - 1)) * 4;
+                wo[s] = (j < BN && cc < KP) ? j * LDA + cc : -1;
+                const bool ld = j < BN && cc < Ci && col0 + j < a.Co;
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    w3[u][s] = ld ? *reinterpret_cast<const float4*>(a.Wk + (size_t)(col0 + j) * 9 * Ci + cc + (t3 + u) * Ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+#pragma unroll
+                for (int s = 0; s < WSLOTS; ++s)
+                    if (wo[s] >= 0) c3_store4(&Bs[(t3 + u) * BN * LDA + wo[s]], w3[u][s]);
+        }
+    }
+    int hbase[RM];
+#pragma unroll
+    for (int rt = 0; rt < RM; ++rt) {
+        const int row = wave * (BM / 4) + rt * 16 + l15;
+        const int im = row >> (a.lth + a.ltw);
+        const int ty = (row >> a.ltw) & (TH - 1);
+        const int tx = row & (TW - 1);
+        hbase[rt] = (im * (TH + 2) + ty + 1) * (TW + 2) + tx + 1;
+    }
+    for (; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();                               // the previous tile's epilogue is done with the image that shares the halo's space
+        commit();
+        __syncthreads();                               // halo (and, first round, the weight slices) visible
+        int n0, y0, x0;
+        tile_origin(a, tile, n0, y0, x0);
+        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+        f32x4 acc[RM][CN];
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int j = 0; j < CN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const elem* Bcur = Bs + tap * BN * LDA;
+            const int toff = (tap / 3 - 1) * (TW + 2) + (tap % 3 - 1);
+            for (int kc = 0; kc < KP; kc += KSTEP) {
+                if constexpr (PREC == 0) {
+                    float4 av[RM], bv[CN];
+#pragma unroll
+                    for (int rt = 0; rt < RM; ++rt) av[rt] = *reinterpret_cast<const float4*>(&Ah[(hbase[rt] + toff) * LDA + kc + kq * 4]);
+#pragma unroll
+                    for (int ct = 0; ct < CN; ++ct) bv[ct] = *reinterpret_cast<const float4*>(&Bcur[(ct * 16 + l15) * LDA + kc + kq * 4]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                            for (int ct = 0; ct < CN; ++ct)
+                                acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(dpp_f4_get(av[rt], t), dpp_f4_get(bv[ct], t), acc[rt][ct], 0, 0, 0);
+                } else {
+                    c3_bf16x8 av[RM], bv[CN];
+#pragma unroll
+                    for (int rt = 0; rt < RM; ++rt) av[rt] = *reinterpret_cast<const c3_bf16x8*>(&Ah[(hbase[rt] + toff) * LDA + kc + kq * 8]);
+#pragma unroll
+                    for (int ct = 0; ct < CN; ++ct) bv[ct] = *reinterpret_cast<const c3_bf16x8*>(&Bcur[(ct * 16 + l15) * LDA + kc + kq * 8]);
+#pragma unroll
+                    for (int rt = 0; rt < RM; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < CN; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rt], bv[ct], acc[rt][ct], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                               // the epilogue's image takes the halo's place
+        const int vi = (a.N - n0 < a.img) ? (a.N - n0) : a.img;
+        const int vy = (a.H - y0 < TH) ? (a.H - y0) : TH;
+        const int vx = (a.W - x0 < TW) ? (a.W - x0) : TW;
+        dpp_epilogue_wide<RM, CN, 4, 1, BM, BN, 1, EST>(acc, smem, col0, a.Co, wco, a.residual, a.Y, a.epi, vi * vy * vx, wave, 0, l15, kq,
+                                                [&](int rl) {
+            const int im = rl >> (a.lth + a.ltw);
+            const int ty = (rl >> a.ltw) & (TH - 1);
+            const int tx = rl & (TW - 1);
+            const int n = n0 + im, y = y0 + ty, x = x0 + tx;
+            const bool ok = !(im >= a.img || n >= a.N || y >= a.H || x >= a.W);
+            return ok ? (long)((((size_t)n * a.H + y) * a.W + x) * a.Co) : -1L;
+        }, 0, a.store, tile, a.ntiles);
+    }
+}
+
 // Wd[c][8 - tap][o] = Wk[o][tap][c]: the weights of the data-gradient correlation (mirrored taps, channels swapped)
 __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wtrans_kernel(const float* __restrict__ Wk, int Co, int Ci, float* __restrict__ Wd) {
     int n = Co * 9 * Ci;
@@ -619,6 +801,33 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, dpp_cdiv(Co, bn));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // the tile-walking form for the narrow layers (conv3x3_p_kernel): all nine weight slices resident, the 16-byte epilogue, whole
+    // column tiles, and more tiles than workgroups so that there is a next halo to fetch under the current tile.  DPP_C3_PERSIST = the
+    // number of workgroups per column tile (0: off; default 512)
+    const char* pe = getenv("DPP_C3_PERSIST");          // (read per call: the tests switch it)
+    const int persist = pe ? atoi(pe) : 512;
+    if (persist > 0 && a.allw && a.wide && Ci <= 32 && bm == 128 && Co % bn == 0 && nblk > persist && a.img == 1) {
+        const size_t region0 = (halo * rowb > need ? halo * rowb : need);
+        a.woff = (int)((region0 + 15) & ~(size_t)15);
+        a.ntiles = nblk;
+        const size_t ldsp = (size_t)a.woff + 9 * bn * rowb;
+        const int hstep = DPP_THREADS >> a.sg.lqp;
+        const int slots = dpp_cdiv((int)halo, hstep);
+        if (ldsp <= 64 * 1024 && slots <= 6) {
+            const dim3 gp(persist, dpp_cdiv(Co, bn));
+            if (getenv("DPP_C3_PERSIST_VERBOSE")) fprintf(stderr, "conv3x3_p_kernel: %d tiles on %d workgroups, C %d, bn %d, prec %d, store %d\n", nblk, persist, Ci, bn, precision, store);
+#define DPP_C3P(BN_, P_, T_, E_) do { if (slots <= 3) DPP_LAUNCH((conv3x3_p_kernel<128, BN_, P_, T_, E_, 3>), gp, dim3(DPP_THREADS), ldsp, st, a); \
+                                       else DPP_LAUNCH((conv3x3_p_kernel<128, BN_, P_, T_, E_, 6>), gp, dim3(DPP_THREADS), ldsp, st, a); return dpp_launch_status(); } while (0)
+#define DPP_C3PE(BN_, P_, T_) do { if (store & (DPP_ST_C | DPP_ST_BNX)) DPP_C3P(BN_, P_, T_, true); else DPP_C3P(BN_, P_, T_, false); } while (0)
+#define DPP_C3PX(BN_) if (bn == BN_) { \
+            if (precision) { if (store & DPP_ST_A) DPP_C3PE(BN_, 1, dpp_bf16); else DPP_C3PE(BN_, 1, float); } \
+            if (store & DPP_ST_A) DPP_C3PE(BN_, 0, dpp_bf16); else DPP_C3PE(BN_, 0, float); }
+            DPP_C3PX(16) DPP_C3PX(32)
+#undef DPP_C3PX
+#undef DPP_C3PE
+#undef DPP_C3P
+        }
+    }
     // gfx950 has 160 KiB of LDS per CU; requests above the default 64 KiB window need the opt-in attribute
 #define DPP_C3K(BM_, BN_, P_, T_, E_) do { \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<BM_, BN_, P_, T_, E_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

@@ -322,7 +322,10 @@ struct dpp_wide_coef {
 template <int RM, int CN, int WM, int WN, int BM, int BN, int NIMG = 1, bool ST = false, class RowOff>
 __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* smem, int col0, int N, dpp_wide_coef& co,
                                                   const float* residual, float* C, const dpp_epilogue& ep, int nvalid, int wm,
-                                                  int wn, int l15, int kq, RowOff rowoff, int img = 0, int store = 0) {
+                                                  int wn, int l15, int kq, RowOff rowoff, int img = 0, int store = 0, int blk = -1, int nblk = 0) {
+    // (blk, nblk): the row block this tile is in the statistics partials -- by default the workgroup's own index; a workgroup that walks
+    // several tiles (conv3x3_p_kernel) passes the tile's
+    const int pblk = blk >= 0 ? blk : (int)blockIdx.x, pnblk = blk >= 0 ? nblk : (int)gridDim.x;
     const bool c16 = ST && (store & DPP_ST_C) != 0, x16 = ST && (store & DPP_ST_BNX) != 0;
     co.finish();
     constexpr int LDT = BN + 4;
@@ -422,8 +425,8 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
         if (tid < Q && cin) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ep.bn_partial[dpp_partial_index(0, col + j, blockIdx.x, N, gridDim.x)] = sx[j];
-                ep.bn_partial[dpp_partial_index(1, col + j, blockIdx.x, N, gridDim.x)] = sy[j];
+                ep.bn_partial[dpp_partial_index(0, col + j, pblk, N, pnblk)] = sx[j];
+                ep.bn_partial[dpp_partial_index(1, col + j, pblk, N, pnblk)] = sy[j];
             }
         }
     }
@@ -460,8 +463,8 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
         if (tid < Q && cin) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ep.stats[dpp_partial_index(0, col + j, blockIdx.x, N, gridDim.x)] = sm[j];
-                ep.stats[dpp_partial_index(1, col + j, blockIdx.x, N, gridDim.x)] = m2[j];
+                ep.stats[dpp_partial_index(0, col + j, pblk, N, pnblk)] = sm[j];
+                ep.stats[dpp_partial_index(1, col + j, pblk, N, pnblk)] = m2[j];
             }
         }
     }

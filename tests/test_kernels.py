@@ -134,6 +134,46 @@ def test_conv3x3_filter_gradient_on_transposed_images(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
+@pytest.mark.parametrize('cfg', [(3, 16, 32, 16, 0, 0), (2, 9, 20, 16, 0, 1), (3, 16, 16, 32, 0, 0), (2, 24, 16, 32, 1, 1), (3, 16, 32, 16, 1, 1)],
+                         ids=lambda c: 'x'.join(str(v) for v in c))
+def test_tile_walking_conv3x3_equals_one_workgroup_per_tile(backend, cfg, monkeypatch):
+    """conv3x3_p_kernel (round 6: a workgroup stages the nine weight slices once and walks tiles, the next halo in flight) against
+    conv3x3_kernel on the same problem: the same images, tap loop and epilogue, so the output, the fused BatchNorm statistics and the
+    BatchNorm-backward sums are BIT-identical -- forward with prologue + statistics, data gradient with the BatchNorm-backward epilogue,
+    whole and ragged maps, float32 and bf16 operands, float32 and bf16-stored tensors, more tiles than workgroups."""
+    from tests.test_bf16_store import both, _bn_coeffs
+    rt = get_runtime(backend)
+    N, H, W, Cc, prec, st16 = cfg
+    rng = np.random.RandomState(41)
+    x16, x32 = both(rt, rng.normal(size=(N, H, W, Cc)) + 0.2)
+    X = x16 if st16 else x32
+    Wk = rt.upload((rng.normal(size=(Cc, 9, Cc)) * 0.2).astype(np.float32))
+    bias = rt.upload(rng.normal(size=Cc).astype(np.float32))
+    mean, scale, beta = (rt.upload(v.astype(np.float32)) for v in (rng.normal(size=Cc) * 0.3, rng.uniform(0.5, 1.5, Cc), rng.normal(size=Cc) * 0.3))
+    act = ops.act(Act.BN_RELU, mean, scale, beta, Cc)
+    ntiles = rt.lib.dpp_conv3x3_tiling(N, H, W, 128, None, None, None)
+    assert ntiles > 3
+    bx16, bx32 = both(rt, rng.normal(size=(N, H, W, Cc)))
+    bn = _bn_coeffs(rt, rng, Cc)
+    dy16, dy32 = both(rt, rng.normal(size=(N, H, W, Cc)))
+    got = {}
+    for mode in ('0', '3'):
+        monkeypatch.setenv('DPP_C3_PERSIST', mode)
+        Y = rt.alloc((N, H, W, Cc), np.uint16 if st16 else np.float32, zero=False)
+        stats = rt.alloc((ntiles, 2, Cc), zero=False)
+        ops.conv3x3(rt, X, N, H, W, Cc, Wk, Cc, Y, actX=act, bias=bias, bm=128, epi=ops.epilogue(stats=stats), precision=prec)(rt.stream)
+        dX = rt.alloc((N, H, W, Cc), np.uint16 if st16 else np.float32, zero=False)
+        part = rt.alloc((ntiles, 2, Cc), zero=False)
+        ops.conv3x3(rt, dy16 if st16 else dy32, N, H, W, Cc, Wk, Cc, dX, bm=128, precision=prec,
+                    epi=ops.epilogue(bn=bn, bn_x=bx16 if st16 else bx32, bn_relu=True, bn_partial=part))(rt.stream)
+        rt.synchronize()
+        got[mode] = (Y.get(), stats.get(), dX.get(), part.get())
+    for a, b in zip(got['0'], got['3']):
+        assert np.array_equal(a, b)
+    assert np.isfinite(got['3'][1]).all() and np.abs(got['3'][0].astype(np.float64)).max() > 0
+
+
+@pytest.mark.parametrize('backend', BACKENDS)
 def test_batchnorm_finalize_with_an_outlier_first_block(backend):
     """the one-pass finalize takes the block means about a PIVOT (block 0's mean) and subtracts S1^2 / M -- what cancels is the
     spread of the block means about that pivot.  Block 0 a constant far-plane background block (mean 1.0, no variance) in front of blocks of
