@@ -803,9 +803,11 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     hipStream_t st = static_cast<hipStream_t>(stream);
     // the tile-walking form for the narrow layers (conv3x3_p_kernel): all nine weight slices resident, the 16-byte epilogue, whole
     // column tiles, and more tiles than workgroups so that there is a next halo to fetch under the current tile.  DPP_C3_PERSIST = the
-    // number of workgroups per column tile (0: off; default 512)
+    // number of workgroups per column tile (0: off; default 1024: same-box A/B, tools/ab_c3p.sh -- bf16 256 x 256 step 7.377 / 7.451 (off), 7.634 / 7.714 (256),
+    // 7.315 / 7.370 (512), 7.311 / 7.367 (1024), 7.335 / 7.394 (2048); float32 128 x 128 (1 024 tiles): 3.392 / 3.409 (off), 3.461 / 3.471 (256), 3.399 / 3.413 (512):
+    // there the occupancy of one workgroup per tile already hides what the walk hides, so it stays on conv3x3_kernel)
     const char* pe = getenv("DPP_C3_PERSIST");          // (read per call: the tests switch it)
-    const int persist = pe ? atoi(pe) : 512;
+    const int persist = pe ? atoi(pe) : 1024;
     if (persist > 0 && a.allw && a.wide && Ci <= 32 && bm == 128 && Co % bn == 0 && nblk > persist && a.img == 1) {
         const size_t region0 = (halo * rowb > need ? halo * rowb : need);
         a.woff = (int)((region0 + 15) & ~(size_t)15);
