@@ -32,7 +32,7 @@ namespace {
 // ST: the instantiation may meet bf16-stored tensors (the float32 ones carry none of the run-time type tests).
 template <int KT, bool BKC, bool IT2, bool ACT, bool RES, bool BNB, bool LZ = false, bool PB = false, bool ST = false>
 __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expand_kernel(GemmArgs ga, int rpw) {
-    static_assert(!PB || (KT % 32 == 0 && !LZ), "bf16 MFMA operands: whole 32-deep steps");
+    static_assert(!PB || ((KT % 32 == 0 || KT == 16) && !LZ), "bf16 MFMA operands: whole 32-deep steps, or K = 16 with a zero upper half");
     dpp_kernarg_warm<sizeof(GemmArgs)>();
     const dpp_gemm_desc& d = ga.d;
     constexpr int KL = KT / 4, KV = KL / 4;                  // k values / 16-byte vectors of a lane
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
             bw[0][e] = t.x; bw[1][e] = t.y; bw[2][e] = t.z; bw[3][e] = t.w;
         }
     }
-    constexpr int KS = PB ? KL / 8 : 1;                      // 8-element bf16 operands per lane and accumulator tile
+    constexpr int KS = PB ? (KL + 7) / 8 : 1;                // 8-element bf16 operands per lane and accumulator tile (K = 16: 4 values + 4 zeros)
     dpp_bf16x8 bwp[4][KS];
     if (PB) {
 #pragma unroll
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
 #pragma unroll
             for (int ss = 0; ss < KS; ++ss)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) bwp[ct][ss][q] = (dpp_bf16)bw[ct][ss * 8 + q];
+                for (int q = 0; q < 8; ++q) bwp[ct][ss][q] = (dpp_bf16)(ss * 8 + q < KL ? bw[ct][ss * 8 + q < KL ? ss * 8 + q : 0] : 0.0f);
     }
     struct Regs { float4 a[RT][KV]; float4 a2[RT][LZ ? KV : 1]; float4 res[RT][4]; float4 bx[RT][4]; };
     auto fetch = [&](Regs& g, int it) {
@@ -142,6 +142,12 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[rt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         dpp_bf16x8 ap[RT][KS];
+        if (PB && KL < 8) {                                  // K = 16: the upper half of the 32-deep step is zero
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ap[rt][0][q] = (dpp_bf16)0.0f;
+        }
 #pragma unroll
         for (int j = 0; j < KV; ++j) {
             float av[RT][4];
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, 2) void gemm_expan
                 }
             }
             if (PB) {
-                if (j & 1) {                                 // the 8 k values 8 (j/2) .. +7 of every row tile are complete: one 32-deep step
+                if ((j & 1) || KL < 8) {                     // the 8 k values 8 (j/2) .. +7 of every row tile are complete: one 32-deep step
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -305,7 +311,7 @@ int dpp_gemm_expand_rows(const dpp_gemm_desc& d, const GemmArgs& ga) {
     // gradient) with a plain or a mode-4 operand (gemm_prepare has checked mode 4's vectors and alignment)
     if (d.b_kc ? (d.epi.bn_x != nullptr || (d.actA.mode & 4)) : (d.actA.mode != 0 && d.actA.mode != 4)) return 0;
     if (d.actA.mode == 4 && d.actA.out && d.lda != d.K) return 0;
-    if (d.precision != 0 && (d.precision != 1 || d.K < 32 || (d.actA.mode & 4))) return 0;      // bf16 MFMA operands: K = 32 / 64, no mode-4 operand
+    if (d.precision != 0 && (d.precision != 1 || (d.actA.mode & 4))) return 0;      // bf16 MFMA operands (round 6: K = 16 too, zero upper half): no mode-4 operand
     int rpw = d.bm;
     if (rpw <= 0) rpw = d.M >= 65536 ? 128 : (d.M >= 16384 ? 64 : 32);
     if (rpw % 32 || d.M % rpw) return 0;
@@ -324,7 +330,7 @@ int launch_expand(const GemmArgs& ga, int rpw, hipStream_t st) {
     const bool stg = d.store != 0;
 #define DPP_EXS(K_, I_, A_, R_, B_, L_, P_, S_) DPP_LAUNCH((gemm_expand_kernel<KT, K_, I_, A_, R_, B_, L_, P_, S_>), grid, dim3(DPP_THREADS), 0, st, ga, rpw)
 #define DPP_EX(K_, I_, A_, R_, B_, L_, P_) do { if (!(L_) && stg) DPP_EXS(K_, I_, A_, R_, B_, L_, P_, !(L_)); else DPP_EXS(K_, I_, A_, R_, B_, L_, P_, false); } while (0)
-#define DPP_EX_P(K_, I_, A_, R_, B_) do { if constexpr (KT >= 32) { if (pb) { DPP_EX(K_, I_, A_, R_, B_, false, true); break; } } \
+#define DPP_EX_P(K_, I_, A_, R_, B_) do { if (pb) { DPP_EX(K_, I_, A_, R_, B_, false, true); break; } \
                                           DPP_EX(K_, I_, A_, R_, B_, false, false); } while (0)
 #define DPP_EX_I(K_, A_, R_, B_, L_) do { if (L_) { if (it2) DPP_EX(K_, true, A_, R_, B_, true, false); else DPP_EX(K_, false, A_, R_, B_, true, false); } \
                                           else if (it2) DPP_EX_P(K_, true, A_, R_, B_); else DPP_EX_P(K_, false, A_, R_, B_); } while (0)

@@ -63,8 +63,13 @@ __device__ __forceinline__ void load_vec(const float* p, float (&v)[V]) {
 
 // TA = Co / 16, TB = Ci / 16 (vector lengths of a full row per lane); the 4 waves split A channels WA ways, B channels WB ways and
 // rows WR = 4 / (WA * WB) ways.  VA = TA / WA, VB = TB / WB floats per lane and operand; VA * VB accumulator tiles per wave.
-template <int TA, int TB, int WA, int WB, int U, bool STRIDED, class TX = float, class TY = float>
+// PB (round 6, dpp_wgrad_stream_bf16): both operands rounded to bfloat16 (the activation after its prologue), the eight stages of a ring
+// round -- lane (i, kq) holds pixel rows m0 + 4 u + kq, u = 0 .. 7 -- packed into ONE v_mfma_f32_16x16x32_bf16 operand per output tile
+// (the same pixel for element u on the dY and on the X side, which is all the reduction needs); the ring, the loads and the epilogue are
+// the float32 kernel's.
+template <int TA, int TB, int WA, int WB, int U, bool STRIDED, class TX = float, class TY = float, bool PB = false>
 __global__ __launch_bounds__(DPP_THREADS) void wgrad_stream_kernel(WgradArgs a) {
+    static_assert(!PB || U == 8, "bf16 operands: eight stages per MFMA");
     constexpr int WR = 4 / (WA * WB), VA = TA / WA, VB = TB / WB;
     static_assert(WA * WB * WR == 4 && VA >= 1 && VB >= 1 && VA <= 4 && VB <= 8, "wave split");
     dpp_kernarg_warm<sizeof(WgradArgs)>();
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(DPP_THREADS) void wgrad_stream_kernel(WgradArgs a) 
     // use makes the compiler wait for all outstanding loads (s_waitcnt vmcnt(0)) at the merge point.
     float av[U][VA], bv[U][VB];
     bool okv[U];
+    dpp_bf16x8 pa[PB ? VA : 1], pb[PB ? VB : 1];
     const int last = row_end - 1;
     auto fetch = [&](int u, int m0) {
         const int m = m0 + kq;
@@ -121,10 +127,23 @@ __global__ __launch_bounds__(DPP_THREADS) void wgrad_stream_kernel(WgradArgs a) 
                 DPP_SCHED_FENCE();
                 fetch(u, m0 + 4 * (U + u));                               // refill: the step U ahead
                 DPP_SCHED_FENCE();
+                if constexpr (PB) {
 #pragma unroll
-                for (int e = 0; e < VA; ++e)
+                    for (int e = 0; e < VA; ++e) pa[e][u] = (dpp_bf16)aq[e];
 #pragma unroll
-                    for (int f = 0; f < VB; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[e], bq[f], acc[e][f], 0, 0, 0);
+                    for (int f = 0; f < VB; ++f) pb[f][u] = (dpp_bf16)bq[f];
+                    if (u == U - 1) {
+#pragma unroll
+                        for (int e = 0; e < VA; ++e)
+#pragma unroll
+                            for (int f = 0; f < VB; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[e], pb[f], acc[e][f], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VA; ++e)
+#pragma unroll
+                        for (int f = 0; f < VB; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[e], bq[f], acc[e][f], 0, 0, 0);
+                }
             }
         }
     }
@@ -374,8 +393,27 @@ extern "C" int dpp_wgrad_stream_slices(int Co, int Ci, int M, int rows_per_wave)
     return dpp_cdiv(M, rows_per_wave * WR) * WR;
 }
 
+static int wgrad_stream_launch(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
+                               int rows_per_wave, float* partial, int store, int precision, dpp_stream_t stream);
+
 extern "C" int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
                                 int rows_per_wave, float* partial, int store, dpp_stream_t stream) {
+    return wgrad_stream_launch(dY, Co, X, Ci, mapX, actX, M, rows_per_wave, partial, store, 0, stream);
+}
+
+// bf16 MFMA operands: the stage-1 shapes (16 / 64 output x 16 / 32 / 64 input channels), the layers the engine puts on this kernel
+extern "C" int dpp_wgrad_stream_bf16_ok(int Co, int Ci) {
+    return ((Co == 16 && (Ci == 64 || Ci == 32)) || (Co == 64 && (Ci == 16 || Ci == 32))) ? 1 : 0;
+}
+
+extern "C" int dpp_wgrad_stream_bf16(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
+                                     int rows_per_wave, float* partial, int store, dpp_stream_t stream) {
+    if (!dpp_wgrad_stream_bf16_ok(Co, Ci)) return DPP_E_UNSUPPORTED;
+    return wgrad_stream_launch(dY, Co, X, Ci, mapX, actX, M, rows_per_wave, partial, store, 1, stream);
+}
+
+static int wgrad_stream_launch(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
+                               int rows_per_wave, float* partial, int store, int precision, dpp_stream_t stream) {
     if (!dY || !X || !partial || (store & ~(DPP_ST_A | DPP_ST_B))) return DPP_E_BADARG;
     const bool x16 = (store & DPP_ST_B) != 0, y16 = (store & DPP_ST_A) != 0;
     const int nsl = dpp_wgrad_stream_slices(Co, Ci, M, rows_per_wave);
@@ -393,6 +431,14 @@ extern "C" int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci,
     const dim3 grid(nsl / WR), block(DPP_THREADS);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define DPP_WGK(CO_, CI_, WA_, WB_, U_, S_, TX_, TY_) DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, WA_, WB_, U_, S_, TX_, TY_>), grid, block, 0, st, a)
+#define DPP_WGKB(CO_, CI_, S_, TX_, TY_) DPP_LAUNCH((wgrad_stream_kernel<CO_ / 16, CI_ / 16, 1, 1, 8, S_, TX_, TY_, true>), grid, block, 0, st, a)
+#define DPP_WGSB(CO_, CI_, TX_, TY_) do { if (a.mapX.s != 1) DPP_WGKB(CO_, CI_, true, TX_, TY_); else DPP_WGKB(CO_, CI_, false, TX_, TY_); } while (0)
+#define DPP_WGB(CO_, CI_) if (precision && Co == CO_ && Ci == CI_) { \
+        if (x16) { if (y16) DPP_WGSB(CO_, CI_, dpp_bf16, dpp_bf16); else DPP_WGSB(CO_, CI_, dpp_bf16, float); } \
+        else { if (y16) DPP_WGSB(CO_, CI_, float, dpp_bf16); else DPP_WGSB(CO_, CI_, float, float); } \
+        return dpp_launch_status(); }
+    DPP_WGB(16, 64) DPP_WGB(64, 16) DPP_WGB(16, 32) DPP_WGB(64, 32)
+    if (precision) return DPP_E_UNSUPPORTED;
 #define DPP_WGS(CO_, CI_, WA_, WB_, U_, TX_, TY_) do { if (a.mapX.s != 1) DPP_WGK(CO_, CI_, WA_, WB_, U_, true, TX_, TY_); \
                                                        else DPP_WGK(CO_, CI_, WA_, WB_, U_, false, TX_, TY_); } while (0)
 #define DPP_WG(CO_, CI_, WA_, WB_, U_) if (Co == CO_ && Ci == CI_) { \
@@ -414,6 +460,9 @@ extern "C" int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci,
 #undef DPP_WG
 #undef DPP_WGS
 #undef DPP_WGK
+#undef DPP_WGB
+#undef DPP_WGSB
+#undef DPP_WGKB
     return DPP_E_UNSUPPORTED;
 }
 

@@ -361,8 +361,9 @@ class BackwardMixin(object):
                 # (workgroup, row split), all of them summed by the pass's single reduction launch
                 nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rpw)
                 part = rt.alloc(nsl * Co * Ci, zero=False)
+                p16 = int(bool(self._gemm_prec(0, M, role='wgrad') and rt.lib.dpp_wgrad_stream_bf16_ok(Co, Ci)))       # bf16 mode: bf16 MFMA operands
                 self.bwd.add(ops.wgrad_stream(rt, dy, Co, src.base.buf, Ci, M, rpw, part, mapX=mp, actX=act,
-                                              name='wgrad1x1_%d' % layer.layerNum), side=True)
+                                              name='wgrad1x1_%d' % layer.layerNum, precision=p16), side=True)
                 self.reduce_jobs.add(part, nsl, Co * Ci, gW)
                 return
             tile, splitk = hz.wgrad_plan(Co, Ci, M)

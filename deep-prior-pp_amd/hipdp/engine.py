@@ -222,7 +222,7 @@ class CompiledNet(BackwardMixin):
         if not (self.prec and hz.BF16_GEMM) or lazy or variant == 1:
             return 0
         if variant == 4:
-            return int(K >= 32)
+            return int(K >= 32 or (K == 16 and hz.BF16_GEMM_ALL))          # (K = 16: a 32-deep step with a zero upper half, round 6)
         if not hz.BF16_GEMM_ALL or role not in hz.BF16_GEMM_ROLES or str(variant) not in hz.BF16_GEMM_VARIANTS:
             return 0
         return int(variant in (2, 3) or K > 16)

@@ -129,6 +129,8 @@ SIGNATURES = {
     'dpp_wgrad_stream': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_fc_wgrad_stream_ok': (C.c_int, [C.c_int, C.c_int, C.c_int]),
     'dpp_fc_wgrad_stream': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, stream_t]),
+    'dpp_wgrad_stream_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, stream_t]),
+    'dpp_wgrad_stream_bf16_ok': (C.c_int, [C.c_int, C.c_int]),
     'dpp_wgrad3_stream_slices': (C.c_int, [C.c_int] * 6),
     'dpp_wgrad3_stream': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, stream_t]),
     'dpp_wtrans_job_bytes': (C.c_size_t, []),

@@ -310,11 +310,13 @@ def gemm_variant_rows(rt, launch):
     return int(rt.lib.dpp_gemm_variant_rows(C.byref(launch.keep[0])))
 
 
-def wgrad_stream(rt, dY, Co, X, Ci, M, rows_per_wave, partial, mapX=None, actX=None, name='wgrad_stream'):
-    """dpp_wgrad_stream: the filter gradient of a 1x1 convolution as per-slice partials [slices][Co][Ci]."""
+def wgrad_stream(rt, dY, Co, X, Ci, M, rows_per_wave, partial, mapX=None, actX=None, name='wgrad_stream', precision=0):
+    """dpp_wgrad_stream: the filter gradient of a 1x1 convolution as per-slice partials [slices][Co][Ci] (precision 1: bf16 MFMA operands,
+    dpp_wgrad_stream_bf16, the shapes dpp_wgrad_stream_bf16_ok accepts)."""
     nsl = rt.lib.dpp_wgrad_stream_slices(Co, Ci, M, rows_per_wave)
-    meta = dict(kernel='gemm_mfma_f32', flops=2.0 * M * Co * Ci, bytes=4.0 * (M * Co + nsl * Co * Ci) + _esz(X) * M * Ci)
-    return Launch(rt.lib.dpp_wgrad_stream, (dY.ptr, int(Co), X.ptr, int(Ci), C.byref(mapX) if mapX is not None else None, _actp(actX), int(M),
+    meta = dict(kernel='gemm_mfma_bf16' if precision else 'gemm_mfma_f32', flops=2.0 * M * Co * Ci,
+                bytes=_esz(dY) * M * Co + 4.0 * nsl * Co * Ci + _esz(X) * M * Ci)
+    return Launch(rt.lib.dpp_wgrad_stream_bf16 if precision else rt.lib.dpp_wgrad_stream, (dY.ptr, int(Co), X.ptr, int(Ci), C.byref(mapX) if mapX is not None else None, _actp(actX), int(M),
                                             int(rows_per_wave), partial.ptr, _store(a=dY, b=X)), (dY, X, partial, mapX, actX), name, meta)
 
 

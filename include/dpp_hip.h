@@ -164,6 +164,11 @@ int dpp_gemm_variant_rows(const dpp_gemm_desc* d);
 int dpp_wgrad_stream_slices(int Co, int Ci, int M, int rows_per_wave);
 int dpp_wgrad_stream(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
                      int rows_per_wave, float* partial, int store /* DPP_ST_B: X, DPP_ST_A: dY hold bf16 */, dpp_stream_t stream);
+/* (ABI v11) the same with both operands on bf16 MFMA (the activation rounded after its prologue); the stage-1 shapes only
+ * (dpp_wgrad_stream_bf16_ok: Co in {16, 64} with Ci in {16, 32, 64}), DPP_E_UNSUPPORTED otherwise.  Same slices / partial layout. */
+int dpp_wgrad_stream_bf16_ok(int Co, int Ci);
+int dpp_wgrad_stream_bf16(const float* dY, int Co, const float* X, int Ci, const dpp_rowmap* mapX, const dpp_act* actX, int M,
+                     int rows_per_wave, float* partial, int store /* DPP_ST_B: X, DPP_ST_A: dY hold bf16 */, dpp_stream_t stream);
 
 /* Filter gradient of a 3x3 'half'-padded, stride-1 ConvLayer on the same kind of stream:
  *   partial[s][o][t][c] = sum over the pixels p of slice s of  dY[p][o] * act(X)[p + (dy, dx)][c],  t = 3 (dy + 1) + (dx + 1),

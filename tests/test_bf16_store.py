@@ -523,10 +523,16 @@ def test_expand_kernel_on_bf16_mfma_operands(backend, cfg, stored):
     keep = ((bnx.astype('f8') - bn.mean.get()) * bn.scale.get() + bn.beta_buf.get()) >= 0
     g = np.where(keep, widen(dY16.get()).reshape(M, K).astype('f8') @ widen(bf16_bits(W2)).astype('f8'), 0.0)
     np.testing.assert_allclose(dH.get(), g, rtol=0, atol=3e-6 * np.sqrt(K) * np.abs(g).max())
-    # refused where it is not built
-    A16k = rt.alloc((M, 16))
-    assert ops.gemm_variant_rows(rt, ops.gemm(rt, A16k, rt.alloc((64, 16)), rt.alloc((M, 64)), M, 64, 16, 1, 1, 16, 16, 64, tile=(32, 64, 4), variant=4,
-                                              precision=1)) == 0
+    # K = 16 (round 6): one 32-deep step whose upper half is zero
+    x16k = (rng.normal(size=(M, 16))).astype(np.float32)
+    w16k = (rng.normal(size=(64, 16)) * 0.3).astype(np.float32)
+    Y16k = rt.alloc((M, 64), zero=False)
+    L16 = ops.gemm(rt, rt.upload(x16k), rt.upload(w16k), Y16k, M, 64, 16, 1, 1, 16, 16, 64, tile=(32, 64, 4), variant=4, precision=1)
+    assert ops.gemm_variant_rows(rt, L16) == 32
+    L16(rt.stream)
+    rt.synchronize()
+    r16 = widen(bf16_bits(x16k)).astype('f8') @ widen(bf16_bits(w16k)).astype('f8').T
+    np.testing.assert_allclose(Y16k.get(), r16, rtol=0, atol=3e-6 * 4 * np.abs(r16).max())
     with pytest.raises(Exception):          # the row-stream kernel (variant 1) has no bf16 path
         ops.gemm(rt, X32, rt.upload(Wk), rt.alloc((M, N)), M, N, K, 1, 1, K, K, N, precision=1, variant=1, tile=(64, 64, 4))(rt.stream)
 
@@ -580,6 +586,24 @@ def test_gemm_tile_ksplit_and_stream_kernels_on_bf16_mfma_operands(backend, stor
     rt.synchronize()
     g = widen(dY16.get()).reshape(M, K).astype('f8') @ q(W2)
     np.testing.assert_allclose(dH.get(), g, rtol=0, atol=3e-6 * np.sqrt(K) * np.abs(g).max())
+    if rt.lib.dpp_wgrad_stream_bf16_ok(N, K) and M % 64 == 0:
+        # the row-stream filter gradient of the same layer on bf16 operands (dpp_wgrad_stream_bf16, the stage-1 shapes)
+        G16s, G32s = both(rt, rng.normal(size=(M, N)))
+        rpw = 32
+        nsl = rt.lib.dpp_wgrad_stream_slices(N, K, M, rpw)
+        assert nsl > 0
+        parts = rt.alloc((nsl, N, K), zero=False)
+        dWs = rt.alloc((N, K), zero=False)
+        ops.wgrad_stream(rt, G16s if stored else G32s, N, X, K, M, rpw, parts, actX=act, precision=1)(rt.stream)
+        ops.reduce_partials(rt, parts, nsl, N * K, dWs)(rt.stream)
+        rt.synchronize()
+        wants = widen(G16s.get()).reshape(M, N).astype('f8').T @ q(a)
+        np.testing.assert_allclose(dWs.get(), wants, rtol=0, atol=3e-6 * np.sqrt(M) * np.abs(wants).max())
+        dW0 = rt.alloc((N, K), zero=False)
+        ops.wgrad_stream(rt, G16s if stored else G32s, N, X, K, M, rpw, parts, actX=act)(rt.stream)
+        ops.reduce_partials(rt, parts, nsl, N * K, dW0)(rt.stream)
+        rt.synchronize()
+        assert np.abs(dW0.get() - wants).max() > 10 * 3e-6 * np.sqrt(M) * np.abs(wants).max()          # the float32 kernel does not round
     if variant == 0:
         # filter gradient dW[N][K] = sum_m G[m][N] * act(X)[m][K], reduction over the M pixel rows in 2 K-slices
         G16, G32 = both(rt, rng.normal(size=(M, N)))
