@@ -101,13 +101,13 @@ __device__ __forceinline__ void rb_mfma16(f32x4 (&acc)[RT][CT], const float4 (&a
 // bf16 mode (round 6; XT / YT = the storage of the block's input / output, Q = YT is bfloat16: BASELINE config 5's deterministic forward,
 // which fell back to ~6 launches per block): the block computes what the layer-by-layer bf16 path computes -- every tensor that path
 // MATERIALISES is rounded to bfloat16 where it would have been stored (c1, c2, the shortcut's output, the block's output), every operand
-// of a product that path runs on bf16 MFMA is rounded as its kernel rounds it (the activated operands after their prologue, the filters;
-// the 16-channel exit convolution multiplies in float32 there and here) -- with float32 MFMA on the rounded values (bf16 x bf16 products
+// of a product that path runs on bf16 MFMA is rounded as its kernel rounds it (the activated operands after their prologue, the filters)
+// -- with float32 MFMA on the rounded values (bf16 x bf16 products
 // are exact in float32: the same sums in another order of additions).
 template <int NB, int BM, int RT1, bool PROJ, class XT = float, class YT = float>
 __global__ __launch_bounds__(DPP_THREADS) void resblock_eval_kernel(RBArgs a) {
     constexpr bool Q = !std::is_same<YT, float>::value;
-    constexpr bool Q3 = Q && NB >= 32;                 // the exit convolution (K = NB) runs on bf16 operands from 32 channels up
+    constexpr bool Q3 = Q;                             // the exit convolution (K = NB) too (K = 16: a 32-deep step with a zero upper half)
     dpp_kernarg_warm<sizeof(RBArgs)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);

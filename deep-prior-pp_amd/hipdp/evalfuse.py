@@ -99,7 +99,7 @@ def emit_block(eng, add_var):
         return None
     if eng.prec or eng.store16:
         # bf16 mode (round 6): the fused block models the DEFAULT bf16 path -- bf16-stored conv outputs and bf16 MFMA operands in every
-        # product of the block but the 16-channel exit convolution; any other combination of the bf16 knobs stays layer by layer
+        # product of the block; any other combination of the bf16 knobs stays layer by layer
         from . import heuristics as hz
         if not (eng.prec and eng.store16 and hz.BF16_GEMM and hz.BF16_GEMM_ALL and hz.EVAL_FUSE_BF16):
             return None

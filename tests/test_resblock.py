@@ -163,16 +163,13 @@ def _q(a):
 
 def _block_ref_bf16(x_stored, P, stride, proj, Nb):
     """The layer-by-layer bf16 path of the engine, restated: every conv output it materialises is bf16-stored (rounded where stored), every
-    product it runs on bf16 MFMA operands rounds both operands (the activation after its prologue; the 16-channel exit convolution stays on
-    float32 operands: hipdp/engine.py:_gemm_prec), the shortcut's output is a stored tensor of its own."""
+    product rounds both operands (the activation after its prologue; hipdp/engine.py:_gemm_prec: every 1x1 product of a block runs on bf16
+    MFMA operands), the shortcut's output is a stored tensor of its own."""
     h = _q(_bnrelu(x_stored, P['bn0']))
     c1 = _q(L.conv2d_fwd(h, _q(P['W1']), P['b1'], (stride, stride), 'half'))
     c2 = _q(L.conv2d_fwd(_q(_bnrelu(c1, P['bn1'])), _q(P['W2']), P['b2'], (1, 1), 'half'))
     a2 = _bnrelu(c2, P['bn2'])
-    if Nb >= 32:
-        c3 = L.conv2d_fwd(_q(a2), _q(P['W3']), P['b3'], (1, 1), 'half')
-    else:
-        c3 = L.conv2d_fwd(a2, P['W3'], P['b3'], (1, 1), 'half')
+    c3 = L.conv2d_fwd(_q(a2), _q(P['W3']), P['b3'], (1, 1), 'half')
     if not proj:
         return _q(x_stored + c3)
     sc = _q(L.conv2d_fwd(h, _q(P['Wsc']), P['bsc'], (stride, stride), 'half'))
