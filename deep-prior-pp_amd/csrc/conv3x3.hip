@@ -884,6 +884,9 @@ static void wgrad_geometry(int N, int H, int W, int Ci, int Co, int bm, int& nbl
     taps_pb = NT <= 4 ? 9 : (NT <= 16 ? 3 : 1);        // (tap, tile) pairs per workgroup <= 4 waves * MAXACC accumulators
     int cap = WGRAD_MAX_BLOCKS;
     while (cap > 32 && (long)cap * Co * 9 * Ci * 4 > 6L * 1024 * 1024) cap >>= 1;
+    // 64 channels on the transposed-image kernel (maps >= 12 wide: the 16-wide maps of the 256 x 256 net): four workgroups per slice (its
+    // output channels over blockIdx.y), so 64 slices fill the chip; their 9.4 MB of partials are a tenth of what the layer reads
+    if (Ci == 64 && Co == 64 && dpp_conv3x3_wgrad_t_ok(N, H, W, Ci, Co, nullptr) && cap < 64) cap = 64;
     nblk = ntiles < cap ? ntiles : cap;
     while (taps_pb > 1 && nblk * (9 / taps_pb) < 256) taps_pb = taps_pb == 9 ? 3 : 1;
 }

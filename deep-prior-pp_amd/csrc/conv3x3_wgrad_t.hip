@@ -101,14 +101,20 @@ __device__ __forceinline__ unsigned short w3_bf16_bits(float v) {
     return *reinterpret_cast<const unsigned short*>(&h);
 }
 
-template <int C, int TPB, class TX, class TY, bool PB>
+// OS (64 channels): the OUTPUT channels are split over blockIdx.y in groups of 16 -- a workgroup owns all nine taps of (its 16 dY channels)
+// x (all 64 X channels), wave = the X channel tile: nine accumulator tiles per wave, the full X halo but only a quarter of dY staged per
+// tile, and one pass over the tiles instead of nine.  (The first 64-channel form gave every tap its own workgroup: nine workgroups staged
+// the same 39 KB per tile for 16 MFMAs each -- 59 us per launch at 256 x 256, no faster than the row stream it replaced.)
+template <int C, int TPB, class TX, class TY, bool PB, bool OS = false>
 __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArgs a) {
+    static_assert(!OS || (C == 64 && TPB == 9), "output-channel split: 64 channels, all taps");
     dpp_kernarg_warm<sizeof(Wgrad3TArgs)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* const smem = reinterpret_cast<float*>(smem4);
     constexpr int Q = C / 4;                                  // channel quads per pixel
+    constexpr int CY = OS ? 16 : C, QY = CY / 4;              // dY channels / quads a workgroup stages
     constexpr int NXS = W3_HR * W3_HC * Q, SX = (NXS + DPP_THREADS - 1) / DPP_THREADS;      // halo staging slots (16 bytes of f32 each)
-    constexpr int NYS = W3_TH * W3_TW * Q, SY = NYS / DPP_THREADS;
+    constexpr int NYS = W3_TH * W3_TW * QY, SY = NYS / DPP_THREADS;
     static_assert(DPP_THREADS % Q == 0 && NYS % DPP_THREADS == 0, "slot geometry");
     // f32 images: floats; bf16 images: the same buffer addressed in 2-byte elements
     float* const Xt = smem;
@@ -121,6 +127,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
     const TX* const Xg = reinterpret_cast<const TX*>(a.X);
     const TY* const Yg = reinterpret_cast<const TY*>(a.dY);
     const int q4 = (tid % Q) * 4;                             // this thread's channel quad, the same in every slot (256 % Q == 0)
+    const int q4y = (tid % QY) * 4, ych0 = OS ? 16 * (int)blockIdx.y : 0;      // ... of dY, and the first dY channel of this workgroup
 
     // ---- slot geometry: independent of the tile ----
     int xl[SX], xg[SX], xyx[SX];
@@ -136,9 +143,9 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
 #pragma unroll
     for (int s = 0; s < SY; ++s) {
         const int slot = tid + s * DPP_THREADS;
-        const int p = slot / Q, ty = p / W3_TW, tx = p - ty * W3_TW;
-        yl[s] = PB ? (q4 * W3_CPYB + ty * W3_TW + tx) : (q4 * W3_CPY + ty * W3_TW + tx);
-        yg[s] = (ty * W + tx) * C + q4;
+        const int p = slot / QY, ty = p / W3_TW, tx = p - ty * W3_TW;
+        yl[s] = PB ? (q4y * W3_CPYB + ty * W3_TW + tx) : (q4y * W3_CPY + ty * W3_TW + tx);
+        yg[s] = (ty * W + tx) * C + ych0 + q4y;
         yyx[s] = (ty << 8) | tx;
     }
     const int mode = a.act.mode;
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
             const int y = y0 + (yyx[s] >> 8), x = x0 + (yyx[s] & 255);
             const bool in = y < H && x < W;
             iny |= in ? (1u << s) : 0u;
-            ry[s] = W3Raw<TY>::ld(Yg + (in ? (ptrdiff_t)org + yg[s] : (ptrdiff_t)q4));
+            ry[s] = W3Raw<TY>::ld(Yg + (in ? (ptrdiff_t)org + yg[s] : (ptrdiff_t)q4y));
         }
     };
     // registers -> transposed LDS images, the prologue applied here (not at the load: the loads stay in flight under the MFMAs)
@@ -213,14 +220,15 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
 
     // 16 channels: the waves split the row groups of a tile (and meet at the end); 32 channels: a wave owns one (o, c) tile; 64 channels
     // (the 16-wide maps of stages 3-4 at 256 x 256 input): a wave owns the four (o = wave, c) tiles
-    constexpr int NTC = C == 64 ? 4 : 1;
+    constexpr int NTC = (C == 64 && !OS) ? 4 : 1;
     f32x4 acc[TPB][NTC];
 #pragma unroll
     for (int t = 0; t < TPB; ++t)
 #pragma unroll
         for (int n = 0; n < NTC; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int to = C == 16 ? 0 : (C == 32 ? (wave >> 1) : wave), tc0 = C == 32 ? (wave & 1) : 0;
-    const int tap0 = blockIdx.y * TPB;
+    // `to`: the 16-channel tile of dY inside the STAGED image (OS: the image holds the workgroup's 16 channels only)
+    const int to = (C == 16 || OS) ? 0 : (C == 32 ? (wave >> 1) : wave), tc0 = C == 32 ? (wave & 1) : (OS ? wave : 0);
+    const int tap0 = OS ? 0 : blockIdx.y * TPB;
     const int dy0 = TPB == 9 ? 0 : tap0 / 3;                  // first halo row offset of the taps this workgroup owns
     const int dx0 = TPB == 1 ? tap0 % 3 : 0;
 
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_wgrad_t_kernel(Wgrad3TArg
             for (int n = 0; n < NTC; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int o = to * 16 + kq * 4 + r, c = (tc0 + n) * 16 + l15;
+                    const int o = (OS ? (int)blockIdx.y : to) * 16 + kq * 4 + r, c = (tc0 + n) * 16 + l15;
                     out[((size_t)o * 9 + tap) * C + c] = acc[t][n][r];
                 }
         }
@@ -350,12 +358,13 @@ int w3t_launch_taps(const Wgrad3TArgs& a, int taps_pb, dim3 grid, size_t lds, bo
     return w3t_launch_typed<C, 1, PB>(a, grid, lds, x16, y16, st);
 }
 
-// 64 channels: one tap per workgroup; the float32 images are 96 KB (above the default 64 KB window: opt in per instantiation)
+// 64 channels: output channels split over blockIdx.y, all nine taps per workgroup; the float32 images are 71 KB (above the default 64 KB
+// window: opt in per instantiation)
 template <bool PB>
 int w3t_launch_c64(const Wgrad3TArgs& a, dim3 grid, size_t lds, bool x16, bool y16, hipStream_t st) {
 #define DPP_W3T64(TX_, TY_) do { \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_t_kernel<64, 1, TX_, TY_, PB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        DPP_LAUNCH((conv3x3_wgrad_t_kernel<64, 1, TX_, TY_, PB>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wgrad_t_kernel<64, 9, TX_, TY_, PB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        DPP_LAUNCH((conv3x3_wgrad_t_kernel<64, 9, TX_, TY_, PB, true>), grid, dim3(DPP_THREADS), lds, st, a); return dpp_launch_status(); } while (0)
     if (x16) { if (y16) DPP_W3T64(dpp_bf16, dpp_bf16); else DPP_W3T64(dpp_bf16, float); }
     if (y16) DPP_W3T64(float, dpp_bf16);
     DPP_W3T64(float, float);
@@ -385,9 +394,10 @@ int dpp_conv3x3_wgrad_t_launch(const float* X, int N, int H, int W, int C, const
     const size_t red = C == 16 ? (size_t)2 * taps_pb * 64 * 16 : 0;
     if (lds < red) lds = red;
     if (C == 64) {
-        // 4 x 4 (o, c) tiles of 9 taps: one tap per workgroup keeps the accumulators at four tiles per wave (and the grid at nblk x 9)
-        if (taps_pb != 1) return DPP_E_UNSUPPORTED;
-        return precision ? w3t_launch_c64<true>(a, grid, lds, x16, y16, st) : w3t_launch_c64<false>(a, grid, lds, x16, y16, st);
+        // all nine taps per workgroup, the 64 output channels in four groups over blockIdx.y (whatever tap split the geometry suggests)
+        const dim3 g64(nblk, 4);
+        const size_t l64 = precision ? (size_t)(64 * W3_CPXB + 16 * W3_CPYB) * 2 : (size_t)(64 * W3_CPX + 16 * W3_CPY) * sizeof(float);
+        return precision ? w3t_launch_c64<true>(a, g64, l64, x16, y16, st) : w3t_launch_c64<false>(a, g64, l64, x16, y16, st);
     }
     if (precision) return C == 16 ? w3t_launch_taps<16, true>(a, taps_pb, grid, lds, x16, y16, st) : w3t_launch_taps<32, true>(a, taps_pb, grid, lds, x16, y16, st);
     return C == 16 ? w3t_launch_taps<16, false>(a, taps_pb, grid, lds, x16, y16, st) : w3t_launch_taps<32, false>(a, taps_pb, grid, lds, x16, y16, st);
