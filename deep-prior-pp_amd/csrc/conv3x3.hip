@@ -887,6 +887,9 @@ static void wgrad_geometry(int N, int H, int W, int Ci, int Co, int bm, int& nbl
     // 64 channels on the transposed-image kernel (maps >= 12 wide: the 16-wide maps of the 256 x 256 net): four workgroups per slice (its
     // output channels over blockIdx.y), so 64 slices fill the chip; their 9.4 MB of partials are a tenth of what the layer reads
     if (Ci == 64 && Co == 64 && dpp_conv3x3_wgrad_t_ok(N, H, W, Ci, Co, nullptr) && cap < 64) cap = 64;
+    // 32 channels with >= 1 024 tiles (the 256 x 256 net): 256 slices, so that a workgroup takes all nine taps in ONE pass over its tiles
+    // instead of three workgroups staging every tile for three taps each
+    if (Ci == 32 && Co == 32 && ntiles >= 1024 && dpp_conv3x3_wgrad_t_ok(N, H, W, Ci, Co, nullptr) && cap < 256) cap = 256;
     nblk = ntiles < cap ? ntiles : cap;
     while (taps_pb > 1 && nblk * (9 / taps_pb) < 256) taps_pb = taps_pb == 9 ? 3 : 1;
 }
