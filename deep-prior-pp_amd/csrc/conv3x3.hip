@@ -417,66 +417,65 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
 // there -- at the top of the next round.  Everything else is conv3x3_kernel's: same images, same tap loop, same 16-byte epilogue
 // through the LDS tile image, and the statistics partials keep ONE block per tile (dpp_epilogue_wide(blk = tile)), so callers size and
 // finalize them exactly as before.  Narrow layers only (all nine weight slices resident), the wide epilogue only.
-template <int BM, int BN, int PREC, class TX, bool EST, int SLOTS>
-__global__ __launch_bounds__(DPP_THREADS) void conv3x3_p_kernel(Conv3Args a) {
+// Everything about the geometry is a compile-time constant here (square layers Ci = Co = BN of 16 / 32 channels, one image tile of
+// 8 x 16 pixels per round, power-of-two tile counts per image): the generic kernel's run-time strides, division constants and slot
+// tables cost it 150-160 registers (3 workgroups per CU); this one is held to six waves per SIMD.
+template <int BN, int PREC, class TX, bool EST>
+__global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(4, 8) void conv3x3_p_kernel(Conv3Args a) {
     dpp_kernarg_warm<sizeof(Conv3Args)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);
     typedef typename C3Prec<PREC>::elem elem;
-    constexpr int RM = BM / 64;
-    constexpr int CN = BN / 16;
-    constexpr int KSTEP = PREC ? 32 : 16;
-    const int TH = 1 << a.lth, TW = 1 << a.ltw;
-    const int Ci = a.Ci, KP = C3Prec<PREC>::kp(Ci), LDA = KP + C3Prec<PREC>::PAD;
-    const int HW2 = (TH + 2) * (TW + 2), TW2 = TW + 2;
-    const int HP = a.img * HW2;
+    constexpr int BM = 128, RM = 2, CN = BN / 16, TH = 8, TW = 16, LTH = 3, LTW = 4, TW2 = TW + 2, HP = (TH + 2) * TW2;
+    constexpr int Ci = BN, KP = PREC ? (BN < 32 ? 32 : BN) : BN, LDA = KP + C3Prec<PREC>::PAD, KSTEP = PREC ? 32 : 16;
+    constexpr int QP = KP / 4, HSTEP = DPP_THREADS / QP, SLOTS = (HP + HSTEP - 1) / HSTEP;     // (QP is a power of two: 4 or 8)
     elem* Ah = reinterpret_cast<elem*>(smem);
     elem* Bs = reinterpret_cast<elem*>(reinterpret_cast<char*>(smem) + a.woff);          // [9][BN][KP+pad], behind the halo / epilogue image
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const int col0 = blockIdx.y * BN;
     const TX* const Xg = reinterpret_cast<const TX*>(a.X);
+    const int H = a.H, W = a.W;
 
-    dpp_wide_coef wco;
-    wco.load<BN>(col0, a.Co, a.bias, a.epi, a.Y);
+    // Per-channel vectors (epilogue: bias, BatchNorm-backward mean / scale / beta / inv_std; prologue: mean / scale / beta) live in LDS,
+    // staged once: in registers they are 32 values held across the whole walk.  Cf[v][BN]; an absent vector is never read.
+    float* Cf = reinterpret_cast<float*>(reinterpret_cast<char*>(Bs) + 9 * BN * LDA * sizeof(elem));
+    const bool on_bn = a.epi.bn_x != nullptr;
 
-    // ---- halo slots of this thread: (position, channel quad), independent of the tile ----
-    const int c0 = (tid & ((1 << a.sg.lqp) - 1)) * 4;
-    const int hstep = DPP_THREADS >> a.sg.lqp;
-    const bool cld = c0 < Ci, cst = c0 < KP;           // loads / stores at all (bf16 images pad narrow layers to 32 channels with zeros)
-    int hq[SLOTS];                                     // packed (im, hy, hx) of the slot, -1 past the halo
-#pragma unroll
-    for (int u = 0; u < SLOTS; ++u) {
-        const int hp = (tid >> a.sg.lqp) + u * hstep;
-        const int im = (int)__umulhi((unsigned)hp, a.sg.m_hw2), rem = hp - im * HW2;
-        const int hy = (int)__umulhi((unsigned)rem, a.sg.m_tw2), hx = rem - hy * TW2;
-        hq[u] = hp < HP ? ((im << 16) | (hy << 8) | hx) : -1;
-    }
-    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
-    if (cld && (a.act.mode & 2)) {
-        mu = *reinterpret_cast<const float4*>(a.act.mean + c0);
-        sc = *reinterpret_cast<const float4*>(a.act.scale + c0);
-        be = *reinterpret_cast<const float4*>(a.act.beta + c0);
-    }
+    // ---- halo slots of this thread: (position hp0 + u * HSTEP, channel quad c0) ----
+    const int c0 = (tid & (QP - 1)) * 4, hp0 = tid / QP;
+    const bool cld = c0 < Ci;                          // bf16 images pad the 16-channel layers to 32 channels with zeros: those lanes only store
     typedef typename std::conditional<std::is_same<TX, float>::value, float4, uint2>::type raw_t;
     raw_t hr[SLOTS];
     unsigned hin = 0;
+    auto origin = [&](int tile, int& n0, int& y0, int& x0) {       // tiles_x, tiles_y are powers of two (a.lth / a.ltw carry their logs here)
+        x0 = (tile & (a.tiles_x - 1)) << LTW;
+        y0 = ((tile >> a.ltw) & (a.tiles_y - 1)) << LTH;
+        n0 = tile >> (a.ltw + a.lth);
+    };
     auto fetch = [&](int tile) {
         int n0, y0, x0;
-        tile_origin(a, tile, n0, y0, x0);
+        origin(tile, n0, y0, x0);
+        const TX* const Xn = Xg + (size_t)n0 * H * W * Ci + c0;
         hin = 0;
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
-            const int n = n0 + (hq[u] >> 16), y = y0 + ((hq[u] >> 8) & 255) - 1, x = x0 + (hq[u] & 255) - 1;
-            const bool in = hq[u] >= 0 && cld && n < a.N && y >= 0 && y < a.H && x >= 0 && x < a.W;
+            const int hp = hp0 + u * HSTEP, hy = hp / TW2, hx = hp - hy * TW2;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            const bool in = hp < HP && cld && y >= 0 && y < H && x >= 0 && x < W;
             hin |= in ? (1u << u) : 0u;
-            const TX* p = Xg + (in ? (((size_t)n * a.H + y) * a.W + x) * Ci + c0 : (size_t)0);
-            hr[u] = *reinterpret_cast<const raw_t*>(p);
+            hr[u] = *reinterpret_cast<const raw_t*>(Xn + (in ? (y * W + x) * Ci : 0));       // unconditional, clamped
         }
     };
     auto commit = [&]() {
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
+        if (cld && (a.act.mode & 2)) {
+            mu = *reinterpret_cast<const float4*>(&Cf[5 * BN + c0]);
+            sc = *reinterpret_cast<const float4*>(&Cf[6 * BN + c0]);
+            be = *reinterpret_cast<const float4*>(&Cf[7 * BN + c0]);
+        }
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
-            if (hq[u] < 0 || !cst) continue;
+            const int hp = hp0 + u * HSTEP;
+            if (hp >= HP) continue;
             float4 t;
             if constexpr (std::is_same<TX, float>::value) t = hr[u];
             else t = make_float4(__uint_as_float(hr[u].x << 16), __uint_as_float(hr[u].x & 0xffff0000u), __uint_as_float(hr[u].y << 16),
@@ -488,52 +487,61 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_p_kernel(Conv3Args a) {
                 }
                 if (a.act.mode & 1) { t.x = fmaxf(t.x, 0.0f); t.y = fmaxf(t.y, 0.0f); t.z = fmaxf(t.z, 0.0f); t.w = fmaxf(t.w, 0.0f); }
             } else t = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int hp = (tid >> a.sg.lqp) + u * hstep;
             c3_store4(&Ah[hp * LDA + c0], t);
         }
     };
 
     int tile = blockIdx.x;
     if (tile < a.ntiles) fetch(tile);
-    // ---- all nine weight slices, once ----
+    {   // the per-channel vectors: thread (v, quad) copies one 16-byte piece (an absent vector: the weights' first bytes, never read back)
+        constexpr int QC = BN / 4;
+        const int v = tid / QC, q4 = (tid % QC) * 4;
+        const float* src = nullptr;
+        if (v == 0) src = a.bias;
+        if (on_bn) { if (v == 1) src = a.epi.bn_mean; if (v == 2) src = a.epi.bn_scale; if (v == 3) src = a.epi.bn_beta; if (v == 4) src = a.epi.bn_inv_std; }
+        if (a.act.mode & 2) { if (v == 5) src = a.act.mean; if (v == 6) src = a.act.scale; if (v == 7) src = a.act.beta; }
+        const float4 cv = *reinterpret_cast<const float4*>(src != nullptr ? src + q4 : a.Wk);
+        if (v < 8) *reinterpret_cast<float4*>(&Cf[v * BN + q4]) = cv;
+    }
+    // ---- all nine weight slices, once: every load is UNCONDITIONAL (a slot outside the slice reads the first weights and is zeroed at the
+    // commit) and issued behind the first halo's, so the entry code is ONE memory round trip.  With `ld ? load : zero` the compiler put
+    // each load in a branch of its own that ends on s_waitcnt vmcnt(0): nine serialized round trips ahead of the first tile.
     {
-        constexpr int WSLOTS = (BN * 16 + DPP_THREADS - 1) / DPP_THREADS;
+        constexpr int WSLOTS = (BN * QP + DPP_THREADS - 1) / DPP_THREADS;
+        constexpr int WB = WSLOTS == 1 ? 9 : 5;          // taps in flight at a time (36 / 40 registers)
 #pragma unroll
-        for (int t3 = 0; t3 < 9; t3 += 3) {
-            float4 w3[3][WSLOTS];
-            int wo[WSLOTS];
+        for (int t0 = 0; t0 < 9; t0 += WB) {
+            float4 wv[WB][WSLOTS];
 #pragma unroll
             for (int s = 0; s < WSLOTS; ++s) {
                 const int slot = tid + s * DPP_THREADS;
-                const int j = slot >> a.sg.lqp, cc = (slot & ((1 << a.sg.lqp) - 1)) * 4;
-                wo[s] = (j < BN && cc < KP) ? j * LDA + cc : -1;
-                const bool ld = j < BN && cc < Ci && col0 + j < a.Co;
+                const int j = slot / QP, cc = (slot & (QP - 1)) * 4;
+                const bool wl = j < BN && cc < Ci;
+                const float* wp = a.Wk + (wl ? j * 9 * Ci + cc : 0);
 #pragma unroll
-                for (int u = 0; u < 3; ++u)
-                    w3[u][s] = ld ? *reinterpret_cast<const float4*>(a.Wk + (size_t)(col0 + j) * 9 * Ci + cc + (t3 + u) * Ci) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < WB; ++u)
+                    if (t0 + u < 9) wv[u][s] = *reinterpret_cast<const float4*>(wp + (wl ? (t0 + u) * Ci : 0));
             }
 #pragma unroll
-            for (int u = 0; u < 3; ++u)
+            for (int u = 0; u < WB; ++u)
 #pragma unroll
-                for (int s = 0; s < WSLOTS; ++s)
-                    if (wo[s] >= 0) c3_store4(&Bs[(t3 + u) * BN * LDA + wo[s]], w3[u][s]);
+                for (int s = 0; s < WSLOTS; ++s) {
+                    const int slot = tid + s * DPP_THREADS;
+                    const int j = slot / QP, cc = (slot & (QP - 1)) * 4;
+                    if (t0 + u < 9 && j < BN) c3_store4(&Bs[(t0 + u) * BN * LDA + j * LDA + cc], cc < Ci ? wv[u][s] : make_float4(0.f, 0.f, 0.f, 0.f));
+                }
         }
     }
     int hbase[RM];
 #pragma unroll
     for (int rt = 0; rt < RM; ++rt) {
         const int row = wave * (BM / 4) + rt * 16 + l15;
-        const int im = row >> (a.lth + a.ltw);
-        const int ty = (row >> a.ltw) & (TH - 1);
-        const int tx = row & (TW - 1);
-        hbase[rt] = (im * (TH + 2) + ty + 1) * (TW + 2) + tx + 1;
+        hbase[rt] = ((row >> LTW) + 1) * TW2 + (row & (TW - 1)) + 1;
     }
     for (; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();                               // the previous tile's epilogue is done with the image that shares the halo's space
         commit();
         __syncthreads();                               // halo (and, first round, the weight slices) visible
-        int n0, y0, x0;
-        tile_origin(a, tile, n0, y0, x0);
         if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
         f32x4 acc[RM][CN];
 #pragma unroll
@@ -543,7 +551,8 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_p_kernel(Conv3Args a) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const elem* Bcur = Bs + tap * BN * LDA;
-            const int toff = (tap / 3 - 1) * (TW + 2) + (tap % 3 - 1);
+            const int toff = (tap / 3 - 1) * TW2 + (tap % 3 - 1);
+#pragma unroll
             for (int kc = 0; kc < KP; kc += KSTEP) {
                 if constexpr (PREC == 0) {
                     float4 av[RM], bv[CN];
@@ -572,18 +581,19 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_p_kernel(Conv3Args a) {
             }
         }
         __syncthreads();                               // the epilogue's image takes the halo's place
-        const int vi = (a.N - n0 < a.img) ? (a.N - n0) : a.img;
-        const int vy = (a.H - y0 < TH) ? (a.H - y0) : TH;
-        const int vx = (a.W - x0 < TW) ? (a.W - x0) : TW;
-        dpp_epilogue_wide<RM, CN, 4, 1, BM, BN, 1, EST>(acc, smem, col0, a.Co, wco, a.residual, a.Y, a.epi, vi * vy * vx, wave, 0, l15, kq,
-                                                [&](int rl) {
-            const int im = rl >> (a.lth + a.ltw);
-            const int ty = (rl >> a.ltw) & (TH - 1);
-            const int tx = rl & (TW - 1);
-            const int n = n0 + im, y = y0 + ty, x = x0 + tx;
-            const bool ok = !(im >= a.img || n >= a.N || y >= a.H || x >= a.W);
-            return ok ? (long)((((size_t)n * a.H + y) * a.W + x) * a.Co) : -1L;
-        }, 0, a.store, tile, a.ntiles);
+        int n0, y0, x0;
+        origin(tile, n0, y0, x0);
+        const long obase = (((long)n0 * H + y0) * W + x0) * BN;
+        dpp_wide_coef wco;
+        wco.on_bias = a.bias != nullptr; wco.on_bn = on_bn;
+        {
+            const int cq4 = (tid % (BN / 4)) * 4;
+#pragma unroll
+            for (int v = 0; v < 5; ++v) wco.raw[v] = *reinterpret_cast<const float4*>(&Cf[v * BN + cq4]);
+        }
+        dpp_epilogue_wide<RM, CN, 4, 1, BM, BN, 1, EST>(acc, smem, 0, BN, wco, a.residual, a.Y, a.epi, BM, wave, 0, l15, kq,
+                                                [&](int rl) { return obase + (long)(((rl >> LTW) * W + (rl & (TW - 1))) * BN); },
+                                                0, a.store, tile, a.ntiles);
     }
 }
 
@@ -801,34 +811,37 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     if (lds > 160 * 1024) return DPP_E_UNSUPPORTED;
     dim3 grid(nblk, dpp_cdiv(Co, bn));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // the tile-walking form for the narrow layers (conv3x3_p_kernel): all nine weight slices resident, the 16-byte epilogue, whole
-    // column tiles, and more tiles than workgroups so that there is a next halo to fetch under the current tile.  DPP_C3_PERSIST = the
-    // number of workgroups per column tile (0: off; default 1024: same-box A/B, tools/ab_c3p.sh -- bf16 256 x 256 step 7.377 / 7.451 (off), 7.634 / 7.714 (256),
-    // 7.315 / 7.370 (512), 7.311 / 7.367 (1024), 7.335 / 7.394 (2048); float32 128 x 128 (1 024 tiles): 3.392 / 3.409 (off), 3.461 / 3.471 (256), 3.399 / 3.413 (512):
-    // there the occupancy of one workgroup per tile already hides what the walk hides, so it stays on conv3x3_kernel)
+    // The narrow square layers (16 / 32 channels, all nine weight slices resident, the 16-byte epilogue, 8 x 16 tiles that divide the maps) run on
+    // conv3x3_p_kernel: DPP_C3_PERSIST workgroups (0: off) walk the tiles, the next halo in flight under the current tile.  The default is what a
+    // chip holds at once -- five workgroups per CU at the kernel's 96 registers (conv3x3_kernel: 112 -> four; the generic round-6 form of the walk:
+    // 152-164 -> three, which is why it gained so little).  tools/conv3_micro.py, us per launch, forward / data-gradient form, one-tile kernel -> walk:
+    // 256 x 256 bf16 16 ch (4 096 tiles) 45.5 / 46.2 -> 27.0 / 25.9 (1 024 workgroups: 27.5 / 27.5, 1 536: 27.0 / 27.5); 128 x 128 float32 16 ch (1 024 tiles,
+    // one each) 14.7 / 14.8 -> 12.3 / 12.6; 256 x 256 bf16 32 ch (1 024 tiles) 16.6 / 17.2 -> 13.8 / 15.7; 256 x 256 float32 16 ch 48.4 / 47.9 -> 39.2 / 37.9.
     const char* pe = getenv("DPP_C3_PERSIST");          // (read per call: the tests switch it)
     const int persist = pe ? atoi(pe) : 1024;
-    if (persist > 0 && a.allw && a.wide && Ci <= 32 && bm == 128 && Co % bn == 0 && nblk > persist && a.img == 1) {
+    static const int p_min = []() { const char* e = getenv("DPP_C3_P_MIN_TILES"); return e ? atoi(e) : 0; }();      // (experiments: the walk only above this many tiles)
+    const bool p_always = nblk > p_min;
+    auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+    if (persist > 0 && a.allw && a.wide && Ci == Co && (Ci == 16 || Ci == 32) && bn == Co && bm == 128 && p_always && a.img == 1 &&
+        TH == 8 && TW == 16 && H % TH == 0 && W % TW == 0 && pow2(a.tiles_x) && pow2(a.tiles_y) && (long)N * H * W * Ci < (1L << 31)) {
         const size_t region0 = (halo * rowb > need ? halo * rowb : need);
         a.woff = (int)((region0 + 15) & ~(size_t)15);
         a.ntiles = nblk;
-        const size_t ldsp = (size_t)a.woff + 9 * bn * rowb;
-        const int hstep = DPP_THREADS >> a.sg.lqp;
-        const int slots = dpp_cdiv((int)halo, hstep);
-        if (ldsp <= 64 * 1024 && slots <= 6) {
-            const dim3 gp(persist, dpp_cdiv(Co, bn));
-            if (getenv("DPP_C3_PERSIST_VERBOSE")) fprintf(stderr, "conv3x3_p_kernel: %d tiles on %d workgroups, C %d, bn %d, prec %d, store %d\n", nblk, persist, Ci, bn, precision, store);
-#define DPP_C3P(BN_, P_, T_, E_) do { if (slots <= 3) DPP_LAUNCH((conv3x3_p_kernel<128, BN_, P_, T_, E_, 3>), gp, dim3(DPP_THREADS), ldsp, st, a); \
-                                       else DPP_LAUNCH((conv3x3_p_kernel<128, BN_, P_, T_, E_, 6>), gp, dim3(DPP_THREADS), ldsp, st, a); return dpp_launch_status(); } while (0)
+        a.ltw = ilog2(a.tiles_x); a.lth = ilog2(a.tiles_y);       // (the tile itself is compile-time 8 x 16 there: the fields carry the tile COUNTS' logs)
+        const size_t ldsp = (size_t)a.woff + 9 * bn * rowb + 8 * bn * sizeof(float);      // halo / epilogue image | nine weight slices | per-channel vectors
+        if (ldsp <= 64 * 1024) {
+            const dim3 gp(persist < nblk ? persist : nblk, 1);
+            if (getenv("DPP_C3_PERSIST_VERBOSE")) fprintf(stderr, "conv3x3_p_kernel: %d tiles on %d workgroups, C %d, prec %d, store %d\n", nblk, (int)gp.x, Ci, precision, store);
+#define DPP_C3P(BN_, P_, T_, E_) do { DPP_LAUNCH((conv3x3_p_kernel<BN_, P_, T_, E_>), gp, dim3(DPP_THREADS), ldsp, st, a); return dpp_launch_status(); } while (0)
 #define DPP_C3PE(BN_, P_, T_) do { if (store & (DPP_ST_C | DPP_ST_BNX)) DPP_C3P(BN_, P_, T_, true); else DPP_C3P(BN_, P_, T_, false); } while (0)
-#define DPP_C3PX(BN_) if (bn == BN_) { \
-            if (precision) { if (store & DPP_ST_A) DPP_C3PE(BN_, 1, dpp_bf16); else DPP_C3PE(BN_, 1, float); } \
-            if (store & DPP_ST_A) DPP_C3PE(BN_, 0, dpp_bf16); else DPP_C3PE(BN_, 0, float); }
-            DPP_C3PX(16) DPP_C3PX(32)
-#undef DPP_C3PX
+            // (float32 images of a 32-channel layer: halo + nine slices are 67 KB, not `allw`: no such instance)
+            if (bn == 16 && precision) { if (store & DPP_ST_A) DPP_C3PE(16, 1, dpp_bf16); else DPP_C3PE(16, 1, float); }
+            if (bn == 16) { if (store & DPP_ST_A) DPP_C3PE(16, 0, dpp_bf16); else DPP_C3PE(16, 0, float); }
+            if (bn == 32 && precision) { if (store & DPP_ST_A) DPP_C3PE(32, 1, dpp_bf16); else DPP_C3PE(32, 1, float); }
 #undef DPP_C3PE
 #undef DPP_C3P
         }
+        a.ltw = ilog2(TW); a.lth = ilog2(TH);
     }
     // gfx950 has 160 KiB of LDS per CU; requests above the default 64 KiB window need the opt-in attribute
 #define DPP_C3K(BM_, BN_, P_, T_, E_) do { \

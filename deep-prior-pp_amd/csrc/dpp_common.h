@@ -334,6 +334,37 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
     constexpr int ITERS = (BM + RSTEP - 1) / RSTEP;
     float* Ts = smem;
     float* red = smem + NIMG * BM * LDT;                     // 4 regions of 4*BN floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cq = tid % Q, rb = tid / Q;
+    const int col = col0 + cq * 4;
+    const bool cin = col < N;                                // N % 4 == 0: the quad is inside or outside as a whole
+    const bool bn = ep.bn_x != nullptr;
+    // What the row sweep reads from memory -- residual and BatchNorm input of a row -- is requested TWO rows ahead: the first two rows' here, ahead
+    // of the accumulators' trip through LDS, row it + 2's behind row it's store.  Unconditional loads (a row outside the problem reads element 0),
+    // raw 16 / 8 bytes, converted where they are used.  With the load at the top of its own row, each one sat behind the previous row's store to C
+    // (which may alias it as far as the compiler knows) and was waited for on the spot: ITERS serialized memory round trips at the end of every
+    // data-gradient launch (2 for 16-column tiles, 4 for 32 / 64 columns).
+    long rofs[ITERS];
+    float4 res32[ITERS], bnx32[ITERS];
+    uint2 res16[ITERS], bnx16[ITERS];
+    auto request = [&](int it) {
+        const int rl = rb + it * RSTEP;
+        rofs[it] = (rl < BM && cin) ? rowoff(rl) : -1L;
+        const size_t o = rofs[it] >= 0 ? (size_t)rofs[it] + col : (size_t)0;
+        if (residual) {
+            if (c16) res16[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const dpp_bf16*>(residual) + o);
+            else res32[it] = *reinterpret_cast<const float4*>(residual + o);
+        }
+        if (bn) {
+            if (x16) bnx16[it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const dpp_bf16*>(ep.bn_x) + o);
+            else bnx32[it] = *reinterpret_cast<const float4*>(ep.bn_x + o);
+        }
+    };
+    request(0);
+    if constexpr (ITERS > 1) request(1);
+    auto widen = [](const uint2& r) {                        // four bf16 -> four f32, exact
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+    };
     // (the K loop ended on a barrier, so nobody reads the operand tiles any more)
     {
         float* Ti = Ts + (NIMG > 1 ? img * BM * LDT : 0);
@@ -347,18 +378,13 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
     }
     __syncthreads();
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cq = tid % Q, rb = tid / Q;
-    const int col = col0 + cq * 4;
-    const bool cin = col < N;                                // N % 4 == 0: the quad is inside or outside as a whole
-    const bool bn = ep.bn_x != nullptr;
     float vals[ITERS][4];
     bool valid[ITERS];
     float sx[4] = {0.f, 0.f, 0.f, 0.f}, sy[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int rl = rb + it * RSTEP;
-        const long ro = (rl < BM && cin) ? rowoff(rl) : -1L;
+        const long ro = rofs[it];
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (ro >= 0) {
             float4 t = *reinterpret_cast<const float4*>(&Ts[rl * LDT + cq * 4]);
@@ -370,11 +396,11 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
             v[0] = t.x + co.cbias[0]; v[1] = t.y + co.cbias[1]; v[2] = t.z + co.cbias[2]; v[3] = t.w + co.cbias[3];
             const size_t o = (size_t)ro + col;
             if (residual) {
-                const float4 rr = dpp_ld4_rt(residual, o, c16);
+                const float4 rr = c16 ? widen(res16[it]) : res32[it];
                 v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
             }
             if (bn) {
-                const float4 xx = dpp_ld4_rt(ep.bn_x, o, x16);
+                const float4 xx = x16 ? widen(bnx16[it]) : bnx32[it];
                 const float x[4] = {xx.x, xx.y, xx.z, xx.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -393,6 +419,7 @@ __device__ __forceinline__ void dpp_epilogue_wide(f32x4 (&acc)[RM][CN], float* s
         valid[it] = ro >= 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) vals[it][j] = v[j];
+        if (it + 2 < ITERS) request(it + 2);
     }
     const bool do_bn = bn && ep.bn_partial != nullptr;
     // lanes of a wave that share a quad differ in the bits >= log2(Q)
