@@ -421,7 +421,7 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
 // 8 x 16 pixels per round, power-of-two tile counts per image): the generic kernel's run-time strides, division constants and slot
 // tables cost it 150-160 registers (3 workgroups per CU); this one is held to six waves per SIMD.
 template <int BN, int PREC, class TX, bool EST>
-__global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(4, 8) void conv3x3_p_kernel(Conv3Args a) {
+__global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU((BN == 32 && PREC == 0) ? 2 : 4, 8) void conv3x3_p_kernel(Conv3Args a) {
     dpp_kernarg_warm<sizeof(Conv3Args)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);
@@ -822,26 +822,32 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     static const int p_min = []() { const char* e = getenv("DPP_C3_P_MIN_TILES"); return e ? atoi(e) : 0; }();      // (experiments: the walk only above this many tiles)
     const bool p_always = nblk > p_min;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (persist > 0 && a.allw && a.wide && Ci == Co && (Ci == 16 || Ci == 32) && bn == Co && bm == 128 && p_always && a.img == 1 &&
+    if (persist > 0 && a.wide && Ci == Co && (Ci == 16 || Ci == 32) && bm == 128 && p_always && a.img == 1 &&
         TH == 8 && TW == 16 && H % TH == 0 && W % TW == 0 && pow2(a.tiles_x) && pow2(a.tiles_y) && (long)N * H * W * Ci < (1L << 31)) {
-        const size_t region0 = (halo * rowb > need ? halo * rowb : need);
-        a.woff = (int)((region0 + 15) & ~(size_t)15);
-        a.ntiles = nblk;
-        a.ltw = ilog2(a.tiles_x); a.lth = ilog2(a.tiles_y);       // (the tile itself is compile-time 8 x 16 there: the fields carry the tile COUNTS' logs)
-        const size_t ldsp = (size_t)a.woff + 9 * bn * rowb + 8 * bn * sizeof(float);      // halo / epilogue image | nine weight slices | per-channel vectors
-        if (ldsp <= 64 * 1024) {
+        // (whole 16 / 32 column tiles here, whatever the column split of the one-tile kernel would have been)
+        const size_t pneed = ((size_t)bm * (Co + 4) + 16 * Co) * sizeof(float);
+        const size_t region0 = (halo * rowb > pneed ? halo * rowb : pneed);
+        const size_t ldsp = ((region0 + 15) & ~(size_t)15) + 9 * Co * rowb + 8 * Co * sizeof(float);      // halo / epilogue image | nine weight slices | per-channel vectors
+        // float32 images of a 32-channel layer are 68 KB: two workgroups per CU, taken where the launch is no more than that (128 x 128 input, stage 2:
+        // 256 tiles -- one workgroup per CU, its tap loop barrier-free at the float32 MFMA rate)
+        if (ldsp <= 64 * 1024 || (ldsp <= 80 * 1024 && nblk <= 512)) {
+            a.woff = (int)((region0 + 15) & ~(size_t)15);
+            a.ntiles = nblk;
+            a.ltw = ilog2(a.tiles_x); a.lth = ilog2(a.tiles_y);       // (the tile itself is compile-time 8 x 16 there: the fields carry the tile COUNTS' logs)
             const dim3 gp(persist < nblk ? persist : nblk, 1);
-            if (getenv("DPP_C3_PERSIST_VERBOSE")) fprintf(stderr, "conv3x3_p_kernel: %d tiles on %d workgroups, C %d, prec %d, store %d\n", nblk, (int)gp.x, Ci, precision, store);
-#define DPP_C3P(BN_, P_, T_, E_) do { DPP_LAUNCH((conv3x3_p_kernel<BN_, P_, T_, E_>), gp, dim3(DPP_THREADS), ldsp, st, a); return dpp_launch_status(); } while (0)
+            if (getenv("DPP_C3_PERSIST_VERBOSE")) fprintf(stderr, "conv3x3_p_kernel: %d tiles on %d workgroups, C %d, prec %d, store %d, %zu bytes of LDS\n", nblk, (int)gp.x, Ci, precision, store, ldsp);
+#define DPP_C3P(BN_, P_, T_, E_) do { \
+            if (ldsp > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p_kernel<BN_, P_, T_, E_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); \
+            DPP_LAUNCH((conv3x3_p_kernel<BN_, P_, T_, E_>), gp, dim3(DPP_THREADS), ldsp, st, a); return dpp_launch_status(); } while (0)
 #define DPP_C3PE(BN_, P_, T_) do { if (store & (DPP_ST_C | DPP_ST_BNX)) DPP_C3P(BN_, P_, T_, true); else DPP_C3P(BN_, P_, T_, false); } while (0)
-            // (float32 images of a 32-channel layer: halo + nine slices are 67 KB, not `allw`: no such instance)
-            if (bn == 16 && precision) { if (store & DPP_ST_A) DPP_C3PE(16, 1, dpp_bf16); else DPP_C3PE(16, 1, float); }
-            if (bn == 16) { if (store & DPP_ST_A) DPP_C3PE(16, 0, dpp_bf16); else DPP_C3PE(16, 0, float); }
-            if (bn == 32 && precision) { if (store & DPP_ST_A) DPP_C3PE(32, 1, dpp_bf16); else DPP_C3PE(32, 1, float); }
+#define DPP_C3PX(BN_) if (Co == BN_) { \
+            if (precision) { if (store & DPP_ST_A) DPP_C3PE(BN_, 1, dpp_bf16); else DPP_C3PE(BN_, 1, float); } \
+            if (store & DPP_ST_A) DPP_C3PE(BN_, 0, dpp_bf16); else DPP_C3PE(BN_, 0, float); }
+            DPP_C3PX(16) DPP_C3PX(32)
+#undef DPP_C3PX
 #undef DPP_C3PE
 #undef DPP_C3P
         }
-        a.ltw = ilog2(TW); a.lth = ilog2(TH);
     }
     // gfx950 has 160 KiB of LDS per CU; requests above the default 64 KiB window need the opt-in attribute
 #define DPP_C3K(BM_, BN_, P_, T_, E_) do { \

@@ -205,6 +205,7 @@ def stream16_plan(M, N, K, forward):
 # csrc/gemm.hip.  DPP_EXPAND = 0 | 1 (forward) | 2 (data gradients) | 3 (both).  Rows per wave (= rows per statistics block) by stage.
 EXPAND = int(knob('DPP_EXPAND', '3'))
 EXPAND_RPW = tuple(int(v) for v in knob('DPP_EXPAND_RPW', '128,64,32').split(','))      # stage 1 | stage 2 | stages 3-4
+EXPAND_MAX_WGS = int(knob('DPP_EXPAND_MAX_WGS', '768'))                                # workgroups of one launch (0: no limit)
 
 
 def expand_plan(M, N, K, forward):
@@ -213,14 +214,26 @@ def expand_plan(M, N, K, forward):
     rpw = EXPAND_RPW[0 if M >= 65536 else (1 if M >= 16384 else 2)]
     while rpw > 32 and M % rpw:
         rpw //= 2
+    # ... and more rows per wave where the launch would not be resident at once: the kernel's instances hold 104-188 registers, i.e. two to four
+    # workgroups per CU; 1 024 workgroups of a three-per-CU instance run as a full round and a third of one (256 x 256 input, stage 1:
+    # 524 288 rows -> 64 columns at 128 rows per wave)
+    while EXPAND_MAX_WGS and (M // rpw) * (N // 64) // 4 > EXPAND_MAX_WGS and M % (2 * rpw) == 0:
+        rpw *= 2
     if M % rpw:
         return None
     return (rpw, 64, 4)
 
 
+C3_BM128_32 = knob('DPP_C3_BM128_32', '1') != '0'
+
+
 def conv3x3_bm(pixels, Co):
     """Rows per workgroup of the 3x3 kernel (the choice dpp_conv3x3 makes for bm = 0, made explicit so that the host knows
     the row-block count of the fused epilogue partials)."""
+    if Co == 32 and C3_BM128_32 and pixels % 128 == 0 and pixels // 128 >= 256:
+        # the square 32-channel layers on the tile-walking kernel (conv3x3_p_kernel: 8 x 16 tiles): at 128 x 128 input 256 workgroups, one per
+        # CU, whose barrier-free tap loop runs at the float32 MFMA rate -- 512 workgroups of 64 pixels spent 6.8 us in their nine barriers
+        return 128
     return 128 if (pixels // 128) * (-(-Co // 64)) >= 512 else 64
 
 

@@ -168,8 +168,13 @@ def test_tile_walking_conv3x3_equals_one_workgroup_per_tile(backend, cfg, monkey
                     epi=ops.epilogue(bn=bn, bn_x=bx16 if st16 else bx32, bn_relu=True, bn_partial=part))(rt.stream)
         rt.synchronize()
         got[mode] = (Y.get(), stats.get(), dX.get(), part.get())
-    for a, b in zip(got['0'], got['3']):
-        assert np.array_equal(a, b)
+    for k, (a, b) in enumerate(zip(got['0'], got['3'])):
+        if k in (0, 2) or Cc == 16:
+            assert np.array_equal(a, b)
+        else:
+            # 32 channels: the walk keeps the 32 columns of a tile together, the one-tile kernel splits a launch this small into 16-column
+            # workgroups -- the same values summed by a different tree of threads: the per-tile sums agree to float32 round-off
+            np.testing.assert_allclose(a, b, rtol=3e-6, atol=3e-6 * np.abs(a).max())
     assert np.isfinite(got['3'][1]).all() and np.abs(got['3'][0].astype(np.float64)).max() > 0
 
 

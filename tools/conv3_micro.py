@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'deep-prior-pp_amd'))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+from hipdp import heuristics as hz  # noqa: E402
 from hipdp import ops  # noqa: E402
 from hipdp.lib import Act  # noqa: E402
 from hipdp.runtime import TorchHipRuntime  # noqa: E402
@@ -47,7 +48,7 @@ def main():
         vec = lambda lo, hi: rt.upload(rng.uniform(lo, hi, C).astype(np.float32))  # noqa: E731
         mean, scale, beta, bias = vec(-.3, .3), vec(.5, 1.5), vec(-.3, .3), vec(-.1, .1)
         act = ops.act(Act.BN_RELU, mean, scale, beta, C)
-        bm = args.bm or (128 if (N * H * W // 128) * (-(-C // 64)) >= 512 else 64)
+        bm = args.bm or hz.conv3x3_bm(N * H * W, C)
         nblk = rt.lib.dpp_conv3x3_tiling(N, H, W, bm, None, None, None)
         stats = rt.alloc((nblk, 2, C), zero=False)
         bn = _BN()
