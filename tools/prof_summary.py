@@ -14,8 +14,22 @@ argv = [a for a in sys.argv[1:] if not a.startswith('--')]
 db = sqlite3.connect(argv[0])
 steps = float(argv[1]) if len(argv) > 1 else 1.0
 key = "name || ' <' || (grid_x/workgroup_x) || ',' || (grid_y/workgroup_y) || ',' || (grid_z/workgroup_z) || '>'" if by_grid else "name"
+# residency of a launch (--by-grid): registers a wave is ALLOCATED = architectural (rounded to 4) + accumulation registers, in granules of 8 of the
+# 512 a SIMD lane has; workgroups per CU = what registers and the 160 KB of LDS allow; rounds = workgroups of the launch / (that x 256 CUs).
+# (The "vgpr" column alone is the architectural count: conv3x3_kernel showed 60 there while its code object allocates 112.)
+cols = [d[0] for d in db.execute("select * from kernels limit 0").description]
+acc_col = next((c for c in ('accum_vgpr_count', 'accum_vgpr', 'agpr_count') if c in cols), None)
 rows = db.execute("select %s, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3, "
-                  "max(vgpr_count), max(lds_size) from kernels group by 1 order by 3 desc" % key).fetchall()
+                  "max(vgpr_count), max(lds_size), max(%s), max(workgroup_x*workgroup_y*workgroup_z), "
+                  "max((grid_x/workgroup_x)*(grid_y/workgroup_y)*(grid_z/workgroup_z)) from kernels group by 1 order by 3 desc" % (key, acc_col or '0')).fetchall()
+
+
+def residency(arch, acc, lds, threads, wgs):
+    alloc = max(8, (((arch or 0) + 3) // 4 * 4 + (acc or 0) + 7) // 8 * 8)
+    waves_simd = min(8, 512 // alloc)
+    per_wg = max(1, -(-(threads or 64) // 64))
+    wg_cu = max(1, min(waves_simd * 4 // per_wg if waves_simd * 4 >= per_wg else 1, (160 * 1024 // lds) if lds else 32, 32))
+    return alloc, wg_cu, (wgs or 1) / (wg_cu * 256.0)
 tot = sum(r[2] for r in rows)
 # a train step launches adam_kernel exactly once: when the trace holds it, the number of traced steps is COUNTED, not taken from the
 # command line (round 3's header said 28 steps for a trace with 29 -- warm-up, timed region and the family re-issues of bench.py)
@@ -26,7 +40,8 @@ if adam_calls:
     steps = float(adam_calls)
 print("rocprofv3 --kernel-trace summary: %d kernels, %d dispatches, total %.1f us (%.1f us per step over %g steps)" %
       (len(rows), sum(r[1] for r in rows), tot, tot / steps, steps))
-print("%-66s %7s %11s %9s %9s %9s %6s %5s %6s" % ('kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%', 'vgpr', 'lds'))
+print("%-66s %7s %11s %9s %9s %9s %6s %5s %6s" % ('kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', '%', 'vgpr', 'lds') +
+      ("  %5s %5s %6s" % ('alloc', 'wg/cu', 'rounds') if by_grid else ''))
 for r in rows:
     name, grid = r[0], ''
     if by_grid:
@@ -34,7 +49,10 @@ for r in rows:
         grid = ' <' + grid
     name = pretty(name)
     name = name[:66 - len(grid)] + grid
-    print("%-66s %7d %11.1f %9.2f %9.2f %9.2f %6.1f %5d %6d" % (name[:66], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot, r[6] or 0, r[7] or 0))
+    line = "%-66s %7d %11.1f %9.2f %9.2f %9.2f %6.1f %5d %6d" % (name[:66], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot, r[6] or 0, r[7] or 0)
+    if by_grid:
+        line += "  %5d %5d %6.2f" % residency(r[6], r[8], r[7], r[9], r[10])
+    print(line)
 
 # per kernel family (all template instances / grids together): the figure bench.py's roofline.avg_launch_us corresponds to
 fam = {}
