@@ -205,7 +205,7 @@ def stream16_plan(M, N, K, forward):
 # csrc/gemm.hip.  DPP_EXPAND = 0 | 1 (forward) | 2 (data gradients) | 3 (both).  Rows per wave (= rows per statistics block) by stage.
 EXPAND = int(knob('DPP_EXPAND', '3'))
 EXPAND_RPW = tuple(int(v) for v in knob('DPP_EXPAND_RPW', '128,64,32').split(','))      # stage 1 | stage 2 | stages 3-4
-EXPAND_MAX_WGS = int(knob('DPP_EXPAND_MAX_WGS', '768'))                                # workgroups of one launch (0: no limit)
+EXPAND_MAX_WGS = int(knob('DPP_EXPAND_MAX_WGS', '256'))                                # workgroups of one launch (0: no limit)
 
 
 def expand_plan(M, N, K, forward):
@@ -214,9 +214,11 @@ def expand_plan(M, N, K, forward):
     rpw = EXPAND_RPW[0 if M >= 65536 else (1 if M >= 16384 else 2)]
     while rpw > 32 and M % rpw:
         rpw //= 2
-    # ... and more rows per wave where the launch would not be resident at once: the kernel's instances hold 104-188 registers, i.e. two to four
-    # workgroups per CU; 1 024 workgroups of a three-per-CU instance run as a full round and a third of one (256 x 256 input, stage 1:
-    # 524 288 rows -> 64 columns at 128 rows per wave)
+    # ... and more rows per wave where the launch would not be resident at once: the kernel's instances are ALLOCATED 196-374 registers (the code
+    # objects' .vgpr_count; the profiler's column shows the architectural half), i.e. ONE workgroup per CU, two for the smallest -- the launches of
+    # the 256 x 256 net (512-1 024 workgroups at the rows per wave tuned for 128 x 128) ran as two to four rounds, every round paying the entry
+    # code's round trips again.  Same box, bf16 256 x 256: no limit 6.995 / 6.993 ms, 768 workgroups 6.944-6.978, 384 6.80 / 6.82, 256 6.796 / 6.814;
+    # float32 256 x 256 9.228 -> 9.037 (tools/prof_summary.py --by-grid prints allocation, workgroups per CU and rounds of every launch).
     while EXPAND_MAX_WGS and (M // rpw) * (N // 64) // 4 > EXPAND_MAX_WGS and M % (2 * rpw) == 0:
         rpw *= 2
     if M % rpw:

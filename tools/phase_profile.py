@@ -24,7 +24,7 @@ rt = TorchHipRuntime(lib_path=os.path.join(ROOT, 'deep-prior-pp_amd', 'lib_prof'
 TICK_US = 0.01
 
 
-def profile(label, launch, nwg, nphase=5):
+def profile(label, launch, nwg, nphase=5, slots=None):
     buf = rt.alloc((nwg + 8, 16), np.int64)
     for _ in range(5):
         launch(rt.stream)
@@ -37,6 +37,8 @@ def profile(label, launch, nwg, nphase=5):
     torch.cuda.synchronize()
     rt.lib.dpp_prof_set(None)
     t = buf.get()[:nwg, :nphase].astype(np.float64) * TICK_US
+    if slots is not None:
+        t, nphase = t[:, list(slots)], len(slots)
     t0 = t[:, 0].min()
     start = t[:, 0] - t0
     span = t[:, nphase - 1].max() - t0
@@ -97,6 +99,29 @@ def conv_case(label, N, H, C, bm, feats):
     profile('%s bm=%d %s' % (label, bm, '+'.join(feats) or 'plain'), L, nblk * -(-C // bn))
 
 
+def expand_case(label, M, N, K, rpw, forward=True):
+    """gemm_expand_kernel (dpp_gemm variant 4).  Phases of a workgroup's first wave: 0 entry -> 1 filter slice, coefficients and the first 32 rows'
+    loads issued -> 3 all rows done -> 4 statistics / BatchNorm-backward partials written."""
+    A = rt.alloc((M, K), zero=False)
+    rt.tensor(A).normal_()
+    B = rt.alloc((N, K) if forward else (K, N), zero=False)
+    rt.tensor(B).normal_()
+    Cb = rt.alloc((M, N), zero=False)
+    kw = {}
+    nblk = M // rpw
+    if forward:
+        mean, scale, beta = rt.alloc(K), rt.alloc(K), rt.alloc(K)
+        a = Act(mean.ptr, scale.ptr, beta.ptr, 3, K)
+        a._keep = (mean, scale, beta)
+        kw = dict(actA=a, bias=rt.alloc(N), residual=rt.alloc((M, N)), epi=ops.epilogue(stats=rt.alloc((nblk, 2, N), zero=False)))
+    else:
+        bn = BN()
+        bn.mean, bn.inv_std, bn.scale, bn.beta_buf = rt.alloc(N), rt.alloc(N), rt.alloc(N), rt.alloc(N)
+        kw = dict(epi=ops.epilogue(bn=bn, bn_x=rt.alloc((M, N)), bn_relu=True, bn_partial=rt.alloc((nblk, 2, N), zero=False)))
+    L = ops.gemm(rt, A, B, Cb, M, N, K, 1, 1 if forward else 0, K, K if forward else N, N, tile=(rpw, 64, 4), variant=4, **kw)
+    profile('%s rpw %d %s' % (label, rpw, 'forward' if forward else 'data gradient'), L, (M // rpw) * (N // 64) // 4, slots=(0, 1, 3, 4))
+
+
 def fc_case(label, M, N, K, a_kc, b_kc, tile, splitk):
     A = rt.alloc((M, K) if a_kc else (K, M), zero=False)
     rt.tensor(A).normal_()
@@ -143,6 +168,12 @@ if __name__ == '__main__':
         resblock_case('projection stage3 128 -> 64 -> 256 /2', 128, 8, 64, proj=True)
         resblock_case('projection stage2  64 -> 32 -> 128 /2', 128, 16, 32, proj=True)
         resblock_case('projection stage1  32 -> 16 ->  64 /2', 128, 32, 16, proj=True)
+        sys.exit(0)
+    if 'expand' in sys.argv[1:]:
+        for fwd in (True, False):
+            expand_case('stage3/4  64 -> 256, 8 192 rows', 8192, 256, 64, 32, fwd)
+            expand_case('stage2    32 -> 128, 32 768 rows', 32768, 128, 32, 64, fwd)
+            expand_case('stage1    16 -> 64, 131 072 rows', 131072, 64, 16, 128, fwd)
         sys.exit(0)
     if 'fc' in sys.argv[1:]:
         fc_case('FC1 fwd   128 x 1024 x 16384', 128, 1024, 16384, 1, 0, (128, 64, 4), 32)
