@@ -1085,22 +1085,41 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16t_kernel(GemmArgs ga
         cbeta[ct] = bn ? *reinterpret_cast<const float4*>(ep.bn_beta + c0) : z4;
         cistd[ct] = bn ? *reinterpret_cast<const float4*>(ep.bn_inv_std + c0) : z4;
     }
-    float4 xr[TPW][CN], rr[TPW][CN];
+    // RAW loads (16 bytes, or 8 of a bf16-stored tensor), widened where they are used: `bn ? dpp_ld4_rt(..) : zero` converts inside the branch, and the
+    // branch then ends on s_waitcnt vmcnt(0) -- the data-gradient instance on bf16-stored tensors waited out four round trips one after the other here
+    const bool has_res = EPI && d.residual != nullptr;
+    float4 xr32[TPW][CN], rr32[TPW][CN];
+    uint2 xr16[TPW][CN], rr16[TPW][CN];
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
         for (int ct = 0; ct < CN; ++ct) {
             const size_t o = (size_t)(wrow0 + t * 16 + l15) * d.ldc + ct * 16 + kq * 4;
-            xr[t][ct] = bn ? dpp_ld4_rt(ep.bn_x, o, x16) : z4;
-            rr[t][ct] = (EPI && d.residual) ? dpp_ld4_rt(d.residual, o, c16) : z4;
+            if (bn) {
+                if (x16) xr16[t][ct] = *reinterpret_cast<const uint2*>(reinterpret_cast<const dpp_bf16*>(ep.bn_x) + o);
+                else xr32[t][ct] = *reinterpret_cast<const float4*>(ep.bn_x + o);
+            }
+            if (has_res) {
+                if (c16) rr16[t][ct] = *reinterpret_cast<const uint2*>(reinterpret_cast<const dpp_bf16*>(d.residual) + o);
+                else rr32[t][ct] = *reinterpret_cast<const float4*>(d.residual + o);
+            }
         }
+    auto widen8 = [](const uint2& r) {
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
+    };
 
     float4 vals[TPW][CN];
     float4 sx[CN], sy[CN];
 #pragma unroll
     for (int ct = 0; ct < CN; ++ct) { sx[ct] = z4; sy[ct] = z4; }
+    float4 xr[TPW][CN], rr[TPW][CN];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+        for (int ct = 0; ct < CN; ++ct) {
+            xr[t][ct] = bn ? (x16 ? widen8(xr16[t][ct]) : xr32[t][ct]) : z4;
+            rr[t][ct] = has_res ? (c16 ? widen8(rr16[t][ct]) : rr32[t][ct]) : z4;
+        }
         f32x4 acc[CN];
 #pragma unroll
         for (int ct = 0; ct < CN; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
