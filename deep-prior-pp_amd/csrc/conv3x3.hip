@@ -417,26 +417,31 @@ __global__ __launch_bounds__(DPP_THREADS) void conv3x3_kernel(Conv3Args a) {
 // there -- at the top of the next round.  Everything else is conv3x3_kernel's: same images, same tap loop, same 16-byte epilogue
 // through the LDS tile image, and the statistics partials keep ONE block per tile (dpp_epilogue_wide(blk = tile)), so callers size and
 // finalize them exactly as before.  Narrow layers only (all nine weight slices resident), the wide epilogue only.
-// Everything about the geometry is a compile-time constant here (square layers Ci = Co = BN of 16 / 32 channels, one image tile of
-// 8 x 16 pixels per round, power-of-two tile counts per image): the generic kernel's run-time strides, division constants and slot
-// tables cost it 150-160 registers (3 workgroups per CU); this one is held to six waves per SIMD.
-template <int BN, int PREC, class TX, bool EST>
-__global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU((BN == 32 && PREC == 0) ? 2 : 4, 8) void conv3x3_p_kernel(Conv3Args a) {
+// Everything about the geometry is a compile-time constant here: CI input channels, BN output columns per workgroup (blockIdx.y picks the
+// column tile), and the tile -- GEOM 0: 8 x 16 pixels of one image (power-of-two tile counts per image), GEOM 1: two whole 8 x 8 images (the
+// 64-channel layers of stages 3-4 at 128 x 128 input).  The generic kernel's run-time strides, division constants and slot tables cost it
+// 150-160 registers (3 workgroups per CU).
+template <int CI, int BN, int PREC, class TX, bool EST, int GEOM>
+__global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU((CI * (PREC ? 2 : 4) * (9 * BN + 200) > 40 * 1024) ? 1 : 4, 8) void conv3x3_p_kernel(Conv3Args a) {
     dpp_kernarg_warm<sizeof(Conv3Args)>();
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* smem = reinterpret_cast<float*>(smem4);
     typedef typename C3Prec<PREC>::elem elem;
-    constexpr int BM = 128, RM = 2, CN = BN / 16, TH = 8, TW = 16, LTH = 3, LTW = 4, TW2 = TW + 2, HP = (TH + 2) * TW2;
-    constexpr int Ci = BN, KP = PREC ? (BN < 32 ? 32 : BN) : BN, LDA = KP + C3Prec<PREC>::PAD, KSTEP = PREC ? 32 : 16;
-    constexpr int QP = KP / 4, HSTEP = DPP_THREADS / QP, SLOTS = (HP + HSTEP - 1) / HSTEP;     // (QP is a power of two: 4 or 8)
+    constexpr int BM = 128, RM = 2, CN = BN / 16, TH = 8, TW = GEOM ? 8 : 16, LTH = 3, LTW = GEOM ? 3 : 4, IMG = GEOM ? 2 : 1, TW2 = TW + 2, HW2 = (TH + 2) * TW2,
+                  HP = IMG * HW2;
+    constexpr int Ci = CI, KP = PREC ? (CI < 32 ? 32 : CI) : CI, LDA = KP + C3Prec<PREC>::PAD, KSTEP = PREC ? 32 : 16;
+    constexpr int QP = KP / 4, HSTEP = DPP_THREADS / QP, SLOTS = (HP + HSTEP - 1) / HSTEP;     // (QP is a power of two: 4, 8 or 16)
+    constexpr int CW = 64;                                                                  // floats per per-channel vector in LDS
     elem* Ah = reinterpret_cast<elem*>(smem);
     elem* Bs = reinterpret_cast<elem*>(reinterpret_cast<char*>(smem) + a.woff);          // [9][BN][KP+pad], behind the halo / epilogue image
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const TX* const Xg = reinterpret_cast<const TX*>(a.X);
     const int H = a.H, W = a.W;
+    const int col0 = GEOM ? (int)blockIdx.y * BN : 0, Co = GEOM ? a.Co : BN;       // (GEOM 0: square layers, the whole column range in one workgroup)
 
-    // Per-channel vectors (epilogue: bias, BatchNorm-backward mean / scale / beta / inv_std; prologue: mean / scale / beta) live in LDS,
-    // staged once: in registers they are 32 values held across the whole walk.  Cf[v][BN]; an absent vector is never read.
+    // Per-channel vectors (epilogue, this workgroup's BN columns: bias, BatchNorm-backward mean / scale / beta / inv_std; prologue, the CI input
+    // channels: mean / scale / beta) live in LDS, staged once: in registers they are 32 values held across the whole walk.  Cf[v][CW]; an absent
+    // vector is never read.
     float* Cf = reinterpret_cast<float*>(reinterpret_cast<char*>(Bs) + 9 * BN * LDA * sizeof(elem));
     const bool on_bn = a.epi.bn_x != nullptr;
 
@@ -446,31 +451,33 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU((BN == 32 && PREC == 
     typedef typename std::conditional<std::is_same<TX, float>::value, float4, uint2>::type raw_t;
     raw_t hr[SLOTS];
     unsigned hin = 0;
-    auto origin = [&](int tile, int& n0, int& y0, int& x0) {       // tiles_x, tiles_y are powers of two (a.lth / a.ltw carry their logs here)
-        x0 = (tile & (a.tiles_x - 1)) << LTW;
+    auto origin = [&](int tile, int& n0, int& y0, int& x0) {
+        if (GEOM) { n0 = tile * IMG; y0 = 0; x0 = 0; return; }
+        x0 = (tile & (a.tiles_x - 1)) << LTW;          // tiles_x, tiles_y are powers of two (a.lth / a.ltw carry their logs here)
         y0 = ((tile >> a.ltw) & (a.tiles_y - 1)) << LTH;
         n0 = tile >> (a.ltw + a.lth);
     };
     auto fetch = [&](int tile) {
         int n0, y0, x0;
         origin(tile, n0, y0, x0);
+        const int nimg = GEOM ? ((a.N - n0 < IMG) ? a.N - n0 : IMG) : 1;
         const TX* const Xn = Xg + (size_t)n0 * H * W * Ci + c0;
         hin = 0;
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
-            const int hp = hp0 + u * HSTEP, hy = hp / TW2, hx = hp - hy * TW2;
+            const int hp = hp0 + u * HSTEP, im = GEOM ? hp / HW2 : 0, rem = hp - im * HW2, hy = rem / TW2, hx = rem - hy * TW2;
             const int y = y0 + hy - 1, x = x0 + hx - 1;
-            const bool in = hp < HP && cld && y >= 0 && y < H && x >= 0 && x < W;
+            const bool in = hp < HP && cld && im < nimg && y >= 0 && y < H && x >= 0 && x < W;
             hin |= in ? (1u << u) : 0u;
-            hr[u] = *reinterpret_cast<const raw_t*>(Xn + (in ? (y * W + x) * Ci : 0));       // unconditional, clamped
+            hr[u] = *reinterpret_cast<const raw_t*>(Xn + (in ? ((im * H + y) * W + x) * Ci : 0));       // unconditional, clamped
         }
     };
     auto commit = [&]() {
         float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
         if (cld && (a.act.mode & 2)) {
-            mu = *reinterpret_cast<const float4*>(&Cf[5 * BN + c0]);
-            sc = *reinterpret_cast<const float4*>(&Cf[6 * BN + c0]);
-            be = *reinterpret_cast<const float4*>(&Cf[7 * BN + c0]);
+            mu = *reinterpret_cast<const float4*>(&Cf[5 * CW + c0]);
+            sc = *reinterpret_cast<const float4*>(&Cf[6 * CW + c0]);
+            be = *reinterpret_cast<const float4*>(&Cf[7 * CW + c0]);
         }
 #pragma unroll
         for (int u = 0; u < SLOTS; ++u) {
@@ -494,21 +501,23 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU((BN == 32 && PREC == 
     int tile = blockIdx.x;
     if (tile < a.ntiles) fetch(tile);
     {   // the per-channel vectors: thread (v, quad) copies one 16-byte piece (an absent vector: the weights' first bytes, never read back)
-        constexpr int QC = BN / 4;
+        constexpr int QC = CW / 4;
         const int v = tid / QC, q4 = (tid % QC) * 4;
         const float* src = nullptr;
         if (v == 0) src = a.bias;
         if (on_bn) { if (v == 1) src = a.epi.bn_mean; if (v == 2) src = a.epi.bn_scale; if (v == 3) src = a.epi.bn_beta; if (v == 4) src = a.epi.bn_inv_std; }
+        if (src != nullptr) src += col0;               // the epilogue's vectors: this workgroup's columns
         if (a.act.mode & 2) { if (v == 5) src = a.act.mean; if (v == 6) src = a.act.scale; if (v == 7) src = a.act.beta; }
-        const float4 cv = *reinterpret_cast<const float4*>(src != nullptr ? src + q4 : a.Wk);
-        if (v < 8) *reinterpret_cast<float4*>(&Cf[v * BN + q4]) = cv;
+        const bool have = src != nullptr && q4 < (v < 5 ? BN : Ci);
+        const float4 cv = *reinterpret_cast<const float4*>(have ? src + q4 : a.Wk);
+        if (v < 8) *reinterpret_cast<float4*>(&Cf[v * CW + q4]) = cv;
     }
     // ---- all nine weight slices, once: every load is UNCONDITIONAL (a slot outside the slice reads the first weights and is zeroed at the
     // commit) and issued behind the first halo's, so the entry code is ONE memory round trip.  With `ld ? load : zero` the compiler put
     // each load in a branch of its own that ends on s_waitcnt vmcnt(0): nine serialized round trips ahead of the first tile.
     {
         constexpr int WSLOTS = (BN * QP + DPP_THREADS - 1) / DPP_THREADS;
-        constexpr int WB = WSLOTS == 1 ? 9 : 5;          // taps in flight at a time (36 / 40 registers)
+        constexpr int WB = WSLOTS == 1 ? 9 : (WSLOTS == 2 ? 5 : 3);          // taps in flight at a time (36 / 40 / 48 registers)
 #pragma unroll
         for (int t0 = 0; t0 < 9; t0 += WB) {
             float4 wv[WB][WSLOTS];
@@ -516,8 +525,8 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU((BN == 32 && PREC == 
             for (int s = 0; s < WSLOTS; ++s) {
                 const int slot = tid + s * DPP_THREADS;
                 const int j = slot / QP, cc = (slot & (QP - 1)) * 4;
-                const bool wl = j < BN && cc < Ci;
-                const float* wp = a.Wk + (wl ? j * 9 * Ci + cc : 0);
+                const bool wl = j < BN && cc < Ci && col0 + j < Co;
+                const float* wp = a.Wk + (wl ? (size_t)(col0 + j) * 9 * Ci + cc : (size_t)0);
 #pragma unroll
                 for (int u = 0; u < WB; ++u)
                     if (t0 + u < 9) wv[u][s] = *reinterpret_cast<const float4*>(wp + (wl ? (t0 + u) * Ci : 0));
@@ -528,7 +537,8 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU((BN == 32 && PREC == 
                 for (int s = 0; s < WSLOTS; ++s) {
                     const int slot = tid + s * DPP_THREADS;
                     const int j = slot / QP, cc = (slot & (QP - 1)) * 4;
-                    if (t0 + u < 9 && j < BN) c3_store4(&Bs[(t0 + u) * BN * LDA + j * LDA + cc], cc < Ci ? wv[u][s] : make_float4(0.f, 0.f, 0.f, 0.f));
+                    if (t0 + u < 9 && j < BN)
+                        c3_store4(&Bs[(t0 + u) * BN * LDA + j * LDA + cc], (cc < Ci && col0 + j < Co) ? wv[u][s] : make_float4(0.f, 0.f, 0.f, 0.f));
                 }
         }
     }
@@ -536,7 +546,7 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU((BN == 32 && PREC == 
 #pragma unroll
     for (int rt = 0; rt < RM; ++rt) {
         const int row = wave * (BM / 4) + rt * 16 + l15;
-        hbase[rt] = ((row >> LTW) + 1) * TW2 + (row & (TW - 1)) + 1;
+        hbase[rt] = ((row >> (LTH + LTW)) * (TH + 2) + ((row >> LTW) & (TH - 1)) + 1) * TW2 + (row & (TW - 1)) + 1;
     }
     for (; tile < a.ntiles; tile += gridDim.x) {
         __syncthreads();                               // the previous tile's epilogue is done with the image that shares the halo's space
@@ -583,17 +593,20 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU((BN == 32 && PREC == 
         __syncthreads();                               // the epilogue's image takes the halo's place
         int n0, y0, x0;
         origin(tile, n0, y0, x0);
-        const long obase = (((long)n0 * H + y0) * W + x0) * BN;
+        const long obase = (((long)n0 * H + y0) * W + x0) * Co;
+        const int nimg = (a.N - n0 < IMG) ? a.N - n0 : IMG;            // (GEOM 1: an odd batch leaves the last tile one image)
         dpp_wide_coef wco;
         wco.on_bias = a.bias != nullptr; wco.on_bn = on_bn;
         {
             const int cq4 = (tid % (BN / 4)) * 4;
 #pragma unroll
-            for (int v = 0; v < 5; ++v) wco.raw[v] = *reinterpret_cast<const float4*>(&Cf[v * BN + cq4]);
+            for (int v = 0; v < 5; ++v) wco.raw[v] = *reinterpret_cast<const float4*>(&Cf[v * CW + cq4]);
         }
-        dpp_epilogue_wide<RM, CN, 4, 1, BM, BN, 1, EST>(acc, smem, 0, BN, wco, a.residual, a.Y, a.epi, BM, wave, 0, l15, kq,
-                                                [&](int rl) { return obase + (long)(((rl >> LTW) * W + (rl & (TW - 1))) * BN); },
-                                                0, a.store, tile, a.ntiles);
+        dpp_epilogue_wide<RM, CN, 4, 1, BM, BN, 1, EST>(acc, smem, col0, Co, wco, a.residual, a.Y, a.epi, nimg * TH * TW, wave, 0, l15, kq,
+                                                [&](int rl) {
+            const int im = rl >> (LTH + LTW), ty = (rl >> LTW) & (TH - 1), tx = rl & (TW - 1);
+            return im < nimg ? obase + (long)(((im * H + ty) * W + tx) * Co) : -1L;
+        }, 0, a.store, tile, a.ntiles);
     }
 }
 
@@ -822,28 +835,38 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     static const int p_min = []() { const char* e = getenv("DPP_C3_P_MIN_TILES"); return e ? atoi(e) : 0; }();      // (experiments: the walk only above this many tiles)
     const bool p_always = nblk > p_min;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (persist > 0 && a.wide && Ci == Co && (Ci == 16 || Ci == 32) && bm == 128 && p_always && a.img == 1 &&
-        TH == 8 && TW == 16 && H % TH == 0 && W % TW == 0 && pow2(a.tiles_x) && pow2(a.tiles_y) && (long)N * H * W * Ci < (1L << 31)) {
-        // (whole 16 / 32 column tiles here, whatever the column split of the one-tile kernel would have been)
-        const size_t pneed = ((size_t)bm * (Co + 4) + 16 * Co) * sizeof(float);
+    const bool geom0 = (Ci == 16 || Ci == 32) && a.img == 1 && TH == 8 && TW == 16 && H % TH == 0 && W % TW == 0 && pow2(a.tiles_x) && pow2(a.tiles_y);
+    // ... and the 64-channel layers of 8 x 8 maps (stages 3-4 at 128 x 128 input): two whole images per tile, 16 of the 64 output columns per
+    // workgroup (blockIdx.y), 94 KB of LDS -- 256 workgroups, one per CU, instead of 512 that met at a barrier after every tap
+    // bf16 operands only by default (52 KB per workgroup): the float32 form (94 KB, one workgroup per CU) is 12.3 / 12.1 us per launch against 12.8 / 12.4
+    // alone, but the step is SLOWER with it (3.371 -> 3.400 ms, same box: a CU full of its LDS takes no gradient-branch workgroup beside it);
+    // bf16 128 x 128: 2.998 -> 2.928 ms.  DPP_C3_P_64 = 0: off, 2: float32 as well.
+    const char* g1e = getenv("DPP_C3_P_64");            // (read per call: the tests switch it)
+    const int geom1_on = g1e ? atoi(g1e) : 1;
+    const bool geom1 = (geom1_on >= 2 || (geom1_on == 1 && precision)) && Ci == 64 && H == 8 && W == 8 && a.img == 2 && TH == 8 && TW == 8;
+    if (persist > 0 && a.wide && Ci == Co && bm == 128 && p_always && (geom0 || geom1) && (long)N * H * W * Ci < (1L << 31)) {
+        // (GEOM 0: whole 16 / 32 column tiles, whatever the column split of the one-tile kernel would have been)
+        const int pbn = geom1 ? 16 : Co;
+        const size_t pneed = ((size_t)bm * (pbn + 4) + 16 * pbn) * sizeof(float);
         const size_t region0 = (halo * rowb > pneed ? halo * rowb : pneed);
-        const size_t ldsp = ((region0 + 15) & ~(size_t)15) + 9 * Co * rowb + 8 * Co * sizeof(float);      // halo / epilogue image | nine weight slices | per-channel vectors
+        const size_t ldsp = ((region0 + 15) & ~(size_t)15) + 9 * pbn * rowb + 8 * 64 * sizeof(float);      // halo / epilogue image | nine weight slices | per-channel vectors
+        const long pwgs = (long)(persist < nblk ? persist : nblk) * (Co / pbn);
         // float32 images of a 32-channel layer are 68 KB: two workgroups per CU, taken where the launch is no more than that (128 x 128 input, stage 2:
-        // 256 tiles -- one workgroup per CU, its tap loop barrier-free at the float32 MFMA rate)
-        if (ldsp <= 64 * 1024 || (ldsp <= 80 * 1024 && nblk <= 512)) {
+        // 256 tiles -- one workgroup per CU, its tap loop barrier-free at the float32 MFMA rate); the 64-channel form: 94 KB, one per CU
+        if (ldsp <= 64 * 1024 || (ldsp <= 80 * 1024 && pwgs <= 512) || (ldsp <= 160 * 1024 && pwgs <= 256)) {
             a.woff = (int)((region0 + 15) & ~(size_t)15);
             a.ntiles = nblk;
-            a.ltw = ilog2(a.tiles_x); a.lth = ilog2(a.tiles_y);       // (the tile itself is compile-time 8 x 16 there: the fields carry the tile COUNTS' logs)
-            const dim3 gp(persist < nblk ? persist : nblk, 1);
-            if (getenv("DPP_C3_PERSIST_VERBOSE")) fprintf(stderr, "conv3x3_p_kernel: %d tiles on %d workgroups, C %d, prec %d, store %d, %zu bytes of LDS\n", nblk, (int)gp.x, Ci, precision, store, ldsp);
-#define DPP_C3P(BN_, P_, T_, E_) do { \
-            if (ldsp > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p_kernel<BN_, P_, T_, E_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); \
-            DPP_LAUNCH((conv3x3_p_kernel<BN_, P_, T_, E_>), gp, dim3(DPP_THREADS), ldsp, st, a); return dpp_launch_status(); } while (0)
-#define DPP_C3PE(BN_, P_, T_) do { if (store & (DPP_ST_C | DPP_ST_BNX)) DPP_C3P(BN_, P_, T_, true); else DPP_C3P(BN_, P_, T_, false); } while (0)
-#define DPP_C3PX(BN_) if (Co == BN_) { \
-            if (precision) { if (store & DPP_ST_A) DPP_C3PE(BN_, 1, dpp_bf16); else DPP_C3PE(BN_, 1, float); } \
-            if (store & DPP_ST_A) DPP_C3PE(BN_, 0, dpp_bf16); else DPP_C3PE(BN_, 0, float); }
-            DPP_C3PX(16) DPP_C3PX(32)
+            if (geom0) { a.ltw = ilog2(a.tiles_x); a.lth = ilog2(a.tiles_y); }      // (the tile itself is compile-time 8 x 16 there: the fields carry the tile COUNTS' logs)
+            const dim3 gp(persist < nblk ? persist : nblk, Co / pbn);
+            if (getenv("DPP_C3_PERSIST_VERBOSE")) fprintf(stderr, "conv3x3_p_kernel: %d tiles on %d x %d workgroups, C %d, prec %d, store %d, %zu bytes of LDS\n", nblk, (int)gp.x, (int)gp.y, Ci, precision, store, ldsp);
+#define DPP_C3P(CI_, BN_, P_, T_, E_, G_) do { \
+            if (ldsp > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_p_kernel<CI_, BN_, P_, T_, E_, G_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp); \
+            DPP_LAUNCH((conv3x3_p_kernel<CI_, BN_, P_, T_, E_, G_>), gp, dim3(DPP_THREADS), ldsp, st, a); return dpp_launch_status(); } while (0)
+#define DPP_C3PE(CI_, BN_, P_, T_, G_) do { if (store & (DPP_ST_C | DPP_ST_BNX)) DPP_C3P(CI_, BN_, P_, T_, true, G_); else DPP_C3P(CI_, BN_, P_, T_, false, G_); } while (0)
+#define DPP_C3PX(CI_, BN_, G_) if (Ci == CI_) { \
+            if (precision) { if (store & DPP_ST_A) DPP_C3PE(CI_, BN_, 1, dpp_bf16, G_); else DPP_C3PE(CI_, BN_, 1, float, G_); } \
+            if (store & DPP_ST_A) DPP_C3PE(CI_, BN_, 0, dpp_bf16, G_); else DPP_C3PE(CI_, BN_, 0, float, G_); }
+            DPP_C3PX(16, 16, 0) DPP_C3PX(32, 32, 0) DPP_C3PX(64, 16, 1)
 #undef DPP_C3PX
 #undef DPP_C3PE
 #undef DPP_C3P

@@ -444,7 +444,7 @@ class BackwardMixin(object):
                 # the mirrored weights only depend on the parameters: they are prepared on the side stream while the forward
                 # pass runs (the side stream is idle then) instead of sitting in the data-gradient chain
                 self._wtrans_jobs.append((st.view(layer.W), Co, Ci, Wd))       # one batched launch, see _emit_backward
-                bmd = hz.conv3x3_bm(N * Hi * Wi, Ci)
+                bmd = hz.conv3x3_bm(N * Hi * Wi, Ci, hw=(Hi, Wi), prec=self.prec)
                 epi = None
                 fuse = not acc and self._sole_consumer_bn_view(src)
                 if not acc and self._conv3_stream(N, Hi, Wi, Ci, Co, dY, dst, src.base.buf if fuse else None):

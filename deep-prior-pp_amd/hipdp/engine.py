@@ -569,7 +569,7 @@ class CompiledNet(BackwardMixin):
             self.fwd.add(ops.conv3x3_stream(rt, src.base.buf, N, Hi, Wi, Ci, st.view(layer.W), out.buf, actX=act, bias=st.view(layer.b), epi=epi,
                                             name='conv3x3_%d' % layer.layerNum))
         else:
-            bm = hz.conv3x3_bm(M, Co)
+            bm = hz.conv3x3_bm(M, Co, hw=(Hi, Wi), prec=self.prec)
             if want_stats:
                 th, tw, img = (C_int() for _ in range(3))
                 nblk = rt.lib.dpp_conv3x3_tiling(N, Hi, Wi, bm, th, tw, img)

@@ -134,7 +134,8 @@ def test_conv3x3_filter_gradient_on_transposed_images(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('cfg', [(3, 16, 32, 16, 0, 0), (2, 9, 20, 16, 0, 1), (3, 16, 16, 32, 0, 0), (2, 24, 16, 32, 1, 1), (3, 16, 32, 16, 1, 1)],
+@pytest.mark.parametrize('cfg', [(3, 16, 32, 16, 0, 0), (2, 9, 20, 16, 0, 1), (3, 16, 16, 32, 0, 0), (2, 24, 16, 32, 1, 1), (3, 16, 32, 16, 1, 1),
+                                 (7, 8, 8, 64, 0, 0), (8, 8, 8, 64, 1, 1)],
                          ids=lambda c: 'x'.join(str(v) for v in c))
 def test_tile_walking_conv3x3_equals_one_workgroup_per_tile(backend, cfg, monkeypatch):
     """conv3x3_p_kernel (round 6: a workgroup stages the nine weight slices once and walks tiles, the next halo in flight) against
@@ -144,6 +145,7 @@ def test_tile_walking_conv3x3_equals_one_workgroup_per_tile(backend, cfg, monkey
     from tests.test_bf16_store import both, _bn_coeffs
     rt = get_runtime(backend)
     N, H, W, Cc, prec, st16 = cfg
+    monkeypatch.setenv('DPP_C3_P_64', '2')            # (the 64-channel form in float32 as well: off by default)
     rng = np.random.RandomState(41)
     x16, x32 = both(rt, rng.normal(size=(N, H, W, Cc)) + 0.2)
     X = x16 if st16 else x32
@@ -169,7 +171,7 @@ def test_tile_walking_conv3x3_equals_one_workgroup_per_tile(backend, cfg, monkey
         rt.synchronize()
         got[mode] = (Y.get(), stats.get(), dX.get(), part.get())
     for k, (a, b) in enumerate(zip(got['0'], got['3'])):
-        if k in (0, 2) or Cc == 16:
+        if k in (0, 2) or Cc == 16 or Cc == 64:         # (64 channels: 16-column workgroups in both kernels, two whole 8 x 8 images per tile)
             assert np.array_equal(a, b)
         else:
             # 32 channels: the walk keeps the 32 columns of a tile together, the one-tile kernel splits a launch this small into 16-column

@@ -48,7 +48,7 @@ def main():
         vec = lambda lo, hi: rt.upload(rng.uniform(lo, hi, C).astype(np.float32))  # noqa: E731
         mean, scale, beta, bias = vec(-.3, .3), vec(.5, 1.5), vec(-.3, .3), vec(-.1, .1)
         act = ops.act(Act.BN_RELU, mean, scale, beta, C)
-        bm = args.bm or hz.conv3x3_bm(N * H * W, C)
+        bm = args.bm or hz.conv3x3_bm(N * H * W, C, hw=(H, W), prec=prec)
         nblk = rt.lib.dpp_conv3x3_tiling(N, H, W, bm, None, None, None)
         stats = rt.alloc((nblk, 2, C), zero=False)
         bn = _BN()
