@@ -437,7 +437,8 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU((CI * (PREC ? 2 : 4) 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
     const TX* const Xg = reinterpret_cast<const TX*>(a.X);
     const int H = a.H, W = a.W;
-    const int col0 = GEOM ? (int)blockIdx.y * BN : 0, Co = GEOM ? a.Co : BN;       // (GEOM 0: square layers, the whole column range in one workgroup)
+    constexpr bool SPLIT = GEOM != 0 || BN != CI;                                // column tiles over blockIdx.y (else: a square layer's whole column range)
+    const int col0 = SPLIT ? (int)blockIdx.y * BN : 0, Co = SPLIT ? a.Co : BN;
 
     // Per-channel vectors (epilogue, this workgroup's BN columns: bias, BatchNorm-backward mean / scale / beta / inv_std; prologue, the CI input
     // channels: mean / scale / beta) live in LDS, staged once: in registers they are 32 values held across the whole walk.  Cf[v][CW]; an absent
@@ -835,7 +836,13 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     static const int p_min = []() { const char* e = getenv("DPP_C3_P_MIN_TILES"); return e ? atoi(e) : 0; }();      // (experiments: the walk only above this many tiles)
     const bool p_always = nblk > p_min;
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    const bool geom0 = (Ci == 16 || Ci == 32) && a.img == 1 && TH == 8 && TW == 16 && H % TH == 0 && W % TW == 0 && pow2(a.tiles_x) && pow2(a.tiles_y);
+    // (64 channels on 8 x 16 tiles: bf16 operands only -- the 16 x 16 maps of the 256 x 256 net, 256 tiles.  DPP_C3_P_64W = the column tile, 0: off.
+    // us per launch alone, forward / data gradient: 512 one-tile workgroups of 64 x 64 16.8 / 16.7, the walk with 64 columns (124 KB of LDS, one
+    // workgroup per CU) 12.5 / 12.9, with 32 columns (70 KB, two per CU) 11.6 / 11.3; the bf16 256 x 256 step, same box: 6.83 / 6.75 -> 6.67 -> 6.57 ms)
+    const char* g0e = getenv("DPP_C3_P_64W");
+    const int bn64 = g0e ? atoi(g0e) : 32;
+    const bool geom0 = (Ci == 16 || Ci == 32 || (Ci == 64 && precision && (bn64 == 64 || bn64 == 32))) && a.img == 1 && TH == 8 && TW == 16 && H % TH == 0 && W % TW == 0 &&
+                       pow2(a.tiles_x) && pow2(a.tiles_y);
     // ... and the 64-channel layers of 8 x 8 maps (stages 3-4 at 128 x 128 input): two whole images per tile, 16 of the 64 output columns per
     // workgroup (blockIdx.y), 94 KB of LDS -- 256 workgroups, one per CU, instead of 512 that met at a barrier after every tap
     // bf16 operands only by default (52 KB per workgroup): the float32 form (94 KB, one workgroup per CU) is 12.3 / 12.1 us per launch against 12.8 / 12.4
@@ -846,7 +853,7 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
     const bool geom1 = (geom1_on >= 2 || (geom1_on == 1 && precision)) && Ci == 64 && H == 8 && W == 8 && a.img == 2 && TH == 8 && TW == 8;
     if (persist > 0 && a.wide && Ci == Co && bm == 128 && p_always && (geom0 || geom1) && (long)N * H * W * Ci < (1L << 31)) {
         // (GEOM 0: whole 16 / 32 column tiles, whatever the column split of the one-tile kernel would have been)
-        const int pbn = geom1 ? 16 : Co;
+        const int pbn = geom1 ? 16 : (Ci == 64 ? bn64 : Co);
         const size_t pneed = ((size_t)bm * (pbn + 4) + 16 * pbn) * sizeof(float);
         const size_t region0 = (halo * rowb > pneed ? halo * rowb : pneed);
         const size_t ldsp = ((region0 + 15) & ~(size_t)15) + 9 * pbn * rowb + 8 * 64 * sizeof(float);      // halo / epilogue image | nine weight slices | per-channel vectors
@@ -866,7 +873,10 @@ static int conv3x3_launch(const float* X, int N, int H, int W, int Ci, const dpp
 #define DPP_C3PX(CI_, BN_, G_) if (Ci == CI_) { \
             if (precision) { if (store & DPP_ST_A) DPP_C3PE(CI_, BN_, 1, dpp_bf16, G_); else DPP_C3PE(CI_, BN_, 1, float, G_); } \
             if (store & DPP_ST_A) DPP_C3PE(CI_, BN_, 0, dpp_bf16, G_); else DPP_C3PE(CI_, BN_, 0, float, G_); }
-            DPP_C3PX(16, 16, 0) DPP_C3PX(32, 32, 0) DPP_C3PX(64, 16, 1)
+            DPP_C3PX(16, 16, 0) DPP_C3PX(32, 32, 0)
+            if (geom1) { DPP_C3PX(64, 16, 1) }
+            if (Ci == 64 && precision && pbn == 64) { if (store & DPP_ST_A) DPP_C3PE(64, 64, 1, dpp_bf16, 0); else DPP_C3PE(64, 64, 1, float, 0); }
+            if (Ci == 64 && precision && pbn == 32) { if (store & DPP_ST_A) DPP_C3PE(64, 32, 1, dpp_bf16, 0); else DPP_C3PE(64, 32, 1, float, 0); }
 #undef DPP_C3PX
 #undef DPP_C3PE
 #undef DPP_C3P

@@ -235,7 +235,7 @@ C3_P64 = knob('DPP_C3_P64', '1') != '0'
 def conv3x3_bm(pixels, Co, hw=None, prec=0):
     """Rows per workgroup of the 3x3 kernel (the choice dpp_conv3x3 makes for bm = 0, made explicit so that the host knows
     the row-block count of the fused epilogue partials).  `hw`: the map size, `prec`: bf16 MFMA operands, where the caller knows them."""
-    if Co == 64 and C3_P64 and prec and hw == (8, 8) and pixels % 128 == 0:
+    if Co == 64 and C3_P64 and prec and hw in ((8, 8), (16, 16)) and pixels % 128 == 0:
         # the 64-channel layers of 8 x 8 maps (stages 3-4 at 128 x 128 input) on the tile-walking kernel: two whole images per workgroup, 16 of the
         # 64 columns each -- 256 workgroups, all nine weight slices resident (conv3x3_p_kernel, GEOM 1).  bf16 operands only: 2.998 -> 2.928 ms per
         # step; the float32 form needs 94 KB of LDS per workgroup and the step is slower with it (3.371 -> 3.400 ms), see conv3x3.hip
