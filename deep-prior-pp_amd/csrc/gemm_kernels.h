@@ -680,13 +680,18 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
     constexpr int SB = BN * QK / DPP_THREADS;
     constexpr int KS = KT / 4;                               // K slice of a wave
     static_assert(DPP_THREADS % QK == 0 && (BM * QK) % DPP_THREADS == 0 && (BN * QK) % DPP_THREADS == 0 && KS % 16 == 0, "tile");
+    // LDS: [A tile | the epilogue's four partial-tile images (they take A's place, and more)] [B: resident for the whole walk]
+    constexpr int EPI_FLOATS = 4 * BM * (BN + 4) + 16 * BN, A_REGION = (BM * LDA_ > EPI_FLOATS ? BM * LDA_ : EPI_FLOATS);
     float* const As = smem;
-    float* const Bs = smem + BM * LDA_;
+    float* const Bs = smem + A_REGION;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+    const int col0 = blockIdx.y * BN, ntiles = d.M / BM;
     dpp_stamp(ga.prof, 0);
 
-    // ---- every load of the kernel, back to back ----
+    // A workgroup WALKS row tiles blockIdx.x, + gridDim.x, ... (the launch is as many workgroups as are resident at once -- one per CU at
+    // 100 KB of LDS): the B slice -- 64 of the 96 KB a 32-row tile takes in -- is staged ONCE, and the next tile's A rows are requested right
+    // after the current tile's commit, so they travel under its products and epilogue.  With one tile per workgroup the 1 024-tile launches
+    // of the 256 x 256 net were four rounds on a CU, each re-reading B (22 us against 9 us for 256 tiles).
     const int modeA = d.actA.mode;
     const int ka = (tid % QK) * 4;                           // this thread's k-quad (the same for all its A slots)
     float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), sc = mu, be = mu;
@@ -697,16 +702,8 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
     }
     float4 ra[SA], rb[SB];
     constexpr int QN = BN / 4;
-    {   // B first (its commit is nothing but LDS writes), then A: loads return in issue order
-        if (BKC) {
-            const float* pb = d.B + (size_t)(col0 + tid / QK) * d.ldb + ka;
-#pragma unroll
-            for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb + (size_t)s * (DPP_THREADS / QK) * d.ldb);
-        } else {
-            const float* pb = d.B + (size_t)(tid / QN) * d.ldb + col0 + (tid % QN) * 4;
-#pragma unroll
-            for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb + (size_t)s * (DPP_THREADS / QN) * d.ldb);
-        }
+    auto fetch_a = [&](int tile) {
+        const int row0 = tile * BM;
         if (ST && ga.shA) {                                 // bf16-stored activations: 8-byte loads, widened at the commit
             const float* pa = d.A + (((size_t)(row0 + tid / QK) * d.lda + ka) >> 1);
 #pragma unroll
@@ -716,12 +713,23 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
 #pragma unroll
             for (int s = 0; s < SA; ++s) ra[s] = *reinterpret_cast<const float4*>(pa + (size_t)s * (DPP_THREADS / QK) * d.lda);
         }
+    };
+    int tile = blockIdx.x;
+    {   // B first (its commit is nothing but LDS writes), then the first A tile: loads return in issue order
+        if (BKC) {
+            const float* pb = d.B + (size_t)(col0 + tid / QK) * d.ldb + ka;
+#pragma unroll
+            for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb + (size_t)s * (DPP_THREADS / QK) * d.ldb);
+        } else {
+            const float* pb = d.B + (size_t)(tid / QN) * d.ldb + col0 + (tid % QN) * 4;
+#pragma unroll
+            for (int s = 0; s < SB; ++s) rb[s] = *reinterpret_cast<const float4*>(pb + (size_t)s * (DPP_THREADS / QN) * d.ldb);
+        }
+        fetch_a(tile);
     }
     dpp_wide_coef wco;
     wco.load<BN>(col0, d.N, d.bias, d.epi, d.C);
     dpp_stamp(ga.prof, 1);
-
-    // ---- commit: both operands into LDS, the prologue on A ----
     {
         if (BKC) {
             float* lb = Bs + (tid / QK) * LDB_ + ka;
@@ -732,6 +740,12 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
 #pragma unroll
             for (int s = 0; s < SB; ++s) *reinterpret_cast<float4*>(lb + s * (DPP_THREADS / QN) * LDB_) = rb[s];
         }
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * BM;
+    if (tile != (int)blockIdx.x) __syncthreads();            // the previous tile's epilogue is done with the images that share A's place
+    // ---- commit: this tile's A rows into LDS with the prologue ----
+    {
         float* la = As + (tid / QK) * LDA_ + ka;
 #pragma unroll
         for (int s = 0; s < SA; ++s) {
@@ -745,7 +759,8 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
         }
     }
     __syncthreads();
-    dpp_stamp(ga.prof, 2);
+    if (tile == (int)blockIdx.x) dpp_stamp(ga.prof, 2);
+    if (tile + (int)gridDim.x < ntiles) fetch_a(tile + gridDim.x);
 
     // ---- wave `wave` multiplies k in [wave*KS, wave*KS + KS): lane (i, kq) owns k = base + 16 g + 4 kq + t ----
     f32x4 acc[RM][CN];
@@ -816,10 +831,11 @@ __global__ __launch_bounds__(DPP_THREADS) DPP_WAVES_PER_EU(1, KT >= 256 ? 1 : 4)
                 for (int ct = 0; ct < CN; ++ct)
                     acc[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[rt][t], bf[ct][t], acc[rt][ct], 0, 0, 0);
     }
-    __syncthreads();                         // the operand images are dead: the epilogue's tile images take their place
-    dpp_stamp(ga.prof, 3);
+    __syncthreads();                         // the A image is dead: the epilogue's tile images take its place
+    if (tile == (int)blockIdx.x) dpp_stamp(ga.prof, 3);
     dpp_epilogue_wide<RM, CN, 1, 1, BM, BN, 4, ST>(acc, smem, col0, d.N, wco, d.residual, d.C, d.epi, BM, 0, 0, l15, kq,
-                                               [&](int rl) { return (long)(row0 + rl) * d.ldc; }, wave, d.store);
+                                               [&](int rl) { return (long)(row0 + rl) * d.ldc; }, wave, d.store, tile, ntiles);
+    }
     dpp_stamp(ga.prof, 4);
 }
 
@@ -1285,12 +1301,14 @@ static int ksplit_bn(const dpp_gemm_desc& d, const GemmArgs& ga) {
 template <int KT, int BN, bool BKC, bool ST, bool PB = false>
 static int launch_ksplit(const GemmArgs& ga, hipStream_t st) {
     const dpp_gemm_desc& d = ga.d;
-    constexpr int opnd = 32 * (KT + 4) + (BKC ? BN * (KT + 4) : KT * (BN + 4));
-    constexpr int epil = 4 * 32 * (BN + 4) + 16 * BN;
-    constexpr size_t lds = sizeof(float) * (opnd > epil ? opnd : epil);
+    constexpr int epil = 4 * 32 * (BN + 4) + 16 * BN, aimg = 32 * (KT + 4);
+    constexpr size_t lds = sizeof(float) * ((aimg > epil ? aimg : epil) + (BKC ? BN * (KT + 4) : KT * (BN + 4)));
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ksplit_kernel<KT, BN, BKC, ST, PB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    DPP_LAUNCH((gemm_ksplit_kernel<KT, BN, BKC, ST, PB>), dim3(d.M / 32, d.N / BN), dim3(DPP_THREADS), lds, st, ga);
+    // as many workgroups as are resident at once (LDS: one per CU for K = 256, four for K = 128), walking the row tiles; DPP_KSPLIT_WALK=0: one tile each
+    static const bool walk = []() { const char* e = getenv("DPP_KSPLIT_WALK"); return !(e && e[0] == '0'); }();
+    const int ntiles = d.M / 32, ncol = d.N / BN, cap = (int)((160 * 1024 / lds) * 256 / ncol);
+    DPP_LAUNCH((gemm_ksplit_kernel<KT, BN, BKC, ST, PB>), dim3((walk && ntiles > cap && cap > 0) ? cap : ntiles, ncol), dim3(DPP_THREADS), lds, st, ga);
     return dpp_launch_status();
 }
 

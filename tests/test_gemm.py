@@ -194,7 +194,8 @@ def test_rowstream_variant_fwd_and_dgrad(backend, cfg):
 
 
 @pytest.mark.parametrize('backend', BACKENDS)
-@pytest.mark.parametrize('cfg', [(256, 64, 96), (256, 128, 96), (128, 32, 96), (128, 96, 96), (256, 64, 512), (128, 32, 1024)])
+@pytest.mark.parametrize('cfg', [(256, 64, 96), (256, 128, 96), (128, 32, 96), (128, 96, 96), (256, 64, 512), (128, 32, 1024),
+                                 (256, 128, 4160), (128, 32, 32960)])       # (the last two: more row tiles than workgroups -- 130 on 128, 1 030 on 1 024: the walk)
 def test_ksplit_variant_fwd_and_dgrad(backend, cfg):
     """The K-split kernel (variant 2: 32 rows x all columns x the whole K per workgroup, the waves split K, partial tiles summed in
     the epilogue's LDS images): 1x1 conv forward (filters K-contiguous) with BN+ReLU prologue, bias, residual and fused statistics,
