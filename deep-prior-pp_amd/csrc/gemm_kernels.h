@@ -1048,13 +1048,18 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16t_kernel(GemmArgs ga
     __shared__ __attribute__((aligned(16))) float red[4 * N];
     constexpr int ROWS = 64 * TPW;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
-    const int wrow0 = blockIdx.x * ROWS + wave * 16 * TPW;
     const dpp_epilogue& ep = d.epi;
     const bool bn = EPI && ep.bn_x != nullptr;
+    const bool has_res = EPI && d.residual != nullptr;
     const int modeA = ACT ? d.actA.mode : 0;
     const bool c16 = ST && (d.store & DPP_ST_C) != 0, x16 = ST && (d.store & DPP_ST_BNX) != 0;
+    const int nblocks = d.M / ROWS;
 
-    // ---- every load up front: filter fragments (lane (i, kq): filter row = output channel ct * 16 + i, k = 16 g + 4 kq ..), pixel rows ----
+    // A workgroup WALKS row blocks blockIdx.x, + gridDim.x, ... (the launch is what is resident at once): the filter fragments and per-channel
+    // vectors are loaded once, and the next block's rows (operand, residual, BatchNorm input) are requested as soon as the current block's
+    // products are issued, so they travel under its epilogue and column sums.  One block per workgroup, the 4 096-block launches of the
+    // 256 x 256 net were four rounds of entry code + one exposed round trip each.
+    // ---- loaded once: filter fragments (lane (i, kq): filter row = output channel ct * 16 + i, k = 16 g + 4 kq ..), per-channel vectors ----
     float4 bw[G][CN];
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -1066,19 +1071,42 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16t_kernel(GemmArgs ga
                 bw[g][ct] = make_float4(pb[0], pb[d.ldb], pb[2 * (size_t)d.ldb], pb[3 * (size_t)d.ldb]);
             }
         }
+    // RAW loads (16 bytes, or 8 of a bf16-stored tensor), widened where they are used: `bn ? dpp_ld4_rt(..) : zero` converts inside the branch, and the
+    // branch then ends on s_waitcnt vmcnt(0) -- the data-gradient instance on bf16-stored tensors waited out four round trips one after the other here
     float4 ra[TPW][G];
+    float4 xr32[TPW][CN], rr32[TPW][CN];
+    uint2 xr16[TPW][CN], rr16[TPW][CN];
+    auto fetch = [&](int block) {
+        const int wrow0 = block * ROWS + wave * 16 * TPW;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        if (ST && ga.shA) {
-            const float* pa = d.A + (((size_t)(wrow0 + t * 16 + l15) * d.lda + kq * 4) >> 1);
+        for (int t = 0; t < TPW; ++t) {
+            if (ST && ga.shA) {
+                const float* pa = d.A + (((size_t)(wrow0 + t * 16 + l15) * d.lda + kq * 4) >> 1);
 #pragma unroll
-            for (int g = 0; g < G; ++g) ra[t][g] = dpp_raw8(pa + g * 8);
-        } else {
-            const float* pa = d.A + (size_t)(wrow0 + t * 16 + l15) * d.lda + kq * 4;
+                for (int g = 0; g < G; ++g) ra[t][g] = dpp_raw8(pa + g * 8);
+            } else {
+                const float* pa = d.A + (size_t)(wrow0 + t * 16 + l15) * d.lda + kq * 4;
 #pragma unroll
-            for (int g = 0; g < G; ++g) ra[t][g] = *reinterpret_cast<const float4*>(pa + g * 16);
+                for (int g = 0; g < G; ++g) ra[t][g] = *reinterpret_cast<const float4*>(pa + g * 16);
+            }
         }
-    }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                const size_t o = (size_t)(wrow0 + t * 16 + l15) * d.ldc + ct * 16 + kq * 4;
+                if (bn) {
+                    if (x16) xr16[t][ct] = *reinterpret_cast<const uint2*>(reinterpret_cast<const dpp_bf16*>(ep.bn_x) + o);
+                    else xr32[t][ct] = *reinterpret_cast<const float4*>(ep.bn_x + o);
+                }
+                if (has_res) {
+                    if (c16) rr16[t][ct] = *reinterpret_cast<const uint2*>(reinterpret_cast<const dpp_bf16*>(d.residual) + o);
+                    else rr32[t][ct] = *reinterpret_cast<const float4*>(d.residual + o);
+                }
+            }
+    };
+    int block = blockIdx.x;
+    fetch(block);
     float4 mu[G], sc[G], be[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -1089,7 +1117,7 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16t_kernel(GemmArgs ga
             be[g] = *reinterpret_cast<const float4*>(d.actA.beta + g * 16 + kq * 4);
         }
     }
-    // per-channel vectors of this lane's quad (channels ct * 16 + 4 kq ..), residual / BatchNorm input of its output elements
+    // per-channel vectors of this lane's quad (channels ct * 16 + 4 kq ..)
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 cb[CN], cmean[CN], cscale[CN], cbeta[CN], cistd[CN];
 #pragma unroll
@@ -1101,109 +1129,9 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16t_kernel(GemmArgs ga
         cbeta[ct] = bn ? *reinterpret_cast<const float4*>(ep.bn_beta + c0) : z4;
         cistd[ct] = bn ? *reinterpret_cast<const float4*>(ep.bn_inv_std + c0) : z4;
     }
-    // RAW loads (16 bytes, or 8 of a bf16-stored tensor), widened where they are used: `bn ? dpp_ld4_rt(..) : zero` converts inside the branch, and the
-    // branch then ends on s_waitcnt vmcnt(0) -- the data-gradient instance on bf16-stored tensors waited out four round trips one after the other here
-    const bool has_res = EPI && d.residual != nullptr;
-    float4 xr32[TPW][CN], rr32[TPW][CN];
-    uint2 xr16[TPW][CN], rr16[TPW][CN];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-        for (int ct = 0; ct < CN; ++ct) {
-            const size_t o = (size_t)(wrow0 + t * 16 + l15) * d.ldc + ct * 16 + kq * 4;
-            if (bn) {
-                if (x16) xr16[t][ct] = *reinterpret_cast<const uint2*>(reinterpret_cast<const dpp_bf16*>(ep.bn_x) + o);
-                else xr32[t][ct] = *reinterpret_cast<const float4*>(ep.bn_x + o);
-            }
-            if (has_res) {
-                if (c16) rr16[t][ct] = *reinterpret_cast<const uint2*>(reinterpret_cast<const dpp_bf16*>(d.residual) + o);
-                else rr32[t][ct] = *reinterpret_cast<const float4*>(d.residual + o);
-            }
-        }
     auto widen8 = [](const uint2& r) {
         return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u));
     };
-
-    float4 vals[TPW][CN];
-    float4 sx[CN], sy[CN];
-#pragma unroll
-    for (int ct = 0; ct < CN; ++ct) { sx[ct] = z4; sy[ct] = z4; }
-    float4 xr[TPW][CN], rr[TPW][CN];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-#pragma unroll
-        for (int ct = 0; ct < CN; ++ct) {
-            xr[t][ct] = bn ? (x16 ? widen8(xr16[t][ct]) : xr32[t][ct]) : z4;
-            rr[t][ct] = has_res ? (c16 ? widen8(rr16[t][ct]) : rr32[t][ct]) : z4;
-        }
-        f32x4 acc[CN];
-#pragma unroll
-        for (int ct = 0; ct < CN; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float4 va[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float4 v = (ST && ga.shA) ? dpp_widen4(ra[t][g]) : ra[t][g];
-            if (modeA & 2) {
-                v.x = dpp_fma(v.x - mu[g].x, sc[g].x, be[g].x); v.y = dpp_fma(v.y - mu[g].y, sc[g].y, be[g].y);
-                v.z = dpp_fma(v.z - mu[g].z, sc[g].z, be[g].z); v.w = dpp_fma(v.w - mu[g].w, sc[g].w, be[g].w);
-            }
-            if (modeA & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            va[g] = v;
-        }
-        if constexpr (PB) {
-#pragma unroll
-            for (int h = 0; h < (G + 1) / 2; ++h) {
-                const float4 a0 = va[2 * h], a1 = (2 * h + 1 < G) ? va[(2 * h + 1 < G) ? 2 * h + 1 : 0] : z4;
-                dpp_bf16x8 af;
-                af[0] = (dpp_bf16)a0.x; af[1] = (dpp_bf16)a0.y; af[2] = (dpp_bf16)a0.z; af[3] = (dpp_bf16)a0.w;
-                af[4] = (dpp_bf16)a1.x; af[5] = (dpp_bf16)a1.y; af[6] = (dpp_bf16)a1.z; af[7] = (dpp_bf16)a1.w;
-#pragma unroll
-                for (int ct = 0; ct < CN; ++ct) {
-                    const float4 b0 = bw[2 * h][ct], b1 = (2 * h + 1 < G) ? bw[(2 * h + 1 < G) ? 2 * h + 1 : 0][ct] : z4;
-                    dpp_bf16x8 bf;
-                    bf[0] = (dpp_bf16)b0.x; bf[1] = (dpp_bf16)b0.y; bf[2] = (dpp_bf16)b0.z; bf[3] = (dpp_bf16)b0.w;
-                    bf[4] = (dpp_bf16)b1.x; bf[5] = (dpp_bf16)b1.y; bf[6] = (dpp_bf16)b1.z; bf[7] = (dpp_bf16)b1.w;
-                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af, acc[ct], 0, 0, 0);      // filter rows x pixel columns
-                }
-            }
-        } else
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const float4 v = va[g];
-#pragma unroll
-            for (int ct = 0; ct < CN; ++ct) {
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].x, v.x, acc[ct], 0, 0, 0);
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].y, v.y, acc[ct], 0, 0, 0);
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].z, v.z, acc[ct], 0, 0, 0);
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].w, v.w, acc[ct], 0, 0, 0);
-            }
-        }
-        // D^T layout: this lane holds channels ct * 16 + 4 kq + r (r = 0 .. 3) of pixel row wrow0 + 16 t + l15
-#pragma unroll
-        for (int ct = 0; ct < CN; ++ct) {
-            const size_t o = (size_t)(wrow0 + t * 16 + l15) * d.ldc + ct * 16 + kq * 4;
-            float v[4] = {acc[ct][0] + cb[ct].x + rr[t][ct].x, acc[ct][1] + cb[ct].y + rr[t][ct].y, acc[ct][2] + cb[ct].z + rr[t][ct].z,
-                          acc[ct][3] + cb[ct].w + rr[t][ct].w};
-            if (bn) {
-                const float dx[4] = {xr[t][ct].x - cmean[ct].x, xr[t][ct].y - cmean[ct].y, xr[t][ct].z - cmean[ct].z, xr[t][ct].w - cmean[ct].w};
-                const float cs[4] = {cscale[ct].x, cscale[ct].y, cscale[ct].z, cscale[ct].w}, cbt[4] = {cbeta[ct].x, cbeta[ct].y, cbeta[ct].z, cbeta[ct].w};
-                const float ci[4] = {cistd[ct].x, cistd[ct].y, cistd[ct].z, cistd[ct].w};
-                float sxa[4] = {sx[ct].x, sx[ct].y, sx[ct].z, sx[ct].w}, sya[4] = {sy[ct].x, sy[ct].y, sy[ct].z, sy[ct].w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (ep.bn_relu && dx[r] * cs[r] + cbt[r] < 0.0f) v[r] = 0.0f;
-                    if (c16) v[r] = dpp_bf16_round(v[r]);            // bf16-stored gradient: sums of the values as stored
-                    sxa[r] += v[r];
-                    sya[r] += v[r] * (dx[r] * ci[r]);
-                }
-                sx[ct] = make_float4(sxa[0], sxa[1], sxa[2], sxa[3]);
-                sy[ct] = make_float4(sya[0], sya[1], sya[2], sya[3]);
-            }
-            const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
-            if (c16) dpp_st4(reinterpret_cast<dpp_bf16*>(d.C) + o, v4); else *reinterpret_cast<float4*>(d.C + o) = v4;
-            vals[t][ct] = v4;
-        }
-    }
     // ---- column sums: the 16 pixel lanes of a quad by xor shuffles, the four waves through LDS in wave order ----
     auto colsum = [&](float4 (&s)[CN]) {
 #pragma unroll
@@ -1231,47 +1159,141 @@ __global__ __launch_bounds__(DPP_THREADS) void gemm_stream16t_kernel(GemmArgs ga
             s[ct] = t;
         }
     };
-    auto put = [&](float* dst, int which, const float4 (&s)[CN]) {
-        if (wave == 0 && l15 == 0) {
+
+    for (; block < nblocks; block += gridDim.x) {
+        const int wrow0 = block * ROWS + wave * 16 * TPW;
+        // ---- this block's epilogue operands out of the fetch registers (the next fetch reuses them) ----
+        float4 xr[TPW][CN], rr[TPW][CN];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
 #pragma unroll
             for (int ct = 0; ct < CN; ++ct) {
-                const int c0 = ct * 16 + kq * 4;
-                dst[dpp_partial_index(which, c0 + 0, blockIdx.x, N, gridDim.x)] = s[ct].x;
-                dst[dpp_partial_index(which, c0 + 1, blockIdx.x, N, gridDim.x)] = s[ct].y;
-                dst[dpp_partial_index(which, c0 + 2, blockIdx.x, N, gridDim.x)] = s[ct].z;
-                dst[dpp_partial_index(which, c0 + 3, blockIdx.x, N, gridDim.x)] = s[ct].w;
+                xr[t][ct] = bn ? (x16 ? widen8(xr16[t][ct]) : xr32[t][ct]) : z4;
+                rr[t][ct] = has_res ? (c16 ? widen8(rr16[t][ct]) : rr32[t][ct]) : z4;
+            }
+        // ---- products of all the wave's tiles ----
+        f32x4 acc[TPW][CN];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) acc[t][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float4 va[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float4 v = (ST && ga.shA) ? dpp_widen4(ra[t][g]) : ra[t][g];
+                if (modeA & 2) {
+                    v.x = dpp_fma(v.x - mu[g].x, sc[g].x, be[g].x); v.y = dpp_fma(v.y - mu[g].y, sc[g].y, be[g].y);
+                    v.z = dpp_fma(v.z - mu[g].z, sc[g].z, be[g].z); v.w = dpp_fma(v.w - mu[g].w, sc[g].w, be[g].w);
+                }
+                if (modeA & 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                va[g] = v;
+            }
+            if constexpr (PB) {
+#pragma unroll
+                for (int h = 0; h < (G + 1) / 2; ++h) {
+                    const float4 a0 = va[2 * h], a1 = (2 * h + 1 < G) ? va[(2 * h + 1 < G) ? 2 * h + 1 : 0] : z4;
+                    dpp_bf16x8 af;
+                    af[0] = (dpp_bf16)a0.x; af[1] = (dpp_bf16)a0.y; af[2] = (dpp_bf16)a0.z; af[3] = (dpp_bf16)a0.w;
+                    af[4] = (dpp_bf16)a1.x; af[5] = (dpp_bf16)a1.y; af[6] = (dpp_bf16)a1.z; af[7] = (dpp_bf16)a1.w;
+#pragma unroll
+                    for (int ct = 0; ct < CN; ++ct) {
+                        const float4 b0 = bw[2 * h][ct], b1 = (2 * h + 1 < G) ? bw[(2 * h + 1 < G) ? 2 * h + 1 : 0][ct] : z4;
+                        dpp_bf16x8 bf;
+                        bf[0] = (dpp_bf16)b0.x; bf[1] = (dpp_bf16)b0.y; bf[2] = (dpp_bf16)b0.z; bf[3] = (dpp_bf16)b0.w;
+                        bf[4] = (dpp_bf16)b1.x; bf[5] = (dpp_bf16)b1.y; bf[6] = (dpp_bf16)b1.z; bf[7] = (dpp_bf16)b1.w;
+                        acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf, af, acc[t][ct], 0, 0, 0);      // filter rows x pixel columns
+                    }
+                }
+            } else
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float4 v = va[g];
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].x, v.x, acc[t][ct], 0, 0, 0);
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].y, v.y, acc[t][ct], 0, 0, 0);
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].z, v.z, acc[t][ct], 0, 0, 0);
+                    acc[t][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[g][ct].w, v.w, acc[t][ct], 0, 0, 0);
+                }
             }
         }
-    };
-    if (bn && ep.bn_partial != nullptr) {
-        colsum(sx);
-        colsum(sy);
-        put(ep.bn_partial, 0, sx);
-        put(ep.bn_partial, 1, sy);
-    }
-    if (ep.stats != nullptr) {
-        float4 sm[CN], m2[CN];
+        // ---- the next block's rows: in flight under this block's epilogue and column sums ----
+        if (block + (int)gridDim.x < nblocks) fetch(block + gridDim.x);
+
+        float4 vals[TPW][CN];
+        float4 sx[CN], sy[CN];
 #pragma unroll
-        for (int ct = 0; ct < CN; ++ct) {
-            sm[ct] = z4;
+        for (int ct = 0; ct < CN; ++ct) { sx[ct] = z4; sy[ct] = z4; }
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) { sm[ct].x += vals[t][ct].x; sm[ct].y += vals[t][ct].y; sm[ct].z += vals[t][ct].z; sm[ct].w += vals[t][ct].w; }
-        }
-        colsum(sm);
+        for (int t = 0; t < TPW; ++t) {
+            // D^T layout: this lane holds channels ct * 16 + 4 kq + r (r = 0 .. 3) of pixel row wrow0 + 16 t + l15
 #pragma unroll
-        for (int ct = 0; ct < CN; ++ct) {
-            const float inv = 1.0f / (float)ROWS;
-            sm[ct].x *= inv; sm[ct].y *= inv; sm[ct].z *= inv; sm[ct].w *= inv;
-            m2[ct] = z4;
+            for (int ct = 0; ct < CN; ++ct) {
+                const size_t o = (size_t)(wrow0 + t * 16 + l15) * d.ldc + ct * 16 + kq * 4;
+                float v[4] = {acc[t][ct][0] + cb[ct].x + rr[t][ct].x, acc[t][ct][1] + cb[ct].y + rr[t][ct].y, acc[t][ct][2] + cb[ct].z + rr[t][ct].z,
+                              acc[t][ct][3] + cb[ct].w + rr[t][ct].w};
+                if (bn) {
+                    const float dx[4] = {xr[t][ct].x - cmean[ct].x, xr[t][ct].y - cmean[ct].y, xr[t][ct].z - cmean[ct].z, xr[t][ct].w - cmean[ct].w};
+                    const float cs[4] = {cscale[ct].x, cscale[ct].y, cscale[ct].z, cscale[ct].w}, cbt[4] = {cbeta[ct].x, cbeta[ct].y, cbeta[ct].z, cbeta[ct].w};
+                    const float ci[4] = {cistd[ct].x, cistd[ct].y, cistd[ct].z, cistd[ct].w};
+                    float sxa[4] = {sx[ct].x, sx[ct].y, sx[ct].z, sx[ct].w}, sya[4] = {sy[ct].x, sy[ct].y, sy[ct].z, sy[ct].w};
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const float a0 = vals[t][ct].x - sm[ct].x, a1 = vals[t][ct].y - sm[ct].y, a2 = vals[t][ct].z - sm[ct].z, a3 = vals[t][ct].w - sm[ct].w;
-                m2[ct].x += a0 * a0; m2[ct].y += a1 * a1; m2[ct].z += a2 * a2; m2[ct].w += a3 * a3;
+                    for (int r = 0; r < 4; ++r) {
+                        if (ep.bn_relu && dx[r] * cs[r] + cbt[r] < 0.0f) v[r] = 0.0f;
+                        if (c16) v[r] = dpp_bf16_round(v[r]);            // bf16-stored gradient: sums of the values as stored
+                        sxa[r] += v[r];
+                        sya[r] += v[r] * (dx[r] * ci[r]);
+                    }
+                    sx[ct] = make_float4(sxa[0], sxa[1], sxa[2], sxa[3]);
+                    sy[ct] = make_float4(sya[0], sya[1], sya[2], sya[3]);
+                }
+                const float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
+                if (c16) dpp_st4(reinterpret_cast<dpp_bf16*>(d.C) + o, v4); else *reinterpret_cast<float4*>(d.C + o) = v4;
+                vals[t][ct] = v4;
             }
         }
-        colsum(m2);
-        put(ep.stats, 0, sm);
-        put(ep.stats, 1, m2);
+        auto put = [&](float* dst, int which, const float4 (&s)[CN]) {
+            if (wave == 0 && l15 == 0) {
+#pragma unroll
+                for (int ct = 0; ct < CN; ++ct) {
+                    const int c0 = ct * 16 + kq * 4;
+                    dst[dpp_partial_index(which, c0 + 0, block, N, nblocks)] = s[ct].x;
+                    dst[dpp_partial_index(which, c0 + 1, block, N, nblocks)] = s[ct].y;
+                    dst[dpp_partial_index(which, c0 + 2, block, N, nblocks)] = s[ct].z;
+                    dst[dpp_partial_index(which, c0 + 3, block, N, nblocks)] = s[ct].w;
+                }
+            }
+        };
+        if (bn && ep.bn_partial != nullptr) {
+            colsum(sx);
+            colsum(sy);
+            put(ep.bn_partial, 0, sx);
+            put(ep.bn_partial, 1, sy);
+        }
+        if (ep.stats != nullptr) {
+            float4 sm[CN], m2[CN];
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                sm[ct] = z4;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) { sm[ct].x += vals[t][ct].x; sm[ct].y += vals[t][ct].y; sm[ct].z += vals[t][ct].z; sm[ct].w += vals[t][ct].w; }
+            }
+            colsum(sm);
+#pragma unroll
+            for (int ct = 0; ct < CN; ++ct) {
+                const float inv = 1.0f / (float)ROWS;
+                sm[ct].x *= inv; sm[ct].y *= inv; sm[ct].z *= inv; sm[ct].w *= inv;
+                m2[ct] = z4;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const float a0 = vals[t][ct].x - sm[ct].x, a1 = vals[t][ct].y - sm[ct].y, a2 = vals[t][ct].z - sm[ct].z, a3 = vals[t][ct].w - sm[ct].w;
+                    m2[ct].x += a0 * a0; m2[ct].y += a1 * a1; m2[ct].z += a2 * a2; m2[ct].w += a3 * a3;
+                }
+            }
+            colsum(m2);
+            put(ep.stats, 0, sm);
+            put(ep.stats, 1, m2);
+        }
     }
 }
 
@@ -1363,12 +1385,14 @@ int gemm_dispatch(GemmArgs& ga, int bm, int bn, int wm, hipStream_t st) {
         const bool act = d.actA.mode != 0, epi = d.residual != nullptr || d.epi.bn_x != nullptr;
         // the transposed-accumulator form (16- / 8-byte epilogue accesses) needs aligned quads everywhere; DPP_STREAM16T=0: the round-2 kernel
         static const bool s16t_on = []() { const char* e = getenv("DPP_STREAM16T"); return !(e && e[0] == '0'); }();
+        // workgroups of a stream16t launch: two per CU (the walking form is allocated 160-172 registers at K = 64: two or three fit), walking the row blocks; DPP_STREAM16T_WGS overrides, 0: one block each.  bf16 256 x 256 step, same box: one block each 6.55 / 6.57 ms, 512 workgroups 6.47 / 6.46, 768 6.52 / 6.50, 1 024 6.51 / 6.54
+        static const int s16t_cap = []() { const char* e = getenv("DPP_STREAM16T_WGS"); const int v = e ? atoi(e) : 512; return v > 0 ? v : (1 << 30); }();
         auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
         // ... and pays on bf16-stored tensors only: same-box A/B of the float32 128 x 128 step 3.462 / 3.465 (transposed) against 3.449 /
         // 3.452 ms (its 4-byte accesses were not the bound there), bf16 256 x 256 7.452 / 7.535 against 7.550 / 7.561 (profiles/r06_ab.txt)
         const bool s16t = s16t_on && ST && (d.store & (DPP_ST_A | DPP_ST_C | DPP_ST_BNX)) != 0 && d.ldc % 4 == 0 && al16(d.C) && al16(d.residual) && al16(d.bias) && al16(d.epi.bn_x) && al16(d.epi.bn_mean) &&
                           al16(d.epi.bn_scale) && al16(d.epi.bn_beta) && al16(d.epi.bn_inv_std);
-#define DPP_S16(K_, CN_, T_, B_, A_, E_) do { if (s16t) DPP_LAUNCH((gemm_stream16t_kernel<K_, CN_, B_, T_, A_, E_, ST, PB>), dim3(d.M / rows), dim3(DPP_THREADS), 0, st, ga); \
+#define DPP_S16(K_, CN_, T_, B_, A_, E_) do { if (s16t) DPP_LAUNCH((gemm_stream16t_kernel<K_, CN_, B_, T_, A_, E_, ST, PB>), dim3(d.M / rows > s16t_cap ? s16t_cap : d.M / rows), dim3(DPP_THREADS), 0, st, ga); \
             else DPP_LAUNCH((gemm_stream16_kernel<K_, CN_, B_, T_, A_, E_, ST, PB>), dim3(d.M / rows), dim3(DPP_THREADS), 0, st, ga); } while (0)
 #define DPP_S16_ALL(K_, CN_, T_) \
         if (d.b_kc) { if (act) { if (epi) DPP_S16(K_, CN_, T_, true, true, true); else DPP_S16(K_, CN_, T_, true, true, false); } \

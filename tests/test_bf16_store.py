@@ -539,7 +539,8 @@ def test_expand_kernel_on_bf16_mfma_operands(backend, cfg, stored):
 
 @pytest.mark.parametrize('backend', BACKENDS)
 @pytest.mark.parametrize('stored', [False, True])
-@pytest.mark.parametrize('case', ['tile_k64_n32', 'tile_k128_n32', 'tile_k40_ragged', 'ksplit256', 'ksplit128', 'stream_64_16', 'stream_16_64'])
+@pytest.mark.parametrize('case', ['tile_k64_n32', 'tile_k128_n32', 'tile_k40_ragged', 'ksplit256', 'ksplit128', 'stream_64_16', 'stream_16_64', 'stream_64_16_walk',
+                                  'stream_16_64_walk'])
 def test_gemm_tile_ksplit_and_stream_kernels_on_bf16_mfma_operands(backend, stored, case):
     """dpp_gemm variants 0, 2 and 3 with precision = 1 (round 6, VERDICT r5 item 1(a): bf16 MFMA operands for gemm_kernel, gemm_ksplit_kernel
     and gemm_stream16_kernel): forward (K-contiguous activations with the BatchNorm + ReLU prologue x K-contiguous filters), data gradient
@@ -550,7 +551,9 @@ def test_gemm_tile_ksplit_and_stream_kernels_on_bf16_mfma_operands(backend, stor
     K, N, M, variant, tile = {'tile_k64_n32': (64, 32, 192, 0, (64, 32, 4)), 'tile_k128_n32': (128, 32, 128, 0, (64, 16, 4)),
                               'tile_k40_ragged': (40, 24, 100, 0, (0, 0, 0)), 'ksplit256': (256, 64, 64, 2, (32, 64, 4)),
                               'ksplit128': (128, 32, 96, 2, (32, 32, 4)), 'stream_64_16': (64, 16, 256, 3, (128, 16, 4)),
-                              'stream_16_64': (16, 64, 128, 3, (64, 64, 4))}[case]
+                              'stream_16_64': (16, 64, 128, 3, (64, 64, 4)),
+                              # more row blocks than the 512 workgroups of a launch: the transposed stream kernel walks (bf16-stored tensors only)
+                              'stream_64_16_walk': (64, 16, 128 * 515, 3, (128, 16, 4)), 'stream_16_64_walk': (16, 64, 64 * 517, 3, (64, 64, 4))}[case]
     rng = np.random.RandomState(83)
     q = lambda v: widen(bf16_bits(np.asarray(v, np.float32))).astype('f8')                  # noqa: E731
     X16, X32 = both(rt, rng.normal(size=(M, K)) * 2 + 1)
@@ -586,6 +589,8 @@ def test_gemm_tile_ksplit_and_stream_kernels_on_bf16_mfma_operands(backend, stor
     rt.synchronize()
     g = widen(dY16.get()).reshape(M, K).astype('f8') @ q(W2)
     np.testing.assert_allclose(dH.get(), g, rtol=0, atol=3e-6 * np.sqrt(K) * np.abs(g).max())
+    if case.endswith('_walk'):
+        return                                    # (the walking cases are about the stream kernel's forward / data gradient above)
     if rt.lib.dpp_wgrad_stream_bf16_ok(N, K) and M % 64 == 0:
         # the row-stream filter gradient of the same layer on bf16 operands (dpp_wgrad_stream_bf16, the stage-1 shapes)
         G16s, G32s = both(rt, rng.normal(size=(M, N)))
