@@ -43,6 +43,8 @@ python $R/tools/forward_profile.py 30 256 bf16 >> $O/forward_only.txt 2>/dev/nul
 python $R/tools/wgrad3_micro.py > $O/wgrad3_micro.txt 2>/dev/null
 python $R/tools/wgrad3_micro.py --precision 1 >> $O/wgrad3_micro.txt 2>/dev/null
 DPP_WGRAD3_T=0 python $R/tools/wgrad3_micro.py >> $O/wgrad3_micro.txt 2>/dev/null
+# the LDS-tiled / tile-walking 3x3 convolution alone at the shapes of the bs128 steps
+python $R/tools/conv3_micro.py > $O/conv3_micro.txt 2>/dev/null
 # the 256 x 256 bf16 step: un-overlapped kernel durations by grid
 DPP_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace -d /tmp/p9 -o run -- python $R/tools/step_profile.py 3 256 bf16 > /dev/null 2>&1
 python $R/tools/prof_summary.py $(find /tmp/p9 -name '*_results.db' | head -1) 3 --by-grid > $O/kernels_256_bf16_by_grid.txt 2>&1
